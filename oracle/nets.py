@@ -1,0 +1,322 @@
+"""CPU restatement of the reference networks and operators (TEST INFRASTRUCTURE ONLY).
+
+This file is the *oracle*: a plain PyTorch-CPU fp32 restatement of the reference's
+hot-path arithmetic, written functionally over `state_dict`s that use the
+reference's key names.  It is pinned against golden vectors produced by running
+the reference itself (oracle/make_golden.py -> tests/golden/*.npz, checked by
+tests/test_oracle_golden.py).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import it; the product path never does.
+
+Each function cites the reference lines it restates (paths relative to
+/root/reference).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# positional encoding, DiffAugment, normals
+# ----------------------------------------------------------------------------
+
+
+def spe_grid(n, h, w, dim=4, device="cpu"):
+    """SinusoidalPositionalEmbedding(dim, padding_idx=0)(x) for a 4-D x.
+
+    thirdparty/mmgeneration/positional_encoding.py:54-82 (get_embedding),
+    :118-160 (make_grid2d): positions run 1..W / 1..H, emb[p] = [sin(p f_i)..., cos(p f_i)...],
+    f_i = exp(-i ln(1e4)/(dim/2-1)); grid = cat(x-embedding over rows, y-embedding over cols).
+    """
+    half = dim // 2
+    f = torch.exp(torch.arange(half, dtype=torch.float) * -(np.log(10000) / (half - 1)))
+
+    def axis(length):
+        pos = torch.arange(length + 1, dtype=torch.float).unsqueeze(1) * f.unsqueeze(0)
+        emb = torch.cat([torch.sin(pos), torch.cos(pos)], dim=1)  # [L+1, dim]
+        return emb[1:].t()  # [dim, L]; row 0 is the padding row
+
+    xe = axis(w)[:, None, :].expand(dim, h, w)
+    ye = axis(h)[:, :, None].expand(dim, h, w)
+    grid = torch.cat([xe, ye], 0)[None].expand(n, 2 * dim, h, w)
+    return grid.contiguous().to(device)
+
+
+def diffaug_bs(x, r_b, r_s):
+    """DiffAugment policy 'bs' with the drawn uniforms passed in.
+
+    thirdparty/DiffAugment.py:25-33: brightness x + (r_b - 0.5); saturation
+    (x - mean_c x) * (2 r_s) + mean_c x.  r_b, r_s: [N] tensors in [0,1).
+    """
+    x = x + (r_b.view(-1, 1, 1, 1) - 0.5)
+    m = x.mean(dim=1, keepdim=True)
+    return ((x - m) * (r_s.view(-1, 1, 1, 1) * 2) + m).contiguous()
+
+
+def compute_normal(t, scale_nz):
+    """models/model_utils.py:408-428."""
+    gx, gy = t[:, 0:1], t[:, 1:2]
+    return F.normalize(torch.cat([gx, gy, scale_nz * torch.ones_like(gx)], 1), dim=1)
+
+
+# ----------------------------------------------------------------------------
+# patch gather
+# ----------------------------------------------------------------------------
+
+
+def find_coords_for_patch(coords, scale_multiplier=1):
+    """models/model_utils.py:23-69.  coords [NT,8] float64 -> int32 (offx, offy, cutout)."""
+    c = np.asarray(coords, dtype=np.float64).reshape(-1, 8)
+    ox = np.round((c[:, 0] + c[:, -2] / c[:, -3]) * scale_multiplier)
+    oy = np.round((c[:, 1] + c[:, -1] / c[:, -3]) * scale_multiplier)
+    cs = np.round(c[:, -4] / c[:, -3] * scale_multiplier)
+    to_i = lambda a: torch.FloatTensor(a).to(torch.int32)
+    return to_i(ox), to_i(oy), to_i(cs)
+
+
+def gather_patches(img, offx, offy, size):
+    """models/model_utils.py:252-333: clamp-to-border crop of `size` x `size` windows.
+
+    img [1,C,H,W]; offx/offy int tensors [P].  Returns [P,C,size,size].
+    (The reference materialises img.repeat(P,...) and fancy-indexes; same values.)
+    """
+    assert img.shape[0] == 1
+    H, W = img.shape[-2:]
+    ar = torch.arange(size, device=img.device)
+    ys = (offy.to(img.device).long()[:, None] + ar[None]).clamp(0, H - 1)  # [P,size]
+    xs = (offx.to(img.device).long()[:, None] + ar[None]).clamp(0, W - 1)
+    out = img[0][:, ys[:, :, None], xs[:, None, :]]  # [C,P,size,size]
+    return out.permute(1, 0, 2, 3).contiguous()
+
+
+def dilated_mask_positions(M):
+    """models/model_utils.py:212-216: 17x17 all-ones conv (padding 1) + clamp, nonzero().
+
+    M [1,1,H,W] -> LongTensor [K,2] of (y, x) in row-major order.  The map is
+    (H-14) x (W-14) and its indices are used un-shifted as patch offsets (quirk kept).
+    """
+    k = torch.ones(1, 1, 17, 17, dtype=M.dtype, device=M.device)
+    e = torch.clamp(F.conv2d(M, k, padding=(1, 1)), 0, 1)
+    return torch.nonzero(e, as_tuple=False)[:, -2:]
+
+
+# ----------------------------------------------------------------------------
+# generator  (models/networks.py:1430-1645, thirdparty/unet/unet_parts_custom.py:9-79)
+# ----------------------------------------------------------------------------
+
+
+def _inorm(x):
+    return F.instance_norm(x, eps=1e-5)
+
+
+def unet_forward(sd, x, num_downs=8, num_layer_separate=4, style_code=None, num_layer_style_code=1,
+                 return_feats=False):
+    """CustomUnetGenerator.forward, instance norm, style mode concat/tile only."""
+    feats = []
+    for i in range(num_downs):
+        key = "down%d.model.%d" % (i, 0 if i == 0 else 1)
+        if i > 0:
+            x = F.leaky_relu(x, 0.2)
+        x = F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=2, padding=1)
+        if 0 < i < num_downs - 1:
+            x = _inorm(x)
+        feats.append(x)
+    ups = {}
+    x_t = None
+    for i in range(num_downs - 1, -1, -1):
+        skip = feats[i]
+        if style_code is not None and i >= num_downs - num_layer_style_code:
+            sc = style_code.to(torch.float32)[..., None, None].expand(-1, -1, skip.shape[2], skip.shape[3])
+            x = torch.cat([x, sc], 1)
+            if x_t is not None:
+                x_t = torch.cat([x_t, sc], 1)
+
+        def up(name, inp):
+            if i == 0 or i == num_downs - 1:  # outermost / innermost: no skip concat
+                z = inp
+            else:
+                z = torch.cat([inp, skip], 1)
+            z = F.relu(z)
+            z = F.conv_transpose2d(z, sd[name + ".model.1.weight"], sd[name + ".model.1.bias"], stride=2, padding=1)
+            return torch.tanh(z) if i == 0 else _inorm(z)
+
+        if num_layer_separate >= i + 1:
+            if x_t is None:
+                x_t = x
+            x_t = up("up%d_T" % i, x_t)
+            ups["up%d_T" % i] = x_t
+        x = up("up%d" % i, x)
+        ups["up%d" % i] = x
+    out = torch.cat([x, x_t], 1) if x_t is not None else x
+    if return_feats:
+        return out, feats, ups
+    return out
+
+
+# ----------------------------------------------------------------------------
+# multiscale PatchGAN discriminator  (models/networks.py:1649-1750)
+# ----------------------------------------------------------------------------
+
+D_CONV_IDX = (0, 2, 5, 8, 11)
+D_BN_IDX = {2: 3, 5: 6, 8: 9}
+D_STRIDE = {0: 2, 2: 2, 5: 2, 8: 1, 11: 1}
+
+
+def nlayer_forward(sd, prefix, x, training=True, update_stats=True, momentum=0.1, feats=None):
+    """One NLayerDiscriminator (n_layers=3, BatchNorm2d affine + running stats)."""
+    for ci in D_CONV_IDX:
+        k = "%s.%d" % (prefix, ci)
+        x = F.conv2d(x, sd[k + ".weight"], sd[k + ".bias"], stride=D_STRIDE[ci], padding=2)
+        if ci in D_BN_IDX:
+            b = "%s.%d" % (prefix, D_BN_IDX[ci])
+            if training and update_stats:
+                x = F.batch_norm(x, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"],
+                                 sd[b + ".bias"], True, momentum, 1e-5)
+                sd[b + ".num_batches_tracked"] += 1
+            elif training:
+                x = F.batch_norm(x, None, None, sd[b + ".weight"], sd[b + ".bias"], True, momentum, 1e-5)
+            else:
+                x = F.batch_norm(x, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"],
+                                 sd[b + ".bias"], False, momentum, 1e-5)
+        if feats is not None:
+            feats.append(x)
+        if ci != 11:
+            x = F.leaky_relu(x, 0.2)
+    return x
+
+
+def msd_forward(sd, x, num_D=3, training=True, update_stats=True):
+    """MultiscaleDiscriminator.forward: layer{num_D-1} sees full resolution first;
+    pyramid by AvgPool2d(3, 2, padding 1, count_include_pad=False).  Returns [[pred_s0],...]."""
+    res = []
+    for i in range(num_D):
+        res.append([nlayer_forward(sd, "layer%d" % (num_D - 1 - i), x, training, update_stats)])
+        if i != num_D - 1:
+            x = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+    return res
+
+
+# ----------------------------------------------------------------------------
+# GAN loss (models/networks.py:448-542)
+# ----------------------------------------------------------------------------
+
+
+def gan_loss_single(pred, target_is_real, mode="nonsaturating", real_label=1.0, fake_label=0.0):
+    bs = pred.size(0)
+    if mode == "lsgan":
+        t = torch.full_like(pred, real_label if target_is_real else fake_label)
+        return F.mse_loss(pred, t)
+    if mode == "vanilla":
+        t = torch.full_like(pred, real_label if target_is_real else fake_label)
+        return F.binary_cross_entropy_with_logits(pred, t)
+    if mode in ("wgan", "wgangp"):
+        return -pred.mean() if target_is_real else pred.mean()
+    if mode == "nonsaturating":
+        return F.softplus(-pred if target_is_real else pred).view(bs, -1).mean(dim=1)
+    if mode == "hinge":
+        return F.relu(1.0 - pred if target_is_real else 1.0 + pred).view(bs, -1).mean(dim=1)
+    raise NotImplementedError(mode)
+
+
+def gan_loss(preds, target_is_real, mode="nonsaturating", real_label=1.0, fake_label=0.0):
+    """Sum over scales of the per-scale loss (networks.py:536-540)."""
+    if isinstance(preds[0], list):
+        loss = 0
+        for p in preds:
+            loss = loss + gan_loss_single(p[-1], target_is_real, mode, real_label, fake_label)
+        return loss
+    return gan_loss_single(preds[-1], target_is_real, mode, real_label, fake_label)
+
+
+# ----------------------------------------------------------------------------
+# PatchNCE (models/patchnce.py:13-55, networks.py:585-594 Normalize)
+# ----------------------------------------------------------------------------
+
+
+def l2_normalize(x):
+    norm = x.pow(2).sum(1, keepdim=True).pow(0.5)
+    return x.div(norm + 1e-7)
+
+
+def patchnce_loss(feat_q, feat_k, batch_size, nce_T=0.07, all_negatives_from_minibatch=False):
+    n, dim = feat_q.shape
+    feat_k = feat_k.detach()
+    l_pos = torch.bmm(feat_q.view(n, 1, -1), feat_k.view(n, -1, 1)).view(n, 1)
+    b = 1 if all_negatives_from_minibatch else batch_size
+    q = feat_q.view(b, -1, dim)
+    k = feat_k.view(b, -1, dim)
+    npatches = q.size(1)
+    l_neg = torch.bmm(q, k.transpose(2, 1))
+    eye = torch.eye(npatches, dtype=torch.bool, device=q.device)[None]
+    l_neg = l_neg.masked_fill(eye, -10.0).view(-1, npatches)
+    out = torch.cat((l_pos, l_neg), 1) / nce_T
+    return F.cross_entropy(out, torch.zeros(out.size(0), dtype=torch.long, device=q.device), reduction="none")
+
+
+# ----------------------------------------------------------------------------
+# Adam (torch.optim.Adam semantics used at sinskitG_model.py:589-599)
+# ----------------------------------------------------------------------------
+
+
+def adam_update(p, g, m, v, step, lr, beta1, beta2, eps=1e-8):
+    """In-place single-tensor Adam, torch.optim.Adam defaults (no amsgrad, no weight decay)."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# ----------------------------------------------------------------------------
+# initialisation (models/networks.py:191-231) -- distribution-level restatement;
+# parity tests load reference-initialised weights instead of matching RNG streams.
+# ----------------------------------------------------------------------------
+
+
+def g_param_shapes(input_nc=9, ngf=10, num_downs=8, num_layer_separate=4, style_nc=0, num_layer_style_code=1):
+    """Ordered {key: shape} of CustomUnetGenerator (instance norm => conv bias present)."""
+    ch = [ngf * min(2 ** i, 8) for i in range(num_downs)]  # out channels of down_i
+    shapes = {}
+    shapes["down0.model.0.weight"] = (ch[0], input_nc, 4, 4)
+    shapes["down0.model.0.bias"] = (ch[0],)
+
+    def add_up(i, suffix=""):
+        outer = 3 if i == 0 else ch[i - 1]
+        if suffix and i == 0:
+            outer = 2
+        inner = ch[i] * (1 if i in (0, num_downs - 1) else 2)
+        if style_nc and i >= num_downs - num_layer_style_code:
+            inner += style_nc
+        shapes["up%d%s.model.1.weight" % (i, suffix)] = (inner, outer, 4, 4)
+        shapes["up%d%s.model.1.bias" % (i, suffix)] = (outer,)
+
+    add_up(0)
+    if num_layer_separate >= 1:
+        add_up(0, "_T")
+    for i in range(1, num_downs):
+        shapes["down%d.model.1.weight" % i] = (ch[i], ch[i - 1], 4, 4)
+        shapes["down%d.model.1.bias" % i] = (ch[i],)
+        add_up(i)
+        if num_layer_separate >= i + 1:
+            add_up(i, "_T")
+    return shapes
+
+
+def d_param_shapes(input_nc, ndf=8, num_D=3):
+    """Ordered {key: shape} of MultiscaleDiscriminator (n_layers=3, BatchNorm2d), incl. buffers."""
+    chans = [input_nc, ndf, ndf * 2, ndf * 4, ndf * 8, 1]
+    shapes = {}
+    for d in range(num_D):
+        for j, ci in enumerate(D_CONV_IDX):
+            shapes["layer%d.%d.weight" % (d, ci)] = (chans[j + 1], chans[j], 4, 4)
+            shapes["layer%d.%d.bias" % (d, ci)] = (chans[j + 1],)
+            if ci in D_BN_IDX:
+                b = "layer%d.%d" % (d, D_BN_IDX[ci])
+                c = chans[j + 1]
+                shapes[b + ".weight"] = (c,)
+                shapes[b + ".bias"] = (c,)
+                shapes[b + ".running_mean"] = (c,)
+                shapes[b + ".running_var"] = (c,)
+                shapes[b + ".num_batches_tracked"] = ()
+    return shapes

@@ -1,0 +1,224 @@
+"""CPU restatement of one SinSKITGModel training step (TEST INFRASTRUCTURE ONLY).
+
+Restates /root/reference/models/sinskitG_model.py:
+  set_input :702-793, forward :1293-1344, compute_additional_output :1268-1291,
+  optimize_parameters :601-700, compute_D1_loss :1346-1407, compute_D2_loss :1409-1617,
+  compute_G1_loss :1660-1726, compute_G2_loss :1728-1842
+with LPIPS / vision-aided / CLIP terms off (lambda 0; "parity unpinned" third-party
+terms) and generalised from the reference's hard N=1 to N>=1 by
+looping the patch gather per sample (SURVEY.md §7 "Batch > 1").
+
+Random draws are *inputs* (`draws`), so the oracle, the reference run that made
+the golden vectors, and the HIP path all consume identical numbers:
+  draws["aug"]      float32 [4, N]  = (brightness real, saturation real, brightness fake, saturation fake)
+                    in the order DiffAugment consumes torch.rand (:1330-1333)
+  draws["more_idx"] int64 [N, n_more] indices into the row-major nonzero list of the
+                    dilated mask (model_utils.py:212-222, random.sample)
+
+Pinned by tests/test_oracle_golden.py against tests/golden/sinskitG_step_*.npz.
+Only tests/, smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import copy
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import nets
+
+DEFAULT_HP = dict(
+    lambda_G1_GAN=1.0, lambda_G1_L1=100.0, lambda_G2_GAN=5.0, lambda_G2_L1=10.0,
+    lr=1e-3, lr_G2=5e-4, beta1=0.0, beta2=0.99, gan_mode="nonsaturating",
+    batch_size_G2=64, add_fake_T_sample_size=32, scale_nz=0.25, num_D=3,
+    use_more_fakeT=True, use_diffaug=True, lr_scale=1.0,
+)
+
+
+def hp(**kw):
+    d = dict(DEFAULT_HP)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def prepare_input(batch):
+    """set_input: mask multiply, SPE, patch reshape."""
+    S = batch["S"].float()
+    M = batch["M"].float()
+    I = batch["I"].float()
+    n, _, h, w = S.shape
+    real_S = S * M
+    real_I = I * M
+    S_pe = nets.spe_grid(n, h, w, 4)
+    T = torch.as_tensor(batch["T_images"]).float()
+    K = torch.as_tensor(batch["I_masks"]).float()
+    nt = T.shape[1]
+    masks = K.reshape(-1, 1, 32, 32)
+    real_T = T.reshape(-1, 2, 32, 32) * masks
+    coords = torch.as_tensor(batch["T_coords"]).numpy()
+    return SimpleNamespace(real_S=real_S, real_I=real_I, M=M, S_pe=S_pe, real_T=real_T, masks=masks,
+                           coords=coords, N=n, NT=nt)
+
+
+def _gather_all(img, coords):
+    outs = []
+    for n in range(img.shape[0]):
+        ox, oy, _ = nets.find_coords_for_patch(coords[n])
+        outs.append(nets.gather_patches(img[n:n + 1], ox, oy, 32))
+    return torch.cat(outs, 0)
+
+
+def generator_forward(sdG, inp, opt, style_code=None):
+    out = nets.unet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), style_code=style_code)
+    fake_I = out[:, 0:3] * inp.M
+    fake_T = out[:, -2:] * inp.M
+    return out, fake_I, fake_T
+
+
+def _req(sd, flag):
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(flag)
+            v.grad = None
+
+
+def _grads(sd):
+    return {k: v.grad.detach().clone() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+def _adam(sd, state, lr, opt):
+    state["step"] += 1
+    for k, p in sd.items():
+        if not p.requires_grad or p.grad is None:
+            continue
+        if k not in state["m"]:
+            state["m"][k] = torch.zeros_like(p)
+            state["v"][k] = torch.zeros_like(p)
+        with torch.no_grad():
+            nets.adam_update(p, p.grad, state["m"][k], state["v"][k], state["step"], lr, opt.beta1, opt.beta2)
+
+
+def new_adam_state():
+    return {"step": 0, "m": {}, "v": {}}
+
+
+def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, record=True):
+    """One G+D1+D2 update, in place on the three state dicts and `adam` (dict of 3 Adam states).
+
+    Returns a dict with losses, outputs and (if record) the gradients taken at each of
+    the three backward points.
+    """
+    opt = opt or hp()
+    out = {}
+    inp = prepare_input(batch)
+    N, NT = inp.N, inp.NT
+    lamD1, lamD2 = opt.lambda_G1_GAN, opt.lambda_G2_GAN
+    gl = lambda p, real: nets.gan_loss(p, real, opt.gan_mode)
+
+    # ---- forward (G requires grad for the later G step) ----
+    _req(sdG, True)
+    _req(sdD, False)
+    _req(sdD2, False)
+    g_out, fake_I, fake_T = generator_forward(sdG, inp, opt, style_code)
+    if opt.use_diffaug:
+        aug = draws["aug"].float()
+        aug_real_I = nets.diffaug_bs(inp.real_I, aug[0], aug[1]) * inp.M
+        aug_fake_I = nets.diffaug_bs(fake_I, aug[2], aug[3]) * inp.M
+    else:
+        aug_real_I, aug_fake_I = inp.real_I * inp.M, fake_I * inp.M
+
+    # ---- patches (compute_additional_output) ----
+    fake_T_concat = _gather_all(fake_T, inp.coords)
+    S_concat = _gather_all(inp.real_S, inp.coords).detach()
+    real_I_concat = torch.cat([_gather_all(aug_real_I, inp.coords).detach(), inp.masks], 1)
+    fake_I_concat = torch.cat([_gather_all(aug_fake_I, inp.coords).detach(), inp.masks], 1)
+    fake_I_full = torch.cat([aug_fake_I.detach(), inp.M], 1)
+
+    # ---- D1 step ----
+    _req(sdD, True)
+    pred_fake = nets.msd_forward(sdD, torch.cat((inp.real_S, fake_I.detach()), 1), opt.num_D)
+    loss_D_fake_I = gl(pred_fake, False).mean() * lamD1
+    pred_real = nets.msd_forward(sdD, torch.cat((inp.real_S, inp.real_I), 1), opt.num_D)
+    loss_D_real_I = gl(pred_real, True).mean() * lamD1
+    loss_D1 = (loss_D_fake_I + loss_D_real_I) * 0.5
+    loss_D1.backward()
+    if record:
+        out["grad_D"] = _grads(sdD)
+        out["pred_fake_I"] = [p[-1].detach().clone() for p in pred_fake]
+    _adam(sdD, adam["D"], opt.lr * opt.lr_scale, opt)
+    _req(sdD, False)
+
+    # ---- D2 step ----
+    _req(sdD2, True)
+    fake_stack = torch.cat((fake_T_concat.detach(), S_concat, fake_I_concat), 1)
+    pred_fake_T = nets.msd_forward(sdD2, fake_stack, opt.num_D)
+    loss_D_fake_T = gl(pred_fake_T, False).mean() * lamD2
+    full_stack = torch.cat((fake_T.detach(), inp.real_S, fake_I_full), 1)
+    pred_full = nets.msd_forward(sdD2, full_stack, opt.num_D)  # visualisation only; still updates BN stats
+    loss_D_more = torch.zeros(())
+    if opt.use_more_fakeT:
+        stacks = []
+        for n in range(N):
+            pos = nets.dilated_mask_positions(inp.M[n:n + 1])
+            sel = pos[draws["more_idx"][n].long()]
+            oy, ox = sel[:, 0].to(torch.int32), sel[:, 1].to(torch.int32)
+            t = nets.gather_patches(fake_T[n:n + 1].detach(), ox, oy, 32)
+            s = nets.gather_patches(inp.real_S[n:n + 1], ox, oy, 32)
+            i = nets.gather_patches(fake_I[n:n + 1].detach(), ox, oy, 32)
+            stacks.append(torch.cat((t, s, i, torch.ones_like(s)), 1))
+        more_stack = torch.cat(stacks, 0)
+        pred_more = nets.msd_forward(sdD2, more_stack, opt.num_D)
+        loss_D_more = gl(pred_more, False).mean() * lamD2
+    real_stack = torch.cat((inp.real_T, S_concat, real_I_concat), 1)
+    pred_real_T = nets.msd_forward(sdD2, real_stack, opt.num_D)
+    loss_D_real_T = gl(pred_real_T, True).mean() * lamD2
+    loss_D2 = (loss_D_fake_T + loss_D_more + loss_D_real_T) * 0.5
+    loss_D2.backward()
+    if record:
+        out["grad_D2"] = _grads(sdD2)
+        out["pred_fake_T_full"] = pred_full[-1][-1].detach().clone()
+    _adam(sdD2, adam["D2"], opt.lr_G2 * opt.lr_scale, opt)
+    _req(sdD2, False)
+
+    # ---- G step ----
+    pred_g = nets.msd_forward(sdD, torch.cat((inp.real_S, fake_I), 1), opt.num_D)
+    loss_G_GAN = gl(pred_g, True).mean() * lamD1
+    loss_G_L1 = F.l1_loss(fake_I, inp.real_I) * opt.lambda_G1_L1
+    g2_stack = torch.cat((fake_T_concat.clone().detach(), S_concat, fake_I_concat), 1)
+    pred_g2 = nets.msd_forward(sdD2, g2_stack, opt.num_D)
+    loss_G2_GAN = (gl(pred_g2, True) * lamD2).view(-1, NT).mean(dim=0).sum()  # logged only: no gradient path
+    l1 = (fake_T_concat - inp.real_T).abs() * opt.lambda_G2_L1
+    loss_G2_L1 = l1.view(-1, NT, 2, 32, 32).sum(dim=1).mean()
+    loss_G = loss_G_GAN + loss_G_L1 + loss_G2_L1 + loss_G2_GAN.detach() * 0
+    loss_G.backward()
+    if record:
+        out["grad_G"] = _grads(sdG)
+    _adam(sdG, adam["G"], opt.lr * opt.lr_scale, opt)
+    _req(sdG, False)
+
+    out["losses"] = {
+        "G_GAN": float(loss_G_GAN.detach()), "D_real_I": float(loss_D_real_I.detach()), "D_fake_I": float(loss_D_fake_I.detach()),
+        "G_L1": float(loss_G_L1.detach()), "G2_GAN": float(loss_G2_GAN.detach()), "D_real_T_concat": float(loss_D_real_T.detach()),
+        "D_fake_T_concat": float(loss_D_fake_T.detach()), "D_more_fake_T": float(loss_D_more.detach()), "G2_L1": float(loss_G2_L1.detach()),
+    }
+    if record:
+        out["g_out"] = g_out.detach().clone()
+        out["fake_I"] = fake_I.detach().clone()
+        out["fake_T"] = fake_T.detach().clone()
+        out["fake_N"] = nets.compute_normal(fake_T.detach(), opt.scale_nz)
+        out["aug_real_I"] = aug_real_I.detach().clone()
+        out["aug_fake_I"] = aug_fake_I.detach().clone()
+        out["fake_T_concat"] = fake_T_concat.detach().clone()
+    return out
+
+
+def clone_sd(sd):
+    return {k: v.detach().clone() for k, v in sd.items()}
+
+
+def inference(sdG, batch, opt=None, style_code=None):
+    """test(): no_grad forward (sinskitG_model.py:795-807)."""
+    opt = opt or hp()
+    inp = prepare_input(batch) if "T_images" in batch else None
+    with torch.no_grad():
+        _, fake_I, fake_T = generator_forward(sdG, inp, opt, style_code)
+    return fake_I, fake_T

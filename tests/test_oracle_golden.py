@@ -1,0 +1,182 @@
+"""Pin the CPU oracle (oracle/) against vectors produced by RUNNING the reference
+(oracle/make_golden.py).  CPU only; nothing here touches /root/reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import default_collate
+
+from oracle import detrand, nets, step
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol)
+
+
+def _probe_close(t, ref, name, rtol=2e-4):
+    """probe = (sum, l2, projection); compare relative to the tensor's l2 norm."""
+    p = detrand.probe(t, name)
+    scale = max(abs(ref[1]), 1e-12)
+    assert abs(p[1] - ref[1]) <= rtol * scale, (name, p, ref)
+    assert abs(p[2] - ref[2]) <= rtol * scale * 4, (name, p, ref)  # |proj| <= l2 * |r|, r~U(-1,1)
+
+
+# ------------------------------------------------------------------ operators
+def test_spe(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    _close(nets.spe_grid(2, 24, 40).numpy(), g["spe_24x40"])
+    big = nets.spe_grid(1, 1100, 1030)[:, :, ::50, ::47]
+    _close(big.numpy(), g["spe_1100x1030_sub"], rtol=1e-4, atol=1e-4)
+
+
+def test_diffaug(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    img = detrand.uniform((2, 3, 20, 28), 11, "diffaug")
+    d = torch.from_numpy(g["diffaug_draws"])
+    _close(nets.diffaug_bs(img, d[0], d[1]).numpy(), g["diffaug_out"])
+
+
+def test_ganloss_all_modes(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    preds = [[detrand.uniform((3, 1, 9, 9), 3, "p0") * 3], [detrand.uniform((3, 1, 5, 5), 3, "p1") * 3]]
+    for mode in ["nonsaturating", "lsgan", "vanilla", "wgan", "hinge"]:
+        for real in (True, False):
+            got = nets.gan_loss(preds, real, mode, real_label=0.8, fake_label=0.0)
+            _close(np.atleast_1d(got.numpy()), g["gan_%s_%d" % (mode, real)])
+
+
+def test_patchnce(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    fq = detrand.uniform((32, 24), 21, "fq")
+    fk = detrand.uniform((32, 24), 21, "fk")
+    fq = fq / fq.norm(dim=1, keepdim=True)
+    fk = fk / fk.norm(dim=1, keepdim=True)
+    for allneg in (False, True):
+        _close(nets.patchnce_loss(fq, fk, 2, 0.07, allneg).numpy(), g["patchnce_%d" % allneg], rtol=1e-5, atol=1e-5)
+    _close(nets.l2_normalize(detrand.uniform((5, 7), 2, "nrm")).numpy(), g["normalize"])
+
+
+def test_patch_gather_and_normals(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    im = detrand.uniform((1, 3, 96, 80), 31, "gather")
+    ox, oy, cs = nets.find_coords_for_patch(g["gather_coords"][0])
+    assert cs.tolist() == [32] * 6
+    _close(nets.gather_patches(im, ox, oy, 32).numpy(), g["gather_out"], rtol=0, atol=0)
+    _close(nets.compute_normal(im[:, :2], 0.25).numpy(), g["normal_out"])
+
+
+def test_more_fake_positions(golden_dir):
+    """random.sample over the dilated-mask nonzero list reproduces the reference's offsets."""
+    import random
+
+    g = _load(golden_dir, "ops.npz")
+    M = torch.from_numpy(g["more_M"])
+    pos = nets.dilated_mask_positions(M)
+    random.seed(9)
+    sel = pos[random.sample(range(pos.shape[0]), 5)]
+    assert sel[:, 1].tolist() == g["more_ox"].astype(int).tolist()
+    assert sel[:, 0].tolist() == g["more_oy"].astype(int).tolist()
+    im = detrand.uniform((1, 3, 96, 80), 31, "gather")[:, :2, :64, :72].contiguous()
+    got = nets.gather_patches(im, sel[:, 1].int(), sel[:, 0].int(), 32)
+    _close(got.numpy(), g["more_samples"], rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------ networks
+def test_generator_fwd_bwd(golden_dir):
+    g = _load(golden_dir, "nets_256.npz")
+    size, seed = int(g["size"]), int(g["seed"])
+    sd = detrand.test_weights(nets.g_param_shapes(), seed)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = detrand.uniform((1, 9, size, size), seed, "g_in").requires_grad_(True)
+    y = nets.unet_forward(sd, x)
+    _close(y.detach()[:, :, ::4, ::4].numpy(), g["G_out_sub"], rtol=1e-4, atol=2e-5)
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    _probe_close(x.grad, g["G_dx_probe"], "g_dx")
+    for k, v in sd.items():
+        _probe_close(v.grad, g["G_grad/" + k], k)
+
+
+@pytest.mark.parametrize("name,cin,n,hw", [("D", 4, 1, 256), ("D2", 7, 6, 32)])
+def test_discriminator_fwd_bwd(golden_dir, name, cin, n, hw):
+    g = _load(golden_dir, "nets_256.npz")
+    seed = int(g["seed"])
+    sd = detrand.test_weights(nets.d_param_shapes(cin), seed + 1)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = detrand.uniform((n, cin, hw, hw), seed, name + "_in").requires_grad_(True)
+    preds = nets.msd_forward(sd, x)
+    tot = 0
+    for s, p in enumerate(preds):
+        _close(p[-1].detach().numpy(), g["%s_pred%d" % (name, s)], rtol=1e-4, atol=1e-5)
+        tot = tot + (p[-1] * detrand.uniform(tuple(p[-1].shape), seed, "%s_cot%d" % (name, s))).sum()
+    tot.backward()
+    _probe_close(x.grad, g[name + "_dx_probe"], name + "_dx")
+    for k, v in sd.items():
+        if v.requires_grad:
+            _probe_close(v.grad, g["%s_grad/%s" % (name, k)], k)
+        elif v.dtype.is_floating_point:
+            _close(v.numpy(), g["%s_buf/%s" % (name, k)], rtol=1e-5, atol=1e-6)
+
+
+def test_init_distribution(golden_dir):
+    """xavier_normal_(gain=0.02) std of the reference init (networks.py:191-231)."""
+    g = _load(golden_dir, "nets_256.npz")
+    for (shape, got) in (((80, 40, 4, 4), g["G_init_std"][0]), ((160, 40, 4, 4), g["G_init_std"][1])):
+        fan_in, fan_out = shape[1] * 16, shape[0] * 16
+        assert abs(got - 0.02 * np.sqrt(2.0 / (fan_in + fan_out))) < 0.05 * got
+
+
+# ------------------------------------------------------------------ full step
+def _batch(size, nt, seed):
+    from data.synthetic_dataset import make_sample
+
+    return default_collate([make_sample(size, nt, nt, seed)])
+
+
+def test_train_step_matches_reference(golden_dir):
+    g = _load(golden_dir, "sinskitG_step_256.npz")
+    size, seed, steps, nt = int(g["size"]), int(g["seed"]), int(g["steps"]), int(g["nt"])
+    sdG = detrand.test_weights(nets.g_param_shapes(), seed)
+    sdD = detrand.test_weights(nets.d_param_shapes(4), seed + 1)
+    sdD2 = detrand.test_weights(nets.d_param_shapes(7), seed + 2)
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    batch = _batch(size, nt, seed)
+    for it in range(steps):
+        tag = "s%d" % it
+        draws = {"aug": torch.from_numpy(g[tag + "/aug"]), "more_idx": torch.from_numpy(g[tag + "/more_idx"])}
+        out = step.train_step(sdG, sdD, sdD2, adam, batch, draws)
+        names = [str(s) for s in g[tag + "/loss_names"]]
+        vals = g[tag + "/loss_values"]
+        ref = dict(zip(names, vals))
+        for k, v in out["losses"].items():
+            assert abs(v - ref["l_" + k]) <= 2e-4 * max(1.0, abs(ref["l_" + k])), (k, v, ref["l_" + k])
+        _close(out["fake_I"][:, :, ::4, ::4].numpy(), g[tag + "/fake_I_sub"], rtol=1e-4, atol=2e-5)
+        _close(out["fake_T"][:, :, ::4, ::4].numpy(), g[tag + "/fake_T_sub"], rtol=1e-4, atol=2e-5)
+        for nm in ("fake_N", "aug_fake_I", "aug_real_I"):
+            _probe_close(out[nm], g["%s/%s_probe" % (tag, nm)], nm)
+        _probe_close(out["pred_fake_T_full"], g[tag + "/pred_fake_T_full_probe"], "pftf")
+        _probe_close(out["pred_fake_I"][-1], g[tag + "/pred_fake_I_probe"], "pfi")
+        for nm, sd in (("G", sdG), ("D", sdD), ("D2", sdD2)):
+            for k, gr in out["grad_" + nm].items():
+                _probe_close(gr, g["%s/grad_%s/%s" % (tag, nm, k)], k, rtol=5e-4)
+            for k, v in sd.items():
+                key = "%s/param_%s/%s" % (tag, nm, k)
+                if key in g:
+                    _probe_close(v, g[key], k, rtol=1e-4)
+                else:
+                    _close(v.double().numpy(), g["%s/buf_%s/%s" % (tag, nm, k)], rtol=1e-4, atol=1e-6)
+
+
+def test_option_fixture_is_reference_dump(golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "ref_option_defaults.json")))
+    assert d["sinskitG_train"]["ngf"]["default"] == 10 and d["sinskitG_train"]["netD2"]["default"] == "multiscale"
