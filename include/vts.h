@@ -1,0 +1,227 @@
+/*
+ * vts.h -- C ABI of libvts_hip.so: the MI355X (gfx950) kernels behind the
+ * sketch -> (RGB, tactile) conditional-GAN training step.
+ *
+ * The reference has NO native/FFI layer on this path: its
+ * boundary is the Python class contract models.create_model()/BaseModel, and every
+ * op below replaces a PyTorch call made inside that class.  Each entry point cites
+ * the reference lines (relative to /root/reference) whose arithmetic it performs.
+ *
+ * Conventions
+ *   - all tensors are device pointers to fp32, NCHW, contiguous unless a batch
+ *     stride ("nstride", in floats) is given, which allows channel-sliced views;
+ *   - no torch types, no allocation inside any call: the caller owns every buffer
+ *     (scratch sizes are returned by the *_ws_floats helpers);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it;
+ *   - return value: 0 = ok, otherwise a negative vts error code; vts_last_error()
+ *     returns a thread-local message for the last failing call.
+ */
+#ifndef VTS_H
+#define VTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTS_OK 0
+#define VTS_ERR_ARG (-1)
+#define VTS_ERR_UNSUPPORTED (-2)
+#define VTS_ERR_LAUNCH (-3)
+
+/* activation codes (applied to the gathered input after its affine, or as derivative masks) */
+#define VTS_ACT_NONE 0
+#define VTS_ACT_LRELU 1 /* LeakyReLU(0.2) */
+#define VTS_ACT_RELU 2
+#define VTS_ACT_TANH 3 /* epilogue only */
+
+const char* vts_last_error(void);
+int vts_version(void);
+
+/* A (possibly channel-concatenated, lazily normalised) activation operand:
+ *   value(n, c, y, x) = act( data[n*nstride + c*H*W + y*W + x] * scale[n*C + c] + shift[n*C + c] )
+ * scale/shift may be NULL (identity).  This is how InstanceNorm / BatchNorm outputs are
+ * consumed: the producer stores the raw conv result plus per-(n,c) scale/shift, and every
+ * consumer normalises on load (no separate normalisation pass over HBM). */
+typedef struct vts_operand {
+  const float* data;
+  const float* scale;
+  const float* shift;
+  int C;
+  int64_t nstride;
+} vts_operand;
+
+/* Convolution-like operator (4x4 kernels).  transposed = 0:
+ *   out[n,co,oy,ox] = bias[co] + sum_{ci,ky,kx} in[n,ci,oy*stride+ky-pad,ox*stride+kx-pad] * W(co,ci,ky,kx)
+ * transposed = 1 (ConvTranspose2d / backward-data of a stride-`stride` conv):
+ *   out[n,co,y,x]   = bias[co] + sum_{ci,ky,kx : (y+pad-ky) % stride == 0} in[n,ci,(y+pad-ky)/stride,(x+pad-kx)/stride] * W(co,ci,ky,kx)
+ * with W(co,ci,ky,kx) = w[co*ws_co + ci*ws_ci + ky*4 + kx], so the same weight tensor serves
+ * nn.Conv2d ([Cout,Cin,4,4]: ws_co=Cin*16, ws_ci=16), nn.ConvTranspose2d ([Cin,Cout,4,4]:
+ * ws_co=16, ws_ci=Cout*16), their backward-data passes and channel sub-ranges (offset w).
+ * `in` is the channel concatenation of in0 and in1 (in1.C = 0 if unused), each normalised and
+ * activated on load (act_in).  Epilogue: + bias, act_out (NONE|TANH), optional derivative mask
+ *   out *= act'( dmask value )      (LRELU: v>0 ? 1 : 0.2; RELU: v>0 ? 1 : 0)
+ * where the dmask operand has the shape of `out`, then optional accumulation into `out`.
+ *
+ * Replaces: F.conv2d / F.conv_transpose2d and their autograd backward-data inside
+ * Down/Up (thirdparty/unet/unet_parts_custom.py:9-79), NLayerDiscriminator
+ * (models/networks.py:1696-1750), incl. the LeakyReLU/ReLU, torch.cat skip concat,
+ * InstanceNorm/BatchNorm application and Tanh that surround them. */
+typedef struct vts_conv_desc {
+  vts_operand in0, in1;
+  int N, IH, IW, OH, OW, Cout;
+  int stride, pad, transposed;
+  const float* w;
+  int ws_co, ws_ci;
+  const float* bias; /* [Cout] or NULL */
+  float* out;
+  int64_t out_nstride;
+  int act_in, act_out;
+  vts_operand dmask; /* data == NULL: no mask */
+  int dmask_act;
+  int accumulate;
+} vts_conv_desc;
+
+int vts_conv4x4(const vts_conv_desc* d, void* stream);
+
+/* Weight gradient of the same operator family:
+ *   dw[cl*dw_s_cl + ch*dw_s_ch + ky*4+kx] = sum_{n,y,x} lo[n,cl,y,x] * hi[n,ch,y*stride+ky-pad,x*stride+kx-pad]
+ * `lo` is the low-resolution side (LH x LW), `hi` the high-resolution side (HH x HW); each is a
+ * (dual, normalise-on-load) operand pair.  nn.Conv2d: lo = grad_out, hi = input, dw layout
+ * [Cout,Cin,4,4]; nn.ConvTranspose2d: lo = input, hi = grad_out, dw layout [Cin,Cout,4,4].
+ * Deterministic: per-workgroup partials in `ws` (vts_wgrad4x4_ws_floats floats) reduced in fixed order.
+ * Replaces the autograd weight-gradient of the convolutions listed above. */
+typedef struct vts_wgrad_desc {
+  vts_operand lo0, lo1, hi0, hi1;
+  int act_lo, act_hi;
+  int N, LH, LW, HH, HW;
+  int stride, pad;
+  float* dw;
+  int accumulate;
+} vts_wgrad_desc;
+
+int64_t vts_wgrad4x4_ws_floats(const vts_wgrad_desc* d);
+int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream);
+
+/* Per-channel sum over (N, H, W): out[c] (+)= sum x[n,c,:,:]  (bias gradients). */
+int vts_channel_sum(const float* x, int64_t nstride, int N, int C, int HW, float* out, int accumulate,
+                    float* ws, void* stream);
+int64_t vts_channel_sum_ws_floats(int N, int C, int HW);
+
+/* Normalisation statistics -> per-(n,c) scale/shift for normalise-on-load.
+ * mode 0: InstanceNorm2d(affine=False, eps) (models/networks.py:139): group = (n,c)
+ * mode 1: BatchNorm2d training mode (networks.py:137): group = c over (N,H,W); gamma/beta
+ *         applied; running_mean/var updated with `momentum` using the unbiased variance and
+ *         num_batches_tracked += 1 when the pointers are non-NULL.
+ * Robust two-level (Chan) variance.  mean_out / rstd_out [N*C] are kept for the backward. */
+typedef struct vts_norm_desc {
+  const float* x;
+  int64_t nstride;
+  int N, C, HW;
+  int mode;
+  float eps, momentum;
+  const float* gamma; /* BN only */
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches_tracked;
+  float* scale;    /* [N*C] out */
+  float* shift;    /* [N*C] out */
+  float* mean_out; /* [N*C] out */
+  float* rstd_out; /* [N*C] out */
+} vts_norm_desc;
+
+int64_t vts_norm_ws_floats(int N, int C, int HW);
+int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream);
+
+/* Backward of the same normalisation (in place on dy):
+ *   dx = A*dy + B*x + C  with the per-group coefficients of InstanceNorm / BatchNorm backward;
+ * BN additionally writes dgamma/dbeta (accumulate flag).  */
+typedef struct vts_norm_bwd_desc {
+  float* dy; /* in: grad wrt normalised(+affine) output; out: grad wrt raw x */
+  const float* x;
+  int64_t nstride;
+  int N, C, HW;
+  int mode;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  int accumulate_param_grads;
+} vts_norm_bwd_desc;
+
+int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream);
+
+/* dy (+)= g * act'(x*scale+shift): derivative mask as a stand-alone op (used where the
+ * producer of g is not one of the conv kernels). */
+int vts_act_bwd(const float* g, const vts_operand* x, int N, int HW, int act, float* dy, int accumulate, void* stream);
+
+/* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
+ * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */
+int vts_avgpool3s2(const float* x, int64_t x_nstride, int N, int C, int H, int W, float* y, void* stream);
+int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, float* dx, int64_t dx_nstride, int accumulate,
+                       void* stream);
+
+/* GANLoss on one scale (models/networks.py:497-521), forward value and gradient in one pass.
+ *   mode: 0 nonsaturating, 1 lsgan, 2 vanilla(BCE logits), 3 wgan, 4 hinge
+ *   loss_out[0] += coeff * mean_over_batch( per-sample loss )   (lsgan/vanilla/wgan: global mean)
+ *   dpred (if non-NULL) = d(coeff * that) / dpred                */
+int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
+                float* loss_out, float* dpred, void* stream);
+
+/* loss_out[0] += coeff * sum|a-b| ;  grad (+)= coeff * sign(a-b)   (nn.L1Loss pieces,
+ * sinskitG_model.py:1702, 1812-1814; the caller folds 1/numel into coeff). */
+int vts_l1(const float* a, const float* b, int64_t n, float coeff, float* loss_out, float* grad, int accumulate,
+           void* stream);
+
+/* Patch gather with clamp-to-border (models/model_utils.py:252-333), for P patches of
+ * size x size taken from image index img[p] at offsets (offx[p], offy[p]):
+ *   out[p, out_c0 + c, y, x] = src[img[p], c, clamp(offy+y), clamp(offx+x)]
+ * and its deterministic backward (each source pixel sums the patches covering it, in patch order). */
+int vts_patch_gather(const float* src, int64_t src_nstride, int C, int H, int W, const int* img, const int* offx,
+                     const int* offy, int P, int size, float* out, int out_C, int out_c0, void* stream);
+int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, int C, const int* img, const int* offx,
+                          const int* offy, int P, int P_per_img, int size, float* dsrc, int64_t dsrc_nstride, int N, int H,
+                          int W, int accumulate, void* stream);
+
+/* Generator output post-processing (sinskitG_model.py:1309-1340), one pass over g_out [N,5,H,W]:
+ *   fake_I = g_out[:, :3]*M ; fake_T = g_out[:, 3:]*M ; fake_N = normalize(gx, gy, scale_nz)
+ *   aug_fake_I = DiffAugment_bs(fake_I; rb, rs) * M            (thirdparty/DiffAugment.py:25-33)
+ * Any output pointer may be NULL. */
+int vts_g_post(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
+               float* fake_I, float* fake_T, float* fake_N, float* aug_fake_I, void* stream);
+/* aug = DiffAugment_bs(x; rb, rs) * M for a 3-channel image. */
+int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, const float* rb, const float* rs, float* aug,
+                        void* stream);
+/* d g_raw = cat(d fake_I, d fake_T) * M * (1 - g_out^2)   (mask multiply + Tanh backward). */
+int vts_g_out_grad(const float* d_fake_I, const float* d_fake_T, const float* M, const float* g_out, int N, int H, int W,
+                   float* d_raw, void* stream);
+/* y = x * M (M broadcast over channels). */
+int vts_mask_mul(const float* x, const float* M, int N, int C, int HW, float* y, void* stream);
+/* Sinusoidal positional grid, SPE(dim,0) (thirdparty/mmgeneration/positional_encoding.py:54-160): out [N,2*dim,H,W]. */
+int vts_spe_grid(float* out, int64_t out_nstride, int N, int H, int W, int dim, void* stream);
+/* Dilated-mask candidate map of the "more fake T" sampler (models/model_utils.py:212-216):
+ * cand[n, y, x] = any(M[n, y-1 .. y+15, x-1 .. x+15]) on the (H-14)x(W-14) grid; row_count[n, y] = number of
+ * candidates in row y.  vts_mask_select resolves row-major ranks into (offx, offy). */
+int vts_mask_candidates(const float* M, int N, int H, int W, uint8_t* cand, int* row_count, void* stream);
+int vts_mask_select(const uint8_t* cand, const int* row_prefix, int N, int H, int W, const int64_t* ranks, int K, int* offx,
+                    int* offy, void* stream);
+
+/* Fused Adam over a flat fp32 buffer (torch.optim.Adam defaults; sinskitG_model.py:589-599).
+ * step_count: 1-based step index; grad_scale multiplies the gradient first (1/world for DDP mean). */
+int vts_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  int step_count, float grad_scale, void* stream);
+
+/* PatchNCE loss forward+backward (models/patchnce.py:13-55): B groups of P patches, dim D.
+ * loss[b*P+i] = CE([q_i.k_i, q_i.k_j (j != i; diagonal -> -10)] / T, 0); dq = d sum(loss*gscale) / dq. */
+int vts_patchnce(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq,
+                 void* stream);
+/* Row L2 normalisation x / (||x|| + 1e-7) (models/networks.py:585-594). */
+int vts_l2norm_rows(const float* x, int rows, int D, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,436 @@
+"""Kernel-level parity: every vts_* entry point (through the C ABI) vs a plain PyTorch fp32
+CPU evaluation of the same op on the same seeded inputs.  Tolerances: rel-L2 <= 1e-5 for
+single ops (fp32 accumulation order differs), exact for pure data movement."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, nets  # noqa: E402  (checker only)
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _affine(n, c, seed, name):
+    sc = 1.0 + 0.3 * detrand.uniform((n * c,), seed, name + "sc")
+    sh = 0.2 * detrand.uniform((n * c,), seed, name + "sh")
+    return sc, sh
+
+
+def _apply(x, sc, sh, act):
+    n, c = x.shape[:2]
+    v = x * sc.view(n, c, 1, 1) + sh.view(n, c, 1, 1)
+    if act == 1:
+        v = F.leaky_relu(v, 0.2)
+    elif act == 2:
+        v = F.relu(v)
+    return v
+
+
+CONV_CASES = [
+    # (N, C0, C1, Cout, H, W, stride, pad, act_in)
+    (2, 9, 0, 10, 64, 64, 2, 1, 0),
+    (1, 10, 0, 20, 50, 70, 2, 1, 1),
+    (2, 20, 0, 40, 32, 32, 2, 1, 1),
+    (1, 40, 0, 80, 16, 16, 2, 1, 1),
+    (1, 80, 0, 80, 4, 4, 2, 1, 1),
+    (2, 1, 3, 8, 64, 64, 2, 2, 0),      # D layer 0 with dual source (S ++ I)
+    (1, 8, 0, 16, 33, 33, 2, 2, 1),
+    (1, 32, 0, 64, 9, 9, 1, 2, 1),
+    (2, 64, 0, 1, 10, 10, 1, 2, 1),
+    (1, 7, 0, 8, 32, 32, 2, 2, 0),
+    (1, 5, 0, 33, 20, 24, 2, 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case):
+    from vts import ops
+    from vts.ops import Act
+
+    N, C0, C1, Cout, H, W, s, p, act = case
+    dev = _dev()
+    x0 = detrand.uniform((N, C0, H, W), 1, "x0")
+    sc0, sh0 = _affine(N, C0, 1, "a0")
+    xs = [_apply(x0, sc0, sh0, act)]
+    in1 = None
+    if C1:
+        x1 = detrand.uniform((N, C1, H, W), 1, "x1")
+        sc1, sh1 = _affine(N, C1, 1, "a1")
+        xs.append(_apply(x1, sc1, sh1, act))
+        in1 = Act(x1.to(dev), sc1.to(dev), sh1.to(dev))
+    w = detrand.uniform((Cout, C0 + C1, 4, 4), 2, "w") * 0.2
+    b = detrand.uniform((Cout,), 2, "b")
+    ref = F.conv2d(torch.cat(xs, 1), w, b, stride=s, padding=p)
+    out = torch.full(ref.shape, float("nan"), device=dev)
+    ops.conv4x4(Act(x0.to(dev), sc0.to(dev), sh0.to(dev)), w.to(dev), (C0 + C1) * 16, 16, Cout, out, in1=in1, bias=b.to(dev),
+                stride=s, pad=p, act_in=act)
+    assert rel(out, ref) < 1e-5
+
+
+CONVT_CASES = [
+    # (N, C0, C1, Cout, H, W, stride, pad, act_in, tanh)
+    (1, 80, 0, 80, 2, 2, 2, 1, 2, 0),
+    (2, 80, 80, 80, 8, 8, 2, 1, 2, 0),
+    (1, 80, 80, 40, 16, 16, 2, 1, 2, 0),
+    (1, 40, 40, 20, 24, 40, 2, 1, 2, 0),
+    (2, 20, 20, 10, 32, 32, 2, 1, 2, 0),
+    (2, 10, 0, 3, 64, 64, 2, 1, 2, 1),
+    (1, 10, 0, 2, 48, 80, 2, 1, 2, 1),
+    (1, 16, 0, 8, 17, 17, 2, 2, 0, 0),   # backward-data geometry of a s2 p2 conv (odd -> even size)
+    (1, 64, 0, 32, 10, 10, 1, 2, 0, 0),  # backward-data geometry of a s1 p2 conv
+    (1, 1, 0, 64, 11, 11, 1, 2, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transposed_forward(case):
+    from vts import ops
+    from vts.ops import Act
+
+    N, C0, C1, Cout, H, W, s, p, act, tanh = case
+    dev = _dev()
+    x0 = detrand.uniform((N, C0, H, W), 3, "x0")
+    sc0, sh0 = _affine(N, C0, 3, "a0")
+    xs = [_apply(x0, sc0, sh0, act)]
+    in1 = None
+    if C1:
+        x1 = detrand.uniform((N, C1, H, W), 3, "x1")
+        sc1, sh1 = _affine(N, C1, 3, "a1")
+        xs.append(_apply(x1, sc1, sh1, act))
+        in1 = Act(x1.to(dev), sc1.to(dev), sh1.to(dev))
+    Cin = C0 + C1
+    w = detrand.uniform((Cin, Cout, 4, 4), 4, "w") * 0.2
+    b = detrand.uniform((Cout,), 4, "b")
+    if s == 2 and p == 2:
+        OH, OW = 2 * H - 2, 2 * W - 2  # the size whose s2/p2 conv gives H (even input sizes only)
+        ref = F.conv_transpose2d(torch.cat(xs, 1), w, b, stride=2, padding=2)
+        assert ref.shape[2] == 2 * H - 2
+    elif s == 2:
+        ref = F.conv_transpose2d(torch.cat(xs, 1), w, b, stride=2, padding=1)
+    else:
+        ref = F.conv_transpose2d(torch.cat(xs, 1), w, b, stride=1, padding=p)
+    if tanh:
+        ref = torch.tanh(ref)
+    out = torch.full(ref.shape, float("nan"), device=dev)
+    ops.conv4x4(Act(x0.to(dev), sc0.to(dev), sh0.to(dev)), w.to(dev), 16, Cout * 16, Cout, out, in1=in1, bias=b.to(dev), stride=s,
+                pad=p, transposed=True, act_in=act, act_out=3 if tanh else 0)
+    assert rel(out, ref) < 1e-5
+
+
+def test_conv_transposed_odd_output_and_dmask_accumulate():
+    """backward-data of Conv2d(4->8, s2, p2) at H=34: output 34 from input 18, channel sub-range,
+    derivative mask and accumulation -- the G-step path into fake_I."""
+    from vts import ops
+    from vts.ops import Act
+
+    dev = _dev()
+    N, Cin, Cout, H = 2, 4, 8, 34
+    x = detrand.uniform((N, Cin, H, H), 5, "x").requires_grad_(True)
+    w = detrand.uniform((Cout, Cin, 4, 4), 5, "w") * 0.3
+    y = F.conv2d(F.leaky_relu(x, 0.2), w, None, stride=2, padding=2)
+    g = detrand.uniform(tuple(y.shape), 5, "g")
+    (y * g).sum().backward()
+    ref_full = x.grad  # includes the LeakyReLU derivative mask
+    prev = detrand.uniform((N, 3, H, H), 5, "prev")
+    out = prev.clone().to(dev)
+    xin = x.detach().to(dev)
+    # channels 1..3 only: offset the weight view by one input channel (16 floats)
+    wd = w.to(dev)
+    dm = L_operand_slice(xin, 1, 3)
+    ops.conv4x4(Act(g.to(dev)), wd.view(-1)[16:], 16, Cin * 16, 3, out, stride=2, pad=2, transposed=True, dmask=dm, dmask_act=1,
+                accumulate=True)
+    assert rel(out, prev + ref_full[:, 1:4]) < 1e-5
+
+
+def L_operand_slice(t, c0, c):
+    from vts import lib as L
+
+    return L.Operand(t[:, c0:].data_ptr(), None, None, c, t.stride(0))
+
+
+WGRAD_CASES = [
+    # (N, CL0, CL1, CH, LH, LW, stride, pad, act_lo, act_hi, convT?)
+    (2, 10, 0, 9, 32, 32, 2, 1, 0, 0, False),
+    (1, 20, 0, 10, 25, 35, 2, 1, 0, 1, False),
+    (2, 80, 0, 80, 4, 4, 2, 1, 0, 1, False),
+    (1, 8, 0, 4, 33, 33, 2, 2, 0, 0, False),
+    (1, 64, 0, 32, 10, 10, 1, 2, 0, 1, False),
+    (2, 1, 0, 64, 11, 11, 1, 2, 0, 1, False),
+    (1, 16, 0, 7, 17, 17, 2, 2, 0, 0, False),
+    (2, 20, 20, 10, 16, 16, 2, 1, 2, 0, True),
+    (1, 80, 80, 40, 8, 8, 2, 1, 2, 0, True),
+    (2, 10, 0, 3, 32, 32, 2, 1, 2, 0, True),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad(case):
+    from vts import ops
+    from vts.ops import Act
+
+    N, CL0, CL1, CH, LH, LW, s, p, act_lo, act_hi, convT = case
+    dev = _dev()
+    HH, HW = (LH - 1) * s + 4 - 2 * p, (LW - 1) * s + 4 - 2 * p
+    lo0 = detrand.uniform((N, CL0, LH, LW), 6, "lo0")
+    a0 = _affine(N, CL0, 6, "l0")
+    los = [_apply(lo0, a0[0], a0[1], act_lo)]
+    lo1_act = None
+    if CL1:
+        lo1 = detrand.uniform((N, CL1, LH, LW), 6, "lo1")
+        a1 = _affine(N, CL1, 6, "l1")
+        los.append(_apply(lo1, a1[0], a1[1], act_lo))
+        lo1_act = Act(lo1.to(dev), a1[0].to(dev), a1[1].to(dev))
+    hi = detrand.uniform((N, CH, HH, HW), 6, "hi")
+    ah = _affine(N, CH, 6, "h")
+    hiv = _apply(hi, ah[0], ah[1], act_hi)
+    lov = torch.cat(los, 1)
+    CL = CL0 + CL1
+    w = torch.zeros(CL, CH, 4, 4, requires_grad=True)
+    # dw[cl][ch][ky][kx] = sum lo * hi(shifted): the weight gradient of conv(hi -> lo) with cotangent lo
+    y = F.conv2d(hiv, w, None, stride=s, padding=p)
+    assert y.shape[2:] == lov.shape[2:]
+    (y * lov).sum().backward()
+    ref = w.grad
+    dw = torch.full((CL, CH, 4, 4), float("nan"), device=dev)
+    ops.wgrad4x4(Act(lo0.to(dev), a0[0].to(dev), a0[1].to(dev)), Act(hi.to(dev), ah[0].to(dev), ah[1].to(dev)), dw, lo1=lo1_act,
+                 act_lo=act_lo, act_hi=act_hi, stride=s, pad=p)
+    assert rel(dw, ref) < 2e-5
+    dw2 = dw.clone()
+    ops.wgrad4x4(Act(lo0.to(dev), a0[0].to(dev), a0[1].to(dev)), Act(hi.to(dev), ah[0].to(dev), ah[1].to(dev)), dw2, lo1=lo1_act,
+                 act_lo=act_lo, act_hi=act_hi, stride=s, pad=p, accumulate=True)
+    assert rel(dw2, 2 * ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 10, 64, 64), (1, 80, 2, 2), (3, 20, 37, 53), (1, 3, 128, 128)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_norm_forward_backward(shape, mode):
+    from vts import ops
+
+    dev = _dev()
+    n, c, h, w = shape
+    x = (detrand.uniform(shape, 7, "x") * 2 + 0.7).requires_grad_(True)
+    gamma = (1 + 0.2 * detrand.uniform((c,), 7, "g")).requires_grad_(True)
+    beta = (0.1 * detrand.uniform((c,), 7, "b")).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    if mode == 0:
+        y = F.instance_norm(x, eps=1e-5)
+    else:
+        y = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    cot = detrand.uniform(shape, 7, "cot")
+    (y * cot).sum().backward()
+    xd = x.detach().to(dev)
+    rmd, rvd = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    nbt = torch.zeros((), dtype=torch.long, device=dev)
+    a = ops.norm_stats(xd, mode, gamma=gamma.detach().to(dev) if mode else None, beta=beta.detach().to(dev) if mode else None,
+                       running_mean=rmd if mode else None, running_var=rvd if mode else None, nbt=nbt if mode else None)
+    yk = xd * a.scale.view(n, c, 1, 1) + a.shift.view(n, c, 1, 1)
+    assert rel(yk, y) < 1e-5
+    if mode:
+        if n * h * w > 1:
+            assert rel(rmd, rm) < 1e-5 and rel(rvd, rv) < 1e-5
+        assert int(nbt) == 1
+    dy = cot.to(dev).clone()
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    ops.norm_bwd(dy, a, mode, gamma=gamma.detach().to(dev) if mode else None, dgamma=dg if mode else None, dbeta=db if mode else None)
+    assert rel(dy, x.grad) < 2e-4
+    if mode:
+        assert rel(dg, gamma.grad) < 1e-4 and rel(db, beta.grad) < 1e-4
+
+
+def test_norm_large_mean_is_robust():
+    from vts import ops
+
+    dev = _dev()
+    x = detrand.uniform((1, 2, 96, 96), 8, "x") * 0.01 + 100.0
+    y = F.instance_norm(x.double(), eps=1e-5).float()
+    a = ops.norm_stats(x.to(dev), 0)
+    yk = x.to(dev) * a.scale.view(1, 2, 1, 1) + a.shift.view(1, 2, 1, 1)
+    # scale*x + shift form loses digits at |mean| >> std; statistics themselves must be right
+    m = x.double().mean(dim=(2, 3)).flatten()
+    v = x.double().var(dim=(2, 3), unbiased=False).flatten()
+    assert rel(a.mean, m) < 1e-6
+    assert rel(a.rstd, 1 / torch.sqrt(v + 1e-5)) < 1e-4
+    assert (yk.cpu() - y).abs().max() < 0.1
+
+
+def test_channel_sum_and_act_bwd():
+    from vts import ops
+    from vts.ops import Act
+
+    dev = _dev()
+    x = detrand.uniform((3, 5, 40, 33), 9, "x")
+    out = torch.zeros(5, device=dev)
+    ops.channel_sum(x.to(dev), out)
+    assert rel(out, x.sum(dim=(0, 2, 3))) < 1e-5
+    sc, sh = _affine(3, 5, 9, "a")
+    g = detrand.uniform((3, 5, 40, 33), 9, "g")
+    v = (x * sc.view(3, 5, 1, 1) + sh.view(3, 5, 1, 1))
+    for kind, ref in ((1, g * torch.where(v > 0, 1.0, 0.2)), (2, g * (v > 0).float())):
+        dy = torch.ones(3, 5, 40, 33, device=dev)
+        ops.act_bwd(g.to(dev), Act(x.to(dev), sc.to(dev), sh.to(dev)), kind, dy, accumulate=True)
+        assert rel(dy, ref + 1) < 1e-6
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (33, 47), (2, 2), (513, 17)])
+def test_avgpool(hw):
+    from vts import ops
+
+    dev = _dev()
+    x = detrand.uniform((2, 4, hw[0], hw[1]), 10, "x").requires_grad_(True)
+    y = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+    cot = detrand.uniform(tuple(y.shape), 10, "c")
+    (y * cot).sum().backward()
+    yk = ops.avgpool(x.detach().to(dev))
+    assert rel(yk, y) < 1e-6
+    dx = torch.ones(2, 4, hw[0], hw[1], device=dev)
+    ops.avgpool_bwd(cot.to(dev), dx, accumulate=True)
+    assert rel(dx, x.grad + 1) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["nonsaturating", "lsgan", "vanilla", "wgan", "hinge"])
+@pytest.mark.parametrize("real", [True, False])
+def test_ganloss(mode, real):
+    from vts import ops
+
+    dev = _dev()
+    p = (detrand.uniform((3, 1, 9, 11), 11, "p") * 4).requires_grad_(True)
+    ref = nets.gan_loss_single(p, real, mode, 0.8, 0.0)
+    ref = ref.mean() * 2.5
+    ref.backward()
+    slot = torch.zeros(1, device=dev)
+    dp = torch.empty(3, 1, 9, 11, device=dev)
+    ops.ganloss(p.detach().to(dev), mode, real, 2.5, slot, dp, label=0.8 if real else 0.0)
+    assert abs(slot.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+    assert rel(dp, p.grad) < 1e-5
+
+
+def test_l1_and_adam():
+    from vts import ops
+
+    dev = _dev()
+    a = detrand.uniform((2, 3, 17, 19), 12, "a").requires_grad_(True)
+    b = detrand.uniform((2, 3, 17, 19), 12, "b")
+    ref = F.l1_loss(a, b) * 100
+    ref.backward()
+    slot = torch.zeros(1, device=dev)
+    g = torch.empty(2, 3, 17, 19, device=dev)
+    ops.l1(a.detach().to(dev), b.to(dev), 100.0 / a.numel(), slot, g)
+    assert abs(slot.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert rel(g, a.grad) < 1e-6
+    # Adam, 3 steps, beta1 = 0 like the reference
+    p = detrand.uniform((1000,), 13, "p")
+    m, v = torch.zeros(1000), torch.zeros(1000)
+    pd, md, vd = p.clone().to(dev), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for step in range(1, 4):
+        gr = detrand.uniform((1000,), 13, "g%d" % step) * 10 ** (-step * 2)
+        nets.adam_update(p, gr, m, v, step, 1e-3, 0.0, 0.99)
+        ops.adam_flat(pd, gr.to(dev), md, vd, 1e-3, 0.0, 0.99, 1e-8, step)
+    assert rel(pd, p) < 1e-6 and rel(vd, v) < 1e-5
+
+
+def test_patch_gather_scatter():
+    from vts import ops
+
+    dev = _dev()
+    N, C, H, W, PPI = 2, 2, 96, 80, 7
+    src = detrand.uniform((N, C, H, W), 14, "src").requires_grad_(True)
+    ox = torch.tensor([0, 10, 60, 70, 33, 5, 10, -3, 12, 50, 60, 1, 2, 12], dtype=torch.int32)  # duplicates + border clamps
+    oy = torch.tensor([0, 20, 80, 5, 64, 90, 20, -5, 30, 70, 1, 2, 3, 30], dtype=torch.int32)
+    img = torch.arange(N).repeat_interleave(PPI).int()
+    outs = [nets.gather_patches(src[n:n + 1], ox[n * PPI:(n + 1) * PPI], oy[n * PPI:(n + 1) * PPI], 32) for n in range(N)]
+    ref = torch.cat(outs, 0)
+    cot = detrand.uniform(tuple(ref.shape), 14, "cot")
+    (ref * cot).sum().backward()
+    out = torch.zeros(N * PPI, 5, 32, 32, device=dev)
+    ops.patch_gather(src.detach().to(dev), img.to(dev), ox.to(dev), oy.to(dev), 32, out, c0=2)
+    assert torch.equal(out[:, 2:4].cpu(), ref.detach())
+    assert float(out[:, :2].abs().sum()) == 0
+    dp = torch.zeros(N * PPI, 5, 32, 32)
+    dp[:, 2:4] = cot
+    dsrc = torch.full((N, C, H, W), 7.0, device=dev)
+    ops.patch_scatter_bwd(dp.to(dev), 2, C, ox.to(dev), oy.to(dev), PPI, 32, dsrc)
+    assert rel(dsrc, src.grad) < 1e-6
+
+
+def test_g_post_diffaug_outgrad_spe():
+    from vts import ops
+
+    dev = _dev()
+    N, H, W = 2, 40, 56
+    g = torch.tanh(detrand.uniform((N, 5, H, W), 15, "g") * 2)
+    M = (detrand.uniform((N, 1, H, W), 15, "m") > -0.5).float()
+    rb, rs = torch.tensor([0.3, 0.9]), torch.tensor([0.1, 0.7])
+    fI, fT = g[:, :3] * M, g[:, 3:] * M
+    outs = [torch.empty(N, c, H, W, device=dev) for c in (3, 2, 3, 3)]
+    ops.g_post(g.to(dev), M.to(dev), 0.25, rb.to(dev), rs.to(dev), *outs)
+    assert rel(outs[0], fI) < 1e-6 and rel(outs[1], fT) < 1e-6
+    assert rel(outs[2], nets.compute_normal(fT, 0.25)) < 1e-6
+    assert rel(outs[3], nets.diffaug_bs(fI, rb, rs) * M) < 1e-6
+    aug = torch.empty(N, 3, H, W, device=dev)
+    ops.diffaug_bs_mask(fI.to(dev), M.to(dev), rb.to(dev), rs.to(dev), aug)
+    assert rel(aug, nets.diffaug_bs(fI, rb, rs) * M) < 1e-6
+    dI, dT = detrand.uniform((N, 3, H, W), 15, "dI"), detrand.uniform((N, 2, H, W), 15, "dT")
+    d = torch.empty(N, 5, H, W, device=dev)
+    ops.g_out_grad(dI.to(dev), dT.to(dev), M.to(dev), g.to(dev), d)
+    assert rel(d, torch.cat([dI, dT], 1) * M * (1 - g * g)) < 1e-6
+    buf = torch.zeros(N, 9, H, W, device=dev)
+    ops.spe_grid(buf, 4, c0=1)
+    assert (buf[:, 1:].cpu() - nets.spe_grid(N, H, W)).abs().max() < 2e-6
+    big = torch.zeros(1, 8, 1100, 1030, device=dev)
+    ops.spe_grid(big, 4)
+    assert (big.cpu() - nets.spe_grid(1, 1100, 1030)).abs().max() < 1e-4
+    y = ops.mask_mul(dI.to(dev), M.to(dev))
+    assert rel(y, dI * M) < 1e-7
+
+
+def test_mask_candidates_and_select():
+    import random
+
+    from vts import ops
+
+    dev = _dev()
+    M = torch.zeros(2, 1, 80, 96)
+    M[0, 0, 20:40, 25:50] = 1
+    M[1, 0, 5:70, 60:90] = 1
+    M[1, 0, 0, 0] = 1
+    cand, prefix = ops.mask_candidates(M.to(dev))
+    ranks = []
+    exp_x, exp_y = [], []
+    random.seed(3)
+    for n in range(2):
+        pos = nets.dilated_mask_positions(M[n:n + 1])
+        assert int(prefix[n, -1]) == pos.shape[0]
+        r = random.sample(range(pos.shape[0]), 9)
+        r[0], r[1] = 0, pos.shape[0] - 1
+        ranks.append(r)
+        exp_y += pos[r][:, 0].tolist()
+        exp_x += pos[r][:, 1].tolist()
+    ox, oy = ops.mask_select(cand, prefix, torch.tensor(ranks, dtype=torch.int64, device=dev), 80, 96)
+    assert ox.cpu().tolist() == exp_x and oy.cpu().tolist() == exp_y
+
+
+@pytest.mark.parametrize("allneg", [False, True])
+def test_patchnce(allneg):
+    from vts import ops
+
+    dev = _dev()
+    B, P, D = 2, 48, 40
+    q0 = detrand.uniform((B * P, D), 16, "q")
+    k0 = detrand.uniform((B * P, D), 16, "k")
+    qn = ops.l2norm_rows(q0.to(dev))
+    assert rel(qn, nets.l2_normalize(q0)) < 1e-6
+    q = nets.l2_normalize(q0).requires_grad_(True)
+    k = nets.l2_normalize(k0)
+    ref = nets.patchnce_loss(q, k, B, 0.07, allneg)
+    ref.sum().backward()
+    loss, dq = ops.patchnce(q.detach().to(dev), k.to(dev), 1 if allneg else B, 0.07)
+    assert rel(loss, ref) < 1e-5 and rel(dq, q.grad) < 1e-5

@@ -1,0 +1,17 @@
+// Error reporting and version entry points of libvts_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "vts.h"
+
+static thread_local char g_err[512] = "";
+
+void vts_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* vts_last_error(void) { return g_err; }
+extern "C" int vts_version(void) { return 1; }

@@ -1,0 +1,62 @@
+// Internal helpers shared by the HIP translation units of libvts_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "vts.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void vts_set_error(const char* fmt, ...);
+
+#define VTS_CHECK_ARG(cond, ...)     \
+  do {                               \
+    if (!(cond)) {                   \
+      vts_set_error(__VA_ARGS__);    \
+      return VTS_ERR_ARG;            \
+    }                                \
+  } while (0)
+
+#define VTS_CHECK_LAUNCH(name)                                             \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      vts_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return VTS_ERR_LAUNCH;                                               \
+    }                                                                      \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float vts_act(float v, int act) {
+  if (act == VTS_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  if (act == VTS_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+__device__ __forceinline__ float vts_act_grad(float v, int act) {
+  if (act == VTS_ACT_LRELU) return v > 0.f ? 1.f : 0.2f;
+  if (act == VTS_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// wave64 sum via DPP-free shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block (<=1024 threads) sum; result valid in every thread. `red` must hold >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}

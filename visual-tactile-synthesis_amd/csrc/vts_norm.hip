@@ -1,0 +1,334 @@
+// InstanceNorm / BatchNorm statistics and backward, channel sums, activation backward.
+// All of these are HBM-bound streaming reductions: one coalesced pass, wave64 shuffle
+// reductions, fixed-order second stage (deterministic, no float atomics).
+#include "vts_internal.h"
+
+namespace {
+
+constexpr int CHUNK = 2048;  // elements per workgroup: 256 threads x 8 registers
+constexpr int EPT = CHUNK / 256;
+
+__host__ __device__ inline int splits_for(int HW) { return (HW + CHUNK - 1) / CHUNK; }
+
+// ---- forward statistics: per (n, c, split) -> (mean, M2, count) via a register-resident two-pass ----
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW,
+                                                            int spl, float* __restrict__ part) {
+  __shared__ float red[16];
+  const int s = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const float* px = x + n * nstride + (int64_t)c * HW;
+  const int base = s * CHUNK;
+  const int cnt = min(CHUNK, HW - base);
+  float v[EPT];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = e * 256 + threadIdx.x;
+    v[e] = (i < cnt) ? px[base + i] : 0.f;
+    sum += v[e];
+  }
+  const float mean = block_sum(sum, red) / (float)cnt;
+  float m2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = e * 256 + threadIdx.x;
+    const float d = v[e] - mean;
+    if (i < cnt) m2 += d * d;
+  }
+  m2 = block_sum(m2, red);
+  if (threadIdx.x == 0) {
+    float* o = part + (((int64_t)n * C + c) * spl + s) * 3;
+    o[0] = mean;
+    o[1] = m2;
+    o[2] = (float)cnt;
+  }
+}
+
+// Chan merge of `np` partials strided by `stride` (one wave); returns (mean, M2, count) in every lane
+__device__ __forceinline__ void chan_merge_wave(const float* part, int np, int64_t stride, float& mean, float& m2, float& cnt) {
+  const int lane = threadIdx.x & 63;
+  float sn = 0.f, sm = 0.f;
+  for (int i = lane; i < np; i += 64) {
+    const float* q = part + i * stride;
+    sn += q[2];
+    sm += q[2] * q[0];
+  }
+  sn = wave_sum(sn);
+  sm = wave_sum(sm);
+  mean = sm / sn;
+  float acc = 0.f;
+  for (int i = lane; i < np; i += 64) {
+    const float* q = part + i * stride;
+    const float d = q[0] - mean;
+    acc += q[1] + q[2] * d * d;
+  }
+  m2 = wave_sum(acc);
+  cnt = sn;
+}
+
+struct NormK {
+  int N, C, HW, spl, mode;
+  float eps, momentum;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  int64_t* nbt;
+  float *scale, *shift, *mean_out, *rstd_out;
+};
+
+// IN: one wave per (n,c).  BN: one wave per c, merging N*spl partials, writing all n.
+__global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restrict__ part, const NormK k) {
+  const int lane = threadIdx.x;
+  if (k.mode == 0) {
+    const int g = blockIdx.x;  // n*C + c
+    float mean, m2, cnt;
+    chan_merge_wave(part + (int64_t)g * k.spl * 3, k.spl, 3, mean, m2, cnt);
+    if (lane == 0) {
+      const float rstd = 1.f / sqrtf(m2 / cnt + k.eps);
+      k.scale[g] = rstd;
+      k.shift[g] = -mean * rstd;
+      if (k.mean_out) k.mean_out[g] = mean;
+      if (k.rstd_out) k.rstd_out[g] = rstd;
+    }
+  } else {
+    const int c = blockIdx.x;
+    // partials of channel c: for n in N, s in spl -> index ((n*C + c)*spl + s); merge in two levels per n
+    float sn = 0.f, sm = 0.f;
+    const int np = k.N * k.spl;
+    for (int i = lane; i < np; i += 64) {
+      const int n = i / k.spl, s = i - n * k.spl;
+      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+      sn += q[2];
+      sm += q[2] * q[0];
+    }
+    sn = wave_sum(sn);
+    sm = wave_sum(sm);
+    const float mean = sm / sn;
+    float acc = 0.f;
+    for (int i = lane; i < np; i += 64) {
+      const int n = i / k.spl, s = i - n * k.spl;
+      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+      const float d = q[0] - mean;
+      acc += q[1] + q[2] * d * d;
+    }
+    const float m2 = wave_sum(acc);
+    const float var = m2 / sn;
+    const float rstd = 1.f / sqrtf(var + k.eps);
+    const float g = k.gamma ? k.gamma[c] : 1.f, b = k.beta ? k.beta[c] : 0.f;
+    for (int n = lane; n < k.N; n += 64) {
+      const int idx = n * k.C + c;
+      k.scale[idx] = g * rstd;
+      k.shift[idx] = b - mean * g * rstd;
+      if (k.mean_out) k.mean_out[idx] = mean;
+      if (k.rstd_out) k.rstd_out[idx] = rstd;
+    }
+    if (lane == 0) {
+      if (k.running_mean) k.running_mean[c] = (1.f - k.momentum) * k.running_mean[c] + k.momentum * mean;
+      if (k.running_var) k.running_var[c] = (1.f - k.momentum) * k.running_var[c] + k.momentum * (m2 / (sn - 1.f));
+      if (k.nbt && c == 0) k.nbt[0] += 1;
+    }
+  }
+}
+
+// ---- backward: partial S1 = sum dy, S2 = sum dy * xhat per (n, c, split) ----
+__global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               int64_t nstride, int C, int HW, int spl,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ part) {
+  __shared__ float red[16];
+  const int s = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const int64_t off = n * nstride + (int64_t)c * HW;
+  const int base = s * CHUNK;
+  const int cnt = min(CHUNK, HW - base);
+  const float mu = mean[n * C + c], rs = rstd[n * C + c];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = e * 256 + threadIdx.x;
+    if (i < cnt) {
+      const float g = dy[off + base + i];
+      const float xh = (x[off + base + i] - mu) * rs;
+      s1 += g;
+      s2 += g * xh;
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    float* o = part + (((int64_t)n * C + c) * spl + s) * 2;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
+struct NormBwdK {
+  int N, C, HW, spl, mode;
+  const float *mean, *rstd, *gamma;
+  float *dgamma, *dbeta;
+  int acc;
+  float* coef;  // [N*C][3]
+};
+
+__global__ __launch_bounds__(64) void norm_bwd_finalize_kernel(const float* __restrict__ part, const NormBwdK k) {
+  const int lane = threadIdx.x;
+  if (k.mode == 0) {
+    const int g = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < k.spl; i += 64) {
+      s1 += part[((int64_t)g * k.spl + i) * 2];
+      s2 += part[((int64_t)g * k.spl + i) * 2 + 1];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      const float m = (float)k.HW, rs = k.rstd[g], mu = k.mean[g];
+      const float B = -rs * rs * s2 / m;
+      k.coef[g * 3 + 0] = rs;
+      k.coef[g * 3 + 1] = B;
+      k.coef[g * 3 + 2] = -rs * s1 / m - B * mu;
+    }
+  } else {
+    const int c = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    const int np = k.N * k.spl;
+    for (int i = lane; i < np; i += 64) {
+      const int n = i / k.spl, s = i - n * k.spl;
+      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 2;
+      s1 += q[0];
+      s2 += q[1];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float m = (float)k.N * (float)k.HW;
+    const float rs = k.rstd[c], mu = k.mean[c];  // identical for every n
+    const float g = k.gamma ? k.gamma[c] : 1.f;
+    const float B = -g * rs * rs * s2 / m;
+    for (int n = lane; n < k.N; n += 64) {
+      const int idx = n * k.C + c;
+      k.coef[idx * 3 + 0] = g * rs;
+      k.coef[idx * 3 + 1] = B;
+      k.coef[idx * 3 + 2] = -g * rs * s1 / m - B * mu;
+    }
+    if (lane == 0) {
+      if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + s2;
+      if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + s1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
+                                                             int C, int HW, const float* __restrict__ coef) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* q = coef + (n * C + c) * 3;
+  const float A = q[0], B = q[1], Cc = q[2];
+  const int64_t off = n * nstride + (int64_t)c * HW;
+  const int base = blockIdx.x * CHUNK;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = base + e * 256 + threadIdx.x;
+    if (i < HW) dy[off + i] = A * dy[off + i] + B * x[off + i] + Cc;
+  }
+}
+
+// ---- channel sum ----
+__global__ __launch_bounds__(256) void chsum_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
+                                                            float* __restrict__ part) {
+  __shared__ float red[16];
+  const int s = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const float* px = x + n * nstride + (int64_t)c * HW;
+  const int base = s * CHUNK;
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = base + e * 256 + threadIdx.x;
+    if (i < HW) sum += px[i];
+  }
+  sum = block_sum(sum, red);
+  if (threadIdx.x == 0) part[((int64_t)n * C + c) * spl + s] = sum;
+}
+
+__global__ __launch_bounds__(64) void chsum_finalize_kernel(const float* __restrict__ part, int N, int C, int spl,
+                                                            float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int i = lane; i < N * spl; i += 64) {
+    const int n = i / spl, j = i - n * spl;
+    s += part[((int64_t)n * C + c) * spl + j];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, int64_t xns,
+                                                      const float* __restrict__ sc, const float* __restrict__ sh, int C, int HW,
+                                                      int act, float* __restrict__ dy, int accumulate) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float a = sc ? sc[n * C + c] : 1.f, b = sh ? sh[n * C + c] : 0.f;
+  const int64_t offx = n * xns + (int64_t)c * HW, off = ((int64_t)n * C + c) * HW;
+  const int base = blockIdx.x * CHUNK;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = base + e * 256 + threadIdx.x;
+    if (i < HW) {
+      const float v = g[off + i] * vts_act_grad(x[offx + i] * a + b, act);
+      dy[off + i] = accumulate ? dy[off + i] + v : v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vts_norm_ws_floats(int N, int C, int HW) { return (int64_t)N * C * splits_for(HW) * 3 + (int64_t)N * C * 3; }
+
+extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
+  VTS_CHECK_ARG(d && d->x && d->scale && d->shift && ws, "vts_norm_stats: null pointer");
+  VTS_CHECK_ARG(d->mode == 0 || d->mode == 1, "vts_norm_stats: mode %d", d->mode);
+  VTS_CHECK_ARG(d->N >= 1 && d->C >= 1 && d->HW >= 1 && d->N <= 65535 && d->C <= 65535, "vts_norm_stats: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int spl = splits_for(d->HW);
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->x, d->nstride, d->C, d->HW, spl, ws);
+  VTS_CHECK_LAUNCH("vts_norm_stats partial");
+  NormK k{d->N, d->C, d->HW, spl, d->mode, d->eps, d->momentum, d->gamma, d->beta, d->running_mean, d->running_var,
+          d->num_batches_tracked, d->scale, d->shift, d->mean_out, d->rstd_out};
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, ws, k);
+  VTS_CHECK_LAUNCH("vts_norm_stats finalize");
+  return VTS_OK;
+}
+
+extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream) {
+  VTS_CHECK_ARG(d && d->dy && d->x && d->mean && d->rstd && ws, "vts_norm_bwd: null pointer");
+  VTS_CHECK_ARG(d->mode == 0 || d->mode == 1, "vts_norm_bwd: mode %d", d->mode);
+  hipStream_t st = (hipStream_t)stream;
+  const int spl = splits_for(d->HW);
+  float* part = ws;
+  float* coef = ws + (int64_t)d->N * d->C * spl * 3;  // same split as vts_norm_ws_floats
+  hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, spl,
+                     d->mean, d->rstd, part);
+  VTS_CHECK_LAUNCH("vts_norm_bwd partial");
+  NormBwdK k{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, coef};
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, part, k);
+  VTS_CHECK_LAUNCH("vts_norm_bwd finalize");
+  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, coef);
+  VTS_CHECK_LAUNCH("vts_norm_bwd apply");
+  return VTS_OK;
+}
+
+extern "C" int64_t vts_channel_sum_ws_floats(int N, int C, int HW) { return (int64_t)N * C * splits_for(HW); }
+
+extern "C" int vts_channel_sum(const float* x, int64_t nstride, int N, int C, int HW, float* out, int accumulate, float* ws,
+                               void* stream) {
+  VTS_CHECK_ARG(x && out && ws, "vts_channel_sum: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int spl = splits_for(HW);
+  hipLaunchKernelGGL(chsum_partial_kernel, dim3(spl, C, N), dim3(256), 0, st, x, nstride, C, HW, spl, ws);
+  VTS_CHECK_LAUNCH("vts_channel_sum partial");
+  hipLaunchKernelGGL(chsum_finalize_kernel, dim3(C), dim3(64), 0, st, ws, N, C, spl, out, accumulate);
+  VTS_CHECK_LAUNCH("vts_channel_sum finalize");
+  return VTS_OK;
+}
+
+extern "C" int vts_act_bwd(const float* g, const vts_operand* x, int N, int HW, int act, float* dy, int accumulate, void* stream) {
+  VTS_CHECK_ARG(g && x && x->data && dy, "vts_act_bwd: null pointer");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(splits_for(HW), x->C, N), dim3(256), 0, (hipStream_t)stream, g, x->data, x->nstride,
+                     x->scale, x->shift, x->C, HW, act, dy, accumulate);
+  VTS_CHECK_LAUNCH("vts_act_bwd");
+  return VTS_OK;
+}

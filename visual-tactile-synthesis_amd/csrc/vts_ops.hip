@@ -1,0 +1,591 @@
+// Loss, data-movement and optimiser kernels of the training step (all HBM-bound or tiny):
+// AvgPool pyramid, GAN loss, L1, patch gather / deterministic scatter, generator output
+// post-processing (mask, normals, DiffAugment), positional encoding, "more fake T" sampler
+// support, fused Adam, PatchNCE.
+#include "vts_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------ AvgPool2d(3,2,1,count_include_pad=False)
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, int64_t xns, int C, int H, int W, int OH, int OW,
+                                                      float* __restrict__ y) {
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int c = blockIdx.z % C, n = blockIdx.z / C;
+  if (ox >= OW || oy >= OH) return;
+  const float* p = x + n * xns + (int64_t)c * H * W;
+  float s = 0.f;
+  int cnt = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int iy = 2 * oy + dy;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int ix = 2 * ox + dx;
+      if (ix < 0 || ix >= W) continue;
+      s += p[(int64_t)iy * W + ix];
+      ++cnt;
+    }
+  }
+  y[(((int64_t)n * C + c) * OH + oy) * OW + ox] = s / (float)cnt;
+}
+
+__device__ __forceinline__ int pool_cnt(int o, int L) {  // valid taps of window o along one axis
+  int c = 0;
+  for (int d = -1; d <= 1; ++d) {
+    const int i = 2 * o + d;
+    c += (i >= 0 && i < L);
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, int C, int H, int W, int OH, int OW,
+                                                          float* __restrict__ dx, int64_t dxns, int accumulate) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int c = blockIdx.z % C, n = blockIdx.z / C;
+  if (x >= W || y >= H) return;
+  const float* g = dy + ((int64_t)n * C + c) * OH * OW;
+  float s = 0.f;
+  // windows covering y: oy with |y - 2 oy| <= 1
+  const int oy_lo = y >> 1, oy_hi = (y + 1) >> 1, ox_lo = x >> 1, ox_hi = (x + 1) >> 1;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    if (oy >= OH) continue;
+    const int cy = pool_cnt(oy, H);
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      if (ox >= OW) continue;
+      s += g[(int64_t)oy * OW + ox] / (float)(cy * pool_cnt(ox, W));
+    }
+  }
+  float* o = dx + n * dxns + ((int64_t)c * H + y) * W + x;
+  *o = accumulate ? *o + s : s;
+}
+
+// ------------------------------------------------------------------ GAN loss
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus, threshold 20
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void ganloss_kernel(const float* __restrict__ pred, int64_t total, int mode, int real, float label,
+                                                      float inv_count, float coeff, float* __restrict__ loss, float* __restrict__ dpred) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float p = pred[i];
+    float l, g;
+    switch (mode) {
+      case 0: l = real ? softplus_t(-p) : softplus_t(p); g = real ? -sigmoid_f(-p) : sigmoid_f(p); break;
+      case 1: l = (p - label) * (p - label); g = 2.f * (p - label); break;
+      case 2: l = fmaxf(p, 0.f) - p * label + log1pf(expf(-fabsf(p))); g = sigmoid_f(p) - label; break;
+      case 3: l = real ? -p : p; g = real ? -1.f : 1.f; break;
+      default: {
+        const float t = real ? 1.f - p : 1.f + p;
+        l = fmaxf(t, 0.f);
+        g = t > 0.f ? (real ? -1.f : 1.f) : 0.f;
+      }
+    }
+    acc += l;
+    if (dpred) dpred[i] = g * inv_count * coeff;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, acc * inv_count * coeff);
+}
+
+// ------------------------------------------------------------------ L1
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float coeff,
+                                                 float* __restrict__ loss, float* __restrict__ grad, int accumulate) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    acc += fabsf(d);
+    if (grad) {
+      const float g = coeff * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      grad[i] = accumulate ? grad[i] + g : g;
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, acc * coeff);
+}
+
+// ------------------------------------------------------------------ patches
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ src, int64_t sns, int C, int H, int W,
+                                                           const int* __restrict__ img, const int* __restrict__ offx,
+                                                           const int* __restrict__ offy, int size, float* __restrict__ out, int outC,
+                                                           int c0) {
+  const int p = blockIdx.x, c = blockIdx.y;
+  const float* s = src + img[p] * sns + (int64_t)c * H * W;
+  const int ox = offx[p], oy = offy[p];
+  float* o = out + (((int64_t)p * outC + c0 + c) * size) * size;
+  for (int i = threadIdx.x; i < size * size; i += 256) {
+    const int y = i / size, x = i - y * size;
+    const int sy = min(max(oy + y, 0), H - 1), sx = min(max(ox + x, 0), W - 1);
+    o[i] = s[(int64_t)sy * W + sx];
+  }
+}
+
+// range of patch-local indices j in [0,size) with clamp(off + j, 0, L-1) == v
+__device__ __forceinline__ void inv_clamp(int v, int off, int size, int L, int& lo, int& hi) {
+  lo = hi = v - off;
+  if (v == 0) lo = 0;                 // everything that clamps up to 0
+  if (v == L - 1) hi = size - 1;      // everything that clamps down to L-1
+  lo = max(lo, 0);
+  hi = min(hi, size - 1);
+}
+
+// deterministic scatter-add: each 32x32 tile of the destination lists the patches that touch it
+// (in patch order) and every pixel sums its contributions in that order.
+__global__ __launch_bounds__(256) void patch_scatter_kernel(const float* __restrict__ dp, int dpC, int c0, int C,
+                                                            const int* __restrict__ offx, const int* __restrict__ offy, int ppi,
+                                                            int size, float* __restrict__ dsrc, int64_t dns, int H, int W,
+                                                            int accumulate) {
+  extern __shared__ int list[];  // ppi ints
+  __shared__ int count;
+  const int n = blockIdx.z, tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    int base = 0;
+    for (int p0 = 0; p0 < ppi; p0 += 64) {
+      const int p = p0 + lane;
+      bool hit = false;
+      if (p < ppi) {
+        const int ox = offx[n * ppi + p], oy = offy[n * ppi + p];
+        const int x_lo = min(max(ox, 0), W - 1), x_hi = min(max(ox + size - 1, 0), W - 1);
+        const int y_lo = min(max(oy, 0), H - 1), y_hi = min(max(oy + size - 1, 0), H - 1);
+        hit = x_lo < tx0 + 32 && x_hi >= tx0 && y_lo < ty0 + 32 && y_hi >= ty0;
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+      base += __popcll(m);
+    }
+    if (lane == 0) count = base;
+  }
+  __syncthreads();
+  const int cnt = count;
+  if (cnt == 0 && accumulate) return;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int y = ty0 + (i >> 5), x = tx0 + (i & 31);
+    if (y >= H || x >= W) continue;
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      for (int q = 0; q < cnt; ++q) {
+        const int p = n * ppi + list[q];
+        int jl, jh, il, ih;
+        inv_clamp(y, offy[p], size, H, jl, jh);
+        inv_clamp(x, offx[p], size, W, il, ih);
+        const float* g = dp + (((int64_t)p * dpC + c0 + c) * size) * size;
+        for (int j = jl; j <= jh; ++j)
+          for (int ii = il; ii <= ih; ++ii) s += g[j * size + ii];
+      }
+      float* o = dsrc + n * dns + ((int64_t)c * H + y) * W + x;
+      *o = accumulate ? *o + s : s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ generator output post-processing
+__global__ __launch_bounds__(256) void g_post_kernel(const float* __restrict__ g, const float* __restrict__ M, int64_t HW,
+                                                     float scale_nz, const float* __restrict__ rb, const float* __restrict__ rs,
+                                                     float* __restrict__ fI, float* __restrict__ fT, float* __restrict__ fN,
+                                                     float* __restrict__ aI) {
+  const int n = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  const float m = M[n * HW + i];
+  const float* gp = g + n * 5 * HW + i;
+  const float r = gp[0] * m, gg = gp[HW] * m, b = gp[2 * HW] * m, tx = gp[3 * HW] * m, ty = gp[4 * HW] * m;
+  if (fI) {
+    float* o = fI + n * 3 * HW + i;
+    o[0] = r; o[HW] = gg; o[2 * HW] = b;
+  }
+  if (fT) {
+    float* o = fT + n * 2 * HW + i;
+    o[0] = tx; o[HW] = ty;
+  }
+  if (fN) {
+    const float nz = scale_nz;
+    const float inv = 1.f / fmaxf(sqrtf(tx * tx + ty * ty + nz * nz), 1e-12f);  // F.normalize eps
+    float* o = fN + n * 3 * HW + i;
+    o[0] = tx * inv; o[HW] = ty * inv; o[2 * HW] = nz * inv;
+  }
+  if (aI) {
+    const float db = rb[n] - 0.5f, k = rs[n] * 2.f;
+    const float r1 = r + db, g1 = gg + db, b1 = b + db;
+    const float mean = (r1 + g1 + b1) / 3.f;
+    float* o = aI + n * 3 * HW + i;
+    o[0] = ((r1 - mean) * k + mean) * m;
+    o[HW] = ((g1 - mean) * k + mean) * m;
+    o[2 * HW] = ((b1 - mean) * k + mean) * m;
+  }
+}
+
+__global__ __launch_bounds__(256) void diffaug_kernel(const float* __restrict__ x, const float* __restrict__ M, int64_t HW,
+                                                      const float* __restrict__ rb, const float* __restrict__ rs, float* __restrict__ a) {
+  const int n = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  const float m = M ? M[n * HW + i] : 1.f;
+  const float* p = x + n * 3 * HW + i;
+  const float db = rb[n] - 0.5f, k = rs[n] * 2.f;
+  const float r1 = p[0] + db, g1 = p[HW] + db, b1 = p[2 * HW] + db;
+  const float mean = (r1 + g1 + b1) / 3.f;
+  float* o = a + n * 3 * HW + i;
+  o[0] = ((r1 - mean) * k + mean) * m;
+  o[HW] = ((g1 - mean) * k + mean) * m;
+  o[2 * HW] = ((b1 - mean) * k + mean) * m;
+}
+
+__global__ __launch_bounds__(256) void g_out_grad_kernel(const float* __restrict__ dI, const float* __restrict__ dT,
+                                                         const float* __restrict__ M, const float* __restrict__ g, int64_t HW,
+                                                         float* __restrict__ d) {
+  const int n = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  const float m = M[n * HW + i];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const float o = g[(n * 5 + c) * HW + i];
+    float up = 0.f;
+    if (c < 3) up = dI ? dI[(n * 3 + c) * HW + i] : 0.f;
+    else up = dT ? dT[(n * 2 + c - 3) * HW + i] : 0.f;
+    d[(n * 5 + c) * HW + i] = up * m * (1.f - o * o);
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_mul_kernel(const float* __restrict__ x, const float* __restrict__ M, int C, int64_t HW,
+                                                       float* __restrict__ y) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  y[((int64_t)n * C + c) * HW + i] = x[((int64_t)n * C + c) * HW + i] * M[n * HW + i];
+}
+
+__global__ __launch_bounds__(256) void spe_kernel(float* __restrict__ out, int64_t ons, int H, int W, int dim) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
+  if (x >= W) return;
+  const int half = dim / 2;
+  const float step = -(logf(10000.f) / (float)(half - 1));
+  for (int d = 0; d < 2 * dim; ++d) {
+    const int e = d % dim;
+    const float pos = (float)((d < dim ? x : y) + 1);
+    const float f = expf((float)(e % half) * step);
+    const float a = pos * f;
+    out[n * ons + ((int64_t)d * H + y) * W + x] = e < half ? sinf(a) : cosf(a);
+  }
+}
+
+// ------------------------------------------------------------------ "more fake T" candidate map
+__global__ __launch_bounds__(256) void mask_cand_kernel(const float* __restrict__ M, int H, int W, int Hc, int Wc,
+                                                        uint8_t* __restrict__ cand) {
+  __shared__ uint8_t in[48][49];
+  __shared__ uint8_t hz[48][33];
+  const int n = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const float* m = M + (int64_t)n * H * W;
+  for (int i = threadIdx.x; i < 48 * 48; i += 256) {
+    const int r = i / 48, c = i - r * 48;
+    const int y = y0 - 1 + r, x = x0 - 1 + c;
+    in[r][c] = (y >= 0 && y < H && x >= 0 && x < W && m[(int64_t)y * W + x] > 0.f) ? 1 : 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 48 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    uint8_t a = 0;
+    for (int d = 0; d < 17; ++d) a |= in[r][c + d];
+    hz[r][c] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    const int r = i >> 5, c = i & 31;
+    const int y = y0 + r, x = x0 + c;
+    if (y >= Hc || x >= Wc) continue;
+    uint8_t a = 0;
+    for (int d = 0; d < 17; ++d) a |= hz[r + d][c];
+    cand[((int64_t)n * Hc + y) * Wc + x] = a;
+  }
+}
+
+__global__ __launch_bounds__(64) void mask_rowcount_kernel(const uint8_t* __restrict__ cand, int Hc, int Wc, int* __restrict__ rc) {
+  const int y = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  int s = 0;
+  for (int x = lane; x < Wc; x += 64) s += cand[((int64_t)n * Hc + y) * Wc + x];
+  s = (int)wave_sum((float)s);
+  if (lane == 0) rc[n * (Hc + 1) + y + 1] = s;
+}
+
+__global__ void mask_prefix_kernel(int* __restrict__ rc, int Hc) {  // in-place inclusive scan -> rc[n][0..Hc] exclusive prefix
+  const int n = blockIdx.x;
+  int* p = rc + n * (Hc + 1);
+  if (threadIdx.x == 0) {
+    p[0] = 0;
+    for (int y = 1; y <= Hc; ++y) p[y] += p[y - 1];
+  }
+}
+
+__global__ __launch_bounds__(64) void mask_select_kernel(const uint8_t* __restrict__ cand, const int* __restrict__ prefix, int Hc,
+                                                         int Wc, const int64_t* __restrict__ ranks, int K, int* __restrict__ offx,
+                                                         int* __restrict__ offy) {
+  const int k = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const int* p = prefix + n * (Hc + 1);
+  const int rank = (int)ranks[n * K + k];
+  int lo = 0, hi = Hc - 1;  // find row with p[row] <= rank < p[row+1]
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (p[mid + 1] <= rank) lo = mid + 1; else hi = mid;
+  }
+  const int row = lo;
+  int need = rank - p[row];
+  int found = -1;
+  for (int x0 = 0; x0 < Wc && found < 0; x0 += 64) {
+    const int x = x0 + lane;
+    const bool bit = x < Wc && cand[((int64_t)n * Hc + row) * Wc + x];
+    const unsigned long long m = __ballot(bit);
+    const int c = __popcll(m);
+    if (need < c) {
+      // the (need)-th set bit of m
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+      const unsigned long long sel = __ballot(bit && before == need);
+      found = x0 + __ffsll((long long)sel) - 1;
+    } else {
+      need -= c;
+    }
+  }
+  if (lane == 0) {
+    offx[n * K + k] = found;
+    offy[n * K + k] = row;
+  }
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float step_size, float b1, float b2, float eps,
+                                                   float inv_bc2_sqrt, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gr = g[i] * gs;
+    const float mi = m[i] * b1 + (1.f - b1) * gr;
+    const float vi = v[i] * b2 + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+  }
+}
+
+// ------------------------------------------------------------------ PatchNCE
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int D, float* __restrict__ y) {
+  __shared__ float red[16];
+  const float* p = x + (int64_t)blockIdx.x * D;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) s += p[i] * p[i];
+  s = block_sum(s, red);
+  const float inv = 1.f / (sqrtf(s) + 1e-7f);
+  for (int i = threadIdx.x; i < D; i += 256) y[(int64_t)blockIdx.x * D + i] = p[i] * inv;
+}
+
+// one workgroup per (group b, query row i): logits against the P keys of the group, CE with the
+// positive at index 0, gradient wrt q_i.  Logits live in LDS only.
+__global__ __launch_bounds__(256) void patchnce_kernel(const float* __restrict__ q, const float* __restrict__ k, int P, int D, float invT,
+                                                       float gscale, float* __restrict__ loss, float* __restrict__ dq) {
+  extern __shared__ float sm[];  // q row [D] | weights [P+1]
+  __shared__ float red[16];
+  float* qrow = sm;
+  float* wgt = sm + D;
+  const int i = blockIdx.x, b = blockIdx.y;
+  const float* qb = q + ((int64_t)b * P + i) * D;
+  const float* kb = k + (int64_t)b * P * D;
+  for (int d = threadIdx.x; d < D; d += 256) qrow[d] = qb[d];
+  __syncthreads();
+  // logits: entry 0 = positive, entry 1+j = negative j (diagonal replaced by -10)
+  for (int j = threadIdx.x; j < P; j += 256) {
+    const float* kr = kb + (int64_t)j * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += qrow[d] * kr[d];
+    if (j == i) {
+      wgt[0] = s * invT;
+      wgt[1 + j] = -10.f * invT;
+    } else {
+      wgt[1 + j] = s * invT;
+    }
+  }
+  __syncthreads();
+  float mx = -3.4e38f;
+  for (int j = threadIdx.x; j <= P; j += 256) mx = fmaxf(mx, wgt[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float pos = wgt[0];
+  __syncthreads();
+  float se = 0.f;
+  for (int j = threadIdx.x; j <= P; j += 256) {
+    const float e = expf(wgt[j] - mx);
+    wgt[j] = e;
+    se += e;
+  }
+  se = block_sum(se, red);
+  if (threadIdx.x == 0 && loss) loss[(int64_t)b * P + i] = logf(se) + mx - pos;
+  if (!dq) return;
+  __syncthreads();
+  const float inv = 1.f / se;
+  // d loss / d q_i = invT * [ (p0 - 1) k_i + sum_{j != i} p_{1+j} k_j ]
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = (wgt[0] * inv - 1.f) * kb[(int64_t)i * D + d];
+    for (int j = 0; j < P; ++j)
+      if (j != i) s += wgt[1 + j] * inv * kb[(int64_t)j * D + d];
+    dq[((int64_t)b * P + i) * D + d] = s * invT * gscale;
+  }
+}
+
+inline unsigned blocks_for(int64_t n, int cap = 2048) {
+  int64_t b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int vts_avgpool3s2(const float* x, int64_t xns, int N, int C, int H, int W, float* y, void* stream) {
+  VTS_CHECK_ARG(x && y && N * C <= 65535, "vts_avgpool3s2: bad args");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(OW, 64), cdiv(OH, 4), N * C), dim3(256), 0, (hipStream_t)stream, x, xns, C, H, W, OH,
+                     OW, y);
+  VTS_CHECK_LAUNCH("vts_avgpool3s2");
+  return VTS_OK;
+}
+
+extern "C" int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, float* dx, int64_t dxns, int accumulate, void* stream) {
+  VTS_CHECK_ARG(dy && dx && N * C <= 65535, "vts_avgpool3s2_bwd: bad args");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(cdiv(W, 64), cdiv(H, 4), N * C), dim3(256), 0, (hipStream_t)stream, dy, C, H, W, OH, OW,
+                     dx, dxns, accumulate);
+  VTS_CHECK_LAUNCH("vts_avgpool3s2_bwd");
+  return VTS_OK;
+}
+
+extern "C" int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
+                           float* loss_out, float* dpred, void* stream) {
+  VTS_CHECK_ARG(pred && N >= 1 && M >= 1 && mode >= 0 && mode <= 4, "vts_ganloss: bad args");
+  const int64_t total = (int64_t)N * M;
+  hipLaunchKernelGGL(ganloss_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, total, mode, target_is_real,
+                     target_label, 1.f / (float)total, coeff, loss_out, dpred);
+  VTS_CHECK_LAUNCH("vts_ganloss");
+  return VTS_OK;
+}
+
+extern "C" int vts_l1(const float* a, const float* b, int64_t n, float coeff, float* loss_out, float* grad, int accumulate,
+                      void* stream) {
+  VTS_CHECK_ARG(a && b && n >= 1, "vts_l1: bad args");
+  hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, coeff, loss_out, grad, accumulate);
+  VTS_CHECK_LAUNCH("vts_l1");
+  return VTS_OK;
+}
+
+extern "C" int vts_patch_gather(const float* src, int64_t sns, int C, int H, int W, const int* img, const int* offx, const int* offy,
+                                int P, int size, float* out, int out_C, int out_c0, void* stream) {
+  VTS_CHECK_ARG(src && img && offx && offy && out && P >= 1 && C >= 1, "vts_patch_gather: bad args");
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(P, C), dim3(256), 0, (hipStream_t)stream, src, sns, C, H, W, img, offx, offy, size, out,
+                     out_C, out_c0);
+  VTS_CHECK_LAUNCH("vts_patch_gather");
+  return VTS_OK;
+}
+
+extern "C" int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, int C, const int* img, const int* offx, const int* offy,
+                                     int P, int P_per_img, int size, float* dsrc, int64_t dns, int N, int H, int W, int accumulate,
+                                     void* stream) {
+  (void)img;  // patches of image n are [n*P_per_img, (n+1)*P_per_img): the layout the gather produces
+  VTS_CHECK_ARG(dpatch && offx && offy && dsrc && P == N * P_per_img, "vts_patch_scatter_bwd: P must equal N*P_per_img");
+  hipLaunchKernelGGL(patch_scatter_kernel, dim3(cdiv(W, 32), cdiv(H, 32), N), dim3(256), P_per_img * sizeof(int), (hipStream_t)stream,
+                     dpatch, dp_C, dp_c0, C, offx, offy, P_per_img, size, dsrc, dns, H, W, accumulate);
+  VTS_CHECK_LAUNCH("vts_patch_scatter_bwd");
+  return VTS_OK;
+}
+
+extern "C" int vts_g_post(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
+                          float* fake_I, float* fake_T, float* fake_N, float* aug_fake_I, void* stream) {
+  VTS_CHECK_ARG(g_out && M && (!aug_fake_I || (rb && rs)), "vts_g_post: bad args");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(g_post_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, g_out, M, HW, scale_nz, rb, rs,
+                     fake_I, fake_T, fake_N, aug_fake_I);
+  VTS_CHECK_LAUNCH("vts_g_post");
+  return VTS_OK;
+}
+
+extern "C" int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, const float* rb, const float* rs, float* aug,
+                                   void* stream) {
+  VTS_CHECK_ARG(x && rb && rs && aug, "vts_diffaug_bs_mask: bad args");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(diffaug_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, x, M, HW, rb, rs, aug);
+  VTS_CHECK_LAUNCH("vts_diffaug_bs_mask");
+  return VTS_OK;
+}
+
+extern "C" int vts_g_out_grad(const float* d_fake_I, const float* d_fake_T, const float* M, const float* g_out, int N, int H, int W,
+                              float* d_raw, void* stream) {
+  VTS_CHECK_ARG(M && g_out && d_raw, "vts_g_out_grad: bad args");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(g_out_grad_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, d_fake_I, d_fake_T, M,
+                     g_out, HW, d_raw);
+  VTS_CHECK_LAUNCH("vts_g_out_grad");
+  return VTS_OK;
+}
+
+extern "C" int vts_mask_mul(const float* x, const float* M, int N, int C, int HW, float* y, void* stream) {
+  VTS_CHECK_ARG(x && M && y, "vts_mask_mul: bad args");
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(cdiv(HW, 256), C, N), dim3(256), 0, (hipStream_t)stream, x, M, C, (int64_t)HW, y);
+  VTS_CHECK_LAUNCH("vts_mask_mul");
+  return VTS_OK;
+}
+
+extern "C" int vts_spe_grid(float* out, int64_t ons, int N, int H, int W, int dim, void* stream) {
+  VTS_CHECK_ARG(out && dim >= 4 && dim % 2 == 0, "vts_spe_grid: dim must be even and >= 4");
+  hipLaunchKernelGGL(spe_kernel, dim3(cdiv(W, 256), H, N), dim3(256), 0, (hipStream_t)stream, out, ons, H, W, dim);
+  VTS_CHECK_LAUNCH("vts_spe_grid");
+  return VTS_OK;
+}
+
+extern "C" int vts_mask_candidates(const float* M, int N, int H, int W, uint8_t* cand, int* row_count, void* stream) {
+  VTS_CHECK_ARG(M && cand && row_count && H > 14 && W > 14, "vts_mask_candidates: image must exceed 14 px");
+  const int Hc = H - 14, Wc = W - 14;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mask_cand_kernel, dim3(cdiv(Wc, 32), cdiv(Hc, 32), N), dim3(256), 0, st, M, H, W, Hc, Wc, cand);
+  VTS_CHECK_LAUNCH("vts_mask_candidates");
+  hipLaunchKernelGGL(mask_rowcount_kernel, dim3(Hc, N), dim3(64), 0, st, cand, Hc, Wc, row_count);
+  hipLaunchKernelGGL(mask_prefix_kernel, dim3(N), dim3(64), 0, st, row_count, Hc);
+  VTS_CHECK_LAUNCH("vts_mask_candidates prefix");
+  return VTS_OK;
+}
+
+extern "C" int vts_mask_select(const uint8_t* cand, const int* row_prefix, int N, int H, int W, const int64_t* ranks, int K, int* offx,
+                               int* offy, void* stream) {
+  VTS_CHECK_ARG(cand && row_prefix && ranks && offx && offy && K >= 1, "vts_mask_select: bad args");
+  hipLaunchKernelGGL(mask_select_kernel, dim3(K, N), dim3(64), 0, (hipStream_t)stream, cand, row_prefix, H - 14, W - 14, ranks, K, offx,
+                     offy);
+  VTS_CHECK_LAUNCH("vts_mask_select");
+  return VTS_OK;
+}
+
+extern "C" int vts_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             int step_count, float grad_scale, void* stream) {
+  VTS_CHECK_ARG(p && g && m && v && n >= 1 && step_count >= 1, "vts_adam_flat: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, step_count), bc2 = 1.0 - pow((double)beta2, step_count);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1,
+                     beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+  VTS_CHECK_LAUNCH("vts_adam_flat");
+  return VTS_OK;
+}
+
+extern "C" int vts_l2norm_rows(const float* x, int rows, int D, float* y, void* stream) {
+  VTS_CHECK_ARG(x && y && rows >= 1 && D >= 1, "vts_l2norm_rows: bad args");
+  hipLaunchKernelGGL(l2norm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, D, y);
+  VTS_CHECK_LAUNCH("vts_l2norm_rows");
+  return VTS_OK;
+}
+
+extern "C" int vts_patchnce(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq,
+                            void* stream) {
+  VTS_CHECK_ARG(q && k && B >= 1 && P >= 1 && D >= 1 && T > 0.f, "vts_patchnce: bad args");
+  const size_t sm = (size_t)(D + P + 1) * sizeof(float);
+  VTS_CHECK_ARG(sm <= 64 * 1024, "vts_patchnce: D + P too large for one LDS tile");
+  hipLaunchKernelGGL(patchnce_kernel, dim3(P, B), dim3(256), sm, (hipStream_t)stream, q, k, P, D, 1.f / T, gscale, loss, dq);
+  VTS_CHECK_LAUNCH("vts_patchnce");
+  return VTS_OK;
+}

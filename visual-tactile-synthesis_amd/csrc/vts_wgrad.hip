@@ -1,0 +1,224 @@
+// Weight gradient of the 4x4 convolution family on the fp32 MFMA path (gfx950).
+//
+//   dw[cl][ch][ky][kx] = sum_{n,y,x} lo[n,cl,y,x] * hi[n,ch, y*S+ky-pad, x*S+kx-pad]
+//
+// GEMM view per v_mfma_f32_16x16x4_f32: M = 16 channels of the low-resolution operand,
+// N = the 16 taps of ONE high-resolution channel, K = 4 consecutive pixels of a row.
+// The reduction dimension (all pixels of the batch) is split over `PW` persistent
+// workgroups that each walk a strided list of 4x32-pixel tiles and keep CLT x CHT 16x16
+// accumulators per wave in registers; waves of a workgroup own one tile row each and are
+// combined through LDS in a fixed order; the PW partials are summed by a second kernel in
+// a fixed order, so the result is deterministic (no float atomics).
+// Both operands are (dual-source, normalise-on-load) like in vts_conv.hip.
+#include "vts_internal.h"
+
+namespace {
+
+struct Src {
+  const float *d0, *d1, *sc0, *sh0, *sc1, *sh1;
+  int64_t ns0, ns1;
+  int C0, C1, C;
+  int act;
+};
+
+struct WgK {
+  Src lo, hi;
+  int N, LH, LW, HH, HW, pad;
+  int cl_groups, ch_groups;
+  int tiles_y, tiles_x, ntiles;
+  float* part;  // [PW][CL][CH][16]
+};
+
+__device__ __forceinline__ float src_val(const Src& s, int n, int c, int y, int x, int H, int W) {
+  if (c >= s.C || y < 0 || y >= H || x < 0 || x >= W) return 0.f;
+  const int64_t plane = (int64_t)H * W;
+  float v, sc = 1.f, sh = 0.f;
+  if (c < s.C0) {
+    v = s.d0[n * s.ns0 + c * plane + (int64_t)y * W + x];
+    if (s.sc0) sc = s.sc0[n * s.C0 + c];
+    if (s.sh0) sh = s.sh0[n * s.C0 + c];
+  } else {
+    const int c1 = c - s.C0;
+    v = s.d1[n * s.ns1 + c1 * plane + (int64_t)y * W + x];
+    if (s.sc1) sc = s.sc1[n * s.C1 + c1];
+    if (s.sh1) sh = s.sh1[n * s.C1 + c1];
+  }
+  return vts_act(v * sc + sh, s.act);
+}
+
+constexpr int TYL = 4, TXL = 32, TXLP = 34;  // TXLP = 2 (mod 32): A reads hit banks 2*cl + k
+
+template <int S, int CLT, int CHT>
+__global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
+  constexpr int CLP = CLT * 16;
+  constexpr int PRH = (TYL - 1) * S + 4;
+  constexpr int PCH = (TXL - 1) * S + 4;
+  constexpr int PCHP = (S == 2) ? 72 : 40;  // = 8 (mod 32): B reads hit banks 8*ky + kx + S*k
+  static_assert(PCHP >= PCH, "pitch");
+  constexpr int LO_FLOATS = TYL * CLP * TXLP;
+  constexpr int HI_FLOATS = CHT * PRH * PCHP;
+  constexpr int RED_FLOATS = CLT * CHT * 256;
+  constexpr int LDS_FLOATS = (LO_FLOATS + HI_FLOATS) > RED_FLOATS ? (LO_FLOATS + HI_FLOATS) : RED_FLOATS;
+  __shared__ float lds[LDS_FLOATS];
+  float* lo = lds;
+  float* hi = lds + LO_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m16 = lane & 15, kq = lane >> 4;
+  const int clg = blockIdx.y / p.ch_groups, chg = blockIdx.y - clg * p.ch_groups;
+  const int cl0 = clg * CLP, ch0 = chg * CHT;
+
+  f32x4 acc[CLT][CHT];
+#pragma unroll
+  for (int t = 0; t < CLT; ++t)
+#pragma unroll
+    for (int h = 0; h < CHT; ++h) acc[t][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int n = tile / (p.tiles_y * p.tiles_x);
+    const int rem = tile - n * (p.tiles_y * p.tiles_x);
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int y0 = ty * TYL, x0 = tx * TXL;
+    // low-res tile: lo[row][cl][x]
+    for (int idx = tid; idx < TYL * CLP * TXL; idx += 256) {
+      const int x = idx % TXL, rc = idx / TXL;
+      const int cl = rc % CLP, row = rc / CLP;
+      lo[(row * CLP + cl) * TXLP + x] = src_val(p.lo, n, cl0 + cl, y0 + row, x0 + x, p.LH, p.LW);
+    }
+    // high-res patch: hi[ch][r][col]
+    const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.pad;
+    for (int idx = tid; idx < CHT * PRH * PCH; idx += 256) {
+      const int col = idx % PCH, rc = idx / PCH;
+      const int r = rc % PRH, h = rc / PRH;
+      const int ch = ch0 + h;
+      hi[(h * PRH + r) * PCHP + col] = (ch < p.hi.C) ? src_val(p.hi, n, ch, hy0 + r, hx0 + col, p.HH, p.HW) : 0.f;
+    }
+    __syncthreads();
+    const float* lrow = lo + (wave * CLP + m16) * TXLP + kq;
+    const float* hrow = hi + (wave * S + (m16 >> 2)) * PCHP + kq * S + (m16 & 3);
+#pragma unroll
+    for (int xs = 0; xs < TXL / 4; ++xs) {
+      float a[CLT], b[CHT];
+#pragma unroll
+      for (int t = 0; t < CLT; ++t) a[t] = lrow[t * 16 * TXLP + xs * 4];
+#pragma unroll
+      for (int h = 0; h < CHT; ++h) b[h] = hrow[h * PRH * PCHP + xs * 4 * S];
+#pragma unroll
+      for (int t = 0; t < CLT; ++t)
+#pragma unroll
+        for (int h = 0; h < CHT; ++h) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[h], acc[t][h], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // fixed-order cross-wave reduction through LDS: red[t][h][lane][4]
+  float* red = lds;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < CLT; ++t)
+#pragma unroll
+        for (int h = 0; h < CHT; ++h) {
+          f32x4* slot = reinterpret_cast<f32x4*>(red + ((t * CHT + h) * 64 + lane) * 4);
+          if (w == 0)
+            *slot = acc[t][h];
+          else
+            *slot = *slot + acc[t][h];
+        }
+    }
+    __syncthreads();
+  }
+  // D layout: row (cl) = (lane>>4)*4 + reg, col (tap) = lane&15
+  const int CL = p.lo.C, CH = p.hi.C;
+  float* part = p.part + (int64_t)blockIdx.x * CL * CH * 16;
+  for (int idx = tid; idx < CLT * CHT * 256; idx += 256) {
+    const int e = idx & 255, th = idx >> 8;
+    const int t = th / CHT, h = th - t * CHT;
+    const int tap = e & 15, clr = e >> 4;  // clr in 0..15 -> lane>>4 = clr>>2, reg = clr&3
+    const int ln = ((clr >> 2) << 4) | tap;
+    const float v = red[((t * CHT + h) * 64 + ln) * 4 + (clr & 3)];
+    const int cl = cl0 + t * 16 + clr, ch = ch0 + h;
+    if (cl < CL && ch < CH) part[((int64_t)cl * CH + ch) * 16 + tap] = v;
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int pw, float* __restrict__ dw, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < pw; ++k) s += part[(int64_t)k * n + i];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+struct Plan {
+  int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles;
+};
+
+Plan make_plan(const vts_wgrad_desc* d) {
+  Plan pl;
+  const int CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
+  pl.clt = CL <= 16 ? 1 : CL <= 32 ? 2 : CL <= 48 ? 3 : 5;
+  pl.cht = (CH <= 4 || CH > 10 || pl.clt == 5) ? 4 : 10;
+  pl.cl_groups = cdiv(CL, pl.clt * 16);
+  pl.ch_groups = cdiv(CH, pl.cht);
+  pl.tiles_y = cdiv(d->LH, TYL);
+  pl.tiles_x = cdiv(d->LW, TXL);
+  pl.ntiles = d->N * pl.tiles_y * pl.tiles_x;
+  const int groups = pl.cl_groups * pl.ch_groups;
+  int pw = 1024 / groups;
+  if (pw < 1) pw = 1;
+  if (pw > pl.ntiles) pw = pl.ntiles;
+  pl.pw = pw;
+  return pl;
+}
+
+void fill_src(Src& s, const vts_operand& a, const vts_operand& b, int act) {
+  s.d0 = a.data; s.sc0 = a.scale; s.sh0 = a.shift; s.ns0 = a.nstride; s.C0 = a.C;
+  s.d1 = b.data; s.sc1 = b.scale; s.sh1 = b.shift; s.ns1 = b.nstride; s.C1 = b.data ? b.C : 0;
+  s.C = s.C0 + s.C1;
+  s.act = act;
+}
+
+template <int S, int CLT, int CHT>
+void launch_wg(const WgK& k, const Plan& pl, hipStream_t st) {
+  dim3 grid(pl.pw, pl.cl_groups * pl.ch_groups);
+  hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT>), grid, dim3(256), 0, st, k);
+}
+
+}  // namespace
+
+extern "C" int64_t vts_wgrad4x4_ws_floats(const vts_wgrad_desc* d) {
+  if (!d) return 0;
+  const Plan pl = make_plan(d);
+  const int64_t CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
+  return (int64_t)pl.pw * CL * CH * 16;
+}
+
+extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
+  VTS_CHECK_ARG(d && d->lo0.data && d->hi0.data && d->dw && ws, "vts_wgrad4x4: null pointer");
+  VTS_CHECK_ARG(d->stride == 1 || d->stride == 2, "vts_wgrad4x4: stride %d unsupported", d->stride);
+  VTS_CHECK_ARG(d->LH == (d->HH + 2 * d->pad - 4) / d->stride + 1 && d->LW == (d->HW + 2 * d->pad - 4) / d->stride + 1,
+                "vts_wgrad4x4: lo %dx%d inconsistent with hi %dx%d s%d p%d", d->LH, d->LW, d->HH, d->HW, d->stride, d->pad);
+  const Plan pl = make_plan(d);
+  WgK k;
+  fill_src(k.lo, d->lo0, d->lo1, d->act_lo);
+  fill_src(k.hi, d->hi0, d->hi1, d->act_hi);
+  k.N = d->N; k.LH = d->LH; k.LW = d->LW; k.HH = d->HH; k.HW = d->HW; k.pad = d->pad;
+  k.cl_groups = pl.cl_groups; k.ch_groups = pl.ch_groups;
+  k.tiles_y = pl.tiles_y; k.tiles_x = pl.tiles_x; k.ntiles = pl.ntiles;
+  k.part = ws;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nel = (int64_t)k.lo.C * k.hi.C * 16;
+  // groups that end beyond CL/CH never write their out-of-range rows, and every in-range element is
+  // written by exactly one (cl-group, ch-group) workgroup of every pixel worker.
+#define WG_CASE(S, CLT, CHT) \
+  if (d->stride == S && pl.clt == CLT && pl.cht == CHT) launch_wg<S, CLT, CHT>(k, pl, st);
+  WG_CASE(2, 1, 4) WG_CASE(2, 1, 10) WG_CASE(2, 2, 4) WG_CASE(2, 2, 10) WG_CASE(2, 3, 4) WG_CASE(2, 3, 10) WG_CASE(2, 5, 4)
+  WG_CASE(1, 1, 4) WG_CASE(1, 1, 10) WG_CASE(1, 2, 4) WG_CASE(1, 2, 10) WG_CASE(1, 3, 4) WG_CASE(1, 3, 10) WG_CASE(1, 5, 4)
+#undef WG_CASE
+  VTS_CHECK_LAUNCH("vts_wgrad4x4");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, st, ws, nel, pl.pw, d->dw,
+                     d->accumulate);
+  VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
+  return VTS_OK;
+}

@@ -1,0 +1,149 @@
+"""ctypes binding of libvts_hip.so (include/vts.h) -- the only way the product path computes.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, this
+module raises.  Tensors are passed as raw device pointers (`tensor.data_ptr()`), shapes as
+ints, and every launch goes to torch's current HIP stream, so torch provides memory and
+stream plumbing only.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvts_hip.so")
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+GAN_MODES = {"nonsaturating": 0, "lsgan": 1, "vanilla": 2, "wgan": 3, "wgangp": 3, "hinge": 4}
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class Operand(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("C", C.c_int), ("nstride", C.c_int64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in0", Operand), ("in1", Operand),
+        ("N", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("transposed", C.c_int),
+        ("w", C.c_void_p), ("ws_co", C.c_int), ("ws_ci", C.c_int),
+        ("bias", C.c_void_p), ("out", C.c_void_p), ("out_nstride", C.c_int64),
+        ("act_in", C.c_int), ("act_out", C.c_int),
+        ("dmask", Operand), ("dmask_act", C.c_int), ("accumulate", C.c_int),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("lo0", Operand), ("lo1", Operand), ("hi0", Operand), ("hi1", Operand),
+        ("act_lo", C.c_int), ("act_hi", C.c_int),
+        ("N", C.c_int), ("LH", C.c_int), ("LW", C.c_int), ("HH", C.c_int), ("HW", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("dw", C.c_void_p), ("accumulate", C.c_int),
+    ]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("nstride", C.c_int64), ("N", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("mode", C.c_int),
+        ("eps", C.c_float), ("momentum", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean_out", C.c_void_p), ("rstd_out", C.c_void_p),
+    ]
+
+
+class NormBwdDesc(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("x", C.c_void_p), ("nstride", C.c_int64), ("N", C.c_int), ("C", C.c_int), ("HW", C.c_int),
+        ("mode", C.c_int), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p),
+        ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate_param_grads", C.c_int),
+    ]
+
+
+_lib = None
+
+# every symbol include/vts.h declares (tests/test_abi.py checks the export list against the header)
+SYMBOLS = [
+    "vts_last_error", "vts_version", "vts_conv4x4", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_channel_sum",
+    "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
+    "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
+    "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
+    "vts_mask_select", "vts_adam_flat", "vts_patchnce", "vts_l2norm_rows",
+]
+
+
+def load():
+    """Load libvts_hip.so (once).  Raises if it is not built: the product has no CPU/eager path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvts_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C visual-tactile-synthesis_amd/csrc`.  There is no fallback path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.vts_last_error.restype = C.c_char_p
+    for name in ("vts_wgrad4x4_ws_floats", "vts_norm_ws_floats", "vts_channel_sum_ws_floats"):
+        getattr(lib, name).restype = C.c_int64
+    lib.vts_norm_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.vts_channel_sum_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    vp, i, i64, f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    sig = {
+        "vts_conv4x4": [C.POINTER(ConvDesc), vp],
+        "vts_wgrad4x4_ws_floats": [C.POINTER(WgradDesc)],
+        "vts_wgrad4x4": [C.POINTER(WgradDesc), vp, vp],
+        "vts_channel_sum": [vp, i64, i, i, i, vp, i, vp, vp],
+        "vts_norm_stats": [C.POINTER(NormDesc), vp, vp],
+        "vts_norm_bwd": [C.POINTER(NormBwdDesc), vp, vp],
+        "vts_act_bwd": [vp, C.POINTER(Operand), i, i, i, vp, i, vp],
+        "vts_avgpool3s2": [vp, i64, i, i, i, i, vp, vp],
+        "vts_avgpool3s2_bwd": [vp, i, i, i, i, vp, i64, i, vp],
+        "vts_ganloss": [vp, i, i, i, i, f, f, vp, vp, vp],
+        "vts_l1": [vp, vp, i64, f, vp, vp, i, vp],
+        "vts_patch_gather": [vp, i64, i, i, i, vp, vp, vp, i, i, vp, i, i, vp],
+        "vts_patch_scatter_bwd": [vp, i, i, i, vp, vp, vp, i, i, i, vp, i64, i, i, i, i, vp],
+        "vts_g_post": [vp, vp, i, i, i, f, vp, vp, vp, vp, vp, vp, vp],
+        "vts_diffaug_bs_mask": [vp, vp, i, i, i, vp, vp, vp, vp],
+        "vts_g_out_grad": [vp, vp, vp, vp, i, i, i, vp, vp],
+        "vts_mask_mul": [vp, vp, i, i, i, vp, vp],
+        "vts_spe_grid": [vp, i64, i, i, i, i, vp],
+        "vts_mask_candidates": [vp, i, i, i, vp, vp, vp],
+        "vts_mask_select": [vp, vp, i, i, i, vp, i, vp, vp, vp],
+        "vts_adam_flat": [vp, vp, vp, vp, i64, f, f, f, f, i, f, vp],
+        "vts_patchnce": [vp, vp, i, i, i, f, f, vp, vp, vp],
+        "vts_l2norm_rows": [vp, i, i, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        if name not in ("vts_wgrad4x4_ws_floats",):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().vts_last_error().decode()))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def operand(t, scale=None, shift=None, C_=None, nstride=None):
+    """Operand view of a contiguous NCHW tensor (or a channel slice given C_/nstride)."""
+    if t is None:
+        return Operand(None, None, None, 0, 0)
+    assert t.dtype == torch.float32 and t.is_cuda
+    c = t.shape[1] if C_ is None else C_
+    ns = t.stride(0) if nstride is None else nstride
+    return Operand(t.data_ptr(), ptr(scale), ptr(shift), c, ns)

@@ -1,0 +1,273 @@
+"""Thin functional wrappers over the C ABI (one Python function per vts_* entry point).
+
+`Act` is the lazily-normalised activation the kernels consume: raw data plus the
+per-(n,c) scale/shift produced by vts_norm_stats (see include/vts.h, vts_operand).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+class Act:
+    """Raw NCHW tensor + optional per-(n,c) affine (normalise-on-load) + saved mean/rstd."""
+
+    __slots__ = ("data", "scale", "shift", "mean", "rstd")
+
+    def __init__(self, data, scale=None, shift=None, mean=None, rstd=None):
+        self.data, self.scale, self.shift, self.mean, self.rstd = data, scale, shift, mean, rstd
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def operand(self):
+        return L.operand(self.data, self.scale, self.shift)
+
+
+_ws = {}
+
+
+def workspace(nfloats, device):
+    """Grow-only scratch; safe to share because every kernel runs in stream order."""
+    key = str(device)
+    t = _ws.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t
+
+
+def _op(a):
+    if a is None:
+        return L.Operand(None, None, None, 0, 0)
+    if isinstance(a, Act):
+        return a.operand()
+    if isinstance(a, L.Operand):
+        return a
+    return L.operand(a)
+
+
+def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, pad=1, transposed=False, act_in=0,
+            act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None):
+    """out <- conv-family(in0 ++ in1).  `w` may be an offset view into a weight tensor."""
+    lib = L.load()
+    d = L.ConvDesc()
+    d.in0, d.in1 = _op(in0), _op(in1)
+    x = in0.data if isinstance(in0, Act) else in0
+    d.N = x.shape[0]
+    d.IH, d.IW = in_hw if in_hw else (x.shape[2], x.shape[3])
+    d.OH, d.OW = out.shape[2], out.shape[3]
+    d.Cout = cout
+    d.stride, d.pad, d.transposed = stride, pad, int(transposed)
+    d.w, d.ws_co, d.ws_ci = w.data_ptr(), ws_co, ws_ci
+    d.bias = L.ptr(bias)
+    d.out = out.data_ptr()
+    d.out_nstride = out.stride(0) if out_nstride is None else out_nstride
+    d.act_in, d.act_out = act_in, act_out
+    d.dmask = _op(dmask)
+    d.dmask_act = dmask_act
+    d.accumulate = int(accumulate)
+    L.check(lib.vts_conv4x4(C.byref(d), L.stream()), "vts_conv4x4")
+    return out
+
+
+def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, pad=1, accumulate=False):
+    lib = L.load()
+    d = L.WgradDesc()
+    d.lo0, d.lo1, d.hi0, d.hi1 = _op(lo0), _op(lo1), _op(hi0), _op(hi1)
+    d.act_lo, d.act_hi = act_lo, act_hi
+    lo = lo0.data if isinstance(lo0, Act) else lo0
+    hi = hi0.data if isinstance(hi0, Act) else hi0
+    d.N, d.LH, d.LW, d.HH, d.HW = lo.shape[0], lo.shape[2], lo.shape[3], hi.shape[2], hi.shape[3]
+    d.stride, d.pad = stride, pad
+    d.dw = dw.data_ptr()
+    d.accumulate = int(accumulate)
+    n = lib.vts_wgrad4x4_ws_floats(C.byref(d))
+    ws = workspace(n, lo.device)
+    L.check(lib.vts_wgrad4x4(C.byref(d), ws.data_ptr(), L.stream()), "vts_wgrad4x4")
+    return dw
+
+
+def channel_sum(x, out, accumulate=False):
+    lib = L.load()
+    n, c, h, w = x.shape
+    ws = workspace(lib.vts_channel_sum_ws_floats(n, c, h * w), x.device)
+    L.check(lib.vts_channel_sum(x.data_ptr(), x.stride(0), n, c, h * w, out.data_ptr(), int(accumulate), ws.data_ptr(),
+                                L.stream()), "vts_channel_sum")
+    return out
+
+
+def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var=None, nbt=None, eps=1e-5,
+               momentum=0.1):
+    """Returns Act(x, scale, shift, mean, rstd) -- x itself is not rewritten."""
+    lib = L.load()
+    n, c, h, w = x.shape
+    st = torch.empty(4, n * c, dtype=torch.float32, device=x.device)
+    d = L.NormDesc()
+    d.x, d.nstride, d.N, d.C, d.HW, d.mode = x.data_ptr(), x.stride(0), n, c, h * w, mode
+    d.eps, d.momentum = eps, momentum
+    d.gamma, d.beta = L.ptr(gamma), L.ptr(beta)
+    d.running_mean, d.running_var, d.num_batches_tracked = L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt)
+    d.scale, d.shift, d.mean_out, d.rstd_out = st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr()
+    ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), x.device)
+    L.check(lib.vts_norm_stats(C.byref(d), ws.data_ptr(), L.stream()), "vts_norm_stats")
+    return Act(x, st[0], st[1], st[2], st[3])
+
+
+def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=False):
+    """In place: dy (grad wrt normalised output) -> grad wrt the raw tensor act.data."""
+    lib = L.load()
+    n, c, h, w = dy.shape
+    d = L.NormBwdDesc()
+    d.dy, d.x, d.nstride, d.N, d.C, d.HW, d.mode = dy.data_ptr(), act.data.data_ptr(), act.data.stride(0), n, c, h * w, mode
+    d.mean, d.rstd = act.mean.data_ptr(), act.rstd.data_ptr()
+    d.gamma, d.dgamma, d.dbeta = L.ptr(gamma), L.ptr(dgamma), L.ptr(dbeta)
+    d.accumulate_param_grads = int(accumulate)
+    ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
+    L.check(lib.vts_norm_bwd(C.byref(d), ws.data_ptr(), L.stream()), "vts_norm_bwd")
+    return dy
+
+
+def act_bwd(g, act, kind, dy, accumulate=False):
+    lib = L.load()
+    n, c, h, w = g.shape
+    o = act.operand() if isinstance(act, Act) else L.operand(act)
+    L.check(lib.vts_act_bwd(g.data_ptr(), C.byref(o), n, h * w, kind, dy.data_ptr(), int(accumulate), L.stream()), "vts_act_bwd")
+    return dy
+
+
+def avgpool(x, y=None):
+    lib = L.load()
+    n, c, h, w = x.shape
+    if y is None:
+        y = torch.empty(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=x.device)
+    L.check(lib.vts_avgpool3s2(x.data_ptr(), x.stride(0), n, c, h, w, y.data_ptr(), L.stream()), "vts_avgpool3s2")
+    return y
+
+
+def avgpool_bwd(dy, dx, accumulate=False, channels=None, dx_nstride=None):
+    lib = L.load()
+    n, c = dy.shape[0], dy.shape[1]
+    h, w = dx.shape[2], dx.shape[3]
+    L.check(lib.vts_avgpool3s2_bwd(dy.data_ptr(), n, c, h, w, dx.data_ptr(), dx.stride(0) if dx_nstride is None else dx_nstride,
+                                   int(accumulate), L.stream()), "vts_avgpool3s2_bwd")
+    return dx
+
+
+def ganloss(pred, mode, target_is_real, coeff, loss_slot, dpred=None, label=None):
+    lib = L.load()
+    n = pred.shape[0]
+    m = pred.numel() // n
+    if label is None:
+        label = 1.0 if target_is_real else 0.0
+    L.check(lib.vts_ganloss(pred.data_ptr(), n, m, L.GAN_MODES[mode], int(target_is_real), label, coeff, L.ptr(loss_slot),
+                            L.ptr(dpred), L.stream()), "vts_ganloss")
+
+
+def l1(a, b, coeff, loss_slot, grad=None, accumulate=False):
+    lib = L.load()
+    L.check(lib.vts_l1(a.data_ptr(), b.data_ptr(), a.numel(), coeff, L.ptr(loss_slot), L.ptr(grad), int(accumulate), L.stream()),
+            "vts_l1")
+
+
+def patch_gather(src, img, offx, offy, size, out, c0=0, channels=None):
+    lib = L.load()
+    c = src.shape[1] if channels is None else channels
+    L.check(lib.vts_patch_gather(src.data_ptr(), src.stride(0), c, src.shape[2], src.shape[3], img.data_ptr(), offx.data_ptr(),
+                                 offy.data_ptr(), img.numel(), size, out.data_ptr(), out.shape[1], c0, L.stream()), "vts_patch_gather")
+    return out
+
+
+def patch_scatter_bwd(dpatch, c0, channels, offx, offy, ppi, size, dsrc, accumulate=False):
+    lib = L.load()
+    n, _, h, w = dsrc.shape
+    L.check(lib.vts_patch_scatter_bwd(dpatch.data_ptr(), dpatch.shape[1], c0, channels, None, offx.data_ptr(), offy.data_ptr(),
+                                      dpatch.shape[0], ppi, size, dsrc.data_ptr(), dsrc.stride(0), n, h, w, int(accumulate), L.stream()),
+            "vts_patch_scatter_bwd")
+    return dsrc
+
+
+def g_post(g_out, M, scale_nz, rb=None, rs=None, fake_I=None, fake_T=None, fake_N=None, aug_fake_I=None):
+    lib = L.load()
+    n, _, h, w = g_out.shape
+    L.check(lib.vts_g_post(g_out.data_ptr(), M.data_ptr(), n, h, w, scale_nz, L.ptr(rb), L.ptr(rs), L.ptr(fake_I), L.ptr(fake_T),
+                           L.ptr(fake_N), L.ptr(aug_fake_I), L.stream()), "vts_g_post")
+
+
+def diffaug_bs_mask(x, M, rb, rs, out):
+    lib = L.load()
+    n, _, h, w = x.shape
+    L.check(lib.vts_diffaug_bs_mask(x.data_ptr(), L.ptr(M), n, h, w, rb.data_ptr(), rs.data_ptr(), out.data_ptr(), L.stream()),
+            "vts_diffaug_bs_mask")
+    return out
+
+
+def g_out_grad(d_fake_I, d_fake_T, M, g_out, d_raw):
+    lib = L.load()
+    n, _, h, w = g_out.shape
+    L.check(lib.vts_g_out_grad(L.ptr(d_fake_I), L.ptr(d_fake_T), M.data_ptr(), g_out.data_ptr(), n, h, w, d_raw.data_ptr(), L.stream()),
+            "vts_g_out_grad")
+    return d_raw
+
+
+def mask_mul(x, M, out=None):
+    lib = L.load()
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.vts_mask_mul(x.data_ptr(), M.data_ptr(), n, c, h * w, out.data_ptr(), L.stream()), "vts_mask_mul")
+    return out
+
+
+def spe_grid(out, dim, c0=0):
+    """Fill out[:, c0:c0+2*dim] with the sinusoidal grid."""
+    lib = L.load()
+    n, _, h, w = out.shape
+    view = out[:, c0:]
+    L.check(lib.vts_spe_grid(view.data_ptr(), out.stride(0), n, h, w, dim, L.stream()), "vts_spe_grid")
+    return out
+
+
+def mask_candidates(M):
+    lib = L.load()
+    n, _, h, w = M.shape
+    cand = torch.empty(n, h - 14, w - 14, dtype=torch.uint8, device=M.device)
+    prefix = torch.zeros(n, h - 14 + 1, dtype=torch.int32, device=M.device)
+    L.check(lib.vts_mask_candidates(M.data_ptr(), n, h, w, cand.data_ptr(), prefix.data_ptr(), L.stream()), "vts_mask_candidates")
+    return cand, prefix
+
+
+def mask_select(cand, prefix, ranks, h, w):
+    lib = L.load()
+    n, k = ranks.shape
+    offx = torch.empty(n * k, dtype=torch.int32, device=cand.device)
+    offy = torch.empty(n * k, dtype=torch.int32, device=cand.device)
+    L.check(lib.vts_mask_select(cand.data_ptr(), prefix.data_ptr(), n, h, w, ranks.data_ptr(), k, offx.data_ptr(), offy.data_ptr(),
+                                L.stream()), "vts_mask_select")
+    return offx, offy
+
+
+def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    lib = L.load()
+    L.check(lib.vts_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
+                              L.stream()), "vts_adam_flat")
+
+
+def l2norm_rows(x, out=None):
+    lib = L.load()
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.vts_l2norm_rows(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), L.stream()), "vts_l2norm_rows")
+    return out
+
+
+def patchnce(q, k, groups, T, gscale=1.0, want_grad=True):
+    lib = L.load()
+    rows, d = q.shape
+    p = rows // groups
+    loss = torch.empty(rows, dtype=torch.float32, device=q.device)
+    dq = torch.empty_like(q) if want_grad else None
+    L.check(lib.vts_patchnce(q.data_ptr(), k.data_ptr(), groups, p, d, T, gscale, loss.data_ptr(), L.ptr(dq), L.stream()), "vts_patchnce")
+    return loss, dq
