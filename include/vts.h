@@ -167,9 +167,9 @@ int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, float* dx, i
 /* GANLoss on one scale (models/networks.py:497-521), forward value and gradient in one pass.
  *   mode: 0 nonsaturating, 1 lsgan, 2 vanilla(BCE logits), 3 wgan, 4 hinge
  *   loss_out[0] += coeff * mean_over_batch( per-sample loss )   (lsgan/vanilla/wgan: global mean)
- *   dpred (if non-NULL) = d(coeff * that) / dpred                */
+ *   dpred (if non-NULL) = grad_coeff * d(mean_over_batch(per-sample loss)) / dpred   */
 int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
-                float* loss_out, float* dpred, void* stream);
+                float grad_coeff, float* loss_out, float* dpred, void* stream);
 
 /* loss_out[0] += coeff * sum|a-b| ;  grad (+)= coeff * sign(a-b)   (nn.L1Loss pieces,
  * sinskitG_model.py:1702, 1812-1814; the caller folds 1/numel into coeff). */
@@ -189,9 +189,12 @@ int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, int C, const
 /* Generator output post-processing (sinskitG_model.py:1309-1340), one pass over g_out [N,5,H,W]:
  *   fake_I = g_out[:, :3]*M ; fake_T = g_out[:, 3:]*M ; fake_N = normalize(gx, gy, scale_nz)
  *   aug_fake_I = DiffAugment_bs(fake_I; rb, rs) * M            (thirdparty/DiffAugment.py:25-33)
- * Any output pointer may be NULL. */
+ * Any output pointer may be NULL.  fake_T / aug_fake_I take a batch stride (floats; 0 = contiguous) so they
+ * can be written straight into channel slices of the 7-channel D2 input stack. */
 int vts_g_post(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
-               float* fake_I, float* fake_T, float* fake_N, float* aug_fake_I, void* stream);
+               float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I,
+               int64_t aug_nstride, void* stream);
+
 /* aug = DiffAugment_bs(x; rb, rs) * M for a 3-channel image. */
 int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, const float* rb, const float* rs, float* aug,
                         void* stream);

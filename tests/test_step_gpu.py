@@ -1,0 +1,207 @@
+"""End-to-end parity of the HIP training step (through models.create_model, i.e. the drop-in
+boundary) against (a) the golden vectors produced by RUNNING THE REFERENCE on BASELINE
+config 0 (sinskitG, 256x256, batch 1) and (b) the CPU oracle at batch 2.
+
+Tolerance (north_star): outputs within 1e-3 rel-L2 of the reference.  Gradients are compared
+at 2e-3 on their l2 norm / fixed random projection.  Biases of convolutions that feed an
+Instance/BatchNorm have a mathematically-zero gradient (pure rounding noise in the reference
+as well), so they are excluded from gradient and parameter comparisons.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import default_collate
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, nets, step  # noqa: E402  (checker only)
+
+FLAGS = ("--model sinskitG --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
+         "--lambda_G2_GAN_feat 0 --checkpoints_dir /tmp/vts_test_ckpt --name t --crop_size %d --batch_size %d")
+
+
+def make_model(size, n):
+    from models import create_model
+    from options.train_options import TrainOptions
+
+    opt = TrainOptions(cmd_line=FLAGS % (size, n)).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    model.train()
+    return model, opt
+
+
+def load_test_weights(model, seed):
+    sds = (detrand.test_weights(nets.g_param_shapes(), seed), detrand.test_weights(nets.d_param_shapes(4), seed + 1),
+           detrand.test_weights(nets.d_param_shapes(7), seed + 2))
+    for net, sd in zip((model.netG, model.netD, model.netD2), sds):
+        assert list(net.state_dict().keys()) == list(sd.keys())
+        net.load_state_dict(sd)
+    return sds
+
+
+def null_grad_bias(net_name, key):
+    if not key.endswith("bias"):
+        return False
+    if net_name == "G":
+        return not any(key.startswith(p) for p in ("down0.", "down7.", "up0.", "up0_T."))
+    return key.split(".")[1] in ("2", "5", "8")
+
+
+def probe_close(t, ref, name, rtol):
+    p = detrand.probe(t.detach().cpu(), name)
+    scale = max(abs(ref[1]), 1e-12)
+    assert abs(p[1] - ref[1]) <= rtol * scale, (name, p, ref)
+    assert abs(p[2] - ref[2]) <= 4 * rtol * scale, (name, p, ref)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_step_matches_reference_golden(golden_dir):
+    from data.synthetic_dataset import make_sample
+
+    g = np.load(os.path.join(golden_dir, "sinskitG_step_256.npz"))
+    size, seed, steps, nt = int(g["size"]), int(g["seed"]), int(g["steps"]), int(g["nt"])
+    model, opt = make_model(size, 1)
+    load_test_weights(model, seed)
+    batch = default_collate([make_sample(size, nt, nt, seed)])
+    for it in range(1):
+        tag = "s%d" % it
+        tol = 1e-3
+        model._draws = {"aug": torch.from_numpy(g[tag + "/aug"]), "more_idx": torch.from_numpy(g[tag + "/more_idx"])}
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+        assert model.fake_sample_offset_x.cpu().tolist() == g[tag + "/more_ox"].astype(int).tolist()
+        assert model.fake_sample_offset_y.cpu().tolist() == g[tag + "/more_oy"].astype(int).tolist()
+        losses = model.get_current_losses()
+        ref = dict(zip([str(s) for s in g[tag + "/loss_names"]], g[tag + "/loss_values"]))
+        for k, v in losses.items():
+            assert abs(v - ref[k]) <= tol * max(1.0, abs(ref[k])), (k, v, ref[k])
+        assert rel(model.fake_I[:, :, ::4, ::4], torch.from_numpy(g[tag + "/fake_I_sub"])) < tol
+        assert rel(model.fake_T[:, :, ::4, ::4], torch.from_numpy(g[tag + "/fake_T_sub"])) < tol
+        for nm in ("fake_N", "aug_fake_I", "aug_real_I", "pred_fake_T_full", "pred_fake_I"):
+            key = {"pred_fake_T_full": "pftf", "pred_fake_I": "pfi"}.get(nm, nm)
+            probe_close(getattr(model, nm).contiguous(), g["%s/%s_probe" % (tag, nm)], key, 2 * tol)
+        for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+            for k, p in net.named_parameters():
+                if null_grad_bias(nm, k):
+                    continue
+                probe_close(p.grad, g["%s/grad_%s/%s" % (tag, nm, k)], k, 2 * tol)
+                probe_close(p.data, g["%s/param_%s/%s" % (tag, nm, k)], k, tol)
+            for k, b in net.named_buffers():
+                refb = torch.from_numpy(g["%s/buf_%s/%s" % (tag, nm, k)])
+                if k.endswith("running_mean"):
+                    # a near-zero mean of O(1) activations: compare on the activation scale sqrt(running_var)
+                    scale = float(np.sqrt(g["%s/buf_%s/%s" % (tag, nm, k.replace("running_mean", "running_var"))].max()))
+                    assert (b.double().cpu() - refb).abs().max().item() < tol * scale, k
+                elif b.dtype.is_floating_point:
+                    assert rel(b, refb) < tol, k
+                else:
+                    assert int(b) == int(refb), k
+
+
+def test_second_step_from_synced_state(golden_dir):
+    """Step 2 (Adam bias correction at step_count=2, BN running stats continuing) from a state
+    synchronised with the oracle after step 1.  With beta1=0 the first Adam update is
+    ~lr*sign(g), so weights whose gradient is rounding noise may differ by 2*lr between any two
+    correct implementations; synchronising isolates the per-step arithmetic.  The oracle's own
+    step 2 is pinned to the reference by tests/test_oracle_golden.py."""
+    from data.synthetic_dataset import make_sample
+
+    g = np.load(os.path.join(golden_dir, "sinskitG_step_256.npz"))
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    model, opt = make_model(size, 1)
+    sds = load_test_weights(model, seed)
+    batch = default_collate([make_sample(size, nt, nt, seed)])
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    d0 = {"aug": torch.from_numpy(g["s0/aug"]), "more_idx": torch.from_numpy(g["s0/more_idx"])}
+    step.train_step(sds[0], sds[1], sds[2], adam, batch, d0, record=False)
+    model._draws = d0
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)          # advances step counters / BN counters on the HIP side
+    for nm, net, sd, optim in (("G", model.netG, sds[0], model.optimizer_G), ("D", model.netD, sds[1], model.optimizer_D),
+                               ("D2", model.netD2, sds[2], model.optimizer_D2)):
+        net.load_state_dict({k: v.detach() for k, v in sd.items()})
+        optim.load_named_state(net, adam[nm]["m"], adam[nm]["v"], adam[nm]["step"])
+    d1 = {"aug": torch.from_numpy(g["s1/aug"]), "more_idx": torch.from_numpy(g["s1/more_idx"])}
+    ref = step.train_step(sds[0], sds[1], sds[2], adam, batch, d1)
+    model._draws = d1
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    for k, v in ref["losses"].items():
+        assert abs(losses["l_" + k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses["l_" + k], v)
+    assert rel(model.fake_I, ref["fake_I"]) < 1e-3 and rel(model.fake_T, ref["fake_T"]) < 1e-3
+    for nm, net, sd in (("G", model.netG, sds[0]), ("D", model.netD, sds[1]), ("D2", model.netD2, sds[2])):
+        for k, p in net.named_parameters():
+            if null_grad_bias(nm, k):
+                continue
+            assert rel(p.grad, ref["grad_" + nm][k]) < 2e-3, (nm, k)
+            assert rel(p.data, sd[k]) < 1e-3, (nm, k)
+
+
+def test_step_batch2_matches_oracle():
+    from data.synthetic_dataset import make_sample
+
+    size, nt, seed, n = 256, 64, 77, 2
+    model, opt = make_model(size, n)
+    sdG, sdD, sdD2 = load_test_weights(model, seed)
+    batch = default_collate([make_sample(size, nt, nt, seed + i) for i in range(n)])
+    import random
+    random.seed(5)
+    counts = [int(nets.dilated_mask_positions(batch["M"][i:i + 1].float()).shape[0]) for i in range(n)]
+    draws = {"aug": detrand.uniform((4, n), 3, "aug") * 0.5 + 0.5,
+             "more_idx": torch.tensor([random.sample(range(c), 32) for c in counts])}
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    ref = step.train_step(sdG, sdD, sdD2, adam, batch, draws)
+    model._draws = draws
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    for k, v in ref["losses"].items():
+        assert abs(losses["l_" + k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses["l_" + k], v)
+    assert rel(model.fake_I, ref["fake_I"]) < 1e-3 and rel(model.fake_T, ref["fake_T"]) < 1e-3
+    for nm, net, sd in (("G", model.netG, sdG), ("D", model.netD, sdD), ("D2", model.netD2, sdD2)):
+        for k, p in net.named_parameters():
+            if null_grad_bias(nm, k):
+                continue
+            assert rel(p.grad, ref["grad_" + nm][k]) < 2e-3, (nm, k)
+            assert rel(p.data, sd[k]) < 1e-3, (nm, k)
+        for k, b in net.named_buffers():
+            if k.endswith("running_mean"):
+                scale = float(sd[k.replace("running_mean", "running_var")].max().sqrt())
+                assert (b.cpu() - sd[k]).abs().max().item() < 1e-3 * scale, (nm, k)
+            elif b.dtype.is_floating_point:
+                assert rel(b, sd[k]) < 1e-3, (nm, k)
+
+
+def test_inference_forward_matches_oracle_and_checkpoint_roundtrip(tmp_path):
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.test_options import TestOptions
+
+    size, seed = 256, 31
+    model, opt = make_model(size, 1)
+    sdG, _, _ = load_test_weights(model, seed)
+    model.save_dir = str(tmp_path)
+    model.save_networks("latest")
+    saved = torch.load(os.path.join(str(tmp_path), "latest_net_G.pth"))
+    assert list(saved.keys()) == list(nets.g_param_shapes().keys())
+    topt = TestOptions(cmd_line="--model sinskitG --gpu_ids 0 --checkpoints_dir %s --name x --crop_size %d" % (tmp_path, size)).parse()
+    tm = create_model(topt)
+    tm.save_dir = str(tmp_path)
+    tm.setup(topt)          # loads latest_net_G.pth
+    tm.parallelize()
+    tm.eval()
+    batch = default_collate([make_sample(size, 8, 8, seed)])
+    tm.set_input(batch, phase="test")
+    tm.test()
+    fi, ft = step.inference(sdG, batch)
+    assert rel(tm.fake_I, fi) < 1e-3 and rel(tm.fake_T, ft) < 1e-3
+    assert set(tm.get_current_visuals().keys()) >= {"real_S", "fake_I", "fake_gx", "fake_gy", "fake_N"}

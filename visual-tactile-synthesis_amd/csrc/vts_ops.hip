@@ -65,7 +65,7 @@ __device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ __launch_bounds__(256) void ganloss_kernel(const float* __restrict__ pred, int64_t total, int mode, int real, float label,
-                                                      float inv_count, float coeff, float* __restrict__ loss, float* __restrict__ dpred) {
+                                                      float inv_count, float coeff, float gcoeff, float* __restrict__ loss, float* __restrict__ dpred) {
   __shared__ float red[16];
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ganloss_kernel(const float* __restrict__ 
       }
     }
     acc += l;
-    if (dpred) dpred[i] = g * inv_count * coeff;
+    if (dpred) dpred[i] = g * inv_count * gcoeff;
   }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0 && loss) atomicAdd(loss, acc * inv_count * coeff);
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void patch_scatter_kernel(const float* __restr
 // ------------------------------------------------------------------ generator output post-processing
 __global__ __launch_bounds__(256) void g_post_kernel(const float* __restrict__ g, const float* __restrict__ M, int64_t HW,
                                                      float scale_nz, const float* __restrict__ rb, const float* __restrict__ rs,
-                                                     float* __restrict__ fI, float* __restrict__ fT, float* __restrict__ fN,
-                                                     float* __restrict__ aI) {
+                                                     float* __restrict__ fI, float* __restrict__ fT, int64_t fTns,
+                                                     float* __restrict__ fN, float* __restrict__ aI, int64_t aIns) {
   const int n = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= HW) return;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void g_post_kernel(const float* __restrict__ g
     o[0] = r; o[HW] = gg; o[2 * HW] = b;
   }
   if (fT) {
-    float* o = fT + n * 2 * HW + i;
+    float* o = fT + n * fTns + i;
     o[0] = tx; o[HW] = ty;
   }
   if (fN) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void g_post_kernel(const float* __restrict__ g
     const float db = rb[n] - 0.5f, k = rs[n] * 2.f;
     const float r1 = r + db, g1 = gg + db, b1 = b + db;
     const float mean = (r1 + g1 + b1) / 3.f;
-    float* o = aI + n * 3 * HW + i;
+    float* o = aI + n * aIns + i;
     o[0] = ((r1 - mean) * k + mean) * m;
     o[HW] = ((g1 - mean) * k + mean) * m;
     o[2 * HW] = ((b1 - mean) * k + mean) * m;
@@ -462,11 +462,11 @@ extern "C" int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, f
 }
 
 extern "C" int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
-                           float* loss_out, float* dpred, void* stream) {
+                           float grad_coeff, float* loss_out, float* dpred, void* stream) {
   VTS_CHECK_ARG(pred && N >= 1 && M >= 1 && mode >= 0 && mode <= 4, "vts_ganloss: bad args");
   const int64_t total = (int64_t)N * M;
   hipLaunchKernelGGL(ganloss_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, total, mode, target_is_real,
-                     target_label, 1.f / (float)total, coeff, loss_out, dpred);
+                     target_label, 1.f / (float)total, coeff, grad_coeff, loss_out, dpred);
   VTS_CHECK_LAUNCH("vts_ganloss");
   return VTS_OK;
 }
@@ -500,11 +500,12 @@ extern "C" int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, i
 }
 
 extern "C" int vts_g_post(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
-                          float* fake_I, float* fake_T, float* fake_N, float* aug_fake_I, void* stream) {
+                          float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I,
+                          int64_t aug_nstride, void* stream) {
   VTS_CHECK_ARG(g_out && M && (!aug_fake_I || (rb && rs)), "vts_g_post: bad args");
   const int64_t HW = (int64_t)H * W;
   hipLaunchKernelGGL(g_post_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, g_out, M, HW, scale_nz, rb, rs,
-                     fake_I, fake_T, fake_N, aug_fake_I);
+                     fake_I, fake_T, fake_T_nstride ? fake_T_nstride : 2 * HW, fake_N, aug_fake_I, aug_nstride ? aug_nstride : 3 * HW);
   VTS_CHECK_LAUNCH("vts_g_post");
   return VTS_OK;
 }

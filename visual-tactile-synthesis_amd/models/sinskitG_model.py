@@ -1,0 +1,451 @@
+"""SinSKITGModel on the MI355X HIP path: sketch -> (RGB image, tactile gx/gy) conditional GAN.
+
+Drop-in for /root/reference/models/sinskitG_model.py behind the BaseModel contract:
+same flags and defaults (:44-376), same loss / visual name lists (:401-470), same training
+step order (optimize_parameters :601-700: forward -> patches -> D1 update -> D2 update ->
+G update), same loss assembly (compute_D1_loss :1346-1407, compute_D2_loss :1409-1617,
+compute_G1_loss :1660-1726, compute_G2_loss :1728-1842) and the same quirks (the G2 GAN
+term is logged but carries no gradient :1751; feature matching is dead :1685,1794; the
+nonsaturating loss ignores label smoothing; identity-size bicubic resamples are elided,
+SURVEY.md §8a "Numerical conventions").
+
+What is different on this side of the boundary:
+  * every tensor op of the step is a libvts_hip.so kernel scheduled by vts.engine (no autograd);
+  * batch size N >= 1 (the reference hard-requires 1): patches are gathered per sample;
+  * losses stay on the device and are read back only in get_current_losses();
+  * third-party terms whose weights cannot exist offline (LPIPS-VGG, CLIP vision-aided D3)
+    must be disabled by flag -- requesting them raises instead of silently dropping them.
+"""
+import random
+
+import numpy as np
+import torch
+
+from util import util
+from vts import engine, ops
+from vts.ops import Act
+from vts.optim import FlatAdam, FlatParams
+
+from . import networks
+from .base_model import BaseModel
+
+B = util.str2bool
+
+# (flag, type, default[, choices])  -- reference: sinskitG_model.py:52-296
+MODEL_FLAGS = [
+    ("use_cGAN", B, True), ("lambda_G1_GAN", float, 1.0), ("lambda_G1_L1", float, 100.0), ("lambda_G1_lpips", float, 1.0),
+    ("use_cGAN_G2", B, True), ("use_cGAN_G2_S", B, True), ("use_cGAN_G2_I", B, True),
+    ("lambda_G2_GAN", float, 5.0), ("lambda_G2_L1", float, 10.0), ("lambda_G2_lpips", float, 10.0),
+    ("lambda_G2_GAN_feat", float, 1), ("smooth_GAN_label", "nargs_bool", True),
+    ("use_vision_aided_loss", B, True), ("vision_aided_warmup_epoch", int, 100),
+    ("lr_G2", float, 0.0005), ("netD2", str, "basic"), ("n_layers_D2", int, 3), ("num_layer_separate", int, 4),
+    ("num_D_D2", int, 3), ("num_D_D1", int, 3), ("model_phase", str, "train"),
+    ("sketch_nc", int, 1), ("image_nc", int, 3), ("touch_nc", int, 2),
+    ("use_positional_encoding", B, True), ("positional_encoding_mode", str, "spe", ["spe", "csg"]),
+    ("positional_encoding_dim", int, 4), ("data_len", int, 200), ("batch_size_G2", int, 64),
+    ("batch_size_G2_val", int, 128), ("center_w", int, 1280), ("center_h", int, 960),
+    ("T_resolution_multiplier", int, 1), ("padded_size", int, 1800), ("num_touch_patch_for_logging", int, 10),
+    ("use_bg_mask", B, True), ("use_more_fakeT", B, True), ("add_fake_T_sample_size", int, 32),
+    ("sample_bbox_per_patch", int, 2), ("use_diffaug", B, True), ("diffaugment", str, "bs"),
+    ("w_resampling", B, True), ("resampling_w_min", int, 1), ("resampling_w_max", int, 10),
+    ("save_S_patch", B, False), ("save_T_concat_tensor", B, False), ("save_raw_arr_vis", B, False),
+    ("scale_nz", float, 0.25),
+]
+
+LOSS_SLOTS = ["G_GAN", "D_real_I", "D_fake_I", "D_I_grad_penalty", "G_L1", "G_lpips", "G2_GAN", "D_real_T_concat",
+              "D_fake_T_concat", "D_T_grad_penalty", "D_more_fake_T", "G2_L1", "G2_lpips", "G2_GAN_feat", "G1_GAN_feat",
+              "G_D3", "D3_real_I", "D3_fake_I"]
+
+
+def add_model_flags(parser, table):
+    for row in table:
+        name, typ, default = row[0], row[1], row[2]
+        if typ == "nargs_bool":
+            parser.add_argument("--" + name, type=B, nargs="?", const=True, default=default)
+        elif len(row) > 3:
+            parser.add_argument("--" + name, type=typ, default=default, choices=row[3])
+        else:
+            parser.add_argument("--" + name, type=typ, default=default)
+
+
+class SinSKITGModel(BaseModel):
+    MODEL_NAME = "sinskitG"
+    DATASET_MODE = "singleskit"
+    DATAROOT = "./datasets/singleskit_FlowerShorts_padded_1800_x1/"
+    DATA_LEN = 200
+
+    @classmethod
+    def modify_commandline_options(cls, parser, is_train=True):
+        add_model_flags(parser, MODEL_FLAGS)
+        cls.add_extra_flags(parser)
+        parser.set_defaults(model=cls.MODEL_NAME, dataset_mode=cls.DATASET_MODE, netG="unet256_custom", netD="multiscale",
+                            netD2="multiscale", gan_mode="nonsaturating", ngf=10, ndf=8, lr=0.001, beta1=0.0, beta2=0.99,
+                            crop_size=1536, no_flip=True, dataroot=cls.DATAROOT, data_len=cls.DATA_LEN)
+        if is_train:
+            parser.set_defaults(preprocess="crop", batch_size=1, display_freq=100, print_freq=100, save_latest_freq=100,
+                                validation_freq=100, save_epoch_freq=50, n_epochs=5, n_epochs_decay=400, num_threads=0,
+                                batch_size_G2=64, val_for_each_epoch=True, model_phase="train", display_id=0,
+                                save_raw_arr_vis=False)
+        else:
+            parser.set_defaults(preprocess="none", batch_size=1, num_test=1, data_len=1, epoch="latest",
+                                num_touch_patch_for_logging=100, batch_size_G2=100, model_phase="eval", display_id=0,
+                                save_S_patch=True, save_raw_arr_vis=False, sample_bbox_per_patch=1)
+        return parser
+
+    @staticmethod
+    def add_extra_flags(parser):
+        pass
+
+    # ------------------------------------------------------------------ construction
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        if not self.gpu_ids or not torch.cuda.is_available():
+            raise RuntimeError("%s runs on the MI355X HIP path only (no CPU fallback): pass --gpu_ids 0 on a GPU box"
+                               % type(self).__name__)
+        self._check_unbuilt_terms(opt)
+        self.test_edit_S = "edit" in opt.dataroot
+        self.model_names = ["G"]
+        if self.isTrain:
+            if opt.lambda_G1_GAN > 0.0:
+                self.model_names.append("D")
+            if opt.lambda_G2_GAN > 0.0:
+                self.model_names.append("D2")
+        self.visual_names = ["real_S", "M", "fake_I", "fake_gx", "fake_gy", "fake_N"]
+        if not self.test_edit_S:
+            self.visual_names.insert(2, "real_I")
+        if self.isTrain and opt.lambda_G1_GAN > 0:
+            self.visual_names.append("pred_fake_I")
+        if self.isTrain and opt.lambda_G2_GAN > 0:
+            self.visual_names.append("pred_fake_T_full")
+        if opt.use_diffaug and not self.test_edit_S:
+            self.visual_names.extend(["aug_fake_I", "aug_real_I"])
+        self.loss_names = []
+        if getattr(opt, "train_for_each_epoch", False):
+            if opt.lambda_G1_GAN > 0.0:
+                self.loss_names.extend(["G_GAN", "D_real_I", "D_fake_I", "D_I_grad_penalty"])
+            if opt.lambda_G1_L1 > 0.0:
+                self.loss_names.append("G_L1")
+            if opt.lambda_G2_GAN > 0.0:
+                self.loss_names.extend(["G2_GAN", "D_real_T_concat", "D_fake_T_concat", "D_T_grad_penalty"])
+                if opt.use_more_fakeT:
+                    self.loss_names.append("D_more_fake_T")
+            if opt.lambda_G2_L1 > 0.0:
+                self.loss_names.append("G2_L1")
+        # evaluation metrics (SIFID / LPIPS / PSNR / SSIM ...) are SURVEY.md §8(f) row 2: not built
+        self.metric_names = []
+
+        if opt.smooth_GAN_label:
+            self.criterionGAN = networks.GANLoss(opt.gan_mode, target_real_label=0.8, target_fake_label=0.0)
+        else:
+            self.criterionGAN = networks.GANLoss(opt.gan_mode)
+        if opt.gan_mode == "wgangp":
+            raise NotImplementedError("gan_mode wgangp needs a double-backward gradient penalty; not built")
+
+        self.pe_channels = 2 * opt.positional_encoding_dim if opt.use_positional_encoding else 0
+        if opt.use_positional_encoding and opt.positional_encoding_mode != "spe":
+            raise NotImplementedError("positional_encoding_mode %s is not built" % opt.positional_encoding_mode)
+        input_nc = opt.sketch_nc + self.pe_channels
+        self.netG = networks.define_G(input_nc, opt.image_nc + opt.touch_nc, opt.ngf, opt.netG, opt.normG, not opt.no_dropout,
+                                      opt.init_type, opt.init_gain, opt.no_antialias, opt.no_antialias_up, self.gpu_ids, opt,
+                                      num_layer_separate=opt.num_layer_separate)
+        self.flatG = FlatParams(self.netG)
+        self.use_cGAN_G2_S = bool(opt.use_cGAN_G2_S)
+        self.use_cGAN_G2_I = bool(opt.use_cGAN_G2_I)
+        if self.isTrain:
+            if not (opt.use_cGAN and opt.use_cGAN_G2 and self.use_cGAN_G2_S and self.use_cGAN_G2_I and opt.use_bg_mask):
+                raise NotImplementedError("the HIP step is built for the default conditioning "
+                                          "(use_cGAN, use_cGAN_G2{,_S,_I}, use_bg_mask all True)")
+            if opt.T_resolution_multiplier != 1:
+                raise NotImplementedError("T_resolution_multiplier != 1 needs the bicubic anti-aliased resampler; not built")
+            if "D" in self.model_names:
+                self.netD = networks.define_D(opt.image_nc + opt.sketch_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.normD,
+                                              opt.init_type, opt.init_gain, opt.no_antialias, num_D=opt.num_D_D1,
+                                              gpu_ids=self.gpu_ids, opt=opt)
+                self.flatD = FlatParams(self.netD)
+            if "D2" in self.model_names:
+                self.netD2 = networks.define_D(opt.touch_nc + opt.sketch_nc + opt.image_nc + 1, opt.ndf, opt.netD2,
+                                               opt.n_layers_D2, opt.normD, opt.init_type, opt.init_gain, opt.no_antialias,
+                                               num_D=opt.num_D_D2, gpu_ids=self.gpu_ids, opt=opt)
+                self.flatD2 = FlatParams(self.netD2)
+            betas = (opt.beta1, opt.beta2)
+            self.optimizer_G = FlatAdam(self.flatG, opt.lr, betas)
+            self.optimizers.append(self.optimizer_G)
+            if "D" in self.model_names:
+                self.optimizer_D = FlatAdam(self.flatD, opt.lr, betas)
+                self.optimizers.append(self.optimizer_D)
+            if "D2" in self.model_names:
+                self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr_G2, betas)
+                self.optimizers.append(self.optimizer_D2)
+        self._loss_buf = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
+        self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
+        self._spe_cache = {}
+        self._draws = None      # tests / parity runs inject {"aug": [4,N], "more_idx": [N,K]}
+        self.ddp = None
+        self.style_code = None
+
+    @staticmethod
+    def _check_unbuilt_terms(opt):
+        if not opt.isTrain:
+            return
+        bad = []
+        if opt.lambda_G1_lpips > 0 or opt.lambda_G2_lpips > 0:
+            bad.append("LPIPS (--lambda_G1_lpips 0 --lambda_G2_lpips 0)")
+        if opt.use_vision_aided_loss:
+            bad.append("CLIP vision-aided discriminator (--use_vision_aided_loss False)")
+        if bad:
+            raise NotImplementedError(
+                "third-party loss terms need pretrained weights that are not available offline and are not built: %s. "
+                "Disable them explicitly (SURVEY.md §7 'Third-party loss terms')." % "; ".join(bad))
+
+    # ------------------------------------------------------------------ input
+    def _spe(self, n, h, w):
+        key = (n, h, w)
+        if key not in self._spe_cache:
+            buf = torch.empty(n, self.pe_channels, h, w, dtype=torch.float32, device=self.device)
+            ops.spe_grid(buf, self.opt.positional_encoding_dim)
+            self._spe_cache = {key: buf}
+        return self._spe_cache[key]
+
+    @staticmethod
+    def _patch_offsets(coords):
+        """find_coords_for_patch (models/model_utils.py:23-69) on the host, per sample."""
+        c = np.asarray(coords, dtype=np.float64)
+        ox = np.round(c[..., 0] + c[..., -2] / c[..., -3])
+        oy = np.round(c[..., 1] + c[..., -1] / c[..., -3])
+        cs = np.round(c[..., -4] / c[..., -3])
+        return ox.astype(np.float32).astype(np.int32), oy.astype(np.float32).astype(np.int32), cs.astype(np.int32)
+
+    def _patch_set(self, T_images, I_masks, T_coords):
+        T = torch.as_tensor(T_images)
+        n, nt = T.shape[0], T.shape[1]
+        dev = self.device
+        ox, oy, cs = self._patch_offsets(torch.as_tensor(T_coords).numpy())
+        if not (cs == 32).all():
+            raise NotImplementedError("patch cutout != 32 px needs the bicubic resampler; not built")
+        real_T = T.reshape(-1, 2, 32, 32).to(torch.float32).to(dev, non_blocking=True).contiguous()
+        masks = torch.as_tensor(I_masks).reshape(-1, 1, 32, 32).to(torch.float32).to(dev, non_blocking=True).contiguous()
+        real_T = ops.mask_mul(real_T, masks)
+        return dict(
+            real_T=real_T, masks=masks, NT=nt,
+            offx=torch.from_numpy(ox.reshape(-1)).to(dev), offy=torch.from_numpy(oy.reshape(-1)).to(dev),
+            img=torch.arange(n, dtype=torch.int32).repeat_interleave(nt).to(dev), coords=np.asarray(T_coords))
+
+    def set_input(self, input, phase="train", timing=False, verbose=False):
+        dev = self.device
+        self.data_phase = phase
+        S = input["S"].to(dev, non_blocking=True).float().contiguous()
+        self.name = input.get("name")
+        self.image_paths = input.get("S_paths")
+        self.augmentation_params = input.get("augmentation_params")
+        n, _, h, w = S.shape
+        if self.opt.use_bg_mask:
+            self.M = input["M"].to(dev, non_blocking=True).float().contiguous()
+            self.real_S = ops.mask_mul(S, self.M)
+            self.M_T = self.M  # nearest resize at multiplier 1 is the identity
+        else:
+            self.real_S = S
+        if "I" in input:
+            I = input["I"].to(dev, non_blocking=True).float().contiguous()
+            self.real_I = ops.mask_mul(I, self.M) if self.opt.use_bg_mask else I
+            self.full_T_coords = input.get("full_T_coords")
+        elif hasattr(self, "real_I"):
+            del self.real_I
+        self.S_pe = self._spe(n, h, w) if self.pe_channels else None
+        if "style_code" in input:
+            self.style_code = input["style_code"].to(dev).float()
+        self.train_set = self.val_set = None
+        if "T_images" in input and len(input["T_images"]) > 0:
+            self.train_set = self._patch_set(input["T_images"], input["I_masks"], input["T_coords"])
+            self.train_T_coords = self.train_set["coords"]
+            self.train_real_T_concat = self.train_set["real_T"]
+            self.train_I_masks = self.train_set["masks"]
+            if "val_T_images" in input and len(input["val_T_images"]) > 0:
+                self.val_set = self._patch_set(input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
+            elif phase == "test":
+                self.val_set = self.train_set
+        if self.isTrain and self.opt.use_more_fakeT and phase == "train":
+            # candidate positions of the "more fake T" sampler depend on the mask only: build them here,
+            # where the host already synchronises for the H2D copies (model_utils.py:212-216)
+            self._cand, self._cand_prefix = ops.mask_candidates(self.M)
+            self._cand_count = self._cand_prefix[:, -1].cpu().tolist()
+
+    # ------------------------------------------------------------------ forward
+    def _g_input(self):
+        return (Act(self.real_S), Act(self.S_pe)) if self.S_pe is not None else Act(self.real_S)
+
+    def forward(self, timing=False, keep=False):
+        opt = self.opt
+        n, _, h, w = self.real_S.shape
+        dev = self.device
+        g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep)
+        self.g_out = g_out
+        self.fake_I = torch.empty(n, 3, h, w, device=dev)
+        self.fake_N = torch.empty(n, 3, h, w, device=dev)
+        has_real = hasattr(self, "real_I") and not self.test_edit_S
+        # the D2 full-resolution stack [fake_T(2), S(1), aug_fake_I(3), M(1)] is filled in place
+        self._full_stack = torch.empty(n, 7, h, w, device=dev)
+        self.fake_T = self._full_stack[:, 0:2]
+        aug_fake = self._full_stack[:, 3:6] if has_real else None
+        rb = rs = None
+        if has_real and opt.use_diffaug:
+            if opt.diffaugment != "bs":
+                raise NotImplementedError("DiffAugment policy '%s' is not built (only 'bs')" % opt.diffaugment)
+            draws = self._draws["aug"].to(dev).float() if self._draws is not None else torch.rand(4, n, device=dev)
+            self._aug = draws
+            rb, rs = draws[2].contiguous(), draws[3].contiguous()
+            self.aug_real_I = ops.diffaug_bs_mask(self.real_I, self.M, draws[0].contiguous(), draws[1].contiguous(),
+                                                  torch.empty_like(self.real_I))
+        elif has_real:
+            # no augmentation: aug_* are the masked images themselves (M is binary, so *M again is idempotent)
+            half, one = torch.full((n,), 0.5, device=dev), torch.full((n,), 0.5, device=dev)
+            rb, rs = half, one  # brightness shift 0, saturation factor 1
+            self.aug_real_I = self.real_I
+        ops.g_post(g_out, self.M, opt.scale_nz, rb, rs, fake_I=self.fake_I, fake_T=self.fake_T, fake_N=self.fake_N,
+                   aug_fake_I=aug_fake)
+        self.aug_fake_I = aug_fake
+        self.fake_gx = self.fake_T[:, 0:1]
+        self.fake_gy = self.fake_T[:, 1:2]
+
+    def _style(self):
+        return None
+
+    def test(self, timing=False):
+        with torch.no_grad():
+            self.forward(keep=False)
+
+    # ------------------------------------------------------------------ training step
+    def _gather(self, src, pset, out, c0, channels=None):
+        return ops.patch_gather(src, pset["img"], pset["offx"], pset["offy"], 32, out, c0=c0, channels=channels)
+
+    def _more_fake_offsets(self, n):
+        k = self.opt.add_fake_T_sample_size
+        if self._draws is not None:
+            ranks = torch.as_tensor(self._draws["more_idx"]).long()
+        else:
+            ranks = torch.tensor([random.sample(range(c), k) for c in self._cand_count], dtype=torch.int64)
+        h, w = self.real_S.shape[2:]
+        return ops.mask_select(self._cand, self._cand_prefix, ranks.to(self.device), h, w)
+
+    def _d_pass(self, net, in0, in1, target_real, coeff, slot, accumulate, backward=True):
+        """One discriminator forward (+ backward into its parameter grads).  Returns preds."""
+        preds, ctx = engine.msd_forward(net, in0, in1, keep=backward)
+        dp = self.criterionGAN.accumulate(preds, target_real, coeff, slot, grad_coeff=0.5 * coeff, want_grad=backward)
+        if backward:
+            engine.msd_backward(net, ctx, dp, param_grads=True, accumulate=accumulate)
+        return preds
+
+    def optimize_parameters(self, epoch=0, timing=False):
+        opt = self.opt
+        dev = self.device
+        ts = self.train_set
+        if ts is None:
+            raise RuntimeError("optimize_parameters needs tactile patches in the batch (T_images)")
+        n, _, h, w = self.real_S.shape
+        nt, P = ts["NT"], ts["real_T"].shape[0]
+        ddp = self.ddp
+        gscale = ddp.grad_scale if ddp is not None else 1.0
+        self._loss_buf.zero_()
+        slot = self._slot
+
+        self.forward(keep=True)
+
+        # ---- patches (compute_additional_output :1268-1291) ----
+        fake_stack = torch.empty(P, 7, 32, 32, device=dev)    # [fake_T, S, aug_fake_I, mask]
+        real_stack = torch.empty(P, 7, 32, 32, device=dev)    # [real_T, S, aug_real_I, mask]
+        self._gather(self.fake_T, ts, fake_stack, 0, channels=2)
+        self._gather(self.real_S, ts, fake_stack, 2)
+        self._gather(self.aug_fake_I, ts, fake_stack, 3, channels=3)
+        fake_stack[:, 6:7].copy_(ts["masks"])
+        real_stack[:, 0:2].copy_(ts["real_T"])
+        self._gather(self.real_S, ts, real_stack, 2)
+        self._gather(self.aug_real_I, ts, real_stack, 3)
+        real_stack[:, 6:7].copy_(ts["masks"])
+        fake_T_concat = torch.empty(P, 2, 32, 32, device=dev)
+        self._gather(self.fake_T, ts, fake_T_concat, 0, channels=2)
+        self.fake_T_concat = fake_T_concat
+
+        # ---- D1 update (compute_D1_loss) ----
+        if "D" in self.model_names:
+            lam = opt.lambda_G1_GAN
+            preds = self._d_pass(self.netD, self.real_S, self.fake_I, False, lam, slot["D_fake_I"], accumulate=False)
+            self.pred_fake_I = preds[-1]
+            self._d_pass(self.netD, self.real_S, self.real_I, True, lam, slot["D_real_I"], accumulate=True)
+            if ddp is not None:
+                ddp.buckets["D"].start()
+
+        # ---- D2 update (compute_D2_loss) ----
+        if "D2" in self.model_names:
+            lam2 = opt.lambda_G2_GAN
+            self._d_pass(self.netD2, fake_stack, None, False, lam2, slot["D_fake_T_concat"], accumulate=False)
+            # full-resolution pass: visualisation only, but it advances the BatchNorm running statistics
+            self._full_stack[:, 2:3].copy_(self.real_S)
+            self._full_stack[:, 6:7].copy_(self.M)
+            preds_full, _ = engine.msd_forward(self.netD2, self._full_stack, None, keep=False)
+            self.pred_fake_T_full = preds_full[-1]
+            if opt.use_more_fakeT:
+                k = opt.add_fake_T_sample_size
+                mox, moy = self._more_fake_offsets(n)
+                mimg = torch.arange(n, dtype=torch.int32, device=dev).repeat_interleave(k)
+                self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
+                more = torch.empty(n * k, 7, 32, 32, device=dev)
+                mset = dict(img=mimg, offx=mox, offy=moy)
+                self._gather(self.fake_T, mset, more, 0, channels=2)
+                self._gather(self.real_S, mset, more, 2)
+                self._gather(self.fake_I, mset, more, 3)
+                more[:, 6:7].fill_(1.0)
+                self._d_pass(self.netD2, more, None, False, lam2, slot["D_more_fake_T"], accumulate=True)
+            self._d_pass(self.netD2, real_stack, None, True, lam2, slot["D_real_T_concat"], accumulate=True)
+            if ddp is not None:
+                ddp.buckets["D2"].start()
+
+        if "D" in self.model_names:
+            if ddp is not None:
+                ddp.buckets["D"].wait()
+            self.optimizer_D.step(gscale)
+
+        # ---- G update (compute_G1_loss + compute_G2_loss) ----
+        d_fake_I = torch.empty(n, 3, h, w, device=dev)
+        have_dI = False
+        if "D" in self.model_names:
+            lam = opt.lambda_G1_GAN
+            preds, ctx = engine.msd_forward(self.netD, self.real_S, self.fake_I, keep=True)
+            dp = self.criterionGAN.accumulate(preds, True, lam, slot["G_GAN"], grad_coeff=lam)
+            engine.msd_backward(self.netD, ctx, dp, param_grads=False, input_grad=(d_fake_I, False))
+            have_dI = True
+        if opt.lambda_G1_L1 > 0.0:
+            ops.l1(self.fake_I, self.real_I, opt.lambda_G1_L1 / self.fake_I.numel(), slot["G_L1"], d_fake_I, accumulate=have_dI)
+            have_dI = True
+        if "D2" in self.model_names:
+            if ddp is not None:
+                ddp.buckets["D2"].wait()
+            self.optimizer_D2.step(gscale)
+            # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
+            preds, _ = engine.msd_forward(self.netD2, fake_stack, None, keep=False)
+            self.criterionGAN.accumulate(preds, True, opt.lambda_G2_GAN * nt, slot["G2_GAN"], want_grad=False)
+        d_fake_T = None
+        if opt.lambda_G2_L1 > 0.0:
+            d_patch = torch.empty(P, 2, 32, 32, device=dev)
+            ops.l1(fake_T_concat, ts["real_T"], opt.lambda_G2_L1 / (n * 2 * 32 * 32), slot["G2_L1"], d_patch)
+            d_fake_T = torch.empty(n, 2, h, w, device=dev)
+            ops.patch_scatter_bwd(d_patch, 0, 2, ts["offx"], ts["offy"], nt, 32, d_fake_T)
+        d_raw = torch.empty(n, 5, h, w, device=dev)
+        ops.g_out_grad(d_fake_I if have_dI else None, d_fake_T, self.M, self.g_out, d_raw)
+        engine.unet_backward(self.netG, self._g_ctx, d_raw)
+        self._g_ctx = None
+        if ddp is not None:
+            ddp.buckets["G"].start()
+            ddp.buckets["G"].wait()
+        self.optimizer_G.step(gscale)
+
+    # ------------------------------------------------------------------ logging
+    def get_current_losses(self):
+        vals = self._loss_buf.cpu().tolist()   # the only device->host sync of the loss path
+        for i, name in enumerate(LOSS_SLOTS):
+            setattr(self, "loss_" + name, vals[i])
+        return BaseModel.get_current_losses(self)
+
+    def compute_visuals(self):
+        pass
+
+    def get_current_visuals(self):
+        return BaseModel.get_current_visuals(self)

@@ -1,0 +1,78 @@
+"""Data-parallel glue: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The hot path shards by image: every rank holds full replicas of G, D and D2
+and draws its own samples.  The only exchange is a sum-all-reduce of ONE flat fp32 gradient
+bucket per network (G 5.9 MB, D and D2 0.54 MB each); the division by world size is folded
+into the fused Adam kernel (`grad_scale`).  The all-reduce is issued asynchronously right
+after a network's backward and waited for just before that network's Adam step, so it
+overlaps the next phase's forward (D bucket under the D2 step, D2 bucket under the G-step
+discriminator forward).  BatchNorm statistics stay per rank, like per-replica BN under the
+reference's nn.DataParallel (base_model.py:104-108).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type="cuda"):
+    """Initialise the default process group from torchrun-style env vars (no-op for 1 rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return int(os.environ.get("RANK", "0")), world
+    rank = int(os.environ["RANK"])
+    if device_type == "cuda":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    else:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return rank, world
+
+
+class GradBucket:
+    """Asynchronous all-reduce of one flat gradient buffer."""
+
+    def __init__(self, flat_grad):
+        self.buf = flat_grad
+        self.work = None
+
+    def start(self):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+
+class DDPState:
+    def __init__(self, world, buckets):
+        self.world = world
+        self.buckets = buckets
+        self.grad_scale = 1.0 / world
+
+
+def broadcast_module(module, src=0):
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def attach(model):
+    """Called by BaseModel.parallelize(): replicate rank 0's weights, create gradient buckets."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    buckets = {}
+    for name in model.model_names:
+        net = getattr(model, "net" + name)
+        if world > 1:
+            flat = getattr(model, "flat" + name, None)
+            if flat is not None:
+                dist.broadcast(flat.flat, 0)
+                for b in net.buffers():
+                    dist.broadcast(b, 0)
+            else:
+                broadcast_module(net, 0)
+        flat = getattr(model, "flat" + name, None)
+        if flat is not None:
+            buckets[name] = GradBucket(flat.grad)
+    return DDPState(world, buckets)

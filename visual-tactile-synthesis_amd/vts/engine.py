@@ -1,0 +1,288 @@
+"""Explicit forward / backward schedules of the two network families over libvts_hip.so.
+
+There is no autograd on the hot path: the U-Net generator and the multiscale PatchGAN
+discriminator are fixed graphs, so their backward passes are written out as kernel
+sequences.  Activations travel as `ops.Act` (raw tensor + per-(n,c) scale/shift): a
+normalisation layer is a statistics pass only, and every consumer (next conv, skip
+concat, derivative mask, weight gradient) normalises on load inside the conv kernels.
+
+Reference graphs reproduced here:
+  CustomUnetGenerator.forward     /root/reference/models/networks.py:1576-1645
+  Down / Up blocks                /root/reference/thirdparty/unet/unet_parts_custom.py:9-79
+  MultiscaleDiscriminator.forward /root/reference/models/networks.py:1682-1693
+  NLayerDiscriminator             /root/reference/models/networks.py:1696-1750
+(their backward is PyTorch autograd in the reference).
+"""
+import torch
+
+from . import lib as L
+from . import ops
+from .ops import Act
+
+LRELU, RELU, TANH = L.ACT_LRELU, L.ACT_RELU, L.ACT_TANH
+
+
+def _empty(n, c, h, w, dev):
+    return torch.empty(n, c, h, w, dtype=torch.float32, device=dev)
+
+
+def _as_act(x):
+    return x if isinstance(x, Act) else Act(x)
+
+
+# =====================================================================================
+# generator
+# =====================================================================================
+
+class UnetCtx:
+    __slots__ = ("x", "feats", "ups", "g_out", "style")
+
+
+def unet_forward(G, x, style_code=None, keep=True):
+    """x: [N, input_nc, H, W] tensor / Act, or a pair (x0, x1) that is concatenated on load
+    (sketch ++ positional grid).  Returns (g_out [N,5,H,W] post-tanh, ctx)."""
+    if isinstance(x, (tuple, list)):
+        x, x_extra = _as_act(x[0]), _as_act(x[1])
+    else:
+        x, x_extra = _as_act(x), None
+    xd = x.data
+    n, _, h, w = xd.shape
+    dev = xd.device
+    nd, ch = G.num_downs, G.channels
+    if h % (1 << nd) or w % (1 << nd):
+        raise ValueError("unet256_custom needs H, W divisible by %d, got %dx%d" % (1 << nd, h, w))
+    feats = []
+    a = x
+    for i in range(nd):
+        blk = getattr(G, "down%d" % i).conv
+        cin = blk.weight.shape[1]
+        hh, ww = h >> (i + 1), w >> (i + 1)
+        out = _empty(n, ch[i], hh, ww, dev)
+        ops.conv4x4(a, blk.weight, cin * 16, 16, ch[i], out, in1=x_extra if i == 0 else None, bias=blk.bias, stride=2, pad=1,
+                    act_in=LRELU if i else 0)
+        a = ops.norm_stats(out, 0) if 0 < i < nd - 1 else Act(out)
+        feats.append(a)
+
+    style = None
+    if style_code is not None:
+        if not G.use_style:
+            raise ValueError("generator was built without style code support")
+        style = style_code.to(torch.float32)
+    g_out = _empty(n, 5, h, w, dev)
+    ups = {}
+    xm, xt = feats[nd - 1], None
+    for i in range(nd - 1, -1, -1):
+        hh, ww = h >> (i + 1), w >> (i + 1)
+        skip = None if i in (0, nd - 1) else feats[i]
+        extra = None
+        if style is not None and i >= nd - G.num_layer_style_code:
+            if skip is not None:
+                raise NotImplementedError("style code on a skip-connected layer needs a third concat source")
+            extra = Act(style[:, :, None, None].expand(-1, -1, hh, ww).contiguous())
+
+        def up(name, inp):
+            blk = getattr(G, name).conv
+            outer = blk.weight.shape[1]
+            if i == 0:
+                c0 = 0 if name == "up0" else 3
+                out = g_out[:, c0:c0 + outer]
+            else:
+                out = _empty(n, outer, hh * 2, ww * 2, dev)
+            ops.conv4x4(inp, blk.weight, 16, outer * 16, outer, out, in1=skip if skip is not None else extra, bias=blk.bias,
+                        stride=2, pad=1, transposed=True, act_in=RELU, act_out=TANH if i == 0 else 0)
+            return Act(out) if i == 0 else ops.norm_stats(out, 0)
+
+        if G.num_layer_separate >= i + 1:
+            if xt is None:
+                xt = xm
+            xt_new = up("up%d_T" % i, xt)
+            ups["up%d_T" % i] = (xt, xt_new, extra)
+            xt = xt_new
+        xm_new = up("up%d" % i, xm)
+        ups["up%d" % i] = (xm, xm_new, extra)
+        xm = xm_new
+    if not keep:
+        return g_out, None
+    ctx = UnetCtx()
+    ctx.x, ctx.feats, ctx.ups, ctx.g_out, ctx.style = (x, x_extra), feats, ups, g_out, style
+    return g_out, ctx
+
+
+def unet_backward(G, ctx, d_raw):
+    """d_raw: [N,5,H,W] gradient wrt the pre-tanh outputs of up0 / up0_T.
+    Writes every parameter's .grad (overwrite) -- the G step has a single backward."""
+    nd, ch = G.num_downs, G.channels
+    n = d_raw.shape[0]
+    dev = d_raw.device
+    feats = ctx.feats
+    dfeat = [None] * nd      # grad wrt the normalised feats[i] (pre-activation), accumulated over consumers
+    dx = {}                  # id(Act) of an up-output -> grad wrt its normalised value
+
+    def add_grad(store, key, shape):
+        """returns (tensor, accumulate?)"""
+        if key in store and store[key] is not None:
+            return store[key], True
+        t = torch.empty(shape, dtype=torch.float32, device=dev)
+        store[key] = t
+        return t, False
+
+    for i in range(nd):
+        names = ["up%d" % i] + (["up%d_T" % i] if G.num_layer_separate >= i + 1 else [])
+        skip = None if i in (0, nd - 1) else feats[i]
+        for name in names:
+            blk = getattr(G, name).conv
+            inp, outp, extra = ctx.ups[name]
+            cin_total, outer = blk.weight.shape[0], blk.weight.shape[1]
+            if i == 0:
+                c0 = 0 if name == "up0" else 3
+                g = d_raw[:, c0:c0 + outer]  # channel-slice view: batch stride stays 5*H*W
+            else:
+                g = dx.pop(id(outp))
+                ops.norm_bwd(g, outp, 0)
+            gop = Act(g)
+            gsum_src = g
+            second = skip if skip is not None else extra
+            ops.wgrad4x4(inp, gop, blk.weight.grad, lo1=second, act_lo=RELU, stride=2, pad=1)
+            ops.channel_sum(gsum_src, blk.bias.grad)
+            c_in0 = inp.data.shape[1]
+            # grad wrt the primary input (normalised output of the previous up block, or feats[nd-1])
+            if i == nd - 1:
+                tgt, acc = add_grad_list(dfeat, nd - 1, inp.data.shape, dev)
+            else:
+                tgt, acc = add_grad(dx, id(inp), inp.data.shape)
+            ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc)
+            if skip is not None:
+                tgt, acc = add_grad_list(dfeat, i, skip.data.shape, dev)
+                wv = blk.weight.view(-1)[c_in0 * outer * 16:]
+                ops.conv4x4(gop, wv, outer * 16, 16, skip.data.shape[1], tgt, stride=2, pad=1, dmask=skip, dmask_act=RELU,
+                            accumulate=acc)
+
+    for i in range(nd - 1, -1, -1):
+        blk = getattr(G, "down%d" % i).conv
+        g = dfeat[i]
+        if 0 < i < nd - 1:
+            ops.norm_bwd(g, feats[i], 0)
+        src, src1 = ctx.x if i == 0 else (feats[i - 1], None)
+        ops.wgrad4x4(Act(g), src, blk.weight.grad, hi1=src1, act_hi=LRELU if i else 0, stride=2, pad=1)
+        ops.channel_sum(g, blk.bias.grad)
+        if i > 0:
+            cin = blk.weight.shape[1]
+            tgt, acc = add_grad_list(dfeat, i - 1, feats[i - 1].data.shape, dev)
+            ops.conv4x4(Act(g), blk.weight, 16, cin * 16, cin, tgt, stride=2, pad=1, transposed=True, dmask=feats[i - 1],
+                        dmask_act=LRELU, accumulate=acc)
+        dfeat[i] = None
+
+
+def add_grad_list(lst, idx, shape, dev):
+    if lst[idx] is not None:
+        return lst[idx], True
+    lst[idx] = torch.empty(shape, dtype=torch.float32, device=dev)
+    return lst[idx], False
+
+
+# =====================================================================================
+# multiscale discriminator
+# =====================================================================================
+
+class MsdCtx:
+    __slots__ = ("scales",)
+
+
+def _pool_act(a):
+    return None if a is None else Act(ops.avgpool(a.data))
+
+
+def msd_forward(D, in0, in1=None, keep=True, update_stats=True):
+    """in0 (++ in1): channel-concatenated input, each a tensor/Act [N,C,H,W].
+    Returns (preds: list over scales (full resolution first) of [N,1,h,w], ctx).
+    BatchNorm runs in training mode (batch statistics); running buffers are updated when
+    update_stats (every reference D call in a train step does: sinskitG_model.py:1361,1374,1490,...)."""
+    in0 = _as_act(in0)
+    in1 = _as_act(in1) if in1 is not None else None
+    n = in0.data.shape[0]
+    dev = in0.data.device
+    preds, scales = [], []
+    a0, a1 = in0, in1
+    for s in range(D.num_D):
+        layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
+        acts = []
+        cur0, cur1 = a0, a1
+        h, w = cur0.data.shape[2], cur0.data.shape[3]
+        for j, ci in enumerate(D.CONV_IDX):
+            conv = getattr(layer, str(ci))
+            st = D.STRIDE[ci]
+            cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+            oh, ow = (h + 4 - 4) // st + 1, (w + 4 - 4) // st + 1
+            out = _empty(n, cout, oh, ow, dev)
+            ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
+                        act_in=LRELU if j else 0)
+            if ci in D.BN_IDX:
+                bn = getattr(layer, str(D.BN_IDX[ci]))
+                a = ops.norm_stats(out, 1, gamma=bn.weight, beta=bn.bias,
+                                   running_mean=bn.running_mean if update_stats else None,
+                                   running_var=bn.running_var if update_stats else None,
+                                   nbt=bn.num_batches_tracked if update_stats else None)
+            else:
+                a = Act(out)
+            acts.append(a)
+            cur0, cur1 = a, None
+            h, w = oh, ow
+        preds.append(acts[-1].data)
+        scales.append((a0, a1, acts))
+        if s != D.num_D - 1:
+            a0, a1 = _pool_act(a0), _pool_act(a1)
+    if not keep:
+        return preds, None
+    ctx = MsdCtx()
+    ctx.scales = scales
+    return preds, ctx
+
+
+def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=None):
+    """dpreds: list over scales of d loss / d pred.
+    param_grads: write (accumulate=False) or add (accumulate=True) into every parameter's .grad.
+    input_grad: None, or (tensor [N,C1,H,W], accumulate_flag) receiving the gradient wrt `in1`
+    (the second concat source: fake_I in the G step), summed over the pyramid."""
+    n = dpreds[0].shape[0]
+    dev = dpreds[0].device
+    din_scales = []
+    for s in range(D.num_D):
+        layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
+        a0, a1, acts = ctx.scales[s]
+        g = dpreds[s]
+        for j in range(len(D.CONV_IDX) - 1, -1, -1):
+            ci = D.CONV_IDX[j]
+            conv = getattr(layer, str(ci))
+            st = D.STRIDE[ci]
+            cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+            if ci in D.BN_IDX:
+                bn = getattr(layer, str(D.BN_IDX[ci]))
+                ops.norm_bwd(g, acts[j], 1, gamma=bn.weight, dgamma=bn.weight.grad if param_grads else None,
+                             dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate)
+            src0, src1 = (a0, a1) if j == 0 else (acts[j - 1], None)
+            if param_grads:
+                ops.wgrad4x4(Act(g), src0, conv.weight.grad, hi1=src1, act_hi=LRELU if j else 0, stride=st, pad=2,
+                             accumulate=accumulate)
+                ops.channel_sum(g, conv.bias.grad, accumulate=accumulate)
+            if j > 0:
+                prev = acts[j - 1]
+                tgt = torch.empty_like(prev.data)
+                ops.conv4x4(Act(g), conv.weight, 16, cin * 16, cin, tgt, stride=st, pad=2, transposed=True, dmask=prev,
+                            dmask_act=LRELU)
+                g = tgt
+            elif input_grad is not None:
+                c0 = a0.data.shape[1]
+                c1 = a1.data.shape[1]
+                tgt = torch.empty_like(a1.data)
+                ops.conv4x4(Act(g), conv.weight.view(-1)[c0 * 16:], 16, cin * 16, c1, tgt, stride=st, pad=2, transposed=True)
+                din_scales.append(tgt)
+    if input_grad is not None:
+        dst, acc = input_grad
+        # d in1 = d0 + pool^T(d1 + pool^T(d2 ...))
+        for s in range(D.num_D - 1, 0, -1):
+            ops.avgpool_bwd(din_scales[s], din_scales[s - 1], accumulate=True)
+        if acc:
+            dst.add_(din_scales[0])
+        else:
+            dst.copy_(din_scales[0])
+    return None

@@ -102,11 +102,11 @@ def load():
         "vts_act_bwd": [vp, C.POINTER(Operand), i, i, i, vp, i, vp],
         "vts_avgpool3s2": [vp, i64, i, i, i, i, vp, vp],
         "vts_avgpool3s2_bwd": [vp, i, i, i, i, vp, i64, i, vp],
-        "vts_ganloss": [vp, i, i, i, i, f, f, vp, vp, vp],
+        "vts_ganloss": [vp, i, i, i, i, f, f, f, vp, vp, vp],
         "vts_l1": [vp, vp, i64, f, vp, vp, i, vp],
         "vts_patch_gather": [vp, i64, i, i, i, vp, vp, vp, i, i, vp, i, i, vp],
         "vts_patch_scatter_bwd": [vp, i, i, i, vp, vp, vp, i, i, i, vp, i64, i, i, i, i, vp],
-        "vts_g_post": [vp, vp, i, i, i, f, vp, vp, vp, vp, vp, vp, vp],
+        "vts_g_post": [vp, vp, i, i, i, f, vp, vp, vp, vp, i64, vp, vp, i64, vp],
         "vts_diffaug_bs_mask": [vp, vp, i, i, i, vp, vp, vp, vp],
         "vts_g_out_grad": [vp, vp, vp, vp, i, i, i, vp, vp],
         "vts_mask_mul": [vp, vp, i, i, i, vp, vp],

@@ -156,13 +156,14 @@ def avgpool_bwd(dy, dx, accumulate=False, channels=None, dx_nstride=None):
     return dx
 
 
-def ganloss(pred, mode, target_is_real, coeff, loss_slot, dpred=None, label=None):
+def ganloss(pred, mode, target_is_real, coeff, loss_slot, dpred=None, label=None, grad_coeff=None):
     lib = L.load()
     n = pred.shape[0]
     m = pred.numel() // n
     if label is None:
         label = 1.0 if target_is_real else 0.0
-    L.check(lib.vts_ganloss(pred.data_ptr(), n, m, L.GAN_MODES[mode], int(target_is_real), label, coeff, L.ptr(loss_slot),
+    L.check(lib.vts_ganloss(pred.data_ptr(), n, m, L.GAN_MODES[mode], int(target_is_real), label, coeff,
+                            coeff if grad_coeff is None else grad_coeff, L.ptr(loss_slot),
                             L.ptr(dpred), L.stream()), "vts_ganloss")
 
 
@@ -193,7 +194,8 @@ def g_post(g_out, M, scale_nz, rb=None, rs=None, fake_I=None, fake_T=None, fake_
     lib = L.load()
     n, _, h, w = g_out.shape
     L.check(lib.vts_g_post(g_out.data_ptr(), M.data_ptr(), n, h, w, scale_nz, L.ptr(rb), L.ptr(rs), L.ptr(fake_I), L.ptr(fake_T),
-                           L.ptr(fake_N), L.ptr(aug_fake_I), L.stream()), "vts_g_post")
+                           0 if fake_T is None else fake_T.stride(0), L.ptr(fake_N), L.ptr(aug_fake_I),
+                           0 if aug_fake_I is None else aug_fake_I.stride(0), L.stream()), "vts_g_post")
 
 
 def diffaug_bs_mask(x, M, rb, rs, out):

@@ -1,0 +1,87 @@
+"""Flat parameter / gradient buffers and the fused Adam step over them.
+
+Every network's parameters are views into ONE contiguous fp32 buffer and their .grad
+fields are views into a second one, so the optimiser is a single kernel per network and
+data-parallel training all-reduces one bucket per network.
+Semantics of torch.optim.Adam as the reference uses it
+(/root/reference/models/sinskitG_model.py:589-599: betas=(0.0, 0.99), eps 1e-8, no weight decay).
+"""
+import torch
+
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, module):
+        params = [p for p in module.parameters()]
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params = params
+        o = 0
+        for p in params:
+            n = p.numel()
+            view = self.flat[o:o + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + n].view_as(p)
+            p.requires_grad_(False)  # no autograd anywhere on the hot path
+            o += n
+        self.numel = total
+
+    def rebind(self):
+        """Re-attach .data/.grad views (after something replaced them, e.g. module.to())."""
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            if p.data.data_ptr() != self.flat[o:o + n].data_ptr():
+                self.flat[o:o + n].view_as(p).copy_(p.data)
+                p.data = self.flat[o:o + n].view_as(p)
+            p.grad = self.grad[o:o + n].view_as(p)
+            o += n
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """Adam over a FlatParams.  A torch Optimizer subclass only so that the reference's LR
+    schedulers (networks.get_scheduler) can drive `param_groups[0]["lr"]`; the update itself
+    is one vts_adam_flat launch."""
+
+    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps))
+        self.flat = flat
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        # gradients are overwritten (not accumulated) by the first backward of every step
+        pass
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0, closure=None):
+        self.step_count += 1
+        g = self.param_groups[0]
+        ops.adam_flat(self.flat.flat, self.flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                      self.step_count, grad_scale)
+
+    def load_named_state(self, module, m_by_name, v_by_name, step):
+        """Load per-parameter Adam moments keyed by state_dict names (resume / parity tests)."""
+        o = 0
+        names = {id(p): k for k, p in module.named_parameters()}
+        for p in self.flat.params:
+            n = p.numel()
+            k = names[id(p)]
+            if k in m_by_name:
+                self.m[o:o + n].copy_(m_by_name[k].reshape(-1))
+                self.v[o:o + n].copy_(v_by_name[k].reshape(-1))
+            o += n
+        self.step_count = int(step)
+
+    def flat_state(self):
+        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
+
+    def load_flat_state(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
