@@ -1,0 +1,196 @@
+"""Headline benchmark: train images/sec of one full G+D step at 1024x1024 (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A step = SKITGModel.optimize_parameters on one synthetic batch (4 images / GPU, 64 tactile
+patches each) that is already resident in HBM: generator forward, patch gather, D1 update,
+D2 update (incl. the reference's full-resolution visualisation pass), G update, three fused
+Adam steps.  LPIPS / CLIP terms are off (their weights cannot exist offline; stated in `config`).
+Rank 0 prints ONE JSON line with the extra `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "visual-tactile-synthesis_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_16x16x4_f32)
+
+
+def build_model(size, batch, model_name, quiet=True):
+    import contextlib
+    import io
+
+    from models import create_model
+    from options.train_options import TrainOptions
+
+    flags = ("--model %s --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
+             "--checkpoints_dir /tmp/vts_bench --name bench --crop_size %d --batch_size %d" % (model_name, size, batch))
+    ctx = contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()
+    with ctx:
+        opt = TrainOptions(cmd_line=flags).parse()
+        opt.gpu_ids = [torch.cuda.current_device()]
+        model = create_model(opt)
+        model.setup(opt)
+        model.parallelize()
+        model.train()
+    return model, opt
+
+
+def make_batch(size, batch, rank, style_dim):
+    from torch.utils.data import default_collate
+
+    from data.synthetic_dataset import make_sample
+
+    return default_collate([make_sample(size, 64, 64, 1234 + 100003 * rank + i, style_dim=style_dim) for i in range(batch)])
+
+
+def kernel_roofline(model, batch_dict):
+    """One extra (untimed-for-throughput) step with HIP events around every launch, on the launch stream."""
+    from vts import ops
+
+    ops.TIMER = []
+    model.optimize_parameters(epoch=1)
+    torch.cuda.synchronize()
+    rec, ops.TIMER = ops.TIMER, None
+    agg = {}
+    for label, nbytes, flops, e0, e1 in rec:
+        a = agg.setdefault(label, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += nbytes
+        a[3] += flops
+    total = sum(a[1] for a in agg.values())
+    label, (cnt, t, nbytes, flops) = max(agg.items(), key=lambda kv: kv[1][1])
+    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
+    if t_hbm >= t_mfma:
+        roof = {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    else:
+        roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    roof["kernel"] = label
+    roof["launches_per_step"] = cnt
+    roof["avg_launch_us"] = t / cnt * 1e6
+    roof["algorithmic_bytes_per_launch"] = nbytes / cnt
+    roof["algorithmic_flops_per_launch"] = flops / cnt
+    roof["share_of_timed_kernels"] = t / total
+    breakdown = sorted(((k, v[1] * 1e3, v[0]) for k, v in agg.items()), key=lambda x: -x[1])
+    roof["breakdown_ms"] = {k: round(ms, 3) for k, ms, _ in breakdown[:8]}
+    return roof
+
+
+def cpu_baseline(size, style_dim, steps=3):
+    """The CPU oracle (PyTorch-CPU restatement pinned to the reference) on this host's cores, N=1."""
+    from torch.utils.data import default_collate
+
+    from data.synthetic_dataset import make_sample
+    from oracle import detrand, nets, step
+
+    # PyTorch-CPU convolutions with 3..160 channels stop scaling (and collapse from oversubscription) well
+    # before a 256-thread host is full: 16 threads is near the best rate for this workload.
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sd = (detrand.test_weights(nets.g_param_shapes(style_nc=style_dim), 1), detrand.test_weights(nets.d_param_shapes(4), 2),
+          detrand.test_weights(nets.d_param_shapes(7), 3))
+    batch = default_collate([make_sample(size, 64, 64, 99, style_dim=style_dim)])
+    import random
+
+    random.seed(0)
+    cnt = int(nets.dilated_mask_positions(batch["M"].float()).shape[0])
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    style = batch.get("style_code")
+    times = []
+    for it in range(steps + 1):
+        draws = {"aug": torch.rand(4, 1), "more_idx": torch.tensor([random.sample(range(cnt), 32)])}
+        t0 = time.time()
+        step.train_step(sd[0], sd[1], sd[2], adam, batch, draws, style_code=style, record=False)
+        times.append(time.time() - t0)
+        if it >= 1 and sum(times) > 45.0:   # keep the default run bounded
+            break
+    steps = max(1, len(times) - 1)
+    t = sum(times[1:]) / steps if len(times) > 1 else times[0]
+    return {"value": 1.0 / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d oracle train steps after 1 warm-up, N=1, %dx%d, same flags" % (steps, size, size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--model", type=str, default="skitG")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    from vts import ddp
+
+    rank, world = ddp.init_from_env("cuda")
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model, opt = build_model(args.size, args.batch, args.model)
+    style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
+    batch = make_batch(args.size, args.batch, rank, style_dim)
+    model.set_input(batch, phase="train")       # H2D once: inputs are resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.optimize_parameters(epoch=1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.optimize_parameters(epoch=1)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.get_current_losses()
+    finite = all(v == v and abs(v) < 1e30 for v in losses.values())
+
+    if rank == 0:
+        roof = kernel_roofline(model, batch) if world == 1 else None
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.size, style_dim)
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "train_images_per_sec", "value": world * args.batch * args.steps / dt, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
+                            "LPIPS/CLIP terms off (no weights offline)" % (args.model, args.size, args.size, args.batch),
+                "global_batch": world * args.batch, "parallelism": "dp%d" % world, "losses_finite": finite,
+            },
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    elif world > 1:
+        pass
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

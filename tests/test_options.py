@@ -1,0 +1,66 @@
+"""Flags round-trip: names, types and defaults equal the reference's parser for both models and
+both phases (fixture: tests/golden/ref_option_defaults.json, dumped from the reference's argparse)."""
+import contextlib
+import io
+import json
+import os
+
+import pytest
+
+
+def parse(cls, cmd):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return cls(cmd_line=cmd).parse()
+
+
+@pytest.mark.parametrize("model", ["sinskitG", "skitG"])
+@pytest.mark.parametrize("phase", ["train", "test"])
+def test_defaults_match_reference(golden_dir, model, phase):
+    from options.test_options import TestOptions
+    from options.train_options import TrainOptions
+
+    ref = json.load(open(os.path.join(golden_dir, "ref_option_defaults.json")))["%s_%s" % (model, phase)]
+    opt = parse(TrainOptions if phase == "train" else TestOptions, "--model %s --gpu_ids -1 --checkpoints_dir /tmp/vts_opt" % model)
+    for k, v in ref.items():
+        if k in ("gpu_ids", "checkpoints_dir"):
+            continue
+        assert hasattr(opt, k), k
+        d = float("inf") if v["default"] == "inf" else v["default"]
+        assert getattr(opt, k) == d or str(getattr(opt, k)) == str(d), (k, getattr(opt, k), d)
+    assert opt.gpu_ids == []
+
+
+def test_quirks_kept():
+    from options.train_options import TrainOptions
+
+    # unknown flags are ignored; prefix abbreviation works (--dataset -> --dataset_mode); str2bool parsing
+    opt = parse(TrainOptions, "--model sinskitG --gpu_ids -1 --no_such_flag 3 --dataset synthetic --use_diffaug false "
+                              "--smooth_GAN_label --checkpoints_dir /tmp/vts_opt --suffix x{ngf}")
+    assert opt.dataset_mode == "synthetic" and opt.use_diffaug is False and opt.smooth_GAN_label is True
+    assert opt.name.endswith("_x10")
+    assert os.path.exists("/tmp/vts_opt/%s/train_opt.txt" % opt.name)
+
+
+def test_unbuilt_third_party_terms_raise():
+    from models.sinskitG_model import SinSKITGModel
+    from options.train_options import TrainOptions
+
+    opt = parse(TrainOptions, "--model sinskitG --gpu_ids 0 --checkpoints_dir /tmp/vts_opt")
+    with pytest.raises(NotImplementedError, match="LPIPS"):
+        SinSKITGModel._check_unbuilt_terms(opt)
+
+
+def test_synthetic_dataset_contract():
+    from data import create_dataset
+    from options.train_options import TrainOptions
+
+    opt = parse(TrainOptions, "--model skitG --gpu_ids -1 --crop_size 64 --batch_size 2 --data_len 4 --checkpoints_dir /tmp/vts_opt")
+    ds = create_dataset(opt)
+    assert len(ds) == 4
+    b = next(iter(ds))
+    assert b["S"].shape == (2, 1, 64, 64) and b["I"].shape == (2, 3, 64, 64) and b["M"].shape == (2, 1, 64, 64)
+    assert b["T_images"].shape == (2, 64, 2, 32, 32) and b["T_coords"].shape == (2, 64, 8) and b["I_masks"].shape == (2, 64, 32, 32)
+    assert b["T_coords"].dtype.is_floating_point and float(b["M"].max()) == 1.0
+    assert b["style_code"].shape == (2, 512)
+    assert abs(float(b["style_code"][0].norm()) - 1) < 1e-5
+    assert set(b["augmentation_params"]) >= {"H", "W", "scale_factor_h", "crop_pos_x", "resize_ratio_w"}

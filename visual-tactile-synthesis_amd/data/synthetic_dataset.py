@@ -30,7 +30,7 @@ def _box_blur(a, k):
     return a
 
 
-def make_sample(size, nt, nt_val, seed, patch=32):
+def make_sample(size, nt, nt_val, seed, patch=32, style_dim=0):
     """One un-collated sample dict.  Deterministic in (size, nt, nt_val, seed)."""
     g = np.random.default_rng(seed)
     H = W = int(size)
@@ -69,7 +69,12 @@ def make_sample(size, nt, nt_val, seed, patch=32):
         "crop_pos_x": 0, "crop_pos_y": 0, "resize_ratio_w": 1.0, "resize_ratio_h": 1.0,
         "patch_crop_size": patch,
     }
+    extra = {}
+    if style_dim:
+        sc = np.random.default_rng(seed + 7919).normal(0.0, 1.0, style_dim)
+        extra["style_code"] = torch.from_numpy((sc / np.linalg.norm(sc)).astype(np.float32))
     return {
+        **extra,
         "S": torch.from_numpy(S), "I": torch.from_numpy(I), "M": torch.from_numpy(M),
         "name": "synthetic_%d" % seed, "S_paths": "synthetic/%d.png" % seed, "M_paths": "synthetic/%d_mask.png" % seed,
         "T_images": T, "T_coords": C, "I_masks": K, "full_T_coords": C.copy(),
@@ -95,6 +100,7 @@ class SyntheticDataset(torch.utils.data.Dataset):
         self.nt = int(getattr(opt, "batch_size_G2", 64))
         self.nt_val = int(getattr(opt, "batch_size_G2_val", self.nt)) if opt.isTrain else self.nt
         self.rank = int(getattr(opt, "rank", 0))
+        self.style_dim = int(getattr(opt, "style_code_dim", 0)) if getattr(opt, "use_style_code", False) else 0
         self.current_epoch = 0
         self._cache = {}
 
@@ -105,6 +111,6 @@ class SyntheticDataset(torch.utils.data.Dataset):
         seed = self.opt.data_seed + 100003 * self.rank + index
         if getattr(self.opt, "cache_samples", True):
             if index not in self._cache:
-                self._cache[index] = make_sample(self.size, self.nt, self.nt_val, seed)
+                self._cache[index] = make_sample(self.size, self.nt, self.nt_val, seed, style_dim=self.style_dim)
             return self._cache[index]
-        return make_sample(self.size, self.nt, self.nt_val, seed)
+        return make_sample(self.size, self.nt, self.nt_val, seed, style_dim=self.style_dim)

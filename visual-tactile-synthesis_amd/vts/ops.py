@@ -26,6 +26,28 @@ class Act:
         return L.operand(self.data, self.scale, self.shift)
 
 
+# When TIMER is a list, every wrapper brackets its launch with HIP events recorded on the launch
+# stream and appends (label, algorithmic_bytes, algorithmic_flops, start, end).  bench.py uses this
+# for its live per-kernel roofline; it is off (None) on the product path.
+TIMER = None
+
+
+def _run(label, nbytes, flops, fn, *args):
+    if TIMER is None:
+        L.check(fn(*args), label)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    L.check(rc, label)
+    TIMER.append((label, nbytes, flops, e0, e1))
+
+
+def _numel(op):
+    return 0
+
+
 _ws = {}
 
 
@@ -69,7 +91,13 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     d.dmask = _op(dmask)
     d.dmask_act = dmask_act
     d.accumulate = int(accumulate)
-    L.check(lib.vts_conv4x4(C.byref(d), L.stream()), "vts_conv4x4")
+    cin = d.in0.C + d.in1.C
+    taps = 4 if (transposed and stride == 2) else 16
+    flops = 2.0 * d.N * d.OH * d.OW * cout * cin * taps
+    nbytes = 4.0 * (d.N * cin * d.IH * d.IW + d.N * cout * d.OH * d.OW * (1 + (dmask is not None) + bool(accumulate))
+                    + cout * cin * 16)
+    label = "conv4x4<%s,s%d,nr%d>" % ("convT" if transposed else "conv", stride, (cout + 15) // 16)
+    _run(label, nbytes, flops, lib.vts_conv4x4, C.byref(d), L.stream())
     return out
 
 
@@ -86,7 +114,10 @@ def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, 
     d.accumulate = int(accumulate)
     n = lib.vts_wgrad4x4_ws_floats(C.byref(d))
     ws = workspace(n, lo.device)
-    L.check(lib.vts_wgrad4x4(C.byref(d), ws.data_ptr(), L.stream()), "vts_wgrad4x4")
+    cl, chn = d.lo0.C + d.lo1.C, d.hi0.C + d.hi1.C
+    flops = 2.0 * d.N * d.LH * d.LW * cl * chn * 16
+    nbytes = 4.0 * (d.N * cl * d.LH * d.LW + d.N * chn * d.HH * d.HW + cl * chn * 16)
+    _run("wgrad4x4<s%d>" % stride, nbytes, flops, lib.vts_wgrad4x4, C.byref(d), ws.data_ptr(), L.stream())
     return dw
 
 
@@ -94,8 +125,8 @@ def channel_sum(x, out, accumulate=False):
     lib = L.load()
     n, c, h, w = x.shape
     ws = workspace(lib.vts_channel_sum_ws_floats(n, c, h * w), x.device)
-    L.check(lib.vts_channel_sum(x.data_ptr(), x.stride(0), n, c, h * w, out.data_ptr(), int(accumulate), ws.data_ptr(),
-                                L.stream()), "vts_channel_sum")
+    _run("channel_sum", 4.0 * n * c * h * w, 0.0, lib.vts_channel_sum, x.data_ptr(), x.stride(0), n, c, h * w, out.data_ptr(),
+         int(accumulate), ws.data_ptr(), L.stream())
     return out
 
 
@@ -112,7 +143,7 @@ def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var
     d.running_mean, d.running_var, d.num_batches_tracked = L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt)
     d.scale, d.shift, d.mean_out, d.rstd_out = st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr()
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), x.device)
-    L.check(lib.vts_norm_stats(C.byref(d), ws.data_ptr(), L.stream()), "vts_norm_stats")
+    _run("norm_stats", 4.0 * n * c * h * w, 0.0, lib.vts_norm_stats, C.byref(d), ws.data_ptr(), L.stream())
     return Act(x, st[0], st[1], st[2], st[3])
 
 
@@ -126,7 +157,7 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
     d.gamma, d.dgamma, d.dbeta = L.ptr(gamma), L.ptr(dgamma), L.ptr(dbeta)
     d.accumulate_param_grads = int(accumulate)
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
-    L.check(lib.vts_norm_bwd(C.byref(d), ws.data_ptr(), L.stream()), "vts_norm_bwd")
+    _run("norm_bwd", 4.0 * n * c * h * w * 5, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
     return dy
 
 
