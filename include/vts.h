@@ -81,7 +81,11 @@ typedef struct vts_conv_desc {
   vts_operand dmask; /* data == NULL: no mask */
   int dmask_act;
   int accumulate;
+  float* ws;          /* optional scratch for the small-grid k-split path (may be NULL: path not taken) */
+  int64_t ws_floats;  /* vts_conv4x4_ws_floats(d) is always enough */
 } vts_conv_desc;
+
+int64_t vts_conv4x4_ws_floats(const vts_conv_desc* d);
 
 int vts_conv4x4(const vts_conv_desc* d, void* stream);
 

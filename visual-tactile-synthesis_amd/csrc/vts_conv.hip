@@ -37,6 +37,9 @@ struct ConvK {
   int64_t dmns;
   int dm_act, dmC;
   int accumulate;
+  // small-grid decomposition: blockIdx.z = n + N * (cout_group + CG * k_slice)
+  int N, CG, cps;   // cps = input-channel chunks per k-slice
+  float* part;      // k-split partial sums [KS][N][Cout][OH][OW] (raw accumulators), or nullptr
 };
 
 template <int MODE, int S, int NR, int RW, int MT, int CK>
@@ -55,7 +58,9 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, kq = lane >> 4;
-  const int n = blockIdx.z;
+  const int n = blockIdx.z % p.N;
+  const int cg = (blockIdx.z / p.N) % p.CG, ks = blockIdx.z / (p.N * p.CG);
+  const int co0 = cg * NR * 16;
   const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
   const int podd = p.pad & 1;
 
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
 
   const int64_t plane = (int64_t)p.IH * p.IW;
   const int nchunks = (p.Cin + CK - 1) / CK;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  const int chunk_end = min(nchunks, (ks + 1) * p.cps);
+  for (int chunk = ks * p.cps; chunk < chunk_end; ++chunk) {
     const int cbase = chunk * CK;
     // ---- stage the input patch (normalise + activate + concat on load) ----
     auto row_setup = [&](int rr, const float*& src, float& sc, float& sh) -> bool {
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         }
         const int ci = cbase + c;
         float v = 0.f;
-        if (co < p.Cout && ci < p.Cin) v = p.w[(int64_t)co * p.ws_co + (int64_t)ci * p.ws_ci + tap];
+        if (co0 + co < p.Cout && ci < p.Cin) v = p.w[(int64_t)(co0 + co) * p.ws_co + (int64_t)ci * p.ws_ci + tap];
         lds_w[(c * 16 + slot) * COP + co] = v;
       }
     }
@@ -222,8 +228,28 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   const int64_t oplane = (int64_t)p.OH * p.OW;
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
-    const int co = nr * 16 + m16;
+    const int co = co0 + nr * 16 + m16;
     if (co >= p.Cout) continue;
+    if (p.part) {  // k-split: raw accumulators, the epilogue runs in conv_split_epilogue_kernel
+      float* pb = p.part + (((int64_t)ks * p.N + n) * p.Cout + co) * oplane;
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int ph = 0; ph < P; ++ph) {
+            const int gy = ty0 + wave * RW + r;
+            const int y = (P == 4) ? gy * 2 + (ph >> 1) : gy;
+            if (y >= p.OH) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int gx = tx0 + mt * 16 + kq * 4 + j;
+              const int x = (P == 4) ? gx * 2 + (ph & 1) : gx;
+              if (x < p.OW) pb[(int64_t)y * p.OW + x] = acc[r][mt][ph][nr][j];
+            }
+          }
+      continue;
+    }
     const float bias = p.bias ? p.bias[co] : 0.f;
     float dsc = 1.f, dsh = 0.f;
     if (p.dm) {
@@ -257,17 +283,51 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   }
 }
 
+// sums the k-split partials in slice order and applies the epilogue of the main kernel
+__global__ __launch_bounds__(256) void conv_split_epilogue_kernel(const ConvK p, int KS) {
+  const int co = blockIdx.y, n = blockIdx.z;
+  const int64_t oplane = (int64_t)p.OH * p.OW;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= oplane) return;
+  float v = 0.f;
+  for (int ks = 0; ks < KS; ++ks) v += p.part[(((int64_t)ks * p.N + n) * p.Cout + co) * oplane + o];
+  v += p.bias ? p.bias[co] : 0.f;
+  if (p.act_out == VTS_ACT_TANH) v = tanhf(v);
+  if (p.dm) {
+    const float dsc = p.dmsc ? p.dmsc[n * p.dmC + co] : 1.f, dsh = p.dmsh ? p.dmsh[n * p.dmC + co] : 0.f;
+    v *= vts_act_grad(p.dm[n * p.dmns + co * oplane + o] * dsc + dsh, p.dm_act);
+  }
+  float* ob = p.out + n * p.ons + co * oplane + o;
+  *ob = p.accumulate ? *ob + v : v;
+}
+
 template <int MODE, int S, int NR, int RW, int MT, int CK>
-int launch(const ConvK& k, int N, hipStream_t st) {
+int launch(const ConvK& k, int N, hipStream_t st, int CG = 1, int KS = 1) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
   const int GH = P == 4 ? (k.OH + 1) / 2 : k.OH, GW = P == 4 ? (k.OW + 1) / 2 : k.OW;
-  dim3 grid(cdiv(GW, 16 * MT), cdiv(GH, 4 * RW), N);
+  dim3 grid(cdiv(GW, 16 * MT), cdiv(GH, 4 * RW), N * CG * KS);
   hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK>), grid, dim3(256), 0, st, k);
   VTS_CHECK_LAUNCH("vts_conv4x4");
   return VTS_OK;
 }
 
+// tile shape (RW, MT) of the full-width variants, as instantiated by VTS_DISPATCH below
+inline void full_tile(int transposed, int stride, int nr, int& rw, int& mt) {
+  static const int T[2][2][5][2] = {
+      {{{2, 4}, {1, 4}, {1, 4}, {1, 2}, {1, 2}}, {{2, 4}, {1, 4}, {1, 4}, {1, 2}, {1, 2}}},   // conv   s1, s2
+      {{{2, 4}, {1, 4}, {1, 4}, {1, 2}, {1, 2}}, {{1, 4}, {1, 2}, {1, 2}, {1, 1}, {1, 1}}}};  // convT  s1, s2
+  rw = T[transposed][stride - 1][nr - 1][0];
+  mt = T[transposed][stride - 1][nr - 1][1];
+}
+
 }  // namespace
+
+extern "C" int64_t vts_conv4x4_ws_floats(const vts_conv_desc* d) {
+  if (!d) return 0;
+  const int nchunks = (d->in0.C + (d->in1.data ? d->in1.C : 0) + 3) / 4;
+  const int ks_max = nchunks / 2 < 1 ? 1 : (nchunks / 2 > 320 ? 320 : nchunks / 2);
+  return (int64_t)ks_max * d->N * d->Cout * d->OH * d->OW;
+}
 
 extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   VTS_CHECK_ARG(d && d->in0.data && d->w && d->out, "vts_conv4x4: null pointer");
@@ -297,9 +357,39 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.dm = d->dmask.data; k.dmsc = d->dmask.scale; k.dmsh = d->dmask.shift; k.dmns = d->dmask.nstride;
   k.dm_act = d->dmask_act; k.dmC = d->dmask.C;
   k.accumulate = d->accumulate;
+  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int nr = (d->Cout + 15) / 16;
   const int N = d->N;
+  {
+    // Small grids (inner U-Net layers: <= 32x32 maps, 80..592 channels) cannot fill 256 CUs with one
+    // workgroup per spatial tile: split the output channels over workgroups (no reduction needed) and,
+    // if that is still too few, the input-channel loop (k-split, deterministic two-kernel reduction).
+    int rw, mt;
+    full_tile(d->transposed, d->stride, nr, rw, mt);
+    const bool ph4 = d->transposed && d->stride == 2;
+    const int GH = ph4 ? (d->OH + 1) / 2 : d->OH, GW = ph4 ? (d->OW + 1) / 2 : d->OW;
+    const int full_wgs = cdiv(GW, 16 * mt) * cdiv(GH, 4 * rw) * N;
+    const int nchunks = (k.Cin + 3) / 4;
+    if (full_wgs < 128 && (nr > 1 || nchunks >= 8)) {
+      const int base = cdiv(GW, 32) * cdiv(GH, 4) * N * nr;
+      int KS = 320 / base;
+      if (KS > nchunks / 2) KS = nchunks / 2;
+      if (KS < 1) KS = 1;
+      int cps = cdiv(nchunks, KS);
+      KS = cdiv(nchunks, cps);
+      const int64_t need = (int64_t)KS * N * d->Cout * d->OH * d->OW;
+      if (KS > 1 && (!d->ws || d->ws_floats < need)) { KS = 1; cps = nchunks; }
+      k.CG = nr; k.cps = cps; k.part = KS > 1 ? d->ws : nullptr;
+      int rc;
+      if (!d->transposed) rc = d->stride == 2 ? launch<0, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<0, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
+      else rc = d->stride == 2 ? launch<1, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<1, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
+      if (rc != VTS_OK || KS == 1) return rc;
+      hipLaunchKernelGGL(conv_split_epilogue_kernel, dim3((unsigned)cdiv64((int64_t)d->OH * d->OW, 256), d->Cout, N), dim3(256), 0, st, k, KS);
+      VTS_CHECK_LAUNCH("vts_conv4x4 split epilogue");
+      return VTS_OK;
+    }
+  }
 #define VTS_DISPATCH(MODE, S, RW1, MT1, RW2, MT2, RW3, MT3, RW4, MT4, RW5, MT5) \
   switch (nr) {                                                                 \
     case 1: return launch<MODE, S, 1, RW1, MT1, 4>(k, N, st);                   \

@@ -142,12 +142,24 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int pw, float* __restrict__ dw, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// Fixed-order sum of the PW partials.  64 consecutive elements per workgroup (one coalesced 256-B
+// row per wave-load), 16 waves each summing every 16th partial, combined through LDS in wave order.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int pw, float* __restrict__ dw,
+                                                            int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int k = 0; k < pw; ++k) s += part[(int64_t)k * n + i];
-  dw[i] = accumulate ? dw[i] + s : s;
+  if (i < n)
+    for (int k = w; k < pw; k += 16) s += part[(int64_t)k * n + i];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
 }
 
 struct Plan {
@@ -166,6 +178,9 @@ Plan make_plan(const vts_wgrad_desc* d) {
   pl.ntiles = d->N * pl.tiles_y * pl.tiles_x;
   const int groups = pl.cl_groups * pl.ch_groups;
   int pw = 1024 / groups;
+  const int64_t nel = (int64_t)CL * CH * 16;
+  const int64_t cap = (4 << 20) / nel;  // keep the partial buffer around <= 16 MB
+  if (pw > cap) pw = (int)cap;
   if (pw < 1) pw = 1;
   if (pw > pl.ntiles) pw = pl.ntiles;
   pl.pw = pw;
@@ -217,7 +232,7 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   WG_CASE(1, 1, 4) WG_CASE(1, 1, 10) WG_CASE(1, 2, 4) WG_CASE(1, 2, 10) WG_CASE(1, 3, 4) WG_CASE(1, 3, 10) WG_CASE(1, 5, 4)
 #undef WG_CASE
   VTS_CHECK_LAUNCH("vts_wgrad4x4");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, st, ws, nel, pl.pw, d->dw,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 64)), dim3(1024), 0, st, ws, nel, pl.pw, d->dw,
                      d->accumulate);
   VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
   return VTS_OK;

@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("bias", C.c_void_p), ("out", C.c_void_p), ("out_nstride", C.c_int64),
         ("act_in", C.c_int), ("act_out", C.c_int),
         ("dmask", Operand), ("dmask_act", C.c_int), ("accumulate", C.c_int),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 
@@ -68,7 +69,7 @@ _lib = None
 
 # every symbol include/vts.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
-    "vts_last_error", "vts_version", "vts_conv4x4", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_channel_sum",
+    "vts_last_error", "vts_version", "vts_conv4x4", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_channel_sum",
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
@@ -87,8 +88,9 @@ def load():
             "or `make -C visual-tactile-synthesis_amd/csrc`.  There is no fallback path." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.vts_last_error.restype = C.c_char_p
-    for name in ("vts_wgrad4x4_ws_floats", "vts_norm_ws_floats", "vts_channel_sum_ws_floats"):
+    for name in ("vts_wgrad4x4_ws_floats", "vts_norm_ws_floats", "vts_channel_sum_ws_floats", "vts_conv4x4_ws_floats"):
         getattr(lib, name).restype = C.c_int64
+    lib.vts_conv4x4_ws_floats.argtypes = [C.POINTER(ConvDesc)]
     lib.vts_norm_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.vts_channel_sum_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     vp, i, i64, f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -91,6 +91,10 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     d.dmask = _op(dmask)
     d.dmask_act = dmask_act
     d.accumulate = int(accumulate)
+    if d.OH * d.OW <= 64 * 64:  # only small maps can take the k-split path; scratch is the shared workspace
+        need = lib.vts_conv4x4_ws_floats(C.byref(d))
+        ws = workspace(need, x.device)
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     cin = d.in0.C + d.in1.C
     taps = 4 if (transposed and stride == 2) else 16
     flops = 2.0 * d.N * d.OH * d.OW * cout * cin * taps
