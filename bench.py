@@ -55,7 +55,7 @@ def make_batch(size, batch, rank, style_dim):
     return default_collate([make_sample(size, 64, 64, 1234 + 100003 * rank + i, style_dim=style_dim) for i in range(batch)])
 
 
-def kernel_roofline(model, batch_dict):
+def kernel_roofline(model, batch_dict, detail_path=None):
     """One extra (untimed-for-throughput) step with HIP events around every launch, on the launch stream."""
     from vts import ops
 
@@ -63,13 +63,26 @@ def kernel_roofline(model, batch_dict):
     model.optimize_parameters(epoch=1)
     torch.cuda.synchronize()
     rec, ops.TIMER = ops.TIMER, None
-    agg = {}
-    for label, nbytes, flops, e0, e1 in rec:
+    agg, det = {}, {}
+    for label, nbytes, flops, e0, e1, detail in rec:
+        dt = e0.elapsed_time(e1) * 1e-3
         a = agg.setdefault(label, [0, 0.0, 0.0, 0.0])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[1] += dt
         a[2] += nbytes
         a[3] += flops
+        if detail_path and detail:
+            b = det.setdefault(label + " | " + detail, [0, 0.0, 0.0, 0.0])
+            b[0] += 1
+            b[1] += dt
+            b[2] += nbytes
+            b[3] += flops
+    if detail_path:
+        rows = sorted(det.items(), key=lambda kv: -kv[1][1])
+        with open(detail_path, "w") as f:
+            f.write("# launches  total_ms  avg_us  achieved_TFLOP/s  achieved_GB/s  kernel | shape\n")
+            for k, (c, t, nb, fl) in rows:
+                f.write("%4d %8.3f %8.1f %8.2f %8.1f  %s\n" % (c, t * 1e3, t / c * 1e6, fl / t / 1e12, nb / t / 1e9, k))
     total = sum(a[1] for a in agg.values())
     label, (cnt, t, nbytes, flops) = max(agg.items(), key=lambda kv: kv[1][1])
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
@@ -133,6 +146,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU")
     ap.add_argument("--model", type=str, default="skitG")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--detail", type=str, default=None, help="write a per-(kernel, shape) timing table to this path")
     args = ap.parse_args()
 
     from vts import ddp
@@ -168,7 +182,14 @@ def main():
     finite = all(v == v and abs(v) < 1e30 for v in losses.values())
 
     if rank == 0:
-        roof = kernel_roofline(model, batch) if world == 1 else None
+        roof = kernel_roofline(model, batch, args.detail) if world == 1 else None
+        if roof is not None:
+            # host enqueue time of one step (no sync): tells whether the step is launch-bound
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            model.optimize_parameters(epoch=1)
+            roof["host_enqueue_ms"] = (time.perf_counter() - th) * 1e3
+            torch.cuda.synchronize()
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.size, style_dim)

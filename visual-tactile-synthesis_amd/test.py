@@ -1,0 +1,46 @@
+"""Headless inference entry point with the reference test.py's control flow
+(/root/reference/test.py:31-116): load `<epoch>_net_G.pth`, forward every test item, time it.
+
+    python test.py --model sinskitG --gpu_ids 0 --dataset_mode synthetic --crop_size 1024 --epoch latest --eval
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+
+from data import create_dataset  # noqa: E402
+from models import create_model  # noqa: E402
+from options.test_options import TestOptions  # noqa: E402
+
+if __name__ == "__main__":
+    opt = TestOptions().parse()
+    opt.num_threads = 0
+    opt.batch_size = max(1, opt.batch_size)
+    opt.serial_batches = True
+    opt.no_flip = True
+    opt.rank = 0
+    dataset = create_dataset(opt)
+    model = create_model(opt)
+    out_dir = os.path.join(opt.results_dir, opt.name, "%s_%s" % (opt.phase, opt.epoch))
+    os.makedirs(out_dir, exist_ok=True)
+    for i, data in enumerate(dataset):
+        if i == 0:
+            model.setup(opt)
+            model.parallelize()
+            if opt.eval:
+                model.eval()
+        if i >= opt.num_test:
+            break
+        model.set_input(data, phase="test")
+        torch.cuda.synchronize()
+        t0 = time.time()
+        model.test(timing=True)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        visuals = model.get_current_visuals()
+        name = data["name"][0] if isinstance(data["name"], (list, tuple)) else data["name"]
+        torch.save({k: v.detach().cpu() for k, v in visuals.items() if torch.is_tensor(v)}, os.path.join(out_dir, "%s.pt" % name))
+        print("processed %s in %.2f ms (%d images)" % (name, dt * 1e3, data["S"].size(0)))

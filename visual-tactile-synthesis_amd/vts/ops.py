@@ -32,7 +32,11 @@ class Act:
 TIMER = None
 
 
+DETAIL = None  # shape string of the launch being issued (only filled while TIMER is on)
+
+
 def _run(label, nbytes, flops, fn, *args):
+    global DETAIL
     if TIMER is None:
         L.check(fn(*args), label)
         return
@@ -41,7 +45,8 @@ def _run(label, nbytes, flops, fn, *args):
     rc = fn(*args)
     e1.record()
     L.check(rc, label)
-    TIMER.append((label, nbytes, flops, e0, e1))
+    TIMER.append((label, nbytes, flops, e0, e1, DETAIL))
+    DETAIL = None
 
 
 def _numel(op):
@@ -101,6 +106,10 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     nbytes = 4.0 * (d.N * cin * d.IH * d.IW + d.N * cout * d.OH * d.OW * (1 + (dmask is not None) + bool(accumulate))
                     + cout * cin * 16)
     label = "conv4x4<%s,s%d,nr%d>" % ("convT" if transposed else "conv", stride, (cout + 15) // 16)
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d p%d%s%s" % (d.N, cin, d.IH, d.IW, cout, d.OH, d.OW, pad, " dmask" if dmask is not None else "",
+                                                      " acc" if accumulate else "")
     _run(label, nbytes, flops, lib.vts_conv4x4, C.byref(d), L.stream())
     return out
 
@@ -121,6 +130,9 @@ def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, 
     cl, chn = d.lo0.C + d.lo1.C, d.hi0.C + d.hi1.C
     flops = 2.0 * d.N * d.LH * d.LW * cl * chn * 16
     nbytes = 4.0 * (d.N * cl * d.LH * d.LW + d.N * chn * d.HH * d.HW + cl * chn * 16)
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d lo %dx%dx%d hi %dx%dx%d p%d" % (d.N, cl, d.LH, d.LW, chn, d.HH, d.HW, pad)
     _run("wgrad4x4<s%d>" % stride, nbytes, flops, lib.vts_wgrad4x4, C.byref(d), ws.data_ptr(), L.stream())
     return dw
 
