@@ -59,10 +59,12 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     """One extra (untimed-for-throughput) step with HIP events around every launch, on the launch stream."""
     from vts import ops
 
+    graph_flag, model.opt.use_hip_graph = model.opt.use_hip_graph, False   # per-launch events need eager launches
     ops.TIMER = []
     model.optimize_parameters(epoch=1)
     torch.cuda.synchronize()
     rec, ops.TIMER = ops.TIMER, None
+    model.opt.use_hip_graph = graph_flag
     agg, det = {}, {}
     for label, nbytes, flops, e0, e1, detail in rec:
         dt = e0.elapsed_time(e1) * 1e-3
@@ -146,6 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU")
     ap.add_argument("--model", type=str, default="skitG")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--detail", type=str, default=None, help="write a per-(kernel, shape) timing table to this path")
     args = ap.parse_args()
 
@@ -157,6 +160,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     dev = torch.device("cuda", torch.cuda.current_device())
     model, opt = build_model(args.size, args.batch, args.model)
+    opt.use_hip_graph = not args.no_graph
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
     batch = make_batch(args.size, args.batch, rank, style_dim)
     model.set_input(batch, phase="train")       # H2D once: inputs are resident in HBM before the timed region
@@ -185,11 +189,14 @@ def main():
         roof = kernel_roofline(model, batch, args.detail) if world == 1 else None
         if roof is not None:
             # host enqueue time of one step (no sync): tells whether the step is launch-bound
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            model.optimize_parameters(epoch=1)
-            roof["host_enqueue_ms"] = (time.perf_counter() - th) * 1e3
-            torch.cuda.synchronize()
+            for key, flag in (("host_enqueue_ms_eager", False), ("host_enqueue_ms", model.opt.use_hip_graph)):
+                keep, model.opt.use_hip_graph = model.opt.use_hip_graph, flag
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                model.optimize_parameters(epoch=1)
+                roof[key] = (time.perf_counter() - th) * 1e3
+                torch.cuda.synchronize()
+                model.opt.use_hip_graph = keep
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.size, style_dim)
@@ -202,6 +209,7 @@ def main():
                 "workload": "%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
                             "LPIPS/CLIP terms off (no weights offline)" % (args.model, args.size, args.size, args.batch),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world, "losses_finite": finite,
+                "hip_graph": bool(opt.use_hip_graph),
             },
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -221,6 +221,11 @@ int vts_mask_select(const uint8_t* cand, const int* row_prefix, int N, int H, in
 int vts_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   int step_count, float grad_scale, void* stream);
 
+/* Same update with the 1-based step counter and the learning rate read from device memory
+ * (*step_dev, *lr_dev), so a captured HIP graph of the step stays valid across iterations. */
+int vts_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                      float eps, const int* step_dev, float grad_scale, void* stream);
+
 /* PatchNCE loss forward+backward (models/patchnce.py:13-55): B groups of P patches, dim D.
  * loss[b*P+i] = CE([q_i.k_i, q_i.k_j (j != i; diagonal -> -10)] / T, 0); dq = d sum(loss*gscale) / dq. */
 int vts_patchnce(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq,

@@ -205,3 +205,42 @@ def test_inference_forward_matches_oracle_and_checkpoint_roundtrip(tmp_path):
     fi, ft = step.inference(sdG, batch)
     assert rel(tm.fake_I, fi) < 1e-3 and rel(tm.fake_T, ft) < 1e-3
     assert set(tm.get_current_visuals().keys()) >= {"real_S", "fake_I", "fake_gx", "fake_gy", "fake_N"}
+
+
+def test_hip_graph_replay_equals_eager():
+    """Steps replayed from the captured HIP graphs (step 2 onwards) equal eager execution;
+    inputs are re-uploaded into the persistent buffers between steps."""
+    import random
+
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+
+    size, n, seed = 256, 2, 55
+    models_ = []
+    for graph in (False, True):
+        flags = (FLAGS % (size, n)) + " --use_diffaug False --use_hip_graph %s" % graph
+        opt = TrainOptions(cmd_line=flags).parse()
+        m = create_model(opt)
+        m.setup(opt)
+        m.parallelize()
+        m.train()
+        load_test_weights(m, seed)
+        models_.append(m)
+    batches = [default_collate([make_sample(size, 64, 64, seed + 10 * s + i) for i in range(n)]) for s in range(3)]
+    for m in models_:
+        random.seed(11)
+        for b in batches + [batches[0]]:
+            m.set_input(b, phase="train")
+            m.optimize_parameters(epoch=1)
+    eager, graph = models_
+    assert graph._graphs is not None and eager._graphs is None
+    le, lg = eager.get_current_losses(), graph.get_current_losses()
+    for k in le:
+        assert abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    for nm in ("G", "D", "D2"):
+        a, b = getattr(eager, "flat" + nm).flat, getattr(graph, "flat" + nm).flat
+        assert rel(b, a) < 1e-6, nm
+        assert getattr(eager, "optimizer_" + nm).step_count == getattr(graph, "optimizer_" + nm).step_count == 4
+        assert int(getattr(graph, "optimizer_" + nm).step_dev) == 4
+    assert rel(graph.fake_I, eager.fake_I) < 1e-6

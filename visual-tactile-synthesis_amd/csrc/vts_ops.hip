@@ -367,6 +367,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// same update with the step counter and learning rate read from device memory, so that a captured
+// HIP graph of the training step stays valid across steps and LR-schedule changes
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev, float b1,
+                                                       float b2, float eps, const int* __restrict__ step_dev, float gs) {
+  const float step = (float)step_dev[0];
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  const float step_size = lr_dev[0] / bc1, inv_bc2_sqrt = 1.f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gr = g[i] * gs;
+    const float mi = m[i] * b1 + (1.f - b1) * gr;
+    const float vi = v[i] * b2 + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+  }
+}
+
 // ------------------------------------------------------------------ PatchNCE
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int D, float* __restrict__ y) {
   __shared__ float red[16];
@@ -571,6 +589,15 @@ extern "C" int vts_adam_flat(float* p, const float* g, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1), beta1,
                      beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
   VTS_CHECK_LAUNCH("vts_adam_flat");
+  return VTS_OK;
+}
+
+extern "C" int vts_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1,
+                                 float beta2, float eps, const int* step_dev, float grad_scale, void* stream) {
+  VTS_CHECK_ARG(p && g && m && v && lr_dev && step_dev && n >= 1, "vts_adam_flat_dev: bad args");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_dev, beta1, beta2,
+                     eps, step_dev, grad_scale);
+  VTS_CHECK_LAUNCH("vts_adam_flat_dev");
   return VTS_OK;
 }
 

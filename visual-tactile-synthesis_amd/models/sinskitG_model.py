@@ -78,6 +78,8 @@ class SinSKITGModel(BaseModel):
     def modify_commandline_options(cls, parser, is_train=True):
         add_model_flags(parser, MODEL_FLAGS)
         cls.add_extra_flags(parser)
+        # not a reference flag: replay the training step from captured HIP graphs (after one eager step)
+        parser.add_argument("--use_hip_graph", type=B, default=True)
         parser.set_defaults(model=cls.MODEL_NAME, dataset_mode=cls.DATASET_MODE, netG="unet256_custom", netD="multiscale",
                             netD2="multiscale", gan_mode="nonsaturating", ngf=10, ndf=8, lr=0.001, beta1=0.0, beta2=0.99,
                             crop_size=1536, no_flip=True, dataroot=cls.DATAROOT, data_len=cls.DATA_LEN)
@@ -179,6 +181,9 @@ class SinSKITGModel(BaseModel):
         self._loss_buf = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
         self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
         self._spe_cache = {}
+        self._bufs = {}         # persistent input buffers (stable addresses for captured HIP graphs)
+        self._graphs = None     # the five captured segments of the step, or None
+        self._eager_steps_done = 0
         self._draws = None      # tests / parity runs inject {"aug": [4,N], "more_idx": [N,K]}
         self.ddp = None
         self.style_code = None
@@ -198,12 +203,30 @@ class SinSKITGModel(BaseModel):
                 "Disable them explicitly (SURVEY.md §7 'Third-party loss terms')." % "; ".join(bad))
 
     # ------------------------------------------------------------------ input
+    def _buf(self, name, shape, dtype=torch.float32):
+        """Persistent device buffer: inputs keep their addresses from batch to batch (captured HIP
+        graphs read them in place; a shape change re-allocates and invalidates the graphs)."""
+        t = self._bufs.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[name] = t
+            self._drop_graphs()
+        return t
+
+    def _load(self, name, host, dtype=torch.float32):
+        t = torch.as_tensor(host)
+        buf = self._buf(name, t.shape, dtype)
+        buf.copy_(t.to(dtype), non_blocking=True)
+        return buf
+
     def _spe(self, n, h, w):
         key = (n, h, w)
         if key not in self._spe_cache:
             buf = torch.empty(n, self.pe_channels, h, w, dtype=torch.float32, device=self.device)
             ops.spe_grid(buf, self.opt.positional_encoding_dim)
             self._spe_cache = {key: buf}
+            self._drop_graphs()
         return self._spe_cache[key]
 
     @staticmethod
@@ -215,59 +238,62 @@ class SinSKITGModel(BaseModel):
         cs = np.round(c[..., -4] / c[..., -3])
         return ox.astype(np.float32).astype(np.int32), oy.astype(np.float32).astype(np.int32), cs.astype(np.int32)
 
-    def _patch_set(self, T_images, I_masks, T_coords):
+    def _patch_set(self, tag, T_images, I_masks, T_coords):
         T = torch.as_tensor(T_images)
         n, nt = T.shape[0], T.shape[1]
-        dev = self.device
         ox, oy, cs = self._patch_offsets(torch.as_tensor(T_coords).numpy())
         if not (cs == 32).all():
             raise NotImplementedError("patch cutout != 32 px needs the bicubic resampler; not built")
-        real_T = T.reshape(-1, 2, 32, 32).to(torch.float32).to(dev, non_blocking=True).contiguous()
-        masks = torch.as_tensor(I_masks).reshape(-1, 1, 32, 32).to(torch.float32).to(dev, non_blocking=True).contiguous()
-        real_T = ops.mask_mul(real_T, masks)
+        raw = self._load(tag + "_T_raw", T.reshape(-1, 2, 32, 32))
+        masks = self._load(tag + "_masks", torch.as_tensor(I_masks).reshape(-1, 1, 32, 32))
+        real_T = ops.mask_mul(raw, masks, out=self._buf(tag + "_real_T", raw.shape))
         return dict(
             real_T=real_T, masks=masks, NT=nt,
-            offx=torch.from_numpy(ox.reshape(-1)).to(dev), offy=torch.from_numpy(oy.reshape(-1)).to(dev),
-            img=torch.arange(n, dtype=torch.int32).repeat_interleave(nt).to(dev), coords=np.asarray(T_coords))
+            offx=self._load(tag + "_offx", ox.reshape(-1), torch.int32), offy=self._load(tag + "_offy", oy.reshape(-1), torch.int32),
+            img=self._load(tag + "_img", torch.arange(n, dtype=torch.int32).repeat_interleave(nt), torch.int32),
+            coords=np.asarray(T_coords))
 
     def set_input(self, input, phase="train", timing=False, verbose=False):
-        dev = self.device
         self.data_phase = phase
-        S = input["S"].to(dev, non_blocking=True).float().contiguous()
         self.name = input.get("name")
         self.image_paths = input.get("S_paths")
         self.augmentation_params = input.get("augmentation_params")
+        S = self._load(phase + "_S", input["S"])
         n, _, h, w = S.shape
         if self.opt.use_bg_mask:
-            self.M = input["M"].to(dev, non_blocking=True).float().contiguous()
-            self.real_S = ops.mask_mul(S, self.M)
+            self.M = self._load(phase + "_M", input["M"])
+            self.real_S = ops.mask_mul(S, self.M, out=self._buf(phase + "_real_S", S.shape))
             self.M_T = self.M  # nearest resize at multiplier 1 is the identity
         else:
             self.real_S = S
         if "I" in input:
-            I = input["I"].to(dev, non_blocking=True).float().contiguous()
-            self.real_I = ops.mask_mul(I, self.M) if self.opt.use_bg_mask else I
+            I = self._load(phase + "_I", input["I"])
+            self.real_I = ops.mask_mul(I, self.M, out=self._buf(phase + "_real_I", I.shape)) if self.opt.use_bg_mask else I
             self.full_T_coords = input.get("full_T_coords")
         elif hasattr(self, "real_I"):
             del self.real_I
         self.S_pe = self._spe(n, h, w) if self.pe_channels else None
         if "style_code" in input:
-            self.style_code = input["style_code"].to(dev).float()
+            self.style_code = self._load(phase + "_style", input["style_code"])
         self.train_set = self.val_set = None
         if "T_images" in input and len(input["T_images"]) > 0:
-            self.train_set = self._patch_set(input["T_images"], input["I_masks"], input["T_coords"])
+            self.train_set = self._patch_set(phase + "_tr", input["T_images"], input["I_masks"], input["T_coords"])
             self.train_T_coords = self.train_set["coords"]
             self.train_real_T_concat = self.train_set["real_T"]
             self.train_I_masks = self.train_set["masks"]
             if "val_T_images" in input and len(input["val_T_images"]) > 0:
-                self.val_set = self._patch_set(input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
+                self.val_set = self._patch_set(phase + "_va", input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
             elif phase == "test":
                 self.val_set = self.train_set
         if self.isTrain and self.opt.use_more_fakeT and phase == "train":
             # candidate positions of the "more fake T" sampler depend on the mask only: build them here,
             # where the host already synchronises for the H2D copies (model_utils.py:212-216)
-            self._cand, self._cand_prefix = ops.mask_candidates(self.M)
+            self._cand, self._cand_prefix = ops.mask_candidates(
+                self.M, self._buf("cand", (n, h - 14, w - 14), torch.uint8), self._buf("cand_prefix", (n, h - 14 + 1), torch.int32))
             self._cand_count = self._cand_prefix[:, -1].cpu().tolist()
+            k = self.opt.add_fake_T_sample_size
+            self._ranks = self._buf("more_ranks", (n, k), torch.int64)
+            self._more_img = self._load("more_img", torch.arange(n, dtype=torch.int32).repeat_interleave(k), torch.int32)
 
     # ------------------------------------------------------------------ forward
     def _g_input(self):
@@ -317,14 +343,17 @@ class SinSKITGModel(BaseModel):
     def _gather(self, src, pset, out, c0, channels=None):
         return ops.patch_gather(src, pset["img"], pset["offx"], pset["offy"], 32, out, c0=c0, channels=channels)
 
-    def _more_fake_offsets(self, n):
+    def _prepare_ranks(self):
+        """Host side of the 'more fake T' sampler (random.sample over the candidate list,
+        model_utils.py:217): draws the ranks and uploads them into the persistent buffer."""
+        if not (self.opt.use_more_fakeT and "D2" in self.model_names):
+            return
         k = self.opt.add_fake_T_sample_size
         if self._draws is not None:
             ranks = torch.as_tensor(self._draws["more_idx"]).long()
         else:
             ranks = torch.tensor([random.sample(range(c), k) for c in self._cand_count], dtype=torch.int64)
-        h, w = self.real_S.shape[2:]
-        return ops.mask_select(self._cand, self._cand_prefix, ranks.to(self.device), h, w)
+        self._ranks.copy_(ranks, non_blocking=True)
 
     def _d_pass(self, net, in0, in1, target_real, coeff, slot, accumulate, backward=True):
         """One discriminator forward (+ backward into its parameter grads).  Returns preds."""
@@ -334,22 +363,15 @@ class SinSKITGModel(BaseModel):
             engine.msd_backward(net, ctx, dp, param_grads=True, accumulate=accumulate)
         return preds
 
-    def optimize_parameters(self, epoch=0, timing=False):
-        opt = self.opt
-        dev = self.device
-        ts = self.train_set
-        if ts is None:
-            raise RuntimeError("optimize_parameters needs tactile patches in the batch (T_images)")
-        n, _, h, w = self.real_S.shape
-        nt, P = ts["NT"], ts["real_T"].shape[0]
-        ddp = self.ddp
-        gscale = ddp.grad_scale if ddp is not None else 1.0
+    # The step is cut into five segments at the points where a data-parallel run exchanges gradients.
+    # Each segment is pure device work on persistent buffers, so it can run eagerly or be replayed
+    # from a captured HIP graph (optimize_parameters below).
+    def _seg_forward_d1(self):
+        opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
+        P = ts["real_T"].shape[0]
         self._loss_buf.zero_()
-        slot = self._slot
-
         self.forward(keep=True)
-
-        # ---- patches (compute_additional_output :1268-1291) ----
+        # patches (compute_additional_output :1268-1291)
         fake_stack = torch.empty(P, 7, 32, 32, device=dev)    # [fake_T, S, aug_fake_I, mask]
         real_stack = torch.empty(P, 7, 32, 32, device=dev)    # [real_T, S, aug_real_I, mask]
         self._gather(self.fake_T, ts, fake_stack, 0, channels=2)
@@ -360,82 +382,147 @@ class SinSKITGModel(BaseModel):
         self._gather(self.real_S, ts, real_stack, 2)
         self._gather(self.aug_real_I, ts, real_stack, 3)
         real_stack[:, 6:7].copy_(ts["masks"])
-        fake_T_concat = torch.empty(P, 2, 32, 32, device=dev)
-        self._gather(self.fake_T, ts, fake_T_concat, 0, channels=2)
-        self.fake_T_concat = fake_T_concat
-
-        # ---- D1 update (compute_D1_loss) ----
+        self.fake_T_concat = torch.empty(P, 2, 32, 32, device=dev)
+        self._gather(self.fake_T, ts, self.fake_T_concat, 0, channels=2)
+        self._fake_stack, self._real_stack = fake_stack, real_stack
+        # D1 update (compute_D1_loss)
         if "D" in self.model_names:
             lam = opt.lambda_G1_GAN
             preds = self._d_pass(self.netD, self.real_S, self.fake_I, False, lam, slot["D_fake_I"], accumulate=False)
             self.pred_fake_I = preds[-1]
             self._d_pass(self.netD, self.real_S, self.real_I, True, lam, slot["D_real_I"], accumulate=True)
-            if ddp is not None:
-                ddp.buckets["D"].start()
 
-        # ---- D2 update (compute_D2_loss) ----
-        if "D2" in self.model_names:
-            lam2 = opt.lambda_G2_GAN
-            self._d_pass(self.netD2, fake_stack, None, False, lam2, slot["D_fake_T_concat"], accumulate=False)
-            # full-resolution pass: visualisation only, but it advances the BatchNorm running statistics
-            self._full_stack[:, 2:3].copy_(self.real_S)
-            self._full_stack[:, 6:7].copy_(self.M)
-            preds_full, _ = engine.msd_forward(self.netD2, self._full_stack, None, keep=False)
-            self.pred_fake_T_full = preds_full[-1]
-            if opt.use_more_fakeT:
-                k = opt.add_fake_T_sample_size
-                mox, moy = self._more_fake_offsets(n)
-                mimg = torch.arange(n, dtype=torch.int32, device=dev).repeat_interleave(k)
-                self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
-                more = torch.empty(n * k, 7, 32, 32, device=dev)
-                mset = dict(img=mimg, offx=mox, offy=moy)
-                self._gather(self.fake_T, mset, more, 0, channels=2)
-                self._gather(self.real_S, mset, more, 2)
-                self._gather(self.fake_I, mset, more, 3)
-                more[:, 6:7].fill_(1.0)
-                self._d_pass(self.netD2, more, None, False, lam2, slot["D_more_fake_T"], accumulate=True)
-            self._d_pass(self.netD2, real_stack, None, True, lam2, slot["D_real_T_concat"], accumulate=True)
-            if ddp is not None:
-                ddp.buckets["D2"].start()
+    def _seg_d2(self):
+        opt, dev, slot = self.opt, self.device, self._slot
+        if "D2" not in self.model_names:
+            return
+        n = self.real_S.shape[0]
+        lam2 = opt.lambda_G2_GAN
+        self._d_pass(self.netD2, self._fake_stack, None, False, lam2, slot["D_fake_T_concat"], accumulate=False)
+        # full-resolution pass: visualisation only, but it advances the BatchNorm running statistics
+        self._full_stack[:, 2:3].copy_(self.real_S)
+        self._full_stack[:, 6:7].copy_(self.M)
+        preds_full, _ = engine.msd_forward(self.netD2, self._full_stack, None, keep=False)
+        self.pred_fake_T_full = preds_full[-1]
+        if opt.use_more_fakeT:
+            k = opt.add_fake_T_sample_size
+            h, w = self.real_S.shape[2:]
+            mox, moy = ops.mask_select(self._cand, self._cand_prefix, self._ranks, h, w)
+            self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
+            more = torch.empty(n * k, 7, 32, 32, device=dev)
+            mset = dict(img=self._more_img, offx=mox, offy=moy)
+            self._gather(self.fake_T, mset, more, 0, channels=2)
+            self._gather(self.real_S, mset, more, 2)
+            self._gather(self.fake_I, mset, more, 3)
+            more[:, 6:7].fill_(1.0)
+            self._d_pass(self.netD2, more, None, False, lam2, slot["D_more_fake_T"], accumulate=True)
+        self._d_pass(self.netD2, self._real_stack, None, True, lam2, slot["D_real_T_concat"], accumulate=True)
 
+    def _seg_adam_d_g1(self):
+        opt, dev, slot = self.opt, self.device, self._slot
+        n, _, h, w = self.real_S.shape
         if "D" in self.model_names:
-            if ddp is not None:
-                ddp.buckets["D"].wait()
-            self.optimizer_D.step(gscale)
-
-        # ---- G update (compute_G1_loss + compute_G2_loss) ----
-        d_fake_I = torch.empty(n, 3, h, w, device=dev)
-        have_dI = False
+            self.optimizer_D.step(self._gscale)
+        # G update, first half (compute_G1_loss)
+        self._d_fake_I = torch.empty(n, 3, h, w, device=dev)
+        have = False
         if "D" in self.model_names:
             lam = opt.lambda_G1_GAN
             preds, ctx = engine.msd_forward(self.netD, self.real_S, self.fake_I, keep=True)
             dp = self.criterionGAN.accumulate(preds, True, lam, slot["G_GAN"], grad_coeff=lam)
-            engine.msd_backward(self.netD, ctx, dp, param_grads=False, input_grad=(d_fake_I, False))
-            have_dI = True
+            engine.msd_backward(self.netD, ctx, dp, param_grads=False, input_grad=(self._d_fake_I, False))
+            have = True
         if opt.lambda_G1_L1 > 0.0:
-            ops.l1(self.fake_I, self.real_I, opt.lambda_G1_L1 / self.fake_I.numel(), slot["G_L1"], d_fake_I, accumulate=have_dI)
-            have_dI = True
+            ops.l1(self.fake_I, self.real_I, opt.lambda_G1_L1 / self.fake_I.numel(), slot["G_L1"], self._d_fake_I, accumulate=have)
+            have = True
+        self._have_dI = have
+
+    def _seg_adam_d2_g2(self):
+        opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
+        n, _, h, w = self.real_S.shape
+        nt, P = ts["NT"], ts["real_T"].shape[0]
         if "D2" in self.model_names:
-            if ddp is not None:
-                ddp.buckets["D2"].wait()
-            self.optimizer_D2.step(gscale)
+            self.optimizer_D2.step(self._gscale)
             # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
-            preds, _ = engine.msd_forward(self.netD2, fake_stack, None, keep=False)
+            preds, _ = engine.msd_forward(self.netD2, self._fake_stack, None, keep=False)
             self.criterionGAN.accumulate(preds, True, opt.lambda_G2_GAN * nt, slot["G2_GAN"], want_grad=False)
         d_fake_T = None
         if opt.lambda_G2_L1 > 0.0:
             d_patch = torch.empty(P, 2, 32, 32, device=dev)
-            ops.l1(fake_T_concat, ts["real_T"], opt.lambda_G2_L1 / (n * 2 * 32 * 32), slot["G2_L1"], d_patch)
+            ops.l1(self.fake_T_concat, ts["real_T"], opt.lambda_G2_L1 / (n * 2 * 32 * 32), slot["G2_L1"], d_patch)
             d_fake_T = torch.empty(n, 2, h, w, device=dev)
             ops.patch_scatter_bwd(d_patch, 0, 2, ts["offx"], ts["offy"], nt, 32, d_fake_T)
         d_raw = torch.empty(n, 5, h, w, device=dev)
-        ops.g_out_grad(d_fake_I if have_dI else None, d_fake_T, self.M, self.g_out, d_raw)
+        ops.g_out_grad(self._d_fake_I if self._have_dI else None, d_fake_T, self.M, self.g_out, d_raw)
         engine.unet_backward(self.netG, self._g_ctx, d_raw)
-        self._g_ctx = None
-        if ddp is not None:
-            ddp.buckets["G"].start()
-            ddp.buckets["G"].wait()
-        self.optimizer_G.step(gscale)
+
+    def _seg_adam_g(self):
+        self.optimizer_G.step(self._gscale)
+
+    def _segments(self):
+        """(segment, bucket to wait for before it, bucket to start after it)"""
+        return [(self._seg_forward_d1, None, "D"), (self._seg_d2, None, "D2"), (self._seg_adam_d_g1, "D", None),
+                (self._seg_adam_d2_g2, "D2", "G"), (self._seg_adam_g, "G", None)]
+
+    def _comm(self, name, start):
+        if self.ddp is None or name not in self.ddp.buckets:
+            return
+        b = self.ddp.buckets[name]
+        b.start() if start else b.wait()
+
+    def _drop_graphs(self):
+        if getattr(self, "_graphs", None) is not None:
+            self._graphs = None
+            ops.FROZEN_WS = False
+
+    def _capture_graphs(self):
+        """Capture the five segments as HIP graphs sharing one memory pool (torch.cuda.CUDAGraph over
+        the launch stream our ctypes kernels use).  Capturing records work without executing it."""
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream()
+        counts = [o.step_count for o in self.optimizers]
+        graphs = []
+        ops.FROZEN_WS = True
+        try:
+            for seg, _, _ in self._segments():
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=stream):
+                    seg()
+                graphs.append(g)
+        except Exception:
+            ops.FROZEN_WS = False
+            raise
+        for o, c in zip(self.optimizers, counts):
+            o.step_count = c   # host mirrors moved during capture; the device counters did not
+        self._graphs = graphs
+
+    def optimize_parameters(self, epoch=0, timing=False):
+        if self.train_set is None:
+            raise RuntimeError("optimize_parameters needs tactile patches in the batch (T_images)")
+        self._gscale = self.ddp.grad_scale if self.ddp is not None else 1.0
+        for o in self.optimizers:
+            o.sync_lr()
+        self._prepare_ranks()
+        use_graph = bool(getattr(self.opt, "use_hip_graph", False)) and self._draws is None
+        if use_graph and self._graphs is None and self._eager_steps_done >= 1:
+            self._capture_graphs()
+        replay = use_graph and self._graphs is not None
+        for i, (seg, wait_for, start_after) in enumerate(self._segments()):
+            if wait_for:
+                self._comm(wait_for, start=False)
+            if replay:
+                self._graphs[i].replay()
+            else:
+                seg()
+            if start_after:
+                self._comm(start_after, start=True)
+        if replay:
+            for o in self.optimizers:
+                o.step_count += 1
+        else:
+            self._eager_steps_done += 1
+            self._g_ctx = None if not use_graph else self._g_ctx
 
     # ------------------------------------------------------------------ logging
     def get_current_losses(self):

@@ -73,7 +73,7 @@ SYMBOLS = [
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
-    "vts_mask_select", "vts_adam_flat", "vts_patchnce", "vts_l2norm_rows",
+    "vts_mask_select", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows",
 ]
 
 
@@ -116,6 +116,7 @@ def load():
         "vts_mask_candidates": [vp, i, i, i, vp, vp, vp],
         "vts_mask_select": [vp, vp, i, i, i, vp, i, vp, vp, vp],
         "vts_adam_flat": [vp, vp, vp, vp, i64, f, f, f, f, i, f, vp],
+        "vts_adam_flat_dev": [vp, vp, vp, vp, i64, vp, f, f, f, vp, f, vp],
         "vts_patchnce": [vp, vp, i, i, i, f, f, vp, vp, vp],
         "vts_l2norm_rows": [vp, i, i, vp, vp],
     }

@@ -61,9 +61,15 @@ def workspace(nfloats, device):
     key = str(device)
     t = _ws.get(key)
     if t is None or t.numel() < nfloats:
+        if FROZEN_WS:
+            raise RuntimeError("workspace would have to grow (%d -> %d floats) while captured HIP graphs reference it; "
+                               "run one eager step with the new shapes first" % (0 if t is None else t.numel(), nfloats))
         t = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
         _ws[key] = t
     return t
+
+
+FROZEN_WS = False  # set while HIP graphs that captured the workspace pointer are alive
 
 
 def _op(a):
@@ -279,11 +285,13 @@ def spe_grid(out, dim, c0=0):
     return out
 
 
-def mask_candidates(M):
+def mask_candidates(M, cand=None, prefix=None):
     lib = L.load()
     n, _, h, w = M.shape
-    cand = torch.empty(n, h - 14, w - 14, dtype=torch.uint8, device=M.device)
-    prefix = torch.zeros(n, h - 14 + 1, dtype=torch.int32, device=M.device)
+    if cand is None:
+        cand = torch.empty(n, h - 14, w - 14, dtype=torch.uint8, device=M.device)
+    if prefix is None:
+        prefix = torch.empty(n, h - 14 + 1, dtype=torch.int32, device=M.device)
     L.check(lib.vts_mask_candidates(M.data_ptr(), n, h, w, cand.data_ptr(), prefix.data_ptr(), L.stream()), "vts_mask_candidates")
     return cand, prefix
 
@@ -302,6 +310,12 @@ def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     lib = L.load()
     L.check(lib.vts_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
                               L.stream()), "vts_adam_flat")
+
+
+def adam_flat_dev(p, g, m, v, lr_dev, beta1, beta2, eps, step_dev, grad_scale=1.0):
+    lib = L.load()
+    L.check(lib.vts_adam_flat_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_dev.data_ptr(), beta1, beta2,
+                                  eps, step_dev.data_ptr(), grad_scale, L.stream()), "vts_adam_flat_dev")
 
 
 def l2norm_rows(x, out=None):

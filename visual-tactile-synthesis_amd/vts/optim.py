@@ -5,6 +5,8 @@ fields are views into a second one, so the optimiser is a single kernel per netw
 data-parallel training all-reduces one bucket per network.
 Semantics of torch.optim.Adam as the reference uses it
 (/root/reference/models/sinskitG_model.py:589-599: betas=(0.0, 0.99), eps 1e-8, no weight decay).
+The step counter and the learning rate live in device memory so that a captured HIP graph
+of the whole training step stays valid from one iteration (and one LR-schedule epoch) to the next.
 """
 import torch
 
@@ -30,40 +32,42 @@ class FlatParams:
             o += n
         self.numel = total
 
-    def rebind(self):
-        """Re-attach .data/.grad views (after something replaced them, e.g. module.to())."""
-        o = 0
-        for p in self.params:
-            n = p.numel()
-            if p.data.data_ptr() != self.flat[o:o + n].data_ptr():
-                self.flat[o:o + n].view_as(p).copy_(p.data)
-                p.data = self.flat[o:o + n].view_as(p)
-            p.grad = self.grad[o:o + n].view_as(p)
-            o += n
-
 
 class FlatAdam(torch.optim.Optimizer):
     """Adam over a FlatParams.  A torch Optimizer subclass only so that the reference's LR
     schedulers (networks.get_scheduler) can drive `param_groups[0]["lr"]`; the update itself
-    is one vts_adam_flat launch."""
+    is one vts_adam_flat_dev launch."""
 
     def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps))
         self.flat = flat
+        dev = flat.flat.device
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
         self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self._lr_on_dev = float(lr)
 
     def zero_grad(self, set_to_none=True):
         # gradients are overwritten (not accumulated) by the first backward of every step
         pass
 
+    def sync_lr(self):
+        """Push a scheduler-updated learning rate to the device scalar (call outside graph capture)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_dev:
+            self.lr_dev.fill_(lr)
+            self._lr_on_dev = lr
+
     @torch.no_grad()
     def step(self, grad_scale=1.0, closure=None):
+        """Capturable: increments the device step counter and launches the fused update."""
         self.step_count += 1
+        self.step_dev.add_(1)
         g = self.param_groups[0]
-        ops.adam_flat(self.flat.flat, self.flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                      self.step_count, grad_scale)
+        ops.adam_flat_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.lr_dev, g["betas"][0], g["betas"][1], g["eps"],
+                          self.step_dev, grad_scale)
 
     def load_named_state(self, module, m_by_name, v_by_name, step):
         """Load per-parameter Adam moments keyed by state_dict names (resume / parity tests)."""
@@ -77,6 +81,7 @@ class FlatAdam(torch.optim.Optimizer):
                 self.v[o:o + n].copy_(v_by_name[k].reshape(-1))
             o += n
         self.step_count = int(step)
+        self.step_dev.fill_(int(step))
 
     def flat_state(self):
         return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.param_groups[0]["lr"]}
@@ -85,3 +90,4 @@ class FlatAdam(torch.optim.Optimizer):
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_count = int(sd["step"])
+        self.step_dev.fill_(self.step_count)
