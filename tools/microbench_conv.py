@@ -1,0 +1,73 @@
+"""Micro-benchmark of single vts_conv4x4 / vts_wgrad4x4 launches (HIP events, 20 reps)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "visual-tactile-synthesis_amd"))
+import torch  # noqa: E402
+
+from vts import ops  # noqa: E402
+from vts.ops import Act  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def conv_case(N, Cin, H, W, Cout, stride, pad, transposed):
+    x = torch.randn(N, Cin, H, W, device=dev)
+    if transposed:
+        OH = (H - 1) * stride - 2 * pad + 4
+        w = torch.randn(Cin, Cout, 4, 4, device=dev) * 0.1
+        wsco, wsci = 16, Cout * 16
+    else:
+        OH = (H + 2 * pad - 4) // stride + 1
+        w = torch.randn(Cout, Cin, 4, 4, device=dev) * 0.1
+        wsco, wsci = Cin * 16, 16
+    out = torch.empty(N, Cout, OH, OH, device=dev)
+    sc = torch.ones(N * Cin, device=dev)
+    sh = torch.zeros(N * Cin, device=dev)
+    a = Act(x, sc, sh)
+    us = timeit(lambda: ops.conv4x4(a, w, wsco, wsci, Cout, out, stride=stride, pad=pad, transposed=transposed, act_in=1))
+    taps = 4 if (transposed and stride == 2) else 16
+    fl = 2.0 * N * OH * OH * Cout * Cin * taps
+    by = 4.0 * (x.numel() + out.numel())
+    print("%s N%d %dx%dx%d -> %dx%dx%d s%d p%d : %8.1f us  %6.2f TF  %7.1f GB/s" % (
+        "convT" if transposed else "conv ", N, Cin, H, W, Cout, OH, OH, stride, pad, us, fl / us / 1e6, by / us / 1e3))
+
+
+def wgrad_case(N, CL, LH, CH, stride, pad):
+    HH = (LH - 1) * stride + 4 - 2 * pad
+    lo = torch.randn(N, CL, LH, LH, device=dev)
+    hi = torch.randn(N, CH, HH, HH, device=dev)
+    dw = torch.empty(CL, CH, 4, 4, device=dev)
+    us = timeit(lambda: ops.wgrad4x4(Act(lo), Act(hi), dw, stride=stride, pad=pad))
+    fl = 2.0 * N * LH * LH * CL * CH * 16
+    by = 4.0 * (lo.numel() + hi.numel())
+    print("wgrad N%d lo %dx%d hi %dx%d s%d : %8.1f us  %6.2f TF  %7.1f GB/s" % (N, CL, LH, CH, HH, stride, us, fl / us / 1e6, by / us / 1e3))
+
+
+if __name__ == "__main__":
+    print("ABLATE=%s SMALL=%s" % (os.environ.get("VTS_ABLATE"), os.environ.get("VTS_SMALL_WGS")))
+    conv_case(4, 9, 1024, 1024, 10, 2, 1, False)
+    conv_case(4, 10, 512, 512, 20, 2, 1, False)
+    conv_case(4, 40, 128, 128, 80, 2, 1, False)
+    conv_case(4, 32, 129, 129, 64, 1, 2, False)
+    conv_case(4, 10, 512, 512, 3, 2, 1, True)
+    conv_case(4, 40, 256, 256, 10, 2, 1, True)
+    conv_case(4, 160, 64, 64, 40, 2, 1, True)
+    if not os.environ.get("VTS_ABLATE"):
+        wgrad_case(4, 10, 512, 9, 2, 1)
+        wgrad_case(4, 40, 256, 10, 2, 1)
+        wgrad_case(4, 64, 130, 32, 1, 2)

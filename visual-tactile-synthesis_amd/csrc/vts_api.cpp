@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+
 #include "vts.h"
 
 static thread_local char g_err[512] = "";
@@ -15,3 +17,13 @@ void vts_set_error(const char* fmt, ...) {
 
 extern "C" const char* vts_last_error(void) { return g_err; }
 extern "C" int vts_version(void) { return 1; }
+
+const float* vts_ident() {
+  static float* dev = nullptr;
+  if (!dev) {
+    const float h[2] = {1.f, 0.f};
+    if (hipMalloc(&dev, sizeof(h)) != hipSuccess) return nullptr;
+    hipMemcpy(dev, h, sizeof(h), hipMemcpyHostToDevice);
+  }
+  return dev;
+}

@@ -18,6 +18,8 @@
 // LDS reads are conflict-free by construction: A fragments read stride-S words of one patch
 // row (32 lanes -> 32 distinct banks or broadcast), B fragments read [k][cout] with the cout
 // pitch = 16 (mod 32).
+#include <stdlib.h>
+
 #include "vts_internal.h"
 
 namespace {
@@ -40,8 +42,13 @@ struct ConvK {
   // small-grid decomposition: blockIdx.z = n + N * (cout_group + CG * k_slice)
   int N, CG, cps;   // cps = input-channel chunks per k-slice
   float* part;      // k-split partial sums [KS][N][Cout][OH][OW] (raw accumulators), or nullptr
+  const float* ident;  // {1, 0}
+  float slope_in;      // input activation as t > 0 ? t : slope * t
+  int ablate;       // profiling only (env VTS_ABLATE): 1 skip global loads, 2 skip MFMA, 4 skip epilogue
 };
 
+// Output staging region of one epilogue pass: 16 output channels x ER rows x EC columns, plane pitch odd
+// so that the 16 channel planes land on distinct LDS banks.
 template <int MODE, int S, int NR, int RW, int MT, int CK>
 __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
@@ -52,11 +59,25 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int COP = (NR % 2 == 1) ? NR * 16 : NR * 16 + 16;
   constexpr int PCM = (PC / 64) * 64;  // columns handled row-wise; the tail goes element-wise
   constexpr int TW = PC - PCM;
+  constexpr int NROWS = CK * PR;
+  constexpr int RPW = (NROWS + 3) / 4;                 // patch rows per wave
+  constexpr int NCM = PCM / 64;                        // 64-column pieces per row
+  constexpr int NPV = RPW * NCM > 0 ? RPW * NCM : 1;   // prefetch registers: row-wise part of the patch
+  constexpr int NTV = (NROWS * TW + 255) / 256 > 0 ? (NROWS * TW + 255) / 256 : 1;  // ... tail columns
+  constexpr int NWV = CK * NR;                         // ... weights (CK*16*NR*16 / 256)
+  constexpr int EC = (P == 4) ? 2 * TX : TX;           // epilogue pass: TY rows x EC columns x 16 channels
+  constexpr int EPL = TY * EC + 1;
+  constexpr int PATCH_FLOATS = CK * PR * PCP, W_FLOATS = CK * 16 * COP, OUT_FLOATS = 16 * EPL;
+  constexpr int LDS_FLOATS = (PATCH_FLOATS + W_FLOATS) > OUT_FLOATS ? (PATCH_FLOATS + W_FLOATS) : OUT_FLOATS;
 
-  __shared__ float lds_patch[CK * PR * PCP];
-  __shared__ float lds_w[CK * 16 * COP];
+  __shared__ float lds[LDS_FLOATS];
+  float* lds_patch = lds;
+  float* lds_w = lds + PATCH_FLOATS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // provably wave-uniform wave index: all per-row staging state (bounds, row pointers, normalisation
+  // scale/shift) then lives in SGPRs / scalar loads instead of per-lane VGPRs and branches
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, kq = lane >> 4;
   const int n = blockIdx.z % p.N;
   const int cg = (blockIdx.z / p.N) % p.CG, ks = blockIdx.z / (p.N * p.CG);
@@ -102,83 +123,180 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
 
   const int64_t plane = (int64_t)p.IH * p.IW;
   const int nchunks = (p.Cin + CK - 1) / CK;
+  const int chunk_begin = ks * p.cps;
   const int chunk_end = min(nchunks, (ks + 1) * p.cps);
-  for (int chunk = ks * p.cps; chunk < chunk_end; ++chunk) {
-    const int cbase = chunk * CK;
-    // ---- stage the input patch (normalise + activate + concat on load) ----
-    auto row_setup = [&](int rr, const float*& src, float& sc, float& sh) -> bool {
-      const int c = rr / PR, r = rr - c * PR;
-      const int ci = cbase + c, iy = iy0 + r;
-      if (ci >= p.Cin || iy < 0 || iy >= p.IH) return false;
-      if (ci < p.C0) {
-        src = p.s0 + n * p.ns0 + ci * plane + (int64_t)iy * p.IW;
-        sc = p.sc0 ? p.sc0[n * p.C0 + ci] : 1.f;
-        sh = p.sh0 ? p.sh0[n * p.C0 + ci] : 0.f;
-      } else {
-        const int c1 = ci - p.C0;
-        src = p.s1 + n * p.ns1 + c1 * plane + (int64_t)iy * p.IW;
-        sc = p.sc1 ? p.sc1[n * p.C1 + c1] : 1.f;
-        sh = p.sh1 ? p.sh1[n * p.C1 + c1] : 0.f;
-      }
-      return true;
-    };
-    if (PCM > 0) {
-      for (int rr = wave; rr < CK * PR; rr += 4) {
-        const float* src = nullptr;
-        float sc = 1.f, sh = 0.f;
-        const bool ok = row_setup(rr, src, sc, sh);
+  const bool co_major = p.ws_co >= p.ws_ci;  // Conv2d layout: taps of (co, ci..ci+CK) are contiguous
+
+  // Software pipeline: the global loads of chunk k+1 (normalise + activate + concat applied on the
+  // fly) are issued into registers before the MFMA phase of chunk k and written to LDS after it.
+  float pv[NPV], tv[NTV], wv[NWV];
 #pragma unroll
-        for (int col = lane; col < PCM; col += 64) {
-          const int ix = ix0 + col;
-          float v = 0.f;
-          if (ok && ix >= 0 && ix < p.IW) v = vts_act(src[ix] * sc + sh, p.act_in);
-          lds_patch[rr * PCP + col] = v;
+  for (int i = 0; i < NPV; ++i) pv[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NTV; ++i) tv[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) wv[i] = 1.f;
+
+  // Staging discipline (this is what makes the kernel stream): load_chunk issues ONLY loads -- every
+  // address is clamped into the tensor so no load sits under a data-dependent branch (hipcc would
+  // branch around it and drain vmcnt per element, serialising every round trip) -- and keeps the raw
+  // values in registers.  store_chunk, which runs after the MFMA phase of the previous chunk, applies
+  // normalisation + activation + zero padding branch-free and writes LDS.  Per chunk the only scalar
+  // state is the CK (scale, shift) pairs.
+  float csc[CK], csh[CK];
+#pragma unroll
+  for (int c = 0; c < CK; ++c) {
+    csc[c] = 1.f;
+    csh[c] = 0.f;
+  }
+
+  auto chunk_affine = [&](int cbase) {
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const int cic = min(cbase + c, p.Cin - 1);
+      const bool first = cic < p.C0;
+      const int cl = first ? cic : cic - p.C0;
+      const float* scp = first ? p.sc0 : p.sc1;
+      const float* shp = first ? p.sh0 : p.sh1;
+      const int aidx = n * (first ? p.C0 : p.C1) + cl;
+      const bool hsc = scp != nullptr, hsh = shp != nullptr;
+      csc[c] = (hsc ? scp : p.ident)[hsc ? aidx : 0];
+      csh[c] = (hsh ? shp : p.ident)[hsh ? aidx : 1];
+    }
+  };
+
+  auto row_ptr = [&](int cbase, int rr) -> const float* {
+    const int c = rr / PR, r = rr - c * PR;
+    const int cic = min(cbase + c, p.Cin - 1), iyc = min(max(iy0 + r, 0), p.IH - 1);
+    const bool first = cic < p.C0;
+    const int cl = first ? cic : cic - p.C0;
+    const float* base = first ? p.s0 + n * p.ns0 : p.s1 + n * p.ns1;
+    return base + cl * plane + (int64_t)iyc * p.IW;
+  };
+
+  auto load_chunk = [&](int chunk) {
+    const int cbase = chunk * CK;
+    chunk_affine(cbase);
+    if (NCM > 0) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const float* src = row_ptr(cbase, min(wave + 4 * i, NROWS - 1));
+#pragma unroll
+        for (int cm = 0; cm < NCM; ++cm) pv[i * NCM + cm] = src[min(max(ix0 + cm * 64 + lane, 0), p.IW - 1)];
+      }
+    }
+    if (TW > 0) {
+#pragma unroll
+      for (int e = 0; e < NTV; ++e) {
+        const int idx = min(tid + e * 256, NROWS * TW - 1);
+        const int rr = idx / TW, col = PCM + (idx - rr * TW);
+        tv[e] = row_ptr(cbase, rr)[min(max(ix0 + col, 0), p.IW - 1)];
+      }
+    }
+    constexpr int NCO = NR * 16;
+#pragma unroll
+    for (int e = 0; e < NWV; ++e) {
+      const int idx = tid + e * 256;
+      int co, c, slot;
+      if (co_major) {
+        co = idx / (CK * 16);
+        const int rem = idx - co * (CK * 16);
+        c = rem >> 4;
+        slot = rem & 15;
+      } else {
+        c = idx / (NCO * 16);
+        const int rem = idx - c * (NCO * 16);
+        co = rem >> 4;
+        slot = rem & 15;
+      }
+      int tap = slot;
+      if (MODE == 1 && S == 2) {
+        const int ph = slot >> 2, a = (slot >> 1) & 1, b = slot & 1;
+        const int ky = (((ph >> 1) + p.pad) & 1) + 2 * a, kx = (((ph & 1) + p.pad) & 1) + 2 * b;
+        tap = ky * 4 + kx;
+      }
+      wv[e] = p.w[(int64_t)min(co0 + co, p.Cout - 1) * p.ws_co + (int64_t)min(cbase + c, p.Cin - 1) * p.ws_ci + tap];
+    }
+  };
+
+  // branch-free  pad( act( x * scale + shift ) )
+  auto finish = [&](float x, float sc, float sh, bool inside) -> float {
+    const float t = fmaf(x, sc, sh);
+    const float a = fmaxf(t, 0.f) + p.slope_in * fminf(t, 0.f);
+    return inside ? a : 0.f;
+  };
+
+  auto store_chunk = [&](int chunk) {
+    const int cbase = chunk * CK;
+    if (NCM > 0) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int rr = wave + 4 * i;
+        const int c = rr / PR, r = rr - c * PR;
+        const int iy = iy0 + r;
+        const bool rok = cbase + c < p.Cin && iy >= 0 && iy < p.IH;
+        float sc = csc[0], sh = csh[0];
+#pragma unroll
+        for (int q = 1; q < CK; ++q) {
+          sc = (c == q) ? csc[q] : sc;
+          sh = (c == q) ? csh[q] : sh;
+        }
+        if (rr < NROWS) {
+#pragma unroll
+          for (int cm = 0; cm < NCM; ++cm) {
+            const int ix = ix0 + cm * 64 + lane;
+            lds_patch[rr * PCP + cm * 64 + lane] = finish(pv[i * NCM + cm], sc, sh, rok && ix >= 0 && ix < p.IW);
+          }
         }
       }
     }
     if (TW > 0) {
-      for (int idx = tid; idx < CK * PR * TW; idx += 256) {
+#pragma unroll
+      for (int e = 0; e < NTV; ++e) {
+        const int idx = tid + e * 256;
         const int rr = idx / TW, col = PCM + (idx - rr * TW);
-        const float* src = nullptr;
-        float sc = 1.f, sh = 0.f;
-        const bool ok = row_setup(rr, src, sc, sh);
-        const int ix = ix0 + col;
-        float v = 0.f;
-        if (ok && ix >= 0 && ix < p.IW) v = vts_act(src[ix] * sc + sh, p.act_in);
-        lds_patch[rr * PCP + col] = v;
+        const int c = rr / PR, r = rr - c * PR;
+        const int iy = iy0 + r, ix = ix0 + col;
+        float sc = csc[0], sh = csh[0];
+#pragma unroll
+        for (int q = 1; q < CK; ++q) {
+          sc = (c == q) ? csc[q] : sc;
+          sh = (c == q) ? csh[q] : sh;
+        }
+        const bool ok = cbase + c < p.Cin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        if (rr < NROWS) lds_patch[rr * PCP + col] = finish(tv[e], sc, sh, ok);
       }
     }
-    // ---- stage the weight slice: lds_w[c][slot][co], slot = K-group * 4 + k ----
-    {
-      constexpr int NCO = NR * 16;
-      const bool co_major = p.ws_co >= p.ws_ci;  // Conv2d layout: taps of (co, ci..ci+CK) are contiguous
-      for (int idx = tid; idx < CK * 16 * NCO; idx += 256) {
-        int co, c, slot;
-        if (co_major) {
-          co = idx / (CK * 16);
-          const int rem = idx - co * (CK * 16);
-          c = rem >> 4;
-          slot = rem & 15;
-        } else {
-          c = idx / (NCO * 16);
-          const int rem = idx - c * (NCO * 16);
-          co = rem >> 4;
-          slot = rem & 15;
-        }
-        int tap = slot;
-        if (MODE == 1 && S == 2) {
-          const int ph = slot >> 2, a = (slot >> 1) & 1, b = slot & 1;
-          const int ky = (((ph >> 1) + p.pad) & 1) + 2 * a, kx = (((ph & 1) + p.pad) & 1) + 2 * b;
-          tap = ky * 4 + kx;
-        }
-        const int ci = cbase + c;
-        float v = 0.f;
-        if (co0 + co < p.Cout && ci < p.Cin) v = p.w[(int64_t)(co0 + co) * p.ws_co + (int64_t)ci * p.ws_ci + tap];
-        lds_w[(c * 16 + slot) * COP + co] = v;
+    constexpr int NCO = NR * 16;
+#pragma unroll
+    for (int e = 0; e < NWV; ++e) {
+      const int idx = tid + e * 256;
+      int co, c, slot;
+      if (co_major) {
+        co = idx / (CK * 16);
+        const int rem = idx - co * (CK * 16);
+        c = rem >> 4;
+        slot = rem & 15;
+      } else {
+        c = idx / (NCO * 16);
+        const int rem = idx - c * (NCO * 16);
+        co = rem >> 4;
+        slot = rem & 15;
       }
+      lds_w[(c * 16 + slot) * COP + co] = (co0 + co < p.Cout && cbase + c < p.Cin) ? wv[e] : 0.f;
     }
-    __syncthreads();
+  };
+
+  if (chunk_begin < chunk_end) {
+    if (!(p.ablate & 1)) load_chunk(chunk_begin);
+    store_chunk(chunk_begin);
+  }
+  __syncthreads();
+  for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+    const bool more = chunk + 1 < chunk_end;
+    if (more && !(p.ablate & 1)) load_chunk(chunk + 1);
     // ---- MFMA accumulate ----
+    if (!(p.ablate & 2))
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const float* pp = lds_patch + c * PR * PCP;
@@ -222,64 +340,116 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
       }
     }
     __syncthreads();
+    if (more) {
+      store_chunk(chunk + 1);
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue: C/D layout of 16x16 tiles: col (cout) = lane&15, row (pixel) = (lane>>4)*4 + reg ----
+  // ---- epilogue: accumulators -> LDS (channel planes) -> coalesced, vectorised global stores.
+  // C/D layout of a 16x16 tile: col (cout) = lane&15, row (pixel) = (lane>>4)*4 + reg.
+  // One pass handles 16 output channels and, for transposed s2, one output row parity (both column
+  // parities interleaved, so rows are contiguous in x).
+  if (p.ablate & 4) {
+    if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
+    return;
+  }
   const int64_t oplane = (int64_t)p.OH * p.OW;
+  constexpr int PY = (P == 4) ? 2 : 1;
+  const int oy0 = (P == 4) ? ty0 * 2 : ty0, ox0 = (P == 4) ? tx0 * 2 : tx0;
+  float* so = lds;
+  const bool vec_ok = ((p.OW & 3) == 0) && ((p.ons & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                      (!p.part || (reinterpret_cast<uintptr_t>(p.part) & 15) == 0) &&
+                      (!p.dm || (((p.dmns & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dm) & 15) == 0)));
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
-    const int co = co0 + nr * 16 + m16;
-    if (co >= p.Cout) continue;
-    if (p.part) {  // k-split: raw accumulators, the epilogue runs in conv_split_epilogue_kernel
-      float* pb = p.part + (((int64_t)ks * p.N + n) * p.Cout + co) * oplane;
+#pragma unroll
+    for (int py = 0; py < PY; ++py) {
+      // write this wave's tiles
 #pragma unroll
       for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int ph = 0; ph < P; ++ph) {
-            const int gy = ty0 + wave * RW + r;
-            const int y = (P == 4) ? gy * 2 + (ph >> 1) : gy;
-            if (y >= p.OH) continue;
+          for (int px = 0; px < (P == 4 ? 2 : 1); ++px) {
+            const int ph = py * 2 + px;
+            const int row = wave * RW + r;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const int gx = tx0 + mt * 16 + kq * 4 + j;
-              const int x = (P == 4) ? gx * 2 + (ph & 1) : gx;
-              if (x < p.OW) pb[(int64_t)y * p.OW + x] = acc[r][mt][ph][nr][j];
+              const int xl = mt * 16 + kq * 4 + j;
+              const int col = (P == 4) ? xl * 2 + px : xl;
+              so[m16 * EPL + row * EC + col] = acc[r][mt][P == 4 ? ph : 0][nr][j];
             }
           }
-      continue;
-    }
-    const float bias = p.bias ? p.bias[co] : 0.f;
-    float dsc = 1.f, dsh = 0.f;
-    if (p.dm) {
-      dsc = p.dmsc ? p.dmsc[n * p.dmC + co] : 1.f;
-      dsh = p.dmsh ? p.dmsh[n * p.dmC + co] : 0.f;
-    }
-    float* obase = p.out + n * p.ons + co * oplane;
-    const float* dbase = p.dm ? p.dm + n * p.dmns + co * oplane : nullptr;
+      __syncthreads();
+      // read back channel-plane rows and store 4 consecutive pixels per thread
+      for (int idx = tid; idx < 16 * TY * (EC / 4); idx += 256) {
+        const int c16 = idx / (TY * (EC / 4));
+        const int rem = idx - c16 * (TY * (EC / 4));
+        const int row = rem / (EC / 4), x4 = (rem - row * (EC / 4)) * 4;
+        const int co = co0 + nr * 16 + c16;
+        const int y = (P == 4) ? oy0 + row * 2 + py : oy0 + row;
+        const int x = ox0 + x4;
+        if (co >= p.Cout || y >= p.OH || x >= p.OW) continue;
+        const float* sp = so + c16 * EPL + row * EC + x4;
+        float v[4] = {sp[0], sp[1], sp[2], sp[3]};
+        const int64_t o = (int64_t)y * p.OW + x;
+        const int nvalid = min(4, p.OW - x);
+        if (p.part) {  // k-split: raw accumulators, the epilogue runs in conv_split_epilogue_kernel
+          float* pb = p.part + (((int64_t)ks * p.N + n) * p.Cout + co) * oplane + o;
+          if (vec_ok && nvalid == 4) {
+            *reinterpret_cast<f32x4*>(pb) = (f32x4){v[0], v[1], v[2], v[3]};
+          } else {
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
+            for (int j = 0; j < 4; ++j)
+              if (j < nvalid) pb[j] = v[j];
+          }
+          continue;
+        }
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        float* ob = p.out + n * p.ons + co * oplane + o;
+        float dv[4] = {1.f, 1.f, 1.f, 1.f}, prev[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool vec = vec_ok && nvalid == 4;
+        if (p.dm) {
+          const float dsc = p.dmsc ? p.dmsc[n * p.dmC + co] : 1.f, dsh = p.dmsh ? p.dmsh[n * p.dmC + co] : 0.f;
+          const float* db = p.dm + n * p.dmns + co * oplane + o;
+          if (vec) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(db);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+            for (int j = 0; j < 4; ++j) dv[j] = vts_act_grad(t[j] * dsc + dsh, p.dm_act);
+          } else {
 #pragma unroll
-        for (int ph = 0; ph < P; ++ph) {
-          const int gy = ty0 + wave * RW + r;
-          const int y = (P == 4) ? gy * 2 + (ph >> 1) : gy;
-          if (y >= p.OH) continue;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int gx = tx0 + mt * 16 + kq * 4 + j;
-            const int x = (P == 4) ? gx * 2 + (ph & 1) : gx;
-            if (x >= p.OW) continue;
-            float v = acc[r][mt][ph][nr][j] + bias;
-            if (p.act_out == VTS_ACT_TANH) v = tanhf(v);
-            const int64_t o = (int64_t)y * p.OW + x;
-            if (dbase) v *= vts_act_grad(dbase[o] * dsc + dsh, p.dm_act);
-            if (p.accumulate) v += obase[o];
-            obase[o] = v;
+            for (int j = 0; j < 4; ++j)
+              if (j < nvalid) dv[j] = vts_act_grad(db[j] * dsc + dsh, p.dm_act);
           }
         }
+        if (p.accumulate) {
+          if (vec) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ob);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prev[j] = t[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < nvalid) prev[j] = ob[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = v[j] + bias;
+          if (p.act_out == VTS_ACT_TANH) t = tanhf(t);
+          v[j] = t * dv[j] + prev[j];
+        }
+        if (vec) {
+          *reinterpret_cast<f32x4*>(ob) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < nvalid) ob[j] = v[j];
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -358,6 +528,11 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.dm_act = d->dmask_act; k.dmC = d->dmask.C;
   k.accumulate = d->accumulate;
   k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr;
+  static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
+  k.ablate = ablate;
+  k.ident = vts_ident();
+  VTS_CHECK_ARG(k.ident, "vts_conv4x4: could not allocate the identity constants");
+  k.slope_in = vts_slope(d->act_in);
   hipStream_t st = (hipStream_t)stream;
   const int nr = (d->Cout + 15) / 16;
   const int N = d->N;
@@ -371,9 +546,11 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
     const int GH = ph4 ? (d->OH + 1) / 2 : d->OH, GW = ph4 ? (d->OW + 1) / 2 : d->OW;
     const int full_wgs = cdiv(GW, 16 * mt) * cdiv(GH, 4 * rw) * N;
     const int nchunks = (k.Cin + 3) / 4;
-    if (full_wgs < 128 && (nr > 1 || nchunks >= 8)) {
+    static const int small_thr = getenv("VTS_SMALL_WGS") ? atoi(getenv("VTS_SMALL_WGS")) : 128;
+    static const int target_wgs = getenv("VTS_TARGET_WGS") ? atoi(getenv("VTS_TARGET_WGS")) : 320;
+    if (full_wgs < small_thr && (nr > 1 || nchunks >= 8)) {
       const int base = cdiv(GW, 32) * cdiv(GH, 4) * N * nr;
-      int KS = 320 / base;
+      int KS = target_wgs / base;
       if (KS > nchunks / 2) KS = nchunks / 2;
       if (KS < 1) KS = 1;
       int cps = cdiv(nchunks, KS);

@@ -9,6 +9,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void vts_set_error(const char* fmt, ...);
+// device pointer to the two floats {1, 0}: identity scale / shift for operands without an affine, so the
+// kernels can fetch scale/shift unconditionally (no data-dependent branch around a load)
+const float* vts_ident();
+// LeakyReLU slope that expresses the activation codes as  t > 0 ? t : slope * t
+static inline float vts_slope(int act) { return act == VTS_ACT_LRELU ? 0.2f : (act == VTS_ACT_RELU ? 0.f : 1.f); }
 
 #define VTS_CHECK_ARG(cond, ...)     \
   do {                               \

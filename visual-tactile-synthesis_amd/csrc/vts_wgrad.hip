@@ -19,6 +19,8 @@ struct Src {
   int64_t ns0, ns1;
   int C0, C1, C;
   int act;
+  float slope;         // activation as t > 0 ? t : slope * t
+  const float* ident;  // {1, 0}
 };
 
 struct WgK {
@@ -29,21 +31,33 @@ struct WgK {
   float* part;  // [PW][CL][CH][16]
 };
 
-__device__ __forceinline__ float src_val(const Src& s, int n, int c, int y, int x, int H, int W) {
-  if (c >= s.C || y < 0 || y >= H || x < 0 || x >= W) return 0.f;
-  const int64_t plane = (int64_t)H * W;
-  float v, sc = 1.f, sh = 0.f;
-  if (c < s.C0) {
-    v = s.d0[n * s.ns0 + c * plane + (int64_t)y * W + x];
-    if (s.sc0) sc = s.sc0[n * s.C0 + c];
-    if (s.sh0) sh = s.sh0[n * s.C0 + c];
-  } else {
-    const int c1 = c - s.C0;
-    v = s.d1[n * s.ns1 + c1 * plane + (int64_t)y * W + x];
-    if (s.sc1) sc = s.sc1[n * s.C1 + c1];
-    if (s.sh1) sh = s.sh1[n * s.C1 + c1];
-  }
-  return vts_act(v * sc + sh, s.act);
+// Staging discipline as in vts_conv.hip: every global load is unconditional on a clamped (always valid)
+// address and is issued before anything consumes it; normalisation + activation + zero padding are
+// applied branch-free afterwards.
+__device__ __forceinline__ const float* src_ptr(const Src& s, int n, int c, int y, int H, int W) {
+  const int cc = min(c, s.C - 1), yc = min(max(y, 0), H - 1);
+  const bool first = cc < s.C0;
+  const int cl = first ? cc : cc - s.C0;
+  const float* base = first ? s.d0 + n * s.ns0 : s.d1 + n * s.ns1;
+  return base + cl * ((int64_t)H * W) + (int64_t)yc * W;
+}
+
+__device__ __forceinline__ void src_affine(const Src& s, int n, int c, float& sc, float& sh) {
+  const int cc = min(c, s.C - 1);
+  const bool first = cc < s.C0;
+  const int cl = first ? cc : cc - s.C0;
+  const float* scp = first ? s.sc0 : s.sc1;
+  const float* shp = first ? s.sh0 : s.sh1;
+  const int aidx = n * (first ? s.C0 : s.C1) + cl;
+  const bool hsc = scp != nullptr, hsh = shp != nullptr;
+  sc = (hsc ? scp : s.ident)[hsc ? aidx : 0];
+  sh = (hsh ? shp : s.ident)[hsh ? aidx : 1];
+}
+
+__device__ __forceinline__ float finish(float x, float sc, float sh, float slope, bool inside) {
+  const float t = fmaf(x, sc, sh);
+  const float a = fmaxf(t, 0.f) + slope * fminf(t, 0.f);
+  return inside ? a : 0.f;
 }
 
 constexpr int TYL = 4, TXL = 32, TXLP = 34;  // TXLP = 2 (mod 32): A reads hit banks 2*cl + k
@@ -58,10 +72,14 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
   constexpr int LO_FLOATS = TYL * CLP * TXLP;
   constexpr int HI_FLOATS = CHT * PRH * PCHP;
   constexpr int RED_FLOATS = CLT * CHT * 256;
-  constexpr int LDS_FLOATS = (LO_FLOATS + HI_FLOATS) > RED_FLOATS ? (LO_FLOATS + HI_FLOATS) : RED_FLOATS;
+  constexpr int AFF_FLOATS = 2 * (CLP + CHT);
+  constexpr int STAGE_FLOATS = LO_FLOATS + HI_FLOATS + AFF_FLOATS;
+  constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
   __shared__ float lds[LDS_FLOATS];
   float* lo = lds;
   float* hi = lds + LO_FLOATS;
+  float* aff_sc = lds + LO_FLOATS + HI_FLOATS;
+  float* aff_sh = aff_sc + CLP + CHT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, kq = lane >> 4;
@@ -79,19 +97,70 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
     const int rem = tile - n * (p.tiles_y * p.tiles_x);
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
     const int y0 = ty * TYL, x0 = tx * TXL;
-    // low-res tile: lo[row][cl][x]
-    for (int idx = tid; idx < TYL * CLP * TXL; idx += 256) {
-      const int x = idx % TXL, rc = idx / TXL;
-      const int cl = rc % CLP, row = rc / CLP;
-      lo[(row * CLP + cl) * TXLP + x] = src_val(p.lo, n, cl0 + cl, y0 + row, x0 + x, p.LH, p.LW);
-    }
-    // high-res patch: hi[ch][r][col]
     const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.pad;
-    for (int idx = tid; idx < CHT * PRH * PCH; idx += 256) {
-      const int col = idx % PCH, rc = idx / PCH;
-      const int r = rc % PRH, h = rc / PRH;
-      const int ch = ch0 + h;
-      hi[(h * PRH + r) * PCHP + col] = (ch < p.hi.C) ? src_val(p.hi, n, ch, hy0 + r, hx0 + col, p.HH, p.HW) : 0.f;
+    constexpr int NLO = TYL * CLP / 8;
+    constexpr int PCM = PCH >= 64 ? 64 : 0, TW = PCH - PCM;
+    constexpr int NHM = PCM > 0 ? (CHT * PRH + 3) / 4 : 1;
+    constexpr int NHT = (CHT * PRH * TW + 255) / 256;
+    const int half = lane >> 5, xl = lane & 31;
+    // (1) per-channel scale/shift of this tile's channels -> LDS
+    if (tid < CLP + CHT) {
+      float sc, sh;
+      if (tid < CLP) src_affine(p.lo, n, cl0 + tid, sc, sh);
+      else src_affine(p.hi, n, ch0 + tid - CLP, sc, sh);
+      aff_sc[tid] = sc;
+      aff_sh[tid] = sh;
+    }
+    // (2) raw loads, all in flight together
+    float lv[NLO], hv[NHM], ht[NHT > 0 ? NHT : 1];
+#pragma unroll
+    for (int i = 0; i < NLO; ++i) {
+      const int it = wave * 2 + half + 8 * i;  // (row, channel) line of 32 pixels per half-wave
+      const int row = it / CLP, cl = it - row * CLP;
+      lv[i] = src_ptr(p.lo, n, cl0 + cl, y0 + row, p.LH, p.LW)[min(x0 + xl, p.LW - 1)];
+    }
+    if (PCM > 0) {
+#pragma unroll
+      for (int i = 0; i < NHM; ++i) {
+        const int rr = min(wave + 4 * i, CHT * PRH - 1);
+        const int h = rr / PRH, r = rr - h * PRH;
+        hv[i] = src_ptr(p.hi, n, ch0 + h, hy0 + r, p.HH, p.HW)[min(max(hx0 + lane, 0), p.HW - 1)];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NHT; ++e) {
+      const int idx = min(tid + e * 256, CHT * PRH * TW - 1);
+      const int rr = idx / TW, col = PCM + (idx - rr * TW);
+      const int h = rr / PRH, r = rr - h * PRH;
+      ht[e] = src_ptr(p.hi, n, ch0 + h, hy0 + r, p.HH, p.HW)[min(max(hx0 + col, 0), p.HW - 1)];
+    }
+    __syncthreads();
+    // (3) normalise + activate + pad, write the LDS tiles: lo[row][cl][x], hi[ch][r][col]
+#pragma unroll
+    for (int i = 0; i < NLO; ++i) {
+      const int it = wave * 2 + half + 8 * i;
+      const int row = it / CLP, cl = it - row * CLP;
+      const bool ok = cl0 + cl < p.lo.C && y0 + row < p.LH && x0 + xl < p.LW;
+      lo[it * TXLP + xl] = finish(lv[i], aff_sc[cl], aff_sh[cl], p.lo.slope, ok);
+    }
+    if (PCM > 0) {
+#pragma unroll
+      for (int i = 0; i < NHM; ++i) {
+        const int rr = wave + 4 * i;
+        const int h = rr / PRH, r = rr - h * PRH;
+        const int iy = hy0 + r, ix = hx0 + lane;
+        const bool ok = ch0 + h < p.hi.C && iy >= 0 && iy < p.HH && ix >= 0 && ix < p.HW;
+        if (rr < CHT * PRH) hi[rr * PCHP + lane] = finish(hv[i], aff_sc[CLP + min(h, CHT - 1)], aff_sh[CLP + min(h, CHT - 1)], p.hi.slope, ok);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NHT; ++e) {
+      const int idx = tid + e * 256;
+      const int rr = min(idx / TW, CHT * PRH - 1), col = PCM + (idx - (idx / TW) * TW);
+      const int h = rr / PRH, r = rr - h * PRH;
+      const int iy = hy0 + r, ix = hx0 + col;
+      const bool ok = ch0 + h < p.hi.C && iy >= 0 && iy < p.HH && ix >= 0 && ix < p.HW;
+      if (idx < CHT * PRH * TW) hi[rr * PCHP + col] = finish(ht[e], aff_sc[CLP + h], aff_sh[CLP + h], p.hi.slope, ok);
     }
     __syncthreads();
     const float* lrow = lo + (wave * CLP + m16) * TXLP + kq;
@@ -192,6 +261,8 @@ void fill_src(Src& s, const vts_operand& a, const vts_operand& b, int act) {
   s.d1 = b.data; s.sc1 = b.scale; s.sh1 = b.shift; s.ns1 = b.nstride; s.C1 = b.data ? b.C : 0;
   s.C = s.C0 + s.C1;
   s.act = act;
+  s.slope = vts_slope(act);
+  s.ident = vts_ident();
 }
 
 template <int S, int CLT, int CHT>
