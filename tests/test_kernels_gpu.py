@@ -48,6 +48,15 @@ CONV_CASES = [
     (2, 64, 0, 1, 10, 10, 1, 2, 1),
     (1, 7, 0, 8, 32, 32, 2, 2, 0),
     (1, 5, 0, 33, 20, 24, 2, 1, 2),
+    # small-map (flattened batch) path: N >= 8, maps <= 34
+    (9, 7, 0, 8, 32, 32, 2, 2, 0),
+    (12, 8, 0, 16, 17, 17, 2, 2, 1),
+    (33, 16, 0, 32, 9, 9, 2, 2, 1),
+    (16, 32, 0, 64, 5, 5, 1, 2, 1),
+    (8, 64, 0, 1, 6, 6, 1, 2, 1),
+    (20, 32, 0, 64, 2, 2, 1, 2, 1),
+    (10, 3, 4, 8, 16, 12, 2, 2, 0),
+    (64, 80, 0, 80, 4, 4, 2, 1, 1),
 ]
 
 
@@ -88,6 +97,14 @@ CONVT_CASES = [
     (1, 16, 0, 8, 17, 17, 2, 2, 0, 0),   # backward-data geometry of a s2 p2 conv (odd -> even size)
     (1, 64, 0, 32, 10, 10, 1, 2, 0, 0),  # backward-data geometry of a s1 p2 conv
     (1, 1, 0, 64, 11, 11, 1, 2, 0, 0),
+    # small-map path
+    (16, 64, 0, 32, 6, 6, 1, 2, 0, 0),
+    (9, 1, 0, 64, 7, 7, 1, 2, 0, 0),
+    (12, 32, 0, 16, 5, 5, 2, 2, 0, 0),
+    (10, 16, 0, 8, 9, 9, 2, 2, 0, 0),
+    (40, 8, 0, 7, 17, 17, 2, 2, 0, 0),
+    (8, 80, 80, 80, 2, 2, 2, 1, 2, 0),
+    (8, 10, 0, 3, 16, 16, 2, 1, 2, 1),
 ]
 
 
@@ -149,6 +166,29 @@ def test_conv_transposed_odd_output_and_dmask_accumulate():
     ops.conv4x4(Act(g.to(dev)), wd.view(-1)[16:], 16, Cin * 16, 3, out, stride=2, pad=2, transposed=True, dmask=dm, dmask_act=1,
                 accumulate=True)
     assert rel(out, prev + ref_full[:, 1:4]) < 1e-5
+
+
+def test_small_map_dmask_accumulate_odd_sizes():
+    """small-map path: backward-data of Conv2d(8->16, s2, p2) on 17x17 maps (odd size: 17 -> 9 -> 17),
+    with derivative mask and accumulation, batch 24."""
+    from vts import ops
+    from vts.ops import Act
+
+    dev = _dev()
+    N, Cin, Cout, H = 24, 8, 16, 17
+    x = detrand.uniform((N, Cin, H, H), 25, "x").requires_grad_(True)
+    sc, sh = _affine(N, Cin, 25, "a")
+    w = detrand.uniform((Cout, Cin, 4, 4), 25, "w") * 0.3
+    xn = x * sc.view(N, Cin, 1, 1) + sh.view(N, Cin, 1, 1)
+    y = F.conv2d(F.leaky_relu(xn, 0.2), w, None, stride=2, padding=2)
+    g = detrand.uniform(tuple(y.shape), 25, "g")
+    (y * g).sum().backward()
+    ref = x.grad / sc.view(N, Cin, 1, 1)   # gradient wrt the normalised tensor, incl. the LeakyReLU mask
+    prev = detrand.uniform((N, Cin, H, H), 25, "prev")
+    out = prev.clone().to(dev)
+    ops.conv4x4(Act(g.to(dev)), w.to(dev), 16, Cin * 16, Cin, out, stride=2, pad=2, transposed=True,
+                dmask=Act(x.detach().to(dev), sc.to(dev), sh.to(dev)), dmask_act=1, accumulate=True)
+    assert rel(out, prev + ref) < 1e-5
 
 
 def L_operand_slice(t, c0, c):

@@ -60,6 +60,12 @@ def wgrad_case(N, CL, LH, CH, stride, pad):
 
 if __name__ == "__main__":
     print("ABLATE=%s SMALL=%s" % (os.environ.get("VTS_ABLATE"), os.environ.get("VTS_SMALL_WGS")))
+    if os.environ.get("VTS_MB") == "small":
+        conv_case(256, 64, 6, 6, 1, 1, 2, False)
+        conv_case(256, 32, 5, 5, 64, 1, 2, False)
+        conv_case(256, 7, 32, 32, 8, 2, 2, False)
+        conv_case(256, 64, 6, 6, 32, 1, 2, True)
+        sys.exit(0)
     conv_case(4, 9, 1024, 1024, 10, 2, 1, False)
     conv_case(4, 10, 512, 512, 20, 2, 1, False)
     conv_case(4, 40, 128, 128, 80, 2, 1, False)

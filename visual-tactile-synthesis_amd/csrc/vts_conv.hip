@@ -515,6 +515,13 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
                   "vts_conv4x4: transposed output %dx%d inconsistent with input %dx%d s%d p%d", d->OH, d->OW, d->IH,
                   d->IW, d->stride, d->pad);
   }
+  {
+    static const int use_small = getenv("VTS_NO_SMALL") ? 0 : 1;
+    if (use_small) {
+      const int rc = vts_conv_small_try(d, (hipStream_t)stream);
+      if (rc != VTS_ERR_UNSUPPORTED) return rc;
+    }
+  }
   ConvK k;
   k.s0 = d->in0.data; k.sc0 = d->in0.scale; k.sh0 = d->in0.shift; k.ns0 = d->in0.nstride; k.C0 = d->in0.C;
   k.s1 = d->in1.data; k.sc1 = d->in1.scale; k.sh1 = d->in1.shift; k.ns1 = d->in1.nstride;
