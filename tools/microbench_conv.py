@@ -60,6 +60,10 @@ def wgrad_case(N, CL, LH, CH, stride, pad):
 
 if __name__ == "__main__":
     print("ABLATE=%s SMALL=%s" % (os.environ.get("VTS_ABLATE"), os.environ.get("VTS_SMALL_WGS")))
+    if os.environ.get("VTS_MB") == "pmc":
+        conv_case(4, 9, 1024, 1024, 10, 2, 1, False)
+        wgrad_case(4, 10, 512, 9, 2, 1)
+        sys.exit(0)
     if os.environ.get("VTS_MB") == "small":
         conv_case(256, 64, 6, 6, 1, 1, 2, False)
         conv_case(256, 32, 5, 5, 64, 1, 2, False)

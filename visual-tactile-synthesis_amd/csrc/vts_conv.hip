@@ -44,6 +44,7 @@ struct ConvK {
   float* part;      // k-split partial sums [KS][N][Cout][OH][OW] (raw accumulators), or nullptr
   const float* ident;  // {1, 0}
   float slope_in;      // input activation as t > 0 ? t : slope * t
+  int identity_in;     // no affine on either source and no input activation
   int ablate;       // profiling only (env VTS_ABLATE): 1 skip global loads, 2 skip MFMA, 4 skip epilogue
 };
 
@@ -57,12 +58,15 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int PC = MODE == 0 ? (TX - 1) * S + 4 : (S == 2 ? TX + 2 : TX + 3);
   constexpr int PCP = PC + 1;
   constexpr int COP = (NR % 2 == 1) ? NR * 16 : NR * 16 + 16;
-  constexpr int PCM = (PC / 64) * 64;  // columns handled row-wise; the tail goes element-wise
-  constexpr int TW = PC - PCM;
+  static_assert(CK == 4, "staging maps wave w to input channel w of the chunk");
+  // Row-wise staging: wave w stages the PR rows of channel w of the chunk, 64 columns per load.  A short
+  // remainder (<= 16 columns) is staged element-wise instead of by a mostly idle 64-lane piece.
+  constexpr int REM = PC % 64;
+  constexpr int NCM = PC / 64 + ((REM > 16) ? 1 : 0);  // 64-column pieces per row (the last may be partial)
+  constexpr int PCM = (REM > 16) ? PC : (PC / 64) * 64;
+  constexpr int TW = PC - PCM;                          // element-wise tail columns
   constexpr int NROWS = CK * PR;
-  constexpr int RPW = (NROWS + 3) / 4;                 // patch rows per wave
-  constexpr int NCM = PCM / 64;                        // 64-column pieces per row
-  constexpr int NPV = RPW * NCM > 0 ? RPW * NCM : 1;   // prefetch registers: row-wise part of the patch
+  constexpr int NPV = PR * NCM > 0 ? PR * NCM : 1;      // prefetch registers: row-wise part of the patch
   constexpr int NTV = (NROWS * TW + 255) / 256 > 0 ? (NROWS * TW + 255) / 256 : 1;  // ... tail columns
   constexpr int NWV = CK * NR;                         // ... weights (CK*16*NR*16 / 256)
   constexpr int EC = (P == 4) ? 2 * TX : TX;           // epilogue pass: TY rows x EC columns x 16 channels
@@ -137,62 +141,34 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
 #pragma unroll
   for (int i = 0; i < NWV; ++i) wv[i] = 1.f;
 
-  // Staging discipline (this is what makes the kernel stream): load_chunk issues ONLY loads -- every
-  // address is clamped into the tensor so no load sits under a data-dependent branch (hipcc would
-  // branch around it and drain vmcnt per element, serialising every round trip) -- and keeps the raw
-  // values in registers.  store_chunk, which runs after the MFMA phase of the previous chunk, applies
-  // normalisation + activation + zero padding branch-free and writes LDS.  Per chunk the only scalar
-  // state is the CK (scale, shift) pairs.
+  // Staging discipline (this is what makes the kernel stream and keeps it off the issue limit):
+  //  * load_chunk issues ONLY loads: every address is clamped into the tensor, so no load sits under a
+  //    data-dependent branch (hipcc would branch around it and drain vmcnt per element), and the raw
+  //    values stay in registers across the MFMA phase of the previous chunk;
+  //  * all address arithmetic is hoisted: wave w owns channel w of the chunk, so per chunk a wave needs
+  //    one base pointer (SGPRs) and its rows differ by compile-time multiples of the row pitch; column
+  //    offsets / masks are per-lane constants computed once per workgroup;
+  //  * store_chunk applies normalisation + activation + zero padding branch-free and writes LDS.
   float csc[CK], csh[CK];
 #pragma unroll
   for (int c = 0; c < CK; ++c) {
     csc[c] = 1.f;
     csh[c] = 0.f;
   }
+  int colofs[NCM > 0 ? NCM : 1];
+  bool colok[NCM > 0 ? NCM : 1];
+#pragma unroll
+  for (int cm = 0; cm < NCM; ++cm) {
+    const int col = cm * 64 + lane, ix = ix0 + col;
+    colofs[cm] = min(max(ix, 0), p.IW - 1);
+    colok[cm] = col < PCM && ix >= 0 && ix < p.IW;
+  }
+  const float* wbase = nullptr;   // this wave's channel plane (clamped)
+  float wsc = 1.f, wsh = 0.f;
 
-  auto chunk_affine = [&](int cbase) {
-#pragma unroll
-    for (int c = 0; c < CK; ++c) {
-      const int cic = min(cbase + c, p.Cin - 1);
-      const bool first = cic < p.C0;
-      const int cl = first ? cic : cic - p.C0;
-      const float* scp = first ? p.sc0 : p.sc1;
-      const float* shp = first ? p.sh0 : p.sh1;
-      const int aidx = n * (first ? p.C0 : p.C1) + cl;
-      const bool hsc = scp != nullptr, hsh = shp != nullptr;
-      csc[c] = (hsc ? scp : p.ident)[hsc ? aidx : 0];
-      csh[c] = (hsh ? shp : p.ident)[hsh ? aidx : 1];
-    }
-  };
-
-  auto row_ptr = [&](int cbase, int rr) -> const float* {
-    const int c = rr / PR, r = rr - c * PR;
-    const int cic = min(cbase + c, p.Cin - 1), iyc = min(max(iy0 + r, 0), p.IH - 1);
-    const bool first = cic < p.C0;
-    const int cl = first ? cic : cic - p.C0;
-    const float* base = first ? p.s0 + n * p.ns0 : p.s1 + n * p.ns1;
-    return base + cl * plane + (int64_t)iyc * p.IW;
-  };
-
-  auto load_chunk = [&](int chunk) {
-    const int cbase = chunk * CK;
-    chunk_affine(cbase);
-    if (NCM > 0) {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const float* src = row_ptr(cbase, min(wave + 4 * i, NROWS - 1));
-#pragma unroll
-        for (int cm = 0; cm < NCM; ++cm) pv[i * NCM + cm] = src[min(max(ix0 + cm * 64 + lane, 0), p.IW - 1)];
-      }
-    }
-    if (TW > 0) {
-#pragma unroll
-      for (int e = 0; e < NTV; ++e) {
-        const int idx = min(tid + e * 256, NROWS * TW - 1);
-        const int rr = idx / TW, col = PCM + (idx - rr * TW);
-        tv[e] = row_ptr(cbase, rr)[min(max(ix0 + col, 0), p.IW - 1)];
-      }
-    }
+  // weights: chunk-invariant part of the per-thread element decode
+  int wgo[NWV], wlo[NWV], wmeta[NWV];
+  {
     constexpr int NCO = NR * 16;
 #pragma unroll
     for (int e = 0; e < NWV; ++e) {
@@ -215,12 +191,75 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         const int ky = (((ph >> 1) + p.pad) & 1) + 2 * a, kx = (((ph & 1) + p.pad) & 1) + 2 * b;
         tap = ky * 4 + kx;
       }
-      wv[e] = p.w[(int64_t)min(co0 + co, p.Cout - 1) * p.ws_co + (int64_t)min(cbase + c, p.Cin - 1) * p.ws_ci + tap];
+      wgo[e] = min(co0 + co, p.Cout - 1) * p.ws_co + tap;
+      wlo[e] = (c * 16 + slot) * COP + co;
+      wmeta[e] = (c << 16) | (co0 + co < p.Cout ? 1 : 0);
+    }
+  }
+
+  auto chunk_affine = [&](int cbase) {
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const int cic = min(cbase + c, p.Cin - 1);
+      const bool first = cic < p.C0;
+      const int cl = first ? cic : cic - p.C0;
+      const float* scp = first ? p.sc0 : p.sc1;
+      const float* shp = first ? p.sh0 : p.sh1;
+      const int aidx = n * (first ? p.C0 : p.C1) + cl;
+      const bool hsc = scp != nullptr, hsh = shp != nullptr;
+      csc[c] = (hsc ? scp : p.ident)[hsc ? aidx : 0];
+      csh[c] = (hsh ? shp : p.ident)[hsh ? aidx : 1];
+    }
+  };
+
+  auto chan_ptr = [&](int ci) -> const float* {
+    const int cic = min(ci, p.Cin - 1);
+    const bool first = cic < p.C0;
+    const int cl = first ? cic : cic - p.C0;
+    const float* base = first ? p.s0 + n * p.ns0 : p.s1 + n * p.ns1;
+    return base + cl * plane;
+  };
+
+  auto load_chunk = [&](int chunk) {
+    const int cbase = chunk * CK;
+    if (TW > 0) chunk_affine(cbase);
+    if (NCM > 0) {
+      const int cic = min(cbase + wave, p.Cin - 1);
+      const bool first = cic < p.C0;
+      const int cl = first ? cic : cic - p.C0;
+      const float* scp = first ? p.sc0 : p.sc1;
+      const float* shp = first ? p.sh0 : p.sh1;
+      const int aidx = n * (first ? p.C0 : p.C1) + cl;
+      const bool hsc = scp != nullptr, hsh = shp != nullptr;
+      wsc = (hsc ? scp : p.ident)[hsc ? aidx : 0];
+      wsh = (hsh ? shp : p.ident)[hsh ? aidx : 1];
+      wbase = chan_ptr(cbase + wave);
+#pragma unroll
+      for (int r = 0; r < PR; ++r) {
+        const float* src = wbase + (int64_t)min(max(iy0 + r, 0), p.IH - 1) * p.IW;
+#pragma unroll
+        for (int cm = 0; cm < NCM; ++cm) pv[r * NCM + cm] = src[colofs[cm]];
+      }
+    }
+    if (TW > 0) {
+#pragma unroll
+      for (int e = 0; e < NTV; ++e) {
+        const int idx = min(tid + e * 256, NROWS * TW - 1);
+        const int rr = idx / TW, col = PCM + (idx - rr * TW);
+        const int c = rr / PR, r = rr - c * PR;
+        tv[e] = chan_ptr(cbase + c)[(int64_t)min(max(iy0 + r, 0), p.IH - 1) * p.IW + min(max(ix0 + col, 0), p.IW - 1)];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NWV; ++e) {
+      const int c = wmeta[e] >> 16;
+      wv[e] = p.w[wgo[e] + (int64_t)min(cbase + c, p.Cin - 1) * p.ws_ci];
     }
   };
 
   // branch-free  pad( act( x * scale + shift ) )
   auto finish = [&](float x, float sc, float sh, bool inside) -> float {
+    if (p.identity_in) return inside ? x : 0.f;   // uniform: gradients and raw inputs carry no affine / activation
     const float t = fmaf(x, sc, sh);
     const float a = fmaxf(t, 0.f) + p.slope_in * fminf(t, 0.f);
     return inside ? a : 0.f;
@@ -229,24 +268,17 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   auto store_chunk = [&](int chunk) {
     const int cbase = chunk * CK;
     if (NCM > 0) {
+      const bool cok = cbase + wave < p.Cin;
+      float* dst = lds_patch + wave * PR * PCP + lane;
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int rr = wave + 4 * i;
-        const int c = rr / PR, r = rr - c * PR;
+      for (int r = 0; r < PR; ++r) {
         const int iy = iy0 + r;
-        const bool rok = cbase + c < p.Cin && iy >= 0 && iy < p.IH;
-        float sc = csc[0], sh = csh[0];
+        const bool rok = cok && iy >= 0 && iy < p.IH;
 #pragma unroll
-        for (int q = 1; q < CK; ++q) {
-          sc = (c == q) ? csc[q] : sc;
-          sh = (c == q) ? csh[q] : sh;
-        }
-        if (rr < NROWS) {
-#pragma unroll
-          for (int cm = 0; cm < NCM; ++cm) {
-            const int ix = ix0 + cm * 64 + lane;
-            lds_patch[rr * PCP + cm * 64 + lane] = finish(pv[i * NCM + cm], sc, sh, rok && ix >= 0 && ix < p.IW);
-          }
+        for (int cm = 0; cm < NCM; ++cm) {
+          const float v = finish(pv[r * NCM + cm], wsc, wsh, rok && colok[cm]);
+          if (cm * 64 + 63 < PCM) dst[r * PCP + cm * 64] = v;          // full piece
+          else if (cm * 64 + lane < PCM) dst[r * PCP + cm * 64] = v;   // partial last piece
         }
       }
     }
@@ -267,23 +299,10 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         if (rr < NROWS) lds_patch[rr * PCP + col] = finish(tv[e], sc, sh, ok);
       }
     }
-    constexpr int NCO = NR * 16;
 #pragma unroll
     for (int e = 0; e < NWV; ++e) {
-      const int idx = tid + e * 256;
-      int co, c, slot;
-      if (co_major) {
-        co = idx / (CK * 16);
-        const int rem = idx - co * (CK * 16);
-        c = rem >> 4;
-        slot = rem & 15;
-      } else {
-        c = idx / (NCO * 16);
-        const int rem = idx - c * (NCO * 16);
-        co = rem >> 4;
-        slot = rem & 15;
-      }
-      lds_w[(c * 16 + slot) * COP + co] = (co0 + co < p.Cout && cbase + c < p.Cin) ? wv[e] : 0.f;
+      const int c = wmeta[e] >> 16;
+      lds_w[wlo[e]] = ((wmeta[e] & 1) && cbase + c < p.Cin) ? wv[e] : 0.f;
     }
   };
 
@@ -296,9 +315,8 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     const bool more = chunk + 1 < chunk_end;
     if (more && !(p.ablate & 1)) load_chunk(chunk + 1);
     // ---- MFMA accumulate ----
-    if (!(p.ablate & 2))
-#pragma unroll
-    for (int c = 0; c < CK; ++c) {
+    const int cvalid = (p.ablate & 2) ? 0 : min(CK, p.Cin - chunk * CK);   // channels beyond Cin are zero: skip them
+    for (int c = 0; c < cvalid; ++c) {
       const float* pp = lds_patch + c * PR * PCP;
       const float* ww = lds_w + c * 16 * COP + kq * COP + m16;
       if (MODE == 1 && S == 2) {
@@ -540,6 +558,7 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.ident = vts_ident();
   VTS_CHECK_ARG(k.ident, "vts_conv4x4: could not allocate the identity constants");
   k.slope_in = vts_slope(d->act_in);
+  k.identity_in = (d->act_in == VTS_ACT_NONE && !d->in0.scale && !d->in0.shift && !(d->in1.data && (d->in1.scale || d->in1.shift))) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int nr = (d->Cout + 15) / 16;
   const int N = d->N;

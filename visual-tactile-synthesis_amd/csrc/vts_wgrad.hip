@@ -92,40 +92,54 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
 #pragma unroll
     for (int h = 0; h < CHT; ++h) acc[t][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const int n = tile / (p.tiles_y * p.tiles_x);
+  // Software pipeline over this workgroup's tiles: the raw loads (and per-channel scale/shift) of tile
+  // t+1 are issued into registers before the MFMA phase of tile t and consumed after it.
+  // All address arithmetic is wave-uniform (SALU) except per-lane column constants computed once per
+  // tile: a (row, channel-pair) line of the low-res operand per wave instruction (one channel per
+  // half-wave), one patch row of one high-res channel per wave instruction.
+  constexpr int NLO = TYL * CLP / 8;           // low-res (row, channel-pair) items per wave
+  constexpr int REM = PCH % 64;
+  constexpr int NCMH = PCH / 64 + ((REM > 16) ? 1 : 0);
+  constexpr int PCM = (REM > 16) ? PCH : (PCH / 64) * 64, TW = PCH - PCM;
+  constexpr int RPWH = (PRH + 3) / 4;          // high-res patch rows per wave per channel
+  constexpr int NHM = CHT * RPWH * NCMH > 0 ? CHT * RPWH * NCMH : 1;
+  constexpr int NHT = (CHT * PRH * TW + 255) / 256;
+  const int half = lane >> 5, xl = lane & 31;
+  float lv[NLO], hv[NHM], ht[NHT > 0 ? NHT : 1];
+  float asc = 1.f, ash = 0.f;
+
+  auto decode = [&](int tile, int& n, int& y0, int& x0) {
+    n = tile / (p.tiles_y * p.tiles_x);
     const int rem = tile - n * (p.tiles_y * p.tiles_x);
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    const int y0 = ty * TYL, x0 = tx * TXL;
+    y0 = ty * TYL;
+    x0 = tx * TXL;
+  };
+
+  auto load_tile = [&](int tile) {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
     const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.pad;
-    constexpr int NLO = TYL * CLP / 8;
-    constexpr int PCM = PCH >= 64 ? 64 : 0, TW = PCH - PCM;
-    constexpr int NHM = PCM > 0 ? (CHT * PRH + 3) / 4 : 1;
-    constexpr int NHT = (CHT * PRH * TW + 255) / 256;
-    const int half = lane >> 5, xl = lane & 31;
-    // (1) per-channel scale/shift of this tile's channels -> LDS
-    if (tid < CLP + CHT) {
-      float sc, sh;
-      if (tid < CLP) src_affine(p.lo, n, cl0 + tid, sc, sh);
-      else src_affine(p.hi, n, ch0 + tid - CLP, sc, sh);
-      aff_sc[tid] = sc;
-      aff_sh[tid] = sh;
-    }
-    // (2) raw loads, all in flight together
-    float lv[NLO], hv[NHM], ht[NHT > 0 ? NHT : 1];
+    if (tid < CLP) src_affine(p.lo, n, cl0 + tid, asc, ash);
+    else if (tid < CLP + CHT) src_affine(p.hi, n, ch0 + tid - CLP, asc, ash);
+    const int lcol = min(x0 + xl, p.LW - 1);
 #pragma unroll
     for (int i = 0; i < NLO; ++i) {
-      const int it = wave * 2 + half + 8 * i;  // (row, channel) line of 32 pixels per half-wave
-      const int row = it / CLP, cl = it - row * CLP;
-      lv[i] = src_ptr(p.lo, n, cl0 + cl, y0 + row, p.LH, p.LW)[min(x0 + xl, p.LW - 1)];
+      const int ip = wave + 4 * i;                       // uniform
+      const int row = (2 * ip) / CLP, cl = 2 * ip - row * CLP;
+      const float* pa = src_ptr(p.lo, n, cl0 + cl, y0 + row, p.LH, p.LW);
+      const float* pb = src_ptr(p.lo, n, cl0 + cl + 1, y0 + row, p.LH, p.LW);
+      lv[i] = (half ? pb : pa)[lcol];
     }
-    if (PCM > 0) {
+    if (NCMH > 0) {
 #pragma unroll
-      for (int i = 0; i < NHM; ++i) {
-        const int rr = min(wave + 4 * i, CHT * PRH - 1);
-        const int h = rr / PRH, r = rr - h * PRH;
-        hv[i] = src_ptr(p.hi, n, ch0 + h, hy0 + r, p.HH, p.HW)[min(max(hx0 + lane, 0), p.HW - 1)];
-      }
+      for (int h = 0; h < CHT; ++h)
+#pragma unroll
+        for (int j = 0; j < RPWH; ++j) {
+          const float* src = src_ptr(p.hi, n, ch0 + h, hy0 + min(wave + 4 * j, PRH - 1), p.HH, p.HW);
+#pragma unroll
+          for (int cm = 0; cm < NCMH; ++cm) hv[(h * RPWH + j) * NCMH + cm] = src[min(max(hx0 + cm * 64 + lane, 0), p.HW - 1)];
+        }
     }
 #pragma unroll
     for (int e = 0; e < NHT; ++e) {
@@ -134,23 +148,44 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
       const int h = rr / PRH, r = rr - h * PRH;
       ht[e] = src_ptr(p.hi, n, ch0 + h, hy0 + r, p.HH, p.HW)[min(max(hx0 + col, 0), p.HW - 1)];
     }
+  };
+
+  auto store_tile = [&](int tile) {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.pad;
+    if (tid < CLP + CHT) {
+      aff_sc[tid] = asc;
+      aff_sh[tid] = ash;
+    }
     __syncthreads();
-    // (3) normalise + activate + pad, write the LDS tiles: lo[row][cl][x], hi[ch][r][col]
+    // normalise + activate + pad, write the LDS tiles: lo[row][cl][x], hi[ch][r][col]
+    const bool xok = x0 + xl < p.LW;
+    float* ldst = lo + half * TXLP + xl;
 #pragma unroll
     for (int i = 0; i < NLO; ++i) {
-      const int it = wave * 2 + half + 8 * i;
-      const int row = it / CLP, cl = it - row * CLP;
-      const bool ok = cl0 + cl < p.lo.C && y0 + row < p.LH && x0 + xl < p.LW;
-      lo[it * TXLP + xl] = finish(lv[i], aff_sc[cl], aff_sh[cl], p.lo.slope, ok);
+      const int ip = wave + 4 * i;
+      const int row = (2 * ip) / CLP, cl = 2 * ip - row * CLP;
+      const bool ok = cl0 + cl + half < p.lo.C && y0 + row < p.LH && xok;
+      ldst[2 * ip * TXLP] = finish(lv[i], aff_sc[cl + half], aff_sh[cl + half], p.lo.slope, ok);
     }
-    if (PCM > 0) {
+    if (NCMH > 0) {
 #pragma unroll
-      for (int i = 0; i < NHM; ++i) {
-        const int rr = wave + 4 * i;
-        const int h = rr / PRH, r = rr - h * PRH;
-        const int iy = hy0 + r, ix = hx0 + lane;
-        const bool ok = ch0 + h < p.hi.C && iy >= 0 && iy < p.HH && ix >= 0 && ix < p.HW;
-        if (rr < CHT * PRH) hi[rr * PCHP + lane] = finish(hv[i], aff_sc[CLP + min(h, CHT - 1)], aff_sh[CLP + min(h, CHT - 1)], p.hi.slope, ok);
+      for (int h = 0; h < CHT; ++h) {
+        const float hsc = aff_sc[CLP + h], hsh = aff_sh[CLP + h];
+        const bool cok = ch0 + h < p.hi.C;
+#pragma unroll
+        for (int j = 0; j < RPWH; ++j) {
+          const int r = wave + 4 * j;
+          const int iy = hy0 + r;
+          const bool rok = cok && iy >= 0 && iy < p.HH;
+#pragma unroll
+          for (int cm = 0; cm < NCMH; ++cm) {
+            const int col = cm * 64 + lane, ix = hx0 + col;
+            const float v = finish(hv[(h * RPWH + j) * NCMH + cm], hsc, hsh, p.hi.slope, rok && ix >= 0 && ix < p.HW);
+            if (r < PRH && col < PCM) hi[(h * PRH + r) * PCHP + col] = v;
+          }
+        }
       }
     }
 #pragma unroll
@@ -163,6 +198,13 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
       if (idx < CHT * PRH * TW) hi[rr * PCHP + col] = finish(ht[e], aff_sc[CLP + h], aff_sh[CLP + h], p.hi.slope, ok);
     }
     __syncthreads();
+  };
+
+  if ((int)blockIdx.x < p.ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    store_tile(tile);
+    const int next = tile + gridDim.x;
+    if (next < p.ntiles) load_tile(next);
     const float* lrow = lo + (wave * CLP + m16) * TXLP + kq;
     const float* hrow = hi + (wave * S + (m16 >> 2)) * PCHP + kq * S + (m16 & 3);
 #pragma unroll
