@@ -209,6 +209,12 @@ WGRAD_CASES = [
     (2, 20, 20, 10, 16, 16, 2, 1, 2, 0, True),
     (1, 80, 80, 40, 8, 8, 2, 1, 2, 0, True),
     (2, 10, 0, 3, 32, 32, 2, 1, 2, 0, True),
+    # narrow-tile path (maps at most 8 wide), D2-on-patches shapes
+    (32, 64, 0, 32, 6, 6, 1, 2, 0, 1, False),
+    (16, 1, 0, 64, 7, 7, 1, 2, 0, 1, False),
+    (9, 32, 0, 16, 5, 5, 2, 2, 0, 1, False),
+    (12, 16, 0, 8, 3, 3, 2, 2, 0, 1, False),
+    (8, 40, 40, 20, 8, 8, 2, 1, 2, 0, True),
 ]
 
 

@@ -60,14 +60,15 @@ __device__ __forceinline__ float finish(float x, float sc, float sh, float slope
   return inside ? a : 0.f;
 }
 
-constexpr int TYL = 4, TXL = 32, TXLP = 34;  // TXLP = 2 (mod 32): A reads hit banks 2*cl + k
+constexpr int TYL = 4;  // tile rows; the tile width TXL is 32, or 8 for maps at most 8 wide (D2 patch passes)
 
-template <int S, int CLT, int CHT>
+template <int S, int CLT, int CHT, int TXL>
 __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
+  constexpr int TXLP = TXL + 2;  // 34 = 2 (mod 32) / 10: A reads (16 channels x 2 pixels) hit distinct banks
   constexpr int CLP = CLT * 16;
   constexpr int PRH = (TYL - 1) * S + 4;
   constexpr int PCH = (TXL - 1) * S + 4;
-  constexpr int PCHP = (S == 2) ? 72 : 40;  // = 8 (mod 32): B reads hit banks 8*ky + kx + S*k
+  constexpr int PCHP = (S == 2 && TXL == 32) ? 72 : 40;  // = 8 (mod 32): B reads hit banks 8*ky + kx + S*k
   static_assert(PCHP >= PCH, "pitch");
   constexpr int LO_FLOATS = TYL * CLP * TXLP;
   constexpr int HI_FLOATS = CHT * PRH * PCHP;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
   // All address arithmetic is wave-uniform (SALU) except per-lane column constants computed once per
   // tile: a (row, channel-pair) line of the low-res operand per wave instruction (one channel per
   // half-wave), one patch row of one high-res channel per wave instruction.
-  constexpr int NLO = TYL * CLP / 8;           // low-res (row, channel-pair) items per wave
+  constexpr int NLO = TYL * CLP * TXL / 256;   // low-res elements per thread
   constexpr int REM = PCH % 64;
   constexpr int NCMH = PCH / 64 + ((REM > 16) ? 1 : 0);
   constexpr int PCM = (REM > 16) ? PCH : (PCH / 64) * 64, TW = PCH - PCM;
@@ -122,14 +123,24 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
     const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.pad;
     if (tid < CLP) src_affine(p.lo, n, cl0 + tid, asc, ash);
     else if (tid < CLP + CHT) src_affine(p.hi, n, ch0 + tid - CLP, asc, ash);
-    const int lcol = min(x0 + xl, p.LW - 1);
+    if (TXL == 32) {
+      const int lcol = min(x0 + xl, p.LW - 1);
 #pragma unroll
-    for (int i = 0; i < NLO; ++i) {
-      const int ip = wave + 4 * i;                       // uniform
-      const int row = (2 * ip) / CLP, cl = 2 * ip - row * CLP;
-      const float* pa = src_ptr(p.lo, n, cl0 + cl, y0 + row, p.LH, p.LW);
-      const float* pb = src_ptr(p.lo, n, cl0 + cl + 1, y0 + row, p.LH, p.LW);
-      lv[i] = (half ? pb : pa)[lcol];
+      for (int i = 0; i < NLO; ++i) {
+        const int ip = wave + 4 * i;                       // uniform
+        const int row = (2 * ip) / CLP, cl = 2 * ip - row * CLP;
+        const float* pa = src_ptr(p.lo, n, cl0 + cl, y0 + row, p.LH, p.LW);
+        const float* pb = src_ptr(p.lo, n, cl0 + cl + 1, y0 + row, p.LH, p.LW);
+        lv[i] = (half ? pb : pa)[lcol];
+      }
+    } else {   // narrow tile: per-lane (row, channel, x) decode, few elements
+#pragma unroll
+      for (int i = 0; i < NLO; ++i) {
+        const int idx = tid + 256 * i;
+        const int x = idx % TXL, line = idx / TXL;
+        const int row = line / CLP, cl = line - row * CLP;
+        lv[i] = src_ptr(p.lo, n, cl0 + cl, y0 + row, p.LH, p.LW)[min(x0 + x, p.LW - 1)];
+      }
     }
     if (NCMH > 0) {
 #pragma unroll
@@ -160,14 +171,25 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
     }
     __syncthreads();
     // normalise + activate + pad, write the LDS tiles: lo[row][cl][x], hi[ch][r][col]
-    const bool xok = x0 + xl < p.LW;
-    float* ldst = lo + half * TXLP + xl;
+    if (TXL == 32) {
+      const bool xok = x0 + xl < p.LW;
+      float* ldst = lo + half * TXLP + xl;
 #pragma unroll
-    for (int i = 0; i < NLO; ++i) {
-      const int ip = wave + 4 * i;
-      const int row = (2 * ip) / CLP, cl = 2 * ip - row * CLP;
-      const bool ok = cl0 + cl + half < p.lo.C && y0 + row < p.LH && xok;
-      ldst[2 * ip * TXLP] = finish(lv[i], aff_sc[cl + half], aff_sh[cl + half], p.lo.slope, ok);
+      for (int i = 0; i < NLO; ++i) {
+        const int ip = wave + 4 * i;
+        const int row = (2 * ip) / CLP, cl = 2 * ip - row * CLP;
+        const bool ok = cl0 + cl + half < p.lo.C && y0 + row < p.LH && xok;
+        ldst[2 * ip * TXLP] = finish(lv[i], aff_sc[cl + half], aff_sh[cl + half], p.lo.slope, ok);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLO; ++i) {
+        const int idx = tid + 256 * i;
+        const int x = idx % TXL, line = idx / TXL;
+        const int row = line / CLP, cl = line - row * CLP;
+        const bool ok = cl0 + cl < p.lo.C && y0 + row < p.LH && x0 + x < p.LW;
+        lo[line * TXLP + x] = finish(lv[i], aff_sc[cl], aff_sh[cl], p.lo.slope, ok);
+      }
     }
     if (NCMH > 0) {
 #pragma unroll
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 }
 
 struct Plan {
-  int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles;
+  int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles, txl;
 };
 
 Plan make_plan(const vts_wgrad_desc* d) {
@@ -285,7 +307,8 @@ Plan make_plan(const vts_wgrad_desc* d) {
   pl.cl_groups = cdiv(CL, pl.clt * 16);
   pl.ch_groups = cdiv(CH, pl.cht);
   pl.tiles_y = cdiv(d->LH, TYL);
-  pl.tiles_x = cdiv(d->LW, TXL);
+  pl.txl = d->LW <= 8 ? 8 : 32;
+  pl.tiles_x = cdiv(d->LW, pl.txl);
   pl.ntiles = d->N * pl.tiles_y * pl.tiles_x;
   const int groups = pl.cl_groups * pl.ch_groups;
   int pw = 1024 / groups;
@@ -310,7 +333,8 @@ void fill_src(Src& s, const vts_operand& a, const vts_operand& b, int act) {
 template <int S, int CLT, int CHT>
 void launch_wg(const WgK& k, const Plan& pl, hipStream_t st) {
   dim3 grid(pl.pw, pl.cl_groups * pl.ch_groups);
-  hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT>), grid, dim3(256), 0, st, k);
+  if (pl.txl == 8) hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT, 8>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT, 32>), grid, dim3(256), 0, st, k);
 }
 
 }  // namespace

@@ -143,7 +143,11 @@ def unet_backward(G, ctx, d_raw):
             gsum_src = g
             second = skip if skip is not None else extra
             ops.wgrad4x4(inp, gop, blk.weight.grad, lo1=second, act_lo=RELU, stride=2, pad=1)
-            ops.channel_sum(gsum_src, blk.bias.grad)
+            if i == 0:
+                ops.channel_sum(gsum_src, blk.bias.grad)
+            # else: the bias feeds an InstanceNorm, so its gradient is identically zero (the norm removes any
+            # per-channel constant).  The reference computes ~1e-9 rounding noise there; the flat gradient
+            # buffer is zero-initialised and this slot is never written, i.e. exactly 0.
             c_in0 = inp.data.shape[1]
             # grad wrt the primary input (normalised output of the previous up block, or feats[nd-1])
             if i == nd - 1:
@@ -164,7 +168,8 @@ def unet_backward(G, ctx, d_raw):
             ops.norm_bwd(g, feats[i], 0)
         src, src1 = ctx.x if i == 0 else (feats[i - 1], None)
         ops.wgrad4x4(Act(g), src, blk.weight.grad, hi1=src1, act_hi=LRELU if i else 0, stride=2, pad=1)
-        ops.channel_sum(g, blk.bias.grad)
+        if not (0 < i < nd - 1):
+            ops.channel_sum(g, blk.bias.grad)   # bias gradients of normalised layers are identically zero (see above)
         if i > 0:
             cin = blk.weight.shape[1]
             tgt, acc = add_grad_list(dfeat, i - 1, feats[i - 1].data.shape, dev)
@@ -263,7 +268,8 @@ def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=
             if param_grads:
                 ops.wgrad4x4(Act(g), src0, conv.weight.grad, hi1=src1, act_hi=LRELU if j else 0, stride=st, pad=2,
                              accumulate=accumulate)
-                ops.channel_sum(g, conv.bias.grad, accumulate=accumulate)
+                if ci not in D.BN_IDX:   # a conv bias in front of a BatchNorm has an identically zero gradient
+                    ops.channel_sum(g, conv.bias.grad, accumulate=accumulate)
             if j > 0:
                 prev = acts[j - 1]
                 tgt = torch.empty_like(prev.data)
