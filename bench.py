@@ -93,7 +93,19 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     else:
         roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    # HBM bytes per launch of this kernel family from the committed PMC passes (profiles/*_traffic_pmc.json:
+    # separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md)
     roof["traffic"] = None
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_pmc.json")))
+        if files:
+            ent = json.load(open(files[-1]))["kernels"].get(label)
+            if ent:
+                roof["traffic"] = ent["hbm_bytes_per_launch"]
+                roof["traffic_source"] = os.path.basename(files[-1])
+    except Exception:
+        pass
     roof["kernel"] = label
     roof["launches_per_step"] = cnt
     roof["avg_launch_us"] = t / cnt * 1e6
@@ -139,6 +151,29 @@ def cpu_baseline(size, style_dim, steps=3):
             "sample": "%d oracle train steps after 1 warm-up, N=1, %dx%d, same flags" % (steps, size, size)}
 
 
+def infer_bench(args):
+    """Generator-only forward (test() of the model): ms per image, inputs resident in HBM."""
+    batch_n = 16 if args.batch == 4 else args.batch
+    model, opt = build_model(args.size, batch_n, args.model)
+    style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
+    model.eval()
+    model.set_input(make_batch(args.size, batch_n, 0, style_dim), phase="test")
+    for _ in range(args.warmup):
+        model.test()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.test()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "inference_ms_per_image", "value": dt / args.steps / batch_n * 1e3, "unit": "ms/image", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s generator forward (test()), %dx%d, %d images/GPU, eager launches" % (args.model, args.size, args.size, batch_n)},
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +184,8 @@ def main():
     ap.add_argument("--model", type=str, default="skitG")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
+    ap.add_argument("--infer", action="store_true",
+                    help="measure the inference forward instead (BASELINE config 4: generator only, 16 images/GPU): ms per image")
     ap.add_argument("--detail", type=str, default=None, help="write a per-(kernel, shape) timing table to this path")
     args = ap.parse_args()
 
@@ -159,6 +196,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     dev = torch.device("cuda", torch.cuda.current_device())
+    if args.infer:
+        return infer_bench(args)
     model, opt = build_model(args.size, args.batch, args.model)
     opt.use_hip_graph = not args.no_graph
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0

@@ -246,3 +246,32 @@ def test_hip_graph_replay_equals_eager():
         assert getattr(eager, "optimizer_" + nm).step_count == getattr(graph, "optimizer_" + nm).step_count == 4
         assert int(getattr(graph, "optimizer_" + nm).step_dev) == 4
     assert rel(graph.fake_I, eager.fake_I) < 1e-6
+
+
+def test_train_and_test_scripts_end_to_end(tmp_path):
+    """The headless train.py / test.py entry points run against the synthetic dataset, write the
+    reference checkpoint file set and loss log, and test.py reloads the generator."""
+    import subprocess
+    import sys
+
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visual-tactile-synthesis_amd")
+    common = ["--model", "sinskitG", "--gpu_ids", "0", "--dataset_mode", "synthetic", "--crop_size", "256", "--checkpoints_dir",
+              str(tmp_path), "--name", "e2e"]
+    train = [sys.executable, os.path.join(pkg, "train.py")] + common + [
+        "--lambda_G1_lpips", "0", "--lambda_G2_lpips", "0", "--use_vision_aided_loss", "False", "--data_len", "3", "--n_epochs", "1",
+        "--n_epochs_decay", "1", "--print_freq", "1", "--save_latest_freq", "2", "--save_epoch_freq", "1", "--batch_size", "1"]
+    out = subprocess.run(train, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = os.path.join(str(tmp_path), "e2e")
+    for f in ("latest_net_G.pth", "latest_net_D.pth", "latest_net_D2.pth", "best_net_G.pth", "1_net_G.pth", "loss_log.txt", "train_opt.txt"):
+        assert os.path.exists(os.path.join(d, f)), f
+    log = open(os.path.join(d, "loss_log.txt")).read()
+    assert "l_G_GAN" in log and "l_G2_L1" in log and "nan" not in log.lower()
+    assert "learning rate = 0.0005000" in out.stdout      # LambdaLR: 1 - 1/(n_epochs_decay+1) after epoch 1
+    test = [sys.executable, os.path.join(pkg, "test.py")] + common + ["--epoch", "latest", "--eval", "--results_dir", str(tmp_path / "res"),
+                                                                       "--num_test", "2", "--data_len", "2"]
+    out = subprocess.run(test, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("processed synthetic_") == 2
+    saved = torch.load(os.path.join(str(tmp_path), "res", "e2e", "test_latest", "synthetic_1234.pt"))
+    assert saved["fake_I"].shape == (1, 3, 256, 256) and saved["fake_gx"].shape == (1, 1, 256, 256)
