@@ -37,6 +37,8 @@ extern "C" {
 #define VTS_ACT_TANH 3 /* epilogue only */
 
 const char* vts_last_error(void);
+/* Kernel instance chosen by the last vts_conv4x4 / vts_wgrad4x4 call of this thread (profiling aid). */
+const char* vts_last_kernel(void);
 int vts_version(void);
 
 /* A (possibly channel-concatenated, lazily normalised) activation operand:

@@ -256,7 +256,7 @@ def test_wgrad(case):
     assert rel(dw2, 2 * ref) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 10, 64, 64), (1, 80, 2, 2), (3, 20, 37, 53), (1, 3, 128, 128)])
+@pytest.mark.parametrize("shape", [(2, 10, 64, 64), (1, 80, 2, 2), (3, 20, 37, 53), (1, 3, 128, 128), (2, 4, 300, 300)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_norm_forward_backward(shape, mode):
     from vts import ops

@@ -16,6 +16,16 @@ void vts_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vts_last_error(void) { return g_err; }
+
+// name of the kernel instance the last dispatching call chose (profiling aid: matches rocprofv3's kernel names)
+static thread_local char g_kernel[160] = "";
+void vts_set_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vts_last_kernel(void) { return g_kernel; }
 extern "C" int vts_version(void) { return 1; }
 
 const float* vts_ident() {

@@ -495,6 +495,7 @@ int launch(const ConvK& k, int N, hipStream_t st, int CG = 1, int KS = 1) {
   const int GH = P == 4 ? (k.OH + 1) / 2 : k.OH, GW = P == 4 ? (k.OW + 1) / 2 : k.OW;
   dim3 grid(cdiv(GW, 16 * MT), cdiv(GH, 4 * RW), N * CG * KS);
   hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK>), grid, dim3(256), 0, st, k);
+  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d>%s", MODE, S, NR, RW, MT, CK, KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
   VTS_CHECK_LAUNCH("vts_conv4x4");
   return VTS_OK;
 }

@@ -262,6 +262,7 @@ template <int MODE, int S, int NR, int UMAX, int CK>
 int launch_small(const SmallK& k, size_t lds_bytes, hipStream_t st) {
   dim3 grid(cdiv(k.N, k.IPB), cdiv(k.Cout, NR * 16));
   hipLaunchKernelGGL((conv_small_kernel<MODE, S, NR, UMAX, CK>), grid, dim3(256), lds_bytes, st, k);
+  vts_set_kernel("conv_small_kernel<%d, %d, %d, %d, %d>", MODE, S, NR, UMAX, CK);
   VTS_CHECK_LAUNCH("vts_conv4x4 (small maps)");
   return VTS_OK;
 }

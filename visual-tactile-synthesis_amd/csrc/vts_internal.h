@@ -9,6 +9,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void vts_set_error(const char* fmt, ...);
+void vts_set_kernel(const char* fmt, ...);
 // device pointer to the two floats {1, 0}: identity scale / shift for operands without an affine, so the
 // kernels can fetch scale/shift unconditionally (no data-dependent branch around a load)
 const float* vts_ident();

@@ -228,6 +228,86 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* __restrict__
   }
 }
 
+// ---- single-launch variants for small groups (<= FUSED_MAX_GROUP elements per normalisation group):
+// one workgroup owns a whole group (IN: one (n,c) plane; BN: channel c of every image), reads it twice
+// (the second pass hits L2) and finishes in place.  Most normalisation calls of the step are this small
+// (inner U-Net layers, every D2 patch pass), where three launches cost more than the arithmetic.
+constexpr int64_t FUSED_MAX_GROUP = 8192;
+
+// element j of group (c; n0..) -> offset into the NCHW tensor; BN groups flatten (n, i) so that every thread has work
+__device__ __forceinline__ int64_t fused_off(int j, int HW, int n0, int c, int64_t nstride, bool bn) {
+  int n = n0, i = j;
+  if (bn) {
+    n = j / HW;
+    i = j - n * HW;
+  }
+  return n * nstride + (int64_t)c * HW + i;
+}
+
+__global__ __launch_bounds__(1024) void norm_stats_fused_kernel(const float* __restrict__ x, int64_t nstride, const NormK k) {
+  __shared__ float red[16];
+  const int g = blockIdx.x;
+  const bool bn = k.mode == 1;
+  const int c = bn ? g : g % k.C;
+  const int n0 = bn ? 0 : g / k.C, n1 = bn ? k.N : n0 + 1;
+  const int total = (n1 - n0) * k.HW;
+  const float cnt = (float)total;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < total; j += blockDim.x) s += x[fused_off(j, k.HW, n0, c, nstride, bn)];
+  const float mean = block_sum(s, red) / cnt;
+  float m2 = 0.f;
+  for (int j = threadIdx.x; j < total; j += blockDim.x) {
+    const float d = x[fused_off(j, k.HW, n0, c, nstride, bn)] - mean;
+    m2 += d * d;
+  }
+  m2 = block_sum(m2, red);
+  const float rstd = 1.f / sqrtf(m2 / cnt + k.eps);
+  const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f, be = (bn && k.beta) ? k.beta[c] : 0.f;
+  for (int n = n0 + threadIdx.x; n < n1; n += blockDim.x) {
+    const int idx = n * k.C + c;
+    k.scale[idx] = ga * rstd;
+    k.shift[idx] = be - mean * ga * rstd;
+    if (k.mean_out) k.mean_out[idx] = mean;
+    if (k.rstd_out) k.rstd_out[idx] = rstd;
+  }
+  if (bn && threadIdx.x == 0) {
+    if (k.running_mean) k.running_mean[c] = (1.f - k.momentum) * k.running_mean[c] + k.momentum * mean;
+    if (k.running_var) k.running_var[c] = (1.f - k.momentum) * k.running_var[c] + k.momentum * (m2 / (cnt - 1.f));
+    if (k.nbt && c == 0) k.nbt[0] += 1;
+  }
+}
+
+__global__ __launch_bounds__(1024) void norm_bwd_fused_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
+                                                              const NormBwdK k) {
+  __shared__ float red[16];
+  const int g = blockIdx.x;
+  const bool bn = k.mode == 1;
+  const int c = bn ? g : g % k.C;
+  const int n0 = bn ? 0 : g / k.C, n1 = bn ? k.N : n0 + 1;
+  const int total = (n1 - n0) * k.HW;
+  const float m = (float)total;
+  const float mu = k.mean[n0 * k.C + c], rs = k.rstd[n0 * k.C + c];  // identical for every n of a BN group
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = threadIdx.x; j < total; j += blockDim.x) {
+    const int64_t off = fused_off(j, k.HW, n0, c, nstride, bn);
+    const float gdy = dy[off];
+    s1 += gdy;
+    s2 += gdy * ((x[off] - mu) * rs);
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f;
+  const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m - B * mu;
+  for (int j = threadIdx.x; j < total; j += blockDim.x) {
+    const int64_t off = fused_off(j, k.HW, n0, c, nstride, bn);
+    dy[off] = A * dy[off] + B * x[off] + Cc;
+  }
+  if (bn && threadIdx.x == 0) {
+    if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + s2;
+    if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + s1;
+  }
+}
+
 // ---- channel sum ----
 __global__ __launch_bounds__(256) void chsum_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
                                                             float* __restrict__ part) {
@@ -284,10 +364,17 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
   VTS_CHECK_ARG(d->N >= 1 && d->C >= 1 && d->HW >= 1 && d->N <= 65535 && d->C <= 65535, "vts_norm_stats: bad shape");
   hipStream_t st = (hipStream_t)stream;
   const int spl = splits_for(d->HW);
-  hipLaunchKernelGGL(stats_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->x, d->nstride, d->C, d->HW, spl, ws);
-  VTS_CHECK_LAUNCH("vts_norm_stats partial");
   NormK k{d->N, d->C, d->HW, spl, d->mode, d->eps, d->momentum, d->gamma, d->beta, d->running_mean, d->running_var,
           d->num_batches_tracked, d->scale, d->shift, d->mean_out, d->rstd_out};
+  const int64_t group = (int64_t)(d->mode == 0 ? 1 : d->N) * d->HW;
+  if (group <= FUSED_MAX_GROUP) {  // small groups: one launch, one workgroup per group (two passes, L2-resident)
+    hipLaunchKernelGGL(norm_stats_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
+                       d->x, d->nstride, k);
+    VTS_CHECK_LAUNCH("vts_norm_stats fused");
+    return VTS_OK;
+  }
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->x, d->nstride, d->C, d->HW, spl, ws);
+  VTS_CHECK_LAUNCH("vts_norm_stats partial");
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, ws, k);
   VTS_CHECK_LAUNCH("vts_norm_stats finalize");
   return VTS_OK;
@@ -300,6 +387,14 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   const int spl = splits_for(d->HW);
   float* part = ws;
   float* coef = ws + (int64_t)d->N * d->C * spl * 3;  // same split as vts_norm_ws_floats
+  const int64_t group = (int64_t)(d->mode == 0 ? 1 : d->N) * d->HW;
+  if (group <= FUSED_MAX_GROUP) {
+    NormBwdK kf{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, coef};
+    hipLaunchKernelGGL(norm_bwd_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
+                       d->dy, d->x, d->nstride, kf);
+    VTS_CHECK_LAUNCH("vts_norm_bwd fused");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, spl,
                      d->mean, d->rstd, part);
   VTS_CHECK_LAUNCH("vts_norm_bwd partial");

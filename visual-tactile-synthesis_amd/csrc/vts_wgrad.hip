@@ -335,6 +335,7 @@ void launch_wg(const WgK& k, const Plan& pl, hipStream_t st) {
   dim3 grid(pl.pw, pl.cl_groups * pl.ch_groups);
   if (pl.txl == 8) hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT, 8>), grid, dim3(256), 0, st, k);
   else hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT, 32>), grid, dim3(256), 0, st, k);
+  vts_set_kernel("wgrad4x4_kernel<%d, %d, %d, %d>", S, CLT, CHT, pl.txl);
 }
 
 }  // namespace

@@ -69,7 +69,7 @@ _lib = None
 
 # every symbol include/vts.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
-    "vts_last_error", "vts_version", "vts_conv4x4", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_channel_sum",
+    "vts_last_error", "vts_last_kernel", "vts_version", "vts_conv4x4", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_channel_sum",
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
@@ -88,6 +88,7 @@ def load():
             "or `make -C visual-tactile-synthesis_amd/csrc`.  There is no fallback path." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.vts_last_error.restype = C.c_char_p
+    lib.vts_last_kernel.restype = C.c_char_p
     for name in ("vts_wgrad4x4_ws_floats", "vts_norm_ws_floats", "vts_channel_sum_ws_floats", "vts_conv4x4_ws_floats"):
         getattr(lib, name).restype = C.c_int64
     lib.vts_conv4x4_ws_floats.argtypes = [C.POINTER(ConvDesc)]

@@ -45,6 +45,8 @@ def _run(label, nbytes, flops, fn, *args):
     rc = fn(*args)
     e1.record()
     L.check(rc, label)
+    if label.startswith(("conv4x4", "wgrad4x4")):
+        label = L.load().vts_last_kernel().decode()   # the exact kernel instance, as rocprofv3 names it
     TIMER.append((label, nbytes, flops, e0, e1, DETAIL))
     DETAIL = None
 
