@@ -1,0 +1,57 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
+
+    python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/r01e_traffic_pmc.json "note"
+
+Keys are kernel instance names exactly as `vts_last_kernel()` / bench.py's breakdown print them
+(`conv4x4_kernel<1, 2, 1, 1, 4, 4>`, `norm_bwd_fused_kernel`, ...).  Bytes follow MI355X_MICROARCH.md's
+HBM section: both counters are in KiB; gfx950 FETCH_SIZE under-counts wide reads by 2x, so
+bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def kernel_key(name):
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    m = re.match(r"([A-Za-z_0-9:]+(<[^>]*>)?)", name)
+    return m.group(1) if m else name
+
+
+def collect(d, counter):
+    acc = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                a = acc.setdefault(kernel_key(row["Kernel_Name"]), [0, 0.0])
+                a[0] += 1
+                a[1] += float(row["Counter_Value"])
+    return acc
+
+
+def main(fetch_dir, write_dir, dst, note=""):
+    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        fc, fv = fe.get(k, [0, 0.0])
+        wc, wv = wr.get(k, [0, 0.0])
+        f_kb = fv / fc if fc else 0.0
+        w_kb = wv / wc if wc else 0.0
+        kernels[k] = {"launches_sampled": max(fc, wc), "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
+                      "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0}
+    out = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) over "
+                  "`python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_graph`; mean per launch of each kernel "
+                  "instance; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)",
+           "note": note, "kernels": kernels}
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote %s (%d kernels)" % (dst, len(kernels)))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])

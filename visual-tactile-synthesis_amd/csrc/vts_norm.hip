@@ -371,12 +371,14 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
     hipLaunchKernelGGL(norm_stats_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
                        d->x, d->nstride, k);
     VTS_CHECK_LAUNCH("vts_norm_stats fused");
+    vts_set_kernel("norm_stats_fused_kernel");
     return VTS_OK;
   }
   hipLaunchKernelGGL(stats_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->x, d->nstride, d->C, d->HW, spl, ws);
   VTS_CHECK_LAUNCH("vts_norm_stats partial");
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, ws, k);
   VTS_CHECK_LAUNCH("vts_norm_stats finalize");
+  vts_set_kernel("stats_partial_kernel+norm_finalize_kernel");
   return VTS_OK;
 }
 
@@ -393,6 +395,7 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
     hipLaunchKernelGGL(norm_bwd_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
                        d->dy, d->x, d->nstride, kf);
     VTS_CHECK_LAUNCH("vts_norm_bwd fused");
+    vts_set_kernel("norm_bwd_fused_kernel");
     return VTS_OK;
   }
   hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, spl,
@@ -403,6 +406,7 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   VTS_CHECK_LAUNCH("vts_norm_bwd finalize");
   hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, coef);
   VTS_CHECK_LAUNCH("vts_norm_bwd apply");
+  vts_set_kernel("norm_bwd_partial_kernel+norm_bwd_finalize_kernel+norm_bwd_apply_kernel");
   return VTS_OK;
 }
 

@@ -45,7 +45,7 @@ def _run(label, nbytes, flops, fn, *args):
     rc = fn(*args)
     e1.record()
     L.check(rc, label)
-    if label.startswith(("conv4x4", "wgrad4x4")):
+    if label.startswith(("conv4x4", "wgrad4x4", "norm_")):
         label = L.load().vts_last_kernel().decode()   # the exact kernel instance, as rocprofv3 names it
     TIMER.append((label, nbytes, flops, e0, e1, DETAIL))
     DETAIL = None
@@ -181,7 +181,7 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
     d.gamma, d.dgamma, d.dbeta = L.ptr(gamma), L.ptr(dgamma), L.ptr(dbeta)
     d.accumulate_param_grads = int(accumulate)
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
-    _run("norm_bwd", 4.0 * n * c * h * w * 5, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
+    _run("norm_bwd", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
     return dy
 
 
