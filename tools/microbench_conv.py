@@ -64,6 +64,22 @@ if __name__ == "__main__":
         conv_case(4, 9, 1024, 1024, 10, 2, 1, False)
         wgrad_case(4, 10, 512, 9, 2, 1)
         sys.exit(0)
+    if os.environ.get("VTS_MB", "").startswith("one:"):
+        a = [int(v) for v in os.environ["VTS_MB"][4:].split(",")]
+        conv_case(a[0], a[1], a[2], a[3], a[4], a[5], a[6], bool(a[7]))
+        sys.exit(0)
+    if os.environ.get("VTS_MB") == "top":
+        conv_case(4, 4, 1024, 1024, 8, 2, 2, False)
+        conv_case(4, 8, 513, 513, 16, 2, 2, False)
+        conv_case(4, 16, 257, 257, 8, 2, 2, True)
+        conv_case(4, 32, 129, 129, 16, 2, 2, True)
+        conv_case(4, 40, 256, 256, 10, 2, 1, True)
+        conv_case(4, 20, 512, 512, 3, 2, 1, True)
+        conv_case(4, 32, 129, 129, 64, 1, 2, False)
+        conv_case(4, 64, 130, 130, 32, 1, 2, True)
+        conv_case(4, 64, 130, 130, 1, 1, 2, False)
+        conv_case(4, 160, 64, 64, 40, 2, 1, True)
+        sys.exit(0)
     if os.environ.get("VTS_MB") == "small":
         conv_case(256, 64, 6, 6, 1, 1, 2, False)
         conv_case(256, 32, 5, 5, 64, 1, 2, False)
