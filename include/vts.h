@@ -85,6 +85,7 @@ typedef struct vts_conv_desc {
   int accumulate;
   float* ws;          /* optional scratch for the small-grid k-split path (may be NULL: path not taken) */
   int64_t ws_floats;  /* vts_conv4x4_ws_floats(d) is always enough */
+  int pad_dx;         /* horizontal padding = pad + pad_dx (0: square padding) */
 } vts_conv_desc;
 
 int64_t vts_conv4x4_ws_floats(const vts_conv_desc* d);
@@ -105,6 +106,7 @@ typedef struct vts_wgrad_desc {
   int stride, pad;
   float* dw;
   int accumulate;
+  int pad_dx; /* horizontal padding = pad + pad_dx */
 } vts_wgrad_desc;
 
 int64_t vts_wgrad4x4_ws_floats(const vts_wgrad_desc* d);
@@ -163,6 +165,35 @@ int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream);
 /* dy (+)= g * act'(x*scale+shift): derivative mask as a stand-alone op (used where the
  * producer of g is not one of the conv kernels). */
 int vts_act_bwd(const float* g, const vts_operand* x, int N, int HW, int act, float* dy, int accumulate, void* stream);
+
+/* ---- ResNet generator building blocks (--netG resnet_{4,6,9}blocks, models/networks.py:1051-1154) ----
+ *
+ * Padding fused with normalise-on-load and an optional residual:
+ *   out[n,c,y,x] = act(in[n,c,map(y-pt),map(x-pl)] * scale[n,c] + shift[n,c]) (+ res[n,c,y,x])
+ * `out` is [N, C, H+pt+pb, W+pl+pr] with batch stride out_nstride (0: contiguous; a larger stride writes a
+ * channel slice of a wider tensor, i.e. torch.cat on store; `res` is always contiguous); mode 0 zero, 1 reflect (nn.ReflectionPad2d,
+ * networks.py:1075,1146,1300), 2 replicate; act may be VTS_ACT_TANH.  With all pads 0 it is the fused
+ * `x + norm(conv_block(x))` of ResnetBlock.forward (networks.py:1322) or a plain activation. */
+int vts_pad_affine(const vts_operand* in, int N, int H, int W, int pt, int pb, int pl, int pr, int mode, int act,
+                   const float* res, float* out, int64_t out_nstride, void* stream);
+/* Adjoint of the padding index map: din[n,c,i,j] (+)= sum of dpad over the padded positions that read (i,j). */
+int vts_pad_bwd(const float* dpad, int N, int C, int H, int W, int pt, int pb, int pl, int pr, int mode, float* din,
+                int accumulate, void* stream);
+
+/* Anti-aliased resampling (networks.py:51-74 Downsample filt 3 / stride 2 / reflect; :87-107 Upsample filt 4 /
+ * stride 2 / replicate), depthwise, with normalise-on-load of the input.  Down: [H,W] -> [(H-1)/2+1, (W-1)/2+1];
+ * up: [H,W] -> [2H,2W].  The *_bwd entry points are the adjoints (gradient w.r.t. the activated input). */
+int vts_blur_down(const vts_operand* in, int act, int N, int H, int W, float* out, void* stream);
+int vts_blur_down_bwd(const float* dout, int N, int C, int H, int W, float* din, int accumulate, void* stream);
+int vts_blur_up(const vts_operand* in, int act, int N, int H, int W, float* out, void* stream);
+int vts_blur_up_bwd(const float* dout, int N, int C, int H, int W, float* din, int accumulate, void* stream);
+
+/* K x K (K <= 8) weights <-> block (a, b) of their zero-extended 8 x 8 tap grid, as a 4 x 4 kernel:
+ *   w4[r][i][j] = w[r][4a+i][4b+j] (0 outside K x K), r over rows = Cout*Cin.
+ * The 3x3 / 7x7 convolutions of the ResNet generator run as 1 / 4 launches of vts_conv4x4 / vts_wgrad4x4
+ * on these blocks (pad -> pad - 4a / 4b; outputs accumulate). */
+int vts_tap_embed(const float* w, int64_t rows, int K, int a, int b, float* w4, void* stream);
+int vts_tap_extract(const float* dw4, int64_t rows, int K, int a, int b, float* dw, int accumulate, void* stream);
 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */

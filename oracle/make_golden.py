@@ -173,6 +173,35 @@ def golden_nets(size=256, seed=101):
     print("wrote nets_%d.npz (%d entries)" % (size, len(out)))
 
 
+def golden_resnet(size=64, seed=303, n_blocks=9, ngf=10):
+    """ResnetGenerator (--netG resnet_9blocks, reference defaults) forward + gradients with seeded test weights."""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from models import networks
+
+    opt = _ref_opt("sinskitG", True, [])
+    out = {"size": size, "seed": seed, "n_blocks": n_blocks, "ngf": ngf}
+    G = networks.define_G(9, 5, ngf, "resnet_%dblocks" % n_blocks, "instance", False, "xavier", 0.02, False, False, [], opt)
+    ref = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    mine = nets.resnet_param_shapes(9, 5, ngf, n_blocks)
+    learn = {k: v for k, v in ref.items() if not k.endswith(".filt")}
+    assert learn == {k: tuple(v) for k, v in mine.items()}, "resnet G key/shape mismatch"
+    out["ref_keys"] = np.array(sorted(ref.keys()))
+    out["ref_filt_down"] = G.state_dict()["model.7.filt"][0, 0].numpy()
+    out["ref_filt_up"] = G.state_dict()["model.%d.filt" % (12 + n_blocks)][0, 0].numpy()
+    G.load_state_dict(detrand.test_weights(mine, seed), strict=False)
+    x = detrand.uniform((2, 9, size, size), seed, "g_in").requires_grad_(True)
+    y = G(x)
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    out["G_out"] = y.detach().numpy()
+    out["G_dx_probe"] = detrand.probe(x.grad, "g_dx")
+    for k, p in G.named_parameters():
+        out["G_grad/" + k] = detrand.probe(p.grad, k)
+    np.savez_compressed(os.path.join(GOLD, "resnet_%d.npz" % size), **out)
+    print("wrote resnet_%d.npz (%d entries)" % (size, len(out)))
+
+
 def golden_step(size=256, seed=202, steps=2, nt=64):
     """Full SinSKITGModel.optimize_parameters x `steps` on one synthetic sample (BASELINE config 0)."""
     from oracle import detrand, nets, ref_import
@@ -233,10 +262,12 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
         golden_nets()
     if "step" in which:
         golden_step()
+    if "resnet" in which:
+        golden_resnet()

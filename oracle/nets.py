@@ -154,6 +154,95 @@ def unet_forward(sd, x, num_downs=8, num_layer_separate=4, style_code=None, num_
 
 
 # ----------------------------------------------------------------------------
+# ResNet generator with anti-aliased resampling  (models/networks.py:1051-1154; ResnetBlock :1267-1324;
+# Downsample :51-74 (filt 3, stride 2, reflect pad); Upsample :87-107 (filt 4, stride 2, replicate pad))
+# reference defaults: InstanceNorm, reflect padding, no dropout, anti-aliased down- and up-sampling
+# ----------------------------------------------------------------------------
+def blur_down(x):
+    """Downsample.forward (networks.py:66-74): reflect pad [1,1,1,1], depthwise [1,2,1]x[1,2,1]/16, stride 2."""
+    c = x.shape[1]
+    a = torch.tensor([1.0, 2.0, 1.0], dtype=x.dtype, device=x.device)
+    f = (a[:, None] * a[None, :]) / 16.0
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), f[None, None].repeat(c, 1, 1, 1), stride=2, groups=c)
+
+
+def blur_up(x):
+    """Upsample.forward (networks.py:101-107): replicate pad 1, depthwise conv_transpose [1,3,3,1]x[1,3,3,1]*4/64,
+    stride 2, padding 2, then [1:, 1:] and (even filter) [:-1, :-1]."""
+    c = x.shape[1]
+    a = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=x.dtype, device=x.device)
+    f = (a[:, None] * a[None, :]) / 64.0 * 4.0
+    y = F.conv_transpose2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), f[None, None].repeat(c, 1, 1, 1), stride=2, padding=2, groups=c)
+    return y[:, :, 1:, 1:][:, :, :-1, :-1]
+
+
+def resnet_layout(n_blocks=9, n_down=2):
+    """nn.Sequential indices of ResnetGenerator.model (networks.py:1075-1147) -> [(kind, idx)]."""
+    lay, idx = [], 0
+
+    def add(kind, n=1):
+        nonlocal idx
+        lay.append((kind, idx))
+        idx += n
+
+    add("conv7_in", 4)                 # pad, conv, norm, relu
+    for _ in range(n_down):
+        add("conv3_down", 4)           # conv, norm, relu, Downsample
+    for _ in range(n_blocks):
+        add("block", 1)
+    for _ in range(n_down):
+        add("up_conv3", 4)             # Upsample, conv, norm, relu
+    add("conv7_out", 3)                # pad, conv, tanh
+    return lay
+
+
+def resnet_forward(sd, x, n_blocks=9, n_down=2):
+    for kind, i in resnet_layout(n_blocks, n_down):
+        if kind == "conv7_in":
+            x = F.relu(_inorm(F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), sd["model.%d.weight" % (i + 1)], sd["model.%d.bias" % (i + 1)])))
+        elif kind == "conv3_down":
+            x = F.relu(_inorm(F.conv2d(x, sd["model.%d.weight" % i], sd["model.%d.bias" % i], padding=1)))
+            x = blur_down(x)
+        elif kind == "block":
+            k = "model.%d.conv_block." % i
+            y = F.relu(_inorm(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[k + "1.weight"], sd[k + "1.bias"])))
+            y = _inorm(F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[k + "5.weight"], sd[k + "5.bias"]))
+            x = x + y
+        elif kind == "up_conv3":
+            x = blur_up(x)
+            x = F.relu(_inorm(F.conv2d(x, sd["model.%d.weight" % (i + 1)], sd["model.%d.bias" % (i + 1)], padding=1)))
+        else:
+            x = torch.tanh(F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), sd["model.%d.weight" % (i + 1)], sd["model.%d.bias" % (i + 1)]))
+    return x
+
+
+def resnet_param_shapes(input_nc=9, output_nc=5, ngf=10, n_blocks=9, n_down=2):
+    """state_dict entries of ResnetGenerator (learnable ones; the `filt` buffers are constants)."""
+    sh = {}
+    for kind, i in resnet_layout(n_blocks, n_down):
+        if kind == "conv7_in":
+            sh["model.%d.weight" % (i + 1)] = (ngf, input_nc, 7, 7)
+            sh["model.%d.bias" % (i + 1)] = (ngf,)
+            c = ngf
+        elif kind == "conv3_down":
+            sh["model.%d.weight" % i] = (2 * c, c, 3, 3)
+            sh["model.%d.bias" % i] = (2 * c,)
+            c *= 2
+        elif kind == "block":
+            for j in (1, 5):
+                sh["model.%d.conv_block.%d.weight" % (i, j)] = (c, c, 3, 3)
+                sh["model.%d.conv_block.%d.bias" % (i, j)] = (c,)
+        elif kind == "up_conv3":
+            sh["model.%d.weight" % (i + 1)] = (c // 2, c, 3, 3)
+            sh["model.%d.bias" % (i + 1)] = (c // 2,)
+            c //= 2
+        else:
+            sh["model.%d.weight" % (i + 1)] = (output_nc, c, 7, 7)
+            sh["model.%d.bias" % (i + 1)] = (output_nc,)
+    return sh
+
+
+# ----------------------------------------------------------------------------
 # multiscale PatchGAN discriminator  (models/networks.py:1649-1750)
 # ----------------------------------------------------------------------------
 

@@ -1,0 +1,179 @@
+"""ResNet generator (--netG resnet_{4,6,9}blocks) on the HIP path: operator parity against plain PyTorch
+fp32 CPU evaluations, and network forward / backward parity against the CPU oracle (which is pinned to the
+reference module by tests/golden/resnet_64.npz) and against the committed reference outputs themselves.
+Tolerances: rel-L2 <= 1e-5 per operator, 2e-4 for whole-network gradients (fp32, different summation order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, nets  # noqa: E402  (checker only)
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _affine(n, c, seed, name):
+    return 1.0 + 0.3 * detrand.uniform((n * c,), seed, name + "sc"), 0.2 * detrand.uniform((n * c,), seed, name + "sh")
+
+
+def _apply(x, sc, sh, act):
+    n, c = x.shape[:2]
+    v = x * sc.view(n, c, 1, 1) + sh.view(n, c, 1, 1)
+    return {0: v, 1: F.leaky_relu(v, 0.2), 2: F.relu(v), 3: torch.tanh(v)}[act]
+
+
+@pytest.mark.parametrize("K,pad,shape", [(3, 1, (2, 10, 20, 37, 41)), (3, 0, (1, 40, 40, 30, 30)), (7, 0, (2, 9, 10, 38, 70)),
+                                         (7, 3, (1, 10, 5, 33, 64)), (3, 1, (1, 20, 10, 128, 128))])
+def test_convk_forward_backward_wgrad(K, pad, shape):
+    """K x K stride-1 convolution as 4x4 tap blocks: forward, adjoint w.r.t. the input, weight gradient."""
+    from vts import ops
+    from vts.ops import Act
+    n, ci, co, h, w = shape
+    dev = _dev()
+    x = detrand.uniform((n, ci, h, w), 5, "x")
+    sc, sh = _affine(n, ci, 5, "a")
+    wt = detrand.uniform((co, ci, K, K), 5, "w") * 0.2
+    b = detrand.uniform((co,), 5, "b")
+    xa = _apply(x, sc, sh, 2).requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    ref = F.conv2d(xa, wr, b, padding=pad)
+    cot = detrand.uniform(tuple(ref.shape), 5, "cot")
+    (ref * cot).sum().backward()
+
+    out = torch.full(ref.shape, float("nan"), device=dev)
+    ops.convk(Act(x.to(dev), sc.to(dev), sh.to(dev)), wt.to(dev), out, bias=b.to(dev), pad=pad, act_in=2)
+    assert rel(out, ref) < 1e-5
+    din = torch.full(x.shape, float("nan"), device=dev)
+    ops.convk_bwd_data(cot.to(dev), wt.to(dev), din, pad=pad)
+    assert rel(din, xa.grad) < 1e-5
+    dw = torch.full(wt.shape, float("nan"), device=dev)
+    ops.wgradk(cot.to(dev), Act(x.to(dev), sc.to(dev), sh.to(dev)), dw, pad=pad, act_hi=2)
+    assert rel(dw, wr.grad) < 2e-5
+    dw2 = dw.clone()
+    ops.wgradk(cot.to(dev), Act(x.to(dev), sc.to(dev), sh.to(dev)), dw2, pad=pad, act_hi=2, accumulate=True)
+    assert rel(dw2, 2 * wr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("mode,pads", [(1, (3, 3, 3, 3)), (1, (1, 1, 1, 1)), (2, (1, 1, 1, 1)), (0, (2, 1, 0, 3)), (1, (2, 0, 1, 3))])
+@pytest.mark.parametrize("shape", [(2, 5, 17, 23), (1, 3, 64, 70)])
+def test_pad_affine_and_adjoint(mode, pads, shape):
+    from vts import ops
+    from vts.ops import Act
+    n, c, h, w = shape
+    dev = _dev()
+    pt, pb, pl, pr = pads
+    x = detrand.uniform(shape, 7, "x")
+    sc, sh = _affine(n, c, 7, "a")
+    xa = _apply(x, sc, sh, 2).requires_grad_(True)
+    ref = F.pad(xa, (pl, pr, pt, pb), mode={0: "constant", 1: "reflect", 2: "replicate"}[mode])
+    res = detrand.uniform(tuple(ref.shape), 7, "res")
+    out = ops.pad_affine(Act(x.to(dev), sc.to(dev), sh.to(dev)), pads, mode, act=2, res=res.to(dev))
+    assert rel(out, ref + res) < 1e-6
+    cot = detrand.uniform(tuple(ref.shape), 7, "cot")
+    (ref * cot).sum().backward()
+    din = torch.full(shape, float("nan"), device=dev)
+    ops.pad_bwd(cot.to(dev), pads, mode, din)
+    assert rel(din, xa.grad) < 1e-6
+    ops.pad_bwd(cot.to(dev), pads, mode, din, accumulate=True)
+    assert rel(din, 2 * xa.grad) < 1e-6
+
+
+def test_pad_affine_concat_on_store_and_tanh():
+    from vts import ops
+    dev = _dev()
+    a, b = detrand.uniform((2, 1, 20, 24), 8, "a"), detrand.uniform((2, 8, 20, 24), 8, "b")
+    p = torch.full((2, 9, 26, 30), float("nan"), device=dev)
+    ops.pad_affine(a.to(dev), (3, 3, 3, 3), 1, out=p[:, 0:1], out_nstride=p.stride(0))
+    ops.pad_affine(b.to(dev), (3, 3, 3, 3), 1, out=p[:, 1:9], out_nstride=p.stride(0))
+    assert rel(p, F.pad(torch.cat([a, b], 1), (3, 3, 3, 3), mode="reflect")) < 1e-7
+    t = ops.pad_affine(b.to(dev), (0, 0, 0, 0), 0, act=3)
+    assert rel(t, torch.tanh(b)) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 32, 32), (1, 3, 17, 21), (1, 4, 64, 50), (2, 2, 2, 2)])
+def test_blur_down_up_and_adjoints(shape):
+    """Downsample / Upsample of the reference (oracle.nets.blur_down / blur_up restate them)."""
+    from vts import ops
+    from vts.ops import Act
+    n, c, h, w = shape
+    dev = _dev()
+    x = detrand.uniform(shape, 9, "x")
+    sc, sh = _affine(n, c, 9, "a")
+    for name, fwd, bwd, oracle_fn in (("down", ops.blur_down, ops.blur_down_bwd, nets.blur_down), ("up", ops.blur_up, ops.blur_up_bwd, nets.blur_up)):
+        xa = _apply(x, sc, sh, 2).requires_grad_(True)
+        ref = oracle_fn(xa)
+        out = fwd(Act(x.to(dev), sc.to(dev), sh.to(dev)), act=2)
+        assert out.shape == ref.shape, name
+        assert rel(out, ref) < 1e-6, name
+        cot = detrand.uniform(tuple(ref.shape), 9, "cot" + name)
+        (ref * cot).sum().backward()
+        din = torch.full(shape, float("nan"), device=dev)
+        bwd(cot.to(dev), din)
+        assert rel(din, xa.grad) < 1e-6, name
+        bwd(cot.to(dev), din, accumulate=True)
+        assert rel(din, 2 * xa.grad) < 1e-6, name
+
+
+def _build_G(nb, ngf, seed, dev):
+    from models import networks
+    from vts.optim import FlatParams
+    G = networks.ResnetGenerator(9, 5, ngf=ngf, n_blocks=nb).to(dev)
+    sd = detrand.test_weights(nets.resnet_param_shapes(9, 5, ngf, nb), seed)
+    G.load_state_dict(sd, strict=False)
+    flat = FlatParams(G)
+    return G, flat, sd
+
+
+def test_resnet_generator_matches_reference_and_oracle(golden_dir):
+    """forward vs the committed reference output; backward vs oracle autograd on the same weights / cotangent"""
+    from vts import engine
+    g = np.load(os.path.join(golden_dir, "resnet_64.npz"), allow_pickle=False)
+    size, seed, nb, ngf = int(g["size"]), int(g["seed"]), int(g["n_blocks"]), int(g["ngf"])
+    dev = _dev()
+    G, flat, sd = _build_G(nb, ngf, seed, dev)
+    x = detrand.uniform((2, 9, size, size), seed, "g_in")
+    y, ctx = engine.resnet_forward(G, (x[:, :1].contiguous().to(dev), x[:, 1:].contiguous().to(dev)))
+    assert rel(y, torch.from_numpy(g["G_out"])) < 2e-5
+    # oracle autograd
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = nets.resnet_forward(sdo, x, nb)
+    cot = detrand.uniform(tuple(yo.shape), seed, "g_cot")
+    (yo * cot).sum().backward()
+    d_raw = (cot.to(dev) * (1.0 - y * y)).contiguous()     # through the tanh
+    flat.grad.zero_()
+    engine.resnet_backward(G, ctx, d_raw)
+    named = dict(G.named_parameters())
+    last_bias = "model.%d.bias" % max(int(k.split(".")[1]) for k in sdo)
+    for k, v in sdo.items():
+        ref = v.grad
+        got = named[k].grad
+        if k.endswith(".bias") and k != last_bias:
+            assert ref.norm() < 2e-3                       # autograd: rounding noise around 0
+            assert got.abs().max().item() == 0.0, k        # bias in front of an InstanceNorm: exactly zero here
+            continue
+        assert rel(got, ref) < 2e-4, (k, rel(got, ref))
+        p = detrand.probe(got.cpu(), k)
+        rp = g["G_grad/" + k]
+        assert abs(p[1] - rp[1]) <= 5e-4 * max(abs(rp[1]), 1e-12), (k, p, rp)
+
+
+def test_resnet_inference_forward_odd_size():
+    """sizes that are not multiples of the tile shapes; 6-block variant"""
+    from vts import engine
+    dev = _dev()
+    G, _, sd = _build_G(6, 8, 11, dev)
+    x = detrand.uniform((1, 9, 52, 76), 11, "x")
+    y, _ = engine.resnet_forward(G, x.to(dev), keep=False)
+    yo = nets.resnet_forward(sd, x, 6)
+    assert rel(y, yo) < 2e-5

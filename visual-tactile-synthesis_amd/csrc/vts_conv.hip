@@ -28,7 +28,7 @@ struct ConvK {
   const float *s0, *s1, *sc0, *sh0, *sc1, *sh1;
   int64_t ns0, ns1;
   int C0, C1, Cin;
-  int IH, IW, OH, OW, Cout, pad;
+  int IH, IW, OH, OW, Cout, pad, padx;   // padx: horizontal padding (pad + pad_dx)
   const float* w;
   int ws_co, ws_ci;
   const float* bias;
@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   int iy0, ix0;
   if (MODE == 0) {
     iy0 = ty0 * S - p.pad;
-    ix0 = tx0 * S - p.pad;
+    ix0 = tx0 * S - p.padx;
   } else if (S == 2) {
     iy0 = ty0 + (p.pad >> 1) - 1;
     ix0 = tx0 + (p.pad >> 1) - 1;
   } else {
     iy0 = ty0 + p.pad - 3;
-    ix0 = tx0 + p.pad - 3;
+    ix0 = tx0 + p.padx - 3;
   }
 
   // per-lane A-fragment base offsets inside one channel plane of the patch
@@ -524,13 +524,16 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   VTS_CHECK_ARG(d->Cout >= 1 && d->Cout <= 80, "vts_conv4x4: Cout %d outside 1..80", d->Cout);
   VTS_CHECK_ARG(d->N >= 1 && d->IH >= 1 && d->IW >= 1 && d->OH >= 1 && d->OW >= 1, "vts_conv4x4: bad shape");
   VTS_CHECK_ARG(d->in0.C >= 1 && d->in1.C >= 0, "vts_conv4x4: bad channel counts");
-  if (!d->transposed) {
-    VTS_CHECK_ARG(d->OH == (d->IH + 2 * d->pad - 4) / d->stride + 1 && d->OW == (d->IW + 2 * d->pad - 4) / d->stride + 1,
-                  "vts_conv4x4: conv output %dx%d inconsistent with input %dx%d s%d p%d", d->OH, d->OW, d->IH, d->IW,
-                  d->stride, d->pad);
-  } else {
+  // The output window is the caller's: out[y, x] for y < OH, x < OW sums the taps that fall inside the input
+  // (zero outside, on every side; pad may be negative).  That is what lets a K x K kernel (K <= 8) run as 4 x 4
+  // blocks of its tap grid (vts_tap_embed): block (a, b) is this operator with pad - 4a / pad - 4b.  Only the
+  // stride-2 transposed form is tied to its forward convolution (the phase decomposition assumes it).
+  VTS_CHECK_ARG(d->OH <= d->IH * d->stride + 16 && d->OW <= d->IW * d->stride + 16 && d->pad >= -8 && d->pad <= 8,
+                "vts_conv4x4: output %dx%d / pad %d implausible for input %dx%d s%d", d->OH, d->OW, d->pad, d->IH, d->IW, d->stride);
+  VTS_CHECK_ARG(d->pad_dx >= -8 && d->pad_dx <= 8 && !(d->transposed && d->stride == 2 && d->pad_dx != 0), "vts_conv4x4: bad pad_dx %d", d->pad_dx);
+  if (d->transposed && d->stride == 2) {
     // output size of a transposed conv is ambiguous (output_padding); require that the forward conv maps it back
-    VTS_CHECK_ARG((d->OH + 2 * d->pad - 4) / d->stride + 1 == d->IH && (d->OW + 2 * d->pad - 4) / d->stride + 1 == d->IW,
+    VTS_CHECK_ARG((d->OH + 2 * d->pad - 4) / d->stride + 1 == d->IH && (d->OW + 2 * d->pad - 4) / d->stride + 1 == d->IW && d->pad >= 0,
                   "vts_conv4x4: transposed output %dx%d inconsistent with input %dx%d s%d p%d", d->OH, d->OW, d->IH,
                   d->IW, d->stride, d->pad);
   }
@@ -546,7 +549,7 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.s1 = d->in1.data; k.sc1 = d->in1.scale; k.sh1 = d->in1.shift; k.ns1 = d->in1.nstride;
   k.C1 = d->in1.data ? d->in1.C : 0;
   k.Cin = k.C0 + k.C1;
-  k.IH = d->IH; k.IW = d->IW; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.pad = d->pad;
+  k.IH = d->IH; k.IW = d->IW; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout; k.pad = d->pad; k.padx = d->pad + d->pad_dx;
   k.w = d->w; k.ws_co = d->ws_co; k.ws_ci = d->ws_ci; k.bias = d->bias;
   k.out = d->out; k.ons = d->out_nstride;
   k.act_in = d->act_in; k.act_out = d->act_out;

@@ -271,6 +271,10 @@ int launch_small(const SmallK& k, size_t lds_bytes, hipStream_t st) {
 
 // Returns VTS_ERR_UNSUPPORTED when the shape is not a small-map case (caller falls back to the tiled kernel).
 int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st) {
+  // only the standard geometry (square, non-negative padding; output size tied to the input size)
+  if (d->pad_dx != 0 || d->pad < 0) return VTS_ERR_UNSUPPORTED;
+  if (!d->transposed && (d->OH != (d->IH + 2 * d->pad - 4) / d->stride + 1 || d->OW != (d->IW + 2 * d->pad - 4) / d->stride + 1)) return VTS_ERR_UNSUPPORTED;
+  if (d->transposed && ((d->OH + 2 * d->pad - 4) / d->stride + 1 != d->IH || (d->OW + 2 * d->pad - 4) / d->stride + 1 != d->IW)) return VTS_ERR_UNSUPPORTED;
   if (d->IH > 34 || d->IW > 34 || d->OH > 34 || d->OW > 34 || d->IW > 64 || d->N < 8) return VTS_ERR_UNSUPPORTED;
   const bool ph4 = d->transposed && d->stride == 2;
   const int P = ph4 ? 4 : 1;

@@ -25,7 +25,7 @@ struct Src {
 
 struct WgK {
   Src lo, hi;
-  int N, LH, LW, HH, HW, pad;
+  int N, LH, LW, HH, HW, pad, padx;
   int cl_groups, ch_groups;
   int tiles_y, tiles_x, ntiles;
   float* part;  // [PW][CL][CH][16]
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
   auto load_tile = [&](int tile) {
     int n, y0, x0;
     decode(tile, n, y0, x0);
-    const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.pad;
+    const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.padx;
     if (tid < CLP) src_affine(p.lo, n, cl0 + tid, asc, ash);
     else if (tid < CLP + CHT) src_affine(p.hi, n, ch0 + tid - CLP, asc, ash);
     if (TXL == 32) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
   auto store_tile = [&](int tile) {
     int n, y0, x0;
     decode(tile, n, y0, x0);
-    const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.pad;
+    const int hy0 = y0 * S - p.pad, hx0 = x0 * S - p.padx;
     if (tid < CLP + CHT) {
       aff_sc[tid] = asc;
       aff_sh[tid] = ash;
@@ -350,13 +350,14 @@ extern "C" int64_t vts_wgrad4x4_ws_floats(const vts_wgrad_desc* d) {
 extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   VTS_CHECK_ARG(d && d->lo0.data && d->hi0.data && d->dw && ws, "vts_wgrad4x4: null pointer");
   VTS_CHECK_ARG(d->stride == 1 || d->stride == 2, "vts_wgrad4x4: stride %d unsupported", d->stride);
-  VTS_CHECK_ARG(d->LH == (d->HH + 2 * d->pad - 4) / d->stride + 1 && d->LW == (d->HW + 2 * d->pad - 4) / d->stride + 1,
-                "vts_wgrad4x4: lo %dx%d inconsistent with hi %dx%d s%d p%d", d->LH, d->LW, d->HH, d->HW, d->stride, d->pad);
+  // lo x hi window semantics as in vts_conv4x4: hi is zero outside its HH x HW extent, pad may be negative
+  VTS_CHECK_ARG(d->LH <= d->HH + 16 && d->LW <= d->HW + 16 && d->pad >= -8 && d->pad <= 8,
+                "vts_wgrad4x4: lo %dx%d / pad %d implausible for hi %dx%d s%d", d->LH, d->LW, d->pad, d->HH, d->HW, d->stride);
   const Plan pl = make_plan(d);
   WgK k;
   fill_src(k.lo, d->lo0, d->lo1, d->act_lo);
   fill_src(k.hi, d->hi0, d->hi1, d->act_hi);
-  k.N = d->N; k.LH = d->LH; k.LW = d->LW; k.HH = d->HH; k.HW = d->HW; k.pad = d->pad;
+  k.N = d->N; k.LH = d->LH; k.LW = d->LW; k.HH = d->HH; k.HW = d->HW; k.pad = d->pad; k.padx = d->pad + d->pad_dx;
   k.cl_groups = pl.cl_groups; k.ch_groups = pl.ch_groups;
   k.tiles_y = pl.tiles_y; k.tiles_x = pl.tiles_x; k.ntiles = pl.ntiles;
   k.part = ws;

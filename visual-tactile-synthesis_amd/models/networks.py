@@ -105,6 +105,71 @@ class CustomUnetGenerator(nn.Module):
         return out
 
 
+class _Filt(nn.Module):
+    """Downsample / Upsample of the reference register their fixed blur kernel as a buffer `filt`
+    (networks.py:62,99); it is part of the state_dict, so it is kept here (the HIP kernels have it built in)."""
+
+    def __init__(self, channels, taps, scale):
+        super().__init__()
+        a = torch.tensor(taps, dtype=torch.float32)
+        f = a[:, None] * a[None, :]
+        self.register_buffer("filt", (f / f.sum() * scale)[None, None].repeat(channels, 1, 1, 1))
+
+
+class ResnetGenerator(nn.Module):
+    """ResNet generator with anti-aliased resampling (reference: networks.py:1051-1154, ResnetBlock :1267-1324,
+    Downsample :51-74, Upsample :87-107), selectable as --netG resnet_{4,6,9}blocks.  InstanceNorm, reflect
+    padding, no dropout (the reference defaults: normG=instance, no_dropout=True, no_antialias[_up]=False).
+    `self.layout` lists the reference's nn.Sequential so that the state_dict keys are `model.<idx>...`."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_blocks=6, n_downsampling=2, opt=None):
+        super().__init__()
+        self.input_nc, self.output_nc, self.ngf, self.n_blocks, self.n_down = input_nc, output_nc, ngf, n_blocks, n_downsampling
+        mods, layout = {}, []
+        idx = 0
+
+        def add(kind, mod=None, **kw):
+            nonlocal idx
+            if mod is not None:
+                mods[idx] = mod
+            layout.append(dict(kind=kind, idx=idx, **kw))
+            idx += 1
+
+        add("pad")
+        add("conv7", _ConvParams((ngf, input_nc, 7, 7), ngf))
+        add("norm"); add("relu")
+        for i in range(n_downsampling):
+            c = ngf * 2 ** i
+            add("conv3", _ConvParams((2 * c, c, 3, 3), 2 * c))
+            add("norm"); add("relu")
+            add("down", _Filt(2 * c, [1.0, 2.0, 1.0], 1.0))
+        c = ngf * 2 ** n_downsampling
+        for _ in range(n_blocks):
+            add("block", _Holder({"conv_block": _Holder({1: _ConvParams((c, c, 3, 3), c), 5: _ConvParams((c, c, 3, 3), c)})}))
+        for i in range(n_downsampling):
+            c = ngf * 2 ** (n_downsampling - i)
+            add("up", _Filt(c, [1.0, 3.0, 3.0, 1.0], 4.0))
+            add("conv3", _ConvParams((c // 2, c, 3, 3), c // 2))
+            add("norm"); add("relu")
+        add("pad")
+        add("conv7", _ConvParams((output_nc, ngf, 7, 7), output_nc))
+        add("tanh")
+        self.model = _Holder(mods)
+        self.layout = layout
+
+    def conv(self, idx):
+        return getattr(self.model, str(idx))
+
+    def block_convs(self, idx):
+        cb = getattr(self.model, str(idx)).conv_block
+        return getattr(cb, "1"), getattr(cb, "5")
+
+    def forward(self, x, style_code=None, verbose=False):
+        """Inference forward on the HIP path; returns [N,output_nc,H,W]."""
+        out, _ = engine.resnet_forward(self, x, keep=False)
+        return out
+
+
 class MultiscaleDiscriminator(nn.Module):
     """num_D PatchGANs over an average-pooled pyramid (reference: networks.py:1649-1750).
     BatchNorm2d(affine, running stats) as in the hot-path default (normD=batch)."""
@@ -166,11 +231,17 @@ def init_net(net, init_type="normal", init_gain=0.02, gpu_ids=(), initialize_wei
 
 def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, init_type="normal", init_gain=0.02,
              no_antialias=False, no_antialias_up=False, gpu_ids=(), opt=None, generate_T_imgs=False, num_layer_separate=0):
-    if netG != "unet256_custom":
-        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom)" % netG)
+    resnet_blocks = {"resnet_9blocks": 9, "resnet_6blocks": 6, "resnet_4blocks": 4}
+    if netG not in resnet_blocks and netG != "unet256_custom":
+        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom, resnet_{4,6,9}blocks)" % netG)
     if norm != "instance":
-        raise NotImplementedError("unet256_custom is built for normG=instance only")
-    net = CustomUnetGenerator(input_nc, output_nc, num_downs=8, ngf=ngf, num_layer_separate=num_layer_separate, opt=opt)
+        raise NotImplementedError("the generators are built for normG=instance only")
+    if netG in resnet_blocks:
+        if use_dropout or no_antialias or no_antialias_up or generate_T_imgs:
+            raise NotImplementedError("resnet generator: only the reference defaults (no dropout, anti-aliased down/up-sampling) are built")
+        net = ResnetGenerator(input_nc, output_nc, ngf=ngf, n_blocks=resnet_blocks[netG], opt=opt)
+    else:
+        net = CustomUnetGenerator(input_nc, output_nc, num_downs=8, ngf=ngf, num_layer_separate=num_layer_separate, opt=opt)
     return init_net(net, init_type, init_gain, gpu_ids)
 
 

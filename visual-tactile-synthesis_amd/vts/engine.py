@@ -178,6 +178,162 @@ def unet_backward(G, ctx, d_raw):
         dfeat[i] = None
 
 
+# -------------------------------------------------------------------------------------
+# ResNet generator (--netG resnet_{4,6,9}blocks): /root/reference/models/networks.py:1051-1154
+# -------------------------------------------------------------------------------------
+
+class ResnetCtx:
+    __slots__ = ("steps", "g_out")
+
+
+def resnet_forward(G, x, keep=True):
+    """x: tensor / Act, or a pair (x0, x1) concatenated on store into the first padded tensor.
+    Returns (g_out [N,output_nc,H,W] post-tanh, ctx).  Every 3x3 / 7x7 conv runs as 4x4 tap blocks
+    (ops.convk); normalisation is a statistics pass only and is applied on load by the consumer."""
+    srcs = [_as_act(t) for t in (x if isinstance(x, (tuple, list)) else (x,))]
+    n, _, h, w = srcs[0].data.shape
+    dev = srcs[0].data.device
+    steps = []          # per layout entry: what the backward needs
+    cur = None          # current activation: Act (raw + affine, activation pending) or identity tensor
+    pending = 0         # activation still to be applied to `cur` by its consumer
+    lay = G.layout
+    i = 0
+    while i < len(lay):
+        e = lay[i]
+        kind = e["kind"]
+        if kind == "pad":      # ReflectionPad2d(3) + conv7 (+ norm / relu | tanh)
+            conv = G.conv(lay[i + 1]["idx"])
+            if cur is None:    # network input: concat the sources while padding
+                cin = sum(s_.data.shape[1] for s_ in srcs)
+                p = _empty(n, cin, h + 6, w + 6, dev)
+                c0 = 0
+                for s_ in srcs:
+                    c = s_.data.shape[1]
+                    ops.pad_affine(s_, (3, 3, 3, 3), 1, out=p[:, c0:c0 + c], out_nstride=p.stride(0))
+                    c0 += c
+                src_act = None
+            else:
+                p = ops.pad_affine(cur, (3, 3, 3, 3), 1, act=pending)
+                src_act = cur if isinstance(cur, Act) else None
+            r = _empty(n, conv.weight.shape[0], p.shape[2] - 6, p.shape[3] - 6, dev)
+            ops.convk(p, conv.weight, r, bias=conv.bias, pad=0)
+            if lay[i + 2]["kind"] == "norm":
+                cur, pending = ops.norm_stats(r, 0), RELU
+                steps.append(("conv7", conv, p, src_act, cur))
+                i += 4
+            else:              # final conv + tanh
+                g_out = ops.pad_affine(r, (0, 0, 0, 0), 0, act=TANH)
+                steps.append(("conv7_out", conv, p, src_act, None))
+                i += 3
+                cur = g_out
+        elif kind == "conv3":  # Conv2d(3, zero pad 1) + norm + relu
+            conv = G.conv(e["idx"])
+            inp, inp_act = cur, pending
+            t = cur.data if isinstance(cur, Act) else cur
+            r = _empty(n, conv.weight.shape[0], t.shape[2], t.shape[3], dev)
+            ops.convk(inp, conv.weight, r, bias=conv.bias, pad=1, act_in=inp_act)
+            cur, pending = ops.norm_stats(r, 0), RELU
+            steps.append(("conv3", conv, inp, inp_act, cur))
+            i += 3
+        elif kind == "down":
+            inp = cur
+            cur, pending = ops.blur_down(cur, act=pending), 0
+            steps.append(("down", inp))
+            i += 1
+        elif kind == "up":
+            inp, inp_act = cur, pending
+            cur, pending = ops.blur_up(cur, act=pending), 0
+            steps.append(("up", inp, inp_act))
+            i += 1
+        elif kind == "block":  # x + IN(conv(reflpad(relu(IN(conv(reflpad(x)))))))
+            ca, cb = G.block_convs(e["idx"])
+            xb = cur           # identity tensor
+            p1 = ops.pad_affine(xb, (1, 1, 1, 1), 1)
+            r1 = _empty(n, ca.weight.shape[0], xb.shape[2], xb.shape[3], dev)
+            ops.convk(p1, ca.weight, r1, bias=ca.bias, pad=0)
+            a1 = ops.norm_stats(r1, 0)
+            p2 = ops.pad_affine(a1, (1, 1, 1, 1), 1, act=RELU)
+            r2 = _empty(n, cb.weight.shape[0], xb.shape[2], xb.shape[3], dev)
+            ops.convk(p2, cb.weight, r2, bias=cb.bias, pad=0)
+            a2 = ops.norm_stats(r2, 0)
+            cur, pending = ops.pad_affine(a2, (0, 0, 0, 0), 0, res=xb), 0
+            steps.append(("block", ca, cb, p1, a1, p2, a2))
+            i += 1
+        else:
+            raise RuntimeError("unexpected layout entry %r" % (e,))
+    ctx = None
+    if keep:
+        ctx = ResnetCtx()
+        ctx.steps, ctx.g_out = steps, cur
+    return cur, ctx
+
+
+def resnet_backward(G, ctx, d_raw):
+    """d_raw: gradient w.r.t. the pre-tanh output.  Writes every parameter's .grad (overwrite).
+    Biases that feed an InstanceNorm have identically zero gradient and are never written."""
+    dev = d_raw.device
+
+    def through_norm_relu(g_act, a):
+        """gradient w.r.t. relu(norm(r)) -> gradient w.r.t. the raw conv output r (in a fresh buffer)"""
+        buf = torch.empty_like(a.data)
+        ops.act_bwd(g_act, a, RELU, buf)
+        ops.norm_bwd(buf, a, 0)
+        return buf
+
+    g = d_raw            # gradient w.r.t. the output of the step being processed
+    for st in reversed(ctx.steps):
+        kind = st[0]
+        if kind == "conv7_out":
+            _, conv, p, src_act, _ = st
+            ops.wgradk(g, p, conv.weight.grad, pad=0)
+            ops.channel_sum(g, conv.bias.grad)
+            dp = torch.empty_like(p)
+            ops.convk_bwd_data(g, conv.weight, dp, pad=0)
+            da = _empty(p.shape[0], p.shape[1], p.shape[2] - 6, p.shape[3] - 6, dev)
+            ops.pad_bwd(dp, (3, 3, 3, 3), 1, da)
+            g = through_norm_relu(da, src_act)       # the padded tensor was relu(norm(r_prev))
+        elif kind == "conv7":
+            _, conv, p, src_act, a = st
+            ops.wgradk(g, p, conv.weight.grad, pad=0)  # network input: no gradient needed below
+        elif kind == "conv3":
+            _, conv, inp, inp_act, a = st
+            hi = inp if isinstance(inp, Act) else Act(inp)
+            ops.wgradk(g, hi, conv.weight.grad, pad=1, act_hi=inp_act)
+            t = inp.data if isinstance(inp, Act) else inp
+            din = torch.empty_like(t)
+            ops.convk_bwd_data(g, conv.weight, din, pad=1)
+            g = through_norm_relu(din, inp) if inp_act == RELU else din
+        elif kind == "down":
+            inp = st[1]       # Act: relu(norm(r)) on load
+            da = torch.empty_like(inp.data)
+            ops.blur_down_bwd(g, da)
+            g = through_norm_relu(da, inp)
+        elif kind == "up":
+            _, inp, inp_act = st
+            t = inp.data if isinstance(inp, Act) else inp
+            da = torch.empty_like(t)
+            ops.blur_up_bwd(g, da)
+            g = through_norm_relu(da, inp) if inp_act == RELU else da
+        elif kind == "block":
+            _, ca, cb, p1, a1, p2, a2 = st
+            dy = g
+            g2 = dy.clone()
+            ops.norm_bwd(g2, a2, 0)
+            ops.wgradk(g2, p2, cb.weight.grad, pad=0)
+            dp2 = torch.empty_like(p2)
+            ops.convk_bwd_data(g2, cb.weight, dp2, pad=0)
+            da1 = torch.empty_like(a1.data)
+            ops.pad_bwd(dp2, (1, 1, 1, 1), 1, da1)
+            g1 = through_norm_relu(da1, a1)
+            ops.wgradk(g1, p1, ca.weight.grad, pad=0)
+            dp1 = torch.empty_like(p1)
+            ops.convk_bwd_data(g1, ca.weight, dp1, pad=0)
+            ops.pad_bwd(dp1, (1, 1, 1, 1), 1, dy, accumulate=True)   # + the skip path
+            g = dy
+        else:
+            raise RuntimeError(kind)
+
+
 def add_grad_list(lst, idx, shape, dev):
     if lst[idx] is not None:
         return lst[idx], True

@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("bias", C.c_void_p), ("out", C.c_void_p), ("out_nstride", C.c_int64),
         ("act_in", C.c_int), ("act_out", C.c_int),
         ("dmask", Operand), ("dmask_act", C.c_int), ("accumulate", C.c_int),
-        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("pad_dx", C.c_int),
     ]
 
 
@@ -44,7 +44,7 @@ class WgradDesc(C.Structure):
         ("lo0", Operand), ("lo1", Operand), ("hi0", Operand), ("hi1", Operand),
         ("act_lo", C.c_int), ("act_hi", C.c_int),
         ("N", C.c_int), ("LH", C.c_int), ("LW", C.c_int), ("HH", C.c_int), ("HW", C.c_int),
-        ("stride", C.c_int), ("pad", C.c_int), ("dw", C.c_void_p), ("accumulate", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("dw", C.c_void_p), ("accumulate", C.c_int), ("pad_dx", C.c_int),
     ]
 
 
@@ -73,6 +73,7 @@ SYMBOLS = [
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
+    "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract",
     "vts_mask_select", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows",
 ]
 
@@ -120,6 +121,14 @@ def load():
         "vts_adam_flat_dev": [vp, vp, vp, vp, i64, vp, f, f, f, vp, f, vp],
         "vts_patchnce": [vp, vp, i, i, i, f, f, vp, vp, vp],
         "vts_l2norm_rows": [vp, i, i, vp, vp],
+        "vts_pad_affine": [C.POINTER(Operand), i, i, i, i, i, i, i, i, i, vp, vp, i64, vp],
+        "vts_pad_bwd": [vp, i, i, i, i, i, i, i, i, i, vp, i, vp],
+        "vts_blur_down": [C.POINTER(Operand), i, i, i, i, vp, vp],
+        "vts_blur_down_bwd": [vp, i, i, i, i, vp, i, vp],
+        "vts_blur_up": [C.POINTER(Operand), i, i, i, i, vp, vp],
+        "vts_blur_up_bwd": [vp, i, i, i, i, vp, i, vp],
+        "vts_tap_embed": [vp, i64, i, i, i, vp, vp],
+        "vts_tap_extract": [vp, i64, i, i, i, vp, i, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

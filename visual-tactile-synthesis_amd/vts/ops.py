@@ -85,7 +85,7 @@ def _op(a):
 
 
 def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, pad=1, transposed=False, act_in=0,
-            act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None):
+            act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None, pad_dx=0):
     """out <- conv-family(in0 ++ in1).  `w` may be an offset view into a weight tensor."""
     lib = L.load()
     d = L.ConvDesc()
@@ -96,6 +96,7 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     d.OH, d.OW = out.shape[2], out.shape[3]
     d.Cout = cout
     d.stride, d.pad, d.transposed = stride, pad, int(transposed)
+    d.pad_dx = pad_dx
     d.w, d.ws_co, d.ws_ci = w.data_ptr(), ws_co, ws_ci
     d.bias = L.ptr(bias)
     d.out = out.data_ptr()
@@ -122,7 +123,7 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     return out
 
 
-def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, pad=1, accumulate=False):
+def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, pad=1, accumulate=False, pad_dx=0):
     lib = L.load()
     d = L.WgradDesc()
     d.lo0, d.lo1, d.hi0, d.hi1 = _op(lo0), _op(lo1), _op(hi0), _op(hi1)
@@ -131,6 +132,7 @@ def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, 
     hi = hi0.data if isinstance(hi0, Act) else hi0
     d.N, d.LH, d.LW, d.HH, d.HW = lo.shape[0], lo.shape[2], lo.shape[3], hi.shape[2], hi.shape[3]
     d.stride, d.pad = stride, pad
+    d.pad_dx = pad_dx
     d.dw = dw.data_ptr()
     d.accumulate = int(accumulate)
     n = lib.vts_wgrad4x4_ws_floats(C.byref(d))
@@ -143,6 +145,121 @@ def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, 
         DETAIL = "N%d lo %dx%dx%d hi %dx%dx%d p%d" % (d.N, cl, d.LH, d.LW, chn, d.HH, d.HW, pad)
     _run("wgrad4x4<s%d>" % stride, nbytes, flops, lib.vts_wgrad4x4, C.byref(d), ws.data_ptr(), L.stream())
     return dw
+
+
+# ---- K x K convolutions (K <= 8, stride 1) on the 4 x 4 kernels: one launch per 4 x 4 block of the tap grid ----
+def _tap_blocks(K):
+    nb = (K + 3) // 4
+    return [(a, b) for a in range(nb) for b in range(nb)]
+
+
+def tap_embed(w, K, a, b, w4):
+    _run("tap_embed", 0.0, 0.0, L.load().vts_tap_embed, w.data_ptr(), w.numel() // (K * K), K, a, b, w4.data_ptr(), L.stream())
+    return w4
+
+
+def tap_extract(dw4, K, a, b, dw, accumulate=False):
+    _run("tap_extract", 0.0, 0.0, L.load().vts_tap_extract, dw4.data_ptr(), dw.numel() // (K * K), K, a, b, dw.data_ptr(),
+         int(accumulate), L.stream())
+    return dw
+
+
+def _w4_scratch(w, K, tag):
+    """4x4 staging buffers for the tap blocks of `w` ([Co, Ci, K, K]); persistent (graph-capture safe)."""
+    key = ("w4", w.data_ptr(), tuple(w.shape), tag)
+    buf = _ws.get(key)
+    if buf is None:
+        buf = _ws[key] = torch.zeros(len(_tap_blocks(K)), w.shape[0], w.shape[1], 4, 4, dtype=torch.float32, device=w.device)
+    return buf
+
+
+def convk(x, w, out, *, bias=None, pad=0, act_in=0, dmask=None, dmask_act=0):
+    """out <- Conv2d(K x K, stride 1, zero padding `pad`)(x); w is [Co, Ci, K, K].  Replaces the 3x3 / 7x7
+    nn.Conv2d of ResnetGenerator / ResnetBlock (networks.py:1076,1084,1144,1306,1318)."""
+    co, ci, K, _ = w.shape
+    w4 = _w4_scratch(w, K, "fwd")
+    for i, (a, b) in enumerate(_tap_blocks(K)):
+        tap_embed(w, K, a, b, w4[i])
+        conv4x4(x, w4[i], ci * 16, 16, co, out, bias=bias if i == 0 else None, stride=1, pad=pad - 4 * a, pad_dx=4 * (a - b),
+                act_in=act_in, accumulate=i > 0)
+    return out
+
+
+def convk_bwd_data(dout, w, din, *, pad=0, accumulate=False):
+    """din (+)= adjoint of convk w.r.t. its input: din[y] = sum_k dout[y + pad - k] w[k]."""
+    co, ci, K, _ = w.shape
+    w4 = _w4_scratch(w, K, "fwd")   # same blocks as the forward (already embedded in this step)
+    for i, (a, b) in enumerate(_tap_blocks(K)):
+        tap_embed(w, K, a, b, w4[i])
+        conv4x4(dout, w4[i], 16, ci * 16, ci, din, stride=1, pad=pad - 4 * a, pad_dx=4 * (a - b), transposed=True,
+                accumulate=accumulate or i > 0)
+    return din
+
+
+def wgradk(dout, x, dw, *, pad=0, act_hi=0, accumulate=False):
+    """dw (+)= weight gradient of convk: dw[co, ci, ky, kx] = sum dout[n, co, y, x] * x[n, ci, y + ky - pad, x + kx - pad]."""
+    co, ci, K, _ = dw.shape
+    dw4 = _w4_scratch(dw, K, "grad")
+    for i, (a, b) in enumerate(_tap_blocks(K)):
+        wgrad4x4(dout, x, dw4[i], stride=1, pad=pad - 4 * a, pad_dx=4 * (a - b), act_hi=act_hi)
+        tap_extract(dw4[i], K, a, b, dw, accumulate=accumulate)
+    return dw
+
+
+def pad_affine(x, pads, mode, out=None, act=0, res=None, out_nstride=0):
+    """out <- act(pad(x)) (+ res).  pads = (top, bottom, left, right); mode 0 zero / 1 reflect / 2 replicate.
+    `out` may be a channel-slice view of a wider tensor (pass its batch stride as out_nstride)."""
+    op = _op(x)
+    t = x.data if isinstance(x, Act) else x
+    n, c, h, w = t.shape
+    pt, pb, pl, pr = pads
+    if out is None:
+        out = torch.empty(n, c, h + pt + pb, w + pl + pr, dtype=torch.float32, device=t.device)
+    _run("pad_affine", 4.0 * (t.numel() + out.numel() * (2 if res is not None else 1)), 0.0, L.load().vts_pad_affine, C.byref(op), n, h, w,
+         pt, pb, pl, pr, mode, act, L.ptr(res), out.data_ptr(), out_nstride, L.stream())
+    return out
+
+
+def pad_bwd(dpad, pads, mode, din, accumulate=False):
+    n, c, h, w = din.shape
+    pt, pb, pl, pr = pads
+    _run("pad_bwd", 4.0 * (dpad.numel() + din.numel()), 0.0, L.load().vts_pad_bwd, dpad.data_ptr(), n, c, h, w, pt, pb, pl, pr, mode,
+         din.data_ptr(), int(accumulate), L.stream())
+    return din
+
+
+def blur_down(x, act=0, out=None):
+    op = _op(x)
+    t = x.data if isinstance(x, Act) else x
+    n, c, h, w = t.shape
+    if out is None:
+        out = torch.empty(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=t.device)
+    _run("blur_down", 4.0 * (t.numel() + out.numel()), 0.0, L.load().vts_blur_down, C.byref(op), act, n, h, w, out.data_ptr(), L.stream())
+    return out
+
+
+def blur_down_bwd(dout, din, accumulate=False):
+    n, c, h, w = din.shape
+    _run("blur_down_bwd", 4.0 * (dout.numel() + din.numel()), 0.0, L.load().vts_blur_down_bwd, dout.data_ptr(), n, c, h, w, din.data_ptr(),
+         int(accumulate), L.stream())
+    return din
+
+
+def blur_up(x, act=0, out=None):
+    op = _op(x)
+    t = x.data if isinstance(x, Act) else x
+    n, c, h, w = t.shape
+    if out is None:
+        out = torch.empty(n, c, 2 * h, 2 * w, dtype=torch.float32, device=t.device)
+    _run("blur_up", 4.0 * (t.numel() + out.numel()), 0.0, L.load().vts_blur_up, C.byref(op), act, n, h, w, out.data_ptr(), L.stream())
+    return out
+
+
+def blur_up_bwd(dout, din, accumulate=False):
+    n, c, h, w = din.shape
+    _run("blur_up_bwd", 4.0 * (dout.numel() + din.numel()), 0.0, L.load().vts_blur_up_bwd, dout.data_ptr(), n, c, h, w, din.data_ptr(),
+         int(accumulate), L.stream())
+    return din
 
 
 def channel_sum(x, out, accumulate=False):
