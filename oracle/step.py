@@ -30,7 +30,7 @@ DEFAULT_HP = dict(
     lambda_G1_GAN=1.0, lambda_G1_L1=100.0, lambda_G2_GAN=5.0, lambda_G2_L1=10.0,
     lr=1e-3, lr_G2=5e-4, beta1=0.0, beta2=0.99, gan_mode="nonsaturating",
     batch_size_G2=64, add_fake_T_sample_size=32, scale_nz=0.25, num_D=3,
-    use_more_fakeT=True, use_diffaug=True, lr_scale=1.0,
+    use_more_fakeT=True, use_diffaug=True, lr_scale=1.0, netG="unet256_custom",
 )
 
 
@@ -68,7 +68,11 @@ def _gather_all(img, coords):
 
 
 def generator_forward(sdG, inp, opt, style_code=None):
-    out = nets.unet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), style_code=style_code)
+    netG = getattr(opt, "netG", "unet256_custom")
+    if netG.startswith("resnet_"):   # --netG resnet_{4,6,9}blocks (sinskitG_model.py:509-520 -> networks.define_G)
+        out = nets.resnet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), n_blocks=int(netG[len("resnet_")]))
+    else:
+        out = nets.unet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), style_code=style_code)
     fake_I = out[:, 0:3] * inp.M
     fake_T = out[:, -2:] * inp.M
     return out, fake_I, fake_T

@@ -303,7 +303,12 @@ class SinSKITGModel(BaseModel):
         opt = self.opt
         n, _, h, w = self.real_S.shape
         dev = self.device
-        g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep)
+        if isinstance(self.netG, networks.ResnetGenerator):
+            if self._style() is not None:
+                raise NotImplementedError("style codes are only built for netG=unet256_custom")
+            g_out, self._g_ctx = engine.resnet_forward(self.netG, self._g_input(), keep=keep)
+        else:
+            g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep)
         self.g_out = g_out
         self.fake_I = torch.empty(n, 3, h, w, device=dev)
         self.fake_N = torch.empty(n, 3, h, w, device=dev)
@@ -454,7 +459,10 @@ class SinSKITGModel(BaseModel):
             ops.patch_scatter_bwd(d_patch, 0, 2, ts["offx"], ts["offy"], nt, 32, d_fake_T)
         d_raw = torch.empty(n, 5, h, w, device=dev)
         ops.g_out_grad(self._d_fake_I if self._have_dI else None, d_fake_T, self.M, self.g_out, d_raw)
-        engine.unet_backward(self.netG, self._g_ctx, d_raw)
+        if isinstance(self.netG, networks.ResnetGenerator):
+            engine.resnet_backward(self.netG, self._g_ctx, d_raw)
+        else:
+            engine.unet_backward(self.netG, self._g_ctx, d_raw)
 
     def _seg_adam_g(self):
         self.optimizer_G.step(self._gscale)
