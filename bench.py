@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s
 MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_16x16x4_f32)
 
 
-def build_model(size, batch, model_name, quiet=True):
+def build_model(size, batch, model_name, quiet=True, netG="unet256_custom"):
     import contextlib
     import io
 
@@ -35,7 +35,7 @@ def build_model(size, batch, model_name, quiet=True):
     from options.train_options import TrainOptions
 
     flags = ("--model %s --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
-             "--checkpoints_dir /tmp/vts_bench --name bench --crop_size %d --batch_size %d" % (model_name, size, batch))
+             "--checkpoints_dir /tmp/vts_bench --name bench --crop_size %d --batch_size %d --netG %s" % (model_name, size, batch, netG))
     ctx = contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()
     with ctx:
         opt = TrainOptions(cmd_line=flags).parse()
@@ -119,7 +119,7 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     return roof
 
 
-def cpu_baseline(size, style_dim, steps=3):
+def cpu_baseline(size, style_dim, steps=3, netG="unet256_custom"):
     """The CPU oracle (PyTorch-CPU restatement pinned to the reference) on this host's cores, N=1."""
     from torch.utils.data import default_collate
 
@@ -130,7 +130,9 @@ def cpu_baseline(size, style_dim, steps=3):
     # before a 256-thread host is full: 16 threads is near the best rate for this workload.
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    sd = (detrand.test_weights(nets.g_param_shapes(style_nc=style_dim), 1), detrand.test_weights(nets.d_param_shapes(4), 2),
+    g_shapes = (nets.resnet_param_shapes(n_blocks=int(netG[len("resnet_")])) if netG.startswith("resnet_")
+                else nets.g_param_shapes(style_nc=style_dim))
+    sd = (detrand.test_weights(g_shapes, 1), detrand.test_weights(nets.d_param_shapes(4), 2),
           detrand.test_weights(nets.d_param_shapes(7), 3))
     batch = default_collate([make_sample(size, 64, 64, 99, style_dim=style_dim)])
     import random
@@ -143,7 +145,7 @@ def cpu_baseline(size, style_dim, steps=3):
     for it in range(steps + 1):
         draws = {"aug": torch.rand(4, 1), "more_idx": torch.tensor([random.sample(range(cnt), 32)])}
         t0 = time.time()
-        step.train_step(sd[0], sd[1], sd[2], adam, batch, draws, style_code=style, record=False)
+        step.train_step(sd[0], sd[1], sd[2], adam, batch, draws, opt=step.hp(netG=netG), style_code=style, record=False)
         times.append(time.time() - t0)
         if it >= 1 and sum(times) > 45.0:   # keep the default run bounded
             break
@@ -184,6 +186,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU")
     ap.add_argument("--model", type=str, default="skitG")
+    ap.add_argument("--netG", type=str, default="unet256_custom",
+                    help="generator: unet256_custom (headline config) | resnet_{4,6,9}blocks (alternate; needs --model sinskitG)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--infer", action="store_true",
@@ -200,7 +204,7 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     if args.infer:
         return infer_bench(args)
-    model, opt = build_model(args.size, args.batch, args.model)
+    model, opt = build_model(args.size, args.batch, args.model, netG=args.netG)
     opt.use_hip_graph = not args.no_graph
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
     batch = make_batch(args.size, args.batch, rank, style_dim)
@@ -240,15 +244,16 @@ def main():
                 model.opt.use_hip_graph = keep
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.size, style_dim)
+            cpu = cpu_baseline(args.size, style_dim, netG=args.netG)
         ms = dt / args.steps * 1e3
         out = {
             "metric": "train_images_per_sec", "value": world * args.batch * args.steps / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
-                            "LPIPS/CLIP terms off (no weights offline)" % (args.model, args.size, args.size, args.batch),
+                "workload": "%s%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
+                            "LPIPS/CLIP terms off (no weights offline)" % (args.model, "" if args.netG == "unet256_custom" else " (netG %s)" % args.netG,
+                                                                          args.size, args.size, args.batch),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world, "losses_finite": finite,
                 "hip_graph": bool(opt.use_hip_graph),
             },
