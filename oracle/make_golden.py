@@ -202,6 +202,39 @@ def golden_resnet(size=64, seed=303, n_blocks=9, ngf=10):
     print("wrote resnet_%d.npz (%d entries)" % (size, len(out)))
 
 
+def golden_global(h=64, w=32, seed=404, ngf=8, n_down=3, n_blocks=3):
+    """pix2pixHD GlobalGenerator (define_G netG='global', BatchNorm, train mode): forward + gradients + BN buffers."""
+    import copy
+
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from models import networks
+
+    opt = copy.copy(_ref_opt("sinskitG", True, []))
+    opt.n_downsample_global, opt.n_blocks_global = n_down, n_blocks
+    out = {"h": h, "w": w, "seed": seed, "ngf": ngf, "n_down": n_down, "n_blocks": n_blocks}
+    G = networks.define_G(1, 5, ngf, "global", "batch", False, "xavier", 0.02, False, False, [], opt)
+    ref = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    mine = nets.resnet_param_shapes(1, 5, ngf, n_blocks, n_down, norm="batch", down="stride", up="convT", conv_bias=True)
+    assert ref == {k: tuple(v) for k, v in mine.items()}, "global G key/shape mismatch"
+    out["ref_keys"] = np.array(sorted(ref.keys()))
+    G.load_state_dict(detrand.test_weights(mine, seed))
+    G.train()
+    x = detrand.uniform((2, 1, h, w), seed, "g_in").requires_grad_(True)
+    y = G(x)
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    out["G_out"] = y.detach().numpy()
+    out["G_dx_probe"] = detrand.probe(x.grad, "g_dx")
+    for k, p in G.named_parameters():
+        out["G_grad/" + k] = detrand.probe(p.grad, k)
+    for k, b in G.named_buffers():
+        if b.dtype.is_floating_point:
+            out["G_buf/" + k] = b.numpy()
+    np.savez_compressed(os.path.join(GOLD, "global_%dx%d.npz" % (h, w)), **out)
+    print("wrote global_%dx%d.npz (%d entries)" % (h, w, len(out)))
+
+
 def golden_step(size=256, seed=202, steps=2, nt=64):
     """Full SinSKITGModel.optimize_parameters x `steps` on one synthetic sample (BASELINE config 0)."""
     from oracle import detrand, nets, ref_import
@@ -262,7 +295,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -271,3 +304,5 @@ if __name__ == "__main__":
         golden_step()
     if "resnet" in which:
         golden_resnet()
+    if "global" in which:
+        golden_global()

@@ -176,8 +176,9 @@ def blur_up(x):
     return y[:, :, 1:, 1:][:, :, :-1, :-1]
 
 
-def resnet_layout(n_blocks=9, n_down=2):
-    """nn.Sequential indices of ResnetGenerator.model (networks.py:1075-1147) -> [(kind, idx)]."""
+def resnet_layout(n_blocks=9, n_down=2, down="blur", up="blur"):
+    """nn.Sequential indices of ResnetGenerator.model (networks.py:1075-1147) / GlobalGenerator.model
+    (networks.py:1959-1975) -> [(kind, idx)]; idx = index of the group's first module."""
     lay, idx = [], 0
 
     def add(kind, n=1):
@@ -187,58 +188,104 @@ def resnet_layout(n_blocks=9, n_down=2):
 
     add("conv7_in", 4)                 # pad, conv, norm, relu
     for _ in range(n_down):
-        add("conv3_down", 4)           # conv, norm, relu, Downsample
+        add("conv3_down", 4 if down == "blur" else 3)   # conv, norm, relu(, Downsample)
     for _ in range(n_blocks):
         add("block", 1)
     for _ in range(n_down):
-        add("up_conv3", 4)             # Upsample, conv, norm, relu
+        add("up_conv3", 4 if up == "blur" else 3)       # (Upsample,) conv | ConvTranspose, norm, relu
     add("conv7_out", 3)                # pad, conv, tanh
     return lay
 
 
-def resnet_forward(sd, x, n_blocks=9, n_down=2):
-    for kind, i in resnet_layout(n_blocks, n_down):
+def _gnorm(sd, key, x, norm, training):
+    """InstanceNorm2d(affine=False) or BatchNorm2d at `key` (training: batch stats + running update)."""
+    if norm == "instance":
+        return _inorm(x)
+    y = F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"], training, 0.1, 1e-5)
+    if training and key + ".num_batches_tracked" in sd:
+        sd[key + ".num_batches_tracked"] += 1
+    return y
+
+
+def resnet_forward(sd, x, n_blocks=9, n_down=2, norm="instance", down="blur", up="blur", training=True):
+    """ResnetGenerator.forward (reference defaults: instance / blur / blur) and, with norm='batch', down='stride',
+    up='convT', pix2pixHD's GlobalGenerator.forward.  Missing biases (`use_bias=False` with BatchNorm) are None."""
+    def wb(i):
+        return sd["model.%d.weight" % i], sd.get("model.%d.bias" % i)
+
+    for kind, i in resnet_layout(n_blocks, n_down, down, up):
         if kind == "conv7_in":
-            x = F.relu(_inorm(F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), sd["model.%d.weight" % (i + 1)], sd["model.%d.bias" % (i + 1)])))
+            w, b = wb(i + 1)
+            x = F.relu(_gnorm(sd, "model.%d" % (i + 2), F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w, b), norm, training))
         elif kind == "conv3_down":
-            x = F.relu(_inorm(F.conv2d(x, sd["model.%d.weight" % i], sd["model.%d.bias" % i], padding=1)))
-            x = blur_down(x)
+            w, b = wb(i)
+            x = F.relu(_gnorm(sd, "model.%d" % (i + 1), F.conv2d(x, w, b, stride=1 if down == "blur" else 2, padding=1), norm, training))
+            if down == "blur":
+                x = blur_down(x)
         elif kind == "block":
             k = "model.%d.conv_block." % i
-            y = F.relu(_inorm(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[k + "1.weight"], sd[k + "1.bias"])))
-            y = _inorm(F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[k + "5.weight"], sd[k + "5.bias"]))
-            x = x + y
+            y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[k + "1.weight"], sd.get(k + "1.bias"))
+            y = F.relu(_gnorm(sd, k + "2", y, norm, training))
+            y = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[k + "5.weight"], sd.get(k + "5.bias"))
+            x = x + _gnorm(sd, k + "6", y, norm, training)
         elif kind == "up_conv3":
-            x = blur_up(x)
-            x = F.relu(_inorm(F.conv2d(x, sd["model.%d.weight" % (i + 1)], sd["model.%d.bias" % (i + 1)], padding=1)))
+            if up == "blur":
+                w, b = wb(i + 1)
+                x = F.relu(_gnorm(sd, "model.%d" % (i + 2), F.conv2d(blur_up(x), w, b, padding=1), norm, training))
+            else:
+                w, b = wb(i)
+                x = F.relu(_gnorm(sd, "model.%d" % (i + 1), F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1), norm, training))
         else:
-            x = torch.tanh(F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), sd["model.%d.weight" % (i + 1)], sd["model.%d.bias" % (i + 1)]))
+            w, b = wb(i + 1)
+            x = torch.tanh(F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w, b))
     return x
 
 
-def resnet_param_shapes(input_nc=9, output_nc=5, ngf=10, n_blocks=9, n_down=2):
-    """state_dict entries of ResnetGenerator (learnable ones; the `filt` buffers are constants)."""
+def resnet_param_shapes(input_nc=9, output_nc=5, ngf=10, n_blocks=9, n_down=2, norm="instance", down="blur", up="blur", conv_bias=None):
+    """state_dict entries of ResnetGenerator / GlobalGenerator (the `filt` buffers of the blur modules are constants
+    and not listed).  conv_bias None: the reference's rule use_bias = (norm == instance)."""
+    if conv_bias is None:
+        conv_bias = norm == "instance"
     sh = {}
-    for kind, i in resnet_layout(n_blocks, n_down):
+
+    def conv(key, shape, bias=conv_bias):
+        sh[key + ".weight"] = shape
+        if bias:
+            sh[key + ".bias"] = (shape[0],)
+
+    def nrm(key, c):
+        if norm == "batch":
+            sh[key + ".weight"] = (c,)
+            sh[key + ".bias"] = (c,)
+            sh[key + ".running_mean"] = (c,)
+            sh[key + ".running_var"] = (c,)
+            sh[key + ".num_batches_tracked"] = ()
+
+    for kind, i in resnet_layout(n_blocks, n_down, down, up):
         if kind == "conv7_in":
-            sh["model.%d.weight" % (i + 1)] = (ngf, input_nc, 7, 7)
-            sh["model.%d.bias" % (i + 1)] = (ngf,)
+            conv("model.%d" % (i + 1), (ngf, input_nc, 7, 7))
+            nrm("model.%d" % (i + 2), ngf)
             c = ngf
         elif kind == "conv3_down":
-            sh["model.%d.weight" % i] = (2 * c, c, 3, 3)
-            sh["model.%d.bias" % i] = (2 * c,)
+            conv("model.%d" % i, (2 * c, c, 3, 3))
+            nrm("model.%d" % (i + 1), 2 * c)
             c *= 2
         elif kind == "block":
             for j in (1, 5):
-                sh["model.%d.conv_block.%d.weight" % (i, j)] = (c, c, 3, 3)
-                sh["model.%d.conv_block.%d.bias" % (i, j)] = (c,)
+                conv("model.%d.conv_block.%d" % (i, j), (c, c, 3, 3))
+                nrm("model.%d.conv_block.%d" % (i, j + 1), c)
         elif kind == "up_conv3":
-            sh["model.%d.weight" % (i + 1)] = (c // 2, c, 3, 3)
-            sh["model.%d.bias" % (i + 1)] = (c // 2,)
+            if up == "blur":
+                conv("model.%d" % (i + 1), (c // 2, c, 3, 3))
+                nrm("model.%d" % (i + 2), c // 2)
+            else:
+                sh["model.%d.weight" % i] = (c, c // 2, 3, 3)       # ConvTranspose2d layout [Cin, Cout, 3, 3]
+                if conv_bias:
+                    sh["model.%d.bias" % i] = (c // 2,)
+                nrm("model.%d" % (i + 1), c // 2)
             c //= 2
         else:
-            sh["model.%d.weight" % (i + 1)] = (output_nc, c, 7, 7)
-            sh["model.%d.bias" % (i + 1)] = (output_nc,)
+            conv("model.%d" % (i + 1), (output_nc, c, 7, 7), bias=True)
     return sh
 
 

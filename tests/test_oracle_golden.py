@@ -148,6 +148,31 @@ def test_resnet_generator_fwd_bwd(golden_dir):
     _close(g["ref_filt_up"], np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0 * 4.0)
 
 
+def test_global_generator_fwd_bwd(golden_dir):
+    """oracle restatement of pix2pixHD's GlobalGenerator (BatchNorm, train mode) vs the reference module"""
+    g = _load(golden_dir, "global_64x32.npz")
+    h, w, seed, ngf, nd, nb = (int(g[k]) for k in ("h", "w", "seed", "ngf", "n_down", "n_blocks"))
+    shapes = nets.resnet_param_shapes(1, 5, ngf, nb, nd, norm="batch", down="stride", up="convT", conv_bias=True)
+    sd = detrand.test_weights(shapes, seed)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = detrand.uniform((2, 1, h, w), seed, "g_in").requires_grad_(True)
+    y = nets.resnet_forward(sd, x, nb, nd, norm="batch", down="stride", up="convT", training=True)
+    _close(y.detach().numpy(), g["G_out"], rtol=1e-4, atol=2e-5)
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    _probe_close(x.grad, g["G_dx_probe"], "g_dx")
+    for k, v in sd.items():
+        if not v.requires_grad:
+            if v.dtype.is_floating_point:
+                _close(v.numpy(), g["G_buf/" + k], rtol=1e-4, atol=1e-6)     # BN running statistics after one forward
+            continue
+        ref = g["G_grad/" + k]
+        if k.endswith(".bias") and abs(ref[1]) < 1e-4:
+            continue    # conv bias in front of a BatchNorm: rounding noise around 0
+        _probe_close(v.grad, ref, k, rtol=5e-4)
+
+
 def test_resnet_state_dict_keys(golden_dir):
     """the product's ResnetGenerator container exposes exactly the reference's state_dict keys"""
     import sys
@@ -159,6 +184,9 @@ def test_resnet_state_dict_keys(golden_dir):
     assert sorted(sd.keys()) == sorted(str(k) for k in g["ref_keys"])
     _close(sd["model.7.filt"][0, 0].numpy(), g["ref_filt_down"])
     _close(sd["model.%d.filt" % (12 + int(g["n_blocks"]))][0, 0].numpy(), g["ref_filt_up"])
+    g = _load(golden_dir, "global_64x32.npz")
+    G = networks.GlobalGenerator(1, 5, ngf=int(g["ngf"]), n_downsampling=int(g["n_down"]), n_blocks=int(g["n_blocks"]))
+    assert sorted(G.state_dict().keys()) == sorted(str(k) for k in g["ref_keys"])
 
 
 def test_init_distribution(golden_dir):

@@ -231,3 +231,86 @@ def test_train_step_with_resnet_generator_matches_oracle():
     torch.cuda.synchronize()
     assert all(np.isfinite(v) for v in model.get_current_losses().values())
     assert (model.flatG.flat - w0).abs().max().item() > 0
+
+
+def _check_param_grads(G, sdo, norm_bias_zero=True):
+    named = dict(G.named_parameters())
+    last_bias = "model.%d.bias" % max(int(k.split(".")[1]) for k in sdo)
+    for k, v in sdo.items():
+        if not (v.dtype.is_floating_point and v.requires_grad):
+            continue
+        ref, got = v.grad, named[k].grad
+        is_conv_bias = k.endswith(".bias") and k != last_bias and k.replace(".bias", ".weight") in sdo and sdo[k.replace(".bias", ".weight")].dim() == 4
+        if is_conv_bias:
+            assert ref.norm() < 5e-3, k                    # autograd: rounding noise around 0
+            assert got.abs().max().item() == 0.0, k        # here: exactly zero (the normalisation removes it)
+            continue
+        assert rel(got, ref) < 3e-4, (k, rel(got, ref))
+
+
+def test_global_generator_matches_reference_and_oracle(golden_dir):
+    """pix2pixHD GlobalGenerator (BatchNorm train mode, stride-2 3x3 convs, ConvTranspose2d): forward vs the committed
+    reference output, BN running statistics, backward vs oracle autograd"""
+    from models import networks
+    from vts import engine
+    from vts.optim import FlatParams
+    g = np.load(os.path.join(golden_dir, "global_64x32.npz"), allow_pickle=False)
+    h, w, seed, ngf, nd, nb = (int(g[k]) for k in ("h", "w", "seed", "ngf", "n_down", "n_blocks"))
+    dev = _dev()
+    shapes = nets.resnet_param_shapes(1, 5, ngf, nb, nd, norm="batch", down="stride", up="convT", conv_bias=True)
+    sd = detrand.test_weights(shapes, seed)
+    G = networks.GlobalGenerator(1, 5, ngf=ngf, n_downsampling=nd, n_blocks=nb).to(dev)
+    G.load_state_dict(sd)
+    flat = FlatParams(G)
+    G.train()
+    x = detrand.uniform((2, 1, h, w), seed, "g_in")
+    y, ctx = engine.resnet_forward(G, x.to(dev))
+    assert rel(y, torch.from_numpy(g["G_out"])) < 5e-5
+    for k, b in G.named_buffers():
+        if b.dtype.is_floating_point:
+            assert rel(b, torch.from_numpy(g["G_buf/" + k])) < 1e-4, k
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdo.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    yo = nets.resnet_forward(sdo, x, nb, nd, norm="batch", down="stride", up="convT", training=True)
+    cot = detrand.uniform(tuple(yo.shape), seed, "g_cot")
+    (yo * cot).sum().backward()
+    flat.grad.zero_()
+    engine.resnet_backward(G, ctx, (cot.to(dev) * (1.0 - y * y)).contiguous())
+    _check_param_grads(G, sdo)
+    # eval mode uses the running statistics
+    G.eval()
+    ye, _ = engine.resnet_forward(G, x.to(dev), keep=False)
+    sde = {k: v.detach() for k, v in sdo.items()}
+    assert rel(ye, nets.resnet_forward(sde, x, nb, nd, norm="batch", down="stride", up="convT", training=False)) < 5e-5
+
+
+def test_resnet_generator_strided_variants_wide():
+    """--no_antialias / --no_antialias_up ResnetGenerator with BatchNorm (no conv biases) and > 80 channels
+    (the output-channel group loop of vts_conv4x4)"""
+    from models import networks
+    from vts import engine
+    from vts.optim import FlatParams
+    dev = _dev()
+    ngf, nb, nd, seed = 48, 2, 2, 17          # 48 -> 96 -> 192 channels
+    shapes = nets.resnet_param_shapes(3, 5, ngf, nb, nd, norm="batch", down="stride", up="convT")
+    sd = detrand.test_weights(shapes, seed)
+    G = networks.ResnetGenerator(3, 5, ngf=ngf, n_blocks=nb, n_downsampling=nd, norm="batch", down="stride", up="convT").to(dev)
+    assert sorted(G.state_dict().keys()) == sorted(sd.keys())
+    G.load_state_dict(sd)
+    flat = FlatParams(G)
+    G.train()
+    x = detrand.uniform((1, 3, 24, 40), seed, "x")
+    y, ctx = engine.resnet_forward(G, x.to(dev))
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdo.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    yo = nets.resnet_forward(sdo, x, nb, nd, norm="batch", down="stride", up="convT", training=True)
+    assert rel(y, yo) < 5e-5
+    cot = detrand.uniform(tuple(yo.shape), seed, "cot")
+    (yo * cot).sum().backward()
+    flat.grad.zero_()
+    engine.resnet_backward(G, ctx, (cot.to(dev) * (1.0 - y * y)).contiguous())
+    _check_param_grads(G, sdo)

@@ -521,7 +521,28 @@ extern "C" int64_t vts_conv4x4_ws_floats(const vts_conv_desc* d) {
 extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   VTS_CHECK_ARG(d && d->in0.data && d->w && d->out, "vts_conv4x4: null pointer");
   VTS_CHECK_ARG(d->stride == 1 || d->stride == 2, "vts_conv4x4: stride %d unsupported", d->stride);
-  VTS_CHECK_ARG(d->Cout >= 1 && d->Cout <= 80, "vts_conv4x4: Cout %d outside 1..80", d->Cout);
+  VTS_CHECK_ARG(d->Cout >= 1, "vts_conv4x4: Cout %d", d->Cout);
+  if (d->Cout > 80) {
+    // wide layers (pix2pixHD: up to 1024 channels): one launch per group of 80 output channels.  Every group
+    // re-reads the input (from L2 / MALL at these map sizes); a GEMM-class kernel that tiles Cout is the
+    // planned replacement for this loop.
+    for (int c0 = 0; c0 < d->Cout; c0 += 80) {
+      vts_conv_desc g = *d;
+      const int64_t oplane = (int64_t)d->OH * d->OW;
+      g.Cout = d->Cout - c0 < 80 ? d->Cout - c0 : 80;
+      g.w = d->w + (int64_t)c0 * d->ws_co;
+      g.bias = d->bias ? d->bias + c0 : nullptr;
+      g.out = d->out + c0 * oplane;
+      if (d->dmask.data) {
+        g.dmask.data = d->dmask.data + c0 * oplane;
+        g.dmask.scale = d->dmask.scale ? d->dmask.scale + c0 : nullptr;
+        g.dmask.shift = d->dmask.shift ? d->dmask.shift + c0 : nullptr;
+      }
+      const int rc = vts_conv4x4(&g, stream);
+      if (rc != VTS_OK) return rc;
+    }
+    return VTS_OK;
+  }
   VTS_CHECK_ARG(d->N >= 1 && d->IH >= 1 && d->IW >= 1 && d->OH >= 1 && d->OW >= 1, "vts_conv4x4: bad shape");
   VTS_CHECK_ARG(d->in0.C >= 1 && d->in1.C >= 0, "vts_conv4x4: bad channel counts");
   // The output window is the caller's: out[y, x] for y < OH, x < OW sums the taps that fall inside the input

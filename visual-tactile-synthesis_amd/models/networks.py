@@ -117,14 +117,23 @@ class _Filt(nn.Module):
 
 
 class ResnetGenerator(nn.Module):
-    """ResNet generator with anti-aliased resampling (reference: networks.py:1051-1154, ResnetBlock :1267-1324,
-    Downsample :51-74, Upsample :87-107), selectable as --netG resnet_{4,6,9}blocks.  InstanceNorm, reflect
-    padding, no dropout (the reference defaults: normG=instance, no_dropout=True, no_antialias[_up]=False).
-    `self.layout` lists the reference's nn.Sequential so that the state_dict keys are `model.<idx>...`."""
+    """ResNet-style generators as one parameter container (reference: ResnetGenerator networks.py:1051-1154,
+    ResnetBlock :1267-1324, Downsample :51-74, Upsample :87-107; pix2pixHD GlobalGenerator :1952-1980).
 
-    def __init__(self, input_nc, output_nc, ngf=64, n_blocks=6, n_downsampling=2, opt=None):
+      norm  'instance' | 'batch'        down  'blur' (conv3 s1 + anti-aliased Downsample) | 'stride' (conv3 s2)
+      up    'blur' (Upsample + conv3) | 'convT' (ConvTranspose2d 3x3 s2 p1 op1)
+
+    `self.layout` lists the reference's nn.Sequential so that the state_dict keys are `model.<idx>...`;
+    reflect padding, no dropout."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_blocks=6, n_downsampling=2, norm="instance", down="blur", up="blur",
+                 conv_bias=None, opt=None):
         super().__init__()
+        assert norm in ("instance", "batch") and down in ("blur", "stride") and up in ("blur", "convT")
         self.input_nc, self.output_nc, self.ngf, self.n_blocks, self.n_down = input_nc, output_nc, ngf, n_blocks, n_downsampling
+        self.norm = norm
+        if conv_bias is None:          # ResnetGenerator: use_bias = (norm_layer == InstanceNorm2d)  (networks.py:1069-1073)
+            conv_bias = norm == "instance"
         mods, layout = {}, []
         idx = 0
 
@@ -135,39 +144,61 @@ class ResnetGenerator(nn.Module):
             layout.append(dict(kind=kind, idx=idx, **kw))
             idx += 1
 
+        def add_norm(c):
+            add("norm", _BNParams(c) if norm == "batch" else None)
+
+        def block(c):
+            kids = {1: _ConvParams((c, c, 3, 3), c if conv_bias else 0), 5: _ConvParams((c, c, 3, 3), c if conv_bias else 0)}
+            if norm == "batch":
+                kids[2], kids[6] = _BNParams(c), _BNParams(c)
+            return _Holder({"conv_block": _Holder(kids)})
+
         add("pad")
-        add("conv7", _ConvParams((ngf, input_nc, 7, 7), ngf))
-        add("norm"); add("relu")
+        add("conv7", _ConvParams((ngf, input_nc, 7, 7), ngf if conv_bias else 0))
+        add_norm(ngf); add("relu")
         for i in range(n_downsampling):
             c = ngf * 2 ** i
-            add("conv3", _ConvParams((2 * c, c, 3, 3), 2 * c))
-            add("norm"); add("relu")
-            add("down", _Filt(2 * c, [1.0, 2.0, 1.0], 1.0))
+            add("conv3", _ConvParams((2 * c, c, 3, 3), 2 * c if conv_bias else 0), stride=2 if down == "stride" else 1)
+            add_norm(2 * c); add("relu")
+            if down == "blur":
+                add("down", _Filt(2 * c, [1.0, 2.0, 1.0], 1.0))
         c = ngf * 2 ** n_downsampling
         for _ in range(n_blocks):
-            add("block", _Holder({"conv_block": _Holder({1: _ConvParams((c, c, 3, 3), c), 5: _ConvParams((c, c, 3, 3), c)})}))
+            add("block", block(c))
         for i in range(n_downsampling):
             c = ngf * 2 ** (n_downsampling - i)
-            add("up", _Filt(c, [1.0, 3.0, 3.0, 1.0], 4.0))
-            add("conv3", _ConvParams((c // 2, c, 3, 3), c // 2))
-            add("norm"); add("relu")
+            if up == "blur":
+                add("up", _Filt(c, [1.0, 3.0, 3.0, 1.0], 4.0))
+                add("conv3", _ConvParams((c // 2, c, 3, 3), c // 2 if conv_bias else 0), stride=1)
+            else:
+                add("convT3", _ConvParams((c, c // 2, 3, 3), c // 2 if conv_bias else 0, transposed=True))
+            add_norm(c // 2); add("relu")
         add("pad")
         add("conv7", _ConvParams((output_nc, ngf, 7, 7), output_nc))
         add("tanh")
         self.model = _Holder(mods)
         self.layout = layout
 
-    def conv(self, idx):
-        return getattr(self.model, str(idx))
+    def mod(self, idx):
+        return getattr(self.model, str(idx), None)
 
-    def block_convs(self, idx):
+    def block_mods(self, idx):
         cb = getattr(self.model, str(idx)).conv_block
-        return getattr(cb, "1"), getattr(cb, "5")
+        return [getattr(cb, k, None) for k in ("1", "2", "5", "6")]   # conv a, norm a, conv b, norm b
 
     def forward(self, x, style_code=None, verbose=False):
         """Inference forward on the HIP path; returns [N,output_nc,H,W]."""
         out, _ = engine.resnet_forward(self, x, keep=False)
         return out
+
+
+class GlobalGenerator(ResnetGenerator):
+    """pix2pixHD coarse generator (reference: networks.py:1952-1980; `define_G(netG='global')` :309-310):
+    BatchNorm, stride-2 3x3 downsampling, ConvTranspose2d upsampling, every convolution with a bias."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, norm="batch", opt=None):
+        super().__init__(input_nc, output_nc, ngf=ngf, n_blocks=n_blocks, n_downsampling=n_downsampling, norm=norm,
+                         down="stride", up="convT", conv_bias=True, opt=opt)
 
 
 class MultiscaleDiscriminator(nn.Module):
@@ -232,14 +263,22 @@ def init_net(net, init_type="normal", init_gain=0.02, gpu_ids=(), initialize_wei
 def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, init_type="normal", init_gain=0.02,
              no_antialias=False, no_antialias_up=False, gpu_ids=(), opt=None, generate_T_imgs=False, num_layer_separate=0):
     resnet_blocks = {"resnet_9blocks": 9, "resnet_6blocks": 6, "resnet_4blocks": 4}
-    if netG not in resnet_blocks and netG != "unet256_custom":
-        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom, resnet_{4,6,9}blocks)" % netG)
-    if norm != "instance":
-        raise NotImplementedError("the generators are built for normG=instance only")
+    if netG not in resnet_blocks and netG not in ("unet256_custom", "global"):
+        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom, resnet_{4,6,9}blocks, global)" % netG)
+    if netG == "global":   # pix2pixHD coarse generator (networks.py:309-310)
+        if norm not in ("batch", "instance"):
+            raise NotImplementedError("global generator: norm %s is not built" % norm)
+        net = GlobalGenerator(input_nc, output_nc, ngf, getattr(opt, "n_downsample_global", 4), getattr(opt, "n_blocks_global", 9), norm, opt=opt)
+        return init_net(net, init_type, init_gain, gpu_ids)
     if netG in resnet_blocks:
-        if use_dropout or no_antialias or no_antialias_up or generate_T_imgs:
-            raise NotImplementedError("resnet generator: only the reference defaults (no dropout, anti-aliased down/up-sampling) are built")
-        net = ResnetGenerator(input_nc, output_nc, ngf=ngf, n_blocks=resnet_blocks[netG], opt=opt)
+        if norm not in ("batch", "instance"):
+            raise NotImplementedError("resnet generator: norm %s is not built" % norm)
+        if use_dropout or generate_T_imgs:
+            raise NotImplementedError("resnet generator: dropout / generate_T_imgs are not built")
+        net = ResnetGenerator(input_nc, output_nc, ngf=ngf, n_blocks=resnet_blocks[netG], norm=norm,
+                              down="stride" if no_antialias else "blur", up="convT" if no_antialias_up else "blur", opt=opt)
+    elif norm != "instance":
+        raise NotImplementedError("unet256_custom is built for normG=instance only")
     else:
         net = CustomUnetGenerator(input_nc, output_nc, num_downs=8, ngf=ngf, num_layer_separate=num_layer_separate, opt=opt)
     return init_net(net, init_type, init_gain, gpu_ids)

@@ -186,6 +186,35 @@ class ResnetCtx:
     __slots__ = ("steps", "g_out")
 
 
+def _g_norm(G, r, bn):
+    """normalisation of a raw conv output as an Act: InstanceNorm (bn None) or BatchNorm2d (train: batch
+    statistics + running-stat update; eval: the running statistics)."""
+    if bn is None:
+        return ops.norm_stats(r, 0)
+    if G.training:
+        return ops.norm_stats(r, 1, gamma=bn.weight, beta=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var,
+                              nbt=bn.num_batches_tracked)
+    n = r.shape[0]
+    sc = bn.weight / torch.sqrt(bn.running_var + 1e-5)     # [C] vectors: plumbing, not arithmetic on activations
+    sh = bn.bias - bn.running_mean * sc
+    return Act(r, sc.repeat(n).contiguous(), sh.repeat(n).contiguous())
+
+
+def _g_norm_bwd(buf, a, bn):
+    if bn is None:
+        ops.norm_bwd(buf, a, 0)
+    else:
+        ops.norm_bwd(buf, a, 1, gamma=bn.weight, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
+
+
+def _conv3(x, conv, out, stride, act_in):
+    if stride == 1:
+        return ops.convk(x, conv.weight, out, bias=conv.bias, pad=1, act_in=act_in)
+    w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
+    co, ci = conv.weight.shape[:2]
+    return ops.conv4x4(x, w4, ci * 16, 16, co, out, bias=conv.bias, stride=2, pad=1, act_in=act_in)
+
+
 def resnet_forward(G, x, keep=True):
     """x: tensor / Act, or a pair (x0, x1) concatenated on store into the first padded tensor.
     Returns (g_out [N,output_nc,H,W] post-tanh, ctx).  Every 3x3 / 7x7 conv runs as 4x4 tap blocks
@@ -193,16 +222,20 @@ def resnet_forward(G, x, keep=True):
     srcs = [_as_act(t) for t in (x if isinstance(x, (tuple, list)) else (x,))]
     n, _, h, w = srcs[0].data.shape
     dev = srcs[0].data.device
-    steps = []          # per layout entry: what the backward needs
+    steps = []          # per layer group: what the backward needs
     cur = None          # current activation: Act (raw + affine, activation pending) or identity tensor
     pending = 0         # activation still to be applied to `cur` by its consumer
     lay = G.layout
     i = 0
+
+    def shape_of(t):
+        return (t.data if isinstance(t, Act) else t).shape
+
     while i < len(lay):
         e = lay[i]
         kind = e["kind"]
         if kind == "pad":      # ReflectionPad2d(3) + conv7 (+ norm / relu | tanh)
-            conv = G.conv(lay[i + 1]["idx"])
+            conv = G.mod(lay[i + 1]["idx"])
             if cur is None:    # network input: concat the sources while padding
                 cin = sum(s_.data.shape[1] for s_ in srcs)
                 p = _empty(n, cin, h + 6, w + 6, dev)
@@ -218,22 +251,36 @@ def resnet_forward(G, x, keep=True):
             r = _empty(n, conv.weight.shape[0], p.shape[2] - 6, p.shape[3] - 6, dev)
             ops.convk(p, conv.weight, r, bias=conv.bias, pad=0)
             if lay[i + 2]["kind"] == "norm":
-                cur, pending = ops.norm_stats(r, 0), RELU
-                steps.append(("conv7", conv, p, src_act, cur))
+                bn = G.mod(lay[i + 2]["idx"])
+                cur, pending = _g_norm(G, r, bn), RELU
+                steps.append(("conv7", conv, p, src_act, cur, bn))
                 i += 4
             else:              # final conv + tanh
                 g_out = ops.pad_affine(r, (0, 0, 0, 0), 0, act=TANH)
-                steps.append(("conv7_out", conv, p, src_act, None))
+                steps.append(("conv7_out", conv, p, src_act, None, None))
                 i += 3
                 cur = g_out
-        elif kind == "conv3":  # Conv2d(3, zero pad 1) + norm + relu
-            conv = G.conv(e["idx"])
+        elif kind == "conv3":  # Conv2d(3, pad 1, stride 1 | 2) + norm + relu
+            conv, bn = G.mod(e["idx"]), G.mod(lay[i + 1]["idx"])
+            inp, inp_act, stride = cur, pending, e["stride"]
+            _, _, ih, iw = shape_of(cur)
+            r = _empty(n, conv.weight.shape[0], (ih - 1) // stride + 1, (iw - 1) // stride + 1, dev)
+            if stride == 2 and (ih % 2 or iw % 2):
+                raise ValueError("stride-2 3x3 convolutions need even sizes, got %dx%d" % (ih, iw))
+            _conv3(inp, conv, r, stride, inp_act)
+            cur, pending = _g_norm(G, r, bn), RELU
+            steps.append(("conv3", conv, inp, inp_act, cur, bn, stride))
+            i += 3
+        elif kind == "convT3":  # ConvTranspose2d(3, stride 2, pad 1, output_padding 1) + norm + relu
+            conv, bn = G.mod(e["idx"]), G.mod(lay[i + 1]["idx"])
             inp, inp_act = cur, pending
-            t = cur.data if isinstance(cur, Act) else cur
-            r = _empty(n, conv.weight.shape[0], t.shape[2], t.shape[3], dev)
-            ops.convk(inp, conv.weight, r, bias=conv.bias, pad=1, act_in=inp_act)
-            cur, pending = ops.norm_stats(r, 0), RELU
-            steps.append(("conv3", conv, inp, inp_act, cur))
+            _, _, ih, iw = shape_of(cur)
+            ci, co = conv.weight.shape[:2]
+            r = _empty(n, co, 2 * ih, 2 * iw, dev)
+            w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
+            ops.conv4x4(inp, w4, 16, co * 16, co, r, bias=conv.bias, stride=2, pad=1, transposed=True, act_in=inp_act)
+            cur, pending = _g_norm(G, r, bn), RELU
+            steps.append(("convT3", conv, inp, inp_act, cur, bn))
             i += 3
         elif kind == "down":
             inp = cur
@@ -245,19 +292,24 @@ def resnet_forward(G, x, keep=True):
             cur, pending = ops.blur_up(cur, act=pending), 0
             steps.append(("up", inp, inp_act))
             i += 1
-        elif kind == "block":  # x + IN(conv(reflpad(relu(IN(conv(reflpad(x)))))))
-            ca, cb = G.block_convs(e["idx"])
+        elif kind == "block":  # x + norm(conv(reflpad(relu(norm(conv(reflpad(x)))))))
+            ca, na, cb, nb = G.block_mods(e["idx"])
+            if pending or isinstance(cur, Act):   # first block after a strided conv: materialise relu(norm(r))
+                blk_src = (cur, pending)
+                cur, pending = ops.pad_affine(cur, (0, 0, 0, 0), 0, act=pending), 0
+            else:
+                blk_src = None
             xb = cur           # identity tensor
             p1 = ops.pad_affine(xb, (1, 1, 1, 1), 1)
             r1 = _empty(n, ca.weight.shape[0], xb.shape[2], xb.shape[3], dev)
             ops.convk(p1, ca.weight, r1, bias=ca.bias, pad=0)
-            a1 = ops.norm_stats(r1, 0)
+            a1 = _g_norm(G, r1, na)
             p2 = ops.pad_affine(a1, (1, 1, 1, 1), 1, act=RELU)
             r2 = _empty(n, cb.weight.shape[0], xb.shape[2], xb.shape[3], dev)
             ops.convk(p2, cb.weight, r2, bias=cb.bias, pad=0)
-            a2 = ops.norm_stats(r2, 0)
+            a2 = _g_norm(G, r2, nb)
             cur, pending = ops.pad_affine(a2, (0, 0, 0, 0), 0, res=xb), 0
-            steps.append(("block", ca, cb, p1, a1, p2, a2))
+            steps.append(("block", ca, cb, p1, a1, p2, a2, na, nb, blk_src))
             i += 1
         else:
             raise RuntimeError("unexpected layout entry %r" % (e,))
@@ -270,66 +322,97 @@ def resnet_forward(G, x, keep=True):
 
 def resnet_backward(G, ctx, d_raw):
     """d_raw: gradient w.r.t. the pre-tanh output.  Writes every parameter's .grad (overwrite).
-    Biases that feed an InstanceNorm have identically zero gradient and are never written."""
+    Biases that feed a normalisation have identically zero gradient and are never written."""
     dev = d_raw.device
 
-    def through_norm_relu(g_act, a):
+    def through_norm_relu(g_act, a, bn):
         """gradient w.r.t. relu(norm(r)) -> gradient w.r.t. the raw conv output r (in a fresh buffer)"""
         buf = torch.empty_like(a.data)
         ops.act_bwd(g_act, a, RELU, buf)
-        ops.norm_bwd(buf, a, 0)
+        _g_norm_bwd(buf, a, bn)
         return buf
+
+    def producer_bn(a):
+        return bn_of.get(id(a))
+
+    bn_of = {}
+    for st in ctx.steps:      # Act -> the BatchNorm module that produced its affine (None: InstanceNorm)
+        if st[0] in ("conv7", "conv3", "convT3"):
+            bn_of[id(st[4])] = st[5]
 
     g = d_raw            # gradient w.r.t. the output of the step being processed
     for st in reversed(ctx.steps):
         kind = st[0]
         if kind == "conv7_out":
-            _, conv, p, src_act, _ = st
+            _, conv, p, src_act, _, _ = st
             ops.wgradk(g, p, conv.weight.grad, pad=0)
             ops.channel_sum(g, conv.bias.grad)
             dp = torch.empty_like(p)
             ops.convk_bwd_data(g, conv.weight, dp, pad=0)
             da = _empty(p.shape[0], p.shape[1], p.shape[2] - 6, p.shape[3] - 6, dev)
             ops.pad_bwd(dp, (3, 3, 3, 3), 1, da)
-            g = through_norm_relu(da, src_act)       # the padded tensor was relu(norm(r_prev))
+            g = through_norm_relu(da, src_act, producer_bn(src_act))   # the padded tensor was relu(norm(r_prev))
         elif kind == "conv7":
-            _, conv, p, src_act, a = st
+            _, conv, p, src_act, a, bn = st
             ops.wgradk(g, p, conv.weight.grad, pad=0)  # network input: no gradient needed below
         elif kind == "conv3":
-            _, conv, inp, inp_act, a = st
+            _, conv, inp, inp_act, a, bn, stride = st
             hi = inp if isinstance(inp, Act) else Act(inp)
-            ops.wgradk(g, hi, conv.weight.grad, pad=1, act_hi=inp_act)
             t = inp.data if isinstance(inp, Act) else inp
             din = torch.empty_like(t)
-            ops.convk_bwd_data(g, conv.weight, din, pad=1)
-            g = through_norm_relu(din, inp) if inp_act == RELU else din
+            if stride == 1:
+                ops.wgradk(g, hi, conv.weight.grad, pad=1, act_hi=inp_act)
+                ops.convk_bwd_data(g, conv.weight, din, pad=1)
+            else:
+                co, ci = conv.weight.shape[:2]
+                dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
+                ops.wgrad4x4(g, hi, dw4, stride=2, pad=1, act_hi=inp_act)
+                ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)
+                w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
+                ops.conv4x4(g, w4, 16, ci * 16, ci, din, stride=2, pad=1, transposed=True)
+            g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
+        elif kind == "convT3":
+            _, conv, inp, inp_act, a, bn = st
+            ci, co = conv.weight.shape[:2]
+            lo = inp if isinstance(inp, Act) else Act(inp)
+            t = inp.data if isinstance(inp, Act) else inp
+            dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
+            ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act)
+            ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)
+            w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
+            din = torch.empty_like(t)
+            ops.conv4x4(g, w4, co * 16, 16, ci, din, stride=2, pad=1)
+            g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
         elif kind == "down":
             inp = st[1]       # Act: relu(norm(r)) on load
             da = torch.empty_like(inp.data)
             ops.blur_down_bwd(g, da)
-            g = through_norm_relu(da, inp)
+            g = through_norm_relu(da, inp, producer_bn(inp))
         elif kind == "up":
             _, inp, inp_act = st
             t = inp.data if isinstance(inp, Act) else inp
             da = torch.empty_like(t)
             ops.blur_up_bwd(g, da)
-            g = through_norm_relu(da, inp) if inp_act == RELU else da
+            g = through_norm_relu(da, inp, producer_bn(inp)) if inp_act == RELU else da
         elif kind == "block":
-            _, ca, cb, p1, a1, p2, a2 = st
+            _, ca, cb, p1, a1, p2, a2, na, nb, blk_src = st
             dy = g
             g2 = dy.clone()
-            ops.norm_bwd(g2, a2, 0)
+            _g_norm_bwd(g2, a2, nb)
             ops.wgradk(g2, p2, cb.weight.grad, pad=0)
             dp2 = torch.empty_like(p2)
             ops.convk_bwd_data(g2, cb.weight, dp2, pad=0)
             da1 = torch.empty_like(a1.data)
             ops.pad_bwd(dp2, (1, 1, 1, 1), 1, da1)
-            g1 = through_norm_relu(da1, a1)
+            g1 = through_norm_relu(da1, a1, na)
             ops.wgradk(g1, p1, ca.weight.grad, pad=0)
             dp1 = torch.empty_like(p1)
             ops.convk_bwd_data(g1, ca.weight, dp1, pad=0)
             ops.pad_bwd(dp1, (1, 1, 1, 1), 1, dy, accumulate=True)   # + the skip path
             g = dy
+            if blk_src is not None:    # the block input was materialised from relu(norm(r)) of a strided conv
+                src, src_act = blk_src
+                g = through_norm_relu(g, src, producer_bn(src)) if src_act == RELU else g
         else:
             raise RuntimeError(kind)
 
