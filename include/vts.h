@@ -195,6 +195,18 @@ int vts_blur_up_bwd(const float* dout, int N, int C, int H, int W, float* din, i
 int vts_tap_embed(const float* w, int64_t rows, int K, int a, int b, float* w4, void* stream);
 int vts_tap_extract(const float* dw4, int64_t rows, int K, int a, int b, float* dw, int accumulate, void* stream);
 
+/* GEMM-class 3x3 stride-1 convolution for wide layers (pix2pixHD GlobalGenerator's ResnetBlocks at up to 1024
+ * channels, models/networks.py:1952-1980, :1267-1324) over a PRE-PADDED input:
+ *   out[n,co,y,x] = bias[co] + sum_{ci,ky,kx} in[n,ci,y+ky,x+kx] * wt[(ci*9 + ky*3+kx)*Cout + co]
+ * in [N,Cin,H+2,W+2] (vts_pad_affine output), out [N,Cout,H,W], wt from vts_w3x3_pack:
+ *   mode 0: wt[(ci*9+t)*Cout + co] = w[co][ci][t]         (forward of nn.Conv2d weight [Cout,Cin,3,3])
+ *   mode 1: wt[(co*9+t)*Cin  + ci] = w[co][ci][8-t]       (adjoint w.r.t. the input: call with Cin<->Cout on the
+ *                                                          output gradient zero-padded by 2)
+ * Cout must be a multiple of 4. */
+int vts_w3x3_pack(const float* w, int Cout, int Cin, int mode, float* wt, void* stream);
+int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
+                     void* stream);
+
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */
 int vts_avgpool3s2(const float* x, int64_t x_nstride, int N, int C, int H, int W, float* y, void* stream);

@@ -314,3 +314,26 @@ def test_resnet_generator_strided_variants_wide():
     flat.grad.zero_()
     engine.resnet_backward(G, ctx, (cot.to(dev) * (1.0 - y * y)).contiguous())
     _check_param_grads(G, sdo)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 20, 132, 9, 37), (1, 256, 256, 8, 64), (1, 8, 4, 5, 5)])
+def test_conv3x3_wide_forward_and_input_adjoint(shape):
+    """GEMM-class 3x3 kernel vs F.conv2d on the padded input; the adjoint through the flipped / transposed packing"""
+    from vts import ops
+    n, ci, co, h, w = shape
+    dev = _dev()
+    p = detrand.uniform((n, ci, h + 2, w + 2), 21, "p").requires_grad_(True)
+    wt = (detrand.uniform((co, ci, 3, 3), 21, "w") * float(np.sqrt(3.0 / (9 * ci)))).requires_grad_(True)
+    b = detrand.uniform((co,), 21, "b")
+    ref = F.conv2d(p, wt, b)
+    cot = detrand.uniform(tuple(ref.shape), 21, "cot")
+    (ref * cot).sum().backward()
+    out = torch.full(ref.shape, float("nan"), device=dev)
+    wd = wt.detach().to(dev)
+    ops.conv3x3_wide(p.detach().to(dev), ops.w3x3_pack(wd, 0, "f"), b.to(dev), out)
+    assert rel(out, ref) < 1e-5
+    if ci % 4 == 0:
+        q = ops.pad_affine(cot.to(dev), (2, 2, 2, 2), 0)
+        dp = torch.full(p.shape, float("nan"), device=dev)
+        ops.conv3x3_wide(q, ops.w3x3_pack(wd, 1, "b"), None, dp)
+        assert rel(dp, p.grad) < 1e-5

@@ -58,6 +58,19 @@ def wgrad_case(N, CL, LH, CH, stride, pad):
     print("wgrad N%d lo %dx%d hi %dx%d s%d : %8.1f us  %6.2f TF  %7.1f GB/s" % (N, CL, LH, CH, HH, stride, us, fl / us / 1e6, by / us / 1e3))
 
 
+def wide_case(N, C, H, W):
+    p = torch.randn(N, C, H + 2, W + 2, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.01
+    out = torch.empty(N, C, H, W, device=dev)
+    wt = ops.w3x3_pack(w, 0, "mb")
+    us = timeit(lambda: ops.conv3x3_wide(p, wt, None, out), reps=5)
+    fl = 2.0 * N * H * W * C * C * 9
+    print("wide3x3 N%d %dx%dx%d : %8.1f us  %6.2f TF (%.1f%% of 157.3)" % (N, C, H, W, us, fl / us / 1e6, fl / us / 1e6 / 1.573))
+    out2 = torch.empty(N, C, H, W, device=dev)
+    us = timeit(lambda: ops.convk(p[:, :, 1:-1, 1:-1].contiguous(), w, out2, pad=1), reps=2)
+    print("   (4x4-block path, zero pad) : %8.1f us  %6.2f TF" % (us, fl / us / 1e6))
+
+
 if __name__ == "__main__":
     print("ABLATE=%s SMALL=%s" % (os.environ.get("VTS_ABLATE"), os.environ.get("VTS_SMALL_WGS")))
     if os.environ.get("VTS_MB") == "pmc":
@@ -67,6 +80,12 @@ if __name__ == "__main__":
     if os.environ.get("VTS_MB", "").startswith("one:"):
         a = [int(v) for v in os.environ["VTS_MB"][4:].split(",")]
         conv_case(a[0], a[1], a[2], a[3], a[4], a[5], a[6], bool(a[7]))
+        sys.exit(0)
+    if os.environ.get("VTS_MB") == "wide":
+        wide_case(1, 1024, 64, 128)
+        wide_case(1, 1024, 16, 32)
+        wide_case(4, 512, 64, 64)
+        wide_case(4, 256, 128, 128)
         sys.exit(0)
     if os.environ.get("VTS_MB") == "top":
         conv_case(4, 4, 1024, 1024, 8, 2, 2, False)

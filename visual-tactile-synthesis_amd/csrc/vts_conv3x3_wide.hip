@@ -1,0 +1,188 @@
+// GEMM-class 3x3 stride-1 convolution for wide layers (pix2pixHD GlobalGenerator: 9 ResnetBlocks at 1024
+// channels, reference models/networks.py:1952-1980 / ResnetBlock :1267-1324; AI ~ 200 flop/B: the MFMA-bound
+// workload of SURVEY.md §8d) on the fp32 MFMA path (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   out[n, co, y, x] = bias[co] + sum_{ci, ky, kx} in[n, ci, y + ky, x + kx] * wt[(ci * 9 + ky * 3 + kx) * Cout + co]
+//
+// `in` is the PRE-PADDED input [N, Cin, H + 2, W + 2] (vts_pad_affine materialises reflection / zero padding
+// together with the pending normalise + activate, so this kernel reads an identity operand and never handles a
+// border); `wt` is the tap-major packed weight of vts_w3x3_pack.  The adjoint w.r.t. the input is the same
+// operator on the zero-padded output gradient with the flipped / transposed packing.
+//
+// GEMM view: M = output channels, N = pixels, K = Cin x 9 taps.  A workgroup (4 waves) owns 128 channels x
+// (4 rows x 32 columns); a wave owns 64 x 64 as 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).
+// Per chunk of 8 input channels the 6 x 34 patch and the 8 x 9 x 128 weight slice are staged in LDS (44 KB);
+// the next chunk's global loads (16-byte buffer loads, hardware bounds check) are in flight during the 144
+// MFMAs of the current one.  LDS reads are conflict-free: an A fragment reads 32 consecutive output channels,
+// a B fragment 32 consecutive pixels of one row, the two k-halves of a fragment are separate lane groups.
+#include "vts_internal.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TCO = 128, TY = 4, TX = 32, CK = 8;
+constexpr int PR = TY + 2, PC = TX + 2, PCP = 36;
+constexpr int PATCH_FLOATS = CK * PR * PCP;           // 1728
+constexpr int W_FLOATS = CK * 9 * TCO;                // 9216
+constexpr int PQ_ROW = PCP / 4;                       // 9 quads per patch row
+constexpr int NPQ = (CK * PR * PQ_ROW + 255) / 256;   // 2 patch quads per thread
+constexpr int NWQ = W_FLOATS / 4 / 256;               // 9 weight quads per thread
+constexpr unsigned RSRC_FLAGS = 0x00020000;
+
+struct WideK {
+  const float *in, *wt, *bias;
+  float* out;
+  int N, Cin, Cout, H, W;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
+  __shared__ __attribute__((aligned(16))) float lds[PATCH_FLOATS + W_FLOATS];
+  float* lds_p = lds;
+  float* lds_w = lds + PATCH_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave & 1, wpx = wave >> 1;
+  const int tiles_x = (p.W + TX - 1) / TX;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * TX, y0 = ty * TY, co0 = blockIdx.y * TCO, n = blockIdx.z;
+  const int PH = p.H + 2, PW = p.W + 2;
+  const int plane = PH * PW;
+
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * 9 * p.Cout * 4, RSRC_FLAGS);
+
+  // staging items of this thread (chunk independent): patch quads (ci, row, quad), weight quads (ci*9+tap, co quad)
+  int pvoff[NPQ], ploff[NPQ];
+#pragma unroll
+  for (int e = 0; e < NPQ; ++e) {
+    const int q = min(tid + e * 256, CK * PR * PQ_ROW - 1);
+    const int row = q / PQ_ROW, cq = q - row * PQ_ROW;      // row = ci * PR + r
+    const int ci = row / PR, r = row - ci * PR;
+    pvoff[e] = (ci * plane + (y0 + r) * PW + x0 + 4 * cq) * 4;
+    ploff[e] = row * PCP + 4 * cq;
+  }
+  int wvoff[NWQ], wloff[NWQ];
+#pragma unroll
+  for (int e = 0; e < NWQ; ++e) {
+    const int q = tid + e * 256;
+    const int row = q >> 5, cq = q & 31;                    // row = ci * 9 + tap
+    wvoff[e] = (row * p.Cout + co0 + 4 * cq) * 4;
+    wloff[e] = row * TCO + 4 * cq;
+  }
+  // rows past the image (bottom tiles) lie beyond the descriptor only for the last channel: clamp by masking the
+  // store instead -- values computed from them are never written.  Channels past Cin read 0 (bounds check).
+
+  u32x4 pq[NPQ], wq[NWQ];
+  auto load_chunk = [&](int c0) {
+    const int pbase = c0 * plane * 4, wbase = c0 * 9 * p.Cout * 4;
+#pragma unroll
+    for (int e = 0; e < NPQ; ++e) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pvoff[e] + pbase, 0, 0);
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e) wq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[e] + wbase, 0, 0);
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < NPQ; ++e) *reinterpret_cast<u32x4*>(lds_p + ploff[e]) = pq[e];
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e) *reinterpret_cast<u32x4*>(lds_w + wloff[e]) = wq[e];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* a_base = lds_w + kh * 9 * TCO + wco * 64 + l32;
+  const float* b_base = lds_p + kh * PR * PCP + (wpx * 2) * PCP + l32;
+
+  const int nchunks = (p.Cin + CK - 1) / CK;
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) load_chunk((c + 1) * CK);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int kc = 0; kc < CK / 2; ++kc) {
+        const float a0 = a_base[(kc * 2 * 9 + tap) * TCO], a1 = a_base[(kc * 2 * 9 + tap) * TCO + 32];
+        const float b0 = b_base[kc * 2 * PR * PCP + ky * PCP + kx], b1 = b_base[kc * 2 * PR * PCP + (ky + 1) * PCP + kx];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C layout of a 32x32 tile: column (pixel) = lane % 32, row (channel) = (r / 4) * 8 + (lane / 32) * 4 + r % 4
+  const int x = x0 + l32;
+  float* ob = p.out + (int64_t)n * p.Cout * p.H * p.W;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int y = y0 + wpx * 2 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 64 + i * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+        if (co < p.Cout && y < p.H && x < p.W) ob[((int64_t)co * p.H + y) * p.W + x] = acc[i][j][r] + (p.bias ? p.bias[co] : 0.f);
+      }
+    }
+}
+
+// w [Cout, Cin, 3, 3]  ->  mode 0: wt[(ci*9 + t) * Cout + co] = w[co][ci][t]                (forward)
+//                          mode 1: wt[(co*9 + t) * Cin  + ci] = w[co][ci][8 - t]            (adjoint w.r.t. the input)
+__global__ __launch_bounds__(256) void w3x3_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int mode, float* __restrict__ wt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  if (i >= total) return;
+  // i indexes the OUTPUT so that writes are coalesced
+  if (mode == 0) {
+    const int co = (int)(i % Cout);
+    const int64_t r = i / Cout;
+    const int t = (int)(r % 9), ci = (int)(r / 9);
+    wt[i] = w[((int64_t)co * Cin + ci) * 9 + t];
+  } else {
+    const int ci = (int)(i % Cin);
+    const int64_t r = i / Cin;
+    const int t = (int)(r % 9), co = (int)(r / 9);
+    wt[i] = w[((int64_t)co * Cin + ci) * 9 + (8 - t)];
+  }
+}
+
+}  // namespace
+
+extern "C" int vts_w3x3_pack(const float* w, int Cout, int Cin, int mode, float* wt, void* stream) {
+  VTS_CHECK_ARG(w && wt && Cout >= 1 && Cin >= 1 && (mode == 0 || mode == 1), "vts_w3x3_pack: bad args");
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  hipLaunchKernelGGL(w3x3_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, mode, wt);
+  VTS_CHECK_LAUNCH("vts_w3x3_pack");
+  return VTS_OK;
+}
+
+extern "C" int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
+                                void* stream) {
+  VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "vts_conv3x3_wide: bad args");
+  VTS_CHECK_ARG((Cout & 3) == 0, "vts_conv3x3_wide: Cout %d must be a multiple of 4 (16-byte weight rows)", Cout);
+  VTS_CHECK_ARG((int64_t)Cin * (H + 2) * (W + 2) * 4 < (1ll << 31) && (int64_t)Cin * 9 * Cout * 4 < (1ll << 31) && N <= 65535,
+                "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
+  WideK k{in, wt, bias, out, N, Cin, Cout, H, W};
+  const int tiles = cdiv(W, TX) * cdiv(H, TY);
+  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(tiles, cdiv(Cout, TCO), N), dim3(256), 0, (hipStream_t)stream, k);
+  vts_set_kernel("conv3x3_wide_kernel");
+  VTS_CHECK_LAUNCH("vts_conv3x3_wide");
+  return VTS_OK;
+}

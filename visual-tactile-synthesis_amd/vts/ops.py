@@ -45,7 +45,7 @@ def _run(label, nbytes, flops, fn, *args):
     rc = fn(*args)
     e1.record()
     L.check(rc, label)
-    if label.startswith(("conv4x4", "wgrad4x4", "norm_")):
+    if label.startswith(("conv4x4", "wgrad4x4", "norm_", "conv3x3_wide")):
         label = L.load().vts_last_kernel().decode()   # the exact kernel instance, as rocprofv3 names it
     TIMER.append((label, nbytes, flops, e0, e1, DETAIL))
     DETAIL = None
@@ -204,6 +204,29 @@ def wgradk(dout, x, dw, *, pad=0, act_hi=0, accumulate=False):
         wgrad4x4(dout, x, dw4[i], stride=1, pad=pad - 4 * a, pad_dx=4 * (a - b), act_hi=act_hi)
         tap_extract(dw4[i], K, a, b, dw, accumulate=accumulate)
     return dw
+
+
+def w3x3_pack(w, mode, tag):
+    """tap-major packing of a [Co, Ci, 3, 3] weight for conv3x3_wide (mode 0 forward, 1 input-adjoint); persistent buffer"""
+    key = ("wt", w.data_ptr(), tuple(w.shape), tag)
+    buf = _ws.get(key)
+    if buf is None:
+        buf = _ws[key] = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    _run("w3x3_pack", 8.0 * w.numel(), 0.0, L.load().vts_w3x3_pack, w.data_ptr(), w.shape[0], w.shape[1], mode, buf.data_ptr(), L.stream())
+    return buf
+
+
+def conv3x3_wide(p, wt, bias, out):
+    """out [N,Co,H,W] <- valid 3x3 conv of the pre-padded p [N,Ci,H+2,W+2] with packed weights wt (GEMM-class kernel)"""
+    n, ci, ph, pw = p.shape
+    co, h, w = out.shape[1], ph - 2, pw - 2
+    assert out.shape == (n, co, h, w) and p.is_contiguous() and out.is_contiguous()
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d" % (n, ci, h, w, co, h, w)
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * h * w * co * ci * 9, L.load().vts_conv3x3_wide,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, L.stream())
+    return out
 
 
 def pad_affine(x, pads, mode, out=None, act=0, res=None, out_nstride=0):
