@@ -205,7 +205,9 @@ int vts_tap_extract(const float* dw4, int64_t rows, int K, int a, int b, float* 
  * Cout must be a multiple of 4. */
 int vts_w3x3_pack(const float* w, int Cout, int Cin, int mode, float* wt, void* stream);
 int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
-                     void* stream);
+                     float* ws, int64_t ws_floats, void* stream);
+/* scratch for the k-split used when the tile grid alone cannot fill the GPU (0: not needed); deterministic reduction */
+int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */

@@ -337,3 +337,19 @@ def test_conv3x3_wide_forward_and_input_adjoint(shape):
         dp = torch.full(p.shape, float("nan"), device=dev)
         ops.conv3x3_wide(q, ops.w3x3_pack(wd, 1, "b"), None, dp)
         assert rel(dp, p.grad) < 1e-5
+
+
+def test_conv3x3_wide_ksplit_small_map():
+    """few tiles: the k-split path with its deterministic reduction"""
+    from vts import ops
+    dev = _dev()
+    n, ci, co, h, w = 1, 256, 128, 8, 16
+    p = detrand.uniform((n, ci, h + 2, w + 2), 22, "p")
+    wt = detrand.uniform((co, ci, 3, 3), 22, "w") * float(np.sqrt(3.0 / (9 * ci)))
+    b = detrand.uniform((co,), 22, "b")
+    out = torch.full((n, co, h, w), float("nan"), device=dev)
+    ops.conv3x3_wide(p.to(dev), ops.w3x3_pack(wt.to(dev), 0, "f"), b.to(dev), out)
+    assert rel(out, F.conv2d(p, wt, b)) < 1e-5
+    out2 = torch.empty_like(out)
+    ops.conv3x3_wide(p.to(dev), ops.w3x3_pack(wt.to(dev), 0, "f"), b.to(dev), out2)
+    assert torch.equal(out, out2)          # deterministic

@@ -35,6 +35,8 @@ struct WideK {
   const float *in, *wt, *bias;
   float* out;
   int N, Cin, Cout, H, W;
+  int KS, cps;   // k-split for small grids: blockIdx.z = n + N * slice, cps input-channel chunks per slice
+  float* part;   // [KS][N][Cout][H][W] raw partial sums (KS > 1), reduced in slice order by wide_reduce_kernel
 };
 
 __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
   const int wco = wave & 1, wpx = wave >> 1;
   const int tiles_x = (p.W + TX - 1) / TX;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x0 = tx * TX, y0 = ty * TY, co0 = blockIdx.y * TCO, n = blockIdx.z;
+  const int x0 = tx * TX, y0 = ty * TY, co0 = blockIdx.y * TCO, n = blockIdx.z % p.N, ks = blockIdx.z / p.N;
   const int PH = p.H + 2, PW = p.W + 2;
   const int plane = PH * PW;
 
@@ -100,11 +102,12 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
   const float* a_base = lds_w + kh * 9 * TCO + wco * 64 + l32;
   const float* b_base = lds_p + kh * PR * PCP + (wpx * 2) * PCP + l32;
 
-  const int nchunks = (p.Cin + CK - 1) / CK;
-  load_chunk(0);
+  const int nchunks_all = (p.Cin + CK - 1) / CK;
+  const int cbeg = ks * p.cps, nchunks = min(nchunks_all, cbeg + p.cps);
+  load_chunk(cbeg * CK);
   store_chunk();
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = cbeg; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     if (more) load_chunk((c + 1) * CK);
 #pragma unroll
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
 
   // epilogue: C layout of a 32x32 tile: column (pixel) = lane % 32, row (channel) = (r / 4) * 8 + (lane / 32) * 4 + r % 4
   const int x = x0 + l32;
-  float* ob = p.out + (int64_t)n * p.Cout * p.H * p.W;
+  float* ob = p.part ? p.part + ((int64_t)ks * p.N + n) * p.Cout * p.H * p.W : p.out + (int64_t)n * p.Cout * p.H * p.W;
+  const bool add_bias = p.bias && !p.part;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -138,9 +142,18 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wco * 64 + i * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
-        if (co < p.Cout && y < p.H && x < p.W) ob[((int64_t)co * p.H + y) * p.W + x] = acc[i][j][r] + (p.bias ? p.bias[co] : 0.f);
+        if (co < p.Cout && y < p.H && x < p.W) ob[((int64_t)co * p.H + y) * p.W + x] = acc[i][j][r] + (add_bias ? p.bias[co] : 0.f);
       }
     }
+}
+
+__global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int KS,
+                                                           int64_t per_slice, int HW, int Cout, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_slice) return;
+  float v = bias ? bias[(i / HW) % Cout] : 0.f;
+  for (int k = 0; k < KS; ++k) v += part[k * per_slice + i];
+  out[i] = v;
 }
 
 // w [Cout, Cin, 3, 3]  ->  mode 0: wt[(ci*9 + t) * Cout + co] = w[co][ci][t]                (forward)
@@ -173,16 +186,44 @@ extern "C" int vts_w3x3_pack(const float* w, int Cout, int Cin, int mode, float*
   return VTS_OK;
 }
 
+static int wide_plan(int N, int Cin, int Cout, int H, int W, int* cps) {
+  const int wgs = cdiv(W, TX) * cdiv(H, TY) * cdiv(Cout, TCO) * N;
+  const int nchunks = cdiv(Cin, CK);
+  int KS = 1;
+  if (wgs < 256) {           // too few tiles for 256 CUs: split the input-channel loop
+    KS = 768 / wgs;
+    if (KS > nchunks / 4) KS = nchunks / 4;
+    if (KS < 1) KS = 1;
+  }
+  *cps = cdiv(nchunks, KS);
+  return cdiv(nchunks, *cps);
+}
+
+extern "C" int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W) {
+  int cps;
+  const int KS = wide_plan(N, Cin, Cout, H, W, &cps);
+  return KS > 1 ? (int64_t)KS * N * Cout * H * W : 0;
+}
+
 extern "C" int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
-                                void* stream) {
+                                float* ws, int64_t ws_floats, void* stream) {
   VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "vts_conv3x3_wide: bad args");
   VTS_CHECK_ARG((Cout & 3) == 0, "vts_conv3x3_wide: Cout %d must be a multiple of 4 (16-byte weight rows)", Cout);
-  VTS_CHECK_ARG((int64_t)Cin * (H + 2) * (W + 2) * 4 < (1ll << 31) && (int64_t)Cin * 9 * Cout * 4 < (1ll << 31) && N <= 65535,
+  VTS_CHECK_ARG((int64_t)Cin * (H + 2) * (W + 2) * 4 < (1ll << 31) && (int64_t)Cin * 9 * Cout * 4 < (1ll << 31) && N <= 1024,
                 "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
-  WideK k{in, wt, bias, out, N, Cin, Cout, H, W};
+  int cps;
+  int KS = wide_plan(N, Cin, Cout, H, W, &cps);
+  const int64_t per_slice = (int64_t)N * Cout * H * W;
+  if (KS > 1 && (!ws || ws_floats < KS * per_slice)) { KS = 1; cps = cdiv(Cin, CK); }
+  WideK k{in, wt, bias, out, N, Cin, Cout, H, W, KS, cps, KS > 1 ? ws : nullptr};
   const int tiles = cdiv(W, TX) * cdiv(H, TY);
-  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(tiles, cdiv(Cout, TCO), N), dim3(256), 0, (hipStream_t)stream, k);
-  vts_set_kernel("conv3x3_wide_kernel");
+  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(tiles, cdiv(Cout, TCO), N * KS), dim3(256), 0, (hipStream_t)stream, k);
+  vts_set_kernel(KS > 1 ? "conv3x3_wide_kernel+ksplit" : "conv3x3_wide_kernel");
   VTS_CHECK_LAUNCH("vts_conv3x3_wide");
+  if (KS > 1) {
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)cdiv64(per_slice, 256)), dim3(256), 0, (hipStream_t)stream, ws, bias, KS, per_slice,
+                       H * W, Cout, out);
+    VTS_CHECK_LAUNCH("vts_conv3x3_wide reduce");
+  }
   return VTS_OK;
 }

@@ -207,6 +207,27 @@ def _g_norm_bwd(buf, a, bn):
         ops.norm_bwd(buf, a, 1, gamma=bn.weight, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
 
 
+def _is_wide(conv):
+    """layers big enough for the GEMM-class 3x3 kernel (vts_conv3x3_wide) to pay: >= 64 x 64 channels"""
+    co, ci = conv.weight.shape[:2]
+    return co >= 64 and ci >= 64 and co % 4 == 0 and ci % 4 == 0 and conv.weight.shape[2] == 3
+
+
+def _conv_valid3(p, conv, out):
+    """valid 3x3 conv of a pre-padded identity tensor"""
+    if _is_wide(conv):
+        return ops.conv3x3_wide(p, ops.w3x3_pack(conv.weight, 0, "fwd"), conv.bias, out)
+    return ops.convk(p, conv.weight, out, bias=conv.bias, pad=0)
+
+
+def _conv_valid3_bwd_data(g, conv, dp):
+    """dp (padded size) <- adjoint of _conv_valid3 w.r.t. its input"""
+    if _is_wide(conv):
+        q = ops.pad_affine(g, (2, 2, 2, 2), 0)
+        return ops.conv3x3_wide(q, ops.w3x3_pack(conv.weight, 1, "bwd"), None, dp)
+    return ops.convk_bwd_data(g, conv.weight, dp, pad=0)
+
+
 def _conv3(x, conv, out, stride, act_in):
     if stride == 1:
         return ops.convk(x, conv.weight, out, bias=conv.bias, pad=1, act_in=act_in)
@@ -302,11 +323,11 @@ def resnet_forward(G, x, keep=True):
             xb = cur           # identity tensor
             p1 = ops.pad_affine(xb, (1, 1, 1, 1), 1)
             r1 = _empty(n, ca.weight.shape[0], xb.shape[2], xb.shape[3], dev)
-            ops.convk(p1, ca.weight, r1, bias=ca.bias, pad=0)
+            _conv_valid3(p1, ca, r1)
             a1 = _g_norm(G, r1, na)
             p2 = ops.pad_affine(a1, (1, 1, 1, 1), 1, act=RELU)
             r2 = _empty(n, cb.weight.shape[0], xb.shape[2], xb.shape[3], dev)
-            ops.convk(p2, cb.weight, r2, bias=cb.bias, pad=0)
+            _conv_valid3(p2, cb, r2)
             a2 = _g_norm(G, r2, nb)
             cur, pending = ops.pad_affine(a2, (0, 0, 0, 0), 0, res=xb), 0
             steps.append(("block", ca, cb, p1, a1, p2, a2, na, nb, blk_src))
@@ -401,13 +422,13 @@ def resnet_backward(G, ctx, d_raw):
             _g_norm_bwd(g2, a2, nb)
             ops.wgradk(g2, p2, cb.weight.grad, pad=0)
             dp2 = torch.empty_like(p2)
-            ops.convk_bwd_data(g2, cb.weight, dp2, pad=0)
+            _conv_valid3_bwd_data(g2, cb, dp2)
             da1 = torch.empty_like(a1.data)
             ops.pad_bwd(dp2, (1, 1, 1, 1), 1, da1)
             g1 = through_norm_relu(da1, a1, na)
             ops.wgradk(g1, p1, ca.weight.grad, pad=0)
             dp1 = torch.empty_like(p1)
-            ops.convk_bwd_data(g1, ca.weight, dp1, pad=0)
+            _conv_valid3_bwd_data(g1, ca, dp1)
             ops.pad_bwd(dp1, (1, 1, 1, 1), 1, dy, accumulate=True)   # + the skip path
             g = dy
             if blk_src is not None:    # the block input was materialised from relu(norm(r)) of a strided conv

@@ -224,8 +224,12 @@ def conv3x3_wide(p, wt, bias, out):
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d" % (n, ci, h, w, co, h, w)
-    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * h * w * co * ci * 9, L.load().vts_conv3x3_wide,
-         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, L.stream())
+    lib = L.load()
+    need = lib.vts_conv3x3_wide_ws_floats(n, ci, co, h, w)
+    ws = workspace(need, p.device) if need else None
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * h * w * co * ci * 9, lib.vts_conv3x3_wide,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, L.ptr(ws), ws.numel() if ws is not None else 0,
+         L.stream())
     return out
 
 
