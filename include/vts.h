@@ -208,6 +208,12 @@ int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float*
                      float* ws, int64_t ws_floats, void* stream);
 /* scratch for the k-split used when the tile grid alone cannot fill the GPU (0: not needed); deterministic reduction */
 int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
+/* Weight gradient of vts_conv3x3_wide:  dw[co][ci][ky][kx] (+)= sum_{n,y,x} dout[n,co,y,x] * in[n,ci,y+ky,x+kx]
+ * (dout [N,Cout,H,W], in pre-padded [N,Cin,H+2,W+2], dw [Cout,Cin,3,3]); GEMM-tiled over channels with the pixel
+ * dimension as K, deterministic slice reduction through `ws` (vts_wgrad3x3_wide_ws_floats floats). */
+int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
+int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int accumulate,
+                      float* ws, int64_t ws_floats, void* stream);
 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */

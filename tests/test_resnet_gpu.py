@@ -353,3 +353,24 @@ def test_conv3x3_wide_ksplit_small_map():
     out2 = torch.empty_like(out)
     ops.conv3x3_wide(p.to(dev), ops.w3x3_pack(wt.to(dev), 0, "f"), b.to(dev), out2)
     assert torch.equal(out, out2)          # deterministic
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 70, 132, 9, 37), (1, 256, 64, 8, 64), (3, 8, 4, 5, 5)])
+def test_wgrad3x3_wide(shape):
+    """GEMM-class weight gradient vs autograd; accumulate; run-to-run determinism"""
+    from vts import ops
+    n, ci, co, h, w = shape
+    dev = _dev()
+    p = detrand.uniform((n, ci, h + 2, w + 2), 23, "p")
+    wt = (detrand.uniform((co, ci, 3, 3), 23, "w") * 0.1).requires_grad_(True)
+    cot = detrand.uniform((n, co, h, w), 23, "cot")
+    (F.conv2d(p, wt) * cot).sum().backward()
+    dw = torch.full(wt.shape, float("nan"), device=dev)
+    ops.wgrad3x3_wide(cot.to(dev), p.to(dev), dw)
+    assert rel(dw, wt.grad) < 2e-5
+    dw2 = dw.clone()
+    ops.wgrad3x3_wide(cot.to(dev), p.to(dev), dw2, accumulate=True)
+    assert rel(dw2, 2 * wt.grad) < 2e-5
+    dw3 = torch.empty_like(dw)
+    ops.wgrad3x3_wide(cot.to(dev), p.to(dev), dw3)
+    assert torch.equal(dw, dw3)

@@ -66,9 +66,9 @@ def wide_case(N, C, H, W):
     us = timeit(lambda: ops.conv3x3_wide(p, wt, None, out), reps=5)
     fl = 2.0 * N * H * W * C * C * 9
     print("wide3x3 N%d %dx%dx%d : %8.1f us  %6.2f TF (%.1f%% of 157.3)" % (N, C, H, W, us, fl / us / 1e6, fl / us / 1e6 / 1.573))
-    out2 = torch.empty(N, C, H, W, device=dev)
-    us = timeit(lambda: ops.convk(p[:, :, 1:-1, 1:-1].contiguous(), w, out2, pad=1), reps=2)
-    print("   (4x4-block path, zero pad) : %8.1f us  %6.2f TF" % (us, fl / us / 1e6))
+    dw = torch.empty_like(w)
+    us = timeit(lambda: ops.wgrad3x3_wide(out, p, dw), reps=5)
+    print("wgrad3x3_wide N%d %dx%dx%d : %8.1f us  %6.2f TF (%.1f%% of 157.3)" % (N, C, H, W, us, fl / us / 1e6, fl / us / 1e6 / 1.573))
 
 
 if __name__ == "__main__":

@@ -227,3 +227,193 @@ extern "C" int vts_conv3x3_wide(const float* in, const float* wt, const float* b
   }
   return VTS_OK;
 }
+
+// =====================================================================================================
+// Weight gradient of the same operator:
+//   dw[co][ci][ky][kx] (+)= sum_{n,y,x} dout[n,co,y,x] * in[n,ci,y+ky,x+kx]          (in pre-padded)
+// GEMM view: M = output channels, N = input channels (x 9 taps, one accumulator tile per tap), K = pixels.
+// A workgroup owns 64 co x 64 ci x 9 taps (a wave 32 x 32 x 9 = 144 accumulator registers) and walks 2 x 32
+// pixel tiles of its K slice; both operands vary their LANE index over channels, so their LDS planes have an
+// odd pitch (conflict-free fragment reads) and are written with 4-byte stores.  Partial sums of the K slices
+// are reduced in slice order by wg_wide_reduce_kernel (deterministic, no float atomics).
+// =====================================================================================================
+namespace {
+
+constexpr int GCO = 64, GCI = 64, GTY = 2, GTX = 32;
+constexpr int GPX = GTY * GTX;                      // 64 pixels per tile
+constexpr int DO_PITCH = GPX + 1;                   // dout plane [co][px], odd pitch
+constexpr int GPR = GTY + 2, GPC = 36;              // patch rows, staged columns (9 quads)
+constexpr int P_PITCH = GPR * GPC + 1;              // in plane [ci][r][c], odd pitch (145)
+constexpr int GDO_FLOATS = GCO * DO_PITCH, GP_FLOATS = GCI * P_PITCH;
+constexpr int NDQ = GCO * GPX / 4 / 256;            // 4 dout quads per thread
+constexpr int NIQ = GCI * GPR * (GPC / 4) / 256;    // 9 patch quads per thread
+
+struct WgWideK {
+  const float *dout, *in;
+  float* part;     // [KS][Cout][Cin][9]
+  int N, Cin, Cout, H, W;
+  int tiles_x, tiles_per_img, ntiles, tps;   // pixel tiles; tps = tiles per K slice
+};
+
+__global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
+  __shared__ float lds[GDO_FLOATS + GP_FLOATS];
+  float* lds_d = lds;
+  float* lds_i = lds + GDO_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave & 1, wci = wave >> 1;
+  const int co0 = blockIdx.x * GCO, ci0 = blockIdx.y * GCI, ks = blockIdx.z;
+  const int PW = p.W + 2, plane = (p.H + 2) * PW, oplane = p.H * p.W;
+
+  // staging items: dout quads (co, row, xquad) and patch quads (ci, r, cquad); tile offsets are added per tile
+  int dvoff[NDQ], dloff[NDQ];
+#pragma unroll
+  for (int e = 0; e < NDQ; ++e) {
+    const int q = tid + e * 256;
+    const int co = q / (GPX / 4), r4 = q - co * (GPX / 4);
+    const int row = r4 / (GTX / 4), xq = r4 - row * (GTX / 4);
+    dvoff[e] = ((co0 + co) * oplane + row * p.W + 4 * xq) * 4;
+    dloff[e] = co * DO_PITCH + row * GTX + 4 * xq;
+  }
+  int ivoff[NIQ], iloff[NIQ];
+#pragma unroll
+  for (int e = 0; e < NIQ; ++e) {
+    const int q = tid + e * 256;
+    const int ci = q / (GPR * (GPC / 4)), r9 = q - ci * (GPR * (GPC / 4));
+    const int r = r9 / (GPC / 4), cq = r9 - r * (GPC / 4);
+    ivoff[e] = ((ci0 + ci) * plane + r * PW + 4 * cq) * 4;
+    iloff[e] = ci * P_PITCH + r * GPC + 4 * cq;
+  }
+
+  u32x4 dq[NDQ], iq[NIQ];
+  int cur_x0 = 0, cur_y0 = 0;   // origin of the tile held in the prefetch registers
+  auto load_tile = [&](int t) {
+    const int n = t / p.tiles_per_img, r = t - n * p.tiles_per_img;
+    const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
+    cur_x0 = tx * GTX;
+    cur_y0 = ty * GTY;
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dout) + (int64_t)n * p.Cout * oplane, 0, p.Cout * oplane * 4, RSRC_FLAGS);
+    const auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
+    const int doff = (cur_y0 * p.W + cur_x0) * 4, ioff = (cur_y0 * PW + cur_x0) * 4;
+#pragma unroll
+    for (int e = 0; e < NDQ; ++e) dq[e] = __builtin_amdgcn_raw_buffer_load_b128(rd, dvoff[e] + doff, 0, 0);
+#pragma unroll
+    for (int e = 0; e < NIQ; ++e) iq[e] = __builtin_amdgcn_raw_buffer_load_b128(ri, ivoff[e] + ioff, 0, 0);
+  };
+  // dout pixels outside the image must contribute 0 (the patch side may hold anything there); channels past
+  // Cout / Cin read 0 through the bounds check except where the next image / channel follows: mask by index.
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int e = 0; e < NDQ; ++e) {
+      const int q = tid + e * 256;
+      const int co = q / (GPX / 4), r4 = q - co * (GPX / 4);
+      const int row = r4 / (GTX / 4), xq = r4 - row * (GTX / 4);
+      const bool rok = co0 + co < p.Cout && cur_y0 + row < p.H;
+      const f32x4 v = __builtin_bit_cast(f32x4, dq[e]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds_d[dloff[e] + j] = (rok && cur_x0 + 4 * xq + j < p.W) ? v[j] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NIQ; ++e) {
+      const int q = tid + e * 256;
+      const int ci = q / (GPR * (GPC / 4));
+      const bool cok = ci0 + ci < p.Cin;
+      const f32x4 v = __builtin_bit_cast(f32x4, iq[e]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds_i[iloff[e] + j] = cok ? v[j] : 0.f;
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* a_base = lds_d + (wco * 32 + l32) * DO_PITCH + kh;            // A[i = co][k = pixel]
+  const float* b_base = lds_i + (wci * 32 + l32) * P_PITCH + kh;             // B[k = pixel][j = ci]
+
+  const int t_beg = ks * p.tps, t_end = min(p.ntiles, t_beg + p.tps);
+  if (t_beg < t_end) {
+    load_tile(t_beg);
+    store_tile();
+  }
+  __syncthreads();
+  for (int t = t_beg; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
+    if (more) load_tile(t + 1);
+#pragma unroll
+    for (int row = 0; row < GTY; ++row)
+#pragma unroll 4
+      for (int xs = 0; xs < GTX / 2; ++xs) {
+        const float a = a_base[row * GTX + xs * 2];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const float b = b_base[(row + ky) * GPC + xs * 2 + kx];
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+    if (more) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // C layout: column (ci) = lane % 32, row (co) = (r / 4) * 8 + (lane / 32) * 4 + r % 4
+  float* ob = p.part + (int64_t)ks * p.Cout * p.Cin * 9;
+  const int ci = ci0 + wci * 32 + l32;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+      if (co < p.Cout && ci < p.Cin) ob[((int64_t)co * p.Cin + ci) * 9 + tap] = acc[tap][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void wg_wide_reduce_kernel(const float* __restrict__ part, int KS, int64_t n, float* __restrict__ dw, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = accumulate ? dw[i] : 0.f;
+  for (int k = 0; k < KS; ++k) v += part[k * n + i];
+  dw[i] = v;
+}
+
+int wg_wide_plan(int N, int Cin, int Cout, int H, int W, int* tps) {
+  const int ntiles = N * cdiv(H, GTY) * cdiv(W, GTX);
+  const int groups = cdiv(Cout, GCO) * cdiv(Cin, GCI);
+  int KS = 512 / groups;                      // aim at two workgroups per CU
+  if (KS > ntiles / 4) KS = ntiles / 4;
+  if (KS < 1) KS = 1;
+  *tps = cdiv(ntiles, KS);
+  return cdiv(ntiles, *tps);
+}
+
+}  // namespace
+
+extern "C" int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W) {
+  int tps;
+  return (int64_t)wg_wide_plan(N, Cin, Cout, H, W, &tps) * Cout * Cin * 9;
+}
+
+extern "C" int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int accumulate,
+                                 float* ws, int64_t ws_floats, void* stream) {
+  VTS_CHECK_ARG(dout && in && dw && ws && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "vts_wgrad3x3_wide: bad args");
+  VTS_CHECK_ARG((int64_t)Cin * (H + 2) * (W + 2) * 4 < (1ll << 31) && (int64_t)Cout * H * W * 4 < (1ll << 31), "vts_wgrad3x3_wide: operand exceeds the 2 GiB buffer range");
+  WgWideK k;
+  k.dout = dout; k.in = in; k.part = ws; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
+  k.tiles_x = cdiv(W, GTX);
+  k.tiles_per_img = k.tiles_x * cdiv(H, GTY);
+  k.ntiles = N * k.tiles_per_img;
+  const int KS = wg_wide_plan(N, Cin, Cout, H, W, &k.tps);
+  const int64_t nel = (int64_t)Cout * Cin * 9;
+  VTS_CHECK_ARG(ws_floats >= KS * nel, "vts_wgrad3x3_wide: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)(KS * nel));
+  hipLaunchKernelGGL(wgrad3x3_wide_kernel, dim3(cdiv(Cout, GCO), cdiv(Cin, GCI), KS), dim3(256), 0, (hipStream_t)stream, k);
+  vts_set_kernel("wgrad3x3_wide_kernel");
+  VTS_CHECK_LAUNCH("vts_wgrad3x3_wide");
+  hipLaunchKernelGGL(wg_wide_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, (hipStream_t)stream, ws, KS, nel, dw, accumulate);
+  VTS_CHECK_LAUNCH("vts_wgrad3x3_wide reduce");
+  return VTS_OK;
+}

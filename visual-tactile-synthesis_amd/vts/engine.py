@@ -228,6 +228,13 @@ def _conv_valid3_bwd_data(g, conv, dp):
     return ops.convk_bwd_data(g, conv.weight, dp, pad=0)
 
 
+def _wgrad_valid3(g, p, conv):
+    """conv.weight.grad <- weight gradient of _conv_valid3"""
+    if _is_wide(conv):
+        return ops.wgrad3x3_wide(g, p, conv.weight.grad)
+    return ops.wgradk(g, p, conv.weight.grad, pad=0)
+
+
 def _conv3(x, conv, out, stride, act_in):
     if stride == 1:
         return ops.convk(x, conv.weight, out, bias=conv.bias, pad=1, act_in=act_in)
@@ -420,13 +427,13 @@ def resnet_backward(G, ctx, d_raw):
             dy = g
             g2 = dy.clone()
             _g_norm_bwd(g2, a2, nb)
-            ops.wgradk(g2, p2, cb.weight.grad, pad=0)
+            _wgrad_valid3(g2, p2, cb)
             dp2 = torch.empty_like(p2)
             _conv_valid3_bwd_data(g2, cb, dp2)
             da1 = torch.empty_like(a1.data)
             ops.pad_bwd(dp2, (1, 1, 1, 1), 1, da1)
             g1 = through_norm_relu(da1, a1, na)
-            ops.wgradk(g1, p1, ca.weight.grad, pad=0)
+            _wgrad_valid3(g1, p1, ca)
             dp1 = torch.empty_like(p1)
             _conv_valid3_bwd_data(g1, ca, dp1)
             ops.pad_bwd(dp1, (1, 1, 1, 1), 1, dy, accumulate=True)   # + the skip path

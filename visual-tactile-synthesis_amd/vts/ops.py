@@ -45,7 +45,7 @@ def _run(label, nbytes, flops, fn, *args):
     rc = fn(*args)
     e1.record()
     L.check(rc, label)
-    if label.startswith(("conv4x4", "wgrad4x4", "norm_", "conv3x3_wide")):
+    if label.startswith(("conv4x4", "wgrad4x4", "norm_", "conv3x3_wide", "wgrad3x3_wide")):
         label = L.load().vts_last_kernel().decode()   # the exact kernel instance, as rocprofv3 names it
     TIMER.append((label, nbytes, flops, e0, e1, DETAIL))
     DETAIL = None
@@ -231,6 +231,21 @@ def conv3x3_wide(p, wt, bias, out):
          p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, L.ptr(ws), ws.numel() if ws is not None else 0,
          L.stream())
     return out
+
+
+def wgrad3x3_wide(dout, p, dw, accumulate=False):
+    """dw [Co,Ci,3,3] (+)= weight gradient of conv3x3_wide for dout [N,Co,H,W] and the pre-padded input p [N,Ci,H+2,W+2]"""
+    n, co, h, w = dout.shape
+    ci = p.shape[1]
+    assert p.shape == (n, ci, h + 2, w + 2) and dw.shape == (co, ci, 3, 3) and dout.is_contiguous() and p.is_contiguous()
+    lib = L.load()
+    ws = workspace(lib.vts_wgrad3x3_wide_ws_floats(n, ci, co, h, w), p.device)
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d dout %dx%dx%d in %dx%dx%d" % (n, co, h, w, ci, h + 2, w + 2)
+    _run("wgrad3x3_wide", 4.0 * (dout.numel() + p.numel() + dw.numel()), 2.0 * n * h * w * co * ci * 9, lib.vts_wgrad3x3_wide,
+         dout.data_ptr(), p.data_ptr(), dw.data_ptr(), n, ci, co, h, w, int(accumulate), ws.data_ptr(), ws.numel(), L.stream())
+    return dw
 
 
 def pad_affine(x, pads, mode, out=None, act=0, res=None, out_nstride=0):
