@@ -195,25 +195,35 @@ int vts_blur_up_bwd(const float* dout, int N, int C, int H, int W, float* din, i
 int vts_tap_embed(const float* w, int64_t rows, int K, int a, int b, float* w4, void* stream);
 int vts_tap_extract(const float* dw4, int64_t rows, int K, int a, int b, float* dw, int accumulate, void* stream);
 
-/* GEMM-class 3x3 stride-1 convolution for wide layers (pix2pixHD GlobalGenerator's ResnetBlocks at up to 1024
- * channels, models/networks.py:1952-1980, :1267-1324) over a PRE-PADDED input:
- *   out[n,co,y,x] = bias[co] + sum_{ci,ky,kx} in[n,ci,y+ky,x+kx] * wt[(ci*9 + ky*3+kx)*Cout + co]
- * in [N,Cin,H+2,W+2] (vts_pad_affine output), out [N,Cout,H,W], wt from vts_w3x3_pack:
- *   mode 0: wt[(ci*9+t)*Cout + co] = w[co][ci][t]         (forward of nn.Conv2d weight [Cout,Cin,3,3])
- *   mode 1: wt[(co*9+t)*Cin  + ci] = w[co][ci][8-t]       (adjoint w.r.t. the input: call with Cin<->Cout on the
- *                                                          output gradient zero-padded by 2)
- * Cout must be a multiple of 4. */
-int vts_w3x3_pack(const float* w, int Cout, int Cin, int mode, float* wt, void* stream);
+/* ---- GEMM-class 3x3 kernels for wide layers (pix2pixHD GlobalGenerator, models/networks.py:1952-1980: stride-2
+ * 3x3 downsampling convs, ResnetBlocks :1267-1324 at up to 1024 channels, ConvTranspose2d(3, s2, p1, op1) upsampling).
+ * All of them read PRE-PADDED identity inputs (vts_pad_affine) and tap-major packed weights:
+ *
+ *   vts_w3x3_pack:  wt[(a*9 + t)*B + b] = w[a*sa + b*sb + (flip ? 8-t : t)],  a < A = operator input channels,
+ *                   b < B = operator output channels (B % 4 == 0), element strides sa / sb into the parameter tensor.
+ *       nn.Conv2d weight [Co,Ci,3,3]:           forward A=Ci,B=Co,sa=9,sb=9Ci;   input adjoint (s1) A=Co,B=Ci,sa=9Ci,sb=9,flip;
+ *                                               input adjoint of the stride-2 conv (a transposed conv): A=Co,B=Ci,sa=9Ci,sb=9
+ *       nn.ConvTranspose2d weight [Ci,Co,3,3]:  forward A=Ci,B=Co,sa=9Co,sb=9;   input adjoint (a stride-2 conv) A=Co,B=Ci,sa=9,sb=9Co
+ *
+ *   vts_conv3x3_wide     out[n,co,y,x]   = bias + sum in[n,ci,y+ky,x+kx]   * wt[..]   in [N,Cin,H+2,W+2]   -> out [N,Cout,H,W]
+ *   vts_conv3x3s2_wide   out[n,co,y,x]   = bias + sum in[n,ci,2y+ky,2x+kx] * wt[..]   in [N,Cin,2OH+2,2OW+2] (zero pad 1) -> [N,Cout,OH,OW]
+ *   vts_tconv3x3s2_wide  out[n,co,y,x]   = bias + sum_{i: k=y+1-2i in 0..2} in[n,ci,i,j] * wt[..]   in [N,Cin,IH+1,IW+1] (zero row /
+ *                        column appended) -> out [N,Cout,2IH,2IW]; one launch per output parity phase
+ *   vts_wgrad3x3_wide    dw[co][ci][ky][kx] (+)= sum_{n,y,x} dout[n,co,y,x] * in[n,ci,stride*y+ky,stride*x+kx]
+ *                        (dout [N,Cout,H,W], in [N,Cin,stride*H+2,stride*W+2]; for a ConvTranspose2d weight pass the layer input
+ *                        as `dout` and the padded output gradient as `in`); deterministic slice reduction through `ws`.
+ * Grids too small to fill the GPU split the channel loop of vts_conv3x3_wide (scratch: vts_conv3x3_wide_ws_floats). */
+int vts_w3x3_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream);
 int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
                      float* ws, int64_t ws_floats, void* stream);
-/* scratch for the k-split used when the tile grid alone cannot fill the GPU (0: not needed); deterministic reduction */
 int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
-/* Weight gradient of vts_conv3x3_wide:  dw[co][ci][ky][kx] (+)= sum_{n,y,x} dout[n,co,y,x] * in[n,ci,y+ky,x+kx]
- * (dout [N,Cout,H,W], in pre-padded [N,Cin,H+2,W+2], dw [Cout,Cin,3,3]); GEMM-tiled over channels with the pixel
- * dimension as K, deterministic slice reduction through `ws` (vts_wgrad3x3_wide_ws_floats floats). */
-int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
-int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int accumulate,
-                      float* ws, int64_t ws_floats, void* stream);
+int vts_conv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int OH, int OW,
+                       void* stream);
+int vts_tconv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int IH, int IW,
+                        void* stream);
+int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int stride);
+int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int stride,
+                      int accumulate, float* ws, int64_t ws_floats, void* stream);
 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */

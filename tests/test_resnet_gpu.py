@@ -330,12 +330,12 @@ def test_conv3x3_wide_forward_and_input_adjoint(shape):
     (ref * cot).sum().backward()
     out = torch.full(ref.shape, float("nan"), device=dev)
     wd = wt.detach().to(dev)
-    ops.conv3x3_wide(p.detach().to(dev), ops.w3x3_pack(wd, 0, "f"), b.to(dev), out)
+    ops.conv3x3_wide(p.detach().to(dev), ops.w3x3_pack(wd, "conv_fwd"), b.to(dev), out)
     assert rel(out, ref) < 1e-5
     if ci % 4 == 0:
         q = ops.pad_affine(cot.to(dev), (2, 2, 2, 2), 0)
         dp = torch.full(p.shape, float("nan"), device=dev)
-        ops.conv3x3_wide(q, ops.w3x3_pack(wd, 1, "b"), None, dp)
+        ops.conv3x3_wide(q, ops.w3x3_pack(wd, "conv_adj"), None, dp)
         assert rel(dp, p.grad) < 1e-5
 
 
@@ -348,10 +348,10 @@ def test_conv3x3_wide_ksplit_small_map():
     wt = detrand.uniform((co, ci, 3, 3), 22, "w") * float(np.sqrt(3.0 / (9 * ci)))
     b = detrand.uniform((co,), 22, "b")
     out = torch.full((n, co, h, w), float("nan"), device=dev)
-    ops.conv3x3_wide(p.to(dev), ops.w3x3_pack(wt.to(dev), 0, "f"), b.to(dev), out)
+    ops.conv3x3_wide(p.to(dev), ops.w3x3_pack(wt.to(dev), "conv_fwd"), b.to(dev), out)
     assert rel(out, F.conv2d(p, wt, b)) < 1e-5
     out2 = torch.empty_like(out)
-    ops.conv3x3_wide(p.to(dev), ops.w3x3_pack(wt.to(dev), 0, "f"), b.to(dev), out2)
+    ops.conv3x3_wide(p.to(dev), ops.w3x3_pack(wt.to(dev), "conv_fwd"), b.to(dev), out2)
     assert torch.equal(out, out2)          # deterministic
 
 
@@ -374,3 +374,48 @@ def test_wgrad3x3_wide(shape):
     dw3 = torch.empty_like(dw)
     ops.wgrad3x3_wide(cot.to(dev), p.to(dev), dw3)
     assert torch.equal(dw, dw3)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 68, 72, 6, 20), (1, 128, 64, 10, 48)])
+def test_wide_strided_and_transposed_family(shape):
+    """stride-2 3x3 conv and ConvTranspose2d(3, s2, p1, op1) on the GEMM-class kernels: forward, input adjoint
+    (each is the other's adjoint) and weight gradient vs autograd; n, ci, co, oh, ow = low-resolution side"""
+    from vts import ops
+    n, ci, co, oh, ow = shape
+    dev = _dev()
+    # --- stride-2 conv: x [n,ci,2oh,2ow] -> y [n,co,oh,ow]
+    x = detrand.uniform((n, ci, 2 * oh, 2 * ow), 31, "x").requires_grad_(True)
+    w = (detrand.uniform((co, ci, 3, 3), 31, "w") * float(np.sqrt(3.0 / (9 * ci)))).requires_grad_(True)
+    b = detrand.uniform((co,), 31, "b")
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    cot = detrand.uniform(tuple(ref.shape), 31, "cot")
+    (ref * cot).sum().backward()
+    xd, wd, cd = x.detach().to(dev), w.detach().to(dev), cot.to(dev)
+    xp = ops.pad_affine(xd, (1, 1, 1, 1), 0)
+    out = torch.full(ref.shape, float("nan"), device=dev)
+    ops.conv3x3s2_wide(xp, ops.w3x3_pack(wd, "conv_fwd"), b.to(dev), out)
+    assert rel(out, ref) < 1e-5
+    dx = torch.full(x.shape, float("nan"), device=dev)
+    ops.tconv3x3s2_wide(ops.pad_affine(cd, (0, 1, 0, 1), 0), ops.w3x3_pack(wd, "conv_s2_adj"), None, dx)
+    assert rel(dx, x.grad) < 1e-5
+    dw = torch.full(w.shape, float("nan"), device=dev)
+    ops.wgrad3x3_wide(cd, xp, dw, stride=2)
+    assert rel(dw, w.grad) < 2e-5
+    # --- transposed conv: z [n,co,oh,ow] -> u [n,ci,2oh,2ow], weight [co, ci, 3, 3] (ConvTranspose2d layout [in, out])
+    z = detrand.uniform((n, co, oh, ow), 32, "z").requires_grad_(True)
+    wt = (detrand.uniform((co, ci, 3, 3), 32, "wt") * float(np.sqrt(3.0 / (4 * co)))).requires_grad_(True)
+    bt = detrand.uniform((ci,), 32, "bt")
+    reft = F.conv_transpose2d(z, wt, bt, stride=2, padding=1, output_padding=1)
+    cott = detrand.uniform(tuple(reft.shape), 32, "cott")
+    (reft * cott).sum().backward()
+    zd, wtd, ctd = z.detach().to(dev), wt.detach().to(dev), cott.to(dev)
+    u = torch.full(reft.shape, float("nan"), device=dev)
+    ops.tconv3x3s2_wide(ops.pad_affine(zd, (0, 1, 0, 1), 0), ops.w3x3_pack(wtd, "convT_fwd"), bt.to(dev), u)
+    assert rel(u, reft) < 1e-5
+    ctp = ops.pad_affine(ctd, (1, 1, 1, 1), 0)
+    dz = torch.full(z.shape, float("nan"), device=dev)
+    ops.conv3x3s2_wide(ctp, ops.w3x3_pack(wtd, "convT_adj"), None, dz)
+    assert rel(dz, z.grad) < 1e-5
+    dwt = torch.full(wt.shape, float("nan"), device=dev)
+    ops.wgrad3x3_wide(zd, ctp, dwt, stride=2)
+    assert rel(dwt, wt.grad) < 2e-5

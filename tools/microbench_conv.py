@@ -62,7 +62,7 @@ def wide_case(N, C, H, W):
     p = torch.randn(N, C, H + 2, W + 2, device=dev)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.01
     out = torch.empty(N, C, H, W, device=dev)
-    wt = ops.w3x3_pack(w, 0, "mb")
+    wt = ops.w3x3_pack(w, "conv_fwd")
     us = timeit(lambda: ops.conv3x3_wide(p, wt, None, out), reps=5)
     fl = 2.0 * N * H * W * C * C * 9
     print("wide3x3 N%d %dx%dx%d : %8.1f us  %6.2f TF (%.1f%% of 157.3)" % (N, C, H, W, us, fl / us / 1e6, fl / us / 1e6 / 1.573))

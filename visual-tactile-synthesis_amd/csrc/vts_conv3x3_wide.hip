@@ -23,23 +23,34 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TCO = 128, TY = 4, TX = 32, CK = 8;
-constexpr int PR = TY + 2, PC = TX + 2, PCP = 36;
-constexpr int PATCH_FLOATS = CK * PR * PCP;           // 1728
-constexpr int W_FLOATS = CK * 9 * TCO;                // 9216
-constexpr int PQ_ROW = PCP / 4;                       // 9 quads per patch row
-constexpr int NPQ = (CK * PR * PQ_ROW + 255) / 256;   // 2 patch quads per thread
-constexpr int NWQ = W_FLOATS / 4 / 256;               // 9 weight quads per thread
 constexpr unsigned RSRC_FLAGS = 0x00020000;
 
+// One kernel serves the three 3x3 operators of the wide layers through a tap table:
+//   out[n, co, oy0 + os*y, ox0 + os*x] = bias[co] + sum_t sum_ci in[n, ci, S*y + dy_t, S*x + dx_t] * wt[(ci*9 + w_t)*Cout + co]
+//   stride-1 conv        S = 1, os = 1, 9 taps (dy, dx) = (ky, kx)        input padded by 1 (any padding mode)
+//   stride-2 conv        S = 2, os = 1, 9 taps                            input zero-padded by 1
+//   ConvTranspose s2     S = 1, os = 2, one launch per output parity phase with its 1 / 2 / 2 / 4 taps, input
+//                        zero-padded by 1 at the bottom / right (also the input adjoint of the stride-2 conv)
 struct WideK {
   const float *in, *wt, *bias;
   float* out;
-  int N, Cin, Cout, H, W;
+  int N, Cin, Cout, H, W;        // H x W: the (phase) grid of output pixels this launch computes
+  int IPH, IPW;                  // padded input extent
+  int OH, OW, os, oy0, ox0;      // full output extent, output stride and phase offset
+  int ntaps;
+  signed char dy[9], dx[9], wt_tap[9];
   int KS, cps;   // k-split for small grids: blockIdx.z = n + N * slice, cps input-channel chunks per slice
-  float* part;   // [KS][N][Cout][H][W] raw partial sums (KS > 1), reduced in slice order by wide_reduce_kernel
+  float* part;   // [KS][N][Cout][OH][OW] raw partial sums (KS > 1), reduced in slice order by wide_reduce_kernel
 };
 
+template <int S>
 __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
+  constexpr int PR = S * (TY - 1) + 3, PC = S * (TX - 1) + 3, PCP = (PC + 3) / 4 * 4;
+  constexpr int PATCH_FLOATS = CK * PR * PCP;
+  constexpr int W_FLOATS = CK * 9 * TCO;
+  constexpr int PQ_ROW = PCP / 4;
+  constexpr int NPQ = (CK * PR * PQ_ROW + 255) / 256;
+  constexpr int NWQ = W_FLOATS / 4 / 256;               // 9 weight quads per thread (fewer taps: fewer are live)
   __shared__ __attribute__((aligned(16))) float lds[PATCH_FLOATS + W_FLOATS];
   float* lds_p = lds;
   float* lds_w = lds + PATCH_FLOATS;
@@ -49,32 +60,34 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
   const int tiles_x = (p.W + TX - 1) / TX;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int x0 = tx * TX, y0 = ty * TY, co0 = blockIdx.y * TCO, n = blockIdx.z % p.N, ks = blockIdx.z / p.N;
-  const int PH = p.H + 2, PW = p.W + 2;
-  const int plane = PH * PW;
+  const int PW = p.IPW, plane = p.IPH * p.IPW;
+  const int ntaps = p.ntaps;
 
   const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * 9 * p.Cout * 4, RSRC_FLAGS);
 
-  // staging items of this thread (chunk independent): patch quads (ci, row, quad), weight quads (ci*9+tap, co quad)
+  // staging items of this thread (chunk independent): patch quads (ci, row, quad), weight quads ((ci, t), co quad)
   int pvoff[NPQ], ploff[NPQ];
 #pragma unroll
   for (int e = 0; e < NPQ; ++e) {
     const int q = min(tid + e * 256, CK * PR * PQ_ROW - 1);
     const int row = q / PQ_ROW, cq = q - row * PQ_ROW;      // row = ci * PR + r
     const int ci = row / PR, r = row - ci * PR;
-    pvoff[e] = (ci * plane + (y0 + r) * PW + x0 + 4 * cq) * 4;
+    pvoff[e] = (ci * plane + (S * y0 + r) * PW + S * x0 + 4 * cq) * 4;
     ploff[e] = row * PCP + 4 * cq;
   }
   int wvoff[NWQ], wloff[NWQ];
 #pragma unroll
   for (int e = 0; e < NWQ; ++e) {
     const int q = tid + e * 256;
-    const int row = q >> 5, cq = q & 31;                    // row = ci * 9 + tap
-    wvoff[e] = (row * p.Cout + co0 + 4 * cq) * 4;
-    wloff[e] = row * TCO + 4 * cq;
+    const int row = q >> 5, cq = q & 31;                    // row = ci * ntaps + t
+    const int ci = row / ntaps, t = row - ci * ntaps;
+    const bool live = row < CK * ntaps;
+    wvoff[e] = live ? ((ci * 9 + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;   // dead rows: out of range -> 0
+    wloff[e] = (live ? row : 0) * TCO + 4 * cq;
   }
-  // rows past the image (bottom tiles) lie beyond the descriptor only for the last channel: clamp by masking the
-  // store instead -- values computed from them are never written.  Channels past Cin read 0 (bounds check).
+  // Pixels past the grid and channels past Cout only ever feed outputs that are never stored; channels past Cin read
+  // 0 through the bounds check.
 
   u32x4 pq[NPQ], wq[NWQ];
   auto load_chunk = [&](int c0) {
@@ -82,13 +95,15 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
 #pragma unroll
     for (int e = 0; e < NPQ; ++e) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pvoff[e] + pbase, 0, 0);
 #pragma unroll
-    for (int e = 0; e < NWQ; ++e) wq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[e] + wbase, 0, 0);
+    for (int e = 0; e < NWQ; ++e)
+      if (e * 8 < CK * ntaps) wq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[e] + wbase, 0, 0);   // uniform
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int e = 0; e < NPQ; ++e) *reinterpret_cast<u32x4*>(lds_p + ploff[e]) = pq[e];
 #pragma unroll
-    for (int e = 0; e < NWQ; ++e) *reinterpret_cast<u32x4*>(lds_w + wloff[e]) = wq[e];
+    for (int e = 0; e < NWQ; ++e)
+      if (e * 8 < CK * ntaps && ((tid + e * 256) >> 5) < CK * ntaps) *reinterpret_cast<u32x4*>(lds_w + wloff[e]) = wq[e];
   };
 
   f32x16 acc[2][2];
@@ -99,8 +114,8 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float* a_base = lds_w + kh * 9 * TCO + wco * 64 + l32;
-  const float* b_base = lds_p + kh * PR * PCP + (wpx * 2) * PCP + l32;
+  const float* a_base = lds_w + kh * ntaps * TCO + wco * 64 + l32;
+  const float* b_base = lds_p + kh * PR * PCP + (S * wpx * 2) * PCP + S * l32;
 
   const int nchunks_all = (p.Cin + CK - 1) / CK;
   const int cbeg = ks * p.cps, nchunks = min(nchunks_all, cbeg + p.cps);
@@ -110,13 +125,12 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
   for (int c = cbeg; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     if (more) load_chunk((c + 1) * CK);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
+    for (int t = 0; t < ntaps; ++t) {
+      const int boff = p.dy[t] * PCP + p.dx[t];
 #pragma unroll
       for (int kc = 0; kc < CK / 2; ++kc) {
-        const float a0 = a_base[(kc * 2 * 9 + tap) * TCO], a1 = a_base[(kc * 2 * 9 + tap) * TCO + 32];
-        const float b0 = b_base[kc * 2 * PR * PCP + ky * PCP + kx], b1 = b_base[kc * 2 * PR * PCP + (ky + 1) * PCP + kx];
+        const float a0 = a_base[(kc * 2 * ntaps + t) * TCO], a1 = a_base[(kc * 2 * ntaps + t) * TCO + 32];
+        const float b0 = b_base[kc * 2 * PR * PCP + boff], b1 = b_base[kc * 2 * PR * PCP + S * PCP + boff];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -132,7 +146,8 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
 
   // epilogue: C layout of a 32x32 tile: column (pixel) = lane % 32, row (channel) = (r / 4) * 8 + (lane / 32) * 4 + r % 4
   const int x = x0 + l32;
-  float* ob = p.part ? p.part + ((int64_t)ks * p.N + n) * p.Cout * p.H * p.W : p.out + (int64_t)n * p.Cout * p.H * p.W;
+  const int64_t oplane = (int64_t)p.OH * p.OW;
+  float* ob = p.part ? p.part + ((int64_t)ks * p.N + n) * p.Cout * oplane : p.out + (int64_t)n * p.Cout * oplane;
   const bool add_bias = p.bias && !p.part;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -142,7 +157,8 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wco * 64 + i * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
-        if (co < p.Cout && y < p.H && x < p.W) ob[((int64_t)co * p.H + y) * p.W + x] = acc[i][j][r] + (add_bias ? p.bias[co] : 0.f);
+        if (co < p.Cout && y < p.H && x < p.W)
+          ob[co * oplane + (int64_t)(p.oy0 + p.os * y) * p.OW + p.ox0 + p.os * x] = acc[i][j][r] + (add_bias ? p.bias[co] : 0.f);
       }
     }
 }
@@ -156,32 +172,23 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
   out[i] = v;
 }
 
-// w [Cout, Cin, 3, 3]  ->  mode 0: wt[(ci*9 + t) * Cout + co] = w[co][ci][t]                (forward)
-//                          mode 1: wt[(co*9 + t) * Cin  + ci] = w[co][ci][8 - t]            (adjoint w.r.t. the input)
-__global__ __launch_bounds__(256) void w3x3_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int mode, float* __restrict__ wt) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)Cout * Cin * 9;
-  if (i >= total) return;
-  // i indexes the OUTPUT so that writes are coalesced
-  if (mode == 0) {
-    const int co = (int)(i % Cout);
-    const int64_t r = i / Cout;
-    const int t = (int)(r % 9), ci = (int)(r / 9);
-    wt[i] = w[((int64_t)co * Cin + ci) * 9 + t];
-  } else {
-    const int ci = (int)(i % Cin);
-    const int64_t r = i / Cin;
-    const int t = (int)(r % 9), co = (int)(r / 9);
-    wt[i] = w[((int64_t)co * Cin + ci) * 9 + (8 - t)];
-  }
+// wt[(a * 9 + t) * B + b] = w[a * sa + b * sb + (flip ? 8 - t : t)]   (a < A: the operator's input channel, b < B: its output channel)
+__global__ __launch_bounds__(256) void w3x3_pack_kernel(const float* __restrict__ w, int A, int B, int64_t sa, int64_t sb, int flip,
+                                                         float* __restrict__ wt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // indexes the OUTPUT so that writes are coalesced
+  if (i >= (int64_t)A * B * 9) return;
+  const int b = (int)(i % B);
+  const int64_t r = i / B;
+  const int t = (int)(r % 9), a = (int)(r / 9);
+  wt[i] = w[a * sa + b * sb + (flip ? 8 - t : t)];
 }
 
 }  // namespace
 
-extern "C" int vts_w3x3_pack(const float* w, int Cout, int Cin, int mode, float* wt, void* stream) {
-  VTS_CHECK_ARG(w && wt && Cout >= 1 && Cin >= 1 && (mode == 0 || mode == 1), "vts_w3x3_pack: bad args");
-  const int64_t total = (int64_t)Cout * Cin * 9;
-  hipLaunchKernelGGL(w3x3_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, mode, wt);
+extern "C" int vts_w3x3_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream) {
+  VTS_CHECK_ARG(w && wt && A >= 1 && B >= 1, "vts_w3x3_pack: bad args");
+  const int64_t total = (int64_t)A * B * 9;
+  hipLaunchKernelGGL(w3x3_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, A, B, sa, sb, flip, wt);
   VTS_CHECK_LAUNCH("vts_w3x3_pack");
   return VTS_OK;
 }
@@ -205,26 +212,73 @@ extern "C" int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, i
   return KS > 1 ? (int64_t)KS * N * Cout * H * W : 0;
 }
 
+static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_t st) {
+  VTS_CHECK_ARG((k.Cout & 3) == 0, "vts_conv3x3_wide: Cout %d must be a multiple of 4 (16-byte weight rows)", k.Cout);
+  VTS_CHECK_ARG((int64_t)k.Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)k.Cin * 9 * k.Cout * 4 < (1ll << 31) && k.N <= 1024,
+                "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
+  int cps;
+  int KS = k.os == 1 ? wide_plan(k.N, k.Cin, k.Cout, k.H, k.W, &cps) : 1;
+  const int64_t per_slice = (int64_t)k.N * k.Cout * k.OH * k.OW;
+  if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; cps = cdiv(k.Cin, CK); }
+  k.KS = KS; k.cps = cps; k.part = KS > 1 ? ws : nullptr;
+  const dim3 grid(cdiv(k.W, TX) * cdiv(k.H, TY), cdiv(k.Cout, TCO), k.N * KS);
+  if (S == 1) hipLaunchKernelGGL(conv3x3_wide_kernel<1>, grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(conv3x3_wide_kernel<2>, grid, dim3(256), 0, st, k);
+  vts_set_kernel(KS > 1 ? "conv3x3_wide_kernel<%d>+ksplit" : "conv3x3_wide_kernel<%d>", S);
+  VTS_CHECK_LAUNCH("vts_conv3x3_wide");
+  if (KS > 1) {
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)cdiv64(per_slice, 256)), dim3(256), 0, st, ws, k.bias, KS, per_slice,
+                       k.OH * k.OW, k.Cout, k.out);
+    VTS_CHECK_LAUNCH("vts_conv3x3_wide reduce");
+  }
+  return VTS_OK;
+}
+
+static void full_taps(WideK& k) {
+  k.ntaps = 9;
+  for (int t = 0; t < 9; ++t) { k.dy[t] = (signed char)(t / 3); k.dx[t] = (signed char)(t % 3); k.wt_tap[t] = (signed char)t; }
+}
+
 extern "C" int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
                                 float* ws, int64_t ws_floats, void* stream) {
   VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "vts_conv3x3_wide: bad args");
-  VTS_CHECK_ARG((Cout & 3) == 0, "vts_conv3x3_wide: Cout %d must be a multiple of 4 (16-byte weight rows)", Cout);
-  VTS_CHECK_ARG((int64_t)Cin * (H + 2) * (W + 2) * 4 < (1ll << 31) && (int64_t)Cin * 9 * Cout * 4 < (1ll << 31) && N <= 1024,
-                "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
-  int cps;
-  int KS = wide_plan(N, Cin, Cout, H, W, &cps);
-  const int64_t per_slice = (int64_t)N * Cout * H * W;
-  if (KS > 1 && (!ws || ws_floats < KS * per_slice)) { KS = 1; cps = cdiv(Cin, CK); }
-  WideK k{in, wt, bias, out, N, Cin, Cout, H, W, KS, cps, KS > 1 ? ws : nullptr};
-  const int tiles = cdiv(W, TX) * cdiv(H, TY);
-  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(tiles, cdiv(Cout, TCO), N * KS), dim3(256), 0, (hipStream_t)stream, k);
-  vts_set_kernel(KS > 1 ? "conv3x3_wide_kernel+ksplit" : "conv3x3_wide_kernel");
-  VTS_CHECK_LAUNCH("vts_conv3x3_wide");
-  if (KS > 1) {
-    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)cdiv64(per_slice, 256)), dim3(256), 0, (hipStream_t)stream, ws, bias, KS, per_slice,
-                       H * W, Cout, out);
-    VTS_CHECK_LAUNCH("vts_conv3x3_wide reduce");
-  }
+  WideK k{};
+  k.in = in; k.wt = wt; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
+  k.IPH = H + 2; k.IPW = W + 2; k.OH = H; k.OW = W; k.os = 1; k.oy0 = 0; k.ox0 = 0;
+  full_taps(k);
+  return wide_launch(k, 1, ws, ws_floats, (hipStream_t)stream);
+}
+
+extern "C" int vts_conv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int OH, int OW,
+                                  void* stream) {
+  VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && OH >= 1 && OW >= 1, "vts_conv3x3s2_wide: bad args");
+  WideK k{};
+  k.in = in; k.wt = wt; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = OH; k.W = OW;
+  k.IPH = 2 * OH + 2; k.IPW = 2 * OW + 2; k.OH = OH; k.OW = OW; k.os = 1; k.oy0 = 0; k.ox0 = 0;
+  full_taps(k);
+  return wide_launch(k, 2, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int vts_tconv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int IH, int IW,
+                                   void* stream) {
+  VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && IH >= 1 && IW >= 1, "vts_tconv3x3s2_wide: bad args");
+  // out[2i + py] = sum over (d, k) with k = py + 1 - 2d:  py = 0: (d 0, k 1);  py = 1: (d 0, k 2), (d 1, k 0); input index i + d
+  static const int ND[2] = {1, 2}, D[2][2] = {{0, 0}, {0, 1}}, KK[2][2] = {{1, 0}, {2, 0}};
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      WideK k{};
+      k.in = in; k.wt = wt; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = IH; k.W = IW;
+      k.IPH = IH + 1; k.IPW = IW + 1; k.OH = 2 * IH; k.OW = 2 * IW; k.os = 2; k.oy0 = py; k.ox0 = px;
+      k.ntaps = 0;
+      for (int a = 0; a < ND[py]; ++a)
+        for (int b = 0; b < ND[px]; ++b) {
+          k.dy[k.ntaps] = (signed char)D[py][a]; k.dx[k.ntaps] = (signed char)D[px][b];
+          k.wt_tap[k.ntaps] = (signed char)(KK[py][a] * 3 + KK[px][b]);
+          ++k.ntaps;
+        }
+      const int rc = wide_launch(k, 1, nullptr, 0, (hipStream_t)stream);
+      if (rc != VTS_OK) return rc;
+    }
   return VTS_OK;
 }
 
@@ -239,23 +293,27 @@ extern "C" int vts_conv3x3_wide(const float* in, const float* wt, const float* b
 // =====================================================================================================
 namespace {
 
-constexpr int GCO = 64, GCI = 64, GTY = 2, GTX = 32;
-constexpr int GPX = GTY * GTX;                      // 64 pixels per tile
-constexpr int DO_PITCH = GPX + 1;                   // dout plane [co][px], odd pitch
-constexpr int GPR = GTY + 2, GPC = 36;              // patch rows, staged columns (9 quads)
-constexpr int P_PITCH = GPR * GPC + 1;              // in plane [ci][r][c], odd pitch (145)
-constexpr int GDO_FLOATS = GCO * DO_PITCH, GP_FLOATS = GCI * P_PITCH;
-constexpr int NDQ = GCO * GPX / 4 / 256;            // 4 dout quads per thread
-constexpr int NIQ = GCI * GPR * (GPC / 4) / 256;    // 9 patch quads per thread
+constexpr int GCO = 64, GCI = 64, GTY = 2;
 
 struct WgWideK {
   const float *dout, *in;
   float* part;     // [KS][Cout][Cin][9]
-  int N, Cin, Cout, H, W;
+  int N, Cin, Cout, H, W;   // H x W: extent of dout
+  int IPH, IPW;             // padded extent of `in`
   int tiles_x, tiles_per_img, ntiles, tps;   // pixel tiles; tps = tiles per K slice
 };
 
+// S: stride of the convolution whose weight gradient this is (in is sampled at S*y + ky, S*x + kx)
+template <int S>
 __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
+  constexpr int GTX = S == 1 ? 32 : 16;
+  constexpr int GPX = GTY * GTX;                           // pixels per tile
+  constexpr int DO_PITCH = GPX + 1;                        // dout plane [co][px], odd pitch
+  constexpr int GPR = S * (GTY - 1) + 3, GPC = (S * (GTX - 1) + 3 + 3) / 4 * 4;   // patch rows, staged columns
+  constexpr int P_PITCH = GPR * GPC + 1;                   // in plane [ci][r][c], odd pitch
+  constexpr int GDO_FLOATS = GCO * DO_PITCH, GP_FLOATS = GCI * P_PITCH;
+  constexpr int DQ_TOTAL = GCO * GPX / 4, IQ_TOTAL = GCI * GPR * (GPC / 4);
+  constexpr int NDQ = (DQ_TOTAL + 255) / 256, NIQ = (IQ_TOTAL + 255) / 256;
   __shared__ float lds[GDO_FLOATS + GP_FLOATS];
   float* lds_d = lds;
   float* lds_i = lds + GDO_FLOATS;
@@ -263,13 +321,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave & 1, wci = wave >> 1;
   const int co0 = blockIdx.x * GCO, ci0 = blockIdx.y * GCI, ks = blockIdx.z;
-  const int PW = p.W + 2, plane = (p.H + 2) * PW, oplane = p.H * p.W;
+  const int PW = p.IPW, plane = p.IPH * p.IPW, oplane = p.H * p.W;
 
   // staging items: dout quads (co, row, xquad) and patch quads (ci, r, cquad); tile offsets are added per tile
   int dvoff[NDQ], dloff[NDQ];
 #pragma unroll
   for (int e = 0; e < NDQ; ++e) {
-    const int q = tid + e * 256;
+    const int q = min(tid + e * 256, DQ_TOTAL - 1);
     const int co = q / (GPX / 4), r4 = q - co * (GPX / 4);
     const int row = r4 / (GTX / 4), xq = r4 - row * (GTX / 4);
     dvoff[e] = ((co0 + co) * oplane + row * p.W + 4 * xq) * 4;
@@ -278,7 +336,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
   int ivoff[NIQ], iloff[NIQ];
 #pragma unroll
   for (int e = 0; e < NIQ; ++e) {
-    const int q = tid + e * 256;
+    const int q = min(tid + e * 256, IQ_TOTAL - 1);
     const int ci = q / (GPR * (GPC / 4)), r9 = q - ci * (GPR * (GPC / 4));
     const int r = r9 / (GPC / 4), cq = r9 - r * (GPC / 4);
     ivoff[e] = ((ci0 + ci) * plane + r * PW + 4 * cq) * 4;
@@ -294,18 +352,19 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
     cur_y0 = ty * GTY;
     const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dout) + (int64_t)n * p.Cout * oplane, 0, p.Cout * oplane * 4, RSRC_FLAGS);
     const auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
-    const int doff = (cur_y0 * p.W + cur_x0) * 4, ioff = (cur_y0 * PW + cur_x0) * 4;
+    const int doff = (cur_y0 * p.W + cur_x0) * 4, ioff = (S * cur_y0 * PW + S * cur_x0) * 4;
 #pragma unroll
     for (int e = 0; e < NDQ; ++e) dq[e] = __builtin_amdgcn_raw_buffer_load_b128(rd, dvoff[e] + doff, 0, 0);
 #pragma unroll
     for (int e = 0; e < NIQ; ++e) iq[e] = __builtin_amdgcn_raw_buffer_load_b128(ri, ivoff[e] + ioff, 0, 0);
   };
-  // dout pixels outside the image must contribute 0 (the patch side may hold anything there); channels past
-  // Cout / Cin read 0 through the bounds check except where the next image / channel follows: mask by index.
+  // dout pixels outside the image must contribute 0 (the patch side may hold anything finite there); channels past
+  // Cout / Cin are masked by index (the bounds check only catches them when nothing follows in memory).
+  // (whole-quad casts: extracting quad[j] through __builtin_bit_cast per element mis-compiled to element 0)
   auto store_tile = [&]() {
 #pragma unroll
     for (int e = 0; e < NDQ; ++e) {
-      const int q = tid + e * 256;
+      const int q = min(tid + e * 256, DQ_TOTAL - 1);
       const int co = q / (GPX / 4), r4 = q - co * (GPX / 4);
       const int row = r4 / (GTX / 4), xq = r4 - row * (GTX / 4);
       const bool rok = co0 + co < p.Cout && cur_y0 + row < p.H;
@@ -315,7 +374,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
     }
 #pragma unroll
     for (int e = 0; e < NIQ; ++e) {
-      const int q = tid + e * 256;
+      const int q = min(tid + e * 256, IQ_TOTAL - 1);
       const int ci = q / (GPR * (GPC / 4));
       const bool cok = ci0 + ci < p.Cin;
       const f32x4 v = __builtin_bit_cast(f32x4, iq[e]);
@@ -331,7 +390,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const float* a_base = lds_d + (wco * 32 + l32) * DO_PITCH + kh;            // A[i = co][k = pixel]
-  const float* b_base = lds_i + (wci * 32 + l32) * P_PITCH + kh;             // B[k = pixel][j = ci]
+  const float* b_base = lds_i + (wci * 32 + l32) * P_PITCH + S * kh;         // B[k = pixel][j = ci]
 
   const int t_beg = ks * p.tps, t_end = min(p.ntiles, t_beg + p.tps);
   if (t_beg < t_end) {
@@ -350,7 +409,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int ky = tap / 3, kx = tap - ky * 3;
-          const float b = b_base[(row + ky) * GPC + xs * 2 + kx];
+          const float b = b_base[(S * row + ky) * GPC + S * xs * 2 + kx];
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
         }
       }
@@ -381,8 +440,8 @@ __global__ __launch_bounds__(256) void wg_wide_reduce_kernel(const float* __rest
   dw[i] = v;
 }
 
-int wg_wide_plan(int N, int Cin, int Cout, int H, int W, int* tps) {
-  const int ntiles = N * cdiv(H, GTY) * cdiv(W, GTX);
+int wg_wide_plan(int N, int Cin, int Cout, int H, int W, int S, int* tps) {
+  const int ntiles = N * cdiv(H, GTY) * cdiv(W, S == 1 ? 32 : 16);
   const int groups = cdiv(Cout, GCO) * cdiv(Cin, GCI);
   int KS = 512 / groups;                      // aim at two workgroups per CU
   if (KS > ntiles / 4) KS = ntiles / 4;
@@ -393,25 +452,29 @@ int wg_wide_plan(int N, int Cin, int Cout, int H, int W, int* tps) {
 
 }  // namespace
 
-extern "C" int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W) {
+extern "C" int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int stride) {
   int tps;
-  return (int64_t)wg_wide_plan(N, Cin, Cout, H, W, &tps) * Cout * Cin * 9;
+  return (int64_t)wg_wide_plan(N, Cin, Cout, H, W, stride, &tps) * Cout * Cin * 9;
 }
 
-extern "C" int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int accumulate,
-                                 float* ws, int64_t ws_floats, void* stream) {
-  VTS_CHECK_ARG(dout && in && dw && ws && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "vts_wgrad3x3_wide: bad args");
-  VTS_CHECK_ARG((int64_t)Cin * (H + 2) * (W + 2) * 4 < (1ll << 31) && (int64_t)Cout * H * W * 4 < (1ll << 31), "vts_wgrad3x3_wide: operand exceeds the 2 GiB buffer range");
+extern "C" int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int stride,
+                                 int accumulate, float* ws, int64_t ws_floats, void* stream) {
+  VTS_CHECK_ARG(dout && in && dw && ws && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && (stride == 1 || stride == 2),
+                "vts_wgrad3x3_wide: bad args");
   WgWideK k;
   k.dout = dout; k.in = in; k.part = ws; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
-  k.tiles_x = cdiv(W, GTX);
+  k.IPH = stride * H + 2; k.IPW = stride * W + 2;
+  VTS_CHECK_ARG((int64_t)Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)Cout * H * W * 4 < (1ll << 31), "vts_wgrad3x3_wide: operand exceeds the 2 GiB buffer range");
+  k.tiles_x = cdiv(W, stride == 1 ? 32 : 16);
   k.tiles_per_img = k.tiles_x * cdiv(H, GTY);
   k.ntiles = N * k.tiles_per_img;
-  const int KS = wg_wide_plan(N, Cin, Cout, H, W, &k.tps);
+  const int KS = wg_wide_plan(N, Cin, Cout, H, W, stride, &k.tps);
   const int64_t nel = (int64_t)Cout * Cin * 9;
   VTS_CHECK_ARG(ws_floats >= KS * nel, "vts_wgrad3x3_wide: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)(KS * nel));
-  hipLaunchKernelGGL(wgrad3x3_wide_kernel, dim3(cdiv(Cout, GCO), cdiv(Cin, GCI), KS), dim3(256), 0, (hipStream_t)stream, k);
-  vts_set_kernel("wgrad3x3_wide_kernel");
+  const dim3 grid(cdiv(Cout, GCO), cdiv(Cin, GCI), KS);
+  if (stride == 1) hipLaunchKernelGGL(wgrad3x3_wide_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(wgrad3x3_wide_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
+  vts_set_kernel("wgrad3x3_wide_kernel<%d>", stride);
   VTS_CHECK_LAUNCH("vts_wgrad3x3_wide");
   hipLaunchKernelGGL(wg_wide_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, (hipStream_t)stream, ws, KS, nel, dw, accumulate);
   VTS_CHECK_LAUNCH("vts_wgrad3x3_wide reduce");

@@ -216,7 +216,7 @@ def _is_wide(conv):
 def _conv_valid3(p, conv, out):
     """valid 3x3 conv of a pre-padded identity tensor"""
     if _is_wide(conv):
-        return ops.conv3x3_wide(p, ops.w3x3_pack(conv.weight, 0, "fwd"), conv.bias, out)
+        return ops.conv3x3_wide(p, ops.w3x3_pack(conv.weight, "conv_fwd"), conv.bias, out)
     return ops.convk(p, conv.weight, out, bias=conv.bias, pad=0)
 
 
@@ -224,7 +224,7 @@ def _conv_valid3_bwd_data(g, conv, dp):
     """dp (padded size) <- adjoint of _conv_valid3 w.r.t. its input"""
     if _is_wide(conv):
         q = ops.pad_affine(g, (2, 2, 2, 2), 0)
-        return ops.conv3x3_wide(q, ops.w3x3_pack(conv.weight, 1, "bwd"), None, dp)
+        return ops.conv3x3_wide(q, ops.w3x3_pack(conv.weight, "conv_adj"), None, dp)
     return ops.convk_bwd_data(g, conv.weight, dp, pad=0)
 
 
@@ -295,9 +295,15 @@ def resnet_forward(G, x, keep=True):
             r = _empty(n, conv.weight.shape[0], (ih - 1) // stride + 1, (iw - 1) // stride + 1, dev)
             if stride == 2 and (ih % 2 or iw % 2):
                 raise ValueError("stride-2 3x3 convolutions need even sizes, got %dx%d" % (ih, iw))
-            _conv3(inp, conv, r, stride, inp_act)
+            xp = None
+            if _is_wide(conv):     # GEMM-class kernels: materialise relu(norm(.)) with the zero padding once
+                xp = ops.pad_affine(inp, (1, 1, 1, 1), 0, act=inp_act)
+                wt = ops.w3x3_pack(conv.weight, "conv_fwd")
+                (ops.conv3x3_wide if stride == 1 else ops.conv3x3s2_wide)(xp, wt, conv.bias, r)
+            else:
+                _conv3(inp, conv, r, stride, inp_act)
             cur, pending = _g_norm(G, r, bn), RELU
-            steps.append(("conv3", conv, inp, inp_act, cur, bn, stride))
+            steps.append(("conv3", conv, inp, inp_act, cur, bn, stride, xp))
             i += 3
         elif kind == "convT3":  # ConvTranspose2d(3, stride 2, pad 1, output_padding 1) + norm + relu
             conv, bn = G.mod(e["idx"]), G.mod(lay[i + 1]["idx"])
@@ -305,10 +311,15 @@ def resnet_forward(G, x, keep=True):
             _, _, ih, iw = shape_of(cur)
             ci, co = conv.weight.shape[:2]
             r = _empty(n, co, 2 * ih, 2 * iw, dev)
-            w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
-            ops.conv4x4(inp, w4, 16, co * 16, co, r, bias=conv.bias, stride=2, pad=1, transposed=True, act_in=inp_act)
+            z = None
+            if _is_wide(conv):
+                z = ops.pad_affine(inp, (0, 0, 0, 0), 0, act=inp_act) if (inp_act or isinstance(inp, Act)) else inp
+                ops.tconv3x3s2_wide(ops.pad_affine(z, (0, 1, 0, 1), 0), ops.w3x3_pack(conv.weight, "convT_fwd"), conv.bias, r)
+            else:
+                w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
+                ops.conv4x4(inp, w4, 16, co * 16, co, r, bias=conv.bias, stride=2, pad=1, transposed=True, act_in=inp_act)
             cur, pending = _g_norm(G, r, bn), RELU
-            steps.append(("convT3", conv, inp, inp_act, cur, bn))
+            steps.append(("convT3", conv, inp, inp_act, cur, bn, z))
             i += 3
         elif kind == "down":
             inp = cur
@@ -384,11 +395,19 @@ def resnet_backward(G, ctx, d_raw):
             _, conv, p, src_act, a, bn = st
             ops.wgradk(g, p, conv.weight.grad, pad=0)  # network input: no gradient needed below
         elif kind == "conv3":
-            _, conv, inp, inp_act, a, bn, stride = st
+            _, conv, inp, inp_act, a, bn, stride, xp = st
             hi = inp if isinstance(inp, Act) else Act(inp)
             t = inp.data if isinstance(inp, Act) else inp
             din = torch.empty_like(t)
-            if stride == 1:
+            if xp is not None:     # wide layer
+                ops.wgrad3x3_wide(g, xp, conv.weight.grad, stride=stride)
+                if stride == 1:
+                    dxp = torch.empty_like(xp)
+                    ops.conv3x3_wide(ops.pad_affine(g, (2, 2, 2, 2), 0), ops.w3x3_pack(conv.weight, "conv_adj"), None, dxp)
+                    ops.pad_bwd(dxp, (1, 1, 1, 1), 0, din)
+                else:
+                    ops.tconv3x3s2_wide(ops.pad_affine(g, (0, 1, 0, 1), 0), ops.w3x3_pack(conv.weight, "conv_s2_adj"), None, din)
+            elif stride == 1:
                 ops.wgradk(g, hi, conv.weight.grad, pad=1, act_hi=inp_act)
                 ops.convk_bwd_data(g, conv.weight, din, pad=1)
             else:
@@ -400,16 +419,21 @@ def resnet_backward(G, ctx, d_raw):
                 ops.conv4x4(g, w4, 16, ci * 16, ci, din, stride=2, pad=1, transposed=True)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
         elif kind == "convT3":
-            _, conv, inp, inp_act, a, bn = st
+            _, conv, inp, inp_act, a, bn, z = st
             ci, co = conv.weight.shape[:2]
             lo = inp if isinstance(inp, Act) else Act(inp)
             t = inp.data if isinstance(inp, Act) else inp
-            dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
-            ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act)
-            ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)
-            w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
             din = torch.empty_like(t)
-            ops.conv4x4(g, w4, co * 16, 16, ci, din, stride=2, pad=1)
+            if z is not None:      # wide layer
+                gp = ops.pad_affine(g, (1, 1, 1, 1), 0)
+                ops.wgrad3x3_wide(z, gp, conv.weight.grad, stride=2)
+                ops.conv3x3s2_wide(gp, ops.w3x3_pack(conv.weight, "convT_adj"), None, din)
+            else:
+                dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
+                ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act)
+                ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)
+                w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
+                ops.conv4x4(g, w4, co * 16, 16, ci, din, stride=2, pad=1)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
         elif kind == "down":
             inp = st[1]       # Act: relu(norm(r)) on load

@@ -206,13 +206,21 @@ def wgradk(dout, x, dw, *, pad=0, act_hi=0, accumulate=False):
     return dw
 
 
-def w3x3_pack(w, mode, tag):
-    """tap-major packing of a [Co, Ci, 3, 3] weight for conv3x3_wide (mode 0 forward, 1 input-adjoint); persistent buffer"""
-    key = ("wt", w.data_ptr(), tuple(w.shape), tag)
+PACK_MODES = ("conv_fwd", "conv_adj", "conv_s2_adj", "convT_fwd", "convT_adj")
+
+
+def w3x3_pack(w, mode, tag=None):
+    """tap-major packing of a 3x3 weight for the *_wide kernels into a persistent buffer (see include/vts.h).
+    w is an nn.Conv2d weight [Co,Ci,3,3] for the conv_* modes, an nn.ConvTranspose2d weight [Ci,Co,3,3] for convT_*."""
+    d0, d1 = w.shape[0], w.shape[1]
+    A, B, sa, sb, flip = {
+        "conv_fwd": (d1, d0, 9, 9 * d1, 0), "conv_adj": (d0, d1, 9 * d1, 9, 1), "conv_s2_adj": (d0, d1, 9 * d1, 9, 0),
+        "convT_fwd": (d0, d1, 9 * d1, 9, 0), "convT_adj": (d1, d0, 9, 9 * d1, 0)}[mode]
+    key = ("wt", w.data_ptr(), tuple(w.shape), mode, tag)
     buf = _ws.get(key)
     if buf is None:
         buf = _ws[key] = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
-    _run("w3x3_pack", 8.0 * w.numel(), 0.0, L.load().vts_w3x3_pack, w.data_ptr(), w.shape[0], w.shape[1], mode, buf.data_ptr(), L.stream())
+    _run("w3x3_pack", 8.0 * w.numel(), 0.0, L.load().vts_w3x3_pack, w.data_ptr(), A, B, sa, sb, flip, buf.data_ptr(), L.stream())
     return buf
 
 
@@ -233,18 +241,45 @@ def conv3x3_wide(p, wt, bias, out):
     return out
 
 
-def wgrad3x3_wide(dout, p, dw, accumulate=False):
-    """dw [Co,Ci,3,3] (+)= weight gradient of conv3x3_wide for dout [N,Co,H,W] and the pre-padded input p [N,Ci,H+2,W+2]"""
-    n, co, h, w = dout.shape
-    ci = p.shape[1]
-    assert p.shape == (n, ci, h + 2, w + 2) and dw.shape == (co, ci, 3, 3) and dout.is_contiguous() and p.is_contiguous()
-    lib = L.load()
-    ws = workspace(lib.vts_wgrad3x3_wide_ws_floats(n, ci, co, h, w), p.device)
+def conv3x3s2_wide(p, wt, bias, out):
+    """out [N,Co,OH,OW] <- 3x3 stride-2 conv of p [N,Ci,2OH+2,2OW+2] (the input zero-padded by 1)"""
+    n, ci, ph, pw = p.shape
+    co, oh, ow = out.shape[1:]
+    assert (ph, pw) == (2 * oh + 2, 2 * ow + 2) and p.is_contiguous() and out.is_contiguous()
     if TIMER is not None:
         global DETAIL
-        DETAIL = "N%d dout %dx%dx%d in %dx%dx%d" % (n, co, h, w, ci, h + 2, w + 2)
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d s2" % (n, ci, ph - 2, pw - 2, co, oh, ow)
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * oh * ow * co * ci * 9, L.load().vts_conv3x3s2_wide,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, oh, ow, L.stream())
+    return out
+
+
+def tconv3x3s2_wide(p, wt, bias, out):
+    """out [N,Co,2IH,2IW] <- ConvTranspose2d(3, stride 2, pad 1, output_padding 1) of p [N,Ci,IH+1,IW+1] (zero row/column appended)"""
+    n, ci, ph, pw = p.shape
+    co = out.shape[1]
+    ih, iw = ph - 1, pw - 1
+    assert out.shape == (n, co, 2 * ih, 2 * iw) and p.is_contiguous() and out.is_contiguous()
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d transposed s2" % (n, ci, ih, iw, co, 2 * ih, 2 * iw)
+    _run("conv3x3_wide", 4.0 * (4 * p.numel() + out.numel() + wt.numel()), 2.0 * n * ih * iw * co * ci * 9, L.load().vts_tconv3x3s2_wide,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, ih, iw, L.stream())
+    return out
+
+
+def wgrad3x3_wide(dout, p, dw, accumulate=False, stride=1):
+    """dw[a][b][3][3] (+)= sum dout[n,a,y,x] * p[n,b,stride*y+ky,stride*x+kx]; dout [N,A,H,W], p [N,B,stride*H+2,stride*W+2]"""
+    n, co, h, w = dout.shape
+    ci = p.shape[1]
+    assert p.shape == (n, ci, stride * h + 2, stride * w + 2) and dw.shape == (co, ci, 3, 3) and dout.is_contiguous() and p.is_contiguous()
+    lib = L.load()
+    ws = workspace(lib.vts_wgrad3x3_wide_ws_floats(n, ci, co, h, w, stride), p.device)
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d dout %dx%dx%d in %dx%dx%d s%d" % (n, co, h, w, ci, p.shape[2], p.shape[3], stride)
     _run("wgrad3x3_wide", 4.0 * (dout.numel() + p.numel() + dw.numel()), 2.0 * n * h * w * co * ci * 9, lib.vts_wgrad3x3_wide,
-         dout.data_ptr(), p.data_ptr(), dw.data_ptr(), n, ci, co, h, w, int(accumulate), ws.data_ptr(), ws.numel(), L.stream())
+         dout.data_ptr(), p.data_ptr(), dw.data_ptr(), n, ci, co, h, w, stride, int(accumulate), ws.data_ptr(), ws.numel(), L.stream())
     return dw
 
 
