@@ -235,6 +235,63 @@ def golden_global(h=64, w=32, seed=404, ngf=8, n_down=3, n_blocks=3):
     print("wrote global_%dx%d.npz (%d entries)" % (h, w, len(out)))
 
 
+def p2p_batch(n, size, seed):
+    """synthetic patch batch with the patchskit contract (data/patchskit_dataset.py:277-333; return_patch=True)"""
+    from oracle import detrand
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    M = (((yy - size / 2) / (0.45 * size)) ** 2 + ((xx - size / 2) / (0.4 * size)) ** 2 <= 1).float()[None, None].repeat(n, 1, 1, 1)
+    return {"S_images": detrand.uniform((n, 1, size, size), seed, "S"), "M_images": M,
+            "I_images": detrand.uniform((n, 3, size, size), seed, "I"), "T_images": 0.3 * detrand.uniform((n, 2, size, size), seed, "T"),
+            "I_masks": torch.ones(n, size, size, dtype=torch.float64), "name": ["synthetic"] * n, "S_paths": ["synthetic.png"] * n,
+            "augmentation_params": {}}
+
+
+P2P_FLAGS = ["--model", "pix2pixHD", "--no_vgg_loss", "True", "--ngf", "8", "--ndf", "8", "--n_downsample_global", "3", "--n_blocks_global", "2", "--batch_size", "4"]
+
+
+def golden_p2p_step(size=32, seed=505, n=4, steps=2):
+    """Pix2PixHDModel.optimize_parameters x `steps` on one synthetic patch batch (small G / D so the fixture stays small)."""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    import models
+    opt = _ref_opt("pix2pixHD", True, P2P_FLAGS)
+    opt.checkpoints_dir, opt.name = "/tmp/vts_golden_ckpt", "p2p"
+    os.makedirs(os.path.join(opt.checkpoints_dir, opt.name), exist_ok=True)
+    model = models.create_model(opt)
+    model.setup(opt)
+    shG = nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True)
+    shD, shD2 = nets.d_if_param_shapes(4, 8, 2), nets.d_if_param_shapes(3, 8, 2)
+    for net, sh in ((model.netG, shG), (model.netD, shD), (model.netD2, shD2)):
+        ref = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert ref == {k: tuple(v) for k, v in sh.items()}, (sorted(set(ref) ^ set(sh))[:6])
+    model.netG.load_state_dict(detrand.test_weights(shG, seed))
+    model.netD.load_state_dict(detrand.test_weights(shD, seed + 1))
+    model.netD2.load_state_dict(detrand.test_weights(shD2, seed + 2))
+    model.train()
+    batch = p2p_batch(n, size, seed)
+    out = {"size": size, "seed": seed, "n": n, "steps": steps, "flags": np.array(P2P_FLAGS),
+           "lr": opt.lr, "beta1": opt.beta1, "gan_mode": np.array(opt.gan_mode)}
+    for it in range(steps):
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+        losses = model.get_current_losses()
+        tag = "s%d" % it
+        out[tag + "/loss_names"] = np.array(list(losses.keys()))
+        out[tag + "/loss_values"] = np.array([float(v) for v in losses.values()], dtype=np.float64)
+        for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+            for kk, p in net.named_parameters():
+                out["%s/grad_%s/%s" % (tag, nm, kk)] = detrand.probe(p.grad, kk)
+                out["%s/param_%s/%s" % (tag, nm, kk)] = detrand.probe(p, kk)
+            for kk, b in net.named_buffers():
+                out["%s/buf_%s/%s" % (tag, nm, kk)] = b.detach().double().numpy()
+        out[tag + "/fake_I"] = model.fake_I.detach().numpy()
+        out[tag + "/fake_T"] = model.fake_T.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, "pix2pixHD_step_%d.npz" % size), **out)
+    print("wrote pix2pixHD_step_%d.npz (%d entries)" % (size, len(out)))
+    print({k: float(v) for k, v in losses.items()})
+
+
 def golden_step(size=256, seed=202, steps=2, nt=64):
     """Full SinSKITGModel.optimize_parameters x `steps` on one synthetic sample (BASELINE config 0)."""
     from oracle import detrand, nets, ref_import
@@ -295,7 +352,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "p2p"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -306,3 +363,5 @@ if __name__ == "__main__":
         golden_resnet()
     if "global" in which:
         golden_global()
+    if "p2p" in which:
+        golden_p2p_step()

@@ -226,3 +226,74 @@ def inference(sdG, batch, opt=None, style_code=None):
     with torch.no_grad():
         _, fake_I, fake_T = generator_forward(sdG, inp, opt, style_code)
     return fake_I, fake_T
+
+
+# ----------------------------------------------------------------------------
+# pix2pixHD baseline step  (models/pix2pixHD_model.py:431-509 set_input, :587-619 forward, :621-644 backward_D,
+# :646-700 backward_G, :702-722 optimize_parameters).  Patch training: S/M/I/T_images are [N,*,32,32].
+# The GAN feature-matching term compares every discriminator feature WITH ITSELF (.detach()) (:662-680): its
+# value and its gradient are identically zero, so it is reported as 0 and contributes nothing; VGG / LPIPS terms
+# need pretrained weights (off: --no_vgg_loss True).
+# ----------------------------------------------------------------------------
+P2P_HP = dict(lr=2e-4, beta1=0.5, beta2=0.999, gan_mode="lsgan", n_blocks_global=9, n_downsample_global=4, num_D_D1=2, num_D_D2=2,
+              scale_nz=0.25)
+
+
+def p2p_hp(**kw):
+    d = dict(P2P_HP)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def p2p_prepare(batch):
+    S, M, I = batch["S_images"].float(), batch["M_images"].float(), batch["I_images"].float()
+    h, w = S.shape[-2:]
+    T = batch["T_images"].reshape(-1, 2, h, w).float()
+    masks = batch["I_masks"].reshape(-1, 1, h, w).float()
+    return SimpleNamespace(real_S=S * M, real_I=I * M, M=M, real_T=T * masks)
+
+
+def p2p_generator(sdG, inp, opt, training=True):
+    out = nets.resnet_forward(sdG, inp.real_S, opt.n_blocks_global, opt.n_downsample_global, norm="batch", down="stride", up="convT",
+                              training=training)
+    return out, out[:, :3] * inp.M, out[:, -2:] * inp.M
+
+
+def p2p_train_step(sdG, sdD, sdD2, adam, batch, opt=None, record=True):
+    """One D + D2 + G update in place on the three state dicts (D / D2 in the getIntermFeat key style) and `adam`."""
+    opt = opt or p2p_hp()
+    inp = p2p_prepare(batch)
+    pD, pD2 = nets.d_if_to_plain(sdD), nets.d_if_to_plain(sdD2)     # views onto the same tensors
+    gl = lambda p, real: nets.gan_loss(p, real, opt.gan_mode)
+    _req(sdG, True)
+    g_out, fake_I, fake_T = p2p_generator(sdG, inp, opt)
+    # ---- D, D2 (one backward for both) ----
+    _req(sdD, True)
+    _req(sdD2, True)
+    loss_D_fake = gl(nets.msd_forward(pD, torch.cat((inp.real_S, fake_I.detach()), 1), opt.num_D_D1), False)
+    loss_D_real = gl(nets.msd_forward(pD, torch.cat((inp.real_S, inp.real_I), 1), opt.num_D_D1), True)
+    loss_D2_fake = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, fake_T.detach()), 1), opt.num_D_D2), False)
+    loss_D2_real = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, inp.real_T), 1), opt.num_D_D2), True)
+    ((loss_D_fake + loss_D_real) * 0.5 + (loss_D2_fake + loss_D2_real) * 0.5).backward()
+    out = {}
+    if record:
+        out["grad_D"], out["grad_D2"] = _grads(sdD), _grads(sdD2)
+    _adam(sdD, adam["D"], opt.lr, opt)
+    _adam(sdD2, adam["D2"], opt.lr, opt)
+    _req(sdD, False)
+    _req(sdD2, False)
+    # ---- G ----
+    loss_G_I = gl(nets.msd_forward(pD, torch.cat((inp.real_S, fake_I), 1), opt.num_D_D1), True)
+    loss_G_T = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, fake_T), 1), opt.num_D_D2), True)
+    (loss_G_I + loss_G_T).backward()
+    if record:
+        out["grad_G"] = _grads(sdG)
+    _adam(sdG, adam["G"], opt.lr, opt)
+    _req(sdG, False)
+    out["losses"] = {"G_GAN_I": float(loss_G_I.detach()), "G_GAN_T": float(loss_G_T.detach()), "G_GAN": float((loss_G_I + loss_G_T).detach()),
+                     "D_real": float(loss_D_real.detach()), "D_fake": float(loss_D_fake.detach()), "D2_real": float(loss_D2_real.detach()),
+                     "D2_fake": float(loss_D2_fake.detach()), "G_GAN_Feat": 0.0, "G_GAN_Feat_I": 0.0, "G_GAN_Feat_T": 0.0}
+    if record:
+        out["fake_I"], out["fake_T"] = fake_I.detach().clone(), fake_T.detach().clone()
+        out["fake_N"] = nets.compute_normal(fake_T.detach(), opt.scale_nz)
+    return out

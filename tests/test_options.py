@@ -13,7 +13,7 @@ def parse(cls, cmd):
         return cls(cmd_line=cmd).parse()
 
 
-@pytest.mark.parametrize("model", ["sinskitG", "skitG"])
+@pytest.mark.parametrize("model", ["sinskitG", "skitG", "pix2pixHD"])
 @pytest.mark.parametrize("phase", ["train", "test"])
 def test_defaults_match_reference(golden_dir, model, phase):
     from options.test_options import TestOptions
@@ -22,7 +22,7 @@ def test_defaults_match_reference(golden_dir, model, phase):
     ref = json.load(open(os.path.join(golden_dir, "ref_option_defaults.json")))["%s_%s" % (model, phase)]
     opt = parse(TrainOptions if phase == "train" else TestOptions, "--model %s --gpu_ids -1 --checkpoints_dir /tmp/vts_opt" % model)
     for k, v in ref.items():
-        if k in ("gpu_ids", "checkpoints_dir"):
+        if k in ("gpu_ids", "checkpoints_dir", "model"):   # given on the command line
             continue
         assert hasattr(opt, k), k
         d = float("inf") if v["default"] == "inf" else v["default"]

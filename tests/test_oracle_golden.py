@@ -173,6 +173,46 @@ def test_global_generator_fwd_bwd(golden_dir):
         _probe_close(v.grad, ref, k, rtol=5e-4)
 
 
+def p2p_batch(n, size, seed):
+    """the synthetic patch batch of oracle/make_golden.py:p2p_batch (patchskit contract)"""
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    M = (((yy - size / 2) / (0.45 * size)) ** 2 + ((xx - size / 2) / (0.4 * size)) ** 2 <= 1).float()[None, None].repeat(n, 1, 1, 1)
+    return {"S_images": detrand.uniform((n, 1, size, size), seed, "S"), "M_images": M,
+            "I_images": detrand.uniform((n, 3, size, size), seed, "I"), "T_images": 0.3 * detrand.uniform((n, 2, size, size), seed, "T"),
+            "I_masks": torch.ones(n, size, size, dtype=torch.float64), "name": ["synthetic"] * n, "S_paths": ["synthetic.png"] * n,
+            "augmentation_params": {}}
+
+
+def test_pix2pixHD_step_matches_reference(golden_dir):
+    """oracle.step.p2p_train_step vs two optimize_parameters() of the reference Pix2PixHDModel"""
+    g = _load(golden_dir, "pix2pixHD_step_32.npz")
+    size, seed, n, steps = int(g["size"]), int(g["seed"]), int(g["n"]), int(g["steps"])
+    sdG = detrand.test_weights(nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True), seed)
+    sdD, sdD2 = detrand.test_weights(nets.d_if_param_shapes(4, 8, 2), seed + 1), detrand.test_weights(nets.d_if_param_shapes(3, 8, 2), seed + 2)
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    opt = step.p2p_hp(n_blocks_global=2, n_downsample_global=3, lr=float(g["lr"]), beta1=float(g["beta1"]))
+    batch = p2p_batch(n, size, seed)
+    for it in range(steps):
+        tag = "s%d" % it
+        out = step.p2p_train_step(sdG, sdD, sdD2, adam, batch, opt)
+        ref = dict(zip([str(k) for k in g[tag + "/loss_names"]], g[tag + "/loss_values"]))
+        for k, v in out["losses"].items():
+            assert abs(ref["l_" + k] - v) <= 2e-4 * max(1.0, abs(v)), (tag, k, ref["l_" + k], v)
+        _close(out["fake_I"].numpy(), g[tag + "/fake_I"], rtol=1e-3, atol=1e-4)
+        _close(out["fake_T"].numpy(), g[tag + "/fake_T"], rtol=1e-3, atol=1e-4)
+        if it == 0:   # later steps inherit the sign sensitivity of Adam's first updates
+            for nm, sd in (("G", sdG), ("D", sdD), ("D2", sdD2)):
+                for k, gr in out["grad_" + nm].items():
+                    rp = g["%s/grad_%s/%s" % (tag, nm, k)]
+                    if k.endswith(".bias") and abs(rp[1]) < 1e-4:
+                        continue
+                    _probe_close(gr, rp, k, rtol=1e-3)
+                for k, v in sd.items():
+                    key = "%s/buf_%s/%s" % (tag, nm, k)
+                    if key in g.files and v.dtype.is_floating_point:
+                        _close(v.numpy(), g[key], rtol=1e-3, atol=1e-5)
+
+
 def test_resnet_state_dict_keys(golden_dir):
     """the product's ResnetGenerator container exposes exactly the reference's state_dict keys"""
     import sys

@@ -10,7 +10,7 @@ import importlib
 
 import torch.utils.data
 
-_ALIASES = {"singleskit": "synthetic", "skit": "synthetic", "patchskit": "synthetic"}
+_ALIASES = {"singleskit": "synthetic", "skit": "synthetic", "patchskit": "synthetic", "aligned": "synthetic"}
 
 
 def find_dataset_using_name(dataset_name):

@@ -83,6 +83,21 @@ def make_sample(size, nt, nt_val, seed, patch=32, style_dim=0):
     }
 
 
+def make_patch_sample(seed, patch=32):
+    """One un-collated patch sample with the patchskit contract used by pix2pixHD's patch-wise training
+    (/root/reference/data/patchskit_dataset.py:277-333, `return_patch=True`): aligned 32x32 sketch / mask /
+    image / tactile patches."""
+    g = np.random.default_rng(seed)
+    S = _box_blur(np.where(g.random((1, patch, patch)) > 0.9, -1.0, 1.0), 3).astype(np.float32)
+    I = _box_blur(g.uniform(-1.0, 1.0, (3, patch, patch)), 5).astype(np.float32)
+    yy, xx = np.mgrid[0:patch, 0:patch]
+    M = (((yy - patch / 2) / (0.45 * patch)) ** 2 + ((xx - patch / 2) / (0.4 * patch)) ** 2 <= 1.0).astype(np.float32)[None]
+    T = np.clip(g.normal(0.0, 0.05, (2, patch, patch)), -0.3, 0.3).astype(np.float32)
+    return {"S_images": torch.from_numpy(S), "M_images": torch.from_numpy(M), "I_images": torch.from_numpy(I),
+            "T_images": torch.from_numpy(T), "I_masks": np.ones((patch, patch), np.float64), "name": "synthetic_%d" % seed,
+            "S_paths": "synthetic/%d.png" % seed, "augmentation_params": {"patch_crop_size": patch}}
+
+
 class SyntheticDataset(torch.utils.data.Dataset):
     @staticmethod
     def modify_commandline_options(parser, is_train):
@@ -109,6 +124,8 @@ class SyntheticDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         seed = self.opt.data_seed + 100003 * self.rank + index
+        if getattr(self.opt, "model", "") == "pix2pixHD" and getattr(self.opt, "return_patch", False):
+            return make_patch_sample(seed)
         if getattr(self.opt, "cache_samples", True):
             if index not in self._cache:
                 self._cache[index] = make_sample(self.size, self.nt, self.nt_val, seed, style_dim=self.style_dim)

@@ -230,6 +230,56 @@ class MultiscaleDiscriminator(nn.Module):
         return [[p] for p in preds]
 
 
+class _LayerView:
+    """`layer<d>`-style accessor over the scale<d>_layer<j> modules of MultiscaleDiscriminatorIF (not a Module)."""
+
+    def __init__(self, owner, d):
+        self._owner, self._d = owner, d
+
+    def __getattr__(self, name):
+        ci = int(name)
+        conv_idx = MultiscaleDiscriminator.CONV_IDX
+        if ci in conv_idx:
+            return getattr(getattr(self._owner, "scale%d_layer%d" % (self._d, conv_idx.index(ci))), "0")
+        j = {v: conv_idx.index(k) for k, v in MultiscaleDiscriminator.BN_IDX.items()}[ci]
+        return getattr(getattr(self._owner, "scale%d_layer%d" % (self._d, j)), "1")
+
+
+class MultiscaleDiscriminatorIF(MultiscaleDiscriminator):
+    """The same discriminator with `getIntermFeat=True` (pix2pixHD's `--getIntermFeat_D` default; reference
+    networks.py:1661-1667): every layer is its own module `scale<d>_layer<j>` (state_dict keys
+    `scale<d>_layer<j>.{0 conv | 1 norm}.*`) and forward returns the per-layer features of every scale."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, opt=None):
+        nn.Module.__init__(self)
+        if n_layers != 3:
+            raise NotImplementedError("MultiscaleDiscriminator: only n_layers=3 is built")
+        self.input_nc, self.ndf, self.num_D = input_nc, ndf, num_D
+        chans = [input_nc, ndf, min(ndf * 2, 512), min(ndf * 4, 512), min(ndf * 8, 512), 1]
+        self.chans = chans
+        for d in range(num_D):
+            for j in range(5):
+                kids = {0: _ConvParams((chans[j + 1], chans[j], 4, 4), chans[j + 1])}
+                if 1 <= j <= 3:
+                    kids[1] = _BNParams(chans[j + 1])
+                setattr(self, "scale%d_layer%d" % (d, j), _Holder(kids))
+
+    def __getattr__(self, name):
+        if name.startswith("layer") and name[5:].isdigit():
+            return _LayerView(self, int(name[5:]))
+        return nn.Module.__getattr__(self, name)
+
+    def forward(self, x):
+        """[[feat_0, ..., pred] per scale]: post-activation layer outputs like the reference's singleD_forward."""
+        from vts import ops as _ops
+        _, ctx = engine.msd_forward(self, x, None, keep=True)
+        res = []
+        for (_, _, acts) in ctx.scales:
+            feats = [_ops.pad_affine(a, (0, 0, 0, 0), 0, act=engine.LRELU) for a in acts[:-1]]
+            res.append(feats + [acts[-1].data])
+        return res
+
+
 def init_weights(net, init_type="normal", init_gain=0.02):
     """networks.py:191-231: conv weights by `init_type`, biases 0, BatchNorm weight ~ N(1, gain)."""
     for m in net.modules():
@@ -290,7 +340,8 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm="batch", init_type="normal"
         raise NotImplementedError("Discriminator model name [%s] is not recognized (built: multiscale)" % netD)
     if norm != "batch":
         raise NotImplementedError("multiscale discriminator is built for normD=batch only")
-    net = MultiscaleDiscriminator(input_nc, ndf, n_layers_D, num_D=num_D, opt=opt)
+    cls = MultiscaleDiscriminatorIF if getattr(opt, "getIntermFeat_D", False) else MultiscaleDiscriminator   # networks.py:1661
+    net = cls(input_nc, ndf, n_layers_D, num_D=num_D, opt=opt)
     return init_net(net, init_type, init_gain, gpu_ids)
 
 

@@ -1,0 +1,268 @@
+"""pix2pixHD baseline on the HIP path (reference: models/pix2pixHD_model.py).
+
+The reference trains this baseline patch-wise (`return_patch=True`: 32x32 sketch / image / tactile patches,
+batch 32) with the coarse `GlobalGenerator`, two multiscale PatchGAN discriminators (D: sketch ++ image,
+D2: sketch ++ tactile, both with `getIntermFeat`) and the LSGAN objective:
+
+    forward            pix2pixHD_model.py:587-619     G(S) -> fake_I = out[:, :3] * M, fake_T = out[:, -2:] * M_T
+    backward_D         :621-644                        0.5 (D_fake + D_real) + 0.5 (D2_fake + D2_real), one backward
+    backward_G         :646-700                        G_GAN_I + G_GAN_T (+ feature matching + VGG)
+    optimize_parameters :702-722                       D and D2 step, then G step
+
+The GAN feature-matching term of the reference compares every discriminator feature with ITSELF (.detach(),
+:662-680), so its value and gradient are identically zero: it is reported as 0.  The VGG / LPIPS terms need
+pretrained weights that cannot exist offline: requesting them raises (`--no_vgg_loss True` is required).
+"""
+import torch
+
+import util.util as util
+from vts import engine, ops
+from vts.ops import Act
+from vts.optim import FlatAdam, FlatParams
+
+from . import networks
+from .base_model import BaseModel
+from .sinskitG_model import add_model_flags
+
+B = util.str2bool
+
+# (flag, type, default[, choices])  -- reference: pix2pixHD_model.py:45-200
+MODEL_FLAGS = [
+    ("lambda_L1", float, 100.0), ("lr_G2", float, 0.0005), ("sketch_nc", int, 1), ("image_nc", int, 3), ("touch_nc", int, 2),
+    ("data_len", int, 200), ("center_w", int, 1280), ("center_h", int, 960), ("num_touch_patch_for_logging", int, 10),
+    ("use_bg_mask", B, True), ("T_resolution_multiplier", int, 1), ("padded_size", int, 1800), ("sample_bbox_per_patch", int, 2),
+    ("save_S_patch", B, False), ("save_T_concat_tensor", B, False), ("save_raw_arr_vis", B, False), ("scale_nz", float, 0.25),
+    ("return_patch", B, True), ("label_nc", int, 0), ("data_type", int, 32, [8, 16, 32]), ("no_instance", B, True),
+    ("instance_feat", B, False), ("label_feat", B, False), ("feat_num", int, 3), ("load_features", "flag", False),
+    ("n_downsample_E", int, 4), ("nef", int, 16), ("n_clusters", int, 10), ("n_downsample_global", int, 4),
+    ("n_blocks_global", int, 9), ("n_blocks_local", int, 3), ("n_local_enhancers", int, 1), ("niter_fix_global", int, 0),
+    ("getIntermFeat_D", B, True), ("num_D_D1", int, 2), ("num_D_D2", int, 2), ("no_gan_loss", B, False),
+    ("no_ganFeat_loss", B, False), ("no_vgg_loss", B, False), ("lambda_feat", float, 10.0), ("lambda_vgg", float, 10.0),
+    ("niter_decay", int, 100), ("separate_val_set", B, False), ("fp16", "flag", False),
+]
+
+LOSS_SLOTS = ["G_GAN_I", "G_GAN_T", "G_GAN", "D_real", "D_fake", "D2_real", "D2_fake", "G_GAN_Feat", "G_GAN_Feat_I", "G_GAN_Feat_T"]
+
+
+class Pix2PixHDModel(BaseModel):
+    @staticmethod
+    def modify_commandline_options(parser, is_train=True):
+        table = [r for r in MODEL_FLAGS if r[1] != "flag"]
+        add_model_flags(parser, table)
+        for name, _, _ in [r for r in MODEL_FLAGS if r[1] == "flag"]:
+            parser.add_argument("--" + name, action="store_true", default=False)
+        parser.add_argument("--use_hip_graph", type=B, default=True)   # not a reference flag: replay captured HIP graphs
+        parser.set_defaults(norm="batch", netG="global", netD="multiscale", ngf=64, dataset_mode="aligned", dataset="patchskit",
+                            crop_size=1536, normG="instance", normD="instance", pool_size=0, n_epochs=50, n_epcohs_decay=150,
+                            gan_mode="lsgan")
+        verbose_freq = 320
+        if is_train:
+            parser.set_defaults(return_patch=True, batch_size=32, display_freq=verbose_freq, print_freq=verbose_freq,
+                                save_latest_freq=verbose_freq, validation_freq=verbose_freq, save_epoch_freq=50, display_id=0,
+                                save_raw_arr_vis=False)
+        else:
+            parser.set_defaults(return_patch=False, batch_size=1, save_S_patch=True, save_raw_arr_vis=False, sample_bbox_per_patch=1,
+                                data_len=1)
+        return parser
+
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        if not self.gpu_ids or not torch.cuda.is_available():
+            raise RuntimeError("Pix2PixHDModel runs on the MI355X HIP path only (no CPU fallback): pass --gpu_ids 0 on a GPU box")
+        self._check_unbuilt(opt)
+        self.test_edit_S = "edit" in opt.dataroot
+        self.model_names = ["G", "D", "D2"] if self.isTrain else ["G"]
+        self.visual_names = ["real_S", "M", "fake_I", "fake_gx", "fake_gy", "fake_N"]
+        if not self.test_edit_S:
+            self.visual_names.insert(2, "real_I")
+        self.loss_names = []
+        if self.isTrain:
+            if not opt.no_gan_loss:
+                self.loss_names += ["G_GAN_I", "G_GAN_T", "G_GAN", "D_real", "D_fake", "D2_real", "D2_fake"]
+            if not opt.no_ganFeat_loss:
+                self.loss_names += ["G_GAN_Feat", "G_GAN_Feat_I", "G_GAN_Feat_T"]
+        self.criterionGAN = networks.GANLoss(opt.gan_mode)
+        self.netG = networks.define_G(opt.sketch_nc, opt.image_nc + opt.touch_nc, opt.ngf, opt.netG, opt.norm, gpu_ids=self.gpu_ids,
+                                      opt=opt)
+        self.flatG = FlatParams(self.netG)
+        if self.isTrain:
+            self.netD = networks.define_D(opt.image_nc + opt.sketch_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm, num_D=opt.num_D_D1,
+                                          gpu_ids=self.gpu_ids, opt=opt)
+            self.netD2 = networks.define_D(opt.touch_nc + opt.sketch_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm,
+                                           num_D=opt.num_D_D2, gpu_ids=self.gpu_ids, opt=opt)
+            self.flatD, self.flatD2 = FlatParams(self.netD), FlatParams(self.netD2)
+            betas = (opt.beta1, 0.999)
+            self.optimizer_G = FlatAdam(self.flatG, opt.lr, betas)
+            self.optimizer_D = FlatAdam(self.flatD, opt.lr, betas)
+            self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr, betas)
+            self.optimizers += [self.optimizer_G, self.optimizer_D, self.optimizer_D2]
+        self._loss_buf = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
+        self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
+        self._bufs = {}
+        self._graphs = None
+        self._eager_steps_done = 0
+        self.ddp = None
+
+    @staticmethod
+    def _check_unbuilt(opt):
+        bad = []
+        if opt.isTrain and not opt.no_vgg_loss:
+            bad.append("VGG perceptual loss needs pretrained VGG19 weights (--no_vgg_loss True)")
+        if not opt.no_instance or opt.instance_feat or opt.label_feat or opt.label_nc != 0 or opt.load_features:
+            bad.append("instance / label feature inputs (netE) are not built")
+        if opt.netG != "global":
+            bad.append("netG %s (only the coarse 'global' generator is built; LocalEnhancer is not)" % opt.netG)
+        if opt.pool_size > 0 or opt.fp16 or opt.niter_fix_global > 0 or opt.T_resolution_multiplier != 1 or not opt.use_bg_mask:
+            bad.append("pool_size > 0 / fp16 / niter_fix_global / T_resolution_multiplier != 1 / use_bg_mask False")
+        if opt.isTrain and opt.no_gan_loss:
+            bad.append("no_gan_loss")
+        if bad:
+            raise NotImplementedError("pix2pixHD on the HIP path: " + "; ".join(bad))
+
+    # ------------------------------------------------------------------ input
+    def _drop_graphs(self):
+        if self._graphs is not None:
+            self._graphs = None
+            ops.FROZEN_WS = False
+
+    def _load(self, name, host):
+        t = torch.as_tensor(host)
+        buf = self._bufs.get(name)
+        if buf is None or tuple(buf.shape) != tuple(t.shape):
+            buf = self._bufs[name] = torch.empty(tuple(t.shape), dtype=torch.float32, device=self.device)
+            self._drop_graphs()
+        buf.copy_(t.to(torch.float32), non_blocking=True)
+        return buf
+
+    def set_input(self, input, phase="train", timing=False, verbose=False):
+        """pix2pixHD_model.py:431-509: mask multiply; tactile patches reshaped to [N, 2, h, w] and masked."""
+        self.data_phase = phase
+        sk, mk, ik = ("S_images", "M_images", "I_images") if self.opt.return_patch else ("S", "M", "I")
+        S = self._load("S", input[sk])
+        self.M = self._load("M", input[mk])
+        self.name = input["name"]
+        self.image_paths = input["S_paths"]
+        self.augmentation_params = input.get("augmentation_params")
+        self.real_S = ops.mask_mul(S, self.M, out=S)
+        if not self.test_edit_S:
+            I = self._load("I", input[ik])
+            self.real_I = ops.mask_mul(I, self.M, out=I)
+            t = torch.as_tensor(input["T_images"])
+            h, w = t.shape[-2:]
+            T = self._load("T", t.reshape(-1, 2, h, w))
+            masks = self._load("I_masks", torch.as_tensor(input["I_masks"]).reshape(-1, 1, h, w))
+            self.real_T = ops.mask_mul(T, masks, out=T)
+            self.real_gx, self.real_gy = self.real_T[:, 0:1], self.real_T[:, 1:2]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, infer=False, keep=False):
+        n, _, h, w = self.real_S.shape
+        dev = self.device
+        g_out, self._g_ctx = engine.resnet_forward(self.netG, Act(self.real_S), keep=keep)
+        self.g_out = g_out
+        self.fake_I = torch.empty(n, 3, h, w, device=dev)
+        self.fake_T = torch.empty(n, 2, h, w, device=dev)
+        self.fake_N = torch.empty(n, 3, h, w, device=dev)
+        ops.g_post(g_out, self.M, self.opt.scale_nz, fake_I=self.fake_I, fake_T=self.fake_T, fake_N=self.fake_N)
+        self.fake_gx, self.fake_gy = self.fake_T[:, 0:1], self.fake_T[:, 1:2]
+
+    def test(self, timing=False):
+        with torch.no_grad():
+            self.forward(keep=False)
+
+    # ------------------------------------------------------------------ training step
+    def _d_pass(self, net, in0, in1, target_real, slot, accumulate):
+        preds, ctx = engine.msd_forward(net, in0, in1, keep=True)
+        dp = self.criterionGAN.accumulate(preds, target_real, 1.0, slot, grad_coeff=0.5)
+        engine.msd_backward(net, ctx, dp, param_grads=True, accumulate=accumulate)
+
+    def _seg_forward_d(self):
+        slot = self._slot
+        self._loss_buf.zero_()
+        self.forward(keep=True)
+        self._d_pass(self.netD, self.real_S, self.fake_I, False, slot["D_fake"], False)
+        self._d_pass(self.netD, self.real_S, self.real_I, True, slot["D_real"], True)
+        self._d_pass(self.netD2, self.real_S, self.fake_T, False, slot["D2_fake"], False)
+        self._d_pass(self.netD2, self.real_S, self.real_T, True, slot["D2_real"], True)
+
+    def _seg_adam_d_g(self):
+        slot, dev = self._slot, self.device
+        n, _, h, w = self.real_S.shape
+        self.optimizer_D.step(self._gscale)
+        self.optimizer_D2.step(self._gscale)
+        d_fake_I = torch.empty(n, 3, h, w, device=dev)
+        d_fake_T = torch.empty(n, 2, h, w, device=dev)
+        for net, fake, dgrad, s in ((self.netD, self.fake_I, d_fake_I, "G_GAN_I"), (self.netD2, self.fake_T, d_fake_T, "G_GAN_T")):
+            preds, ctx = engine.msd_forward(net, self.real_S, fake, keep=True)
+            dp = self.criterionGAN.accumulate(preds, True, 1.0, slot[s], grad_coeff=1.0)
+            engine.msd_backward(net, ctx, dp, param_grads=False, input_grad=(dgrad, False))
+        slot["G_GAN"].copy_(slot["G_GAN_I"] + slot["G_GAN_T"])
+        d_raw = torch.empty(n, 5, h, w, device=dev)
+        ops.g_out_grad(d_fake_I, d_fake_T, self.M, self.g_out, d_raw)
+        engine.resnet_backward(self.netG, self._g_ctx, d_raw)
+
+    def _seg_adam_g(self):
+        self.optimizer_G.step(self._gscale)
+
+    def _segments(self):
+        """(segment, buckets to wait for before it, buckets to start after it)"""
+        return [(self._seg_forward_d, (), ("D", "D2")), (self._seg_adam_d_g, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
+
+    def _comm(self, name, start):
+        if self.ddp is None or name not in self.ddp.buckets:
+            return
+        b = self.ddp.buckets[name]
+        b.start() if start else b.wait()
+
+    def _capture_graphs(self):
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream()
+        counts = [o.step_count for o in self.optimizers]
+        graphs = []
+        ops.FROZEN_WS = True
+        try:
+            for seg, _, _ in self._segments():
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=stream):
+                    seg()
+                graphs.append(g)
+        except Exception:
+            ops.FROZEN_WS = False
+            raise
+        for o, c in zip(self.optimizers, counts):
+            o.step_count = c
+        self._graphs = graphs
+
+    def optimize_parameters(self, epoch=0, timing=False):
+        self._gscale = self.ddp.grad_scale if self.ddp is not None else 1.0
+        for o in self.optimizers:
+            o.sync_lr()
+        use_graph = bool(getattr(self.opt, "use_hip_graph", False))
+        if use_graph and self._graphs is None and self._eager_steps_done >= 1:
+            self._capture_graphs()
+        replay = use_graph and self._graphs is not None
+        for i, (seg, wait_for, start_after) in enumerate(self._segments()):
+            for nme in wait_for:
+                self._comm(nme, start=False)
+            if replay:
+                self._graphs[i].replay()
+            else:
+                seg()
+            for nme in start_after:
+                self._comm(nme, start=True)
+        if replay:
+            for o in self.optimizers:
+                o.step_count += 1
+        else:
+            self._eager_steps_done += 1
+
+    # ------------------------------------------------------------------ logging
+    def get_current_losses(self):
+        vals = self._loss_buf.cpu().tolist()
+        for i, name in enumerate(LOSS_SLOTS):
+            setattr(self, "loss_" + name, vals[i])
+        return BaseModel.get_current_losses(self)
+
+    def compute_visuals(self):
+        pass
