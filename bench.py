@@ -36,6 +36,9 @@ def build_model(size, batch, model_name, quiet=True, netG="unet256_custom"):
 
     flags = ("--model %s --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
              "--checkpoints_dir /tmp/vts_bench --name bench --crop_size %d --batch_size %d --netG %s" % (model_name, size, batch, netG))
+    if model_name == "pix2pixHD":   # reference defaults (ngf 64, 4 downsamplings, 9 blocks), VGG term off (no weights offline)
+        flags = ("--model pix2pixHD --gpu_ids 0 --no_vgg_loss True --checkpoints_dir /tmp/vts_bench --name bench --batch_size %d "
+                 "--dataset_mode patchskit" % batch)
     ctx = contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()
     with ctx:
         opt = TrainOptions(cmd_line=flags).parse()
@@ -53,6 +56,14 @@ def make_batch(size, batch, rank, style_dim):
     from data.synthetic_dataset import make_sample
 
     return default_collate([make_sample(size, 64, 64, 1234 + 100003 * rank + i, style_dim=style_dim) for i in range(batch)])
+
+
+def make_patch_batch(batch, rank):
+    from torch.utils.data import default_collate
+
+    from data.synthetic_dataset import make_patch_sample
+
+    return default_collate([make_patch_sample(1234 + 100003 * rank + i) for i in range(batch)])
 
 
 def kernel_roofline(model, batch_dict, detail_path=None):
@@ -207,7 +218,7 @@ def main():
     model, opt = build_model(args.size, args.batch, args.model, netG=args.netG)
     opt.use_hip_graph = not args.no_graph
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
-    batch = make_batch(args.size, args.batch, rank, style_dim)
+    batch = make_patch_batch(args.batch, rank) if args.model == "pix2pixHD" else make_batch(args.size, args.batch, rank, style_dim)
     model.set_input(batch, phase="train")       # H2D once: inputs are resident in HBM before the timed region
 
     def barrier():
@@ -243,7 +254,7 @@ def main():
                 torch.cuda.synchronize()
                 model.opt.use_hip_graph = keep
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model != "pix2pixHD":
             cpu = cpu_baseline(args.size, style_dim, netG=args.netG)
         ms = dt / args.steps * 1e3
         out = {
@@ -251,7 +262,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "%s%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
+                "workload": ("pix2pixHD G+D+D2 patch-wise train step (GlobalGenerator ngf 64, ndf 64), %d 32x32 patches/GPU, VGG term off "
+                             "(no weights offline)" % args.batch) if args.model == "pix2pixHD" else
+                            "%s%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
                             "LPIPS/CLIP terms off (no weights offline)" % (args.model, "" if args.netG == "unet256_custom" else " (netG %s)" % args.netG,
                                                                           args.size, args.size, args.batch),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world, "losses_finite": finite,
