@@ -70,12 +70,15 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     """One extra (untimed-for-throughput) step with HIP events around every launch, on the launch stream."""
     from vts import ops
 
+    from vts import engine
     graph_flag, model.opt.use_hip_graph = model.opt.use_hip_graph, False   # per-launch events need eager launches
+    par_flag, engine.PARALLEL_SCALES = engine.PARALLEL_SCALES, False       # ... issued one after the other on one stream
     ops.TIMER = []
     model.optimize_parameters(epoch=1)
     torch.cuda.synchronize()
     rec, ops.TIMER = ops.TIMER, None
     model.opt.use_hip_graph = graph_flag
+    engine.PARALLEL_SCALES = par_flag
     agg, det = {}, {}
     for label, nbytes, flops, e0, e1, detail in rec:
         dt = e0.elapsed_time(e1) * 1e-3

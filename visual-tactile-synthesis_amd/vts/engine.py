@@ -13,6 +13,8 @@ Reference graphs reproduced here:
   NLayerDiscriminator             /root/reference/models/networks.py:1696-1750
 (their backward is PyTorch autograd in the reference).
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -488,6 +490,36 @@ def _pool_act(a):
     return None if a is None else Act(ops.avgpool(a.data))
 
 
+# The scales of a multiscale discriminator are independent chains of small kernels (the D2 passes over 32x32
+# tactile patches never fill 256 CUs): they run concurrently on side HIP streams, forked from and joined back
+# into the launch stream (so the schedule is still a DAG that torch.cuda.CUDAGraph captures as such).
+PARALLEL_SCALES = os.environ.get("VTS_PARALLEL_SCALES", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _run_scales(num, body):
+    """body(s) for s in range(num); scale 0 (the largest) on the current stream, the others on side streams."""
+    if num == 1 or not PARALLEL_SCALES:
+        for s in range(num):
+            body(s)
+        return
+    main = torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    side = _SIDE_STREAMS.get(dev)
+    if side is None or len(side) < num - 1:
+        side = _SIDE_STREAMS[dev] = [torch.cuda.Stream() for _ in range(num - 1)]
+    for st in side[:num - 1]:
+        st.wait_stream(main)
+    for s in range(1, num):
+        ops.WS_LANE = s
+        with torch.cuda.stream(side[s - 1]):
+            body(s)
+    ops.WS_LANE = 0
+    body(0)
+    for st in side[:num - 1]:
+        main.wait_stream(st)
+
+
 def msd_forward(D, in0, in1=None, keep=True, update_stats=True):
     """in0 (++ in1): channel-concatenated input, each a tensor/Act [N,C,H,W].
     Returns (preds: list over scales (full resolution first) of [N,1,h,w], ctx).
@@ -497,9 +529,14 @@ def msd_forward(D, in0, in1=None, keep=True, update_stats=True):
     in1 = _as_act(in1) if in1 is not None else None
     n = in0.data.shape[0]
     dev = in0.data.device
-    preds, scales = [], []
-    a0, a1 = in0, in1
-    for s in range(D.num_D):
+    # the input pyramid first (sequential), then one independent chain per scale
+    pyr = [(in0, in1)]
+    for s in range(1, D.num_D):
+        pyr.append((_pool_act(pyr[-1][0]), _pool_act(pyr[-1][1])))
+    preds, scales = [None] * D.num_D, [None] * D.num_D
+
+    def scale_fwd(s):
+        a0, a1 = pyr[s]
         layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
         acts = []
         cur0, cur1 = a0, a1
@@ -523,10 +560,10 @@ def msd_forward(D, in0, in1=None, keep=True, update_stats=True):
             acts.append(a)
             cur0, cur1 = a, None
             h, w = oh, ow
-        preds.append(acts[-1].data)
-        scales.append((a0, a1, acts))
-        if s != D.num_D - 1:
-            a0, a1 = _pool_act(a0), _pool_act(a1)
+        preds[s] = acts[-1].data
+        scales[s] = (a0, a1, acts)
+
+    _run_scales(D.num_D, scale_fwd)
     if not keep:
         return preds, None
     ctx = MsdCtx()
@@ -541,8 +578,9 @@ def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=
     (the second concat source: fake_I in the G step), summed over the pyramid."""
     n = dpreds[0].shape[0]
     dev = dpreds[0].device
-    din_scales = []
-    for s in range(D.num_D):
+    din_scales = [None] * D.num_D
+
+    def scale_bwd(s):
         layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
         a0, a1, acts = ctx.scales[s]
         g = dpreds[s]
@@ -572,7 +610,9 @@ def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=
                 c1 = a1.data.shape[1]
                 tgt = torch.empty_like(a1.data)
                 ops.conv4x4(Act(g), conv.weight.view(-1)[c0 * 16:], 16, cin * 16, c1, tgt, stride=st, pad=2, transposed=True)
-                din_scales.append(tgt)
+                din_scales[s] = tgt
+
+    _run_scales(D.num_D, scale_bwd)
     if input_grad is not None:
         dst, acc = input_grad
         # d in1 = d0 + pool^T(d1 + pool^T(d2 ...))

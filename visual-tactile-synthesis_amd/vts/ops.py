@@ -60,18 +60,21 @@ _ws = {}
 
 def workspace(nfloats, device):
     """Grow-only scratch; safe to share because every kernel runs in stream order."""
-    key = str(device)
+    key = (str(device), WS_LANE)   # one scratch per concurrent lane (scale-parallel discriminator passes run on side streams)
     t = _ws.get(key)
     if t is None or t.numel() < nfloats:
-        if FROZEN_WS:
-            raise RuntimeError("workspace would have to grow (%d -> %d floats) while captured HIP graphs reference it; "
-                               "run one eager step with the new shapes first" % (0 if t is None else t.numel(), nfloats))
-        t = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+        if t is not None and FROZEN_WS:
+            _retired.append(t)   # captured HIP graphs hold the old pointer: keep that buffer alive, never reuse it
+        t = torch.empty(max(int(nfloats), 2 * (t.numel() if t is not None else 0), 1 << 20), dtype=torch.float32, device=device)
         _ws[key] = t
     return t
 
 
+_retired = []
+
+
 FROZEN_WS = False  # set while HIP graphs that captured the workspace pointer are alive
+WS_LANE = 0        # which scratch buffer the wrappers use: 0 = the launch stream, s = side stream s (engine._run_scales)
 
 
 def _op(a):
