@@ -182,7 +182,7 @@ class SinSKITGModel(BaseModel):
         self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
         self._spe_cache = {}
         self._bufs = {}         # persistent input buffers (stable addresses for captured HIP graphs)
-        self._graphs = None     # the five captured segments of the step, or None
+        self._graphs = None     # the captured segments of the step, or None
         self._eager_steps_done = 0
         self._draws = None      # tests / parity runs inject {"aug": [4,N], "more_idx": [N,K]}
         self.ddp = None
@@ -368,10 +368,10 @@ class SinSKITGModel(BaseModel):
             engine.msd_backward(net, ctx, dp, param_grads=True, accumulate=accumulate)
         return preds
 
-    # The step is cut into five segments at the points where a data-parallel run exchanges gradients.
+    # The step is cut into segments at the points where a data-parallel run exchanges gradients.
     # Each segment is pure device work on persistent buffers, so it can run eagerly or be replayed
     # from a captured HIP graph (optimize_parameters below).
-    def _seg_forward_d1(self):
+    def _forward_and_stacks(self):
         opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
         P = ts["real_T"].shape[0]
         self._loss_buf.zero_()
@@ -390,75 +390,86 @@ class SinSKITGModel(BaseModel):
         self.fake_T_concat = torch.empty(P, 2, 32, 32, device=dev)
         self._gather(self.fake_T, ts, self.fake_T_concat, 0, channels=2)
         self._fake_stack, self._real_stack = fake_stack, real_stack
-        # D1 update (compute_D1_loss)
-        if "D" in self.model_names:
+
+    def _seg_d_updates(self):
+        """forward, then the D1 (full resolution) and D2 (32x32 patches) updates: all scales of both discriminators run
+        side by side (engine.msd_multi); within one discriminator the passes keep the reference's order."""
+        self._forward_and_stacks()
+        opt, dev, slot = self.opt, self.device, self._slot
+        jobs = []
+        p_fake_I = p_full = None
+        if "D" in self.model_names:      # compute_D1_loss
             lam = opt.lambda_G1_GAN
-            preds = self._d_pass(self.netD, self.real_S, self.fake_I, False, lam, slot["D_fake_I"], accumulate=False)
-            self.pred_fake_I = preds[-1]
-            self._d_pass(self.netD, self.real_S, self.real_I, True, lam, slot["D_real_I"], accumulate=True)
+            p_fake_I = dict(in0=self.real_S, in1=self.fake_I, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)
+            jobs.append((self.netD, [p_fake_I, dict(in0=self.real_S, in1=self.real_I, real=True, coeff=lam, slot=slot["D_real_I"],
+                                                    grad_coeff=0.5 * lam, accumulate=True)]))
+        if "D2" in self.model_names:     # compute_D2_loss
+            n = self.real_S.shape[0]
+            lam2 = opt.lambda_G2_GAN
+            passes = [dict(in0=self._fake_stack, real=False, coeff=lam2, slot=slot["D_fake_T_concat"], grad_coeff=0.5 * lam2)]
+            # full-resolution pass: visualisation only, but it advances the BatchNorm running statistics
+            self._full_stack[:, 2:3].copy_(self.real_S)
+            self._full_stack[:, 6:7].copy_(self.M)
+            p_full = dict(in0=self._full_stack, loss=False)
+            passes.append(p_full)
+            if opt.use_more_fakeT:
+                k = opt.add_fake_T_sample_size
+                h, w = self.real_S.shape[2:]
+                mox, moy = ops.mask_select(self._cand, self._cand_prefix, self._ranks, h, w)
+                self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
+                more = torch.empty(n * k, 7, 32, 32, device=dev)
+                mset = dict(img=self._more_img, offx=mox, offy=moy)
+                self._gather(self.fake_T, mset, more, 0, channels=2)
+                self._gather(self.real_S, mset, more, 2)
+                self._gather(self.fake_I, mset, more, 3)
+                more[:, 6:7].fill_(1.0)
+                passes.append(dict(in0=more, real=False, coeff=lam2, slot=slot["D_more_fake_T"], grad_coeff=0.5 * lam2, accumulate=True))
+            passes.append(dict(in0=self._real_stack, real=True, coeff=lam2, slot=slot["D_real_T_concat"], grad_coeff=0.5 * lam2,
+                               accumulate=True))
+            jobs.append((self.netD2, passes))
+        engine.msd_multi(jobs, self.criterionGAN)
+        if p_fake_I is not None:
+            self.pred_fake_I = p_fake_I["preds"][-1]
+        if p_full is not None:
+            self.pred_fake_T_full = p_full["preds"][-1]
 
-    def _seg_d2(self):
-        opt, dev, slot = self.opt, self.device, self._slot
-        if "D2" not in self.model_names:
-            return
-        n = self.real_S.shape[0]
-        lam2 = opt.lambda_G2_GAN
-        self._d_pass(self.netD2, self._fake_stack, None, False, lam2, slot["D_fake_T_concat"], accumulate=False)
-        # full-resolution pass: visualisation only, but it advances the BatchNorm running statistics
-        self._full_stack[:, 2:3].copy_(self.real_S)
-        self._full_stack[:, 6:7].copy_(self.M)
-        preds_full, _ = engine.msd_forward(self.netD2, self._full_stack, None, keep=False)
-        self.pred_fake_T_full = preds_full[-1]
-        if opt.use_more_fakeT:
-            k = opt.add_fake_T_sample_size
-            h, w = self.real_S.shape[2:]
-            mox, moy = ops.mask_select(self._cand, self._cand_prefix, self._ranks, h, w)
-            self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
-            more = torch.empty(n * k, 7, 32, 32, device=dev)
-            mset = dict(img=self._more_img, offx=mox, offy=moy)
-            self._gather(self.fake_T, mset, more, 0, channels=2)
-            self._gather(self.real_S, mset, more, 2)
-            self._gather(self.fake_I, mset, more, 3)
-            more[:, 6:7].fill_(1.0)
-            self._d_pass(self.netD2, more, None, False, lam2, slot["D_more_fake_T"], accumulate=True)
-        self._d_pass(self.netD2, self._real_stack, None, True, lam2, slot["D_real_T_concat"], accumulate=True)
-
-    def _seg_adam_d_g1(self):
-        opt, dev, slot = self.opt, self.device, self._slot
+    def _seg_g_update(self):
+        """Adam for D / D2, then the generator's loss terms (compute_G1_loss / compute_G2_loss) and its backward"""
+        opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
         n, _, h, w = self.real_S.shape
-        if "D" in self.model_names:
-            self.optimizer_D.step(self._gscale)
-        # G update, first half (compute_G1_loss)
+        nt, P = ts["NT"], ts["real_T"].shape[0]
+        jobs = []
         self._d_fake_I = torch.empty(n, 3, h, w, device=dev)
         have = False
         if "D" in self.model_names:
+            self.optimizer_D.step(self._gscale)
             lam = opt.lambda_G1_GAN
-            preds, ctx = engine.msd_forward(self.netD, self.real_S, self.fake_I, keep=True)
-            dp = self.criterionGAN.accumulate(preds, True, lam, slot["G_GAN"], grad_coeff=lam)
-            engine.msd_backward(self.netD, ctx, dp, param_grads=False, input_grad=(self._d_fake_I, False))
+            jobs.append((self.netD, [dict(in0=self.real_S, in1=self.fake_I, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
+                                          param_grads=False, input_grad=(self._d_fake_I, False))]))
             have = True
+        if "D2" in self.model_names:
+            self.optimizer_D2.step(self._gscale)
+            # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
+            jobs.append((self.netD2, [dict(in0=self._fake_stack, real=True, coeff=opt.lambda_G2_GAN * nt, slot=slot["G2_GAN"])]))
+        if jobs:
+            engine.msd_multi(jobs, self.criterionGAN)
         if opt.lambda_G1_L1 > 0.0:
             ops.l1(self.fake_I, self.real_I, opt.lambda_G1_L1 / self.fake_I.numel(), slot["G_L1"], self._d_fake_I, accumulate=have)
             have = True
         self._have_dI = have
-
-    def _seg_adam_d2_g2(self):
-        opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
-        n, _, h, w = self.real_S.shape
-        nt, P = ts["NT"], ts["real_T"].shape[0]
-        if "D2" in self.model_names:
-            self.optimizer_D2.step(self._gscale)
-            # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
-            preds, _ = engine.msd_forward(self.netD2, self._fake_stack, None, keep=False)
-            self.criterionGAN.accumulate(preds, True, opt.lambda_G2_GAN * nt, slot["G2_GAN"], want_grad=False)
         d_fake_T = None
         if opt.lambda_G2_L1 > 0.0:
             d_patch = torch.empty(P, 2, 32, 32, device=dev)
             ops.l1(self.fake_T_concat, ts["real_T"], opt.lambda_G2_L1 / (n * 2 * 32 * 32), slot["G2_L1"], d_patch)
             d_fake_T = torch.empty(n, 2, h, w, device=dev)
             ops.patch_scatter_bwd(d_patch, 0, 2, ts["offx"], ts["offy"], nt, 32, d_fake_T)
-        d_raw = torch.empty(n, 5, h, w, device=dev)
-        ops.g_out_grad(self._d_fake_I if self._have_dI else None, d_fake_T, self.M, self.g_out, d_raw)
+        self._d_fake_T = d_fake_T
+        self._g_backward()
+
+    def _g_backward(self):
+        n, _, h, w = self.real_S.shape
+        d_raw = torch.empty(n, 5, h, w, device=self.device)
+        ops.g_out_grad(self._d_fake_I if self._have_dI else None, self._d_fake_T, self.M, self.g_out, d_raw)
         if isinstance(self.netG, networks.ResnetGenerator):
             engine.resnet_backward(self.netG, self._g_ctx, d_raw)
         else:
@@ -468,9 +479,8 @@ class SinSKITGModel(BaseModel):
         self.optimizer_G.step(self._gscale)
 
     def _segments(self):
-        """(segment, bucket to wait for before it, bucket to start after it)"""
-        return [(self._seg_forward_d1, None, "D"), (self._seg_d2, None, "D2"), (self._seg_adam_d_g1, "D", None),
-                (self._seg_adam_d2_g2, "D2", "G"), (self._seg_adam_g, "G", None)]
+        """(segment, buckets to wait for before it, buckets to start after it)"""
+        return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_update, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
 
     def _comm(self, name, start):
         if self.ddp is None or name not in self.ddp.buckets:
@@ -484,7 +494,7 @@ class SinSKITGModel(BaseModel):
             ops.FROZEN_WS = False
 
     def _capture_graphs(self):
-        """Capture the five segments as HIP graphs sharing one memory pool (torch.cuda.CUDAGraph over
+        """Capture the segments as HIP graphs sharing one memory pool (torch.cuda.CUDAGraph over
         the launch stream our ctypes kernels use).  Capturing records work without executing it."""
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
@@ -517,14 +527,14 @@ class SinSKITGModel(BaseModel):
             self._capture_graphs()
         replay = use_graph and self._graphs is not None
         for i, (seg, wait_for, start_after) in enumerate(self._segments()):
-            if wait_for:
-                self._comm(wait_for, start=False)
+            for nme in wait_for:
+                self._comm(nme, start=False)
             if replay:
                 self._graphs[i].replay()
             else:
                 seg()
-            if start_after:
-                self._comm(start_after, start=True)
+            for nme in start_after:
+                self._comm(nme, start=True)
         if replay:
             for o in self.optimizers:
                 o.step_count += 1

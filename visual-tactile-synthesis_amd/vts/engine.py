@@ -497,27 +497,113 @@ PARALLEL_SCALES = os.environ.get("VTS_PARALLEL_SCALES", "1") != "0"
 _SIDE_STREAMS = {}
 
 
-def _run_scales(num, body):
-    """body(s) for s in range(num); scale 0 (the largest) on the current stream, the others on side streams."""
-    if num == 1 or not PARALLEL_SCALES:
-        for s in range(num):
-            body(s)
+def _run_lanes(n_lanes, body):
+    """body(lane) for lane in range(n_lanes): lane 0 on the current stream, the others on side streams forked
+    from it and joined back into it (a flat fork: nested forks made hipStreamEndCapture crash), each with its own
+    scratch buffer.  The discriminator scales -- and the D1 / D2 updates of one step -- are independent chains
+    of mostly small kernels; run side by side they fill the CUs that one chain leaves idle, and the schedule
+    is still a DAG that torch.cuda.CUDAGraph captures as such."""
+    if n_lanes == 1 or not PARALLEL_SCALES:
+        for lane in range(n_lanes):
+            body(lane)
         return
     main = torch.cuda.current_stream()
     dev = torch.cuda.current_device()
-    side = _SIDE_STREAMS.get(dev)
-    if side is None or len(side) < num - 1:
-        side = _SIDE_STREAMS[dev] = [torch.cuda.Stream() for _ in range(num - 1)]
-    for st in side[:num - 1]:
+    side = _SIDE_STREAMS.setdefault(dev, [])
+    while len(side) < n_lanes - 1:
+        side.append(torch.cuda.Stream())
+    for st in side[:n_lanes - 1]:
         st.wait_stream(main)
-    for s in range(1, num):
-        ops.WS_LANE = s
-        with torch.cuda.stream(side[s - 1]):
-            body(s)
+    for lane in range(1, n_lanes):
+        ops.WS_LANE = lane
+        with torch.cuda.stream(side[lane - 1]):
+            body(lane)
     ops.WS_LANE = 0
     body(0)
-    for st in side[:num - 1]:
+    for st in side[:n_lanes - 1]:
         main.wait_stream(st)
+
+
+def _pyramid(D, in0, in1):
+    in0 = _as_act(in0)
+    in1 = _as_act(in1) if in1 is not None else None
+    pyr = [(in0, in1)]
+    for s in range(1, D.num_D):
+        pyr.append((_pool_act(pyr[-1][0]), _pool_act(pyr[-1][1])))
+    return pyr
+
+
+def _msd_scale_forward(D, s, a0, a1, update_stats):
+    """one PatchGAN of the pyramid: returns the list of layer outputs (Act), the last one is the prediction"""
+    n, dev = a0.data.shape[0], a0.data.device
+    layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
+    acts = []
+    cur0, cur1 = a0, a1
+    h, w = cur0.data.shape[2], cur0.data.shape[3]
+    for j, ci in enumerate(D.CONV_IDX):
+        conv = getattr(layer, str(ci))
+        st = D.STRIDE[ci]
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        oh, ow = (h + 4 - 4) // st + 1, (w + 4 - 4) // st + 1
+        out = _empty(n, cout, oh, ow, dev)
+        ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
+                    act_in=LRELU if j else 0)
+        if ci in D.BN_IDX:
+            bn = getattr(layer, str(D.BN_IDX[ci]))
+            a = ops.norm_stats(out, 1, gamma=bn.weight, beta=bn.bias,
+                               running_mean=bn.running_mean if update_stats else None,
+                               running_var=bn.running_var if update_stats else None,
+                               nbt=bn.num_batches_tracked if update_stats else None)
+        else:
+            a = Act(out)
+        acts.append(a)
+        cur0, cur1 = a, None
+        h, w = oh, ow
+    return acts
+
+
+def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad):
+    """backward of one PatchGAN; returns the gradient w.r.t. the second concat source (or None)"""
+    layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
+    for j in range(len(D.CONV_IDX) - 1, -1, -1):
+        ci = D.CONV_IDX[j]
+        conv = getattr(layer, str(ci))
+        st = D.STRIDE[ci]
+        cin = conv.weight.shape[1]
+        if ci in D.BN_IDX:
+            bn = getattr(layer, str(D.BN_IDX[ci]))
+            ops.norm_bwd(g, acts[j], 1, gamma=bn.weight, dgamma=bn.weight.grad if param_grads else None,
+                         dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate)
+        src0, src1 = (a0, a1) if j == 0 else (acts[j - 1], None)
+        if param_grads:
+            ops.wgrad4x4(Act(g), src0, conv.weight.grad, hi1=src1, act_hi=LRELU if j else 0, stride=st, pad=2,
+                         accumulate=accumulate)
+            if ci not in D.BN_IDX:   # a conv bias in front of a BatchNorm has an identically zero gradient
+                ops.channel_sum(g, conv.bias.grad, accumulate=accumulate)
+        if j > 0:
+            prev = acts[j - 1]
+            tgt = torch.empty_like(prev.data)
+            ops.conv4x4(Act(g), conv.weight, 16, cin * 16, cin, tgt, stride=st, pad=2, transposed=True, dmask=prev,
+                        dmask_act=LRELU)
+            g = tgt
+        elif want_input_grad:
+            c0 = a0.data.shape[1]
+            c1 = a1.data.shape[1]
+            tgt = torch.empty_like(a1.data)
+            ops.conv4x4(Act(g), conv.weight.view(-1)[c0 * 16:], 16, cin * 16, c1, tgt, stride=st, pad=2, transposed=True)
+            return tgt
+    return None
+
+
+def _merge_input_grads(din_scales, input_grad):
+    """d in1 = d0 + pool^T(d1 + pool^T(d2 ...)) into input_grad = (tensor, accumulate?)"""
+    dst, acc = input_grad
+    for s in range(len(din_scales) - 1, 0, -1):
+        ops.avgpool_bwd(din_scales[s], din_scales[s - 1], accumulate=True)
+    if acc:
+        dst.add_(din_scales[0])
+    else:
+        dst.copy_(din_scales[0])
 
 
 def msd_forward(D, in0, in1=None, keep=True, update_stats=True):
@@ -525,45 +611,14 @@ def msd_forward(D, in0, in1=None, keep=True, update_stats=True):
     Returns (preds: list over scales (full resolution first) of [N,1,h,w], ctx).
     BatchNorm runs in training mode (batch statistics); running buffers are updated when
     update_stats (every reference D call in a train step does: sinskitG_model.py:1361,1374,1490,...)."""
-    in0 = _as_act(in0)
-    in1 = _as_act(in1) if in1 is not None else None
-    n = in0.data.shape[0]
-    dev = in0.data.device
-    # the input pyramid first (sequential), then one independent chain per scale
-    pyr = [(in0, in1)]
-    for s in range(1, D.num_D):
-        pyr.append((_pool_act(pyr[-1][0]), _pool_act(pyr[-1][1])))
-    preds, scales = [None] * D.num_D, [None] * D.num_D
+    pyr = _pyramid(D, in0, in1)
+    scales = [None] * D.num_D
 
-    def scale_fwd(s):
-        a0, a1 = pyr[s]
-        layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
-        acts = []
-        cur0, cur1 = a0, a1
-        h, w = cur0.data.shape[2], cur0.data.shape[3]
-        for j, ci in enumerate(D.CONV_IDX):
-            conv = getattr(layer, str(ci))
-            st = D.STRIDE[ci]
-            cout, cin = conv.weight.shape[0], conv.weight.shape[1]
-            oh, ow = (h + 4 - 4) // st + 1, (w + 4 - 4) // st + 1
-            out = _empty(n, cout, oh, ow, dev)
-            ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
-                        act_in=LRELU if j else 0)
-            if ci in D.BN_IDX:
-                bn = getattr(layer, str(D.BN_IDX[ci]))
-                a = ops.norm_stats(out, 1, gamma=bn.weight, beta=bn.bias,
-                                   running_mean=bn.running_mean if update_stats else None,
-                                   running_var=bn.running_var if update_stats else None,
-                                   nbt=bn.num_batches_tracked if update_stats else None)
-            else:
-                a = Act(out)
-            acts.append(a)
-            cur0, cur1 = a, None
-            h, w = oh, ow
-        preds[s] = acts[-1].data
-        scales[s] = (a0, a1, acts)
+    def lane(s):
+        scales[s] = (pyr[s][0], pyr[s][1], _msd_scale_forward(D, s, pyr[s][0], pyr[s][1], update_stats))
 
-    _run_scales(D.num_D, scale_fwd)
+    _run_lanes(D.num_D, lane)
+    preds = [sc[2][-1].data for sc in scales]
     if not keep:
         return preds, None
     ctx = MsdCtx()
@@ -576,50 +631,53 @@ def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=
     param_grads: write (accumulate=False) or add (accumulate=True) into every parameter's .grad.
     input_grad: None, or (tensor [N,C1,H,W], accumulate_flag) receiving the gradient wrt `in1`
     (the second concat source: fake_I in the G step), summed over the pyramid."""
-    n = dpreds[0].shape[0]
-    dev = dpreds[0].device
     din_scales = [None] * D.num_D
 
-    def scale_bwd(s):
-        layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
+    def lane(s):
         a0, a1, acts = ctx.scales[s]
-        g = dpreds[s]
-        for j in range(len(D.CONV_IDX) - 1, -1, -1):
-            ci = D.CONV_IDX[j]
-            conv = getattr(layer, str(ci))
-            st = D.STRIDE[ci]
-            cout, cin = conv.weight.shape[0], conv.weight.shape[1]
-            if ci in D.BN_IDX:
-                bn = getattr(layer, str(D.BN_IDX[ci]))
-                ops.norm_bwd(g, acts[j], 1, gamma=bn.weight, dgamma=bn.weight.grad if param_grads else None,
-                             dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate)
-            src0, src1 = (a0, a1) if j == 0 else (acts[j - 1], None)
-            if param_grads:
-                ops.wgrad4x4(Act(g), src0, conv.weight.grad, hi1=src1, act_hi=LRELU if j else 0, stride=st, pad=2,
-                             accumulate=accumulate)
-                if ci not in D.BN_IDX:   # a conv bias in front of a BatchNorm has an identically zero gradient
-                    ops.channel_sum(g, conv.bias.grad, accumulate=accumulate)
-            if j > 0:
-                prev = acts[j - 1]
-                tgt = torch.empty_like(prev.data)
-                ops.conv4x4(Act(g), conv.weight, 16, cin * 16, cin, tgt, stride=st, pad=2, transposed=True, dmask=prev,
-                            dmask_act=LRELU)
-                g = tgt
-            elif input_grad is not None:
-                c0 = a0.data.shape[1]
-                c1 = a1.data.shape[1]
-                tgt = torch.empty_like(a1.data)
-                ops.conv4x4(Act(g), conv.weight.view(-1)[c0 * 16:], 16, cin * 16, c1, tgt, stride=st, pad=2, transposed=True)
-                din_scales[s] = tgt
+        din_scales[s] = _msd_scale_backward(D, s, a0, a1, acts, dpreds[s], param_grads, accumulate, input_grad is not None)
 
-    _run_scales(D.num_D, scale_bwd)
+    _run_lanes(D.num_D, lane)
     if input_grad is not None:
-        dst, acc = input_grad
-        # d in1 = d0 + pool^T(d1 + pool^T(d2 ...))
-        for s in range(D.num_D - 1, 0, -1):
-            ops.avgpool_bwd(din_scales[s], din_scales[s - 1], accumulate=True)
-        if acc:
-            dst.add_(din_scales[0])
-        else:
-            dst.copy_(din_scales[0])
+        _merge_input_grads(din_scales, input_grad)
     return None
+
+
+def msd_multi(jobs, criterion):
+    """Several discriminators' passes of one training phase, all scales of all of them side by side.
+
+    jobs: [(D, [pass, ...]), ...]; the passes of one D run in order (BatchNorm running statistics and gradient
+    accumulation are order dependent), different D's and different scales are independent lanes.
+    pass: dict(in0, in1=None, real: bool, coeff, slot, grad_coeff=None (None: no gradient / no backward),
+               param_grads=True, accumulate=False, input_grad=None, loss=True); `preds` is filled in.
+    The first job's first scale (put the full-resolution discriminator first) runs on the launch stream."""
+    lanes = []
+    for D, passes in jobs:
+        for p in passes:
+            p["_pyr"] = _pyramid(D, p["in0"], p.get("in1"))
+            p["preds"] = [None] * D.num_D
+            p["_din"] = [None] * D.num_D
+        for s in range(D.num_D):
+            lanes.append((D, s, passes))
+
+    def lane(i):
+        D, s, passes = lanes[i]
+        for p in passes:
+            a0, a1 = p["_pyr"][s]
+            acts = _msd_scale_forward(D, s, a0, a1, True)
+            pred = acts[-1].data
+            p["preds"][s] = pred
+            if not p.get("loss", True):
+                continue
+            gc = p.get("grad_coeff")
+            g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None)[0]
+            if gc is not None:
+                p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
+                                                   p.get("input_grad") is not None)
+
+    _run_lanes(len(lanes), lane)
+    for D, passes in jobs:
+        for p in passes:
+            if p.get("input_grad") is not None:
+                _merge_input_grads(p["_din"], p["input_grad"])
+            p.pop("_pyr"), p.pop("_din")

@@ -60,7 +60,7 @@ _ws = {}
 
 def workspace(nfloats, device):
     """Grow-only scratch; safe to share because every kernel runs in stream order."""
-    key = (str(device), WS_LANE)   # one scratch per concurrent lane (scale-parallel discriminator passes run on side streams)
+    key = (str(device), WS_BASE + WS_LANE)   # one scratch per concurrent lane (branches / scale-parallel discriminator passes)
     t = _ws.get(key)
     if t is None or t.numel() < nfloats:
         if t is not None and FROZEN_WS:
@@ -75,6 +75,7 @@ _retired = []
 
 FROZEN_WS = False  # set while HIP graphs that captured the workspace pointer are alive
 WS_LANE = 0        # which scratch buffer the wrappers use: 0 = the launch stream, s = side stream s (engine._run_scales)
+WS_BASE = 0        # ... offset of the concurrent branch that is being enqueued (engine.Branch)
 
 
 def _op(a):
