@@ -117,6 +117,7 @@ def unet_backward(G, ctx, d_raw):
     n = d_raw.shape[0]
     dev = d_raw.device
     feats = ctx.feats
+    sq = SideQueue()         # weight / bias gradients: off the critical path
     dfeat = [None] * nd      # grad wrt the normalised feats[i] (pre-activation), accumulated over consumers
     dx = {}                  # id(Act) of an up-output -> grad wrt its normalised value
 
@@ -144,9 +145,9 @@ def unet_backward(G, ctx, d_raw):
             gop = Act(g)
             gsum_src = g
             second = skip if skip is not None else extra
-            ops.wgrad4x4(inp, gop, blk.weight.grad, lo1=second, act_lo=RELU, stride=2, pad=1)
+            sq.run(lambda: ops.wgrad4x4(inp, gop, blk.weight.grad, lo1=second, act_lo=RELU, stride=2, pad=1), g)
             if i == 0:
-                ops.channel_sum(gsum_src, blk.bias.grad)
+                sq.run(lambda: ops.channel_sum(gsum_src, blk.bias.grad), g)
             # else: the bias feeds an InstanceNorm, so its gradient is identically zero (the norm removes any
             # per-channel constant).  The reference computes ~1e-9 rounding noise there; the flat gradient
             # buffer is zero-initialised and this slot is never written, i.e. exactly 0.
@@ -169,15 +170,16 @@ def unet_backward(G, ctx, d_raw):
         if 0 < i < nd - 1:
             ops.norm_bwd(g, feats[i], 0)
         src, src1 = ctx.x if i == 0 else (feats[i - 1], None)
-        ops.wgrad4x4(Act(g), src, blk.weight.grad, hi1=src1, act_hi=LRELU if i else 0, stride=2, pad=1)
+        sq.run(lambda: ops.wgrad4x4(Act(g), src, blk.weight.grad, hi1=src1, act_hi=LRELU if i else 0, stride=2, pad=1), g)
         if not (0 < i < nd - 1):
-            ops.channel_sum(g, blk.bias.grad)   # bias gradients of normalised layers are identically zero (see above)
+            sq.run(lambda: ops.channel_sum(g, blk.bias.grad), g)   # bias gradients of normalised layers are identically zero (see above)
         if i > 0:
             cin = blk.weight.shape[1]
             tgt, acc = add_grad_list(dfeat, i - 1, feats[i - 1].data.shape, dev)
             ops.conv4x4(Act(g), blk.weight, 16, cin * 16, cin, tgt, stride=2, pad=1, transposed=True, dmask=feats[i - 1],
                         dmask_act=LRELU, accumulate=acc)
         dfeat[i] = None
+    sq.join()
 
 
 # -------------------------------------------------------------------------------------
@@ -495,6 +497,38 @@ def _pool_act(a):
 # into the launch stream (so the schedule is still a DAG that torch.cuda.CUDAGraph captures as such).
 PARALLEL_SCALES = os.environ.get("VTS_PARALLEL_SCALES", "1") != "0"
 _SIDE_STREAMS = {}
+
+
+class SideQueue:
+    """Work that nothing on the launch stream waits for until the end of a phase -- the weight / bias gradients of a
+    backward pass (28 % of the step's kernel time, all of it off the critical path of the backward-data chain) --
+    is enqueued on one side stream: `run` forks at the current point of the launch stream (the operands are ready
+    there) and keeps the operand tensors alive; `join` makes the launch stream wait once, at the end."""
+    LANE = 7
+
+    def __init__(self):
+        self.main = torch.cuda.current_stream()
+        side = _SIDE_STREAMS.setdefault(torch.cuda.current_device(), [])
+        while len(side) < SideQueue.LANE:
+            side.append(torch.cuda.Stream())
+        self.stream = side[SideQueue.LANE - 1]
+        self.keep = []
+        self.on = PARALLEL_SCALES
+
+    def run(self, fn, *tensors):
+        if not self.on:
+            return fn()
+        self.stream.wait_stream(self.main)
+        lane, ops.WS_LANE = ops.WS_LANE, SideQueue.LANE
+        with torch.cuda.stream(self.stream):
+            fn()
+        ops.WS_LANE = lane
+        self.keep.extend(tensors)
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.stream)
+        self.keep = []
 
 
 def _run_lanes(n_lanes, body):
