@@ -72,37 +72,42 @@ def unet_forward(G, x, style_code=None, keep=True):
         style = style_code.to(torch.float32)
     g_out = _empty(n, 5, h, w, dev)
     ups = {}
-    xm, xt = feats[nd - 1], None
-    for i in range(nd - 1, -1, -1):
+    extras = {}
+    for i in range(nd):
+        if style is not None and i >= nd - G.num_layer_style_code:
+            if i not in (0, nd - 1):
+                raise NotImplementedError("style code on a skip-connected layer needs a third concat source")
+            extras[i] = Act(style[:, :, None, None].expand(-1, -1, h >> (i + 1), w >> (i + 1)).contiguous())
+
+    def up(i, name, inp):
         hh, ww = h >> (i + 1), w >> (i + 1)
         skip = None if i in (0, nd - 1) else feats[i]
-        extra = None
-        if style is not None and i >= nd - G.num_layer_style_code:
-            if skip is not None:
-                raise NotImplementedError("style code on a skip-connected layer needs a third concat source")
-            extra = Act(style[:, :, None, None].expand(-1, -1, hh, ww).contiguous())
+        extra = extras.get(i)
+        blk = getattr(G, name).conv
+        outer = blk.weight.shape[1]
+        if i == 0:
+            c0 = 0 if name == "up0" else 3
+            out = g_out[:, c0:c0 + outer]
+        else:
+            out = _empty(n, outer, hh * 2, ww * 2, dev)
+        ops.conv4x4(inp, blk.weight, 16, outer * 16, outer, out, in1=skip if skip is not None else extra, bias=blk.bias,
+                    stride=2, pad=1, transposed=True, act_in=RELU, act_out=TANH if i == 0 else 0)
+        res = Act(out) if i == 0 else ops.norm_stats(out, 0)
+        ups[name] = (inp, res, extra)
+        return res
 
-        def up(name, inp):
-            blk = getattr(G, name).conv
-            outer = blk.weight.shape[1]
-            if i == 0:
-                c0 = 0 if name == "up0" else 3
-                out = g_out[:, c0:c0 + outer]
-            else:
-                out = _empty(n, outer, hh * 2, ww * 2, dev)
-            ops.conv4x4(inp, blk.weight, 16, outer * 16, outer, out, in1=skip if skip is not None else extra, bias=blk.bias,
-                        stride=2, pad=1, transposed=True, act_in=RELU, act_out=TANH if i == 0 else 0)
-            return Act(out) if i == 0 else ops.norm_stats(out, 0)
+    nls = G.num_layer_separate
+    xm = feats[nd - 1]
+    for i in range(nd - 1, nls - 1, -1):      # shared trunk
+        xm = up(i, "up%d" % i, xm)
 
-        if G.num_layer_separate >= i + 1:
-            if xt is None:
-                xt = xm
-            xt_new = up("up%d_T" % i, xt)
-            ups["up%d_T" % i] = (xt, xt_new, extra)
-            xt = xt_new
-        xm_new = up("up%d" % i, xm)
-        ups["up%d" % i] = (xm, xm_new, extra)
-        xm = xm_new
+    def chain(lane):                          # the visual (lane 0) and tactile (lane 1) decoders are independent chains
+        x = xm
+        for i in range(nls - 1, -1, -1):
+            x = up(i, "up%d%s" % (i, "_T" if lane else ""), x)
+
+    if nls > 0:
+        _run_lanes(2, chain)
     if not keep:
         return g_out, None
     ctx = UnetCtx()
@@ -129,40 +134,69 @@ def unet_backward(G, ctx, d_raw):
         store[key] = t
         return t, False
 
-    for i in range(nd):
-        names = ["up%d" % i] + (["up%d_T" % i] if G.num_layer_separate >= i + 1 else [])
+    def up_bwd(i, name, dx, dfeat, wq):
+        """backward of one up block: weight gradient (through wq: side queue, or inline inside a lane), gradient w.r.t.
+        the block input into dx / dfeat[nd-1], gradient w.r.t. the skip feature into dfeat[i]"""
         skip = None if i in (0, nd - 1) else feats[i]
+        blk = getattr(G, name).conv
+        inp, outp, extra = ctx.ups[name]
+        outer = blk.weight.shape[1]
+        if i == 0:
+            c0 = 0 if name == "up0" else 3
+            g = d_raw[:, c0:c0 + outer]  # channel-slice view: batch stride stays 5*H*W
+        else:
+            g = dx.pop(id(outp))
+            ops.norm_bwd(g, outp, 0)
+        gop = Act(g)
+        second = skip if skip is not None else extra
+        wq(lambda: ops.wgrad4x4(inp, gop, blk.weight.grad, lo1=second, act_lo=RELU, stride=2, pad=1), g)
+        if i == 0:
+            wq(lambda: ops.channel_sum(g, blk.bias.grad), g)
+        # else: the bias feeds an InstanceNorm, so its gradient is identically zero (the norm removes any
+        # per-channel constant).  The reference computes ~1e-9 rounding noise there; the flat gradient
+        # buffer is zero-initialised and this slot is never written, i.e. exactly 0.
+        c_in0 = inp.data.shape[1]
+        # grad wrt the primary input (normalised output of the previous up block, or feats[nd-1])
+        if i == nd - 1:
+            tgt, acc = add_grad_list(dfeat, nd - 1, inp.data.shape, dev)
+        else:
+            tgt, acc = add_grad(dx, id(inp), inp.data.shape)
+        ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc)
+        if skip is not None:
+            tgt, acc = add_grad_list(dfeat, i, skip.data.shape, dev)
+            wv = blk.weight.view(-1)[c_in0 * outer * 16:]
+            ops.conv4x4(gop, wv, outer * 16, 16, skip.data.shape[1], tgt, stride=2, pad=1, dmask=skip, dmask_act=RELU,
+                        accumulate=acc)
+
+    nls = G.num_layer_separate
+    if nls > 0 and PARALLEL_SCALES:
+        # the visual and the tactile decoder are independent chains: two lanes with their own gradient buffers,
+        # summed where the chains share a tensor (skip features, the split point)
+        lane_dx, lane_df = [{}, {}], [[None] * nd, [None] * nd]
+
+        def inline(fn, *keep):
+            fn()
+
+        def chain(lane):
+            for i in range(nls):
+                up_bwd(i, "up%d%s" % (i, "_T" if lane else ""), lane_dx[lane], lane_df[lane], inline)
+
+        _run_lanes(2, chain)
+
+        def total(a, b):
+            return a if b is None else (b if a is None else ops.pad_affine(a, (0, 0, 0, 0), 0, res=b))
+
+        for i in range(nd):
+            dfeat[i] = total(lane_df[0][i], lane_df[1][i])
+        for key in set(lane_dx[0]) | set(lane_dx[1]):
+            dx[key] = total(lane_dx[0].get(key), lane_dx[1].get(key))
+        first_shared = nls
+    else:
+        first_shared = 0
+    for i in range(first_shared, nd):
+        names = ["up%d" % i] + (["up%d_T" % i] if nls >= i + 1 else [])
         for name in names:
-            blk = getattr(G, name).conv
-            inp, outp, extra = ctx.ups[name]
-            cin_total, outer = blk.weight.shape[0], blk.weight.shape[1]
-            if i == 0:
-                c0 = 0 if name == "up0" else 3
-                g = d_raw[:, c0:c0 + outer]  # channel-slice view: batch stride stays 5*H*W
-            else:
-                g = dx.pop(id(outp))
-                ops.norm_bwd(g, outp, 0)
-            gop = Act(g)
-            gsum_src = g
-            second = skip if skip is not None else extra
-            sq.run(lambda: ops.wgrad4x4(inp, gop, blk.weight.grad, lo1=second, act_lo=RELU, stride=2, pad=1), g)
-            if i == 0:
-                sq.run(lambda: ops.channel_sum(gsum_src, blk.bias.grad), g)
-            # else: the bias feeds an InstanceNorm, so its gradient is identically zero (the norm removes any
-            # per-channel constant).  The reference computes ~1e-9 rounding noise there; the flat gradient
-            # buffer is zero-initialised and this slot is never written, i.e. exactly 0.
-            c_in0 = inp.data.shape[1]
-            # grad wrt the primary input (normalised output of the previous up block, or feats[nd-1])
-            if i == nd - 1:
-                tgt, acc = add_grad_list(dfeat, nd - 1, inp.data.shape, dev)
-            else:
-                tgt, acc = add_grad(dx, id(inp), inp.data.shape)
-            ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc)
-            if skip is not None:
-                tgt, acc = add_grad_list(dfeat, i, skip.data.shape, dev)
-                wv = blk.weight.view(-1)[c_in0 * outer * 16:]
-                ops.conv4x4(gop, wv, outer * 16, 16, skip.data.shape[1], tgt, stride=2, pad=1, dmask=skip, dmask_act=RELU,
-                            accumulate=acc)
+            up_bwd(i, name, dx, dfeat, sq.run)
 
     for i in range(nd - 1, -1, -1):
         blk = getattr(G, "down%d" % i).conv
