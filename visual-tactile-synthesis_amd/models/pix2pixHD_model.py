@@ -171,19 +171,18 @@ class Pix2PixHDModel(BaseModel):
             self.forward(keep=False)
 
     # ------------------------------------------------------------------ training step
-    def _d_pass(self, net, in0, in1, target_real, slot, accumulate):
-        preds, ctx = engine.msd_forward(net, in0, in1, keep=True)
-        dp = self.criterionGAN.accumulate(preds, target_real, 1.0, slot, grad_coeff=0.5)
-        engine.msd_backward(net, ctx, dp, param_grads=True, accumulate=accumulate)
-
     def _seg_forward_d(self):
+        """forward, then backward_D: both discriminators, all scales side by side (engine.msd_multi)"""
         slot = self._slot
         self._loss_buf.zero_()
         self.forward(keep=True)
-        self._d_pass(self.netD, self.real_S, self.fake_I, False, slot["D_fake"], False)
-        self._d_pass(self.netD, self.real_S, self.real_I, True, slot["D_real"], True)
-        self._d_pass(self.netD2, self.real_S, self.fake_T, False, slot["D2_fake"], False)
-        self._d_pass(self.netD2, self.real_S, self.real_T, True, slot["D2_real"], True)
+
+        def pair(fake, real, s_fake, s_real):
+            return [dict(in0=self.real_S, in1=fake, real=False, coeff=1.0, slot=slot[s_fake], grad_coeff=0.5),
+                    dict(in0=self.real_S, in1=real, real=True, coeff=1.0, slot=slot[s_real], grad_coeff=0.5, accumulate=True)]
+
+        engine.msd_multi([(self.netD, pair(self.fake_I, self.real_I, "D_fake", "D_real")),
+                          (self.netD2, pair(self.fake_T, self.real_T, "D2_fake", "D2_real"))], self.criterionGAN)
 
     def _seg_adam_d_g(self):
         slot, dev = self._slot, self.device
@@ -192,10 +191,10 @@ class Pix2PixHDModel(BaseModel):
         self.optimizer_D2.step(self._gscale)
         d_fake_I = torch.empty(n, 3, h, w, device=dev)
         d_fake_T = torch.empty(n, 2, h, w, device=dev)
-        for net, fake, dgrad, s in ((self.netD, self.fake_I, d_fake_I, "G_GAN_I"), (self.netD2, self.fake_T, d_fake_T, "G_GAN_T")):
-            preds, ctx = engine.msd_forward(net, self.real_S, fake, keep=True)
-            dp = self.criterionGAN.accumulate(preds, True, 1.0, slot[s], grad_coeff=1.0)
-            engine.msd_backward(net, ctx, dp, param_grads=False, input_grad=(dgrad, False))
+        engine.msd_multi([(self.netD, [dict(in0=self.real_S, in1=self.fake_I, real=True, coeff=1.0, slot=slot["G_GAN_I"], grad_coeff=1.0,
+                                            param_grads=False, input_grad=(d_fake_I, False))]),
+                          (self.netD2, [dict(in0=self.real_S, in1=self.fake_T, real=True, coeff=1.0, slot=slot["G_GAN_T"], grad_coeff=1.0,
+                                             param_grads=False, input_grad=(d_fake_T, False))])], self.criterionGAN)
         slot["G_GAN"].copy_(slot["G_GAN_I"] + slot["G_GAN_T"])
         d_raw = torch.empty(n, 5, h, w, device=dev)
         ops.g_out_grad(d_fake_I, d_fake_T, self.M, self.g_out, d_raw)
