@@ -401,6 +401,7 @@ def resnet_backward(G, ctx, d_raw):
     """d_raw: gradient w.r.t. the pre-tanh output.  Writes every parameter's .grad (overwrite).
     Biases that feed a normalisation have identically zero gradient and are never written."""
     dev = d_raw.device
+    sq = SideQueue()     # weight / bias gradients: off the critical path of the backward-data chain
 
     def through_norm_relu(g_act, a, bn):
         """gradient w.r.t. relu(norm(r)) -> gradient w.r.t. the raw conv output r (in a fresh buffer)"""
@@ -422,8 +423,7 @@ def resnet_backward(G, ctx, d_raw):
         kind = st[0]
         if kind == "conv7_out":
             _, conv, p, src_act, _, _ = st
-            ops.wgradk(g, p, conv.weight.grad, pad=0)
-            ops.channel_sum(g, conv.bias.grad)
+            sq.run(lambda: (ops.wgradk(g, p, conv.weight.grad, pad=0), ops.channel_sum(g, conv.bias.grad)), g)
             dp = torch.empty_like(p)
             ops.convk_bwd_data(g, conv.weight, dp, pad=0)
             da = _empty(p.shape[0], p.shape[1], p.shape[2] - 6, p.shape[3] - 6, dev)
@@ -431,14 +431,14 @@ def resnet_backward(G, ctx, d_raw):
             g = through_norm_relu(da, src_act, producer_bn(src_act))   # the padded tensor was relu(norm(r_prev))
         elif kind == "conv7":
             _, conv, p, src_act, a, bn = st
-            ops.wgradk(g, p, conv.weight.grad, pad=0)  # network input: no gradient needed below
+            sq.run(lambda: ops.wgradk(g, p, conv.weight.grad, pad=0), g)  # network input: no gradient needed below
         elif kind == "conv3":
             _, conv, inp, inp_act, a, bn, stride, xp = st
             hi = inp if isinstance(inp, Act) else Act(inp)
             t = inp.data if isinstance(inp, Act) else inp
             din = torch.empty_like(t)
             if xp is not None:     # wide layer
-                ops.wgrad3x3_wide(g, xp, conv.weight.grad, stride=stride)
+                sq.run(lambda: ops.wgrad3x3_wide(g, xp, conv.weight.grad, stride=stride), g)
                 if stride == 1:
                     dxp = torch.empty_like(xp)
                     ops.conv3x3_wide(ops.pad_affine(g, (2, 2, 2, 2), 0), ops.w3x3_pack(conv.weight, "conv_adj"), None, dxp)
@@ -446,13 +446,12 @@ def resnet_backward(G, ctx, d_raw):
                 else:
                     ops.tconv3x3s2_wide(ops.pad_affine(g, (0, 1, 0, 1), 0), ops.w3x3_pack(conv.weight, "conv_s2_adj"), None, din)
             elif stride == 1:
-                ops.wgradk(g, hi, conv.weight.grad, pad=1, act_hi=inp_act)
+                sq.run(lambda: ops.wgradk(g, hi, conv.weight.grad, pad=1, act_hi=inp_act), g)
                 ops.convk_bwd_data(g, conv.weight, din, pad=1)
             else:
                 co, ci = conv.weight.shape[:2]
                 dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
-                ops.wgrad4x4(g, hi, dw4, stride=2, pad=1, act_hi=inp_act)
-                ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)
+                sq.run(lambda: (ops.wgrad4x4(g, hi, dw4, stride=2, pad=1, act_hi=inp_act), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
                 w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
                 ops.conv4x4(g, w4, 16, ci * 16, ci, din, stride=2, pad=1, transposed=True)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
@@ -464,12 +463,11 @@ def resnet_backward(G, ctx, d_raw):
             din = torch.empty_like(t)
             if z is not None:      # wide layer
                 gp = ops.pad_affine(g, (1, 1, 1, 1), 0)
-                ops.wgrad3x3_wide(z, gp, conv.weight.grad, stride=2)
+                sq.run(lambda: ops.wgrad3x3_wide(z, gp, conv.weight.grad, stride=2), gp)
                 ops.conv3x3s2_wide(gp, ops.w3x3_pack(conv.weight, "convT_adj"), None, din)
             else:
                 dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
-                ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act)
-                ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)
+                sq.run(lambda: (ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
                 w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
                 ops.conv4x4(g, w4, co * 16, 16, ci, din, stride=2, pad=1)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
@@ -489,13 +487,13 @@ def resnet_backward(G, ctx, d_raw):
             dy = g
             g2 = dy.clone()
             _g_norm_bwd(g2, a2, nb)
-            _wgrad_valid3(g2, p2, cb)
+            sq.run(lambda: _wgrad_valid3(g2, p2, cb), g2)
             dp2 = torch.empty_like(p2)
             _conv_valid3_bwd_data(g2, cb, dp2)
             da1 = torch.empty_like(a1.data)
             ops.pad_bwd(dp2, (1, 1, 1, 1), 1, da1)
             g1 = through_norm_relu(da1, a1, na)
-            _wgrad_valid3(g1, p1, ca)
+            sq.run(lambda: _wgrad_valid3(g1, p1, ca), g1)
             dp1 = torch.empty_like(p1)
             _conv_valid3_bwd_data(g1, ca, dp1)
             ops.pad_bwd(dp1, (1, 1, 1, 1), 1, dy, accumulate=True)   # + the skip path
@@ -505,6 +503,7 @@ def resnet_backward(G, ctx, d_raw):
                 g = through_norm_relu(g, src, producer_bn(src)) if src_act == RELU else g
         else:
             raise RuntimeError(kind)
+    sq.join()
 
 
 def add_grad_list(lst, idx, shape, dev):
