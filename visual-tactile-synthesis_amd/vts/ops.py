@@ -60,7 +60,7 @@ _ws = {}
 
 def workspace(nfloats, device):
     """Grow-only scratch; safe to share because every kernel runs in stream order."""
-    key = (str(device), WS_BASE + WS_LANE)   # one scratch per concurrent lane (branches / scale-parallel discriminator passes)
+    key = (str(device), WS_LANE)   # one scratch per concurrent lane (engine._run_lanes / SideQueue)
     t = _ws.get(key)
     if t is None or t.numel() < nfloats:
         if t is not None and FROZEN_WS:
@@ -74,8 +74,7 @@ _retired = []
 
 
 FROZEN_WS = False  # set while HIP graphs that captured the workspace pointer are alive
-WS_LANE = 0        # which scratch buffer the wrappers use: 0 = the launch stream, s = side stream s (engine._run_scales)
-WS_BASE = 0        # ... offset of the concurrent branch that is being enqueued (engine.Branch)
+WS_LANE = 0        # which scratch buffer the wrappers use: 0 = the launch stream, i = side lane i (engine._run_lanes)
 
 
 def _op(a):
@@ -177,7 +176,7 @@ def _w4_scratch(w, K, tag):
     return buf
 
 
-def convk(x, w, out, *, bias=None, pad=0, act_in=0, dmask=None, dmask_act=0):
+def convk(x, w, out, *, bias=None, pad=0, act_in=0):
     """out <- Conv2d(K x K, stride 1, zero padding `pad`)(x); w is [Co, Ci, K, K].  Replaces the 3x3 / 7x7
     nn.Conv2d of ResnetGenerator / ResnetBlock (networks.py:1076,1084,1144,1306,1318)."""
     co, ci, K, _ = w.shape
@@ -208,9 +207,6 @@ def wgradk(dout, x, dw, *, pad=0, act_hi=0, accumulate=False):
         wgrad4x4(dout, x, dw4[i], stride=1, pad=pad - 4 * a, pad_dx=4 * (a - b), act_hi=act_hi)
         tap_extract(dw4[i], K, a, b, dw, accumulate=accumulate)
     return dw
-
-
-PACK_MODES = ("conv_fwd", "conv_adj", "conv_s2_adj", "convT_fwd", "convT_adj")
 
 
 def w3x3_pack(w, mode, tag=None):
