@@ -22,8 +22,9 @@ def init_from_env(device_type="cuda"):
         return int(os.environ.get("RANK", "0")), world
     rank = int(os.environ["RANK"])
     if device_type == "cuda":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # one GPU per rank; VTS_DDP_BACKEND=gloo (ranks sharing a device) exists to exercise this path on a 1-GPU box
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        dist.init_process_group(backend=os.environ.get("VTS_DDP_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     return rank, world
