@@ -173,6 +173,7 @@ def infer_bench(args):
     """Generator-only forward (test() of the model): ms per image, inputs resident in HBM."""
     batch_n = 16 if args.batch == 4 else args.batch
     model, opt = build_model(args.size, batch_n, args.model)
+    opt.use_hip_graph = not args.no_graph
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
     model.eval()
     model.set_input(make_batch(args.size, batch_n, 0, style_dim), phase="test")
@@ -188,7 +189,8 @@ def infer_bench(args):
         "metric": "inference_ms_per_image", "value": dt / args.steps / batch_n * 1e3, "unit": "ms/image", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s generator forward (test()), %dx%d, %d images/GPU, eager launches" % (args.model, args.size, args.size, batch_n)},
+        "config": {"workload": "%s generator forward (test()), %dx%d, %d images/GPU" % (args.model, args.size, args.size, batch_n),
+                   "hip_graph": bool(opt.use_hip_graph)},
     }))
 
 

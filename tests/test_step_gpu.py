@@ -275,3 +275,22 @@ def test_train_and_test_scripts_end_to_end(tmp_path):
     assert out.stdout.count("processed synthetic_") == 2
     saved = torch.load(os.path.join(str(tmp_path), "res", "e2e", "test_latest", "synthetic_1234.pt"))
     assert saved["fake_I"].shape == (1, 3, 256, 256) and saved["fake_gx"].shape == (1, 1, 256, 256)
+
+
+def test_inference_graph_replay_equals_eager_and_follows_new_inputs():
+    from data.synthetic_dataset import make_sample
+    model, opt = make_model(256, 1)
+    load_test_weights(model, 5)
+    model.eval()
+    outs = []
+    for seed in (1, 2, 3, 2):
+        model.set_input(default_collate([make_sample(256, 8, 8, seed)]), phase="test")
+        model.test()
+        outs.append((model.fake_I.clone(), model.fake_T.clone()))
+    assert model._infer_graph is not None               # calls 3 and 4 were graph replays
+    opt.use_hip_graph = False
+    model.set_input(default_collate([make_sample(256, 8, 8, 2)]), phase="test")
+    model.test()
+    for o in (outs[1], outs[3]):
+        assert torch.equal(o[0], model.fake_I) and torch.equal(o[1], model.fake_T)
+    assert not torch.equal(outs[2][0], outs[1][0])

@@ -183,6 +183,7 @@ class SinSKITGModel(BaseModel):
         self._spe_cache = {}
         self._bufs = {}         # persistent input buffers (stable addresses for captured HIP graphs)
         self._graphs = None     # the captured segments of the step, or None
+        self._infer_graph, self._infer_eager_done = None, False   # captured inference forward (test())
         self._eager_steps_done = 0
         self._draws = None      # tests / parity runs inject {"aug": [4,N], "more_idx": [N,K]}
         self.ddp = None
@@ -341,8 +342,23 @@ class SinSKITGModel(BaseModel):
         return None
 
     def test(self, timing=False):
+        """inference forward; with --use_hip_graph the second call on unchanged shapes captures it as a HIP graph and
+        later calls replay it (the ~45 launches of one image are otherwise host-latency bound)"""
         with torch.no_grad():
+            if not getattr(self.opt, "use_hip_graph", False) or self._draws is not None:
+                return self.forward(keep=False)
+            if self._infer_graph is not None:
+                return self._infer_graph.replay()
+            if self._infer_eager_done:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                ops.FROZEN_WS = True
+                with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+                    self.forward(keep=False)
+                self._infer_graph = g
+                return g.replay()
             self.forward(keep=False)
+            self._infer_eager_done = True
 
     # ------------------------------------------------------------------ training step
     def _gather(self, src, pset, out, c0, channels=None):
@@ -489,6 +505,7 @@ class SinSKITGModel(BaseModel):
         b.start() if start else b.wait()
 
     def _drop_graphs(self):
+        self._infer_graph, self._infer_eager_done = None, False
         if getattr(self, "_graphs", None) is not None:
             self._graphs = None
             ops.FROZEN_WS = False
