@@ -225,6 +225,19 @@ int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int 
 int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int stride,
                       int accumulate, float* ws, int64_t ws_floats, void* stream);
 
+/* ---- Evaluation metrics that need no pretrained network (models/model_utils.py:431-561 compute_evaluation_metric) ----
+ * vts_minmax:          out2 = {min x, max x}
+ * vts_metric_psnr:     I_PSNR (:481-496): both images mapped with the REAL image's range {lo, hi} (range2, device memory) to
+ *                      [0,1], the fake one clamped, PSNR with data_range 1 = 10 log10(1 / mse)
+ * vts_metric_tactile:  T_AE (:531-536: mean angle in degrees between normalize(gx, gy, 1) of the real and of the fake patches,
+ *                      normal_losses.py:10-33 mode 'evaluate') and T_MSE (:557); fake patches clamped to [0,1] first (:521).
+ * real_T / fake_T are [P, 2, HW]; `ws` holds vts_metric_ws_floats() floats; fixed-order (deterministic) reductions. */
+int64_t vts_metric_ws_floats(void);
+int vts_minmax(const float* x, int64_t n, float* out2, float* ws, void* stream);
+int vts_metric_psnr(const float* real, const float* fake, int64_t n, const float* range2, float* out, float* ws, void* stream);
+int vts_metric_tactile(const float* real_T, const float* fake_T, int64_t P, int HW, float* out_ae, float* out_mse, float* ws,
+                       void* stream);
+
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */
 int vts_avgpool3s2(const float* x, int64_t x_nstride, int N, int C, int H, int W, float* y, void* stream);

@@ -292,6 +292,22 @@ def golden_p2p_step(size=32, seed=505, n=4, steps=2):
     print({k: float(v) for k, v in losses.items()})
 
 
+def golden_metrics(seed=606):
+    """T_AE / T_MSE from the reference's compute_evaluation_metric (I_PSNR needs torchmetrics, which is not installed:
+    the oracle restates torchmetrics' published formula for it)"""
+    from oracle import detrand, ref_import
+
+    ref_import.load()
+    from models.model_utils import compute_evaluation_metric
+
+    real_I, fake_I = detrand.uniform((1, 3, 64, 64), seed, "rI"), 1.2 * detrand.uniform((1, 3, 64, 64), seed, "fI")
+    real_T, fake_T = 0.3 * detrand.uniform((6, 2, 32, 32), seed, "rT"), 0.6 * detrand.uniform((6, 2, 32, 32), seed, "fT")
+    m = compute_evaluation_metric(["G"], real_I, fake_I, real_T_concat=real_T, fake_T_concat=fake_T, eval_metrics=["T_AE", "T_MSE"])
+    out = {"seed": seed, "T_AE": float(m["metric_T_AE"]), "T_MSE": float(m["metric_T_MSE"])}
+    np.savez_compressed(os.path.join(GOLD, "metrics.npz"), **out)
+    print("wrote metrics.npz", out)
+
+
 def golden_step(size=256, seed=202, steps=2, nt=64):
     """Full SinSKITGModel.optimize_parameters x `steps` on one synthetic sample (BASELINE config 0)."""
     from oracle import detrand, nets, ref_import
@@ -352,7 +368,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "p2p"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "p2p", "metrics"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -365,3 +381,5 @@ if __name__ == "__main__":
         golden_global()
     if "p2p" in which:
         golden_p2p_step()
+    if "metrics" in which:
+        golden_metrics()

@@ -59,6 +59,19 @@ def compute_normal(t, scale_nz):
     return F.normalize(torch.cat([gx, gy, scale_nz * torch.ones_like(gx)], 1), dim=1)
 
 
+def eval_metrics(real_I, fake_I, real_T, fake_T):
+    """compute_evaluation_metric (models/model_utils.py:431-561), the metrics that need no pretrained network:
+    I_PSNR (:481-496; torchmetrics' peak_signal_noise_ratio(data_range=1) = 10 log10(1 / mse)), T_AE (:531-536 with
+    normal_losses.py:10-33 mode 'evaluate'), T_MSE (:557).  The fake tactile patches are clamped to [0, 1] (:521)."""
+    lo, hi = real_I.min(), real_I.max()
+    r = (real_I - lo) / (hi - lo)
+    f = torch.clamp((fake_I - lo) / (hi - lo), 0, 1)
+    psnr = 10.0 * torch.log10(1.0 / torch.mean((r - f) ** 2))
+    fT = torch.clamp(fake_T, 0, 1)
+    cos = torch.clamp(torch.cosine_similarity(compute_normal(fT, 1), compute_normal(real_T, 1), dim=1, eps=1e-6), -1.0, 1.0)
+    return {"I_PSNR": float(psnr), "T_AE": float((torch.acos(cos) * 180.0 / np.pi).mean()), "T_MSE": float(torch.mean((real_T - fT) ** 2))}
+
+
 # ----------------------------------------------------------------------------
 # patch gather
 # ----------------------------------------------------------------------------

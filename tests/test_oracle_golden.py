@@ -213,6 +213,19 @@ def test_pix2pixHD_step_matches_reference(golden_dir):
                         _close(v.numpy(), g[key], rtol=1e-3, atol=1e-5)
 
 
+def test_eval_metrics(golden_dir):
+    """T_AE / T_MSE of oracle.nets.eval_metrics vs the reference's compute_evaluation_metric; I_PSNR vs its definition"""
+    g = _load(golden_dir, "metrics.npz")
+    seed = int(g["seed"])
+    real_I, fake_I = detrand.uniform((1, 3, 64, 64), seed, "rI"), 1.2 * detrand.uniform((1, 3, 64, 64), seed, "fI")
+    real_T, fake_T = 0.3 * detrand.uniform((6, 2, 32, 32), seed, "rT"), 0.6 * detrand.uniform((6, 2, 32, 32), seed, "fT")
+    m = nets.eval_metrics(real_I, fake_I, real_T, fake_T)
+    assert abs(m["T_AE"] - float(g["T_AE"])) < 1e-4 and abs(m["T_MSE"] - float(g["T_MSE"])) < 1e-7
+    r = (real_I - real_I.min()) / (real_I.max() - real_I.min())
+    f = ((fake_I - real_I.min()) / (real_I.max() - real_I.min())).clamp(0, 1)
+    assert abs(m["I_PSNR"] - float(-10 * torch.log10(((r - f) ** 2).mean()))) < 1e-4
+
+
 def test_resnet_state_dict_keys(golden_dir):
     """the product's ResnetGenerator container exposes exactly the reference's state_dict keys"""
     import sys

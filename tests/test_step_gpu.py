@@ -294,3 +294,32 @@ def test_inference_graph_replay_equals_eager_and_follows_new_inputs():
     for o in (outs[1], outs[3]):
         assert torch.equal(o[0], model.fake_I) and torch.equal(o[1], model.fake_T)
     assert not torch.equal(outs[2][0], outs[1][0])
+
+
+def test_eval_metrics_match_oracle():
+    """I_PSNR / T_AE / T_MSE kernels vs the oracle (pinned to the reference's compute_evaluation_metric), and through the model"""
+    from data.synthetic_dataset import make_sample
+    from vts import ops
+    dev = torch.device("cuda:0")
+    real_I, fake_I = detrand.uniform((2, 3, 70, 90), 8, "rI"), 1.2 * detrand.uniform((2, 3, 70, 90), 8, "fI")
+    real_T, fake_T = 0.3 * detrand.uniform((9, 2, 32, 32), 8, "rT"), 0.6 * detrand.uniform((9, 2, 32, 32), 8, "fT")
+    got = ops.eval_metrics(real_I.to(dev), fake_I.to(dev), real_T.to(dev), fake_T.to(dev)).cpu().tolist()
+    ref = nets.eval_metrics(real_I, fake_I, real_T, fake_T)
+    for v, k in zip(got, ("I_PSNR", "T_AE", "T_MSE")):
+        assert abs(v - ref[k]) <= 1e-4 * max(1.0, abs(ref[k])), (k, v, ref[k])
+    model, opt = make_model(256, 1)
+    sdG, _, _ = load_test_weights(model, 13)
+    batch = default_collate([make_sample(256, 16, 24, 13)])
+    model.set_input(batch, phase="val")
+    model.test()
+    m = model.compute_metrics()
+    fi, ft = step.inference(sdG, batch)
+    coords = batch["val_T_coords"][0]
+    ox, oy, _ = nets.find_coords_for_patch(coords)
+    fake_T_concat = nets.gather_patches(ft, ox, oy, 32)
+    inp = step.prepare_input(batch)
+    real_T_val = batch["val_T_images"][0].float() * batch["val_I_masks"][0].float()[:, None]
+    ref = nets.eval_metrics(inp.real_I, fi, real_T_val, fake_T_concat)
+    for k in ("I_PSNR", "T_AE", "T_MSE"):
+        assert abs(m[k] - ref[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, m[k], ref[k])
+    assert set(model.get_current_metrics().keys()) == {"m_I_PSNR", "m_T_AE", "m_T_MSE"}

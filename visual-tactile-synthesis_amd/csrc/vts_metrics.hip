@@ -1,0 +1,136 @@
+// Evaluation metrics on device (reference models/model_utils.py:431-561 compute_evaluation_metric): the ones that need no
+// pretrained network -- I_PSNR (:496, on images min-max normalised with the REAL image's range, the fake one clamped to
+// [0,1], :481-485), T_MSE (:557) and T_AE, the mean angle in degrees between the surface normals of the real and the fake
+// tactile patches (:531-536, compute_normal :408-428 with scale_nz = 1, normal_losses.py:10-33 mode 'evaluate'); the fake
+// tactile patches are clamped to [0,1] first, as the reference does (:521).  Streaming reductions: per-workgroup partials
+// and a fixed-order final sum (deterministic).
+#include "vts_internal.h"
+
+namespace {
+
+constexpr int MB = 512;   // workgroups of the first stage
+
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+  __shared__ float smin[4], smax[4];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    lo = fminf(lo, x[i]);
+    hi = fmaxf(hi, x[i]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = lo;
+    smax[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  }
+}
+
+__global__ __launch_bounds__(64) void minmax_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += 64) {
+    lo = fminf(lo, part[2 * i]);
+    hi = fmaxf(hi, part[2 * i + 1]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if (threadIdx.x == 0) {
+    out[0] = lo;
+    out[1] = hi;
+  }
+}
+
+// mode 0: sum (clamp((b - lo) / (hi - lo), 0, 1) - (a - lo) / (hi - lo))^2   (lo, hi = range[0], range[1]; PSNR)
+// mode 1: sum (a - clamp(b, 0, 1))^2                                           (T_MSE)
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int mode,
+                                                              const float* __restrict__ range, float* __restrict__ part) {
+  __shared__ float red[16];
+  const float lo = mode == 0 ? range[0] : 0.f, inv = mode == 0 ? 1.f / (range[1] - range[0]) : 1.f;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float ra = (a[i] - lo) * inv;
+    const float fb = fminf(fmaxf((b[i] - lo) * inv, 0.f), 1.f);
+    const float d = ra - fb;
+    acc += d * d;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// real / fake tactile patches [P, 2, HW]: angle between normalize(gx, gy, 1) of the real and of the clamped fake patch
+__global__ __launch_bounds__(256) void angle_partial_kernel(const float* __restrict__ real, const float* __restrict__ fake, int64_t P, int HW,
+                                                             float* __restrict__ part) {
+  __shared__ float red[16];
+  const int64_t n = P * HW;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / HW, o = i - p * HW;
+    const float rx = real[(p * 2) * HW + o], ry = real[(p * 2 + 1) * HW + o];
+    const float fx = fminf(fmaxf(fake[(p * 2) * HW + o], 0.f), 1.f), fy = fminf(fmaxf(fake[(p * 2 + 1) * HW + o], 0.f), 1.f);
+    // F.normalize(eps 1e-12) then cosine_similarity(eps 1e-6): the normals have unit length, so cos = dot of the unit vectors
+    const float rn = fmaxf(sqrtf(rx * rx + ry * ry + 1.f), 1e-12f), fn = fmaxf(sqrtf(fx * fx + fy * fy + 1.f), 1e-12f);
+    const float ux = rx / rn, uy = ry / rn, uz = 1.f / rn, vx = fx / fn, vy = fy / fn, vz = 1.f / fn;
+    const float nu = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-6f), nv = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-6f);
+    float c = (ux * vx + uy * vy + uz * vz) / (nu * nv);
+    c = fminf(fmaxf(c, -1.f), 1.f);
+    acc += acosf(c) * 57.29577951308232f;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// out[0] = scale * sum(part)  (mode 0), or 10 log10(1 / (scale * sum))  (mode 1: PSNR with data_range 1)
+__global__ __launch_bounds__(64) void metric_final_kernel(const float* __restrict__ part, int nb, float scale, int mode, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = mode == 1 ? 10.f * log10f(1.f / (s * scale)) : s * scale;
+}
+
+inline int nblocks(int64_t n) {
+  const int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > MB ? MB : b));
+}
+
+}  // namespace
+
+extern "C" int64_t vts_metric_ws_floats(void) { return 2 * MB; }
+
+extern "C" int vts_minmax(const float* x, int64_t n, float* out2, float* ws, void* stream) {
+  VTS_CHECK_ARG(x && out2 && ws && n >= 1, "vts_minmax: bad args");
+  const int nb = nblocks(n);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, ws);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, out2);
+  VTS_CHECK_LAUNCH("vts_minmax");
+  return VTS_OK;
+}
+
+extern "C" int vts_metric_psnr(const float* real, const float* fake, int64_t n, const float* range2, float* out, float* ws, void* stream) {
+  VTS_CHECK_ARG(real && fake && range2 && out && ws && n >= 1, "vts_metric_psnr: bad args");
+  const int nb = nblocks(n);
+  hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, real, fake, n, 0, range2, ws);
+  hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, 1.f / (float)n, 1, out);
+  VTS_CHECK_LAUNCH("vts_metric_psnr");
+  return VTS_OK;
+}
+
+extern "C" int vts_metric_tactile(const float* real_T, const float* fake_T, int64_t P, int HW, float* out_ae, float* out_mse, float* ws,
+                                  void* stream) {
+  VTS_CHECK_ARG(real_T && fake_T && out_ae && out_mse && ws && P >= 1 && HW >= 1, "vts_metric_tactile: bad args");
+  const int64_t n = P * HW;
+  const int nb = nblocks(n), nb2 = nblocks(2 * n);
+  hipLaunchKernelGGL(angle_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, real_T, fake_T, P, HW, ws);
+  hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, 1.f / (float)n, 0, out_ae);
+  hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(nb2), dim3(256), 0, (hipStream_t)stream, real_T, fake_T, 2 * n, 1, (const float*)nullptr, ws + MB);
+  hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws + MB, nb2, 1.f / (float)(2 * n), 0, out_mse);
+  VTS_CHECK_LAUNCH("vts_metric_tactile");
+  return VTS_OK;
+}

@@ -559,6 +559,27 @@ class SinSKITGModel(BaseModel):
             self._eager_steps_done += 1
             self._g_ctx = None if not use_graph else self._g_ctx
 
+    # ------------------------------------------------------------------ evaluation metrics
+    METRICS = ("I_PSNR", "T_AE", "T_MSE")
+
+    def compute_metrics(self, prefix=""):
+        """The evaluation metrics that need no pretrained network (reference: compute_evaluation_metric,
+        models/model_utils.py:431-561, called from compute_visuals sinskitG_model.py:889-925) for the current outputs:
+        I_PSNR, T_AE, T_MSE on the validation patches (the training patches with prefix 'train_').  I_SIFID / *_LPIPS /
+        I_SSIM / T_SIFID need Inception / VGG / AlexNet weights or torchmetrics and are not built."""
+        pset = self.train_set if prefix == "train_" else self.val_set
+        if pset is None or not hasattr(self, "real_I") or self.test_edit_S:
+            return {}
+        P = pset["real_T"].shape[0]
+        fake_T_concat = torch.empty(P, 2, 32, 32, device=self.device)
+        self._gather(self.fake_T, pset, fake_T_concat, 0, channels=2)
+        vals = ops.eval_metrics(self.real_I, self.fake_I, pset["real_T"], fake_T_concat).cpu().tolist()
+        for name, v in zip(self.METRICS, vals):
+            setattr(self, "metric_%s%s" % (prefix, name), v)
+            if prefix + name not in self.metric_names:
+                self.metric_names.append(prefix + name)
+        return {prefix + n: v for n, v in zip(self.METRICS, vals)}
+
     # ------------------------------------------------------------------ logging
     def get_current_losses(self):
         vals = self._loss_buf.cpu().tolist()   # the only device->host sync of the loss path

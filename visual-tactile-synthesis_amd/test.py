@@ -44,3 +44,6 @@ if __name__ == "__main__":
         name = data["name"][0] if isinstance(data["name"], (list, tuple)) else data["name"]
         torch.save({k: v.detach().cpu() for k, v in visuals.items() if torch.is_tensor(v)}, os.path.join(out_dir, "%s.pt" % name))
         print("processed %s in %.2f ms (%d images)" % (name, dt * 1e3, data["S"].size(0)))
+        if hasattr(model, "compute_metrics"):
+            model.compute_metrics()
+            print("metrics:", dict(model.get_current_metrics()))

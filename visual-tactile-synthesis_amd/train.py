@@ -69,6 +69,15 @@ if __name__ == "__main__":
         dataset.set_epoch(epoch)
         if opt.train_for_each_epoch:
             total_iters = train_model(epoch, total_iters, dataset, model, opt, visualizer, dataset_size)
+        if getattr(opt, "val_for_each_epoch", False) and hasattr(model, "compute_metrics"):
+            # validation pass (train.py:89-160 of the reference): forward on a sample, metrics on its validation patches
+            for data in dataset:
+                model.eval()
+                model.set_input(data, phase="val")
+                model.test()
+                model.compute_metrics()
+                model.train()
+                break
         metrics = model.get_current_metrics()
         visualizer.print_current_metrics(epoch, metrics)
         visualizer.save_current_metrics(metrics, epoch=epoch)

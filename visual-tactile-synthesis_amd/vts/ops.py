@@ -502,6 +502,21 @@ def mask_select(cand, prefix, ranks, h, w):
     return offx, offy
 
 
+def eval_metrics(real_I, fake_I, real_T, fake_T):
+    """device tensor [I_PSNR, T_AE, T_MSE] (model_utils.py:431-561; the metrics that need no pretrained network)"""
+    lib = L.load()
+    ws = workspace(lib.vts_metric_ws_floats(), real_I.device)
+    out = torch.empty(5, dtype=torch.float32, device=real_I.device)   # [lo, hi, psnr, ae, mse]
+    st = L.stream()
+    L.check(lib.vts_minmax(real_I.data_ptr(), real_I.numel(), out.data_ptr(), ws.data_ptr(), st), "vts_minmax")
+    L.check(lib.vts_metric_psnr(real_I.data_ptr(), fake_I.data_ptr(), real_I.numel(), out.data_ptr(), out[2:].data_ptr(), ws.data_ptr(), st),
+            "vts_metric_psnr")
+    p, _, h, w = real_T.shape
+    L.check(lib.vts_metric_tactile(real_T.data_ptr(), fake_T.data_ptr(), p, h * w, out[3:].data_ptr(), out[4:].data_ptr(), ws.data_ptr(), st),
+            "vts_metric_tactile")
+    return out[2:]
+
+
 def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     lib = L.load()
     L.check(lib.vts_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
