@@ -235,6 +235,38 @@ def golden_global(h=64, w=32, seed=404, ngf=8, n_down=3, n_blocks=3):
     print("wrote global_%dx%d.npz (%d entries)" % (h, w, len(out)))
 
 
+def golden_local(h=64, w=32, seed=707, ngf=4, n_down=2, n_blocks_global=2, n_blocks_local=2):
+    """pix2pixHD LocalEnhancer (define_G netG='local', BatchNorm, train mode): forward + gradients + BN buffers."""
+    import copy
+
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from models import networks
+
+    opt = copy.copy(_ref_opt("sinskitG", True, []))
+    opt.n_downsample_global, opt.n_blocks_global, opt.n_local_enhancers, opt.n_blocks_local = n_down, n_blocks_global, 1, n_blocks_local
+    out = {"h": h, "w": w, "seed": seed, "ngf": ngf, "n_down": n_down, "n_blocks_global": n_blocks_global, "n_blocks_local": n_blocks_local}
+    G = networks.define_G(1, 5, ngf, "local", "batch", False, "xavier", 0.02, False, False, [], opt)
+    ref = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    mine = nets.local_enhancer_param_shapes(1, 5, ngf, n_down, n_blocks_global, n_blocks_local)
+    assert ref == {k: tuple(v) for k, v in mine.items()}, sorted(set(ref) ^ set(mine))[:8]
+    out["ref_keys"] = np.array(sorted(ref.keys()))
+    G.load_state_dict(detrand.test_weights(mine, seed))
+    G.train()
+    x = detrand.uniform((2, 1, h, w), seed, "g_in").requires_grad_(True)
+    y = G(x)
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    out["G_out"] = y.detach().numpy()
+    for k, p in G.named_parameters():
+        out["G_grad/" + k] = detrand.probe(p.grad, k)
+    for k, b in G.named_buffers():
+        if b.dtype.is_floating_point:
+            out["G_buf/" + k] = b.numpy()
+    np.savez_compressed(os.path.join(GOLD, "local_%dx%d.npz" % (h, w)), **out)
+    print("wrote local_%dx%d.npz (%d entries)" % (h, w, len(out)))
+
+
 def p2p_batch(n, size, seed):
     """synthetic patch batch with the patchskit contract (data/patchskit_dataset.py:277-333; return_patch=True)"""
     from oracle import detrand
@@ -368,7 +400,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "p2p", "metrics"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -379,6 +411,8 @@ if __name__ == "__main__":
         golden_resnet()
     if "global" in which:
         golden_global()
+    if "local" in which:
+        golden_local()
     if "p2p" in which:
         golden_p2p_step()
     if "metrics" in which:

@@ -254,6 +254,89 @@ def resnet_forward(sd, x, n_blocks=9, n_down=2, norm="instance", down="blur", up
     return x
 
 
+def local_enhancer_forward(sd, x, n_down=3, n_blocks_global=9, n_blocks_local=3, norm="batch", training=True):
+    """pix2pixHD LocalEnhancer.forward, one local enhancer (models/networks.py:1897-1949)"""
+    def c7(pre, i, t):
+        return F.conv2d(F.pad(t, (3, 3, 3, 3), mode="reflect"), sd["%s.%d.weight" % (pre, i)], sd["%s.%d.bias" % (pre, i)])
+
+    def nr(pre, i, t):
+        return F.relu(_gnorm(sd, "%s.%d" % (pre, i), t, norm, training))
+
+    def block(pre, i, t):
+        k = "%s.%d.conv_block." % (pre, i)
+        y = F.conv2d(F.pad(t, (1, 1, 1, 1), mode="reflect"), sd[k + "1.weight"], sd[k + "1.bias"])
+        y = F.relu(_gnorm(sd, k + "2", y, norm, training))
+        y = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[k + "5.weight"], sd[k + "5.bias"])
+        return t + _gnorm(sd, k + "6", y, norm, training)
+
+    def convT(pre, i, t):
+        return F.conv_transpose2d(t, sd["%s.%d.weight" % (pre, i)], sd["%s.%d.bias" % (pre, i)], stride=2, padding=1, output_padding=1)
+
+    # global trunk on the average-pooled input (GlobalGenerator.model[:-3])
+    g = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+    g = nr("model", 2, c7("model", 1, g))
+    i = 4
+    for _ in range(n_down):
+        g = nr("model", i + 1, F.conv2d(g, sd["model.%d.weight" % i], sd["model.%d.bias" % i], stride=2, padding=1))
+        i += 3
+    for _ in range(n_blocks_global):
+        g = block("model", i, g)
+        i += 1
+    for _ in range(n_down):
+        g = nr("model", i + 1, convT("model", i, g))
+        i += 3
+    # local branch
+    d = nr("model1_1", 2, c7("model1_1", 1, x))
+    d = nr("model1_1", 5, F.conv2d(d, sd["model1_1.4.weight"], sd["model1_1.4.bias"], stride=2, padding=1))
+    u = d + g
+    for j in range(n_blocks_local):
+        u = block("model1_2", j, u)
+    j = n_blocks_local
+    u = nr("model1_2", j + 1, convT("model1_2", j, u))
+    return torch.tanh(c7("model1_2", j + 4, u))
+
+
+def local_enhancer_param_shapes(input_nc=1, output_nc=5, ngf=32, n_down=3, n_blocks_global=9, n_blocks_local=3):
+    """state_dict of LocalEnhancer (BatchNorm, every conv with bias)"""
+    sh = {}
+
+    def conv(key, shape, bias_n):
+        sh[key + ".weight"] = shape
+        sh[key + ".bias"] = (bias_n,)
+
+    def bn(key, c):
+        for nm, shp in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,)), ("num_batches_tracked", ())):
+            sh[key + "." + nm] = shp
+
+    def block(key, c):
+        for j in (1, 5):
+            conv("%s.conv_block.%d" % (key, j), (c, c, 3, 3), c)
+            bn("%s.conv_block.%d" % (key, j + 1), c)
+
+    c = 2 * ngf
+    conv("model.1", (c, input_nc, 7, 7), c); bn("model.2", c)
+    i = 4
+    for _ in range(n_down):
+        conv("model.%d" % i, (2 * c, c, 3, 3), 2 * c); bn("model.%d" % (i + 1), 2 * c)
+        c *= 2
+        i += 3
+    for _ in range(n_blocks_global):
+        block("model.%d" % i, c)
+        i += 1
+    for _ in range(n_down):
+        conv("model.%d" % i, (c, c // 2, 3, 3), c // 2); bn("model.%d" % (i + 1), c // 2)
+        c //= 2
+        i += 3
+    conv("model1_1.1", (ngf, input_nc, 7, 7), ngf); bn("model1_1.2", ngf)
+    conv("model1_1.4", (2 * ngf, ngf, 3, 3), 2 * ngf); bn("model1_1.5", 2 * ngf)
+    for j in range(n_blocks_local):
+        block("model1_2.%d" % j, 2 * ngf)
+    j = n_blocks_local
+    conv("model1_2.%d" % j, (2 * ngf, ngf, 3, 3), ngf); bn("model1_2.%d" % (j + 1), ngf)
+    conv("model1_2.%d" % (j + 4), (output_nc, ngf, 7, 7), output_nc)
+    return sh
+
+
 def resnet_param_shapes(input_nc=9, output_nc=5, ngf=10, n_blocks=9, n_down=2, norm="instance", down="blur", up="blur", conv_bias=None):
     """state_dict entries of ResnetGenerator / GlobalGenerator (the `filt` buffers of the blur modules are constants
     and not listed).  conv_bias None: the reference's rule use_bias = (norm == instance)."""

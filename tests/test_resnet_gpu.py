@@ -419,3 +419,42 @@ def test_wide_strided_and_transposed_family(shape):
     dwt = torch.full(wt.shape, float("nan"), device=dev)
     ops.wgrad3x3_wide(zd, ctp, dwt, stride=2)
     assert rel(dwt, wt.grad) < 2e-5
+
+
+def test_local_enhancer_matches_reference_and_oracle(golden_dir):
+    """pix2pixHD LocalEnhancer (define_G netG='local'): forward vs the committed reference output, BN buffers, backward vs oracle"""
+    from models import networks
+    from vts import engine
+    from vts.optim import FlatParams
+    g = np.load(os.path.join(golden_dir, "local_64x32.npz"), allow_pickle=False)
+    h, w, seed, ngf, nd, nbg, nbl = (int(g[k]) for k in ("h", "w", "seed", "ngf", "n_down", "n_blocks_global", "n_blocks_local"))
+    dev = _dev()
+    sd = detrand.test_weights(nets.local_enhancer_param_shapes(1, 5, ngf, nd, nbg, nbl), seed)
+    G = networks.LocalEnhancer(1, 5, ngf=ngf, n_downsample_global=nd, n_blocks_global=nbg, n_blocks_local=nbl).to(dev)
+    G.load_state_dict(sd)
+    flat = FlatParams(G)
+    G.train()
+    x = detrand.uniform((2, 1, h, w), seed, "g_in")
+    y, ctx = engine.resnet_forward(G, x.to(dev))
+    assert rel(y, torch.from_numpy(g["G_out"])) < 5e-5
+    for k, b in G.named_buffers():
+        if b.dtype.is_floating_point:
+            assert rel(b, torch.from_numpy(g["G_buf/" + k])) < 1e-4, k
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdo.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    yo = nets.local_enhancer_forward(sdo, x, nd, nbg, nbl)
+    cot = detrand.uniform(tuple(yo.shape), seed, "g_cot")
+    (yo * cot).sum().backward()
+    flat.grad.zero_()
+    engine.resnet_backward(G, ctx, (cot.to(dev) * (1.0 - y * y)).contiguous())
+    named = dict(G.named_parameters())
+    last_bias = "model1_2.%d.bias" % (nbl + 4)
+    for k, v in sdo.items():
+        if not (v.dtype.is_floating_point and v.requires_grad):
+            continue
+        if k.endswith(".bias") and k != last_bias and sdo[k.replace(".bias", ".weight")].dim() == 4:
+            assert named[k].grad.abs().max().item() == 0.0, k
+            continue
+        assert rel(named[k].grad, v.grad) < 3e-4, (k, rel(named[k].grad, v.grad))

@@ -192,6 +192,98 @@ class ResnetGenerator(nn.Module):
         return out
 
 
+class _SeqBuilder:
+    """collects (module index -> parameter container) and the layout list of one nn.Sequential of the reference"""
+
+    def __init__(self, norm, conv_bias=True):
+        self.mods, self.layout, self.idx, self.norm, self.conv_bias = {}, [], 0, norm, conv_bias
+
+    def add(self, kind, mod=None, **kw):
+        if mod is not None:
+            self.mods[self.idx] = mod
+        self.layout.append(dict(kind=kind, idx=self.idx, **kw))
+        self.idx += 1
+
+    def conv7(self, cin, cout, final=False):
+        self.add("pad")
+        self.add("conv7", _ConvParams((cout, cin, 7, 7), cout if (self.conv_bias or final) else 0))
+        if final:
+            self.add("tanh")
+        else:
+            self.norm_relu(cout)
+
+    def norm_relu(self, c):
+        self.add("norm", _BNParams(c) if self.norm == "batch" else None)
+        self.add("relu")
+
+    def conv3(self, cin, cout, stride):
+        self.add("conv3", _ConvParams((cout, cin, 3, 3), cout if self.conv_bias else 0), stride=stride)
+        self.norm_relu(cout)
+
+    def convT3(self, cin, cout):
+        self.add("convT3", _ConvParams((cin, cout, 3, 3), cout if self.conv_bias else 0, transposed=True))
+        self.norm_relu(cout)
+
+    def block(self, c):
+        kids = {1: _ConvParams((c, c, 3, 3), c if self.conv_bias else 0), 5: _ConvParams((c, c, 3, 3), c if self.conv_bias else 0)}
+        if self.norm == "batch":
+            kids[2], kids[6] = _BNParams(c), _BNParams(c)
+        self.add("block", _Holder({"conv_block": _Holder(kids)}))
+
+
+class _SeqView:
+    """layout + module lookup over one _Holder (what engine._seq_forward walks); not an nn.Module"""
+
+    def __init__(self, holder, layout):
+        self._holder, self.layout = holder, layout
+
+    def mod(self, idx):
+        return getattr(self._holder, str(idx), None)
+
+    def block_mods(self, idx):
+        cb = getattr(self._holder, str(idx)).conv_block
+        return [getattr(cb, k, None) for k in ("1", "2", "5", "6")]
+
+
+class LocalEnhancer(nn.Module):
+    """pix2pixHD LocalEnhancer with one local enhancer (reference: networks.py:1897-1949; `define_G(netG='local')`
+    :311-313): `model` = GlobalGenerator(ngf*2).model without its last three layers, applied to the average-pooled
+    input; `model1_1` = 7x7 conv + stride-2 3x3 conv on the full input; `model1_2` = ResnetBlocks, ConvTranspose2d,
+    7x7 conv, tanh on the sum."""
+    is_local_enhancer = True
+
+    def __init__(self, input_nc, output_nc, ngf=32, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1, n_blocks_local=3,
+                 norm="batch", opt=None):
+        super().__init__()
+        if n_local_enhancers != 1:
+            raise NotImplementedError("LocalEnhancer: only n_local_enhancers=1 is built")
+        self.norm = norm
+        ngf_g = ngf * 2
+        g = _SeqBuilder(norm)
+        g.conv7(input_nc, ngf_g)
+        for i in range(n_downsample_global):
+            g.conv3(ngf_g * 2 ** i, ngf_g * 2 ** (i + 1), 2)
+        for _ in range(n_blocks_global):
+            g.block(ngf_g * 2 ** n_downsample_global)
+        for i in range(n_downsample_global):
+            c = ngf_g * 2 ** (n_downsample_global - i)
+            g.convT3(c, c // 2)
+        d = _SeqBuilder(norm)
+        d.conv7(input_nc, ngf)
+        d.conv3(ngf, ngf * 2, 2)
+        u = _SeqBuilder(norm)
+        for _ in range(n_blocks_local):
+            u.block(ngf * 2)
+        u.convT3(ngf * 2, ngf)
+        u.conv7(ngf, output_nc, final=True)
+        self.model, self.model1_1, self.model1_2 = _Holder(g.mods), _Holder(d.mods), _Holder(u.mods)
+        self.seq_global, self.seq_11, self.seq_12 = _SeqView(self.model, g.layout), _SeqView(self.model1_1, d.layout), _SeqView(self.model1_2, u.layout)
+
+    def forward(self, x, style_code=None, verbose=False):
+        out, _ = engine.resnet_forward(self, x, keep=False)
+        return out
+
+
 class GlobalGenerator(ResnetGenerator):
     """pix2pixHD coarse generator (reference: networks.py:1952-1980; `define_G(netG='global')` :309-310):
     BatchNorm, stride-2 3x3 downsampling, ConvTranspose2d upsampling, every convolution with a bias."""
@@ -313,8 +405,14 @@ def init_net(net, init_type="normal", init_gain=0.02, gpu_ids=(), initialize_wei
 def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, init_type="normal", init_gain=0.02,
              no_antialias=False, no_antialias_up=False, gpu_ids=(), opt=None, generate_T_imgs=False, num_layer_separate=0):
     resnet_blocks = {"resnet_9blocks": 9, "resnet_6blocks": 6, "resnet_4blocks": 4}
-    if netG not in resnet_blocks and netG not in ("unet256_custom", "global"):
-        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom, resnet_{4,6,9}blocks, global)" % netG)
+    if netG not in resnet_blocks and netG not in ("unet256_custom", "global", "local"):
+        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom, resnet_{4,6,9}blocks, global, local)" % netG)
+    if netG == "local":    # pix2pixHD LocalEnhancer (networks.py:311-313)
+        if norm not in ("batch", "instance"):
+            raise NotImplementedError("local enhancer: norm %s is not built" % norm)
+        net = LocalEnhancer(input_nc, output_nc, ngf, getattr(opt, "n_downsample_global", 4), getattr(opt, "n_blocks_global", 9),
+                            getattr(opt, "n_local_enhancers", 1), getattr(opt, "n_blocks_local", 3), norm, opt=opt)
+        return init_net(net, init_type, init_gain, gpu_ids)
     if netG == "global":   # pix2pixHD coarse generator (networks.py:309-310)
         if norm not in ("batch", "instance"):
             raise NotImplementedError("global generator: norm %s is not built" % norm)

@@ -110,8 +110,8 @@ class Pix2PixHDModel(BaseModel):
             bad.append("VGG perceptual loss needs pretrained VGG19 weights (--no_vgg_loss True)")
         if not opt.no_instance or opt.instance_feat or opt.label_feat or opt.label_nc != 0 or opt.load_features:
             bad.append("instance / label feature inputs (netE) are not built")
-        if opt.netG != "global":
-            bad.append("netG %s (only the coarse 'global' generator is built; LocalEnhancer is not)" % opt.netG)
+        if opt.netG not in ("global", "local"):
+            bad.append("netG %s (built: global, local)" % opt.netG)
         if opt.pool_size > 0 or opt.fp16 or opt.niter_fix_global > 0 or opt.T_resolution_multiplier != 1 or not opt.use_bg_mask:
             bad.append("pool_size > 0 / fp16 / niter_fix_global / T_resolution_multiplier != 1 / use_bg_mask False")
         if opt.isTrain and opt.no_gan_loss:

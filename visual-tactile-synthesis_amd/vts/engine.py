@@ -281,17 +281,16 @@ def _conv3(x, conv, out, stride, act_in):
     return ops.conv4x4(x, w4, ci * 16, 16, co, out, bias=conv.bias, stride=2, pad=1, act_in=act_in)
 
 
-def resnet_forward(G, x, keep=True):
-    """x: tensor / Act, or a pair (x0, x1) concatenated on store into the first padded tensor.
-    Returns (g_out [N,output_nc,H,W] post-tanh, ctx).  Every 3x3 / 7x7 conv runs as 4x4 tap blocks
-    (ops.convk); normalisation is a statistics pass only and is applied on load by the consumer."""
-    srcs = [_as_act(t) for t in (x if isinstance(x, (tuple, list)) else (x,))]
-    n, _, h, w = srcs[0].data.shape
-    dev = srcs[0].data.device
-    steps = []          # per layer group: what the backward needs
-    cur = None          # current activation: Act (raw + affine, activation pending) or identity tensor
-    pending = 0         # activation still to be applied to `cur` by its consumer
-    lay = G.layout
+def _seq_forward(G, seq, srcs, cur, pending):
+    """Run one nn.Sequential-like segment (`seq.layout` over `seq.mod` / `seq.block_mods`).  srcs: the network input(s)
+    (Acts, concatenated on store into the first padded tensor) when the segment starts at the input (cur None);
+    otherwise cur is the incoming activation (Act with `pending` activation, or an identity tensor).
+    Returns (cur, pending, steps); steps hold what the backward needs.  G supplies the train / eval mode."""
+    first = srcs[0].data if cur is None else (cur.data if isinstance(cur, Act) else cur)
+    n, _, h, w = first.shape
+    dev = first.device
+    steps = []
+    lay = seq.layout
     i = 0
 
     def shape_of(t):
@@ -301,7 +300,7 @@ def resnet_forward(G, x, keep=True):
         e = lay[i]
         kind = e["kind"]
         if kind == "pad":      # ReflectionPad2d(3) + conv7 (+ norm / relu | tanh)
-            conv = G.mod(lay[i + 1]["idx"])
+            conv = seq.mod(lay[i + 1]["idx"])
             if cur is None:    # network input: concat the sources while padding
                 cin = sum(s_.data.shape[1] for s_ in srcs)
                 p = _empty(n, cin, h + 6, w + 6, dev)
@@ -317,7 +316,7 @@ def resnet_forward(G, x, keep=True):
             r = _empty(n, conv.weight.shape[0], p.shape[2] - 6, p.shape[3] - 6, dev)
             ops.convk(p, conv.weight, r, bias=conv.bias, pad=0)
             if lay[i + 2]["kind"] == "norm":
-                bn = G.mod(lay[i + 2]["idx"])
+                bn = seq.mod(lay[i + 2]["idx"])
                 cur, pending = _g_norm(G, r, bn), RELU
                 steps.append(("conv7", conv, p, src_act, cur, bn))
                 i += 4
@@ -327,7 +326,7 @@ def resnet_forward(G, x, keep=True):
                 i += 3
                 cur = g_out
         elif kind == "conv3":  # Conv2d(3, pad 1, stride 1 | 2) + norm + relu
-            conv, bn = G.mod(e["idx"]), G.mod(lay[i + 1]["idx"])
+            conv, bn = seq.mod(e["idx"]), seq.mod(lay[i + 1]["idx"])
             inp, inp_act, stride = cur, pending, e["stride"]
             _, _, ih, iw = shape_of(cur)
             r = _empty(n, conv.weight.shape[0], (ih - 1) // stride + 1, (iw - 1) // stride + 1, dev)
@@ -344,7 +343,7 @@ def resnet_forward(G, x, keep=True):
             steps.append(("conv3", conv, inp, inp_act, cur, bn, stride, xp))
             i += 3
         elif kind == "convT3":  # ConvTranspose2d(3, stride 2, pad 1, output_padding 1) + norm + relu
-            conv, bn = G.mod(e["idx"]), G.mod(lay[i + 1]["idx"])
+            conv, bn = seq.mod(e["idx"]), seq.mod(lay[i + 1]["idx"])
             inp, inp_act = cur, pending
             _, _, ih, iw = shape_of(cur)
             ci, co = conv.weight.shape[:2]
@@ -370,7 +369,7 @@ def resnet_forward(G, x, keep=True):
             steps.append(("up", inp, inp_act))
             i += 1
         elif kind == "block":  # x + norm(conv(reflpad(relu(norm(conv(reflpad(x)))))))
-            ca, na, cb, nb = G.block_mods(e["idx"])
+            ca, na, cb, nb = seq.block_mods(e["idx"])
             if pending or isinstance(cur, Act):   # first block after a strided conv: materialise relu(norm(r))
                 blk_src = (cur, pending)
                 cur, pending = ops.pad_affine(cur, (0, 0, 0, 0), 0, act=pending), 0
@@ -390,6 +389,18 @@ def resnet_forward(G, x, keep=True):
             i += 1
         else:
             raise RuntimeError("unexpected layout entry %r" % (e,))
+    return cur, pending, steps
+
+
+def resnet_forward(G, x, keep=True):
+    """x: tensor / Act, or a pair (x0, x1) concatenated on store into the first padded tensor.
+    Returns (g_out [N,output_nc,H,W] post-tanh, ctx).  Every 3x3 / 7x7 conv runs as 4x4 tap blocks
+    (ops.convk) or, for wide layers, on the GEMM-class kernels; normalisation is a statistics pass only and is
+    applied on load by the consumer."""
+    if getattr(G, "is_local_enhancer", False):
+        return local_enhancer_forward(G, x, keep)
+    srcs = [_as_act(t) for t in (x if isinstance(x, (tuple, list)) else (x,))]
+    cur, _, steps = _seq_forward(G, G, srcs, None, 0)
     ctx = None
     if keep:
         ctx = ResnetCtx()
@@ -397,29 +408,52 @@ def resnet_forward(G, x, keep=True):
     return cur, ctx
 
 
-def resnet_backward(G, ctx, d_raw):
-    """d_raw: gradient w.r.t. the pre-tanh output.  Writes every parameter's .grad (overwrite).
-    Biases that feed a normalisation have identically zero gradient and are never written."""
-    dev = d_raw.device
-    sq = SideQueue()     # weight / bias gradients: off the critical path of the backward-data chain
+def local_enhancer_forward(G, x, keep=True):
+    """pix2pixHD LocalEnhancer.forward with one local enhancer (networks.py:1933-1949): the global trunk on the
+    average-pooled input, the local downsampling branch on the full input, their sum through the local upsampling branch"""
+    x = _as_act(x)
+    xd = Act(ops.avgpool(x.data))
+    a, pa, steps_g = _seq_forward(G, G.seq_global, [xd], None, 0)
+    b, pb, steps_1 = _seq_forward(G, G.seq_11, [x], None, 0)
+    bm = ops.pad_affine(b, (0, 0, 0, 0), 0, act=pb)
+    s = ops.pad_affine(a, (0, 0, 0, 0), 0, act=pa, res=bm)
+    out, _, steps_2 = _seq_forward(G, G.seq_12, None, s, 0)
+    ctx = None
+    if keep:
+        ctx = ResnetCtx()
+        ctx.steps, ctx.g_out = (steps_g, steps_1, steps_2, a, b), out
+    return out, ctx
 
-    def through_norm_relu(g_act, a, bn):
-        """gradient w.r.t. relu(norm(r)) -> gradient w.r.t. the raw conv output r (in a fresh buffer)"""
-        buf = torch.empty_like(a.data)
-        ops.act_bwd(g_act, a, RELU, buf)
-        _g_norm_bwd(buf, a, bn)
-        return buf
+
+def _through_norm_relu(g_act, a, bn):
+    """gradient w.r.t. relu(norm(r)) -> gradient w.r.t. the raw conv output r (in a fresh buffer)"""
+    buf = torch.empty_like(a.data)
+    ops.act_bwd(g_act, a, RELU, buf)
+    _g_norm_bwd(buf, a, bn)
+    return buf
+
+
+def _bn_map(*step_lists):
+    """Act -> the BatchNorm module that produced its affine (None: InstanceNorm)"""
+    bn_of = {}
+    for steps in step_lists:
+        for st in steps:
+            if st[0] in ("conv7", "conv3", "convT3"):
+                bn_of[id(st[4])] = st[5]
+    return bn_of
+
+
+def _seq_backward(steps, g, sq, bn_of):
+    """backward of one segment: g = gradient w.r.t. its output (the pre-tanh output for a final conv7, else w.r.t. the
+    raw output of its last conv / the identity output of its last block).  Writes the parameters' .grad (overwrite;
+    through the side queue sq) and returns the gradient w.r.t. the segment's input (None for a network input)."""
+    dev = g.device
+    through_norm_relu = _through_norm_relu
 
     def producer_bn(a):
         return bn_of.get(id(a))
 
-    bn_of = {}
-    for st in ctx.steps:      # Act -> the BatchNorm module that produced its affine (None: InstanceNorm)
-        if st[0] in ("conv7", "conv3", "convT3"):
-            bn_of[id(st[4])] = st[5]
-
-    g = d_raw            # gradient w.r.t. the output of the step being processed
-    for st in reversed(ctx.steps):
+    for st in reversed(steps):
         kind = st[0]
         if kind == "conv7_out":
             _, conv, p, src_act, _, _ = st
@@ -503,6 +537,21 @@ def resnet_backward(G, ctx, d_raw):
                 g = through_norm_relu(g, src, producer_bn(src)) if src_act == RELU else g
         else:
             raise RuntimeError(kind)
+    return g
+
+
+def resnet_backward(G, ctx, d_raw):
+    """d_raw: gradient w.r.t. the pre-tanh output.  Writes every parameter's .grad (overwrite).
+    Biases that feed a normalisation have identically zero gradient and are never written."""
+    sq = SideQueue()     # weight / bias gradients: off the critical path of the backward-data chain
+    if getattr(G, "is_local_enhancer", False):
+        steps_g, steps_1, steps_2, a, b = ctx.steps
+        bn_of = _bn_map(steps_g, steps_1, steps_2)
+        g_s = _seq_backward(steps_2, d_raw, sq, bn_of)         # gradient w.r.t. relu(norm(a)) + relu(norm(b))
+        _seq_backward(steps_g, _through_norm_relu(g_s, a, bn_of.get(id(a))), sq, bn_of)
+        _seq_backward(steps_1, _through_norm_relu(g_s, b, bn_of.get(id(b))), sq, bn_of)
+    else:
+        _seq_backward(ctx.steps, d_raw, sq, _bn_map(ctx.steps))
     sq.join()
 
 
