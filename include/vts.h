@@ -212,15 +212,20 @@ int vts_tap_extract(const float* dw4, int64_t rows, int K, int a, int b, float* 
  *   vts_wgrad3x3_wide    dw[co][ci][ky][kx] (+)= sum_{n,y,x} dout[n,co,y,x] * in[n,ci,stride*y+ky,stride*x+kx]
  *                        (dout [N,Cout,H,W], in [N,Cin,stride*H+2,stride*W+2]; for a ConvTranspose2d weight pass the layer input
  *                        as `dout` and the padded output gradient as `in`); deterministic slice reduction through `ws`.
- * Grids too small to fill the GPU split the channel loop of vts_conv3x3_wide (scratch: vts_conv3x3_wide_ws_floats). */
+ * Grids too small to fill the GPU split the channel loop (scratch: vts_conv3x3_wide_ws_floats, called with the grid of output
+ * pixels of ONE launch: the output extent for the convolutions, the input extent for the transposed one).
+ * Maps of <= 128 output pixels per image (pix2pixHD trained patch-wise, models/pix2pixHD_model.py:587-722 on the 32 x 32
+ * patches of data/patchskit_dataset.py:277-333: the 1024-channel blocks see 2 x 2 maps) run on flattened-batch variants of the
+ * same kernels (GEMM N / K dimension = the (image, y, x) index of whole images); results and interface are unchanged.
+ * `ws` of vts_wgrad3x3_wide may be NULL when vts_wgrad3x3_wide_ws_floats returns 0. */
 int vts_w3x3_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream);
 int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
                      float* ws, int64_t ws_floats, void* stream);
 int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
 int vts_conv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int OH, int OW,
-                       void* stream);
+                       float* ws, int64_t ws_floats, void* stream);
 int vts_tconv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int IH, int IW,
-                        void* stream);
+                        float* ws, int64_t ws_floats, void* stream);
 int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int stride);
 int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int stride,
                       int accumulate, float* ws, int64_t ws_floats, void* stream);

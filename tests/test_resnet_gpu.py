@@ -316,7 +316,11 @@ def test_resnet_generator_strided_variants_wide():
     _check_param_grads(G, sdo)
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 20, 132, 9, 37), (1, 256, 256, 8, 64), (1, 8, 4, 5, 5)])
+# maps of <= 128 pixels take the flattened-batch variants (several whole images per pixel tile, k-split)
+FLAT_SHAPES = [(32, 64, 128, 2, 2), (5, 132, 68, 4, 4), (7, 40, 64, 3, 5), (3, 72, 136, 8, 8), (2, 36, 132, 9, 11), (33, 256, 128, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 20, 132, 9, 37), (1, 256, 256, 8, 64), (1, 8, 4, 5, 5)] + FLAT_SHAPES)
 def test_conv3x3_wide_forward_and_input_adjoint(shape):
     """GEMM-class 3x3 kernel vs F.conv2d on the padded input; the adjoint through the flipped / transposed packing"""
     from vts import ops
@@ -355,7 +359,8 @@ def test_conv3x3_wide_ksplit_small_map():
     assert torch.equal(out, out2)          # deterministic
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 70, 132, 9, 37), (1, 256, 64, 8, 64), (3, 8, 4, 5, 5)])
+@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 70, 132, 9, 37), (1, 256, 64, 8, 64), (3, 8, 4, 5, 5), (32, 64, 128, 2, 2),
+                                   (5, 70, 132, 4, 4), (9, 136, 72, 3, 5), (2, 64, 64, 8, 8), (33, 130, 64, 1, 1), (32, 1024, 512, 2, 2)])
 def test_wgrad3x3_wide(shape):
     """GEMM-class weight gradient vs autograd; accumulate; run-to-run determinism"""
     from vts import ops
@@ -376,7 +381,8 @@ def test_wgrad3x3_wide(shape):
     assert torch.equal(dw, dw3)
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 68, 72, 6, 20), (1, 128, 64, 10, 48)])
+@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 68, 72, 6, 20), (1, 128, 64, 10, 48), (32, 64, 68, 2, 2), (5, 72, 64, 4, 4),
+                                   (3, 68, 64, 1, 2), (2, 64, 64, 8, 8)])
 def test_wide_strided_and_transposed_family(shape):
     """stride-2 3x3 conv and ConvTranspose2d(3, s2, p1, op1) on the GEMM-class kernels: forward, input adjoint
     (each is the other's adjoint) and weight gradient vs autograd; n, ci, co, oh, ow = low-resolution side"""

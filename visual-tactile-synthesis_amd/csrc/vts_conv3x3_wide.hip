@@ -172,6 +172,170 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
   out[i] = v;
 }
 
+// ---- flattened small-map variant -------------------------------------------------------------------------------
+// Maps of <= 128 output pixels (pix2pixHD trained patch-wise: the 1024-channel ResnetBlocks then see 2 x 2 maps,
+// reference models/pix2pixHD_model.py:587-722 with data/patchskit_dataset.py:277-333) would leave the 4 x 32 pixel
+// tile of conv3x3_wide_kernel almost empty.  Here the N dimension of the GEMM is the FLATTENED (image, y, x) index
+// of IPT whole images (IPT * H * W <= 128), the staged operand is the IPT x CK complete padded planes, and a lane
+// finds its pixel through a precomputed plane offset; everything else (tap table, packed weights, MFMA tiling,
+// k-split) is the same.  The work per layer is then dominated by reading the weights once, so the channel loop
+// is split until the grid fills the GPU.  TW = taps of the packed weight (9, or 16 for 4 x 4 kernels).
+struct FlatK {
+  const float *in, *wt, *bias;
+  float* out;
+  int N, Cin, Cout, H, W;        // H x W: the (phase) grid of output pixels
+  int IPH, IPW, S;               // padded input extent, input stride
+  int OH, OW, os, oy0, ox0;      // full output extent, output stride and phase offset
+  int TW, ntaps;
+  signed char dy[16], dx[16], wt_tap[16];
+  int IPT, slot;                 // images per pixel tile, LDS floats per (channel, image) plane (multiple of 4)
+  int KS, cps;
+  float* part;                   // [KS][N][Cout][H][W] raw partial sums of the phase grid (KS > 1)
+};
+
+constexpr int FLAT_PATCH_CAP = 8192;
+
+template <int FCK, int MAXT>
+__global__ __launch_bounds__(256) void conv_flat_kernel(const FlatK p) {
+  constexpr int W_FLOATS = FCK * MAXT * TCO;
+  constexpr int NPQ = FLAT_PATCH_CAP / 4 / 256;
+  constexpr int NWQ = W_FLOATS / 4 / 256;
+  __shared__ __attribute__((aligned(16))) float lds[FLAT_PATCH_CAP + W_FLOATS];
+  float* lds_p = lds;
+  float* lds_w = lds + FLAT_PATCH_CAP;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave & 1, wpx = wave >> 1;
+  const int n0 = blockIdx.x * p.IPT, co0 = blockIdx.y * TCO, ks = blockIdx.z;
+  const int PW = p.IPW, plane = p.IPH * p.IPW, HW = p.H * p.W;
+  const int ntaps = p.ntaps, slot = p.slot, sq = slot >> 2, chs = p.IPT * slot;
+  const int TQ = FCK * p.IPT * sq;                     // patch quads per chunk
+
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.N * p.Cin * plane * 4, RSRC_FLAGS);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * p.TW * p.Cout * 4, RSRC_FLAGS);
+
+  int pvoff[NPQ], ploff[NPQ], pci[NPQ];
+#pragma unroll
+  for (int e = 0; e < NPQ; ++e) {
+    const int q = min(tid + e * 256, TQ - 1);
+    const int ci = q / (p.IPT * sq), r = q - ci * (p.IPT * sq);
+    const int img = r / sq, pqi = r - img * sq;
+    pci[e] = ci;
+    pvoff[e] = n0 + img < p.N ? (((n0 + img) * p.Cin + ci) * plane + 4 * pqi) * 4 : 0x7ffffff0;
+    ploff[e] = (ci * p.IPT + img) * slot + 4 * pqi;
+  }
+  int wvoff[NWQ], wloff[NWQ];
+#pragma unroll
+  for (int e = 0; e < NWQ; ++e) {
+    const int q = tid + e * 256;
+    const int row = q >> 5, cq = q & 31;                    // row = ci * ntaps + t
+    const int ci = row / ntaps, t = row - ci * ntaps;
+    const bool live = row < FCK * ntaps;
+    wvoff[e] = live ? ((ci * p.TW + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;
+    wloff[e] = (live ? row : 0) * TCO + 4 * cq;
+  }
+
+  u32x4 pq[NPQ], wq[NWQ];
+  auto load_chunk = [&](int c0) {
+    const int pbase = c0 * plane * 4, wbase = c0 * p.TW * p.Cout * 4;
+#pragma unroll
+    for (int e = 0; e < NPQ; ++e)
+      if (e * 256 < TQ) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, c0 + pci[e] < p.Cin ? pvoff[e] + pbase : 0x7ffffff0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e)
+      if (e * 8 < FCK * ntaps) wq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[e] + wbase, 0, 0);
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < NPQ; ++e)
+      if (e * 256 < TQ) *reinterpret_cast<u32x4*>(lds_p + ploff[e]) = pq[e];
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e)
+      if (e * 8 < FCK * ntaps && ((tid + e * 256) >> 5) < FCK * ntaps) *reinterpret_cast<u32x4*>(lds_w + wloff[e]) = wq[e];
+  };
+
+  // this lane's two pixels (B fragments j = 0, 1): plane offset of tap (0, 0) and the output position
+  int pixoff[2], oimg[2], opos[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int px = wpx * 64 + j * 32 + l32;
+    const int img = px / HW, r = px - img * HW;
+    const int y = r / p.W, x = r - y * p.W;
+    const bool ok = img < p.IPT && n0 + img < p.N;
+    pixoff[j] = ok ? img * slot + p.S * y * PW + p.S * x : 0;
+    oimg[j] = ok ? n0 + img : -1;
+    opos[j] = p.part ? r : (p.oy0 + p.os * y) * p.OW + p.ox0 + p.os * x;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* a_base = lds_w + kh * ntaps * TCO + wco * 64 + l32;
+  const float* b0_base = lds_p + kh * chs + pixoff[0];
+  const float* b1_base = lds_p + kh * chs + pixoff[1];
+
+  const int nchunks_all = (p.Cin + FCK - 1) / FCK;
+  const int cbeg = ks * p.cps, nchunks = min(nchunks_all, cbeg + p.cps);
+  load_chunk(cbeg * FCK);
+  store_chunk();
+  __syncthreads();
+  for (int c = cbeg; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) load_chunk((c + 1) * FCK);
+    for (int t = 0; t < ntaps; ++t) {
+      const int boff = p.dy[t] * PW + p.dx[t];
+#pragma unroll
+      for (int kc = 0; kc < FCK / 2; ++kc) {
+        const float a0 = a_base[(kc * 2 * ntaps + t) * TCO], a1 = a_base[(kc * 2 * ntaps + t) * TCO + 32];
+        const float b0 = b0_base[kc * 2 * chs + boff], b1 = b1_base[kc * 2 * chs + boff];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  const int64_t oplane = p.part ? HW : (int64_t)p.OH * p.OW;
+  float* ob = p.part ? p.part + (int64_t)ks * p.N * p.Cout * oplane : p.out;
+  const bool add_bias = p.bias && !p.part;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (oimg[j] < 0) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 64 + i * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+        if (co < p.Cout) ob[((int64_t)oimg[j] * p.Cout + co) * oplane + opos[j]] = acc[i][j][r] + (add_bias ? p.bias[co] : 0.f);
+      }
+    }
+}
+
+// out[n, co, oy0 + os*y, ox0 + os*x] = bias[co] + sum_k part[k][n][co][y][x]
+__global__ __launch_bounds__(256) void flat_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int KS,
+                                                           int64_t per_slice, int H, int W, int Cout, int OH, int OW, int os, int oy0,
+                                                           int ox0, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_slice) return;
+  const int HW = H * W;
+  const int64_t nc = i / HW;
+  const int r = (int)(i - nc * HW), y = r / W, x = r - y * W;
+  float v = bias ? bias[nc % Cout] : 0.f;
+  for (int k = 0; k < KS; ++k) v += part[k * per_slice + i];
+  out[nc * OH * OW + (int64_t)(oy0 + os * y) * OW + ox0 + os * x] = v;
+}
+
 // wt[(a * 9 + t) * B + b] = w[a * sa + b * sb + (flip ? 8 - t : t)]   (a < A: the operator's input channel, b < B: its output channel)
 __global__ __launch_bounds__(256) void w3x3_pack_kernel(const float* __restrict__ w, int A, int B, int64_t sa, int64_t sb, int flip,
                                                          float* __restrict__ wt) {
@@ -206,16 +370,73 @@ static int wide_plan(int N, int Cin, int Cout, int H, int W, int* cps) {
   return cdiv(nchunks, *cps);
 }
 
+// flattened small-map variant: images per pixel tile, k-split
+constexpr int FLAT_MAX_PIXELS = 128;
+static bool flat_ok(int H, int W, int plane, int fck) { return H * W <= FLAT_MAX_PIXELS && fck * ((plane + 3) / 4 * 4) <= FLAT_PATCH_CAP; }
+static int flat_plan(int N, int Cin, int Cout, int H, int W, int plane, int fck, int* ipt, int* cps) {
+  const int slot = (plane + 3) / 4 * 4;
+  int IPT = FLAT_MAX_PIXELS / (H * W);
+  if (IPT > FLAT_PATCH_CAP / (fck * slot)) IPT = FLAT_PATCH_CAP / (fck * slot);
+  if (IPT > N) IPT = N;
+  *ipt = IPT;
+  const int wgs = cdiv(N, IPT) * cdiv(Cout, TCO);
+  const int nchunks = cdiv(Cin, fck);
+  int KS = 1;
+  if (wgs < 384) {
+    KS = 512 / wgs;
+    if (KS > nchunks / 2) KS = nchunks / 2;
+    if (KS < 1) KS = 1;
+  }
+  *cps = cdiv(nchunks, KS);
+  return cdiv(nchunks, *cps);
+}
+
 extern "C" int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W) {
-  int cps;
+  // H x W is the grid of output pixels of ONE launch (stride-1 / stride-2 convolution: the output extent; transposed
+  // stride 2: the input extent = one parity phase); the bound covers the three operators' padded planes
+  int cps, ipt;
+  int64_t need = 0;
+  const int planes[3] = {(H + 2) * (W + 2), (2 * H + 2) * (2 * W + 2), (H + 1) * (W + 1)};
+  for (int v = 0; v < 3; ++v)
+    if (flat_ok(H, W, planes[v], CK)) {
+      const int KS = flat_plan(N, Cin, Cout, H, W, planes[v], CK, &ipt, &cps);
+      if (KS > 1 && (int64_t)KS * N * Cout * H * W > need) need = (int64_t)KS * N * Cout * H * W;
+    }
   const int KS = wide_plan(N, Cin, Cout, H, W, &cps);
-  return KS > 1 ? (int64_t)KS * N * Cout * H * W : 0;
+  if (KS > 1 && (int64_t)KS * N * Cout * H * W > need) need = (int64_t)KS * N * Cout * H * W;
+  return need;
+}
+
+static int flat_launch(const WideK& k, int S, float* ws, int64_t ws_floats, hipStream_t st) {
+  FlatK f{};
+  f.in = k.in; f.wt = k.wt; f.bias = k.bias; f.out = k.out; f.N = k.N; f.Cin = k.Cin; f.Cout = k.Cout; f.H = k.H; f.W = k.W;
+  f.IPH = k.IPH; f.IPW = k.IPW; f.S = S; f.OH = k.OH; f.OW = k.OW; f.os = k.os; f.oy0 = k.oy0; f.ox0 = k.ox0;
+  f.TW = 9; f.ntaps = k.ntaps;
+  for (int t = 0; t < k.ntaps; ++t) { f.dy[t] = k.dy[t]; f.dx[t] = k.dx[t]; f.wt_tap[t] = k.wt_tap[t]; }
+  const int plane = k.IPH * k.IPW;
+  VTS_CHECK_ARG((int64_t)k.N * k.Cin * plane * 4 < (1ll << 31), "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
+  f.slot = (plane + 3) / 4 * 4;
+  int KS = flat_plan(k.N, k.Cin, k.Cout, k.H, k.W, plane, CK, &f.IPT, &f.cps);
+  const int64_t per_slice = (int64_t)k.N * k.Cout * k.H * k.W;
+  if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; f.cps = cdiv(k.Cin, CK); }
+  f.KS = KS; f.part = KS > 1 ? ws : nullptr;
+  const dim3 grid(cdiv(k.N, f.IPT), cdiv(k.Cout, TCO), KS);
+  hipLaunchKernelGGL((conv_flat_kernel<CK, 9>), grid, dim3(256), 0, st, f);
+  vts_set_kernel(KS > 1 ? "conv_flat_kernel<%d, 9>+ksplit" : "conv_flat_kernel<%d, 9>", CK);
+  VTS_CHECK_LAUNCH("vts_conv3x3_wide (flat)");
+  if (KS > 1) {
+    hipLaunchKernelGGL(flat_reduce_kernel, dim3((unsigned)cdiv64(per_slice, 256)), dim3(256), 0, st, ws, k.bias, KS, per_slice, k.H, k.W,
+                       k.Cout, k.OH, k.OW, k.os, k.oy0, k.ox0, k.out);
+    VTS_CHECK_LAUNCH("vts_conv3x3_wide (flat) reduce");
+  }
+  return VTS_OK;
 }
 
 static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_t st) {
   VTS_CHECK_ARG((k.Cout & 3) == 0, "vts_conv3x3_wide: Cout %d must be a multiple of 4 (16-byte weight rows)", k.Cout);
   VTS_CHECK_ARG((int64_t)k.Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)k.Cin * 9 * k.Cout * 4 < (1ll << 31) && k.N <= 1024,
                 "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
+  if (flat_ok(k.H, k.W, k.IPH * k.IPW, CK)) return flat_launch(k, S, ws, ws_floats, st);
   int cps;
   int KS = k.os == 1 ? wide_plan(k.N, k.Cin, k.Cout, k.H, k.W, &cps) : 1;
   const int64_t per_slice = (int64_t)k.N * k.Cout * k.OH * k.OW;
@@ -250,17 +471,17 @@ extern "C" int vts_conv3x3_wide(const float* in, const float* wt, const float* b
 }
 
 extern "C" int vts_conv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int OH, int OW,
-                                  void* stream) {
+                                  float* ws, int64_t ws_floats, void* stream) {
   VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && OH >= 1 && OW >= 1, "vts_conv3x3s2_wide: bad args");
   WideK k{};
   k.in = in; k.wt = wt; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = OH; k.W = OW;
   k.IPH = 2 * OH + 2; k.IPW = 2 * OW + 2; k.OH = OH; k.OW = OW; k.os = 1; k.oy0 = 0; k.ox0 = 0;
   full_taps(k);
-  return wide_launch(k, 2, nullptr, 0, (hipStream_t)stream);
+  return wide_launch(k, 2, flat_ok(OH, OW, k.IPH * k.IPW, CK) ? ws : nullptr, ws_floats, (hipStream_t)stream);
 }
 
 extern "C" int vts_tconv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int IH, int IW,
-                                   void* stream) {
+                                   float* ws, int64_t ws_floats, void* stream) {
   VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && IH >= 1 && IW >= 1, "vts_tconv3x3s2_wide: bad args");
   // out[2i + py] = sum over (d, k) with k = py + 1 - 2d:  py = 0: (d 0, k 1);  py = 1: (d 0, k 2), (d 1, k 0); input index i + d
   static const int ND[2] = {1, 2}, D[2][2] = {{0, 0}, {0, 1}}, KK[2][2] = {{1, 0}, {2, 0}};
@@ -276,7 +497,7 @@ extern "C" int vts_tconv3x3s2_wide(const float* in, const float* wt, const float
           k.wt_tap[k.ntaps] = (signed char)(KK[py][a] * 3 + KK[px][b]);
           ++k.ntaps;
         }
-      const int rc = wide_launch(k, 1, nullptr, 0, (hipStream_t)stream);
+      const int rc = wide_launch(k, 1, flat_ok(IH, IW, k.IPH * k.IPW, CK) ? ws : nullptr, ws_floats, (hipStream_t)stream);
       if (rc != VTS_OK) return rc;
     }
   return VTS_OK;
@@ -440,6 +661,137 @@ __global__ __launch_bounds__(256) void wg_wide_reduce_kernel(const float* __rest
   dw[i] = v;
 }
 
+// ---- flattened small-map variant of the weight gradient: K = the flattened (image, y, x) index of IPT whole images
+// (<= 64 pixels per tile), operands staged as complete planes, per-pixel plane offsets from an LDS table.
+constexpr int WGF_PX = 64, WGF_DO_PITCH = WGF_PX + 1, WGF_IN_CAP = 256;   // WGF_IN_CAP: floats per input channel (IPT planes)
+
+struct WgFlatK {
+  const float *dout, *in;
+  float* out;               // dw (direct) or part [KS][Cout][Cin][9]
+  int N, Cin, Cout, H, W;   // H x W: extent of dout
+  int IPH, IPW, S;
+  int IPT, ntiles, tps;     // images per K tile, tiles, tiles per K slice
+  int direct, accumulate;   // direct: one K slice, write (or accumulate into) dw from the epilogue
+};
+
+__global__ __launch_bounds__(256) void wgrad3x3_flat_kernel(const WgFlatK p) {
+  constexpr int P_PITCH = WGF_IN_CAP + 1;
+  constexpr int NIQ = GCI * (WGF_IN_CAP / 4) / 256;       // 16 quads per thread at most
+  __shared__ float lds[GCO * WGF_DO_PITCH + GCI * P_PITCH];
+  __shared__ int lds_pix[WGF_PX];
+  float* lds_d = lds;
+  float* lds_i = lds + GCO * WGF_DO_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave & 1, wci = wave >> 1;
+  const int co0 = blockIdx.x * GCO, ci0 = blockIdx.y * GCI, ks = blockIdx.z;
+  const int PW = p.IPW, plane = p.IPH * p.IPW, HW = p.H * p.W;
+  const int pq = (plane + 3) >> 2, TQ = GCI * p.IPT * pq;
+  const int KPX = p.IPT * HW;                              // pixels per full tile (<= 64)
+
+  const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dout), 0, p.N * p.Cout * HW * 4, RSRC_FLAGS);
+  const auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.N * p.Cin * plane * 4, RSRC_FLAGS);
+
+  // pixel table (tile independent): px -> offset of tap (0, 0) inside this channel's IPT planes
+  if (tid < WGF_PX) {
+    const int img = tid / HW, r = tid - img * HW, y = r / p.W, x = r - y * p.W;
+    lds_pix[tid] = tid < KPX ? img * plane + p.S * y * PW + p.S * x : 0;
+  }
+  // dout staging: thread -> pixel tid % 64, channels tid / 64 + 4 e
+  const int dpx = tid & 63, dimg = dpx / HW, dr = dpx - dimg * HW;
+  // input staging: quads (ci, img, quad of the plane)
+  int ivoff[NIQ], iloff[NIQ], irem[NIQ];
+#pragma unroll
+  for (int e = 0; e < NIQ; ++e) {
+    const int q = min(tid + e * 256, TQ - 1);
+    const int ci = q / (p.IPT * pq), r = q - ci * (p.IPT * pq);
+    const int img = r / pq, qi = r - img * pq;
+    ivoff[e] = ci0 + ci < p.Cin ? ((img * p.Cin + ci0 + ci) * plane + 4 * qi) * 4 : 0x7ffffff0;
+    iloff[e] = ci * P_PITCH + img * plane + 4 * qi;
+    irem[e] = (plane - 4 * qi) | (img << 16);             // valid floats of the quad, image index
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* a_base = lds_d + (wco * 32 + l32) * WGF_DO_PITCH + kh;
+  const float* b_base = lds_i + (wci * 32 + l32) * P_PITCH;
+
+  const int t_beg = ks * p.tps, t_end = min(p.ntiles, t_beg + p.tps);
+  for (int t = t_beg; t < t_end; ++t) {
+    const int n0 = t * p.IPT;
+    float dv[16];
+    {
+      const bool pok = dpx < KPX && n0 + dimg < p.N;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + (tid >> 6) + 4 * e;
+        dv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, pok && co < p.Cout ? (((n0 + dimg) * p.Cout + co) * HW + dr) * 4 : 0x7ffffff0, 0, 0));
+      }
+    }
+    u32x4 iq[NIQ];
+    const int ibase = n0 * p.Cin * plane * 4;
+#pragma unroll
+    for (int e = 0; e < NIQ; ++e)
+      if (e * 256 < TQ) iq[e] = __builtin_amdgcn_raw_buffer_load_b128(ri, n0 + (irem[e] >> 16) < p.N ? ivoff[e] + ibase : 0x7ffffff0, 0, 0);
+    if (t > t_beg) __syncthreads();                        // the previous tile's fragments have been read
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds_d[((tid >> 6) + 4 * e) * WGF_DO_PITCH + dpx] = dv[e];
+#pragma unroll
+    for (int e = 0; e < NIQ; ++e)
+      if (e * 256 < TQ) {
+        const f32x4 v = __builtin_bit_cast(f32x4, iq[e]);
+        const int rem = irem[e] & 0xffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < rem) lds_i[iloff[e] + j] = v[j];
+      }
+    __syncthreads();
+    const int kend = (min(KPX, (p.N - n0) * HW) + 1) >> 1;
+    for (int kk = 0; kk < kend; ++kk) {
+      const float a = a_base[2 * kk];
+      const float* b = b_base + lds_pix[2 * kk + kh];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[ky * PW + kx], acc[tap], 0, 0, 0);
+      }
+    }
+  }
+
+  float* ob = p.direct ? p.out : p.out + (int64_t)ks * p.Cout * p.Cin * 9;
+  const int ci = ci0 + wci * 32 + l32;
+  const bool rmw = p.direct && p.accumulate;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+      if (co < p.Cout && ci < p.Cin) {
+        float* o = ob + ((int64_t)co * p.Cin + ci) * 9 + tap;
+        *o = acc[tap][r] + (rmw ? *o : 0.f);
+      }
+    }
+}
+
+bool wg_flat_ok(int H, int W, int plane) { return H * W <= WGF_PX && (plane + 3) / 4 * 4 <= WGF_IN_CAP; }
+int wg_flat_plan(int N, int Cin, int Cout, int H, int W, int plane, int* ipt, int* tps) {
+  int IPT = WGF_PX / (H * W);
+  if (IPT > WGF_IN_CAP / 4 / ((plane + 3) / 4)) IPT = WGF_IN_CAP / 4 / ((plane + 3) / 4);   // staged as whole quads
+  if (IPT > N) IPT = N;
+  *ipt = IPT;
+  const int ntiles = cdiv(N, IPT);
+  const int groups = cdiv(Cout, GCO) * cdiv(Cin, GCI);
+  int KS = groups >= 192 ? 1 : 384 / groups;
+  if (KS > ntiles) KS = ntiles;
+  if (KS < 1) KS = 1;
+  *tps = cdiv(ntiles, KS);
+  return cdiv(ntiles, *tps);
+}
+
 int wg_wide_plan(int N, int Cin, int Cout, int H, int W, int S, int* tps) {
   const int ntiles = N * cdiv(H, GTY) * cdiv(W, S == 1 ? 32 : 16);
   const int groups = cdiv(Cout, GCO) * cdiv(Cin, GCI);
@@ -453,23 +805,49 @@ int wg_wide_plan(int N, int Cin, int Cout, int H, int W, int S, int* tps) {
 }  // namespace
 
 extern "C" int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int stride) {
-  int tps;
+  int tps, ipt;
+  const int plane = (stride * H + 2) * (stride * W + 2);
+  if (wg_flat_ok(H, W, plane)) {
+    const int KS = wg_flat_plan(N, Cin, Cout, H, W, plane, &ipt, &tps);
+    return KS > 1 ? (int64_t)KS * Cout * Cin * 9 : 0;
+  }
   return (int64_t)wg_wide_plan(N, Cin, Cout, H, W, stride, &tps) * Cout * Cin * 9;
 }
 
 extern "C" int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int stride,
                                  int accumulate, float* ws, int64_t ws_floats, void* stream) {
-  VTS_CHECK_ARG(dout && in && dw && ws && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && (stride == 1 || stride == 2),
+  VTS_CHECK_ARG(dout && in && dw && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && (stride == 1 || stride == 2),
                 "vts_wgrad3x3_wide: bad args");
+  const int IPH = stride * H + 2, IPW = stride * W + 2;
+  const int64_t nel = (int64_t)Cout * Cin * 9;
+  if (wg_flat_ok(H, W, IPH * IPW)) {
+    VTS_CHECK_ARG((int64_t)N * Cin * IPH * IPW * 4 < (1ll << 31) && (int64_t)N * Cout * H * W * 4 < (1ll << 31),
+                  "vts_wgrad3x3_wide: operand exceeds the 2 GiB buffer range");
+    WgFlatK f;
+    f.dout = dout; f.in = in; f.N = N; f.Cin = Cin; f.Cout = Cout; f.H = H; f.W = W; f.IPH = IPH; f.IPW = IPW; f.S = stride;
+    const int KS = wg_flat_plan(N, Cin, Cout, H, W, IPH * IPW, &f.IPT, &f.tps);
+    f.ntiles = cdiv(N, f.IPT);
+    f.direct = KS == 1; f.accumulate = accumulate; f.out = KS == 1 ? dw : ws;
+    VTS_CHECK_ARG(KS == 1 || (ws && ws_floats >= KS * nel), "vts_wgrad3x3_wide: workspace too small (%lld < %lld floats)",
+                  (long long)ws_floats, (long long)(KS * nel));
+    hipLaunchKernelGGL(wgrad3x3_flat_kernel, dim3(cdiv(Cout, GCO), cdiv(Cin, GCI), KS), dim3(256), 0, (hipStream_t)stream, f);
+    vts_set_kernel("wgrad3x3_flat_kernel<%d>", stride);
+    VTS_CHECK_LAUNCH("vts_wgrad3x3_wide (flat)");
+    if (KS > 1) {
+      hipLaunchKernelGGL(wg_wide_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, (hipStream_t)stream, ws, KS, nel, dw, accumulate);
+      VTS_CHECK_LAUNCH("vts_wgrad3x3_wide (flat) reduce");
+    }
+    return VTS_OK;
+  }
+  VTS_CHECK_ARG(ws != nullptr, "vts_wgrad3x3_wide: workspace required");
   WgWideK k;
   k.dout = dout; k.in = in; k.part = ws; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
-  k.IPH = stride * H + 2; k.IPW = stride * W + 2;
+  k.IPH = IPH; k.IPW = IPW;
   VTS_CHECK_ARG((int64_t)Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)Cout * H * W * 4 < (1ll << 31), "vts_wgrad3x3_wide: operand exceeds the 2 GiB buffer range");
   k.tiles_x = cdiv(W, stride == 1 ? 32 : 16);
   k.tiles_per_img = k.tiles_x * cdiv(H, GTY);
   k.ntiles = N * k.tiles_per_img;
   const int KS = wg_wide_plan(N, Cin, Cout, H, W, stride, &k.tps);
-  const int64_t nel = (int64_t)Cout * Cin * 9;
   VTS_CHECK_ARG(ws_floats >= KS * nel, "vts_wgrad3x3_wide: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)(KS * nel));
   const dim3 grid(cdiv(Cout, GCO), cdiv(Cin, GCI), KS);
   if (stride == 1) hipLaunchKernelGGL(wgrad3x3_wide_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);

@@ -139,8 +139,8 @@ def load():
         "vts_tap_embed": [vp, i64, i, i, i, vp, vp],
         "vts_tap_extract": [vp, i64, i, i, i, vp, i, vp],
         "vts_w3x3_pack": [vp, i, i, i64, i64, i, vp, vp],
-        "vts_conv3x3s2_wide": [vp, vp, vp, vp, i, i, i, i, i, vp],
-        "vts_tconv3x3s2_wide": [vp, vp, vp, vp, i, i, i, i, i, vp],
+        "vts_conv3x3s2_wide": [vp, vp, vp, vp, i, i, i, i, i, vp, i64, vp],
+        "vts_tconv3x3s2_wide": [vp, vp, vp, vp, i, i, i, i, i, vp, i64, vp],
         "vts_conv3x3_wide": [vp, vp, vp, vp, i, i, i, i, i, vp, i64, vp],
         "vts_wgrad3x3_wide": [vp, vp, vp, i, i, i, i, i, i, i, vp, i64, vp],
     }

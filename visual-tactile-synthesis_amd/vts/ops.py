@@ -249,8 +249,12 @@ def conv3x3s2_wide(p, wt, bias, out):
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d s2" % (n, ci, ph - 2, pw - 2, co, oh, ow)
-    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * oh * ow * co * ci * 9, L.load().vts_conv3x3s2_wide,
-         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, oh, ow, L.stream())
+    lib = L.load()
+    need = lib.vts_conv3x3_wide_ws_floats(n, ci, co, oh, ow)
+    ws = workspace(need, p.device) if need else None
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * oh * ow * co * ci * 9, lib.vts_conv3x3s2_wide,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, oh, ow, L.ptr(ws), ws.numel() if ws is not None else 0,
+         L.stream())
     return out
 
 
@@ -263,8 +267,12 @@ def tconv3x3s2_wide(p, wt, bias, out):
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d transposed s2" % (n, ci, ih, iw, co, 2 * ih, 2 * iw)
-    _run("conv3x3_wide", 4.0 * (4 * p.numel() + out.numel() + wt.numel()), 2.0 * n * ih * iw * co * ci * 9, L.load().vts_tconv3x3s2_wide,
-         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, ih, iw, L.stream())
+    lib = L.load()
+    need = lib.vts_conv3x3_wide_ws_floats(n, ci, co, ih, iw)
+    ws = workspace(need, p.device) if need else None
+    _run("conv3x3_wide", 4.0 * (4 * p.numel() + out.numel() + wt.numel()), 2.0 * n * ih * iw * co * ci * 9, lib.vts_tconv3x3s2_wide,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, ih, iw, L.ptr(ws), ws.numel() if ws is not None else 0,
+         L.stream())
     return out
 
 
@@ -274,12 +282,14 @@ def wgrad3x3_wide(dout, p, dw, accumulate=False, stride=1):
     ci = p.shape[1]
     assert p.shape == (n, ci, stride * h + 2, stride * w + 2) and dw.shape == (co, ci, 3, 3) and dout.is_contiguous() and p.is_contiguous()
     lib = L.load()
-    ws = workspace(lib.vts_wgrad3x3_wide_ws_floats(n, ci, co, h, w, stride), p.device)
+    need = lib.vts_wgrad3x3_wide_ws_floats(n, ci, co, h, w, stride)
+    ws = workspace(need, p.device) if need else None
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d dout %dx%dx%d in %dx%dx%d s%d" % (n, co, h, w, ci, p.shape[2], p.shape[3], stride)
     _run("wgrad3x3_wide", 4.0 * (dout.numel() + p.numel() + dw.numel()), 2.0 * n * h * w * co * ci * 9, lib.vts_wgrad3x3_wide,
-         dout.data_ptr(), p.data_ptr(), dw.data_ptr(), n, ci, co, h, w, stride, int(accumulate), ws.data_ptr(), ws.numel(), L.stream())
+         dout.data_ptr(), p.data_ptr(), dw.data_ptr(), n, ci, co, h, w, stride, int(accumulate), L.ptr(ws),
+         ws.numel() if ws is not None else 0, L.stream())
     return dw
 
 
