@@ -38,7 +38,7 @@ struct WideK {
   int IPH, IPW;                  // padded input extent
   int OH, OW, os, oy0, ox0;      // full output extent, output stride and phase offset
   int ntaps;
-  signed char dy[9], dx[9], wt_tap[9];
+  signed char dy[16], dx[16], wt_tap[16];   // (the 3x3 kernels use <= 9; the 4x4 flat entry up to 16)
   int KS, cps;   // k-split for small grids: blockIdx.z = n + N * slice, cps input-channel chunks per slice
   float* part;   // [KS][N][Cout][OH][OW] raw partial sums (KS > 1), reduced in slice order by wide_reduce_kernel
 };
@@ -186,7 +186,7 @@ struct FlatK {
   int N, Cin, Cout, H, W;        // H x W: the (phase) grid of output pixels
   int IPH, IPW, S;               // padded input extent, input stride
   int OH, OW, os, oy0, ox0;      // full output extent, output stride and phase offset
-  int TW, ntaps;
+  int TW, ntaps, Cw;             // taps of the packed weight, taps of this launch, weight row pitch (>= Cout, multiple of 4)
   signed char dy[16], dx[16], wt_tap[16];
   int IPT, slot;                 // images per pixel tile, LDS floats per (channel, image) plane (multiple of 4)
   int KS, cps;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const FlatK p) {
   const int TQ = FCK * p.IPT * sq;                     // patch quads per chunk
 
   const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.N * p.Cin * plane * 4, RSRC_FLAGS);
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * p.TW * p.Cout * 4, RSRC_FLAGS);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * p.TW * p.Cw * 4, RSRC_FLAGS);
 
   int pvoff[NPQ], ploff[NPQ], pci[NPQ];
 #pragma unroll
@@ -231,13 +231,13 @@ __global__ __launch_bounds__(256) void conv_flat_kernel(const FlatK p) {
     const int row = q >> 5, cq = q & 31;                    // row = ci * ntaps + t
     const int ci = row / ntaps, t = row - ci * ntaps;
     const bool live = row < FCK * ntaps;
-    wvoff[e] = live ? ((ci * p.TW + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;
+    wvoff[e] = live ? ((ci * p.TW + p.wt_tap[live ? t : 0]) * p.Cw + co0 + 4 * cq) * 4 : 0x7ffffff0;
     wloff[e] = (live ? row : 0) * TCO + 4 * cq;
   }
 
   u32x4 pq[NPQ], wq[NWQ];
   auto load_chunk = [&](int c0) {
-    const int pbase = c0 * plane * 4, wbase = c0 * p.TW * p.Cout * 4;
+    const int pbase = c0 * plane * 4, wbase = c0 * p.TW * p.Cw * 4;
 #pragma unroll
     for (int e = 0; e < NPQ; ++e)
       if (e * 256 < TQ) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, c0 + pci[e] < p.Cin ? pvoff[e] + pbase : 0x7ffffff0, 0, 0);
@@ -336,25 +336,52 @@ __global__ __launch_bounds__(256) void flat_reduce_kernel(const float* __restric
   out[nc * OH * OW + (int64_t)(oy0 + os * y) * OW + ox0 + os * x] = v;
 }
 
-// wt[(a * 9 + t) * B + b] = w[a * sa + b * sb + (flip ? 8 - t : t)]   (a < A: the operator's input channel, b < B: its output channel)
-__global__ __launch_bounds__(256) void w3x3_pack_kernel(const float* __restrict__ w, int A, int B, int64_t sa, int64_t sb, int flip,
-                                                         float* __restrict__ wt) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // indexes the OUTPUT so that writes are coalesced
-  if (i >= (int64_t)A * B * 9) return;
-  const int b = (int)(i % B);
-  const int64_t r = i / B;
-  const int t = (int)(r % 9), a = (int)(r / 9);
-  wt[i] = w[a * sa + b * sb + (flip ? 8 - t : t)];
+// wt[(a * T + t) * Bp + b] = b < B ? w[a * sa + b * sb + (flip ? T - 1 - t : t)] : 0   (a < A: the operator's input channel, b < B: its
+// output channel, Bp = B rounded up to 4).  A workgroup transposes a tile of 32 output channels x 64 (a, t) rows through LDS so that
+// both the gather from the parameter tensor and the packed store run along their contiguous index where there is one.
+__global__ __launch_bounds__(256) void wtap_pack_kernel(const float* __restrict__ w, int A, int B, int Bp, int64_t sa, int64_t sb, int T,
+                                                         int flip, int rows_contig, float* __restrict__ wt) {
+  __shared__ float tile[64][33];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int b0 = blockIdx.y * 32;
+  const int64_t R = (int64_t)A * T;
+  // gather: rows_contig: consecutive lanes walk the (a, t) rows (contiguous in w when sa == T), else the b index
+  for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+    const int rr = rows_contig ? e & 63 : e >> 5, bb = rows_contig ? e >> 6 : e & 31;
+    const int64_t r = r0 + rr;
+    const int b = b0 + bb;
+    float v = 0.f;
+    if (r < R && b < B) {
+      const int t = (int)(r % T);
+      const int64_t a = r / T;
+      v = w[a * sa + b * sb + (flip ? T - 1 - t : t)];
+    }
+    tile[rr][bb] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+    const int rr = e >> 5, bb = e & 31;
+    if (r0 + rr < R && b0 + bb < Bp) wt[(r0 + rr) * Bp + b0 + bb] = tile[rr][bb];
+  }
 }
 
 }  // namespace
 
-extern "C" int vts_w3x3_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream) {
-  VTS_CHECK_ARG(w && wt && A >= 1 && B >= 1, "vts_w3x3_pack: bad args");
-  const int64_t total = (int64_t)A * B * 9;
-  hipLaunchKernelGGL(w3x3_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, A, B, sa, sb, flip, wt);
-  VTS_CHECK_LAUNCH("vts_w3x3_pack");
+static int wtap_pack(const char* who, const float* w, int A, int B, int64_t sa, int64_t sb, int T, int flip, float* wt, void* stream) {
+  VTS_CHECK_ARG(w && wt && A >= 1 && B >= 1, "%s: bad args", who);
+  const int Bp = (B + 3) & ~3;
+  const dim3 grid((unsigned)cdiv64((int64_t)A * T, 64), (unsigned)cdiv(Bp, 32));
+  hipLaunchKernelGGL(wtap_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, A, B, Bp, sa, sb, T, flip, sa == T ? 1 : 0, wt);
+  VTS_CHECK_LAUNCH(who);
   return VTS_OK;
+}
+
+extern "C" int vts_w3x3_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream) {
+  return wtap_pack("vts_w3x3_pack", w, A, B, sa, sb, 9, flip, wt, stream);
+}
+
+extern "C" int vts_w4x4_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream) {
+  return wtap_pack("vts_w4x4_pack", w, A, B, sa, sb, 16, flip, wt, stream);
 }
 
 static int wide_plan(int N, int Cin, int Cout, int H, int W, int* cps) {
@@ -407,27 +434,30 @@ extern "C" int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, i
   return need;
 }
 
-static int flat_launch(const WideK& k, int S, float* ws, int64_t ws_floats, hipStream_t st) {
+static int flat_launch(const WideK& k, int S, int TW, float* ws, int64_t ws_floats, hipStream_t st) {
+  const int fck = TW == 16 ? 4 : CK;
   FlatK f{};
   f.in = k.in; f.wt = k.wt; f.bias = k.bias; f.out = k.out; f.N = k.N; f.Cin = k.Cin; f.Cout = k.Cout; f.H = k.H; f.W = k.W;
   f.IPH = k.IPH; f.IPW = k.IPW; f.S = S; f.OH = k.OH; f.OW = k.OW; f.os = k.os; f.oy0 = k.oy0; f.ox0 = k.ox0;
-  f.TW = 9; f.ntaps = k.ntaps;
+  f.TW = TW; f.ntaps = k.ntaps; f.Cw = (k.Cout + 3) & ~3;
   for (int t = 0; t < k.ntaps; ++t) { f.dy[t] = k.dy[t]; f.dx[t] = k.dx[t]; f.wt_tap[t] = k.wt_tap[t]; }
   const int plane = k.IPH * k.IPW;
-  VTS_CHECK_ARG((int64_t)k.N * k.Cin * plane * 4 < (1ll << 31), "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
+  VTS_CHECK_ARG((int64_t)k.N * k.Cin * plane * 4 < (1ll << 31) && (int64_t)k.Cin * TW * k.Cout * 4 < (1ll << 31),
+                "flat conv: operand exceeds the 2 GiB buffer range");
   f.slot = (plane + 3) / 4 * 4;
-  int KS = flat_plan(k.N, k.Cin, k.Cout, k.H, k.W, plane, CK, &f.IPT, &f.cps);
+  int KS = flat_plan(k.N, k.Cin, k.Cout, k.H, k.W, plane, fck, &f.IPT, &f.cps);
   const int64_t per_slice = (int64_t)k.N * k.Cout * k.H * k.W;
-  if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; f.cps = cdiv(k.Cin, CK); }
+  if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; f.cps = cdiv(k.Cin, fck); }
   f.KS = KS; f.part = KS > 1 ? ws : nullptr;
   const dim3 grid(cdiv(k.N, f.IPT), cdiv(k.Cout, TCO), KS);
-  hipLaunchKernelGGL((conv_flat_kernel<CK, 9>), grid, dim3(256), 0, st, f);
-  vts_set_kernel(KS > 1 ? "conv_flat_kernel<%d, 9>+ksplit" : "conv_flat_kernel<%d, 9>", CK);
-  VTS_CHECK_LAUNCH("vts_conv3x3_wide (flat)");
+  if (TW == 16) hipLaunchKernelGGL((conv_flat_kernel<4, 16>), grid, dim3(256), 0, st, f);
+  else hipLaunchKernelGGL((conv_flat_kernel<CK, 9>), grid, dim3(256), 0, st, f);
+  vts_set_kernel(KS > 1 ? "conv_flat_kernel<%d, %d>+ksplit" : "conv_flat_kernel<%d, %d>", fck, TW);
+  VTS_CHECK_LAUNCH("flat conv");
   if (KS > 1) {
     hipLaunchKernelGGL(flat_reduce_kernel, dim3((unsigned)cdiv64(per_slice, 256)), dim3(256), 0, st, ws, k.bias, KS, per_slice, k.H, k.W,
                        k.Cout, k.OH, k.OW, k.os, k.oy0, k.ox0, k.out);
-    VTS_CHECK_LAUNCH("vts_conv3x3_wide (flat) reduce");
+    VTS_CHECK_LAUNCH("flat conv reduce");
   }
   return VTS_OK;
 }
@@ -436,7 +466,7 @@ static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_
   VTS_CHECK_ARG((k.Cout & 3) == 0, "vts_conv3x3_wide: Cout %d must be a multiple of 4 (16-byte weight rows)", k.Cout);
   VTS_CHECK_ARG((int64_t)k.Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)k.Cin * 9 * k.Cout * 4 < (1ll << 31) && k.N <= 1024,
                 "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
-  if (flat_ok(k.H, k.W, k.IPH * k.IPW, CK)) return flat_launch(k, S, ws, ws_floats, st);
+  if (flat_ok(k.H, k.W, k.IPH * k.IPW, CK)) return flat_launch(k, S, 9, ws, ws_floats, st);
   int cps;
   int KS = k.os == 1 ? wide_plan(k.N, k.Cin, k.Cout, k.H, k.W, &cps) : 1;
   const int64_t per_slice = (int64_t)k.N * k.Cout * k.OH * k.OW;
@@ -498,6 +528,58 @@ extern "C" int vts_tconv3x3s2_wide(const float* in, const float* wt, const float
           ++k.ntaps;
         }
       const int rc = wide_launch(k, 1, flat_ok(IH, IW, k.IPH * k.IPW, CK) ? ws : nullptr, ws_floats, (hipStream_t)stream);
+      if (rc != VTS_OK) return rc;
+    }
+  return VTS_OK;
+}
+
+// 4 x 4 convolutions of wide layers on small maps (the ndf = 64 PatchGAN discriminators of pix2pixHD on 32 x 32 patches,
+// reference models/networks.py NLayerDiscriminator via MultiscaleDiscriminator, kw = 4, padw = 2): the flattened kernel with
+// 16-tap packed weights.  transposed = 0: out[n,co,y,x] = bias + sum in[n,ci,S*y+ky,S*x+kx] * wt[(ci*16 + ky*4+kx)*Cout + co]
+// on the pre-padded input.  transposed = 1 (stride 2, the input adjoint of Conv2d(4, s2, p2)): `in` is the output gradient
+// with one zero row / column appended; out[2m+py] = sum_{d in {0,1}} in[m+d] * w[k = py + 2(1-d)], one launch per parity phase.
+static bool flat4_shapes_ok(int OH, int OW, int PH, int PW, int transposed) {
+  const int gh = transposed ? (OH + 1) / 2 : OH, gw = transposed ? (OW + 1) / 2 : OW;
+  return flat_ok(gh, gw, PH * PW, 4);
+}
+
+extern "C" int vts_conv4x4_flat_ok(int OH, int OW, int PH, int PW, int transposed) { return flat4_shapes_ok(OH, OW, PH, PW, transposed) ? 1 : 0; }
+
+extern "C" int64_t vts_conv4x4_flat_ws_floats(int N, int Cin, int Cout, int OH, int OW, int PH, int PW, int transposed) {
+  if (!flat4_shapes_ok(OH, OW, PH, PW, transposed)) return 0;
+  const int gh = transposed ? (OH + 1) / 2 : OH, gw = transposed ? (OW + 1) / 2 : OW;
+  int ipt, cps;
+  const int KS = flat_plan(N, Cin, Cout, gh, gw, PH * PW, 4, &ipt, &cps);
+  return KS > 1 ? (int64_t)KS * N * Cout * gh * gw : 0;
+}
+
+extern "C" int vts_conv4x4_flat(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int PH, int PW,
+                                int OH, int OW, int stride, int transposed, float* ws, int64_t ws_floats, void* stream) {
+  VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && OH >= 1 && OW >= 1 && (stride == 1 || stride == 2),
+                "vts_conv4x4_flat: bad args");
+  VTS_CHECK_ARG(flat4_shapes_ok(OH, OW, PH, PW, transposed), "vts_conv4x4_flat: map %d x %d (padded %d x %d) is not a small-map case", OH, OW, PH, PW);
+  WideK k{};
+  k.in = in; k.wt = wt; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.IPH = PH; k.IPW = PW; k.OH = OH; k.OW = OW;
+  if (!transposed) {
+    VTS_CHECK_ARG(PH >= stride * (OH - 1) + 4 && PW >= stride * (OW - 1) + 4, "vts_conv4x4_flat: padded input %d x %d too small for output %d x %d", PH, PW, OH, OW);
+    k.H = OH; k.W = OW; k.os = 1; k.oy0 = 0; k.ox0 = 0; k.ntaps = 16;
+    for (int t = 0; t < 16; ++t) { k.dy[t] = (signed char)(t / 4); k.dx[t] = (signed char)(t % 4); k.wt_tap[t] = (signed char)t; }
+    return flat_launch(k, stride, 16, ws, ws_floats, (hipStream_t)stream);
+  }
+  VTS_CHECK_ARG(stride == 2, "vts_conv4x4_flat: the transposed form is the stride-2 one (stride 1: flipped packing on the padded gradient)");
+  VTS_CHECK_ARG(2 * (PH - 1) >= OH + 1 && 2 * (PW - 1) >= OW + 1 - 0, "vts_conv4x4_flat: gradient extent %d x %d too small for %d x %d", PH, PW, OH, OW);
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      k.H = (OH - py + 1) / 2; k.W = (OW - px + 1) / 2;
+      if (k.H < 1 || k.W < 1) continue;
+      k.os = 2; k.oy0 = py; k.ox0 = px; k.ntaps = 0;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+          k.dy[k.ntaps] = (signed char)a; k.dx[k.ntaps] = (signed char)b;
+          k.wt_tap[k.ntaps] = (signed char)((py + 2 * (1 - a)) * 4 + px + 2 * (1 - b));
+          ++k.ntaps;
+        }
+      const int rc = flat_launch(k, 1, 16, ws, ws_floats, (hipStream_t)stream);
       if (rc != VTS_OK) return rc;
     }
   return VTS_OK;

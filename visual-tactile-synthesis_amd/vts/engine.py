@@ -649,6 +649,18 @@ def _pyramid(D, in0, in1):
     return pyr
 
 
+FLAT_D = os.environ.get("VTS_FLAT_D", "1") != "0"
+
+
+def _flat4(conv, j, h, w, oh, ow, st):
+    """whether this PatchGAN layer takes the flattened small-map GEMM-class route (wide layer, <= 128 pixels per image):
+    (forward ok, padded extent) -- the input adjoint has its own check in _msd_scale_backward"""
+    co, ci = conv.weight.shape[0], conv.weight.shape[1]
+    if not FLAT_D or j == 0 or ci < 32 or (co < 32 and ci < 256):   # thin layers stay on the 4x4 kernels
+        return False
+    return ops.conv4x4_flat_ok(oh, ow, st * (oh - 1) + 4, st * (ow - 1) + 4)
+
+
 def _msd_scale_forward(D, s, a0, a1, update_stats):
     """one PatchGAN of the pyramid: returns the list of layer outputs (Act), the last one is the prediction"""
     n, dev = a0.data.shape[0], a0.data.device
@@ -662,8 +674,13 @@ def _msd_scale_forward(D, s, a0, a1, update_stats):
         cout, cin = conv.weight.shape[0], conv.weight.shape[1]
         oh, ow = (h + 4 - 4) // st + 1, (w + 4 - 4) // st + 1
         out = _empty(n, cout, oh, ow, dev)
-        ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
-                    act_in=LRELU if j else 0)
+        if _flat4(conv, j, h, w, oh, ow, st):
+            ph, pw = st * (oh - 1) + 4, st * (ow - 1) + 4
+            p = ops.pad_affine(cur0, (2, ph - h - 2, 2, pw - w - 2), 0, act=LRELU)
+            ops.conv4x4_flat(p, ops.w4x4_pack(conv.weight, "conv_fwd"), conv.bias, out, stride=st)
+        else:
+            ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
+                        act_in=LRELU if j else 0)
         if ci in D.BN_IDX:
             bn = getattr(layer, str(D.BN_IDX[ci]))
             a = ops.norm_stats(out, 1, gamma=bn.weight, beta=bn.bias,
@@ -699,8 +716,19 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
         if j > 0:
             prev = acts[j - 1]
             tgt = torch.empty_like(prev.data)
-            ops.conv4x4(Act(g), conv.weight, 16, cin * 16, cin, tgt, stride=st, pad=2, transposed=True, dmask=prev,
-                        dmask_act=LRELU)
+            h, w, oh, ow = prev.data.shape[2], prev.data.shape[3], g.shape[2], g.shape[3]
+            qh, qw = (oh + 2, ow + 2) if st == 1 else (oh + 1, ow + 1)
+            if _flat4(conv, j, h, w, oh, ow, st) and ops.conv4x4_flat_ok(h, w, qh, qw, st == 2):
+                raw = torch.empty_like(prev.data)
+                if st == 1:   # adjoint of the stride-1 conv: the same operator on the padded gradient, flipped taps
+                    ops.conv4x4_flat(ops.pad_affine(g, (1, 1, 1, 1), 0), ops.w4x4_pack(conv.weight, "conv_adj"), None, raw)
+                else:
+                    ops.conv4x4_flat(ops.pad_affine(g, (0, 1, 0, 1), 0), ops.w4x4_pack(conv.weight, "conv_s2_adj"), None, raw,
+                                     stride=2, transposed=True)
+                ops.act_bwd(raw, prev, LRELU, tgt)
+            else:
+                ops.conv4x4(Act(g), conv.weight, 16, cin * 16, cin, tgt, stride=st, pad=2, transposed=True, dmask=prev,
+                            dmask_act=LRELU)
             g = tgt
         elif want_input_grad:
             c0 = a0.data.shape[1]

@@ -219,7 +219,7 @@ def w3x3_pack(w, mode, tag=None):
     key = ("wt", w.data_ptr(), tuple(w.shape), mode, tag)
     buf = _ws.get(key)
     if buf is None:
-        buf = _ws[key] = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+        buf = _ws[key] = torch.empty(A * 9 * ((B + 3) // 4 * 4), dtype=torch.float32, device=w.device)
     _run("w3x3_pack", 8.0 * w.numel(), 0.0, L.load().vts_w3x3_pack, w.data_ptr(), A, B, sa, sb, flip, buf.data_ptr(), L.stream())
     return buf
 
@@ -291,6 +291,42 @@ def wgrad3x3_wide(dout, p, dw, accumulate=False, stride=1):
          dout.data_ptr(), p.data_ptr(), dw.data_ptr(), n, ci, co, h, w, stride, int(accumulate), L.ptr(ws),
          ws.numel() if ws is not None else 0, L.stream())
     return dw
+
+
+def w4x4_pack(w, mode, tag=None):
+    """tap-major packing of an nn.Conv2d weight [Co,Ci,4,4] for conv4x4_flat (see include/vts.h) into a persistent buffer"""
+    d0, d1 = w.shape[0], w.shape[1]
+    A, B, sa, sb, flip = {"conv_fwd": (d1, d0, 16, 16 * d1, 0), "conv_adj": (d0, d1, 16 * d1, 16, 1),
+                          "conv_s2_adj": (d0, d1, 16 * d1, 16, 0)}[mode]
+    key = ("wt4", w.data_ptr(), tuple(w.shape), mode, tag)
+    buf = _ws.get(key)
+    if buf is None:
+        buf = _ws[key] = torch.empty(A * 16 * ((B + 3) // 4 * 4), dtype=torch.float32, device=w.device)   # row pitch: B rounded up to 4
+    _run("w4x4_pack", 8.0 * w.numel(), 0.0, L.load().vts_w4x4_pack, w.data_ptr(), A, B, sa, sb, flip, buf.data_ptr(), L.stream())
+    return buf
+
+
+def conv4x4_flat_ok(oh, ow, ph, pw, transposed=False):
+    return bool(L.load().vts_conv4x4_flat_ok(oh, ow, ph, pw, int(transposed)))
+
+
+def conv4x4_flat(p, wt, bias, out, stride=1, transposed=False):
+    """4x4 conv of the pre-padded p [N,Ci,PH,PW] with 16-tap packed weights on the flattened small-map kernel; transposed:
+    p is the output gradient of a Conv2d(4, s2, p2) with a zero row / column appended, out its input gradient"""
+    n, ci, ph, pw = p.shape
+    co, oh, ow = out.shape[1:]
+    assert out.shape[0] == n and p.is_contiguous() and out.is_contiguous()
+    lib = L.load()
+    need = lib.vts_conv4x4_flat_ws_floats(n, ci, co, oh, ow, ph, pw, int(transposed))
+    ws = workspace(need, p.device) if need else None
+    taps = 4 if transposed else 16
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d s%d%s" % (n, ci, ph, pw, co, oh, ow, stride, " transposed" if transposed else "")
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * oh * ow * co * ci * taps, lib.vts_conv4x4_flat,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, ph, pw, oh, ow, stride, int(transposed), L.ptr(ws),
+         ws.numel() if ws is not None else 0, L.stream())
+    return out
 
 
 def pad_affine(x, pads, mode, out=None, act=0, res=None, out_nstride=0):
