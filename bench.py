@@ -185,7 +185,7 @@ def infer_bench(args):
         model.test()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({
+    emit(json.dumps({
         "metric": "inference_ms_per_image", "value": dt / args.steps / batch_n * 1e3, "unit": "ms/image", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -194,7 +194,21 @@ def infer_bench(args):
     }))
 
 
+_JSON_FD = None
+
+
+def emit(line):
+    """the ONE JSON line goes to the real stdout; everything else that writes to fd 1 (RCCL prints a version banner there when
+    the communicator is created) has been sent to stderr by main()"""
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
+
+
 def main():
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -280,10 +294,10 @@ def main():
             },
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        emit(json.dumps(out))
     elif world > 1:
         pass
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -223,7 +223,7 @@ class Pix2PixHDModel(BaseModel):
         try:
             for seg, _, _ in self._segments():
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=stream):
+                with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):   # RCCL's watchdog thread queries events meanwhile
                     seg()
                 graphs.append(g)
         except Exception:

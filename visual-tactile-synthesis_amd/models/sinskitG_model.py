@@ -353,7 +353,7 @@ class SinSKITGModel(BaseModel):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 ops.FROZEN_WS = True
-                with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+                with torch.cuda.graph(g, stream=torch.cuda.Stream(), capture_error_mode="thread_local"):
                     self.forward(keep=False)
                 self._infer_graph = g
                 return g.replay()
@@ -522,7 +522,7 @@ class SinSKITGModel(BaseModel):
         try:
             for seg, _, _ in self._segments():
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=stream):
+                with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):   # RCCL's watchdog thread queries events meanwhile
                     seg()
                 graphs.append(g)
         except Exception:

@@ -15,11 +15,24 @@ import torch
 import torch.distributed as dist
 
 
+# VTS_DDP_FORCE=1: create the process group and run the bucket all-reduces even with ONE rank, so that the RCCL path
+# (async all-reduce on RCCL's stream between the captured segments of the step) can be exercised on a 1-GPU box.
+FORCE = os.environ.get("VTS_DDP_FORCE", "0") == "1"
+
+
+def _active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
+
+
 def init_from_env(device_type="cuda"):
     """Initialise the default process group from torchrun-style env vars (no-op for 1 rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or dist.is_initialized():
+    if (world <= 1 and not FORCE) or dist.is_initialized():
         return int(os.environ.get("RANK", "0")), world
+    if world <= 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
     rank = int(os.environ["RANK"])
     if device_type == "cuda":
         # one GPU per rank; VTS_DDP_BACKEND=gloo (ranks sharing a device) exists to exercise this path on a 1-GPU box
@@ -38,7 +51,7 @@ class GradBucket:
         self.work = None
 
     def start(self):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _active():
             self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, async_op=True)
 
     def wait(self):
@@ -65,7 +78,7 @@ def attach(model):
     buckets = {}
     for name in model.model_names:
         net = getattr(model, "net" + name)
-        if world > 1:
+        if world > 1 or _active():
             flat = getattr(model, "flat" + name, None)
             if flat is not None:
                 dist.broadcast(flat.flat, 0)
