@@ -340,6 +340,58 @@ def golden_metrics(seed=606):
     print("wrote metrics.npz", out)
 
 
+def golden_sg2(size=32, seed=808, ndf=8, input_nc=4, n=3):
+    """StyleGAN2 blocks: the reference's StyleGAN2Discriminator forward + gradients, upfirdn2d in several
+    up / down / pad configurations, fused_leaky_relu, ModulatedConv2d (plain / upsample / downsample) with a style vector."""
+    import argparse
+
+    from oracle import detrand, ref_import, stylegan2 as sg
+
+    ref_import.load()
+    from models import stylegan_networks as R
+
+    out = {"size": size, "seed": seed, "ndf": ndf, "input_nc": input_nc, "n": n}
+    opt = argparse.Namespace(netD="stylegan2", D_patch_size=None, load_size=size, crop_size=size)
+    D = R.StyleGAN2Discriminator(input_nc, ndf, 3, False, size=size, opt=opt)
+    ref = {k: tuple(v.shape) for k, v in D.named_parameters()}
+    mine = sg.d_param_shapes(input_nc, ndf, size)
+    assert ref == {k: tuple(v) for k, v in mine.items()}, "StyleGAN2 D key/shape mismatch"
+    for k, v in sg.d_buffers(input_nc, ndf, size).items():
+        assert torch.equal(D.state_dict()[k], v), k
+    out["ref_keys"] = np.array(sorted(D.state_dict().keys()))
+    D.load_state_dict(sg.test_weights(mine, seed), strict=False)
+    x = detrand.uniform((n, input_nc, size, size), seed, "d_in").requires_grad_(True)
+    y = D(x)
+    (y * detrand.uniform(tuple(y.shape), seed, "d_cot")).sum().backward()
+    out["D_out"] = y.detach().numpy()
+    out["D_dx_probe"] = detrand.probe(x.grad, "d_dx")
+    out["D_dx_sub"] = x.grad[:, :, ::4, ::4].numpy()
+    for k, p in D.named_parameters():
+        out["D_grad/" + k] = detrand.probe(p.grad, k)
+    # upfirdn2d
+    u = detrand.uniform((2, 3, 9, 11), seed, "ufd_in")
+    k4 = R.make_kernel([1, 3, 3, 1])
+    for i, (up, down, pad) in enumerate(sg.UPFIRDN_CASES):
+        out["ufd/%d" % i] = R.upfirdn2d(u, k4 * (up ** 2), up=up, down=down, pad=pad).numpy()
+    out["flrelu"] = R.fused_leaky_relu(u, detrand.uniform((1, 3, 1, 1), seed, "flb")).numpy()
+    # ModulatedConv2d with a style vector
+    for tag, kw in (("plain", {}), ("up", {"upsample": True}), ("down", {"downsample": True}), ("nodemod", {"demodulate": False})):
+        M = R.ModulatedConv2d(12, 20, 3, 16, **kw)
+        shapes = {k: tuple(v.shape) for k, v in M.named_parameters()}
+        M.load_state_dict(sg.test_weights(shapes, seed + 1), strict=False)
+        xi = detrand.uniform((2, 12, 10, 10), seed, "mod_in").requires_grad_(True)
+        st = detrand.uniform((2, 16), seed, "mod_style").requires_grad_(True)
+        yo = M(xi, st)
+        (yo * detrand.uniform(tuple(yo.shape), seed, "mod_cot" + tag)).sum().backward()
+        out["mod/%s/out" % tag] = yo.detach().numpy()
+        out["mod/%s/dx" % tag] = detrand.probe(xi.grad, "mdx")
+        out["mod/%s/dstyle" % tag] = st.grad.numpy()
+        for k, p in M.named_parameters():
+            out["mod/%s/grad/%s" % (tag, k)] = detrand.probe(p.grad, k)
+    np.savez_compressed(os.path.join(GOLD, "stylegan2_%d.npz" % size), **out)
+    print("wrote stylegan2_%d.npz (%d entries)" % (size, len(out)))
+
+
 def golden_step(size=256, seed=202, steps=2, nt=64):
     """Full SinSKITGModel.optimize_parameters x `steps` on one synthetic sample (BASELINE config 0)."""
     from oracle import detrand, nets, ref_import
@@ -400,7 +452,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -417,3 +469,5 @@ if __name__ == "__main__":
         golden_p2p_step()
     if "metrics" in which:
         golden_metrics()
+    if "sg2" in which:
+        golden_sg2()

@@ -322,3 +322,41 @@ def test_train_step_matches_reference(golden_dir):
 def test_option_fixture_is_reference_dump(golden_dir):
     d = json.load(open(os.path.join(golden_dir, "ref_option_defaults.json")))
     assert d["sinskitG_train"]["ngf"]["default"] == 10 and d["sinskitG_train"]["netD2"]["default"] == "multiscale"
+
+
+def _probe_close(p, rp, tol=2e-4):
+    return abs(p[1] - rp[1]) <= tol * max(abs(rp[1]), 1e-12) and abs(p[2] - rp[2]) <= tol * max(abs(rp[1]), 1e-12)
+
+
+def test_stylegan2_blocks_match_reference(golden_dir):
+    """oracle/stylegan2.py vs the reference's stylegan_networks.py run on CPU: discriminator forward + gradients,
+    upfirdn2d configurations, fused_leaky_relu, ModulatedConv2d variants"""
+    from oracle import stylegan2 as sg
+    g = _load(golden_dir, "stylegan2_32.npz")
+    size, seed, ndf, cin, n = (int(g[k]) for k in ("size", "seed", "ndf", "input_nc", "n"))
+    shapes = sg.d_param_shapes(cin, ndf, size)
+    assert set(shapes) | set(sg.d_buffers(cin, ndf, size)) == set(g["ref_keys"].tolist())
+    sd = {k: v.requires_grad_(True) for k, v in sg.test_weights(shapes, seed).items()}
+    x = detrand.uniform((n, cin, size, size), seed, "d_in").requires_grad_(True)
+    y = sg.discriminator_forward(sd, x, size)
+    np.testing.assert_allclose(y.detach().numpy(), g["D_out"], rtol=1e-4, atol=1e-5)
+    (y * detrand.uniform(tuple(y.shape), seed, "d_cot")).sum().backward()
+    np.testing.assert_allclose(x.grad[:, :, ::4, ::4].numpy(), g["D_dx_sub"], rtol=2e-3, atol=1e-6)
+    for k, v in sd.items():
+        assert _probe_close(detrand.probe(v.grad, k), g["D_grad/" + k]), k
+    u = detrand.uniform((2, 3, 9, 11), seed, "ufd_in")
+    for i, (up, down, pad) in enumerate(sg.UPFIRDN_CASES):
+        np.testing.assert_allclose(sg.upfirdn2d(u, sg.make_kernel() * (up ** 2), up, down, pad).numpy(), g["ufd/%d" % i], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sg.fused_leaky_relu(u, detrand.uniform((1, 3, 1, 1), seed, "flb")).numpy(), g["flrelu"], rtol=1e-6, atol=1e-7)
+    for tag, kw in (("plain", {}), ("up", {"upsample": True}), ("down", {"downsample": True}), ("nodemod", {"demodulate": False})):
+        shapes = {"weight": (1, 20, 12, 3, 3), "modulation.weight": (12, 16), "modulation.bias": (12,)}
+        w = {k: v.requires_grad_(True) for k, v in sg.test_weights(shapes, seed + 1).items()}
+        xi = detrand.uniform((2, 12, 10, 10), seed, "mod_in").requires_grad_(True)
+        st = detrand.uniform((2, 16), seed, "mod_style").requires_grad_(True)
+        yo = sg.modulated_conv2d(xi, st, w["weight"], w["modulation.weight"], w["modulation.bias"], **kw)
+        np.testing.assert_allclose(yo.detach().numpy(), g["mod/%s/out" % tag], rtol=1e-4, atol=1e-5)
+        (yo * detrand.uniform(tuple(yo.shape), seed, "mod_cot" + tag)).sum().backward()
+        assert _probe_close(detrand.probe(xi.grad, "mdx"), g["mod/%s/dx" % tag]), tag
+        np.testing.assert_allclose(st.grad.numpy(), g["mod/%s/dstyle" % tag], rtol=2e-3, atol=1e-5)
+        for k, v in w.items():
+            assert _probe_close(detrand.probe(v.grad, k), g["mod/%s/grad/%s" % (tag, k)]), (tag, k)
