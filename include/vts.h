@@ -194,6 +194,11 @@ int vts_blur_up_bwd(const float* dout, int N, int C, int H, int W, float* din, i
  * on these blocks (pad -> pad - 4a / 4b; outputs accumulate). */
 int vts_tap_embed(const float* w, int64_t rows, int K, int a, int b, float* w4, void* stream);
 int vts_tap_extract(const float* dw4, int64_t rows, int K, int a, int b, float* dw, int accumulate, void* stream);
+/* the same with an explicit origin: (oy, ox) in [-3, 7] is the position of the block's tap (0, 0) in the K x K grid; a negative origin
+ * places a small kernel inside the block, which (with pad = -origin) runs the stride-2 3x3 / 1x1 EqualConv2d of the StyleGAN2
+ * ConvLayers (models/stylegan_networks.py:622-668) on the stride-2 4x4 kernels */
+int vts_tap_embed_at(const float* w, int64_t rows, int K, int oy, int ox, float* w4, void* stream);
+int vts_tap_extract_at(const float* dw4, int64_t rows, int K, int oy, int ox, float* dw, int accumulate, void* stream);
 
 /* ---- GEMM-class 3x3 kernels for wide layers (pix2pixHD GlobalGenerator, models/networks.py:1952-1980: stride-2
  * 3x3 downsampling convs, ResnetBlocks :1267-1324 at up to 1024 channels, ConvTranspose2d(3, s2, p1, op1) upsampling).
@@ -246,6 +251,32 @@ int vts_conv4x4_flat_ok(int OH, int OW, int PH, int PW, int transposed);
 int64_t vts_conv4x4_flat_ws_floats(int N, int Cin, int Cout, int OH, int OW, int PH, int PW, int transposed);
 int vts_conv4x4_flat(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int PH, int PW,
                      int OH, int OW, int stride, int transposed, float* ws, int64_t ws_floats, void* stream);
+
+/* ---- StyleGAN2 building blocks (models/stylegan_networks.py) ----
+ * vts_upfirdn2d      upfirdn2d_native :38-76 (Blur :140-156, Upsample :98-116, Downsample :119-137): insert up-1 zeros, pad
+ *                    (negative pad crops) by (px0, px1, py0, py1), correlate with the FLIPPED `kernel` (HOST pointer, KH x KW <= 64
+ *                    floats, copied into the launch), keep every down-th sample; in [NC, IH, IW] -> out [NC, OH, OW],
+ *                    OH = vts_upfirdn2d_out_size(IH, KH, up, down, py0, py1).  vts_upfirdn2d_bwd is its adjoint (same arguments
+ *                    as the forward; dout [NC, OH, OW] -> din [NC, IH, IW]), a gather: deterministic.
+ * vts_bias_act       fused_leaky_relu :18-19 / FusedLeakyReLU :22-35 / ScaledLeakyReLU :236-245:
+ *                    out = leaky_relu(x + bias[c], slope) * gain (+ res); bias / res may be NULL.  The residual input serves
+ *                    ResBlock :686-693, (out * skip_gain + skip) / sqrt(skip_gain^2 + 1), with the constants folded into `gain`
+ *                    and into the skip convolution's operand scale.  vts_bias_act_bwd: dx = g * gain * (x + bias > 0 ? 1 : slope)
+ *                    (the bias gradient is vts_channel_sum of dx).
+ * vts_modconv_demod  ModulatedConv2d :311-317: demod[n,co] = rsqrt(scale^2 * sum_{ci,k} (w[co,ci,k] * s[n,ci])^2 + eps); with it the
+ *                    modulated convolution is conv(x * s[n,ci] * scale, w) * demod[n,co] on the shared weight (both factors are
+ *                    operand affines of the conv kernels) instead of the reference's per-sample grouped convolution. */
+int vts_upfirdn2d_out_size(int in, int k, int up, int down, int pad0, int pad1);
+int vts_upfirdn2d(const float* in, int64_t NC, int IH, int IW, const float* kernel, int KH, int KW, int up, int down, int px0,
+                  int px1, int py0, int py1, float* out, int accumulate, void* stream);
+int vts_upfirdn2d_bwd(const float* dout, int64_t NC, int IH, int IW, const float* kernel, int KH, int KW, int up, int down, int px0,
+                      int px1, int py0, int py1, float* din, int accumulate, void* stream);
+int vts_bias_act(const float* x, const float* bias, const float* res, int N, int C, int64_t HW, float slope, float gain, float* out,
+                 void* stream);
+int vts_bias_act_bwd(const float* g, const float* x, const float* bias, int N, int C, int64_t HW, float slope, float gain, float* dx,
+                     void* stream);
+int vts_modconv_demod(const float* w, const float* s, int N, int Cout, int Cin, int KK, float scale, float eps, float* demod,
+                      void* stream);
 
 /* ---- Evaluation metrics that need no pretrained network (models/model_utils.py:431-561 compute_evaluation_metric) ----
  * vts_minmax:          out2 = {min x, max x}

@@ -105,6 +105,14 @@ def new_adam_state():
     return {"step": 0, "m": {}, "v": {}}
 
 
+def _d1(sdD, x, opt):
+    """netD: the multiscale PatchGAN (default) or the StyleGAN2 discriminator (--netD stylegan2, networks.py:437-442)"""
+    if getattr(opt, "netD", "multiscale") == "stylegan2":
+        from oracle import stylegan2
+        return [[stylegan2.discriminator_forward(sdD, x, x.shape[-1])]]
+    return nets.msd_forward(sdD, x, opt.num_D)
+
+
 def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, record=True):
     """One G+D1+D2 update, in place on the three state dicts and `adam` (dict of 3 Adam states).
 
@@ -139,9 +147,9 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
 
     # ---- D1 step ----
     _req(sdD, True)
-    pred_fake = nets.msd_forward(sdD, torch.cat((inp.real_S, fake_I.detach()), 1), opt.num_D)
+    pred_fake = _d1(sdD, torch.cat((inp.real_S, fake_I.detach()), 1), opt)
     loss_D_fake_I = gl(pred_fake, False).mean() * lamD1
-    pred_real = nets.msd_forward(sdD, torch.cat((inp.real_S, inp.real_I), 1), opt.num_D)
+    pred_real = _d1(sdD, torch.cat((inp.real_S, inp.real_I), 1), opt)
     loss_D_real_I = gl(pred_real, True).mean() * lamD1
     loss_D1 = (loss_D_fake_I + loss_D_real_I) * 0.5
     loss_D1.backward()
@@ -184,7 +192,7 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     _req(sdD2, False)
 
     # ---- G step ----
-    pred_g = nets.msd_forward(sdD, torch.cat((inp.real_S, fake_I), 1), opt.num_D)
+    pred_g = _d1(sdD, torch.cat((inp.real_S, fake_I), 1), opt)
     loss_G_GAN = gl(pred_g, True).mean() * lamD1
     loss_G_L1 = F.l1_loss(fake_I, inp.real_I) * opt.lambda_G1_L1
     g2_stack = torch.cat((fake_T_concat.clone().detach(), S_concat, fake_I_concat), 1)

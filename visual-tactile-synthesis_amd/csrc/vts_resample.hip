@@ -192,22 +192,24 @@ __global__ __launch_bounds__(256) void blur_up_bwd_kernel(const BlurK k) {
 }
 
 // ---- K x K weights <-> the (a, b) 4 x 4 block of their zero-extended 8 x 8 tap grid -----------------------
-__global__ __launch_bounds__(256) void tap_embed_kernel(const float* __restrict__ w, int64_t rows, int K, int a, int b,
+// (oy, ox): position of the block's tap (0, 0) in the K x K grid (4a, 4b for the blocks of a large kernel; negative to place a
+// small kernel inside the 4 x 4 block: the stride-2 3x3 / 1x1 convolutions of the StyleGAN2 ConvLayers)
+__global__ __launch_bounds__(256) void tap_embed_kernel(const float* __restrict__ w, int64_t rows, int K, int oy, int ox,
                                                          float* __restrict__ w4) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * 16) return;
   const int64_t r = i >> 4;
-  const int ky = 4 * a + (((int)i >> 2) & 3), kx = 4 * b + ((int)i & 3);
-  w4[i] = (ky < K && kx < K) ? w[(r * K + ky) * K + kx] : 0.f;
+  const int ky = oy + (((int)i >> 2) & 3), kx = ox + ((int)i & 3);
+  w4[i] = (ky >= 0 && kx >= 0 && ky < K && kx < K) ? w[(r * K + ky) * K + kx] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void tap_extract_kernel(const float* __restrict__ dw4, int64_t rows, int K, int a, int b,
+__global__ __launch_bounds__(256) void tap_extract_kernel(const float* __restrict__ dw4, int64_t rows, int K, int oy, int ox,
                                                            float* __restrict__ dw, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * 16) return;
   const int64_t r = i >> 4;
-  const int ky = 4 * a + (((int)i >> 2) & 3), kx = 4 * b + ((int)i & 3);
-  if (ky < K && kx < K) {
+  const int ky = oy + (((int)i >> 2) & 3), kx = ox + ((int)i & 3);
+  if (ky >= 0 && kx >= 0 && ky < K && kx < K) {
     float* o = dw + (r * K + ky) * K + kx;
     *o = accumulate ? *o + dw4[i] : dw4[i];
   }
@@ -271,15 +273,30 @@ extern "C" int vts_blur_up_bwd(const float* dout, int N, int C, int H, int W, fl
 
 extern "C" int vts_tap_embed(const float* w, int64_t rows, int K, int a, int b, float* w4, void* stream) {
   VTS_CHECK_ARG(w && w4 && rows >= 1 && K >= 1 && K <= 8 && a >= 0 && a <= 1 && b >= 0 && b <= 1, "vts_tap_embed: bad args");
-  hipLaunchKernelGGL(tap_embed_kernel, dim3((unsigned)cdiv64(rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, K, a, b, w4);
+  hipLaunchKernelGGL(tap_embed_kernel, dim3((unsigned)cdiv64(rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, K, 4 * a, 4 * b, w4);
   VTS_CHECK_LAUNCH("vts_tap_embed");
   return VTS_OK;
 }
 
 extern "C" int vts_tap_extract(const float* dw4, int64_t rows, int K, int a, int b, float* dw, int accumulate, void* stream) {
   VTS_CHECK_ARG(dw4 && dw && rows >= 1 && K >= 1 && K <= 8 && a >= 0 && a <= 1 && b >= 0 && b <= 1, "vts_tap_extract: bad args");
-  hipLaunchKernelGGL(tap_extract_kernel, dim3((unsigned)cdiv64(rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, dw4, rows, K, a, b, dw,
+  hipLaunchKernelGGL(tap_extract_kernel, dim3((unsigned)cdiv64(rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, dw4, rows, K, 4 * a, 4 * b, dw,
                      accumulate);
   VTS_CHECK_LAUNCH("vts_tap_extract");
+  return VTS_OK;
+}
+
+extern "C" int vts_tap_embed_at(const float* w, int64_t rows, int K, int oy, int ox, float* w4, void* stream) {
+  VTS_CHECK_ARG(w && w4 && rows >= 1 && K >= 1 && K <= 8 && oy >= -3 && oy <= 7 && ox >= -3 && ox <= 7, "vts_tap_embed_at: bad args");
+  hipLaunchKernelGGL(tap_embed_kernel, dim3((unsigned)cdiv64(rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, K, oy, ox, w4);
+  VTS_CHECK_LAUNCH("vts_tap_embed_at");
+  return VTS_OK;
+}
+
+extern "C" int vts_tap_extract_at(const float* dw4, int64_t rows, int K, int oy, int ox, float* dw, int accumulate, void* stream) {
+  VTS_CHECK_ARG(dw4 && dw && rows >= 1 && K >= 1 && K <= 8 && oy >= -3 && oy <= 7 && ox >= -3 && ox <= 7, "vts_tap_extract_at: bad args");
+  hipLaunchKernelGGL(tap_extract_kernel, dim3((unsigned)cdiv64(rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, dw4, rows, K, oy, ox, dw,
+                     accumulate);
+  VTS_CHECK_LAUNCH("vts_tap_extract_at");
   return VTS_OK;
 }

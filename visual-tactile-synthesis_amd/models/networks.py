@@ -434,8 +434,14 @@ def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, in
 
 def define_D(input_nc, ndf, netD, n_layers_D=3, norm="batch", init_type="normal", init_gain=0.02, no_antialias=False,
              num_D=1, gpu_ids=(), opt=None):
+    if netD == "stylegan2":   # networks.py:437-442: no init_weights for StyleGAN2 nets (randn weights, runtime 1/sqrt(fan_in) scale)
+        import math
+
+        from .stylegan2_blocks import StyleGAN2Discriminator
+        size = 2 ** int(round(math.log2(min(opt.load_size, opt.crop_size))))            # stylegan_networks.py:701-702
+        return init_net(StyleGAN2Discriminator(input_nc, ndf, size), init_type, init_gain, gpu_ids, initialize_weights=False)
     if netD != "multiscale":
-        raise NotImplementedError("Discriminator model name [%s] is not recognized (built: multiscale)" % netD)
+        raise NotImplementedError("Discriminator model name [%s] is not recognized (built: multiscale, stylegan2)" % netD)
     if norm != "batch":
         raise NotImplementedError("multiscale discriminator is built for normD=batch only")
     cls = MultiscaleDiscriminatorIF if getattr(opt, "getIntermFeat_D", False) else MultiscaleDiscriminator   # networks.py:1661

@@ -794,7 +794,45 @@ def msd_multi(jobs, criterion):
     accumulation are order dependent), different D's and different scales are independent lanes.
     pass: dict(in0, in1=None, real: bool, coeff, slot, grad_coeff=None (None: no gradient / no backward),
                param_grads=True, accumulate=False, input_grad=None, loss=True); `preds` is filled in.
-    The first job's first scale (put the full-resolution discriminator first) runs on the launch stream."""
+    The first job's first scale (put the full-resolution discriminator first) runs on the launch stream.
+    A StyleGAN2 discriminator (`--netD stylegan2`) in `jobs` runs its passes on the launch stream after the lanes have joined."""
+    sg_jobs = [j for j in jobs if getattr(j[0], "is_stylegan2_d", False)]
+    jobs = [j for j in jobs if not getattr(j[0], "is_stylegan2_d", False)]
+    if jobs:
+        _msd_multi(jobs, criterion)
+    for D, passes in sg_jobs:
+        _sg2d_passes(D, passes, criterion)
+
+
+def _sg2d_passes(D, passes, criterion):
+    """the pass dictionaries of msd_multi for a single-output StyleGAN2 discriminator"""
+    for p in passes:
+        in0, in1 = p["in0"], p.get("in1")
+        n, c0, h, w = in0.shape
+        if in1 is not None:   # torch.cat([in0, in1], 1) as concat-on-store
+            x = _empty(n, c0 + in1.shape[1], h, w, in0.device)
+            ops.pad_affine(in0, (0, 0, 0, 0), 0, out=x[:, :c0], out_nstride=x.stride(0))
+            ops.pad_affine(in1, (0, 0, 0, 0), 0, out=x[:, c0:], out_nstride=x.stride(0))
+        else:
+            x = in0
+        gc = p.get("grad_coeff")
+        y, ctx = sg2d_forward(D, x, keep=gc is not None and p.get("loss", True))
+        pred = y.view(n, 1, 1, 1)
+        p["preds"] = [pred]
+        if not p.get("loss", True):
+            continue
+        g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None)[0]
+        if gc is None:
+            continue
+        want_in = p.get("input_grad") is not None
+        dx = sg2d_backward(D, ctx, g, accumulate=p.get("accumulate", False), input_grad=want_in, param_grads=p.get("param_grads", True))
+        if want_in:
+            dst, acc = p["input_grad"]
+            src = dx[:, c0:] if in1 is not None else dx
+            dst.add_(src) if acc else dst.copy_(src)
+
+
+def _msd_multi(jobs, criterion):
     lanes = []
     for D, passes in jobs:
         for p in passes:
@@ -825,3 +863,175 @@ def msd_multi(jobs, criterion):
             if p.get("input_grad") is not None:
                 _merge_input_grads(p["_din"], p["input_grad"])
             p.pop("_pyr"), p.pop("_din")
+
+
+# ======================================================================================================================
+# StyleGAN2 discriminator (`--netD stylegan2`; reference models/stylegan_networks.py:696-786)
+# The equalised-learning-rate scale 1/sqrt(fan_in) (:166, :214) is an operand affine of the conv kernels (normalise-on-load),
+# ResBlock's 1/sqrt 2 (:691) is folded into conv2's activation gain and into the skip convolution's operand scale, Blur is
+# vts_upfirdn2d, the stride-2 3x3 / 1x1 convolutions run on the stride-2 4x4 kernels (ops.convk_s2), EqualLinear(C*16, C) on the
+# flattened 4x4 map is a valid 4x4 convolution.
+# ======================================================================================================================
+_CONST = {}
+SQRT2 = 2.0 ** 0.5
+
+
+def _const(n, v, dev):
+    key = (n, float(v), str(dev))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((n,), float(v), dtype=torch.float32, device=dev)
+    return t
+
+
+def _scaled(t, s):
+    """operand t * s (per-(n, c) affine with a constant scale)"""
+    nc = t.shape[0] * t.shape[1]
+    return Act(t, _const(nc, s, t.device), _const(nc, 0.0, t.device))
+
+
+def _sg_layer_forward(m, x, gain=SQRT2, res=None, extra_scale=1.0):
+    """ConvLayer (:622-668).  Returns (output, saved) with saved = (blurred input or x, pre-activation z, operand scale)"""
+    from models.stylegan2_blocks import BLUR_KERNEL
+    conv, act = m.conv[0], m.act[0]
+    n = x.shape[0]
+    t = ops.upfirdn2d(x, BLUR_KERNEL, pad=m.blur_pad) if m.downsample else x
+    s = extra_scale / (m.cin * m.k * m.k) ** 0.5
+    if m.downsample:
+        oh, ow = (t.shape[2] - m.k) // 2 + 1, (t.shape[3] - m.k) // 2 + 1
+        z = _empty(n, m.cout, oh, ow, x.device)
+        ops.convk_s2(_scaled(t, s), conv.weight, z, bias=getattr(conv, "bias", None))
+    else:
+        z = _empty(n, m.cout, t.shape[2], t.shape[3], x.device)
+        ops.convk(_scaled(t, s), conv.weight, z, bias=getattr(conv, "bias", None), pad=m.k // 2)
+    if m.activate:
+        y = ops.bias_act(z, act.bias if act is not None else None, 0.2, gain, res=res)
+    else:
+        assert res is None
+        y = z
+    return y, (t, z, s)
+
+
+def _sg_layer_backward(m, x_shape, saved, g, gain, accumulate, want_dx=True, dx=None, dx_accumulate=False, param_grads=True):
+    """backward of _sg_layer_forward: parameter gradients into .grad, returns the gradient w.r.t. the layer input"""
+    from models.stylegan2_blocks import BLUR_KERNEL
+    conv, act = m.conv[0], m.act[0]
+    t, z, s = saved
+    if m.activate:
+        dz = ops.bias_act_bwd(g, z, act.bias if act is not None else None, 0.2, gain)
+        if act is not None and param_grads:
+            ops.channel_sum(dz, act.bias.grad.view(-1), accumulate=accumulate)
+    else:
+        dz = g
+        if getattr(conv, "bias", None) is not None and param_grads:
+            ops.channel_sum(dz, conv.bias.grad, accumulate=accumulate)
+    if not param_grads:
+        pass
+    elif m.downsample:
+        ops.wgradk_s2(dz, _scaled(t, s), conv.weight.grad, accumulate=accumulate)
+    else:
+        ops.wgradk(dz, _scaled(t, s), conv.weight.grad, pad=m.k // 2, accumulate=accumulate)
+    if not want_dx:
+        return None
+    if m.downsample:
+        dt = torch.empty_like(t)
+        ops.convk_s2_bwd_data(_scaled(dz, s), conv.weight, dt)
+        if dx is None:
+            dx = torch.empty(x_shape, dtype=torch.float32, device=g.device)
+        ops.upfirdn2d_bwd(dt, dx, BLUR_KERNEL, pad=m.blur_pad, accumulate=dx_accumulate)
+    else:
+        if dx is None:
+            dx = torch.empty(x_shape, dtype=torch.float32, device=g.device)
+        ops.convk_bwd_data(_scaled(dz, s), conv.weight, dx, pad=m.k // 2, accumulate=dx_accumulate)
+    return dx
+
+
+class Sg2dCtx:
+    __slots__ = ("x_shape", "first", "blocks", "final", "lin")
+
+
+def sg2d_forward(D, x, keep=True):
+    """StyleGAN2Discriminator.forward (:755-786) for netD = 'stylegan2'.  x [N, C, size, size] -> ([N, 1], ctx)"""
+    n, dev = x.shape[0], x.device
+    ctx = Sg2dCtx()
+    ctx.x_shape = tuple(x.shape)
+    y, ctx.first = _sg_layer_forward(D.convs[0], x)
+    ctx.blocks = []
+    for blk in list(D.convs)[1:]:
+        y1, s1 = _sg_layer_forward(blk.conv1, y)
+        sk, ss = _sg_layer_forward(blk.skip, y, extra_scale=1.0 / SQRT2)
+        out, s2 = _sg_layer_forward(blk.conv2, y1, gain=1.0, res=sk)     # sqrt 2 (activation gain) / sqrt 2 (residual merge)
+        ctx.blocks.append((tuple(y.shape), s1, tuple(y1.shape), s2, ss))
+        y = out
+    yf, ctx.final = _sg_layer_forward(D.final_conv, y)
+    l0, l1 = D.final_linear[0], D.final_linear[1]
+    c4 = l0.weight.shape[0]
+    assert yf.shape[2:] == (4, 4), "the discriminator is built for inputs of its `size`"
+    z0 = _empty(n, c4, 1, 1, dev)
+    s0 = 1.0 / (c4 * 16) ** 0.5
+    ops.conv4x4(_scaled(yf, s0), l0.weight, c4 * 16, 16, c4, z0, stride=1, pad=0)         # EqualLinear(C*16 -> C) :199-227
+    a0 = ops.bias_act(z0, l0.bias, 0.2, SQRT2)
+    s1l = 1.0 / c4 ** 0.5
+    out = _empty(n, 1, 1, 1, dev)
+    ops.convk(_scaled(a0, s1l), l1.weight.view(1, c4, 1, 1), out, bias=l1.bias, pad=0)
+    ctx.lin = (tuple(y.shape), yf, z0, a0, s0, s1l)
+    if not keep:
+        ctx = None
+    return out.view(n, 1), ctx
+
+
+def sg2d_backward(D, ctx, dout, accumulate=False, input_grad=False, param_grads=True):
+    """gradients of all parameters into .grad (param_grads); returns d/dx when input_grad"""
+    l0, l1 = D.final_linear[0], D.final_linear[1]
+    c4 = l0.weight.shape[0]
+    y_shape, yf, z0, a0, s0, s1l = ctx.lin
+    n = dout.shape[0]
+    g = dout.reshape(n, 1, 1, 1).contiguous()
+    pg = param_grads
+    if pg:
+        ops.channel_sum(g, l1.bias.grad, accumulate=accumulate)
+        ops.wgradk(g, _scaled(a0, s1l), l1.weight.grad.view(1, c4, 1, 1), pad=0, accumulate=accumulate)
+    da0 = torch.empty_like(a0)
+    ops.convk_bwd_data(_scaled(g, s1l), l1.weight.view(1, c4, 1, 1), da0, pad=0)
+    dz0 = ops.bias_act_bwd(da0, z0, l0.bias, 0.2, SQRT2)
+    if pg:
+        ops.channel_sum(dz0, l0.bias.grad, accumulate=accumulate)
+        ops.wgrad4x4(dz0, _scaled(yf, s0), l0.weight.grad, stride=1, pad=0, accumulate=accumulate)
+    dyf = torch.empty_like(yf)
+    ops.conv4x4(_scaled(dz0, s0), l0.weight, 16, c4 * 16, c4, dyf, stride=1, pad=0, transposed=True)
+    g = _sg_layer_backward(D.final_conv, y_shape, ctx.final, dyf, SQRT2, accumulate, param_grads=pg)
+    blocks = list(D.convs)[1:]
+    for blk, (x_shape, s1, y1_shape, s2, ss) in zip(reversed(blocks), reversed(ctx.blocks)):
+        dy1 = _sg_layer_backward(blk.conv2, y1_shape, s2, g, 1.0, accumulate, param_grads=pg)
+        dx = _sg_layer_backward(blk.skip, x_shape, ss, g, 1.0, accumulate, param_grads=pg)
+        g = _sg_layer_backward(blk.conv1, x_shape, s1, dy1, SQRT2, accumulate, dx=dx, dx_accumulate=True, param_grads=pg)
+    return _sg_layer_backward(D.convs[0], ctx.x_shape, ctx.first, g, SQRT2, accumulate, want_dx=input_grad, param_grads=pg)
+
+
+def modulated_conv2d(x, style, weight, mod_weight, mod_bias, demodulate=True, downsample=False):
+    """ModulatedConv2d.forward (:304-348), forward only, for the plain and the downsampling form (the upsampling form -- a
+    transposed convolution followed by Blur -- is not built).  Instead of the reference's per-sample weights in a grouped
+    convolution: y = conv(x * s[n,ci] / sqrt(fan_in), W) * demod[n,co] on the shared weight W = weight[0]; both factors ride on the
+    operand affines.  style [N, style_dim]; the modulation is EqualLinear(style_dim, Ci, bias_init=1) (:199-227)."""
+    from models.stylegan2_blocks import BLUR_KERNEL
+    n, ci, h, w_ = x.shape
+    wt = weight.view(weight.shape[-4], ci, weight.shape[-2], weight.shape[-1])
+    co, k = wt.shape[0], wt.shape[2]
+    sd = style.shape[1]
+    s = _empty(n, ci, 1, 1, x.device)
+    ops.convk(_scaled(style.reshape(n, sd, 1, 1).contiguous(), 1.0 / sd ** 0.5), mod_weight.view(ci, sd, 1, 1), s, bias=mod_bias, pad=0)
+    scale = 1.0 / (ci * k * k) ** 0.5
+    xin = Act(x, (s.view(-1) * scale).contiguous(), _const(n * ci, 0.0, x.device))
+    if downsample:
+        p = 2 + (k - 1)
+        t = ops.pad_affine(xin, (0, 0, 0, 0), 0)                      # materialise x * s, then Blur (:323-327), then stride 2
+        t = ops.upfirdn2d(t, BLUR_KERNEL, pad=((p + 1) // 2, p // 2))
+        out = _empty(n, co, (t.shape[2] - k) // 2 + 1, (t.shape[3] - k) // 2 + 1, x.device)
+        ops.convk_s2(t, wt, out)
+    else:
+        out = _empty(n, co, h, w_, x.device)
+        ops.convk(xin, wt, out, pad=k // 2)
+    if not demodulate:
+        return out
+    demod = ops.modconv_demod(wt, s.view(n, ci), scale)
+    return ops.pad_affine(Act(out, demod.view(-1), _const(n * co, 0.0, x.device)), (0, 0, 0, 0), 0)

@@ -209,6 +209,117 @@ def wgradk(dout, x, dw, *, pad=0, act_hi=0, accumulate=False):
     return dw
 
 
+# ---- stride-2 K x K convolutions (K <= 4, zero padding 0) on the stride-2 4 x 4 kernels: the K x K taps sit at offset o inside the
+# 4 x 4 block and the operator runs with pad = o; o is chosen so that the transposed (input-adjoint) geometry check holds ----
+def _s2_origin(K, h, w):
+    oh, ow = (h - K) // 2 + 1, (w - K) // 2 + 1
+    for o in range(0, 5 - K):
+        if (h + 2 * o - 4) // 2 + 1 == oh and (w + 2 * o - 4) // 2 + 1 == ow:
+            return o
+    raise ValueError("no 4x4 embedding for a stride-2 %dx%d convolution on a %dx%d input" % (K, K, h, w))
+
+
+def _embed_at(w, K, o, tag):
+    w4 = _w4_scratch(w, K, tag)[0]
+    _run("tap_embed", 0.0, 0.0, L.load().vts_tap_embed_at, w.data_ptr(), w.numel() // (K * K), K, -o, -o, w4.data_ptr(), L.stream())
+    return w4
+
+
+def convk_s2(x, w, out, *, bias=None, act_in=0):
+    """out <- Conv2d(K x K, stride 2, padding 0)(x), K <= 4 (the EqualConv2d behind a Blur: stylegan_networks.py:639-657)"""
+    co, ci, K, _ = w.shape
+    xs = x.data.shape if isinstance(x, Act) else x.shape
+    o = _s2_origin(K, xs[2], xs[3])
+    conv4x4(x, _embed_at(w, K, o, "s2"), ci * 16, 16, co, out, bias=bias, stride=2, pad=o, act_in=act_in)
+    return out
+
+
+def convk_s2_bwd_data(dout, w, din, *, accumulate=False):
+    co, ci, K, _ = w.shape
+    o = _s2_origin(K, din.shape[2], din.shape[3])
+    conv4x4(dout, _embed_at(w, K, o, "s2"), 16, ci * 16, ci, din, stride=2, pad=o, transposed=True, accumulate=accumulate)
+    return din
+
+
+def wgradk_s2(dout, x, dw, *, act_hi=0, accumulate=False):
+    co, ci, K, _ = dw.shape
+    xs = x.data.shape if isinstance(x, Act) else x.shape
+    o = _s2_origin(K, xs[2], xs[3])
+    dw4 = _w4_scratch(dw, K, "grad_s2")[0]
+    wgrad4x4(dout, x, dw4, stride=2, pad=o, act_hi=act_hi)
+    _run("tap_extract", 0.0, 0.0, L.load().vts_tap_extract_at, dw4.data_ptr(), dw.numel() // (K * K), K, -o, -o, dw.data_ptr(),
+         int(accumulate), L.stream())
+    return dw
+
+
+# ---- StyleGAN2 blocks (include/vts.h; reference models/stylegan_networks.py) ----
+_HOST_KERNELS = {}
+
+
+def _host_kernel(kernel):
+    key = tuple(tuple(float(v) for v in row) for row in kernel)
+    arr = _HOST_KERNELS.get(key)
+    if arr is None:
+        flat = [v for row in key for v in row]
+        arr = _HOST_KERNELS[key] = ((C.c_float * len(flat))(*flat), len(key), len(key[0]))
+    return arr
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0), out=None, accumulate=False):
+    """upfirdn2d (stylegan_networks.py:38-76) of x [N,C,H,W]; kernel: 2-D host array (make_kernel); pad = (before, after)"""
+    n, c, h, w = x.shape
+    karr, kh, kw = _host_kernel(kernel)
+    lib = L.load()
+    oh, ow = lib.vts_upfirdn2d_out_size(h, kh, up, down, pad[0], pad[1]), lib.vts_upfirdn2d_out_size(w, kw, up, down, pad[0], pad[1])
+    if out is None:
+        out = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+    assert out.shape == (n, c, oh, ow) and x.is_contiguous() and out.is_contiguous()
+    _run("upfirdn2d", 4.0 * (x.numel() + out.numel()), 2.0 * out.numel() * kh * kw / (up * up), lib.vts_upfirdn2d, x.data_ptr(), n * c, h, w,
+         karr, kh, kw, up, down, pad[0], pad[1], pad[0], pad[1], out.data_ptr(), int(accumulate), L.stream())
+    return out
+
+
+def upfirdn2d_bwd(dout, din, kernel, up=1, down=1, pad=(0, 0), accumulate=False):
+    """din [N,C,H,W] (+)= adjoint of upfirdn2d(., kernel, up, down, pad) applied to dout"""
+    n, c, h, w = din.shape
+    karr, kh, kw = _host_kernel(kernel)
+    assert dout.is_contiguous() and din.is_contiguous()
+    _run("upfirdn2d_bwd", 4.0 * (dout.numel() + din.numel()), 2.0 * dout.numel() * kh * kw / (up * up), L.load().vts_upfirdn2d_bwd,
+         dout.data_ptr(), n * c, h, w, karr, kh, kw, up, down, pad[0], pad[1], pad[0], pad[1], din.data_ptr(), int(accumulate), L.stream())
+    return din
+
+
+def bias_act(x, bias, slope=0.2, gain=2.0 ** 0.5, res=None, out=None):
+    """out = leaky_relu(x + bias[c], slope) * gain (+ res)  (fused_leaky_relu, stylegan_networks.py:18-19)"""
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    if out is None:
+        out = torch.empty_like(x)
+    _run("bias_act", 4.0 * x.numel() * (3 if res is not None else 2), 0.0, L.load().vts_bias_act, x.data_ptr(), L.ptr(bias), L.ptr(res), n, c, hw,
+         slope, gain, out.data_ptr(), L.stream())
+    return out
+
+
+def bias_act_bwd(g, x, bias, slope=0.2, gain=2.0 ** 0.5, dx=None):
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    if dx is None:
+        dx = torch.empty_like(x)
+    _run("bias_act_bwd", 12.0 * x.numel(), 0.0, L.load().vts_bias_act_bwd, g.data_ptr(), x.data_ptr(), L.ptr(bias), n, c, hw, slope, gain,
+         dx.data_ptr(), L.stream())
+    return dx
+
+
+def modconv_demod(w, s, scale, eps=1e-8):
+    """demod [N, Co] of ModulatedConv2d (stylegan_networks.py:311-317); w [Co,Ci,K,K] (or [1,Co,Ci,K,K]), s [N,Ci]"""
+    co, ci, kk = w.shape[-4], w.shape[-3], w.shape[-1] * w.shape[-2]
+    n = s.shape[0]
+    out = torch.empty(n, co, dtype=torch.float32, device=w.device)
+    _run("modconv_demod", 4.0 * (w.numel() + s.numel() + out.numel()), 3.0 * n * w.numel(), L.load().vts_modconv_demod, w.data_ptr(), s.data_ptr(),
+         n, co, ci, kk, scale, eps, out.data_ptr(), L.stream())
+    return out
+
+
 def w3x3_pack(w, mode, tag=None):
     """tap-major packing of a 3x3 weight for the *_wide kernels into a persistent buffer (see include/vts.h).
     w is an nn.Conv2d weight [Co,Ci,3,3] for the conv_* modes, an nn.ConvTranspose2d weight [Ci,Co,3,3] for convT_*."""
