@@ -324,7 +324,7 @@ def test_option_fixture_is_reference_dump(golden_dir):
     assert d["sinskitG_train"]["ngf"]["default"] == 10 and d["sinskitG_train"]["netD2"]["default"] == "multiscale"
 
 
-def _probe_close(p, rp, tol=2e-4):
+def _sg_probe_close(p, rp, tol=2e-4):
     return abs(p[1] - rp[1]) <= tol * max(abs(rp[1]), 1e-12) and abs(p[2] - rp[2]) <= tol * max(abs(rp[1]), 1e-12)
 
 
@@ -343,7 +343,7 @@ def test_stylegan2_blocks_match_reference(golden_dir):
     (y * detrand.uniform(tuple(y.shape), seed, "d_cot")).sum().backward()
     np.testing.assert_allclose(x.grad[:, :, ::4, ::4].numpy(), g["D_dx_sub"], rtol=2e-3, atol=1e-6)
     for k, v in sd.items():
-        assert _probe_close(detrand.probe(v.grad, k), g["D_grad/" + k]), k
+        assert _sg_probe_close(detrand.probe(v.grad, k), g["D_grad/" + k]), k
     u = detrand.uniform((2, 3, 9, 11), seed, "ufd_in")
     for i, (up, down, pad) in enumerate(sg.UPFIRDN_CASES):
         np.testing.assert_allclose(sg.upfirdn2d(u, sg.make_kernel() * (up ** 2), up, down, pad).numpy(), g["ufd/%d" % i], rtol=1e-5, atol=1e-6)
@@ -356,7 +356,7 @@ def test_stylegan2_blocks_match_reference(golden_dir):
         yo = sg.modulated_conv2d(xi, st, w["weight"], w["modulation.weight"], w["modulation.bias"], **kw)
         np.testing.assert_allclose(yo.detach().numpy(), g["mod/%s/out" % tag], rtol=1e-4, atol=1e-5)
         (yo * detrand.uniform(tuple(yo.shape), seed, "mod_cot" + tag)).sum().backward()
-        assert _probe_close(detrand.probe(xi.grad, "mdx"), g["mod/%s/dx" % tag]), tag
+        assert _sg_probe_close(detrand.probe(xi.grad, "mdx"), g["mod/%s/dx" % tag]), tag
         np.testing.assert_allclose(st.grad.numpy(), g["mod/%s/dstyle" % tag], rtol=2e-3, atol=1e-5)
         for k, v in w.items():
-            assert _probe_close(detrand.probe(v.grad, k), g["mod/%s/grad/%s" % (tag, k)]), (tag, k)
+            assert _sg_probe_close(detrand.probe(v.grad, k), g["mod/%s/grad/%s" % (tag, k)]), (tag, k)
