@@ -235,22 +235,28 @@ int64_t vts_wgrad3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int 
 int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int stride,
                       int accumulate, float* ws, int64_t ws_floats, void* stream);
 
-/* ---- 4 x 4 convolutions of wide layers on small maps (the ndf = 64 PatchGAN discriminators of pix2pixHD on 32 x 32 patches:
+/* ---- 4 x 4 convolutions of wide layers (the ndf = 64 PatchGAN discriminators of pix2pixHD, full-size images or 32 x 32 patches:
  * models/networks.py MultiscaleDiscriminator / NLayerDiscriminator, kw = 4, padw = 2, called from models/pix2pixHD_model.py:587-722).
- * The flattened-batch GEMM-class kernel with 16-tap packed weights (vts_w4x4_pack: wt[(a*16 + t)*B + b] = w[a*sa + b*sb + (flip ? 15-t : t)];
+ * The GEMM-class kernels (tiled for full-size maps, flattened-batch for maps of <= 128 pixels) with 16-tap packed weights (vts_w4x4_pack: wt[(a*16 + t)*B + b] = w[a*sa + b*sb + (flip ? 15-t : t)];
  * nn.Conv2d weight [Co,Ci,4,4]: forward A=Ci,B=Co,sa=16,sb=16Ci; input adjoint of the stride-1 conv A=Co,B=Ci,sa=16Ci,sb=16,flip on the
  * gradient zero-padded by 3 - pad; input adjoint of the stride-2 conv: the same A/B/sa/sb without flip and transposed = 1).
  *   transposed = 0:  out[n,co,y,x] = bias + sum in[n,ci,stride*y+ky,stride*x+kx] * wt[..]   in [N,Cin,PH,PW] pre-padded (vts_pad_affine)
  *   transposed = 1:  (stride 2, pad 2) `in` = output gradient with one zero row / column appended, out = input gradient [N,Cout,OH,OW],
  *                    one launch per output parity phase.
- * vts_conv4x4_flat_ok tells whether a shape is a small-map case (<= 128 output pixels per image and launch); larger maps stay on
- * vts_conv4x4.  Packed rows have a pitch of B rounded up to 4 floats (zero filled), so Cout = 1 prediction heads qualify as well
+ * vts_conv4x4_flat_ok tells whether a shape is a small-map case (<= 128 output pixels per image and launch); the tiled kernel
+ * for larger maps needs Cout % 4 == 0.  Packed rows have a pitch of B rounded up to 4 floats (zero filled), so Cout = 1 prediction heads qualify as well
  * (vts_w3x3_pack: the same; its consumers require B % 4 == 0). */
 int vts_w4x4_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream);
 int vts_conv4x4_flat_ok(int OH, int OW, int PH, int PW, int transposed);
-int64_t vts_conv4x4_flat_ws_floats(int N, int Cin, int Cout, int OH, int OW, int PH, int PW, int transposed);
-int vts_conv4x4_flat(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int PH, int PW,
+int64_t vts_conv4x4_wide_ws_floats(int N, int Cin, int Cout, int OH, int OW, int PH, int PW, int transposed);
+int vts_conv4x4_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int PH, int PW,
                      int OH, int OW, int stride, int transposed, float* ws, int64_t ws_floats, void* stream);
+/* weight gradient of the same layers on full-size maps: dw[co][ci][ky][kx] (+)= sum dout[n,co,y,x] * in[n,ci,stride*y+ky,stride*x+kx],
+ * dout [N,Cout,H,W], in [N,Cin,PH,PW] pre-padded; GEMM-class (K = pixels), deterministic slice reduction through `ws`
+ * (vts_wgrad4x4_wide_ws_floats).  Small maps stay on vts_wgrad4x4. */
+int64_t vts_wgrad4x4_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int stride);
+int vts_wgrad4x4_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int PH, int PW,
+                      int stride, int accumulate, float* ws, int64_t ws_floats, void* stream);
 
 /* ---- StyleGAN2 building blocks (models/stylegan_networks.py) ----
  * vts_upfirdn2d      upfirdn2d_native :38-76 (Blur :140-156, Upsample :98-116, Downsample :119-137): insert up-1 zeros, pad

@@ -428,10 +428,11 @@ def test_wide_strided_and_transposed_family(shape):
 
 
 @pytest.mark.parametrize("shape,stride", [((32, 64, 128, 17, 17), 2), ((32, 256, 512, 5, 5), 1), ((5, 128, 68, 9, 9), 2), ((3, 36, 64, 3, 3), 1),
-                                          ((7, 64, 32, 4, 6), 2), ((2, 32, 36, 7, 10), 1), ((33, 512, 64, 2, 2), 1), ((32, 512, 1, 6, 6), 1), ((3, 70, 5, 4, 5), 2)])
+                                          ((7, 64, 32, 4, 6), 2), ((2, 32, 36, 7, 10), 1), ((33, 512, 64, 2, 2), 1), ((32, 512, 1, 6, 6), 1), ((3, 70, 5, 4, 5), 2),
+                                          ((2, 64, 128, 70, 75), 2), ((1, 256, 512, 40, 33), 1), ((2, 128, 64, 37, 41), 2), ((1, 36, 132, 129, 129), 1)])
 def test_conv4x4_flat_forward_and_input_adjoint(shape, stride):
-    """the PatchGAN layers Conv2d(4, stride, padding 2) of a wide discriminator on small maps: flattened GEMM-class kernel
-    vs F.conv2d, and its input adjoint (stride 1: flipped packing on the padded gradient; stride 2: parity phases) vs autograd"""
+    """the PatchGAN layers Conv2d(4, stride, padding 2) of a wide discriminator on the GEMM-class kernels (flattened for maps of
+    <= 128 pixels, tiled above) vs F.conv2d, and its input adjoint (stride 1: flipped packing on the padded gradient; stride 2: parity phases) vs autograd"""
     from vts import ops
     n, ci, co, h, w = shape
     dev = _dev()
@@ -443,18 +444,42 @@ def test_conv4x4_flat_forward_and_input_adjoint(shape, stride):
     (ref * cot).sum().backward()
     oh, ow = ref.shape[2:]
     ph, pw = stride * (oh - 1) + 4, stride * (ow - 1) + 4
-    assert ops.conv4x4_flat_ok(oh, ow, ph, pw)
     xd, wd, cd = x.detach().to(dev), wt.detach().to(dev), cot.to(dev)
     p = ops.pad_affine(xd, (2, ph - h - 2, 2, pw - w - 2), 0)
     out = torch.full(ref.shape, float("nan"), device=dev)
-    ops.conv4x4_flat(p, ops.w4x4_pack(wd, "conv_fwd"), b.to(dev), out, stride=stride)
+    ops.conv4x4_wide(p, ops.w4x4_pack(wd, "conv_fwd"), b.to(dev), out, stride=stride)
     assert rel(out, ref) < 1e-5
     dx = torch.full(x.shape, float("nan"), device=dev)
     if stride == 1:
-        ops.conv4x4_flat(ops.pad_affine(cd, (1, 1, 1, 1), 0), ops.w4x4_pack(wd, "conv_adj"), None, dx)
+        ops.conv4x4_wide(ops.pad_affine(cd, (1, 1, 1, 1), 0), ops.w4x4_pack(wd, "conv_adj"), None, dx)
     else:
-        ops.conv4x4_flat(ops.pad_affine(cd, (0, 1, 0, 1), 0), ops.w4x4_pack(wd, "conv_s2_adj"), None, dx, stride=2, transposed=True)
+        ops.conv4x4_wide(ops.pad_affine(cd, (0, 1, 0, 1), 0), ops.w4x4_pack(wd, "conv_s2_adj"), None, dx, stride=2, transposed=True)
     assert rel(dx, x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape,stride", [((2, 64, 128, 70, 75), 2), ((1, 256, 512, 40, 33), 1), ((2, 132, 68, 37, 41), 2), ((1, 64, 64, 129, 129), 1)])
+def test_wgrad4x4_wide(shape, stride):
+    """weight gradient of Conv2d(4, stride, padding 2) on the GEMM-class kernel (two tap-row launches) vs autograd"""
+    from vts import ops
+    n, ci, co, h, w = shape
+    dev = _dev()
+    x = detrand.uniform((n, ci, h, w), 43, "x")
+    wt = (detrand.uniform((co, ci, 4, 4), 43, "w") * 0.1).requires_grad_(True)
+    ref = F.conv2d(x, wt, stride=stride, padding=2)
+    cot = detrand.uniform(tuple(ref.shape), 43, "cot")
+    (ref * cot).sum().backward()
+    oh, ow = ref.shape[2:]
+    ph, pw = stride * (oh - 1) + 4, stride * (ow - 1) + 4
+    p = ops.pad_affine(x.to(dev), (2, ph - h - 2, 2, pw - w - 2), 0)
+    dw = torch.full(wt.shape, float("nan"), device=dev)
+    ops.wgrad4x4_wide(cot.to(dev), p, dw, stride=stride)
+    assert rel(dw, wt.grad) < 2e-5
+    dw2 = dw.clone()
+    ops.wgrad4x4_wide(cot.to(dev), p, dw2, stride=stride, accumulate=True)
+    assert rel(dw2, 2 * wt.grad) < 2e-5
+    dw3 = torch.empty_like(dw)
+    ops.wgrad4x4_wide(cot.to(dev), p, dw3, stride=stride)
+    assert torch.equal(dw, dw3)
 
 
 def test_local_enhancer_matches_reference_and_oracle(golden_dir):

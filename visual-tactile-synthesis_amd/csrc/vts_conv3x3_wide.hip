@@ -43,14 +43,16 @@ struct WideK {
   float* part;   // [KS][N][Cout][OH][OW] raw partial sums (KS > 1), reduced in slice order by wide_reduce_kernel
 };
 
-template <int S>
-__global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
-  constexpr int PR = S * (TY - 1) + 3, PC = S * (TX - 1) + 3, PCP = (PC + 3) / 4 * 4;
+// K: kernel extent (3 | 4: taps of the packed weight = K * K), CKT: input channels per chunk
+template <int S, int K, int CKT>
+__device__ __forceinline__ void wide_body(const WideK& p) {
+  constexpr int CK = CKT, TWT = K * K;
+  constexpr int PR = S * (TY - 1) + K, PC = S * (TX - 1) + K, PCP = (PC + 3) / 4 * 4;
   constexpr int PATCH_FLOATS = CK * PR * PCP;
-  constexpr int W_FLOATS = CK * 9 * TCO;
+  constexpr int W_FLOATS = CK * TWT * TCO;
   constexpr int PQ_ROW = PCP / 4;
   constexpr int NPQ = (CK * PR * PQ_ROW + 255) / 256;
-  constexpr int NWQ = W_FLOATS / 4 / 256;               // 9 weight quads per thread (fewer taps: fewer are live)
+  constexpr int NWQ = W_FLOATS / 4 / 256;               // 9 (8 for K = 4) weight quads per thread (fewer taps: fewer are live)
   __shared__ __attribute__((aligned(16))) float lds[PATCH_FLOATS + W_FLOATS];
   float* lds_p = lds;
   float* lds_w = lds + PATCH_FLOATS;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
   const int ntaps = p.ntaps;
 
   const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * 9 * p.Cout * 4, RSRC_FLAGS);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * TWT * p.Cout * 4, RSRC_FLAGS);
 
   // staging items of this thread (chunk independent): patch quads (ci, row, quad), weight quads ((ci, t), co quad)
   int pvoff[NPQ], ploff[NPQ];
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
     const int row = q >> 5, cq = q & 31;                    // row = ci * ntaps + t
     const int ci = row / ntaps, t = row - ci * ntaps;
     const bool live = row < CK * ntaps;
-    wvoff[e] = live ? ((ci * 9 + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;   // dead rows: out of range -> 0
+    wvoff[e] = live ? ((ci * TWT + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;   // dead rows: out of range -> 0
     wloff[e] = (live ? row : 0) * TCO + 4 * cq;
   }
   // Pixels past the grid and channels past Cout only ever feed outputs that are never stored; channels past Cin read
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
 
   u32x4 pq[NPQ], wq[NWQ];
   auto load_chunk = [&](int c0) {
-    const int pbase = c0 * plane * 4, wbase = c0 * 9 * p.Cout * 4;
+    const int pbase = c0 * plane * 4, wbase = c0 * TWT * p.Cout * 4;
 #pragma unroll
     for (int e = 0; e < NPQ; ++e) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pvoff[e] + pbase, 0, 0);
 #pragma unroll
@@ -162,6 +164,14 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) {
       }
     }
 }
+
+template <int S>
+__global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) { wide_body<S, 3, 8>(p); }
+
+// the same tiling for 4 x 4 kernels (the ndf = 64 PatchGAN discriminators of pix2pixHD on full-size images): 16-tap packed
+// weights, 4 input channels per chunk (32 KB of weights + a 7 x 36 / 10 x 68 patch per channel in LDS)
+template <int S>
+__global__ __launch_bounds__(256) void conv4x4_wide_kernel(const WideK p) { wide_body<S, 4, 4>(p); }
 
 __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int KS,
                                                            int64_t per_slice, int HW, int Cout, float* __restrict__ out) {
@@ -384,9 +394,9 @@ extern "C" int vts_w4x4_pack(const float* w, int A, int B, int64_t sa, int64_t s
   return wtap_pack("vts_w4x4_pack", w, A, B, sa, sb, 16, flip, wt, stream);
 }
 
-static int wide_plan(int N, int Cin, int Cout, int H, int W, int* cps) {
+static int wide_plan(int N, int Cin, int Cout, int H, int W, int* cps, int ck = CK) {
   const int wgs = cdiv(W, TX) * cdiv(H, TY) * cdiv(Cout, TCO) * N;
-  const int nchunks = cdiv(Cin, CK);
+  const int nchunks = cdiv(Cin, ck);
   int KS = 1;
   if (wgs < 256) {           // too few tiles for 256 CUs: split the input-channel loop
     KS = 768 / wgs;
@@ -462,25 +472,32 @@ static int flat_launch(const WideK& k, int S, int TW, float* ws, int64_t ws_floa
   return VTS_OK;
 }
 
-static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_t st) {
-  VTS_CHECK_ARG((k.Cout & 3) == 0, "vts_conv3x3_wide: Cout %d must be a multiple of 4 (16-byte weight rows)", k.Cout);
-  VTS_CHECK_ARG((int64_t)k.Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)k.Cin * 9 * k.Cout * 4 < (1ll << 31) && k.N <= 1024,
-                "vts_conv3x3_wide: operand exceeds the 2 GiB buffer range");
-  if (flat_ok(k.H, k.W, k.IPH * k.IPW, CK)) return flat_launch(k, S, 9, ws, ws_floats, st);
+static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_t st, int K = 3) {
+  const int ck = K == 4 ? 4 : CK, TW = K * K;
+  VTS_CHECK_ARG((k.Cout & 3) == 0 || (K == 4 && flat_ok(k.H, k.W, k.IPH * k.IPW, ck)), "wide conv: Cout %d must be a multiple of 4 (16-byte weight rows)", k.Cout);
+  VTS_CHECK_ARG((int64_t)k.Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)k.Cin * TW * k.Cout * 4 < (1ll << 31) && k.N <= 1024,
+                "wide conv: operand exceeds the 2 GiB buffer range");
+  if (flat_ok(k.H, k.W, k.IPH * k.IPW, ck)) return flat_launch(k, S, TW, ws, ws_floats, st);
   int cps;
-  int KS = k.os == 1 ? wide_plan(k.N, k.Cin, k.Cout, k.H, k.W, &cps) : 1;
+  int KS = k.os == 1 ? wide_plan(k.N, k.Cin, k.Cout, k.H, k.W, &cps, ck) : 1;
   const int64_t per_slice = (int64_t)k.N * k.Cout * k.OH * k.OW;
-  if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; cps = cdiv(k.Cin, CK); }
+  if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; cps = cdiv(k.Cin, ck); }
   k.KS = KS; k.cps = cps; k.part = KS > 1 ? ws : nullptr;
   const dim3 grid(cdiv(k.W, TX) * cdiv(k.H, TY), cdiv(k.Cout, TCO), k.N * KS);
-  if (S == 1) hipLaunchKernelGGL(conv3x3_wide_kernel<1>, grid, dim3(256), 0, st, k);
-  else hipLaunchKernelGGL(conv3x3_wide_kernel<2>, grid, dim3(256), 0, st, k);
-  vts_set_kernel(KS > 1 ? "conv3x3_wide_kernel<%d>+ksplit" : "conv3x3_wide_kernel<%d>", S);
-  VTS_CHECK_LAUNCH("vts_conv3x3_wide");
+  if (K == 4) {
+    if (S == 1) hipLaunchKernelGGL(conv4x4_wide_kernel<1>, grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(conv4x4_wide_kernel<2>, grid, dim3(256), 0, st, k);
+    vts_set_kernel(KS > 1 ? "conv4x4_wide_kernel<%d>+ksplit" : "conv4x4_wide_kernel<%d>", S);
+  } else {
+    if (S == 1) hipLaunchKernelGGL(conv3x3_wide_kernel<1>, grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(conv3x3_wide_kernel<2>, grid, dim3(256), 0, st, k);
+    vts_set_kernel(KS > 1 ? "conv3x3_wide_kernel<%d>+ksplit" : "conv3x3_wide_kernel<%d>", S);
+  }
+  VTS_CHECK_LAUNCH("wide conv");
   if (KS > 1) {
     hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)cdiv64(per_slice, 256)), dim3(256), 0, st, ws, k.bias, KS, per_slice,
                        k.OH * k.OW, k.Cout, k.out);
-    VTS_CHECK_LAUNCH("vts_conv3x3_wide reduce");
+    VTS_CHECK_LAUNCH("wide conv reduce");
   }
   return VTS_OK;
 }
@@ -533,9 +550,9 @@ extern "C" int vts_tconv3x3s2_wide(const float* in, const float* wt, const float
   return VTS_OK;
 }
 
-// 4 x 4 convolutions of wide layers on small maps (the ndf = 64 PatchGAN discriminators of pix2pixHD on 32 x 32 patches,
-// reference models/networks.py NLayerDiscriminator via MultiscaleDiscriminator, kw = 4, padw = 2): the flattened kernel with
-// 16-tap packed weights.  transposed = 0: out[n,co,y,x] = bias + sum in[n,ci,S*y+ky,S*x+kx] * wt[(ci*16 + ky*4+kx)*Cout + co]
+// 4 x 4 convolutions of wide layers (the ndf = 64 PatchGAN discriminators of pix2pixHD, reference models/networks.py
+// NLayerDiscriminator via MultiscaleDiscriminator, kw = 4, padw = 2): 16-tap packed weights on the GEMM-class kernels --
+// conv4x4_wide_kernel for full-size maps, the flattened kernel for maps of <= 128 pixels (32 x 32 training patches).  transposed = 0: out[n,co,y,x] = bias + sum in[n,ci,S*y+ky,S*x+kx] * wt[(ci*16 + ky*4+kx)*Cout + co]
 // on the pre-padded input.  transposed = 1 (stride 2, the input adjoint of Conv2d(4, s2, p2)): `in` is the output gradient
 // with one zero row / column appended; out[2m+py] = sum_{d in {0,1}} in[m+d] * w[k = py + 2(1-d)], one launch per parity phase.
 static bool flat4_shapes_ok(int OH, int OW, int PH, int PW, int transposed) {
@@ -545,29 +562,32 @@ static bool flat4_shapes_ok(int OH, int OW, int PH, int PW, int transposed) {
 
 extern "C" int vts_conv4x4_flat_ok(int OH, int OW, int PH, int PW, int transposed) { return flat4_shapes_ok(OH, OW, PH, PW, transposed) ? 1 : 0; }
 
-extern "C" int64_t vts_conv4x4_flat_ws_floats(int N, int Cin, int Cout, int OH, int OW, int PH, int PW, int transposed) {
-  if (!flat4_shapes_ok(OH, OW, PH, PW, transposed)) return 0;
+extern "C" int64_t vts_conv4x4_wide_ws_floats(int N, int Cin, int Cout, int OH, int OW, int PH, int PW, int transposed) {
   const int gh = transposed ? (OH + 1) / 2 : OH, gw = transposed ? (OW + 1) / 2 : OW;
   int ipt, cps;
-  const int KS = flat_plan(N, Cin, Cout, gh, gw, PH * PW, 4, &ipt, &cps);
-  return KS > 1 ? (int64_t)KS * N * Cout * gh * gw : 0;
+  if (flat4_shapes_ok(OH, OW, PH, PW, transposed)) {
+    const int KS = flat_plan(N, Cin, Cout, gh, gw, PH * PW, 4, &ipt, &cps);
+    return KS > 1 ? (int64_t)KS * N * Cout * gh * gw : 0;
+  }
+  if (transposed) return 0;
+  const int KS = wide_plan(N, Cin, Cout, OH, OW, &cps, 4);
+  return KS > 1 ? (int64_t)KS * N * Cout * OH * OW : 0;
 }
 
-extern "C" int vts_conv4x4_flat(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int PH, int PW,
+extern "C" int vts_conv4x4_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int PH, int PW,
                                 int OH, int OW, int stride, int transposed, float* ws, int64_t ws_floats, void* stream) {
   VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && OH >= 1 && OW >= 1 && (stride == 1 || stride == 2),
-                "vts_conv4x4_flat: bad args");
-  VTS_CHECK_ARG(flat4_shapes_ok(OH, OW, PH, PW, transposed), "vts_conv4x4_flat: map %d x %d (padded %d x %d) is not a small-map case", OH, OW, PH, PW);
+                "vts_conv4x4_wide: bad args");
   WideK k{};
   k.in = in; k.wt = wt; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.IPH = PH; k.IPW = PW; k.OH = OH; k.OW = OW;
   if (!transposed) {
-    VTS_CHECK_ARG(PH >= stride * (OH - 1) + 4 && PW >= stride * (OW - 1) + 4, "vts_conv4x4_flat: padded input %d x %d too small for output %d x %d", PH, PW, OH, OW);
+    VTS_CHECK_ARG(PH >= stride * (OH - 1) + 4 && PW >= stride * (OW - 1) + 4, "vts_conv4x4_wide: padded input %d x %d too small for output %d x %d", PH, PW, OH, OW);
     k.H = OH; k.W = OW; k.os = 1; k.oy0 = 0; k.ox0 = 0; k.ntaps = 16;
     for (int t = 0; t < 16; ++t) { k.dy[t] = (signed char)(t / 4); k.dx[t] = (signed char)(t % 4); k.wt_tap[t] = (signed char)t; }
-    return flat_launch(k, stride, 16, ws, ws_floats, (hipStream_t)stream);
+    return wide_launch(k, stride, ws, ws_floats, (hipStream_t)stream, 4);
   }
-  VTS_CHECK_ARG(stride == 2, "vts_conv4x4_flat: the transposed form is the stride-2 one (stride 1: flipped packing on the padded gradient)");
-  VTS_CHECK_ARG(2 * (PH - 1) >= OH + 1 && 2 * (PW - 1) >= OW + 1 - 0, "vts_conv4x4_flat: gradient extent %d x %d too small for %d x %d", PH, PW, OH, OW);
+  VTS_CHECK_ARG(stride == 2, "vts_conv4x4_wide: the transposed form is the stride-2 one (stride 1: flipped packing on the padded gradient)");
+  VTS_CHECK_ARG(2 * (PH - 1) >= OH + 1 && 2 * (PW - 1) >= OW + 1, "vts_conv4x4_wide: gradient extent %d x %d too small for %d x %d", PH, PW, OH, OW);
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       k.H = (OH - py + 1) / 2; k.W = (OW - px + 1) / 2;
@@ -579,7 +599,7 @@ extern "C" int vts_conv4x4_flat(const float* in, const float* wt, const float* b
           k.wt_tap[k.ntaps] = (signed char)((py + 2 * (1 - a)) * 4 + px + 2 * (1 - b));
           ++k.ntaps;
         }
-      const int rc = flat_launch(k, 1, 16, ws, ws_floats, (hipStream_t)stream);
+      const int rc = wide_launch(k, 1, ws, ws_floats, (hipStream_t)stream, 4);
       if (rc != VTS_OK) return rc;
     }
   return VTS_OK;
@@ -604,15 +624,18 @@ struct WgWideK {
   int N, Cin, Cout, H, W;   // H x W: extent of dout
   int IPH, IPW;             // padded extent of `in`
   int tiles_x, tiles_per_img, ntiles, tps;   // pixel tiles; tps = tiles per K slice
+  int TW, tap0, in_skip;    // taps of dw (9 | 16), first tap of this launch, floats by which `in` was advanced (bounds)
 };
 
 // S: stride of the convolution whose weight gradient this is (in is sampled at S*y + ky, S*x + kx)
-template <int S>
-__global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
+// KH x KW: the taps this launch accumulates (3 x 3; a 4 x 4 kernel takes two launches of 2 x 4 taps: 128 accumulator registers each)
+template <int S, int KH, int KW>
+__device__ __forceinline__ void wg_wide_body(const WgWideK& p) {
+  constexpr int NT = KH * KW;
   constexpr int GTX = S == 1 ? 32 : 16;
   constexpr int GPX = GTY * GTX;                           // pixels per tile
   constexpr int DO_PITCH = GPX + 1;                        // dout plane [co][px], odd pitch
-  constexpr int GPR = S * (GTY - 1) + 3, GPC = (S * (GTX - 1) + 3 + 3) / 4 * 4;   // patch rows, staged columns
+  constexpr int GPR = S * (GTY - 1) + KH, GPC = (S * (GTX - 1) + KW + 3) / 4 * 4;   // patch rows, staged columns
   constexpr int P_PITCH = GPR * GPC + 1;                   // in plane [ci][r][c], odd pitch
   constexpr int GDO_FLOATS = GCO * DO_PITCH, GP_FLOATS = GCI * P_PITCH;
   constexpr int DQ_TOTAL = GCO * GPX / 4, IQ_TOTAL = GCI * GPR * (GPC / 4);
@@ -654,7 +677,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
     cur_x0 = tx * GTX;
     cur_y0 = ty * GTY;
     const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dout) + (int64_t)n * p.Cout * oplane, 0, p.Cout * oplane * 4, RSRC_FLAGS);
-    const auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
+    const auto ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4 - p.in_skip * 4, RSRC_FLAGS);
     const int doff = (cur_y0 * p.W + cur_x0) * 4, ioff = (S * cur_y0 * PW + S * cur_x0) * 4;
 #pragma unroll
     for (int e = 0; e < NDQ; ++e) dq[e] = __builtin_amdgcn_raw_buffer_load_b128(rd, dvoff[e] + doff, 0, 0);
@@ -686,9 +709,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -710,8 +733,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
       for (int xs = 0; xs < GTX / 2; ++xs) {
         const float a = a_base[row * GTX + xs * 2];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
+        for (int tap = 0; tap < NT; ++tap) {
+          const int ky = tap / KW, kx = tap - ky * KW;
           const float b = b_base[(S * row + ky) * GPC + S * xs * 2 + kx];
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
         }
@@ -724,16 +747,24 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) {
   }
 
   // C layout: column (ci) = lane % 32, row (co) = (r / 4) * 8 + (lane / 32) * 4 + r % 4
-  float* ob = p.part + (int64_t)ks * p.Cout * p.Cin * 9;
+  float* ob = p.part + (int64_t)ks * p.Cout * p.Cin * p.TW + p.tap0;
   const int ci = ci0 + wci * 32 + l32;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wco * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
-      if (co < p.Cout && ci < p.Cin) ob[((int64_t)co * p.Cin + ci) * 9 + tap] = acc[tap][r];
+      if (co < p.Cout && ci < p.Cin) ob[((int64_t)co * p.Cin + ci) * p.TW + tap] = acc[tap][r];
     }
 }
+
+template <int S>
+__global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgWideK p) { wg_wide_body<S, 3, 3>(p); }
+
+// two rows of the taps of a 4 x 4 kernel (p.tap0 = 4 * first row; p.in starts at that row of the padded input)
+template <int S>
+__global__ __launch_bounds__(256) void wgrad4x4_wide_kernel(const WgWideK p) { wg_wide_body<S, 2, 4>(p); }
+
 
 __global__ __launch_bounds__(256) void wg_wide_reduce_kernel(const float* __restrict__ part, int KS, int64_t n, float* __restrict__ dw, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -924,7 +955,7 @@ extern "C" int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, 
   VTS_CHECK_ARG(ws != nullptr, "vts_wgrad3x3_wide: workspace required");
   WgWideK k;
   k.dout = dout; k.in = in; k.part = ws; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
-  k.IPH = IPH; k.IPW = IPW;
+  k.IPH = IPH; k.IPW = IPW; k.TW = 9; k.tap0 = 0; k.in_skip = 0;
   VTS_CHECK_ARG((int64_t)Cin * k.IPH * k.IPW * 4 < (1ll << 31) && (int64_t)Cout * H * W * 4 < (1ll << 31), "vts_wgrad3x3_wide: operand exceeds the 2 GiB buffer range");
   k.tiles_x = cdiv(W, stride == 1 ? 32 : 16);
   k.tiles_per_img = k.tiles_x * cdiv(H, GTY);
@@ -938,5 +969,40 @@ extern "C" int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, 
   VTS_CHECK_LAUNCH("vts_wgrad3x3_wide");
   hipLaunchKernelGGL(wg_wide_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, (hipStream_t)stream, ws, KS, nel, dw, accumulate);
   VTS_CHECK_LAUNCH("vts_wgrad3x3_wide reduce");
+  return VTS_OK;
+}
+
+// Weight gradient of Conv2d(4, stride, padding) of a wide layer on full-size maps (the ndf = 64 PatchGAN layers of pix2pixHD):
+//   dw[co][ci][ky][kx] (+)= sum_{n,y,x} dout[n,co,y,x] * in[n,ci,stride*y+ky,stride*x+kx]      in [N,Cin,PH,PW] pre-padded
+// two launches of wgrad4x4_wide_kernel (tap rows 0-1 and 2-3) into one partial buffer, one slice reduction.
+extern "C" int64_t vts_wgrad4x4_wide_ws_floats(int N, int Cin, int Cout, int H, int W, int stride) {
+  int tps;
+  return (int64_t)wg_wide_plan(N, Cin, Cout, H, W, stride, &tps) * Cout * Cin * 16;
+}
+
+extern "C" int vts_wgrad4x4_wide(const float* dout, const float* in, float* dw, int N, int Cin, int Cout, int H, int W, int PH, int PW,
+                                 int stride, int accumulate, float* ws, int64_t ws_floats, void* stream) {
+  VTS_CHECK_ARG(dout && in && dw && ws && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && (stride == 1 || stride == 2),
+                "vts_wgrad4x4_wide: bad args");
+  VTS_CHECK_ARG(PH >= stride * (H - 1) + 4 && PW >= stride * (W - 1) + 4, "vts_wgrad4x4_wide: padded input %d x %d too small for a %d x %d gradient", PH, PW, H, W);
+  VTS_CHECK_ARG((int64_t)Cin * PH * PW * 4 < (1ll << 31) && (int64_t)Cout * H * W * 4 < (1ll << 31), "vts_wgrad4x4_wide: operand exceeds the 2 GiB buffer range");
+  WgWideK k;
+  k.dout = dout; k.part = ws; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W; k.IPH = PH; k.IPW = PW; k.TW = 16;
+  k.tiles_x = cdiv(W, stride == 1 ? 32 : 16);
+  k.tiles_per_img = k.tiles_x * cdiv(H, GTY);
+  k.ntiles = N * k.tiles_per_img;
+  const int KS = wg_wide_plan(N, Cin, Cout, H, W, stride, &k.tps);
+  const int64_t nel = (int64_t)Cout * Cin * 16;
+  VTS_CHECK_ARG(ws_floats >= KS * nel, "vts_wgrad4x4_wide: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)(KS * nel));
+  const dim3 grid(cdiv(Cout, GCO), cdiv(Cin, GCI), KS);
+  for (int half = 0; half < 2; ++half) {
+    k.in = in + (int64_t)2 * half * PW; k.in_skip = 2 * half * PW; k.tap0 = 8 * half;
+    if (stride == 1) hipLaunchKernelGGL(wgrad4x4_wide_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(wgrad4x4_wide_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    VTS_CHECK_LAUNCH("vts_wgrad4x4_wide");
+  }
+  vts_set_kernel("wgrad4x4_wide_kernel<%d>", stride);
+  hipLaunchKernelGGL(wg_wide_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, (hipStream_t)stream, ws, KS, nel, dw, accumulate);
+  VTS_CHECK_LAUNCH("vts_wgrad4x4_wide reduce");
   return VTS_OK;
 }

@@ -653,12 +653,15 @@ FLAT_D = os.environ.get("VTS_FLAT_D", "1") != "0"
 
 
 def _flat4(conv, j, h, w, oh, ow, st):
-    """whether this PatchGAN layer takes the flattened small-map GEMM-class route (wide layer, <= 128 pixels per image):
-    (forward ok, padded extent) -- the input adjoint has its own check in _msd_scale_backward"""
+    """whether this PatchGAN layer takes the GEMM-class route with 16-tap packed weights (vts_conv4x4_wide: flattened-batch kernel
+    for maps of <= 128 pixels, tiled kernel above): wide layers only; Cout = 1 heads only on small maps"""
     co, ci = conv.weight.shape[0], conv.weight.shape[1]
-    if not FLAT_D or j == 0 or ci < 32 or (co < 32 and ci < 256):   # thin layers stay on the 4x4 kernels
+    if not FLAT_D or j == 0 or ci < 32:
         return False
-    return ops.conv4x4_flat_ok(oh, ow, st * (oh - 1) + 4, st * (ow - 1) + 4)
+    small = ops.conv4x4_flat_ok(oh, ow, st * (oh - 1) + 4, st * (ow - 1) + 4)
+    if small:
+        return co >= 32 or ci >= 256
+    return co >= 64 and co % 4 == 0 and ci % 4 == 0
 
 
 def _msd_scale_forward(D, s, a0, a1, update_stats):
@@ -677,7 +680,8 @@ def _msd_scale_forward(D, s, a0, a1, update_stats):
         if _flat4(conv, j, h, w, oh, ow, st):
             ph, pw = st * (oh - 1) + 4, st * (ow - 1) + 4
             p = ops.pad_affine(cur0, (2, ph - h - 2, 2, pw - w - 2), 0, act=LRELU)
-            ops.conv4x4_flat(p, ops.w4x4_pack(conv.weight, "conv_fwd"), conv.bias, out, stride=st)
+            cur0.padded = p
+            ops.conv4x4_wide(p, ops.w4x4_pack(conv.weight, "conv_fwd"), conv.bias, out, stride=st)
         else:
             ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
                         act_in=LRELU if j else 0)
@@ -709,8 +713,12 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
                          dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate)
         src0, src1 = (a0, a1) if j == 0 else (acts[j - 1], None)
         if param_grads:
-            ops.wgrad4x4(Act(g), src0, conv.weight.grad, hi1=src1, act_hi=LRELU if j else 0, stride=st, pad=2,
-                         accumulate=accumulate)
+            pp = src0.padded if j else None
+            if pp is not None and not ops.conv4x4_flat_ok(g.shape[2], g.shape[3], pp.shape[2], pp.shape[3]):
+                ops.wgrad4x4_wide(g, pp, conv.weight.grad, stride=st, accumulate=accumulate)     # full-size map: GEMM-class
+            else:
+                ops.wgrad4x4(Act(g), src0, conv.weight.grad, hi1=src1, act_hi=LRELU if j else 0, stride=st, pad=2,
+                             accumulate=accumulate)
             if ci not in D.BN_IDX:   # a conv bias in front of a BatchNorm has an identically zero gradient
                 ops.channel_sum(g, conv.bias.grad, accumulate=accumulate)
         if j > 0:
@@ -718,12 +726,12 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
             tgt = torch.empty_like(prev.data)
             h, w, oh, ow = prev.data.shape[2], prev.data.shape[3], g.shape[2], g.shape[3]
             qh, qw = (oh + 2, ow + 2) if st == 1 else (oh + 1, ow + 1)
-            if _flat4(conv, j, h, w, oh, ow, st) and ops.conv4x4_flat_ok(h, w, qh, qw, st == 2):
+            if _flat4(conv, j, h, w, oh, ow, st) and (cin % 4 == 0 or ops.conv4x4_flat_ok(h, w, qh, qw, st == 2)):
                 raw = torch.empty_like(prev.data)
                 if st == 1:   # adjoint of the stride-1 conv: the same operator on the padded gradient, flipped taps
-                    ops.conv4x4_flat(ops.pad_affine(g, (1, 1, 1, 1), 0), ops.w4x4_pack(conv.weight, "conv_adj"), None, raw)
+                    ops.conv4x4_wide(ops.pad_affine(g, (1, 1, 1, 1), 0), ops.w4x4_pack(conv.weight, "conv_adj"), None, raw)
                 else:
-                    ops.conv4x4_flat(ops.pad_affine(g, (0, 1, 0, 1), 0), ops.w4x4_pack(conv.weight, "conv_s2_adj"), None, raw,
+                    ops.conv4x4_wide(ops.pad_affine(g, (0, 1, 0, 1), 0), ops.w4x4_pack(conv.weight, "conv_s2_adj"), None, raw,
                                      stride=2, transposed=True)
                 ops.act_bwd(raw, prev, LRELU, tgt)
             else:

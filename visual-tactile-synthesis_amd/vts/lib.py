@@ -73,7 +73,7 @@ SYMBOLS = [
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
-    "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract", "vts_tap_embed_at", "vts_tap_extract_at", "vts_w3x3_pack", "vts_conv3x3_wide", "vts_conv3x3_wide_ws_floats", "vts_conv3x3s2_wide", "vts_tconv3x3s2_wide", "vts_wgrad3x3_wide", "vts_wgrad3x3_wide_ws_floats", "vts_upfirdn2d_out_size", "vts_upfirdn2d", "vts_upfirdn2d_bwd", "vts_bias_act", "vts_bias_act_bwd", "vts_modconv_demod", "vts_w4x4_pack", "vts_conv4x4_flat_ok", "vts_conv4x4_flat_ws_floats", "vts_conv4x4_flat",
+    "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract", "vts_tap_embed_at", "vts_tap_extract_at", "vts_w3x3_pack", "vts_conv3x3_wide", "vts_conv3x3_wide_ws_floats", "vts_conv3x3s2_wide", "vts_tconv3x3s2_wide", "vts_wgrad3x3_wide", "vts_wgrad3x3_wide_ws_floats", "vts_upfirdn2d_out_size", "vts_upfirdn2d", "vts_upfirdn2d_bwd", "vts_bias_act", "vts_bias_act_bwd", "vts_modconv_demod", "vts_w4x4_pack", "vts_conv4x4_flat_ok", "vts_conv4x4_wide_ws_floats", "vts_conv4x4_wide", "vts_wgrad4x4_wide_ws_floats", "vts_wgrad4x4_wide",
     "vts_metric_ws_floats", "vts_minmax", "vts_metric_psnr", "vts_metric_tactile",
     "vts_mask_select", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows",
 ]
@@ -95,8 +95,10 @@ def load():
     lib.vts_metric_ws_floats.restype = C.c_int64
     lib.vts_conv3x3_wide_ws_floats.argtypes = [C.c_int] * 5
     lib.vts_wgrad3x3_wide_ws_floats.argtypes = [C.c_int] * 6
-    lib.vts_conv4x4_flat_ws_floats.argtypes = [C.c_int] * 8
-    lib.vts_conv4x4_flat_ws_floats.restype = C.c_int64
+    lib.vts_conv4x4_wide_ws_floats.argtypes = [C.c_int] * 8
+    lib.vts_wgrad4x4_wide_ws_floats.argtypes = [C.c_int] * 6
+    lib.vts_wgrad4x4_wide_ws_floats.restype = C.c_int64
+    lib.vts_conv4x4_wide_ws_floats.restype = C.c_int64
     lib.vts_conv4x4_flat_ok.argtypes = [C.c_int] * 5
     lib.vts_upfirdn2d_out_size.argtypes = [C.c_int] * 6
     lib.vts_upfirdn2d_out_size.restype = C.c_int
@@ -148,12 +150,13 @@ def load():
         "vts_tap_extract_at": [vp, i64, i, i, i, vp, i, vp],
         "vts_w3x3_pack": [vp, i, i, i64, i64, i, vp, vp],
         "vts_w4x4_pack": [vp, i, i, i64, i64, i, vp, vp],
+        "vts_wgrad4x4_wide": [vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, i64, vp],
         "vts_upfirdn2d": [vp, i64, i, i, vp, i, i, i, i, i, i, i, i, vp, i, vp],
         "vts_upfirdn2d_bwd": [vp, i64, i, i, vp, i, i, i, i, i, i, i, i, vp, i, vp],
         "vts_bias_act": [vp, vp, vp, i, i, i64, f, f, vp, vp],
         "vts_bias_act_bwd": [vp, vp, vp, i, i, i64, f, f, vp, vp],
         "vts_modconv_demod": [vp, vp, i, i, i, i, f, f, vp, vp],
-        "vts_conv4x4_flat": [vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, i64, vp],
+        "vts_conv4x4_wide": [vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, i64, vp],
         "vts_conv3x3s2_wide": [vp, vp, vp, vp, i, i, i, i, i, vp, i64, vp],
         "vts_tconv3x3s2_wide": [vp, vp, vp, vp, i, i, i, i, i, vp, i64, vp],
         "vts_conv3x3_wide": [vp, vp, vp, vp, i, i, i, i, i, vp, i64, vp],

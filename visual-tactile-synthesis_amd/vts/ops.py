@@ -13,10 +13,11 @@ from . import lib as L
 class Act:
     """Raw NCHW tensor + optional per-(n,c) affine (normalise-on-load) + saved mean/rstd."""
 
-    __slots__ = ("data", "scale", "shift", "mean", "rstd")
+    __slots__ = ("data", "scale", "shift", "mean", "rstd", "padded")
 
     def __init__(self, data, scale=None, shift=None, mean=None, rstd=None):
         self.data, self.scale, self.shift, self.mean, self.rstd = data, scale, shift, mean, rstd
+        self.padded = None   # the materialised activate(normalise(data)) with zero padding, when a GEMM-class consumer made one
 
     @property
     def shape(self):
@@ -421,23 +422,38 @@ def conv4x4_flat_ok(oh, ow, ph, pw, transposed=False):
     return bool(L.load().vts_conv4x4_flat_ok(oh, ow, ph, pw, int(transposed)))
 
 
-def conv4x4_flat(p, wt, bias, out, stride=1, transposed=False):
+def conv4x4_wide(p, wt, bias, out, stride=1, transposed=False):
     """4x4 conv of the pre-padded p [N,Ci,PH,PW] with 16-tap packed weights on the flattened small-map kernel; transposed:
     p is the output gradient of a Conv2d(4, s2, p2) with a zero row / column appended, out its input gradient"""
     n, ci, ph, pw = p.shape
     co, oh, ow = out.shape[1:]
     assert out.shape[0] == n and p.is_contiguous() and out.is_contiguous()
     lib = L.load()
-    need = lib.vts_conv4x4_flat_ws_floats(n, ci, co, oh, ow, ph, pw, int(transposed))
+    need = lib.vts_conv4x4_wide_ws_floats(n, ci, co, oh, ow, ph, pw, int(transposed))
     ws = workspace(need, p.device) if need else None
     taps = 4 if transposed else 16
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d s%d%s" % (n, ci, ph, pw, co, oh, ow, stride, " transposed" if transposed else "")
-    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * oh * ow * co * ci * taps, lib.vts_conv4x4_flat,
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * oh * ow * co * ci * taps, lib.vts_conv4x4_wide,
          p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, ph, pw, oh, ow, stride, int(transposed), L.ptr(ws),
          ws.numel() if ws is not None else 0, L.stream())
     return out
+
+
+def wgrad4x4_wide(dout, p, dw, stride=1, accumulate=False):
+    """dw[a][b][4][4] (+)= sum dout[n,a,y,x] * p[n,b,stride*y+ky,stride*x+kx]; p pre-padded (GEMM-class kernel, full-size maps)"""
+    n, co, h, w = dout.shape
+    ci, ph, pw = p.shape[1:]
+    assert dw.shape == (co, ci, 4, 4) and dout.is_contiguous() and p.is_contiguous()
+    lib = L.load()
+    ws = workspace(lib.vts_wgrad4x4_wide_ws_floats(n, ci, co, h, w, stride), p.device)
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d dout %dx%dx%d in %dx%dx%d s%d" % (n, co, h, w, ci, ph, pw, stride)
+    _run("wgrad3x3_wide", 4.0 * (dout.numel() + p.numel() + dw.numel()), 2.0 * n * h * w * co * ci * 16, lib.vts_wgrad4x4_wide,
+         dout.data_ptr(), p.data_ptr(), dw.data_ptr(), n, ci, co, h, w, ph, pw, stride, int(accumulate), ws.data_ptr(), ws.numel(), L.stream())
+    return dw
 
 
 def pad_affine(x, pads, mode, out=None, act=0, res=None, out_nstride=0):
