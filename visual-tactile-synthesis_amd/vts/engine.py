@@ -656,12 +656,12 @@ def _flat4(conv, j, h, w, oh, ow, st):
     """whether this PatchGAN layer takes the GEMM-class route with 16-tap packed weights (vts_conv4x4_wide: flattened-batch kernel
     for maps of <= 128 pixels, tiled kernel above): wide layers only; Cout = 1 heads only on small maps"""
     co, ci = conv.weight.shape[0], conv.weight.shape[1]
-    if not FLAT_D or j == 0 or ci < 32:
+    if not FLAT_D or j == 0 or ci < 64:      # the reference's own ndf = 8 discriminators (<= 64 channels) stay on the 4x4 kernels
         return False
     small = ops.conv4x4_flat_ok(oh, ow, st * (oh - 1) + 4, st * (ow - 1) + 4)
     if small:
-        return co >= 32 or ci >= 256
-    return co >= 64 and co % 4 == 0 and ci % 4 == 0
+        return co >= 64 or ci >= 256
+    return co >= 128 and co % 4 == 0 and ci % 4 == 0
 
 
 def _msd_scale_forward(D, s, a0, a1, update_stats):
