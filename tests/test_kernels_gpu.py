@@ -105,6 +105,14 @@ CONVT_CASES = [
     (40, 8, 0, 7, 17, 17, 2, 2, 0, 0),
     (8, 80, 80, 80, 2, 2, 2, 1, 2, 0),
     (8, 10, 0, 3, 16, 16, 2, 1, 2, 1),
+    # thin full-size path (Cout <= 16, output >= 128 x 128): direct packed-FMA kernel
+    (1, 10, 10, 3, 70, 90, 2, 1, 2, 1),
+    (2, 16, 0, 8, 65, 65, 2, 2, 0, 0),
+    (1, 10, 0, 10, 64, 72, 2, 1, 2, 0),
+    (1, 5, 3, 16, 64, 64, 2, 1, 1, 0),
+    (1, 8, 0, 2, 129, 67, 2, 1, 0, 0),
+    (2, 5, 0, 13, 80, 66, 2, 2, 1, 0),
+    (1, 40, 0, 10, 64, 72, 2, 1, 2, 0),      # same geometry, too many channels for it: MFMA kernel
 ]
 
 
@@ -143,14 +151,15 @@ def test_conv_transposed_forward(case):
     assert rel(out, ref) < 1e-5
 
 
-def test_conv_transposed_odd_output_and_dmask_accumulate():
+@pytest.mark.parametrize("H", [34, 130, 257])
+def test_conv_transposed_odd_output_and_dmask_accumulate(H):
     """backward-data of Conv2d(4->8, s2, p2) at H=34: output 34 from input 18, channel sub-range,
-    derivative mask and accumulation -- the G-step path into fake_I."""
+    derivative mask and accumulation -- the G-step path into fake_I (H >= 128: the thin full-size kernel)."""
     from vts import ops
     from vts.ops import Act
 
     dev = _dev()
-    N, Cin, Cout, H = 2, 4, 8, 34
+    N, Cin, Cout = 2, 4, 8
     x = detrand.uniform((N, Cin, H, H), 5, "x").requires_grad_(True)
     w = detrand.uniform((Cout, Cin, 4, 4), 5, "w") * 0.3
     y = F.conv2d(F.leaky_relu(x, 0.2), w, None, stride=2, padding=2)

@@ -15,6 +15,8 @@ void vts_set_kernel(const char* fmt, ...);
 const float* vts_ident();
 // small-map (flattened-batch) path of vts_conv4x4; VTS_ERR_UNSUPPORTED means "use the tiled kernel"
 int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st);
+// thin (Cout <= 16) stride-2 transposed layers on full-size maps: direct packed-FMA kernel; VTS_ERR_UNSUPPORTED otherwise
+int vts_conv_thin_try(const vts_conv_desc* d, hipStream_t st);
 // LeakyReLU slope that expresses the activation codes as  t > 0 ? t : slope * t
 static inline float vts_slope(int act) { return act == VTS_ACT_LRELU ? 0.2f : (act == VTS_ACT_RELU ? 0.f : 1.f); }
 
