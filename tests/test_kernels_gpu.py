@@ -57,6 +57,12 @@ CONV_CASES = [
     (20, 32, 0, 64, 2, 2, 1, 2, 1),
     (10, 3, 4, 8, 16, 12, 2, 2, 0),
     (64, 80, 0, 80, 4, 4, 2, 1, 1),
+    # thin full-size path (stride 2, Cin x Cout <= 128, output >= 128 x 128): direct packed-FMA kernel
+    (2, 1, 3, 8, 256, 256, 2, 2, 0),
+    (1, 9, 0, 10, 300, 260, 2, 1, 0),
+    (1, 8, 0, 16, 257, 259, 2, 2, 1),
+    (1, 3, 0, 2, 301, 277, 2, 1, 2),
+    (1, 5, 2, 13, 270, 256, 2, 2, 1),
 ]
 
 

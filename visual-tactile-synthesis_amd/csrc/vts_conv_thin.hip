@@ -152,7 +152,10 @@ int thin_launch(const ThinK& k, int N, hipStream_t st) {
 
 }  // namespace
 
-// VTS_ERR_UNSUPPORTED: not a thin full-size stride-2 transposed case, use the MFMA kernels
+// VTS_ERR_UNSUPPORTED: not a thin full-size stride-2 transposed case, use the MFMA kernels.
+// (A forward stride-2 member of the same design -- one output pixel, or a 2 x 2 block, per thread with a 4 x 4 / 6 x 6 window -- was
+// measured and dropped: 54 us vs 58 us for 4 -> 8 @513^2 at best, 2x slower with the blocked window at 2-3 waves per SIMD; its 16
+// stride-2 loads and activations per output leave it instruction-bound like the MFMA kernel.)
 int vts_conv_thin_try(const vts_conv_desc* d, hipStream_t st) {
   static const int enabled = getenv("VTS_NO_THIN") ? 0 : 1;
   const int Cin = d->in0.C + (d->in1.data ? d->in1.C : 0);
