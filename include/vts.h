@@ -296,6 +296,11 @@ int vts_minmax(const float* x, int64_t n, float* out2, float* ws, void* stream);
 int vts_metric_psnr(const float* real, const float* fake, int64_t n, const float* range2, float* out, float* ws, void* stream);
 int vts_metric_tactile(const float* real_T, const float* fake_T, int64_t P, int HW, float* out_ae, float* out_mse, float* ws,
                        void* stream);
+/* I_SSIM (:498-499: torchmetrics.functional.structural_similarity_index_measure(real_I, fake_I, data_range=1), an un-pinned pip
+ * dependency absent from this image: its published algorithm is restated -- 11 x 11 Gaussian window (sigma 1.5), k1 0.01, k2 0.03,
+ * reflect padding by 5 cropped again = mean of the SSIM map over the (H-10) x (W-10) positions whose window lies inside the image,
+ * variances clamped at 0) on the same {lo, hi}-normalised images as vts_metric_psnr; real / fake are [NC, H, W]. */
+int vts_metric_ssim(const float* real, const float* fake, int NC, int H, int W, const float* range2, float* out, float* ws, void* stream);
 
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */

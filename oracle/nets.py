@@ -69,7 +69,32 @@ def eval_metrics(real_I, fake_I, real_T, fake_T):
     psnr = 10.0 * torch.log10(1.0 / torch.mean((r - f) ** 2))
     fT = torch.clamp(fake_T, 0, 1)
     cos = torch.clamp(torch.cosine_similarity(compute_normal(fT, 1), compute_normal(real_T, 1), dim=1, eps=1e-6), -1.0, 1.0)
-    return {"I_PSNR": float(psnr), "T_AE": float((torch.acos(cos) * 180.0 / np.pi).mean()), "T_MSE": float(torch.mean((real_T - fT) ** 2))}
+    out = {"I_PSNR": float(psnr), "T_AE": float((torch.acos(cos) * 180.0 / np.pi).mean()), "T_MSE": float(torch.mean((real_T - fT) ** 2))}
+    if min(real_I.shape[2:]) >= 11:
+        out["I_SSIM"] = float(ssim(r, f))
+    return out
+
+
+def ssim(target, preds, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
+    """I_SSIM (models/model_utils.py:498-499) = torchmetrics.functional.structural_similarity_index_measure(data_range=1).
+    torchmetrics is an un-pinned pip dependency of the reference (requirements.txt:18) that is absent from this image, so this is a
+    restatement of its published algorithm (torchmetrics/functional/image/ssim.py, _ssim_update: Gaussian window from
+    exp(-(d / sigma)^2 / 2) normalised to sum 1, reflect padding by (k-1)/2, five grouped-convolution moments, variances clamped at
+    0, the padded border cropped, per-image mean then batch mean) -- PARITY UNPINNED for this one metric (no reference run possible)."""
+    n, c, h, w = preds.shape
+    pad = (kernel_size - 1) // 2
+    d = torch.arange((1 - kernel_size) / 2, (1 + kernel_size) / 2, 1.0, dtype=preds.dtype)
+    g = torch.exp(-((d / sigma) ** 2) / 2)
+    g = (g / g.sum()).unsqueeze(0)
+    kernel = (g.t() @ g).expand(c, 1, kernel_size, kernel_size)
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    p = F.pad(preds, (pad, pad, pad, pad), mode="reflect")
+    t = F.pad(target, (pad, pad, pad, pad), mode="reflect")
+    outs = F.conv2d(torch.cat((p, t, p * p, t * t, p * t)), kernel, groups=c).split(n)
+    mu_p2, mu_t2, mu_pt = outs[0] ** 2, outs[1] ** 2, outs[0] * outs[1]
+    s_p, s_t, s_pt = torch.clamp(outs[2] - mu_p2, min=0.0), torch.clamp(outs[3] - mu_t2, min=0.0), outs[4] - mu_pt
+    full = ((2 * mu_pt + c1) * (2 * s_pt + c2)) / ((mu_p2 + mu_t2 + c1) * (s_p + s_t + c2))
+    return full[..., pad:-pad, pad:-pad].reshape(n, -1).mean(-1).mean()
 
 
 # ----------------------------------------------------------------------------

@@ -305,8 +305,11 @@ def test_eval_metrics_match_oracle():
     real_T, fake_T = 0.3 * detrand.uniform((9, 2, 32, 32), 8, "rT"), 0.6 * detrand.uniform((9, 2, 32, 32), 8, "fT")
     got = ops.eval_metrics(real_I.to(dev), fake_I.to(dev), real_T.to(dev), fake_T.to(dev)).cpu().tolist()
     ref = nets.eval_metrics(real_I, fake_I, real_T, fake_T)
-    for v, k in zip(got, ("I_PSNR", "T_AE", "T_MSE")):
+    for v, k in zip(got, ("I_PSNR", "T_AE", "T_MSE", "I_SSIM")):
         assert abs(v - ref[k]) <= 1e-4 * max(1.0, abs(ref[k])), (k, v, ref[k])
+    # SSIM sanity that does not depend on the restatement: identical images give exactly 1, and it is symmetric in its arguments
+    same = ops.eval_metrics(real_I.to(dev), real_I.to(dev), real_T.to(dev), fake_T.to(dev)).cpu().tolist()
+    assert abs(same[3] - 1.0) < 1e-6
     model, opt = make_model(256, 1)
     sdG, _, _ = load_test_weights(model, 13)
     batch = default_collate([make_sample(256, 16, 24, 13)])
@@ -320,6 +323,6 @@ def test_eval_metrics_match_oracle():
     inp = step.prepare_input(batch)
     real_T_val = batch["val_T_images"][0].float() * batch["val_I_masks"][0].float()[:, None]
     ref = nets.eval_metrics(inp.real_I, fi, real_T_val, fake_T_concat)
-    for k in ("I_PSNR", "T_AE", "T_MSE"):
+    for k in ("I_PSNR", "T_AE", "T_MSE", "I_SSIM"):
         assert abs(m[k] - ref[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, m[k], ref[k])
-    assert set(model.get_current_metrics().keys()) == {"m_I_PSNR", "m_T_AE", "m_T_MSE"}
+    assert set(model.get_current_metrics().keys()) == {"m_I_PSNR", "m_T_AE", "m_T_MSE", "m_I_SSIM"}

@@ -95,6 +95,55 @@ __global__ __launch_bounds__(64) void metric_final_kernel(const float* __restric
   if (threadIdx.x == 0) out[0] = mode == 1 ? 10.f * log10f(1.f / (s * scale)) : s * scale;
 }
 
+// I_SSIM (:498-499): torchmetrics' structural_similarity_index_measure(data_range = 1) defaults -- 11 x 11 Gaussian window
+// (sigma 1.5), k1 = 0.01, k2 = 0.03, reflect padding by 5 and the padded border cropped again, i.e. the mean of the SSIM map over the
+// positions whose window lies inside the image -- on the same normalised images as the PSNR.  One output position per thread,
+// 16 x 16 positions per tile from a 26 x 26 LDS tile of both images, workgroups walk the tiles (fixed order: deterministic).
+struct SsimK {
+  const float *a, *b, *range;
+  int NC, H, W;
+  float g[11], c1, c2;
+  float* part;
+};
+
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const SsimK p) {
+  __shared__ float ta[26][27], tb[26][27];
+  __shared__ float red[16];
+  const float lo = p.range[0], inv = 1.f / (p.range[1] - p.range[0]);
+  const int VH = p.H - 10, VW = p.W - 10;
+  const int tiles_x = (VW + 15) / 16, tiles_y = (VH + 15) / 16;
+  const int64_t ntiles = (int64_t)p.NC * tiles_y * tiles_x;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc = 0.f;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t nc = t / (tiles_y * tiles_x);
+    const int r = (int)(t - nc * tiles_y * tiles_x), y0 = (r / tiles_x) * 16, x0 = (r % tiles_x) * 16;
+    const float* pa = p.a + nc * p.H * p.W;
+    const float* pb = p.b + nc * p.H * p.W;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 26 * 26; e += 256) {
+      const int yy = e / 26, xx = e - yy * 26;
+      const int y = min(y0 + yy, p.H - 1), x = min(x0 + xx, p.W - 1);
+      ta[yy][xx] = (pa[(int64_t)y * p.W + x] - lo) * inv;
+      tb[yy][xx] = fminf(fmaxf((pb[(int64_t)y * p.W + x] - lo) * inv, 0.f), 1.f);
+    }
+    __syncthreads();
+    float ma = 0.f, mb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+    for (int dy = 0; dy < 11; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 11; ++dx) {
+        const float w = p.g[dy] * p.g[dx], va = ta[ty + dy][tx + dx], vb = tb[ty + dy][tx + dx];
+        ma += w * va; mb += w * vb; saa += w * va * va; sbb += w * vb * vb; sab += w * va * vb;
+      }
+    if (y0 + ty < VH && x0 + tx < VW) {
+      const float va = fmaxf(saa - ma * ma, 0.f), vb = fmaxf(sbb - mb * mb, 0.f), cab = sab - ma * mb;
+      acc += ((2.f * ma * mb + p.c1) * (2.f * cab + p.c2)) / ((ma * ma + mb * mb + p.c1) * (va + vb + p.c2));
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) p.part[blockIdx.x] = acc;
+}
+
 inline int nblocks(int64_t n) {
   const int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > MB ? MB : b));
@@ -132,5 +181,21 @@ extern "C" int vts_metric_tactile(const float* real_T, const float* fake_T, int6
   hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(nb2), dim3(256), 0, (hipStream_t)stream, real_T, fake_T, 2 * n, 1, (const float*)nullptr, ws + MB);
   hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws + MB, nb2, 1.f / (float)(2 * n), 0, out_mse);
   VTS_CHECK_LAUNCH("vts_metric_tactile");
+  return VTS_OK;
+}
+
+extern "C" int vts_metric_ssim(const float* real, const float* fake, int NC, int H, int W, const float* range2, float* out, float* ws, void* stream) {
+  VTS_CHECK_ARG(real && fake && range2 && out && ws && NC >= 1 && H >= 11 && W >= 11, "vts_metric_ssim: bad args (the 11 x 11 window needs H, W >= 11)");
+  SsimK k;
+  k.a = real; k.b = fake; k.range = range2; k.NC = NC; k.H = H; k.W = W; k.part = ws;
+  float sum = 0.f;
+  for (int i = 0; i < 11; ++i) { const float d = (float)(i - 5) / 1.5f; k.g[i] = expf(-0.5f * d * d); sum += k.g[i]; }
+  for (int i = 0; i < 11; ++i) k.g[i] /= sum;
+  k.c1 = 0.01f * 0.01f; k.c2 = 0.03f * 0.03f;
+  const int64_t ntiles = (int64_t)NC * ((H - 10 + 15) / 16) * ((W - 10 + 15) / 16);
+  const int nb = (int)(ntiles < MB ? ntiles : MB);
+  hipLaunchKernelGGL(ssim_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, k);
+  hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, 1.f / ((float)NC * (float)(H - 10) * (float)(W - 10)), 0, out);
+  VTS_CHECK_LAUNCH("vts_metric_ssim");
   return VTS_OK;
 }

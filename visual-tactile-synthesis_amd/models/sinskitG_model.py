@@ -560,13 +560,13 @@ class SinSKITGModel(BaseModel):
             self._g_ctx = None if not use_graph else self._g_ctx
 
     # ------------------------------------------------------------------ evaluation metrics
-    METRICS = ("I_PSNR", "T_AE", "T_MSE")
+    METRICS = ("I_PSNR", "T_AE", "T_MSE", "I_SSIM")
 
     def compute_metrics(self, prefix=""):
         """The evaluation metrics that need no pretrained network (reference: compute_evaluation_metric,
         models/model_utils.py:431-561, called from compute_visuals sinskitG_model.py:889-925) for the current outputs:
-        I_PSNR, T_AE, T_MSE on the validation patches (the training patches with prefix 'train_').  I_SIFID / *_LPIPS /
-        I_SSIM / T_SIFID need Inception / VGG / AlexNet weights or torchmetrics and are not built."""
+        I_PSNR, I_SSIM, T_AE, T_MSE on the validation patches (the training patches with prefix 'train_').  I_SIFID / *_LPIPS /
+        T_SIFID need Inception / VGG / AlexNet weights and are not built."""
         pset = self.train_set if prefix == "train_" else self.val_set
         if pset is None or not hasattr(self, "real_I") or self.test_edit_S:
             return {}

@@ -676,10 +676,11 @@ def mask_select(cand, prefix, ranks, h, w):
 
 
 def eval_metrics(real_I, fake_I, real_T, fake_T):
-    """device tensor [I_PSNR, T_AE, T_MSE] (model_utils.py:431-561; the metrics that need no pretrained network)"""
+    """device tensor [I_PSNR, T_AE, T_MSE, I_SSIM] (model_utils.py:431-561; the metrics that need no pretrained network; I_SSIM is
+    NaN for images smaller than its 11 x 11 window)"""
     lib = L.load()
     ws = workspace(lib.vts_metric_ws_floats(), real_I.device)
-    out = torch.empty(5, dtype=torch.float32, device=real_I.device)   # [lo, hi, psnr, ae, mse]
+    out = torch.full((6,), float("nan"), dtype=torch.float32, device=real_I.device)   # [lo, hi, psnr, ae, mse, ssim]
     st = L.stream()
     L.check(lib.vts_minmax(real_I.data_ptr(), real_I.numel(), out.data_ptr(), ws.data_ptr(), st), "vts_minmax")
     L.check(lib.vts_metric_psnr(real_I.data_ptr(), fake_I.data_ptr(), real_I.numel(), out.data_ptr(), out[2:].data_ptr(), ws.data_ptr(), st),
@@ -687,6 +688,11 @@ def eval_metrics(real_I, fake_I, real_T, fake_T):
     p, _, h, w = real_T.shape
     L.check(lib.vts_metric_tactile(real_T.data_ptr(), fake_T.data_ptr(), p, h * w, out[3:].data_ptr(), out[4:].data_ptr(), ws.data_ptr(), st),
             "vts_metric_tactile")
+    n, c, ih, iw = real_I.shape
+    if ih >= 11 and iw >= 11:
+        assert real_I.is_contiguous() and fake_I.is_contiguous()
+        L.check(lib.vts_metric_ssim(real_I.data_ptr(), fake_I.data_ptr(), n * c, ih, iw, out.data_ptr(), out[5:].data_ptr(), ws.data_ptr(), st),
+                "vts_metric_ssim")
     return out[2:]
 
 
