@@ -27,6 +27,7 @@ CASES = [
     ("sinskitG G-only-D1", "--model sinskitG --crop_size 256 --batch_size 1 --lambda_G2_GAN 0", 256, 1),
     ("sinskitG separate0", "--model sinskitG --crop_size 256 --batch_size 1 --num_layer_separate 0", 256, 1),
     ("sinskitG resnet6", "--model sinskitG --crop_size 256 --batch_size 2 --netG resnet_6blocks", 256, 2),
+    ("sinskitG netD stylegan2", "--model sinskitG --crop_size 256 --load_size 256 --batch_size 2 --netD stylegan2", 256, 2),
     ("sinskitG 200 steps + lr decay", "--model sinskitG --crop_size 256 --batch_size 1", 256, 1),
 ]
 

@@ -43,13 +43,15 @@ struct WideK {
   float* part;   // [KS][N][Cout][OH][OW] raw partial sums (KS > 1), reduced in slice order by wide_reduce_kernel
 };
 
-// K: kernel extent (3 | 4: taps of the packed weight = K * K), CKT: input channels per chunk
-template <int S, int K, int CKT>
+// K: kernel extent (3 | 4: taps of the packed weight = K * K), CKT: input channels per chunk, LIVE: most taps one launch uses
+// (K * K, or 4 for the parity phases of the transposed stride-2 layers, which then stage 16 channels per chunk: with 1-4 taps
+// a chunk of 4-8 channels is too few MFMAs per barrier)
+template <int S, int K, int CKT, int LIVE = K * K>
 __device__ __forceinline__ void wide_body(const WideK& p) {
   constexpr int CK = CKT, TWT = K * K;
   constexpr int PR = S * (TY - 1) + K, PC = S * (TX - 1) + K, PCP = (PC + 3) / 4 * 4;
   constexpr int PATCH_FLOATS = CK * PR * PCP;
-  constexpr int W_FLOATS = CK * TWT * TCO;
+  constexpr int W_FLOATS = CK * LIVE * TCO;
   constexpr int PQ_ROW = PCP / 4;
   constexpr int NPQ = (CK * PR * PQ_ROW + 255) / 256;
   constexpr int NWQ = W_FLOATS / 4 / 256;               // 9 (8 for K = 4) weight quads per thread (fewer taps: fewer are live)
@@ -172,6 +174,10 @@ __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) { wide
 // weights, 4 input channels per chunk (32 KB of weights + a 7 x 36 / 10 x 68 patch per channel in LDS)
 template <int S>
 __global__ __launch_bounds__(256) void conv4x4_wide_kernel(const WideK p) { wide_body<S, 4, 4>(p); }
+
+// parity-phase launches (<= 4 taps, stride 1 on the input) of the transposed stride-2 layers
+template <int K>
+__global__ __launch_bounds__(256) void conv_wide_phase_kernel(const WideK p) { wide_body<1, K, 16, 4>(p); }
 
 __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int KS,
                                                            int64_t per_slice, int HW, int Cout, float* __restrict__ out) {
@@ -484,7 +490,12 @@ static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_
   if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; cps = cdiv(k.Cin, ck); }
   k.KS = KS; k.cps = cps; k.part = KS > 1 ? ws : nullptr;
   const dim3 grid(cdiv(k.W, TX) * cdiv(k.H, TY), cdiv(k.Cout, TCO), k.N * KS);
-  if (K == 4) {
+  if (k.os == 2 && k.ntaps <= 4 && S == 1 && KS == 1) {
+    k.cps = cdiv(k.Cin, 16);
+    if (K == 4) hipLaunchKernelGGL(conv_wide_phase_kernel<4>, grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(conv_wide_phase_kernel<3>, grid, dim3(256), 0, st, k);
+    vts_set_kernel("conv_wide_phase_kernel<%d>", K);
+  } else if (K == 4) {
     if (S == 1) hipLaunchKernelGGL(conv4x4_wide_kernel<1>, grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL(conv4x4_wide_kernel<2>, grid, dim3(256), 0, st, k);
     vts_set_kernel(KS > 1 ? "conv4x4_wide_kernel<%d>+ksplit" : "conv4x4_wide_kernel<%d>", S);
