@@ -1,6 +1,6 @@
 # end-of-round measurement pass (run through gpurun): headline bench + rocprof kernel stats, pix2pixHD patch / full-size benches
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r1j; rm -rf $O; mkdir -p $O
+O=gpurun_out/prof_r1k; rm -rf $O; mkdir -p $O
 python bench.py --detail $O/detail.txt > $O/bench.json 2>$O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python bench.py --steps 10 --warmup 3 --no_cpu_baseline > $O/stats.log 2>&1
 python bench.py --model pix2pixHD --batch 32 --no_cpu_baseline --detail $O/p2p_patch_detail.txt > $O/p2p_patch_bench.json 2>$O/p2p_patch.err
