@@ -174,6 +174,7 @@ def infer_bench(args):
     batch_n = 16 if args.batch == 4 else args.batch
     model, opt = build_model(args.size, batch_n, args.model)
     opt.use_hip_graph = not args.no_graph
+    opt.skip_D2_visualisation_pass = bool(args.no_viz)
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
     model.eval()
     model.set_input(make_batch(args.size, batch_n, 0, style_dim), phase="test")
@@ -221,6 +222,9 @@ def main():
     ap.add_argument("--p2p_size", type=int, default=32, help="pix2pixHD only: side of the (square) training images / patches")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no_viz", action="store_true",
+                    help="leave out the reference step's full-resolution D2 visualisation pass (2.85 GFLOP/image, no gradient): SURVEY 8d "
+                         "asks for the rate with and without it; the default (and the headline) includes it")
     ap.add_argument("--infer", action="store_true",
                     help="measure the inference forward instead (BASELINE config 4: generator only, 16 images/GPU): ms per image")
     ap.add_argument("--detail", type=str, default=None, help="write a per-(kernel, shape) timing table to this path")
@@ -237,6 +241,7 @@ def main():
         return infer_bench(args)
     model, opt = build_model(args.size, args.batch, args.model, netG=args.netG)
     opt.use_hip_graph = not args.no_graph
+    opt.skip_D2_visualisation_pass = bool(args.no_viz)
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
     # pix2pixHD: the reference trains it on 32x32 patches (default); --p2p_size S feeds S x S images instead (BASELINE config 3)
     batch = (make_patch_batch(args.batch, rank, args.p2p_size) if args.model == "pix2pixHD"
@@ -290,7 +295,7 @@ def main():
                             "LPIPS/CLIP terms off (no weights offline)" % (args.model, "" if args.netG == "unet256_custom" else " (netG %s)" % args.netG,
                                                                           args.size, args.size, args.batch),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world, "losses_finite": finite,
-                "hip_graph": bool(opt.use_hip_graph),
+                "hip_graph": bool(opt.use_hip_graph), "d2_visualisation_pass": not args.no_viz,
             },
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -424,10 +424,13 @@ class SinSKITGModel(BaseModel):
             lam2 = opt.lambda_G2_GAN
             passes = [dict(in0=self._fake_stack, real=False, coeff=lam2, slot=slot["D_fake_T_concat"], grad_coeff=0.5 * lam2)]
             # full-resolution pass: visualisation only, but it advances the BatchNorm running statistics
-            self._full_stack[:, 2:3].copy_(self.real_S)
-            self._full_stack[:, 6:7].copy_(self.M)
-            p_full = dict(in0=self._full_stack, loss=False)
-            passes.append(p_full)
+            # (opt.skip_D2_visualisation_pass is a measurement switch of bench.py --no_viz, not a reference option: SURVEY §8d asks
+            # for the step rate with and without this pass)
+            if not getattr(opt, "skip_D2_visualisation_pass", False):
+                self._full_stack[:, 2:3].copy_(self.real_S)
+                self._full_stack[:, 6:7].copy_(self.M)
+                p_full = dict(in0=self._full_stack, loss=False)
+                passes.append(p_full)
             if opt.use_more_fakeT:
                 k = opt.add_fake_T_sample_size
                 h, w = self.real_S.shape[2:]
