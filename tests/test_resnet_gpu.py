@@ -320,7 +320,11 @@ def test_resnet_generator_strided_variants_wide():
 FLAT_SHAPES = [(32, 64, 128, 2, 2), (5, 132, 68, 4, 4), (7, 40, 64, 3, 5), (3, 72, 136, 8, 8), (2, 36, 132, 9, 11), (33, 256, 128, 1, 1)]
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 20, 132, 9, 37), (1, 256, 256, 8, 64), (1, 8, 4, 5, 5)] + FLAT_SHAPES)
+# widths just above a multiple of 32 (64 .. 94): the row-run kernel (runs of 128 flattened pixels)
+ROWRUN_SHAPES = [(2, 64, 128, 66, 66), (1, 72, 132, 19, 70), (3, 16, 8, 5, 65), (1, 128, 64, 130, 66), (2, 8, 4, 33, 94), (1, 64, 64, 66, 130), (1, 16, 8, 7, 134), (2, 8, 8, 9, 106)]
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 20, 132, 9, 37), (1, 256, 256, 8, 64), (1, 8, 4, 5, 5)] + FLAT_SHAPES + ROWRUN_SHAPES)
 def test_conv3x3_wide_forward_and_input_adjoint(shape):
     """GEMM-class 3x3 kernel vs F.conv2d on the padded input; the adjoint through the flipped / transposed packing"""
     from vts import ops

@@ -81,6 +81,9 @@ if __name__ == "__main__":
         a = [int(v) for v in os.environ["VTS_MB"][4:].split(",")]
         conv_case(a[0], a[1], a[2], a[3], a[4], a[5], a[6], bool(a[7]))
         sys.exit(0)
+    if os.environ.get("VTS_MB", "").startswith("wideone:"):     # VTS_MB=wideone:N,C,H,W  (with VTS_WIDE_KS=k to force the k-split)
+        wide_case(*[int(v) for v in os.environ["VTS_MB"].split(":")[1].split(",")])
+        sys.exit(0)
     if os.environ.get("VTS_MB") == "wide":
         wide_case(1, 1024, 64, 128)
         wide_case(1, 1024, 16, 32)

@@ -179,6 +179,143 @@ __global__ __launch_bounds__(256) void conv4x4_wide_kernel(const WideK p) { wide
 template <int K>
 __global__ __launch_bounds__(256) void conv_wide_phase_kernel(const WideK p) { wide_body<1, K, 16, 4>(p); }
 
+// ---- row-run variant of the 3 x 3 stride-1 kernel ---------------------------------------------------------------------
+// A 4 x 32 pixel tile wastes a third of its columns on maps whose width is just above a multiple of 32 -- exactly the shape of the
+// input adjoint of a reflection-padded ResnetBlock (reference models/networks.py:1267-1324: 64 x 64 features, 66 x 66 padded
+// gradient).  Here the pixel dimension of the GEMM is a RUN of 128 consecutive pixels of the flattened image (35 instead of 51 tiles
+// per 66 x 66 image); the staged operand is the <= 5 full-width rows the run touches, a lane finds its two pixels through plane
+// offsets.  The staged rows (worst case 127 / W + 4 per channel) must fit the patch buffer: widths 64 .. 94.  (A 4352-float patch
+// would admit 128 .. 134 wide maps -- the 66 x 130 gradient of a 2048 x 1024 image -- but 54,272 B of LDS no longer lets three
+// workgroups share a CU: measured 2090 us against 1922 us for the tiled kernel.)
+constexpr int RR_PATCH_FLOATS = 3840;
+static inline int rr_rows(int W) { return 127 / W + 4; }
+
+__global__ __launch_bounds__(256) void conv3x3_rowrun_kernel(const WideK p) {
+  constexpr int PATCH_FLOATS = RR_PATCH_FLOATS;
+  constexpr int W_FLOATS = CK * 9 * TCO;
+  constexpr int NPQ = (PATCH_FLOATS / 4 + 255) / 256;
+  constexpr int NWQ = W_FLOATS / 4 / 256;
+  __shared__ __attribute__((aligned(16))) float lds[PATCH_FLOATS + W_FLOATS];
+  float* lds_p = lds;
+  float* lds_w = lds + PATCH_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave & 1, wpx = wave >> 1;
+  const int HW = p.H * p.W;
+  const int g0 = blockIdx.x * 128, co0 = blockIdx.y * TCO, n = blockIdx.z % p.N, ks = blockIdx.z / p.N;
+  const int PW = p.IPW, plane = p.IPH * p.IPW;
+  const int PCP = (PW + 3) & ~3, PQ = PCP >> 2;
+  const int ymin = g0 / p.W, ymax = min(g0 + 127, HW - 1) / p.W;
+  const int nr = ymax - ymin + 3;                        // rows of the padded input this run touches
+  const int nrm = 127 / p.W + 4;                         // rows allocated per channel (worst case)
+  const int TQ = CK * nr * PQ;
+  const int ntaps = p.ntaps;
+
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * 9 * p.Cout * 4, RSRC_FLAGS);
+
+  int pvoff[NPQ], ploff[NPQ];
+#pragma unroll
+  for (int e = 0; e < NPQ; ++e) {
+    const int q = min(tid + e * 256, TQ - 1);
+    const int row = q / PQ, cq = q - row * PQ;            // row = ci * nr + r
+    const int ci = row / nr, r = row - ci * nr;
+    pvoff[e] = (ci * plane + (ymin + r) * PW + 4 * cq) * 4;
+    ploff[e] = (ci * nrm + r) * PCP + 4 * cq;
+  }
+  int wvoff[NWQ], wloff[NWQ];
+#pragma unroll
+  for (int e = 0; e < NWQ; ++e) {
+    const int q = tid + e * 256;
+    const int row = q >> 5, cq = q & 31;                    // row = ci * ntaps + t
+    const int ci = row / ntaps, t = row - ci * ntaps;
+    const bool live = row < CK * ntaps;
+    wvoff[e] = live ? ((ci * 9 + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;
+    wloff[e] = (live ? row : 0) * TCO + 4 * cq;
+  }
+  u32x4 pq[NPQ], wq[NWQ];
+  auto load_chunk = [&](int c0) {
+    const int pbase = c0 * plane * 4, wbase = c0 * 9 * p.Cout * 4;
+#pragma unroll
+    for (int e = 0; e < NPQ; ++e)
+      if (e * 256 < TQ) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pvoff[e] + pbase, 0, 0);
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e)
+      if (e * 8 < CK * ntaps) wq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[e] + wbase, 0, 0);
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < NPQ; ++e)
+      if (e * 256 < TQ) *reinterpret_cast<u32x4*>(lds_p + ploff[e]) = pq[e];
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e)
+      if (e * 8 < CK * ntaps && ((tid + e * 256) >> 5) < CK * ntaps) *reinterpret_cast<u32x4*>(lds_w + wloff[e]) = wq[e];
+  };
+
+  int poff[2], gpx[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int g = g0 + wpx * 64 + j * 32 + l32;
+    const int y = g / p.W, x = g - y * p.W;
+    gpx[j] = g < HW ? g : -1;
+    poff[j] = g < HW ? (y - ymin) * PCP + x : 0;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int chs = nrm * PCP;
+  const float* a_base = lds_w + kh * ntaps * TCO + wco * 64 + l32;
+  const float* b0_base = lds_p + kh * chs + poff[0];
+  const float* b1_base = lds_p + kh * chs + poff[1];
+
+  const int nchunks_all = (p.Cin + CK - 1) / CK;
+  const int cbeg = ks * p.cps, nchunks = min(nchunks_all, cbeg + p.cps);
+  load_chunk(cbeg * CK);
+  store_chunk();
+  __syncthreads();
+  for (int c = cbeg; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) load_chunk((c + 1) * CK);
+    for (int t = 0; t < ntaps; ++t) {
+      const int boff = p.dy[t] * PCP + p.dx[t];
+#pragma unroll
+      for (int kc = 0; kc < CK / 2; ++kc) {
+        const float a0 = a_base[(kc * 2 * ntaps + t) * TCO], a1 = a_base[(kc * 2 * ntaps + t) * TCO + 32];
+        const float b0 = b0_base[kc * 2 * chs + boff], b1 = b1_base[kc * 2 * chs + boff];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  float* ob = p.part ? p.part + ((int64_t)ks * p.N + n) * p.Cout * HW : p.out + (int64_t)n * p.Cout * HW;
+  const bool add_bias = p.bias && !p.part;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (gpx[j] < 0) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 64 + i * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+        if (co < p.Cout) ob[(int64_t)co * HW + gpx[j]] = acc[i][j][r] + (add_bias ? p.bias[co] : 0.f);
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int KS,
                                                            int64_t per_slice, int HW, int Cout, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -409,6 +546,8 @@ static int wide_plan(int N, int Cin, int Cout, int H, int W, int* cps, int ck = 
     if (KS > nchunks / 4) KS = nchunks / 4;
     if (KS < 1) KS = 1;
   }
+  static const int force = getenv("VTS_WIDE_KS") ? atoi(getenv("VTS_WIDE_KS")) : 0;   // measurement override
+  if (force > 0) KS = force < nchunks ? force : nchunks;
   *cps = cdiv(nchunks, KS);
   return cdiv(nchunks, *cps);
 }
@@ -489,8 +628,17 @@ static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_
   const int64_t per_slice = (int64_t)k.N * k.Cout * k.OH * k.OW;
   if (KS == 1 || !ws || ws_floats < KS * per_slice) { KS = 1; cps = cdiv(k.Cin, ck); }
   k.KS = KS; k.cps = cps; k.part = KS > 1 ? ws : nullptr;
-  const dim3 grid(cdiv(k.W, TX) * cdiv(k.H, TY), cdiv(k.Cout, TCO), k.N * KS);
-  if (k.os == 2 && k.ntaps <= 4 && S == 1 && KS == 1) {
+  dim3 grid(cdiv(k.W, TX) * cdiv(k.H, TY), cdiv(k.Cout, TCO), k.N * KS);
+  // maps whose 4 x 32 tiling wastes >= 10 %% more than runs of 128 flattened pixels (and whose rows fit the patch): the row-run kernel
+  static const int no_rowrun = getenv("VTS_NO_ROWRUN") ? 1 : 0;
+  const double eff_tile = (double)k.W * k.H / ((double)cdiv(k.W, TX) * TX * cdiv(k.H, TY) * TY);
+  const double eff_run = (double)k.W * k.H / (128.0 * cdiv(k.W * k.H, 128));
+  if (!no_rowrun && K == 3 && S == 1 && k.os == 1 && k.W >= 64 && CK * rr_rows(k.W) * ((k.IPW + 3) & ~3) <= RR_PATCH_FLOATS &&
+      k.OH == k.H && k.OW == k.W && eff_run > 1.1 * eff_tile) {
+    grid.x = cdiv(k.W * k.H, 128);
+    hipLaunchKernelGGL(conv3x3_rowrun_kernel, grid, dim3(256), 0, st, k);
+    vts_set_kernel(KS > 1 ? "conv3x3_rowrun_kernel+ksplit" : "conv3x3_rowrun_kernel");
+  } else if (k.os == 2 && k.ntaps <= 4 && S == 1 && KS == 1) {
     k.cps = cdiv(k.Cin, 16);
     if (K == 4) hipLaunchKernelGGL(conv_wide_phase_kernel<4>, grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL(conv_wide_phase_kernel<3>, grid, dim3(256), 0, st, k);
