@@ -188,11 +188,14 @@ __global__ __launch_bounds__(256) void conv_wide_phase_kernel(const WideK p) { w
 // would admit 128 .. 134 wide maps -- the 66 x 130 gradient of a 2048 x 1024 image -- but 54,272 B of LDS no longer lets three
 // workgroups share a CU: measured 2090 us against 1922 us for the tiled kernel.)
 constexpr int RR_PATCH_FLOATS = 3840;
-static inline int rr_rows(int W) { return 127 / W + 4; }
+static inline int rr_rows(int W, int K) { return 127 / W + 1 + K; }
 
-__global__ __launch_bounds__(256) void conv3x3_rowrun_kernel(const WideK p) {
+// K x K taps (3: 8 input channels per chunk, 4: 4 -- the PatchGAN layers at 130 x 130 / 66 x 66), stride 1
+template <int K, int CKT>
+__device__ __forceinline__ void rowrun_body(const WideK& p) {
+  constexpr int CK = CKT, TWT = K * K;
   constexpr int PATCH_FLOATS = RR_PATCH_FLOATS;
-  constexpr int W_FLOATS = CK * 9 * TCO;
+  constexpr int W_FLOATS = CK * TWT * TCO;
   constexpr int NPQ = (PATCH_FLOATS / 4 + 255) / 256;
   constexpr int NWQ = W_FLOATS / 4 / 256;
   __shared__ __attribute__((aligned(16))) float lds[PATCH_FLOATS + W_FLOATS];
@@ -206,13 +209,13 @@ __global__ __launch_bounds__(256) void conv3x3_rowrun_kernel(const WideK p) {
   const int PW = p.IPW, plane = p.IPH * p.IPW;
   const int PCP = (PW + 3) & ~3, PQ = PCP >> 2;
   const int ymin = g0 / p.W, ymax = min(g0 + 127, HW - 1) / p.W;
-  const int nr = ymax - ymin + 3;                        // rows of the padded input this run touches
-  const int nrm = 127 / p.W + 4;                         // rows allocated per channel (worst case)
+  const int nr = ymax - ymin + K;                        // rows of the padded input this run touches
+  const int nrm = 127 / p.W + 1 + K;                     // rows allocated per channel (worst case)
   const int TQ = CK * nr * PQ;
   const int ntaps = p.ntaps;
 
   const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0, p.Cin * plane * 4, RSRC_FLAGS);
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * 9 * p.Cout * 4, RSRC_FLAGS);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.Cin * TWT * p.Cout * 4, RSRC_FLAGS);
 
   int pvoff[NPQ], ploff[NPQ];
 #pragma unroll
@@ -230,12 +233,12 @@ __global__ __launch_bounds__(256) void conv3x3_rowrun_kernel(const WideK p) {
     const int row = q >> 5, cq = q & 31;                    // row = ci * ntaps + t
     const int ci = row / ntaps, t = row - ci * ntaps;
     const bool live = row < CK * ntaps;
-    wvoff[e] = live ? ((ci * 9 + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;
+    wvoff[e] = live ? ((ci * TWT + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;
     wloff[e] = (live ? row : 0) * TCO + 4 * cq;
   }
   u32x4 pq[NPQ], wq[NWQ];
   auto load_chunk = [&](int c0) {
-    const int pbase = c0 * plane * 4, wbase = c0 * 9 * p.Cout * 4;
+    const int pbase = c0 * plane * 4, wbase = c0 * TWT * p.Cout * 4;
 #pragma unroll
     for (int e = 0; e < NPQ; ++e)
       if (e * 256 < TQ) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pvoff[e] + pbase, 0, 0);
@@ -315,6 +318,9 @@ __global__ __launch_bounds__(256) void conv3x3_rowrun_kernel(const WideK p) {
       }
     }
 }
+
+__global__ __launch_bounds__(256) void conv3x3_rowrun_kernel(const WideK p) { rowrun_body<3, 8>(p); }
+__global__ __launch_bounds__(256) void conv4x4_rowrun_kernel(const WideK p) { rowrun_body<4, 4>(p); }
 
 __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, int KS,
                                                            int64_t per_slice, int HW, int Cout, float* __restrict__ out) {
@@ -633,11 +639,12 @@ static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_
   static const int no_rowrun = getenv("VTS_NO_ROWRUN") ? 1 : 0;
   const double eff_tile = (double)k.W * k.H / ((double)cdiv(k.W, TX) * TX * cdiv(k.H, TY) * TY);
   const double eff_run = (double)k.W * k.H / (128.0 * cdiv(k.W * k.H, 128));
-  if (!no_rowrun && K == 3 && S == 1 && k.os == 1 && k.W >= 64 && CK * rr_rows(k.W) * ((k.IPW + 3) & ~3) <= RR_PATCH_FLOATS &&
+  if (!no_rowrun && S == 1 && k.os == 1 && k.ntaps == TW && k.W >= 64 && ck * rr_rows(k.W, K) * ((k.IPW + 3) & ~3) <= RR_PATCH_FLOATS &&
       k.OH == k.H && k.OW == k.W && eff_run > 1.1 * eff_tile) {
     grid.x = cdiv(k.W * k.H, 128);
-    hipLaunchKernelGGL(conv3x3_rowrun_kernel, grid, dim3(256), 0, st, k);
-    vts_set_kernel(KS > 1 ? "conv3x3_rowrun_kernel+ksplit" : "conv3x3_rowrun_kernel");
+    if (K == 4) hipLaunchKernelGGL(conv4x4_rowrun_kernel, grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(conv3x3_rowrun_kernel, grid, dim3(256), 0, st, k);
+    vts_set_kernel(KS > 1 ? "conv%dx%d_rowrun_kernel+ksplit" : "conv%dx%d_rowrun_kernel", K, K);
   } else if (k.os == 2 && k.ntaps <= 4 && S == 1 && KS == 1) {
     k.cps = cdiv(k.Cin, 16);
     if (K == 4) hipLaunchKernelGGL(conv_wide_phase_kernel<4>, grid, dim3(256), 0, st, k);
