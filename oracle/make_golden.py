@@ -37,6 +37,50 @@ def _synthetic_batch(size, nt, seed, n=1):
     return default_collate([mod.make_sample(size, nt, nt, seed + i) for i in range(n)])
 
 
+def golden_step_sg2d(size=256, seed=909, nt=64):
+    """One SinSKITGModel.optimize_parameters of the REFERENCE with --netD stylegan2 (networks.py:437-442): pins the step-level use of the
+    StyleGAN2 discriminator (losses, gradients of G / D / D2, outputs)."""
+    from oracle import detrand, nets, ref_import, stylegan2 as sg
+
+    ref_import.load()
+    from models.sinskitG_model import SinSKITGModel
+
+    flags = ["--lambda_G1_lpips", "0", "--lambda_G2_lpips", "0", "--use_vision_aided_loss", "False", "--lambda_G2_GAN_feat", "0",
+             "--checkpoints_dir", "/tmp/vts_golden_ckpt", "--name", "golden_sg2d", "--netD", "stylegan2", "--load_size", str(size),
+             "--crop_size", str(size)]
+    opt = _ref_opt("sinskitG", True, flags)
+    model = SinSKITGModel(opt)
+    model.setup(opt)
+    shapesD = sg.d_param_shapes(4, opt.ndf, size)
+    assert {k: tuple(v.shape) for k, v in model.netD.named_parameters()} == {k: tuple(v) for k, v in shapesD.items()}
+    model.netG.load_state_dict(detrand.test_weights(nets.g_param_shapes(), seed))
+    model.netD.load_state_dict(sg.test_weights(shapesD, seed + 1), strict=False)
+    model.netD2.load_state_dict(detrand.test_weights(nets.d_param_shapes(7), seed + 2))
+    model.train()
+    batch = _synthetic_batch(size, nt, seed)
+    out = {"size": size, "seed": seed, "nt": nt, "ndf": opt.ndf, "flags": json.dumps(flags)}
+    model.set_input(batch, phase="train")
+    k = int(nets.dilated_mask_positions(model.M).shape[0])
+    torch.manual_seed(seed)
+    out["aug"] = torch.stack([torch.rand(1, 1, 1, 1).flatten() for _ in range(4)]).numpy()
+    random.seed(seed)
+    out["more_idx"] = np.array(random.sample(range(k), opt.add_fake_T_sample_size), dtype=np.int64)[None]
+    torch.manual_seed(seed)
+    random.seed(seed)
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    out["loss_names"] = np.array(list(losses.keys()))
+    out["loss_values"] = np.array(list(losses.values()), dtype=np.float64)
+    for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+        for kk, p in net.named_parameters():
+            out["grad_%s/%s" % (nm, kk)] = detrand.probe(p.grad, kk)
+    out["fake_I_sub"] = model.fake_I.detach()[:, :, ::4, ::4].numpy()
+    out["pred_fake_I"] = model.pred_fake_I.detach().numpy() if torch.is_tensor(model.pred_fake_I) else np.asarray(model.pred_fake_I[-1].detach())
+    np.savez_compressed(os.path.join(GOLD, "sinskitG_sg2d_step_%d.npz" % size), **out)
+    print("wrote sinskitG_sg2d_step_%d.npz (%d entries)" % (size, len(out)))
+    print({k: float(v) for k, v in losses.items()})
+
+
 def _ref_opt(model, is_train, extra):
     from options.test_options import TestOptions
     from options.train_options import TrainOptions
@@ -452,7 +496,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -471,3 +515,5 @@ if __name__ == "__main__":
         golden_metrics()
     if "sg2" in which:
         golden_sg2()
+    if "sg2step" in which:
+        golden_step_sg2d()

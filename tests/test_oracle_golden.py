@@ -360,3 +360,23 @@ def test_stylegan2_blocks_match_reference(golden_dir):
         np.testing.assert_allclose(st.grad.numpy(), g["mod/%s/dstyle" % tag], rtol=2e-3, atol=1e-5)
         for k, v in w.items():
             assert _sg_probe_close(detrand.probe(v.grad, k), g["mod/%s/grad/%s" % (tag, k)]), (tag, k)
+
+
+def test_train_step_with_stylegan2_discriminator_matches_reference(golden_dir):
+    """the oracle step with --netD stylegan2 vs the REFERENCE's SinSKITGModel.optimize_parameters run with that flag"""
+    from oracle import stylegan2 as sg
+    g = _load(golden_dir, "sinskitG_sg2d_step_256.npz")
+    size, seed, nt, ndf = int(g["size"]), int(g["seed"]), int(g["nt"]), int(g["ndf"])
+    sdG = detrand.test_weights(nets.g_param_shapes(), seed)
+    sdD = sg.test_weights(sg.d_param_shapes(4, ndf, size), seed + 1)
+    sdD2 = detrand.test_weights(nets.d_param_shapes(7), seed + 2)
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    draws = {"aug": torch.from_numpy(g["aug"]), "more_idx": torch.from_numpy(g["more_idx"])}
+    out = step.train_step(sdG, sdD, sdD2, adam, _batch(size, nt, seed), draws, opt=step.hp(netD="stylegan2"))
+    ref = dict(zip([str(s) for s in g["loss_names"]], g["loss_values"]))
+    for k, v in out["losses"].items():
+        assert abs(v - ref["l_" + k]) <= 2e-4 * max(1.0, abs(ref["l_" + k])), (k, v, ref["l_" + k])
+    _close(out["fake_I"][:, :, ::4, ::4].numpy(), g["fake_I_sub"], rtol=1e-4, atol=2e-5)
+    for nm in ("G", "D", "D2"):
+        for k, gr in out["grad_" + nm].items():
+            _probe_close(gr, g["grad_%s/%s" % (nm, k)], k, rtol=5e-4)

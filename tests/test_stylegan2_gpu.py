@@ -216,3 +216,45 @@ def test_train_step_with_stylegan2_discriminator_matches_oracle():
         model.optimize_parameters(epoch=1)
     torch.cuda.synchronize()
     assert all(np.isfinite(v) for v in model.get_current_losses().values())
+
+
+def test_train_step_with_stylegan2_discriminator_matches_reference_golden(golden_dir):
+    """the HIP step with --netD stylegan2 against the REFERENCE's own SinSKITGModel.optimize_parameters run with that flag
+    (tests/golden/sinskitG_sg2d_step_256.npz): losses, outputs, gradient probes of all three networks"""
+    from torch.utils.data import default_collate
+
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+    from oracle import nets
+
+    g = np.load(os.path.join(golden_dir, "sinskitG_sg2d_step_256.npz"), allow_pickle=False)
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    flags = ("--model sinskitG --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
+             "--lambda_G2_GAN_feat 0 --checkpoints_dir /tmp/vts_test_ckpt --name tsg2 --crop_size %d --load_size %d --batch_size 1 "
+             "--netD stylegan2" % (size, size))
+    opt = TrainOptions(cmd_line=flags).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    model.train()
+    model.netG.load_state_dict(detrand.test_weights(nets.g_param_shapes(), seed))
+    model.netD.load_state_dict(sg.test_weights(sg.d_param_shapes(4, opt.ndf, size), seed + 1), strict=False)
+    model.netD2.load_state_dict(detrand.test_weights(nets.d_param_shapes(7), seed + 2))
+    batch = default_collate([make_sample(size, nt, nt, seed)])
+    model._draws = {"aug": torch.from_numpy(g["aug"]), "more_idx": torch.from_numpy(g["more_idx"])}
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    ref = dict(zip([str(s) for s in g["loss_names"]], g["loss_values"]))
+    for k, v in ref.items():
+        assert abs(losses[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses[k], v)
+    assert rel(model.fake_I[:, :, ::4, ::4], torch.from_numpy(g["fake_I_sub"])) < 1e-3
+    for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+        for k, p in net.named_parameters():
+            if k.endswith("bias") and ((nm == "G" and not any(k.startswith(q) for q in ("down0.", "down7.", "up0.", "up0_T.")))
+                                       or (nm == "D2" and k.split(".")[1] in ("2", "5", "8"))):
+                continue                                   # bias in front of a norm: analytically zero gradient
+            pr, rp = detrand.probe(p.grad.cpu(), k), g["grad_%s/%s" % (nm, k)]
+            scale = max(abs(rp[1]), 1e-12)
+            assert abs(pr[1] - rp[1]) <= 2e-3 * scale and abs(pr[2] - rp[2]) <= 8e-3 * scale, (nm, k, pr, rp)
