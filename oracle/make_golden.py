@@ -217,6 +217,39 @@ def golden_nets(size=256, seed=101):
     print("wrote nets_%d.npz (%d entries)" % (size, len(out)))
 
 
+def golden_nets_style(size=256, seed=111, n=2):
+    """skitG generator: CustomUnetGenerator with a style code (use_style_code, style_code_mode concat, mapping tile; reference
+    networks.py:1436-1466, 1595-1640) -- the network of the headline configuration.  Forward + gradients (incl. d/d style_code)."""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from models import networks
+
+    opt = _ref_opt("skitG", True, ["--use_style_code", "True", "--batch_size", str(n)])
+    out = {"size": size, "seed": seed, "n": n, "style_code_dim": opt.style_code_dim, "num_layer_style_code": opt.num_layer_style_code}
+    G = networks.define_G(9, 5, 10, "unet256_custom", "instance", False, "xavier", 0.02, False, False, [], opt, num_layer_separate=4)
+    ref = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    mine = nets.g_param_shapes(style_nc=opt.style_code_dim, num_layer_style_code=opt.num_layer_style_code)
+    dead = {k: v for k, v in ref.items() if k.startswith("style_code_mapping")}      # created upstream, unused in tile mode
+    assert {k: v for k, v in ref.items() if k not in dead} == {k: tuple(v) for k, v in mine.items()}, "style G key/shape mismatch"
+    out["dead_keys"] = np.array(sorted(dead.keys()))
+    G.load_state_dict(detrand.test_weights(mine, seed), strict=False)
+    x = detrand.uniform((n, 9, size, size), seed, "g_in").requires_grad_(True)
+    sc = detrand.uniform((n, opt.style_code_dim), seed, "style")
+    sc = (sc / sc.norm(dim=1, keepdim=True)).requires_grad_(True)
+    y = G(x, style_code=sc)
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    out["G_out_sub"] = y.detach()[:, :, ::4, ::4].numpy()
+    out["G_out_probe"] = detrand.probe(y, "g_out")
+    out["G_dx_probe"] = detrand.probe(x.grad, "g_dx")
+    out["G_dstyle"] = sc.grad.numpy()
+    for k, p in G.named_parameters():
+        if k not in dead:
+            out["G_grad/" + k] = detrand.probe(p.grad, k)
+    np.savez_compressed(os.path.join(GOLD, "nets_style_%d.npz" % size), **out)
+    print("wrote nets_style_%d.npz (%d entries)" % (size, len(out)))
+
+
 def golden_resnet(size=64, seed=303, n_blocks=9, ngf=10):
     """ResnetGenerator (--netG resnet_9blocks, reference defaults) forward + gradients with seeded test weights."""
     from oracle import detrand, nets, ref_import
@@ -496,7 +529,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step", "style"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -517,3 +550,5 @@ if __name__ == "__main__":
         golden_sg2()
     if "sg2step" in which:
         golden_step_sg2d()
+    if "style" in which:
+        golden_nets_style()

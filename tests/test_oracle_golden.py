@@ -380,3 +380,22 @@ def test_train_step_with_stylegan2_discriminator_matches_reference(golden_dir):
     for nm in ("G", "D", "D2"):
         for k, gr in out["grad_" + nm].items():
             _probe_close(gr, g["grad_%s/%s" % (nm, k)], k, rtol=5e-4)
+
+
+def test_style_code_generator_fwd_bwd(golden_dir):
+    """the skitG generator (CustomUnetGenerator with a style code, concat / tile) of the oracle vs the reference module"""
+    g = _load(golden_dir, "nets_style_256.npz")
+    size, seed, n, sd_dim, nl = (int(g[k]) for k in ("size", "seed", "n", "style_code_dim", "num_layer_style_code"))
+    sd = detrand.test_weights(nets.g_param_shapes(style_nc=sd_dim, num_layer_style_code=nl), seed)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = detrand.uniform((n, 9, size, size), seed, "g_in").requires_grad_(True)
+    sc = detrand.uniform((n, sd_dim), seed, "style")
+    sc = (sc / sc.norm(dim=1, keepdim=True)).requires_grad_(True)
+    y = nets.unet_forward(sd, x, style_code=sc, num_layer_style_code=nl)
+    _close(y.detach()[:, :, ::4, ::4].numpy(), g["G_out_sub"], rtol=1e-4, atol=2e-5)
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    _probe_close(x.grad, g["G_dx_probe"], "g_dx")
+    _close(sc.grad.numpy(), g["G_dstyle"], rtol=2e-3, atol=1e-6)
+    for k, v in sd.items():
+        _probe_close(v.grad, g["G_grad/" + k], k)

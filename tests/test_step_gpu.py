@@ -326,3 +326,35 @@ def test_eval_metrics_match_oracle():
     for k in ("I_PSNR", "T_AE", "T_MSE", "I_SSIM"):
         assert abs(m[k] - ref[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, m[k], ref[k])
     assert set(model.get_current_metrics().keys()) == {"m_I_PSNR", "m_T_AE", "m_T_MSE", "m_I_SSIM"}
+
+
+def test_style_code_generator_matches_reference_golden(golden_dir):
+    """the skitG generator (CustomUnetGenerator + style code, the network of the headline configuration) on the HIP engine vs the
+    REFERENCE module run on CPU (tests/golden/nets_style_256.npz): outputs and every parameter gradient"""
+    from models import create_model
+    from options.train_options import TrainOptions
+    from vts import engine
+
+    g = np.load(os.path.join(golden_dir, "nets_style_256.npz"))
+    size, seed, n, sd_dim, nl = (int(g[k]) for k in ("size", "seed", "n", "style_code_dim", "num_layer_style_code"))
+    flags = (FLAGS % (size, n)).replace("--model sinskitG", "--model skitG")
+    opt = TrainOptions(cmd_line=flags).parse()
+    assert opt.use_style_code and opt.style_code_dim == sd_dim and opt.num_layer_style_code == nl
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    G = model.netG
+    G.load_state_dict(detrand.test_weights(nets.g_param_shapes(style_nc=sd_dim, num_layer_style_code=nl), seed))
+    dev = torch.device("cuda:0")
+    x = detrand.uniform((n, 9, size, size), seed, "g_in").to(dev)
+    sc = detrand.uniform((n, sd_dim), seed, "style")
+    sc = (sc / sc.norm(dim=1, keepdim=True)).to(dev)
+    y, ctx = engine.unet_forward(G, x, style_code=sc)
+    assert rel(y[:, :, ::4, ::4], torch.from_numpy(g["G_out_sub"])) < 1e-4
+    probe_close(y, g["G_out_probe"], "g_out", 2e-4)
+    cot = detrand.uniform(tuple(y.shape), seed, "g_cot").to(dev)
+    engine.unet_backward(G, ctx, (cot * (1.0 - y * y)).contiguous())
+    for k, p in G.named_parameters():
+        if null_grad_bias("G", k):
+            continue
+        probe_close(p.grad, g["G_grad/" + k], k, 1e-3)
