@@ -650,17 +650,20 @@ def _pyramid(D, in0, in1):
 
 
 FLAT_D = os.environ.get("VTS_FLAT_D", "1") != "0"
+FLAT_MIN_C = int(os.environ.get("VTS_FLAT_MIN_C", "64"))   # small maps: channels from which the flattened GEMM-class kernel takes over
 
 
 def _flat4(conv, j, h, w, oh, ow, st):
     """whether this PatchGAN layer takes the GEMM-class route with 16-tap packed weights (vts_conv4x4_wide: flattened-batch kernel
     for maps of <= 128 pixels, tiled kernel above): wide layers only; Cout = 1 heads only on small maps"""
     co, ci = conv.weight.shape[0], conv.weight.shape[1]
-    if not FLAT_D or j == 0 or ci < 64:      # the reference's own ndf = 8 discriminators (<= 64 channels) stay on the 4x4 kernels
+    if not FLAT_D or j == 0 or ci < FLAT_MIN_C:
         return False
     small = ops.conv4x4_flat_ok(oh, ow, st * (oh - 1) + 4, st * (ow - 1) + 4)
     if small:
-        return co >= 64 or ci >= 256
+        return co >= FLAT_MIN_C or ci >= 256
+    if ci < 64:                              # full-size maps of the reference's own ndf = 8 discriminators stay on the 4x4 kernels
+        return False
     return co >= 128 and co % 4 == 0 and ci % 4 == 0
 
 
