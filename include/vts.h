@@ -114,7 +114,7 @@ int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream);
 
 /* Per-channel sum over (N, H, W): out[c] (+)= sum x[n,c,:,:]  (bias gradients). */
 int vts_channel_sum(const float* x, int64_t nstride, int N, int C, int HW, float* out, int accumulate,
-                    float* ws, void* stream);
+                    float* ws, int* counters /* optional, >= C zeroed ints: see vts_norm_desc */, void* stream);
 int64_t vts_channel_sum_ws_floats(int N, int C, int HW);
 
 /* Normalisation statistics -> per-(n,c) scale/shift for normalise-on-load.
@@ -138,6 +138,10 @@ typedef struct vts_norm_desc {
   float* shift;    /* [N*C] out */
   float* mean_out; /* [N*C] out */
   float* rstd_out; /* [N*C] out */
+  int* counters;   /* optional: >= N*C ints of caller-owned device memory, ZERO on entry and left zero; when given, the last
+                      workgroup of each group finalises (one launch instead of two: same arithmetic, same order).  One buffer
+                      per concurrently running stream.  Measured SLOWER on MI355X inside a busy step (device-scope fences
+                      flush the per-XCD L2): leave NULL unless the launch count matters more than the time. */
 } vts_norm_desc;
 
 int64_t vts_norm_ws_floats(int N, int C, int HW);
@@ -158,6 +162,7 @@ typedef struct vts_norm_bwd_desc {
   float* dgamma;
   float* dbeta;
   int accumulate_param_grads;
+  int* counters; /* optional, as in vts_norm_desc */
 } vts_norm_bwd_desc;
 
 int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream);

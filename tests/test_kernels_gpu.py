@@ -271,9 +271,17 @@ def test_wgrad(case):
     assert rel(dw2, 2 * ref) < 2e-5
 
 
+@pytest.fixture(params=[False, True], ids=["two_launches", "last_block_finalizes"])
+def fuse_finalize(request):
+    from vts import ops
+    keep, ops.FUSE_FINALIZE = ops.FUSE_FINALIZE, request.param
+    yield request.param
+    ops.FUSE_FINALIZE = keep
+
+
 @pytest.mark.parametrize("shape", [(2, 10, 64, 64), (1, 80, 2, 2), (3, 20, 37, 53), (1, 3, 128, 128), (2, 4, 300, 300)])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_norm_forward_backward(shape, mode):
+def test_norm_forward_backward(shape, mode, fuse_finalize):
     from vts import ops
 
     dev = _dev()
@@ -323,7 +331,7 @@ def test_norm_large_mean_is_robust():
     assert (yk.cpu() - y).abs().max() < 0.1
 
 
-def test_channel_sum_and_act_bwd():
+def test_channel_sum_and_act_bwd(fuse_finalize):
     from vts import ops
     from vts.ops import Act
 

@@ -11,8 +11,8 @@ constexpr int EPT = CHUNK / 256;
 __host__ __device__ inline int splits_for(int HW) { return (HW + CHUNK - 1) / CHUNK; }
 
 // ---- forward statistics: per (n, c, split) -> (mean, M2, count) via a register-resident two-pass ----
-__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW,
-                                                            int spl, float* __restrict__ part) {
+__device__ __forceinline__ void stats_partial_body(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
+                                                    float* __restrict__ part) {
   __shared__ float red[16];
   const int s = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
   const float* px = x + n * nstride + (int64_t)c * HW;
@@ -43,12 +43,32 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restr
   }
 }
 
+// "The last workgroup of a group finalises": every workgroup publishes its partial, takes a ticket from the group's counter and the
+// one that draws the last ticket reduces all partials in the fixed order of the stand-alone finalize kernels (bit-identical results,
+// deterministic) -- one launch and one dependency hop fewer per normalisation / bias gradient.  `counters` is caller-owned device
+// memory, zero on entry; the last workgroup resets its counter, so it stays zero between launches (stream order).  The partials
+// of the other workgroups are read through volatile pointers (L2, not this CU's vector cache).
+__device__ __forceinline__ bool last_block_of(int* counters, int g, int nblk, int* sflag) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = atomicAdd(&counters[g], 1);
+    const int last = t == nblk - 1;
+    if (last) counters[g] = 0;
+    *sflag = last;
+  }
+  __syncthreads();
+  const bool last = *sflag != 0;
+  if (last) __threadfence();
+  return last;
+}
+
 // Chan merge of `np` partials strided by `stride` (one wave); returns (mean, M2, count) in every lane
-__device__ __forceinline__ void chan_merge_wave(const float* part, int np, int64_t stride, float& mean, float& m2, float& cnt) {
+__device__ __forceinline__ void chan_merge_wave(const volatile float* part, int np, int64_t stride, float& mean, float& m2, float& cnt) {
   const int lane = threadIdx.x & 63;
   float sn = 0.f, sm = 0.f;
   for (int i = lane; i < np; i += 64) {
-    const float* q = part + i * stride;
+    const volatile float* q = part + i * stride;
     sn += q[2];
     sm += q[2] * q[0];
   }
@@ -57,7 +77,7 @@ __device__ __forceinline__ void chan_merge_wave(const float* part, int np, int64
   mean = sm / sn;
   float acc = 0.f;
   for (int i = lane; i < np; i += 64) {
-    const float* q = part + i * stride;
+    const volatile float* q = part + i * stride;
     const float d = q[0] - mean;
     acc += q[1] + q[2] * d * d;
   }
@@ -75,10 +95,10 @@ struct NormK {
 };
 
 // IN: one wave per (n,c).  BN: one wave per c, merging N*spl partials, writing all n.
-__global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restrict__ part, const NormK k) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void norm_finalize_group(const volatile float* part, const NormK& k, int group) {
+  const int lane = threadIdx.x & 63;
   if (k.mode == 0) {
-    const int g = blockIdx.x;  // n*C + c
+    const int g = group;  // n*C + c
     float mean, m2, cnt;
     chan_merge_wave(part + (int64_t)g * k.spl * 3, k.spl, 3, mean, m2, cnt);
     if (lane == 0) {
@@ -89,13 +109,13 @@ __global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restri
       if (k.rstd_out) k.rstd_out[g] = rstd;
     }
   } else {
-    const int c = blockIdx.x;
+    const int c = group;
     // partials of channel c: for n in N, s in spl -> index ((n*C + c)*spl + s); merge in two levels per n
     float sn = 0.f, sm = 0.f;
     const int np = k.N * k.spl;
     for (int i = lane; i < np; i += 64) {
       const int n = i / k.spl, s = i - n * k.spl;
-      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+      const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
       sn += q[2];
       sm += q[2] * q[0];
     }
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restri
     float acc = 0.f;
     for (int i = lane; i < np; i += 64) {
       const int n = i / k.spl, s = i - n * k.spl;
-      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+      const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
       const float d = q[0] - mean;
       acc += q[1] + q[2] * d * d;
     }
@@ -128,11 +148,27 @@ __global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restri
   }
 }
 
+__global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restrict__ part, const NormK k) { norm_finalize_group(part, k, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
+                                                            float* __restrict__ part) {
+  stats_partial_body(x, nstride, C, HW, spl, part);
+}
+
+// partial statistics + finalize by the last workgroup of the group ((n, c) for InstanceNorm, c for BatchNorm)
+__global__ __launch_bounds__(256) void stats_fin_kernel(const float* __restrict__ x, int64_t nstride, float* __restrict__ part, const NormK k,
+                                                        int* __restrict__ counters) {
+  __shared__ int flag;
+  stats_partial_body(x, nstride, k.C, k.HW, k.spl, part);
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int g = k.mode == 0 ? n * k.C + c : c, nblk = k.mode == 0 ? k.spl : k.N * k.spl;
+  if (last_block_of(counters, g, nblk, &flag) && threadIdx.x < 64) norm_finalize_group(part, k, g);
+}
+
 // ---- backward: partial S1 = sum dy, S2 = sum dy * xhat per (n, c, split) ----
-__global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                               int64_t nstride, int C, int HW, int spl,
-                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               float* __restrict__ part) {
+__device__ __forceinline__ void norm_bwd_partial_body(const float* __restrict__ dy, const float* __restrict__ x, int64_t nstride, int C,
+                                                       int HW, int spl, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       float* __restrict__ part) {
   __shared__ float red[16];
   const int s = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
   const int64_t off = n * nstride + (int64_t)c * HW;
@@ -167,10 +203,10 @@ struct NormBwdK {
   float* coef;  // [N*C][3]
 };
 
-__global__ __launch_bounds__(64) void norm_bwd_finalize_kernel(const float* __restrict__ part, const NormBwdK k) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void norm_bwd_finalize_group(const volatile float* part, const NormBwdK& k, int group) {
+  const int lane = threadIdx.x & 63;
   if (k.mode == 0) {
-    const int g = blockIdx.x;
+    const int g = group;
     float s1 = 0.f, s2 = 0.f;
     for (int i = lane; i < k.spl; i += 64) {
       s1 += part[((int64_t)g * k.spl + i) * 2];
@@ -186,12 +222,12 @@ __global__ __launch_bounds__(64) void norm_bwd_finalize_kernel(const float* __re
       k.coef[g * 3 + 2] = -rs * s1 / m - B * mu;
     }
   } else {
-    const int c = blockIdx.x;
+    const int c = group;
     float s1 = 0.f, s2 = 0.f;
     const int np = k.N * k.spl;
     for (int i = lane; i < np; i += 64) {
       const int n = i / k.spl, s = i - n * k.spl;
-      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 2;
+      const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 2;
       s1 += q[0];
       s2 += q[1];
     }
@@ -308,9 +344,26 @@ __global__ __launch_bounds__(1024) void norm_bwd_fused_kernel(float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(64) void norm_bwd_finalize_kernel(const float* __restrict__ part, const NormBwdK k) { norm_bwd_finalize_group(part, k, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t nstride, int C,
+                                                               int HW, int spl, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ part) {
+  norm_bwd_partial_body(dy, x, nstride, C, HW, spl, mean, rstd, part);
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_fin_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
+                                                           float* __restrict__ part, const NormBwdK k, int* __restrict__ counters) {
+  __shared__ int flag;
+  norm_bwd_partial_body(dy, x, nstride, k.C, k.HW, k.spl, k.mean, k.rstd, part);
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int g = k.mode == 0 ? n * k.C + c : c, nblk = k.mode == 0 ? k.spl : k.N * k.spl;
+  if (last_block_of(counters, g, nblk, &flag) && threadIdx.x < 64) norm_bwd_finalize_group(part, k, g);
+}
+
 // ---- channel sum ----
-__global__ __launch_bounds__(256) void chsum_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
-                                                            float* __restrict__ part) {
+__device__ __forceinline__ void chsum_partial_body(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
+                                                    float* __restrict__ part) {
   __shared__ float red[16];
   const int s = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
   const float* px = x + n * nstride + (int64_t)c * HW;
@@ -325,9 +378,9 @@ __global__ __launch_bounds__(256) void chsum_partial_kernel(const float* __restr
   if (threadIdx.x == 0) part[((int64_t)n * C + c) * spl + s] = sum;
 }
 
-__global__ __launch_bounds__(64) void chsum_finalize_kernel(const float* __restrict__ part, int N, int C, int spl,
-                                                            float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void chsum_finalize_group(const volatile float* part, int N, int C, int spl, float* __restrict__ out, int accumulate,
+                                                      int c) {
+  const int lane = threadIdx.x & 63;
   float s = 0.f;
   for (int i = lane; i < N * spl; i += 64) {
     const int n = i / spl, j = i - n * spl;
@@ -335,6 +388,25 @@ __global__ __launch_bounds__(64) void chsum_finalize_kernel(const float* __restr
   }
   s = wave_sum(s);
   if (lane == 0) out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(64) void chsum_finalize_kernel(const float* __restrict__ part, int N, int C, int spl, float* __restrict__ out,
+                                                            int accumulate) {
+  chsum_finalize_group(part, N, C, spl, out, accumulate, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void chsum_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
+                                                            float* __restrict__ part) {
+  chsum_partial_body(x, nstride, C, HW, spl, part);
+}
+
+__global__ __launch_bounds__(256) void chsum_fin_kernel(const float* __restrict__ x, int64_t nstride, int N, int C, int HW, int spl,
+                                                        float* __restrict__ part, float* __restrict__ out, int accumulate,
+                                                        int* __restrict__ counters) {
+  __shared__ int flag;
+  chsum_partial_body(x, nstride, C, HW, spl, part);
+  const int c = blockIdx.y;
+  if (last_block_of(counters, c, N * spl, &flag) && threadIdx.x < 64) chsum_finalize_group(part, N, C, spl, out, accumulate, c);
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, int64_t xns,
@@ -374,6 +446,12 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
     vts_set_kernel("norm_stats_fused_kernel");
     return VTS_OK;
   }
+  if (d->counters) {
+    hipLaunchKernelGGL(stats_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->x, d->nstride, ws, k, d->counters);
+    VTS_CHECK_LAUNCH("vts_norm_stats");
+    vts_set_kernel("stats_fin_kernel");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(stats_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->x, d->nstride, d->C, d->HW, spl, ws);
   VTS_CHECK_LAUNCH("vts_norm_stats partial");
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, ws, k);
@@ -398,10 +476,18 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
     vts_set_kernel("norm_bwd_fused_kernel");
     return VTS_OK;
   }
+  NormBwdK k{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, coef};
+  if (d->counters) {
+    hipLaunchKernelGGL(norm_bwd_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, part, k, d->counters);
+    VTS_CHECK_LAUNCH("vts_norm_bwd partial+finalize");
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, coef);
+    VTS_CHECK_LAUNCH("vts_norm_bwd apply");
+    vts_set_kernel("norm_bwd_fin_kernel+norm_bwd_apply_kernel");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, spl,
                      d->mean, d->rstd, part);
   VTS_CHECK_LAUNCH("vts_norm_bwd partial");
-  NormBwdK k{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, coef};
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, part, k);
   VTS_CHECK_LAUNCH("vts_norm_bwd finalize");
   hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, coef);
@@ -413,10 +499,15 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
 extern "C" int64_t vts_channel_sum_ws_floats(int N, int C, int HW) { return (int64_t)N * C * splits_for(HW); }
 
 extern "C" int vts_channel_sum(const float* x, int64_t nstride, int N, int C, int HW, float* out, int accumulate, float* ws,
-                               void* stream) {
+                               int* counters, void* stream) {
   VTS_CHECK_ARG(x && out && ws, "vts_channel_sum: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int spl = splits_for(HW);
+  if (counters) {
+    hipLaunchKernelGGL(chsum_fin_kernel, dim3(spl, C, N), dim3(256), 0, st, x, nstride, N, C, HW, spl, ws, out, accumulate, counters);
+    VTS_CHECK_LAUNCH("vts_channel_sum");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(chsum_partial_kernel, dim3(spl, C, N), dim3(256), 0, st, x, nstride, C, HW, spl, ws);
   VTS_CHECK_LAUNCH("vts_channel_sum partial");
   hipLaunchKernelGGL(chsum_finalize_kernel, dim3(C), dim3(64), 0, st, ws, N, C, spl, out, accumulate);

@@ -53,7 +53,7 @@ class NormDesc(C.Structure):
         ("x", C.c_void_p), ("nstride", C.c_int64), ("N", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("mode", C.c_int),
         ("eps", C.c_float), ("momentum", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
-        ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean_out", C.c_void_p), ("rstd_out", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean_out", C.c_void_p), ("rstd_out", C.c_void_p), ("counters", C.c_void_p),
     ]
 
 
@@ -61,7 +61,7 @@ class NormBwdDesc(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("x", C.c_void_p), ("nstride", C.c_int64), ("N", C.c_int), ("C", C.c_int), ("HW", C.c_int),
         ("mode", C.c_int), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p),
-        ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate_param_grads", C.c_int),
+        ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate_param_grads", C.c_int), ("counters", C.c_void_p),
     ]
 
 
@@ -114,7 +114,7 @@ def load():
         "vts_conv4x4": [C.POINTER(ConvDesc), vp],
         "vts_wgrad4x4_ws_floats": [C.POINTER(WgradDesc)],
         "vts_wgrad4x4": [C.POINTER(WgradDesc), vp, vp],
-        "vts_channel_sum": [vp, i64, i, i, i, vp, i, vp, vp],
+        "vts_channel_sum": [vp, i64, i, i, i, vp, i, vp, vp, vp],
         "vts_norm_stats": [C.POINTER(NormDesc), vp, vp],
         "vts_norm_bwd": [C.POINTER(NormBwdDesc), vp, vp],
         "vts_act_bwd": [vp, C.POINTER(Operand), i, i, i, vp, i, vp],

@@ -4,6 +4,7 @@
 per-(n,c) scale/shift produced by vts_norm_stats (see include/vts.h, vts_operand).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -72,6 +73,25 @@ def workspace(nfloats, device):
 
 
 _retired = []
+
+_counters = {}
+# Off by default: measured 3x SLOWER on MI355X (10.5 -> 30 ms per step).  The release / acquire fences the pattern needs are
+# device-scope, and with one L2 per XCD a device-scope fence writes back / invalidates that whole L2 -- thousands of workgroups doing
+# so while six other lanes keep the L2s dirty is far more expensive than the ~140 tiny finalize launches it saves.  A kernel boundary
+# is the cheap cross-XCD synchronisation on this part.  (VTS_FUSE_FINALIZE=1 turns it on; tests/test_kernels_gpu.py covers both.)
+FUSE_FINALIZE = os.environ.get("VTS_FUSE_FINALIZE", "0") == "1"
+
+
+def counters(device):
+    """zeroed int32 scratch of the current lane for the 'last workgroup finalises' kernels (they leave it zero); None switches
+    the library back to its separate finalize launches"""
+    if not FUSE_FINALIZE:
+        return None
+    key = (str(device), WS_LANE)
+    t = _counters.get(key)
+    if t is None:
+        t = _counters[key] = torch.zeros(1 << 16, dtype=torch.int32, device=device)
+    return t
 
 
 FROZEN_WS = False  # set while HIP graphs that captured the workspace pointer are alive
@@ -517,7 +537,7 @@ def channel_sum(x, out, accumulate=False):
     n, c, h, w = x.shape
     ws = workspace(lib.vts_channel_sum_ws_floats(n, c, h * w), x.device)
     _run("channel_sum", 4.0 * n * c * h * w, 0.0, lib.vts_channel_sum, x.data_ptr(), x.stride(0), n, c, h * w, out.data_ptr(),
-         int(accumulate), ws.data_ptr(), L.stream())
+         int(accumulate), ws.data_ptr(), L.ptr(counters(x.device)) if c <= (1 << 16) else None, L.stream())
     return out
 
 
@@ -534,6 +554,7 @@ def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var
     d.running_mean, d.running_var, d.num_batches_tracked = L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt)
     d.scale, d.shift, d.mean_out, d.rstd_out = st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr()
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), x.device)
+    d.counters = L.ptr(counters(x.device)) if n * c <= (1 << 16) else None
     _run("norm_stats", 4.0 * n * c * h * w, 0.0, lib.vts_norm_stats, C.byref(d), ws.data_ptr(), L.stream())
     return Act(x, st[0], st[1], st[2], st[3])
 
@@ -548,6 +569,7 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
     d.gamma, d.dgamma, d.dbeta = L.ptr(gamma), L.ptr(dgamma), L.ptr(dbeta)
     d.accumulate_param_grads = int(accumulate)
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
+    d.counters = L.ptr(counters(dy.device)) if n * c <= (1 << 16) else None
     _run("norm_bwd", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
     return dy
 
