@@ -307,6 +307,14 @@ int vts_metric_tactile(const float* real_T, const float* fake_T, int64_t P, int 
  * variances clamped at 0) on the same {lo, hi}-normalised images as vts_metric_psnr; real / fake are [NC, H, W]. */
 int vts_metric_ssim(const float* real, const float* fake, int NC, int H, int W, const float* range2, float* out, float* ws, void* stream);
 
+/* Fréchet distance between two feature sets -- the arithmetic of SIFID behind the Inception features (models/sifid.py:102-176:
+ * np.mean / np.cov(rowvar=False) per set, then |mu1-mu2|^2 + tr(S1) + tr(S2) - 2 tr(sqrtm(S1 S2))).  feat1 / feat2 are channel-major
+ * [D, P] float32 (one image's NCHW feature map: D <= 64 channels, P1 / P2 positions); moments and the matrix square root (coupled
+ * Newton-Schulz) are computed in float64; out[0] is the distance.  ws: vts_frechet_ws_floats() floats, 8-byte aligned.  (The
+ * reference's fallback for a singular product -- adding 1e-6 to the diagonals -- is not reproduced.) */
+int64_t vts_frechet_ws_floats(void);
+int vts_frechet_distance(const float* feat1, const float* feat2, int D, int64_t P1, int64_t P2, float* out, float* ws, void* stream);
+
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */
 int vts_avgpool3s2(const float* x, int64_t x_nstride, int N, int C, int H, int W, float* y, void* stream);

@@ -413,6 +413,14 @@ def golden_metrics(seed=606):
     real_T, fake_T = 0.3 * detrand.uniform((6, 2, 32, 32), seed, "rT"), 0.6 * detrand.uniform((6, 2, 32, 32), seed, "fT")
     m = compute_evaluation_metric(["G"], real_I, fake_I, real_T_concat=real_T, fake_T_concat=fake_T, eval_metrics=["T_AE", "T_MSE"])
     out = {"seed": seed, "T_AE": float(m["metric_T_AE"]), "T_MSE": float(m["metric_T_MSE"])}
+    # Frechet distance of the reference (models/sifid.py:102-176) on synthetic channel-major features [D, P]
+    from models import sifid
+    from oracle import nets
+    for i, (d, p1, p2) in enumerate(nets.FRECHET_CASES):
+        f1, f2 = nets.frechet_case(i, seed)
+        a1, a2 = f1.numpy().T.astype(np.float64), f2.numpy().T.astype(np.float64)       # (positions, dims) as get_activations returns
+        out["fd/%d" % i] = float(sifid.calculate_frechet_distance(np.mean(a1, axis=0), np.cov(a1, rowvar=False), np.mean(a2, axis=0),
+                                                                  np.cov(a2, rowvar=False)))
     np.savez_compressed(os.path.join(GOLD, "metrics.npz"), **out)
     print("wrote metrics.npz", out)
 

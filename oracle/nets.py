@@ -75,6 +75,30 @@ def eval_metrics(real_I, fake_I, real_T, fake_T):
     return out
 
 
+# (dims, positions of set 1, positions of set 2) of the synthetic Frechet-distance cases shared by the golden generator and the tests
+FRECHET_CASES = [(64, 4096, 4096), (64, 1000, 777), (16, 300, 300), (64, 200, 200), (3, 50, 64)]
+
+
+def frechet_case(i, seed):
+    """channel-major features [D, P]: correlated channels with different means / scales for the two sets"""
+    from oracle import detrand
+    d, p1, p2 = FRECHET_CASES[i]
+    mix = detrand.uniform((d, d), seed, "fd_mix%d" % i) * (1.0 / d ** 0.5) + torch.eye(d)
+    f1 = mix @ detrand.uniform((d, p1), seed, "fd_a%d" % i) + 0.3 * detrand.uniform((d, 1), seed, "fd_m%d" % i)
+    f2 = 1.3 * (mix.t() @ detrand.uniform((d, p2), seed, "fd_b%d" % i)) + 0.1
+    return f1.contiguous(), f2.contiguous()
+
+
+def frechet_distance(f1, f2):
+    """models/sifid.py:102-176 on channel-major features [D, P] (float64 numpy + scipy.linalg.sqrtm, as the reference)"""
+    from scipy import linalg
+    a1, a2 = f1.numpy().T.astype(np.float64), f2.numpy().T.astype(np.float64)
+    mu1, mu2, s1, s2 = np.mean(a1, axis=0), np.mean(a2, axis=0), np.atleast_2d(np.cov(a1, rowvar=False)), np.atleast_2d(np.cov(a2, rowvar=False))
+    covmean, _ = linalg.sqrtm(s1.dot(s2), disp=False)
+    diff = mu1 - mu2
+    return float(diff.dot(diff) + np.trace(s1) + np.trace(s2) - 2 * np.trace(covmean.real))
+
+
 def ssim(target, preds, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
     """I_SSIM (models/model_utils.py:498-499) = torchmetrics.functional.structural_similarity_index_measure(data_range=1).
     torchmetrics is an un-pinned pip dependency of the reference (requirements.txt:18) that is absent from this image, so this is a

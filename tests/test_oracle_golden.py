@@ -252,6 +252,10 @@ def test_eval_metrics(golden_dir):
     r = (real_I - real_I.min()) / (real_I.max() - real_I.min())
     f = ((fake_I - real_I.min()) / (real_I.max() - real_I.min())).clamp(0, 1)
     assert abs(m["I_PSNR"] - float(-10 * torch.log10(((r - f) ** 2).mean()))) < 1e-4
+    for i in range(len(nets.FRECHET_CASES)):       # Frechet distance vs the reference's calculate_frechet_distance
+        f1, f2 = nets.frechet_case(i, seed)
+        ref = float(g["fd/%d" % i])
+        assert abs(nets.frechet_distance(f1, f2) - ref) <= 1e-9 * max(1.0, abs(ref)), i
 
 
 def test_resnet_state_dict_keys(golden_dir):

@@ -358,3 +358,19 @@ def test_style_code_generator_matches_reference_golden(golden_dir):
         if null_grad_bias("G", k):
             continue
         probe_close(p.grad, g["G_grad/" + k], k, 1e-3)
+
+
+def test_frechet_distance_matches_reference(golden_dir):
+    """vts_frechet_distance (float64 moments + Newton-Schulz matrix square root) vs the REFERENCE's calculate_frechet_distance on
+    synthetic features (tests/golden/metrics.npz) and vs the oracle restatement (scipy sqrtm)"""
+    from vts import ops
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    seed = int(g["seed"])
+    dev = torch.device("cuda:0")
+    for i in range(len(nets.FRECHET_CASES)):
+        f1, f2 = nets.frechet_case(i, seed)
+        got = float(ops.frechet_distance(f1.to(dev), f2.to(dev)).cpu())
+        ref = float(g["fd/%d" % i])
+        assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (i, got, ref, nets.frechet_distance(f1, f2))
+    f1, _ = nets.frechet_case(0, seed)
+    assert abs(float(ops.frechet_distance(f1.to(dev), f1.to(dev)).cpu())) < 1e-4      # identical sets: 0

@@ -144,6 +144,137 @@ __global__ __launch_bounds__(256) void ssim_partial_kernel(const SsimK p) {
   if (threadIdx.x == 0) p.part[blockIdx.x] = acc;
 }
 
+// ---- Fréchet distance between two feature sets (SIFID glue, reference models/sifid.py:102-176: calculate_activation_statistics
+// = np.mean / np.cov(rowvar=False) in float64, calculate_frechet_distance = |mu1-mu2|^2 + tr(S1) + tr(S2) - 2 tr(sqrtm(S1 S2)) with
+// scipy's sqrtm).  Features are channel-major [D, P] (one image's NCHW feature map, D <= 64 channels, P positions).  Moments are
+// accumulated in float64 by FD_BLOCKS workgroups (fixed order: deterministic); tr(sqrtm(S1 S2)) by a coupled Newton-Schulz iteration in
+// float64 on the 64 x 64 matrices in LDS (one workgroup): Y <- Y (3I - ZY) / 2, Z <- (3I - ZY) Z / 2 from Y = A / |A|_F, Z = I, so that
+// Y -> sqrtm(A / |A|_F); 60 iterations cover condition numbers up to ~2^60.
+constexpr int FD_D = 64, FD_BLOCKS = 128, FD_CHUNK = 64;
+
+__global__ __launch_bounds__(256) void fd_moments_partial_kernel(const float* __restrict__ f, int D, int64_t P, double* __restrict__ part) {
+  __shared__ float tile[FD_D][FD_CHUNK + 1];
+  const int tid = threadIdx.x;
+  double sx = 0.0, sxx[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sxx[i] = 0.0;
+  const int d0 = tid >> 2, e0 = (tid & 3) * 16;      // this thread's 16 (d, e) pairs: d = d0, e = e0 .. e0 + 15
+  for (int64_t base = (int64_t)blockIdx.x * FD_CHUNK; base < P; base += (int64_t)gridDim.x * FD_CHUNK) {
+    __syncthreads();
+    for (int e = tid; e < FD_D * FD_CHUNK; e += 256) {
+      const int d = e / FD_CHUNK, j = e - d * FD_CHUNK;
+      tile[d][j] = (d < D && base + j < P) ? f[(int64_t)d * P + base + j] : 0.f;
+    }
+    __syncthreads();
+    for (int j = 0; j < FD_CHUNK; ++j) {
+      const double a = tile[d0][j];
+      if ((tid & 3) == 0) sx += a;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sxx[i] += a * (double)tile[e0 + i][j];
+    }
+  }
+  double* o = part + (int64_t)blockIdx.x * (FD_D + FD_D * FD_D);
+  if ((tid & 3) == 0) o[d0] = sx;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[FD_D + d0 * FD_D + e0 + i] = sxx[i];
+}
+
+// mean [64] and unbiased covariance [64][64] (zero rows / columns beyond D) from the partial raw moments
+__global__ __launch_bounds__(256) void fd_moments_final_kernel(const double* __restrict__ part, int nb, int D, int64_t P, double* __restrict__ stat) {
+  const int tid = threadIdx.x;
+  __shared__ double mu[FD_D];
+  if (tid < FD_D) {
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(int64_t)b * (FD_D + FD_D * FD_D) + tid];
+    mu[tid] = s / (double)P;
+    stat[tid] = mu[tid];
+  }
+  __syncthreads();
+  for (int e = tid; e < FD_D * FD_D; e += 256) {
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(int64_t)b * (FD_D + FD_D * FD_D) + FD_D + e];
+    const int d = e / FD_D, c = e - d * FD_D;
+    stat[FD_D + e] = (d < D && c < D) ? (s - (double)P * mu[d] * mu[c]) / (double)(P - 1) : 0.0;
+  }
+}
+
+// 64 x 64 float64 matrix steps of the Newton-Schulz iteration, one workgroup each (a workgroup may hold at most 64 KB of LDS -- two
+// such matrices -- so the iteration runs as a chain of small launches on global scratch; kernel boundaries order them)
+__global__ __launch_bounds__(256) void fd_init_kernel(const double* __restrict__ st1, const double* __restrict__ st2, double* __restrict__ Y,
+                                                      double* __restrict__ Z, double* __restrict__ nrm_out) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  const double *S1 = st1 + FD_D, *S2 = st2 + FD_D;
+  double a[16], fro = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + i * 256, r = e / FD_D, c = e - r * FD_D;
+    double s = 0.0;
+    for (int k = 0; k < FD_D; ++k) s += S1[r * FD_D + k] * S2[k * FD_D + c];
+    a[i] = s;
+    fro += s * s;
+  }
+  red[tid] = fro;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double nrm = sqrt(red[0]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + i * 256, r = e / FD_D, c = e - r * FD_D;
+    Y[e] = nrm > 0.0 ? a[i] / nrm : 0.0;
+    Z[e] = r == c ? 1.0 : 0.0;
+  }
+  if (tid == 0) nrm_out[0] = nrm;
+}
+
+// T = 3I - Z Y
+__global__ __launch_bounds__(256) void fd_t_kernel(const double* __restrict__ Y, const double* __restrict__ Z, double* __restrict__ T) {
+  const int tid = threadIdx.x;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + i * 256, r = e / FD_D, c = e - r * FD_D;
+    double s = 0.0;
+    for (int k = 0; k < FD_D; ++k) s += Z[r * FD_D + k] * Y[k * FD_D + c];
+    T[e] = (r == c ? 3.0 : 0.0) - s;
+  }
+}
+
+// Y2 = Y T / 2, Z2 = T Z / 2
+__global__ __launch_bounds__(256) void fd_yz_kernel(const double* __restrict__ Y, const double* __restrict__ Z, const double* __restrict__ T,
+                                                    double* __restrict__ Y2, double* __restrict__ Z2) {
+  const int tid = threadIdx.x;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + i * 256, r = e / FD_D, c = e - r * FD_D;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < FD_D; ++k) {
+      a += Y[r * FD_D + k] * T[k * FD_D + c];
+      b += T[r * FD_D + k] * Z[k * FD_D + c];
+    }
+    Y2[e] = 0.5 * a;
+    Z2[e] = 0.5 * b;
+  }
+}
+
+__global__ __launch_bounds__(64) void fd_final_kernel(const double* __restrict__ st1, const double* __restrict__ st2, const double* __restrict__ Y,
+                                                      const double* __restrict__ nrm, int D, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const double *S1 = st1 + FD_D, *S2 = st2 + FD_D;
+    double tr = 0.0, t1 = 0.0, t2 = 0.0, dm = 0.0;
+    for (int d = 0; d < D; ++d) {
+      tr += Y[d * FD_D + d];
+      t1 += S1[d * FD_D + d];
+      t2 += S2[d * FD_D + d];
+      const double df = st1[d] - st2[d];
+      dm += df * df;
+    }
+    out[0] = (float)(dm + t1 + t2 - 2.0 * sqrt(nrm[0]) * tr);
+  }
+}
+
 inline int nblocks(int64_t n) {
   const int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > MB ? MB : b));
@@ -197,5 +328,37 @@ extern "C" int vts_metric_ssim(const float* real, const float* fake, int NC, int
   hipLaunchKernelGGL(ssim_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, k);
   hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, 1.f / ((float)NC * (float)(H - 10) * (float)(W - 10)), 0, out);
   VTS_CHECK_LAUNCH("vts_metric_ssim");
+  return VTS_OK;
+}
+
+extern "C" int64_t vts_frechet_ws_floats(void) { return 2 * ((int64_t)2 * (FD_BLOCKS + 1) * (FD_D + FD_D * FD_D) + 5 * FD_D * FD_D + 2); }
+
+extern "C" int vts_frechet_distance(const float* feat1, const float* feat2, int D, int64_t P1, int64_t P2, float* out, float* ws, void* stream) {
+  VTS_CHECK_ARG(feat1 && feat2 && out && ws && D >= 1 && D <= FD_D && P1 >= 2 && P2 >= 2, "vts_frechet_distance: bad args (D <= 64, P >= 2)");
+  VTS_CHECK_ARG(((uintptr_t)ws & 7) == 0, "vts_frechet_distance: ws must be 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per = FD_D + FD_D * FD_D, MM = FD_D * FD_D;
+  double* w = reinterpret_cast<double*>(ws);
+  double* part[2] = {w, w + (FD_BLOCKS + 1) * per};
+  double* stat[2] = {part[0] + FD_BLOCKS * per, part[1] + FD_BLOCKS * per};
+  double* mats = w + 2 * (FD_BLOCKS + 1) * per;
+  double *Y = mats, *Z = mats + MM, *T = mats + 2 * MM, *Y2 = mats + 3 * MM, *Z2 = mats + 4 * MM, *nrm = mats + 5 * MM;
+  const float* f[2] = {feat1, feat2};
+  const int64_t P[2] = {P1, P2};
+  for (int i = 0; i < 2; ++i) {
+    const int64_t chunks = (P[i] + FD_CHUNK - 1) / FD_CHUNK;
+    const int nb = (int)(chunks < FD_BLOCKS ? chunks : FD_BLOCKS);
+    hipLaunchKernelGGL(fd_moments_partial_kernel, dim3(nb), dim3(256), 0, st, f[i], D, P[i], part[i]);
+    hipLaunchKernelGGL(fd_moments_final_kernel, dim3(1), dim3(256), 0, st, part[i], nb, D, P[i], stat[i]);
+  }
+  hipLaunchKernelGGL(fd_init_kernel, dim3(1), dim3(256), 0, st, stat[0], stat[1], Y, Z, nrm);
+  for (int it = 0; it < 60; ++it) {      // 60 iterations: condition numbers up to ~2^60
+    hipLaunchKernelGGL(fd_t_kernel, dim3(1), dim3(256), 0, st, Y, Z, T);
+    hipLaunchKernelGGL(fd_yz_kernel, dim3(1), dim3(256), 0, st, Y, Z, T, Y2, Z2);
+    double* t = Y; Y = Y2; Y2 = t;
+    t = Z; Z = Z2; Z2 = t;
+  }
+  hipLaunchKernelGGL(fd_final_kernel, dim3(1), dim3(64), 0, st, stat[0], stat[1], Y, nrm, D, out);
+  VTS_CHECK_LAUNCH("vts_frechet_distance");
   return VTS_OK;
 }

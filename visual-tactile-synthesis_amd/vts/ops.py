@@ -718,6 +718,18 @@ def eval_metrics(real_I, fake_I, real_T, fake_T):
     return out[2:]
 
 
+def frechet_distance(f1, f2):
+    """Frechet distance (the arithmetic of SIFID, models/sifid.py:102-176) between two channel-major feature sets [D, P1] / [D, P2]
+    (D <= 64); returns a 1-element device tensor"""
+    lib = L.load()
+    d, p1 = f1.shape
+    assert f2.shape[0] == d and f1.is_contiguous() and f2.is_contiguous()
+    ws = workspace(lib.vts_frechet_ws_floats(), f1.device)
+    out = torch.empty(1, dtype=torch.float32, device=f1.device)
+    L.check(lib.vts_frechet_distance(f1.data_ptr(), f2.data_ptr(), d, p1, f2.shape[1], out.data_ptr(), ws.data_ptr(), L.stream()), "vts_frechet_distance")
+    return out
+
+
 def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     lib = L.load()
     L.check(lib.vts_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
