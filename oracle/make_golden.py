@@ -425,6 +425,20 @@ def golden_metrics(seed=606):
     print("wrote metrics.npz", out)
 
 
+def golden_io():
+    """util.tensor2im / tensor2arr of the reference (util/util.py:58-122) on a ramp tensor"""
+    from oracle import ref_import
+
+    ref_import.load()
+    from util import util as ru
+
+    x = torch.linspace(-1.5, 1.5, 2 * 3 * 4 * 5).reshape(2, 3, 4, 5)
+    out = {"im_rgb": ru.tensor2im(x), "im_gray": ru.tensor2im(x[:, :1]), "im_2d": ru.tensor2im(x[0, 0]),
+           "arr_gray": ru.tensor2arr(x[:1, :1], imtype=np.float32), "arr_rgb": ru.tensor2arr(x[:1])}
+    np.savez_compressed(os.path.join(GOLD, "image_io.npz"), **out)
+    print("wrote image_io.npz", {k: v.shape for k, v in out.items()})
+
+
 def golden_sg2(size=32, seed=808, ndf=8, input_nc=4, n=3):
     """StyleGAN2 blocks: the reference's StyleGAN2Discriminator forward + gradients, upfirdn2d in several
     up / down / pad configurations, fused_leaky_relu, ModulatedConv2d (plain / upsample / downsample) with a style vector."""
@@ -537,7 +551,7 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step", "style"]
+    which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step", "style", "io"]
     if "ops" in which:
         golden_ops()
     if "nets" in which:
@@ -560,3 +574,5 @@ if __name__ == "__main__":
         golden_step_sg2d()
     if "style" in which:
         golden_nets_style()
+    if "io" in which:
+        golden_io()

@@ -14,6 +14,7 @@ import torch  # noqa: E402
 from data import create_dataset  # noqa: E402
 from models import create_model  # noqa: E402
 from options.test_options import TestOptions  # noqa: E402
+from util.image_io import save_images  # noqa: E402
 
 if __name__ == "__main__":
     opt = TestOptions().parse()
@@ -43,6 +44,9 @@ if __name__ == "__main__":
         visuals = model.get_current_visuals()
         name = data["name"][0] if isinstance(data["name"], (list, tuple)) else data["name"]
         torch.save({k: v.detach().cpu() for k, v in visuals.items() if torch.is_tensor(v)}, os.path.join(out_dir, "%s.pt" % name))
+        # the files the reference's save_images writes (test.py:93): PNG per visual, raw gx / gy as .npz (and .npy on request)
+        save_images(os.path.join(out_dir, "images"), visuals, name, save_raw_gxgy=True,
+                    save_raw_arr_vis=bool(getattr(opt, "save_raw_arr_vis", False)))
         print("processed %s in %.2f ms (%d images)" % (name, dt * 1e3, data["S"].size(0)))
         if hasattr(model, "compute_metrics"):
             model.compute_metrics()
