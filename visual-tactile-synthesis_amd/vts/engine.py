@@ -667,7 +667,19 @@ def _flat4(conv, j, h, w, oh, ow, st):
     return co >= 128 and co % 4 == 0 and ci % 4 == 0
 
 
-def _msd_scale_forward(D, s, a0, a1, update_stats):
+def _packed4(conv, mode, cache):
+    """16-tap packing of a PatchGAN layer's weight, once per discriminator invocation: the passes of one scale run back to back in
+    one lane and the weights only change between invocations (Adam), so `cache` (created per msd_multi / msd_forward call) is safe"""
+    if cache is None:
+        return ops.w4x4_pack(conv.weight, mode)
+    key = (id(conv), mode)
+    buf = cache.get(key)
+    if buf is None:
+        buf = cache[key] = ops.w4x4_pack(conv.weight, mode)
+    return buf
+
+
+def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None):
     """one PatchGAN of the pyramid: returns the list of layer outputs (Act), the last one is the prediction"""
     n, dev = a0.data.shape[0], a0.data.device
     layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
@@ -684,7 +696,7 @@ def _msd_scale_forward(D, s, a0, a1, update_stats):
             ph, pw = st * (oh - 1) + 4, st * (ow - 1) + 4
             p = ops.pad_affine(cur0, (2, ph - h - 2, 2, pw - w - 2), 0, act=LRELU)
             cur0.padded = p
-            ops.conv4x4_wide(p, ops.w4x4_pack(conv.weight, "conv_fwd"), conv.bias, out, stride=st)
+            ops.conv4x4_wide(p, _packed4(conv, "conv_fwd", cache), conv.bias, out, stride=st)
         else:
             ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
                         act_in=LRELU if j else 0)
@@ -702,7 +714,7 @@ def _msd_scale_forward(D, s, a0, a1, update_stats):
     return acts
 
 
-def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad):
+def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad, cache=None):
     """backward of one PatchGAN; returns the gradient w.r.t. the second concat source (or None)"""
     layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
     for j in range(len(D.CONV_IDX) - 1, -1, -1):
@@ -732,9 +744,9 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
             if _flat4(conv, j, h, w, oh, ow, st) and (cin % 4 == 0 or ops.conv4x4_flat_ok(h, w, qh, qw, st == 2)):
                 raw = torch.empty_like(prev.data)
                 if st == 1:   # adjoint of the stride-1 conv: the same operator on the padded gradient, flipped taps
-                    ops.conv4x4_wide(ops.pad_affine(g, (1, 1, 1, 1), 0), ops.w4x4_pack(conv.weight, "conv_adj"), None, raw)
+                    ops.conv4x4_wide(ops.pad_affine(g, (1, 1, 1, 1), 0), _packed4(conv, "conv_adj", cache), None, raw)
                 else:
-                    ops.conv4x4_wide(ops.pad_affine(g, (0, 1, 0, 1), 0), ops.w4x4_pack(conv.weight, "conv_s2_adj"), None, raw,
+                    ops.conv4x4_wide(ops.pad_affine(g, (0, 1, 0, 1), 0), _packed4(conv, "conv_s2_adj", cache), None, raw,
                                      stride=2, transposed=True)
                 ops.act_bwd(raw, prev, LRELU, tgt)
             else:
@@ -855,9 +867,10 @@ def _msd_multi(jobs, criterion):
 
     def lane(i):
         D, s, passes = lanes[i]
+        cache = {}      # packed weights of this scale: shared by its passes (they run in order in this lane)
         for p in passes:
             a0, a1 = p["_pyr"][s]
-            acts = _msd_scale_forward(D, s, a0, a1, True)
+            acts = _msd_scale_forward(D, s, a0, a1, True, cache)
             pred = acts[-1].data
             p["preds"][s] = pred
             if not p.get("loss", True):
@@ -866,7 +879,7 @@ def _msd_multi(jobs, criterion):
             g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None)[0]
             if gc is not None:
                 p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
-                                                   p.get("input_grad") is not None)
+                                                   p.get("input_grad") is not None, cache)
 
     _run_lanes(len(lanes), lane)
     for D, passes in jobs:
