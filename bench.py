@@ -237,6 +237,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(1234 + rank)      # per-rank DiffAugment draws (the default generator is seeded identically on every rank)
     if args.infer:
         return infer_bench(args)
     model, opt = build_model(args.size, args.batch, args.model, netG=args.netG)

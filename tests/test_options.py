@@ -54,7 +54,8 @@ def test_synthetic_dataset_contract():
     from data import create_dataset
     from options.train_options import TrainOptions
 
-    opt = parse(TrainOptions, "--model skitG --gpu_ids -1 --crop_size 64 --batch_size 2 --data_len 4 --checkpoints_dir /tmp/vts_opt")
+    opt = parse(TrainOptions, "--model skitG --gpu_ids -1 --dataset_mode synthetic --crop_size 64 --batch_size 2 --data_len 4 "
+                              "--checkpoints_dir /tmp/vts_opt")
     ds = create_dataset(opt)
     assert len(ds) == 4
     b = next(iter(ds))
@@ -64,3 +65,28 @@ def test_synthetic_dataset_contract():
     assert b["style_code"].shape == (2, 512)
     assert abs(float(b["style_code"][0].norm()) - 1) < 1e-5
     assert set(b["augmentation_params"]) >= {"H", "W", "scale_factor_h", "crop_pos_x", "resize_ratio_w"}
+
+
+def test_unbuilt_dataset_modes_raise_instead_of_aliasing():
+    """a reference dataset mode whose front-end is not built must never resolve to synthetic noise"""
+    from data import create_dataset
+    from options.train_options import TrainOptions
+
+    opt = parse(TrainOptions, "--model skitG --gpu_ids -1 --dataset_mode skit --checkpoints_dir /tmp/vts_opt")
+    with pytest.raises(NotImplementedError, match="dataset_mode skit"):
+        create_dataset(opt)
+
+
+def test_rank_device_comes_from_local_rank(monkeypatch):
+    """torchrun launches: parse() binds the process to cuda:LOCAL_RANK even though --gpu_ids defaults to 0"""
+    import torch
+    from options.train_options import TrainOptions
+
+    chosen = []
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: chosen.append(i))
+    opt = parse(TrainOptions, "--model skitG --gpu_ids 0 --dataset_mode synthetic --checkpoints_dir /tmp/vts_opt")
+    assert opt.gpu_ids == [5] and chosen == [5]

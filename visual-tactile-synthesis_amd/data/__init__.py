@@ -1,29 +1,37 @@
 """Dataset factory (mirror of /root/reference/data/__init__.py:17-104).
 
-Only a synthetic batch generator is built: the reference's CPU dataset front-end
-(PNG/npz loading, crop/zoom augmentation, patch bookkeeping) is SURVEY.md §8(f)
-row 3 and the TouchClothing data is not available offline.  `singleskit` and
-`skit` therefore resolve to the synthetic dataset, which honours the same
-post-collate batch-dict contract.
+`--dataset_mode synthetic` is the seeded generator bench.py / the tests use (same post-collate batch-dict contract, SURVEY.md
+§8b).  A dataset mode whose front-end is not built in this package RAISES when a dataset is created -- it is never silently
+replaced by synthetic noise (a maintainer pointing --dataroot at real TouchClothing data must not train on noise).
 """
 import importlib
 
 import torch.utils.data
 
-_ALIASES = {"singleskit": "synthetic", "skit": "synthetic", "patchskit": "synthetic", "aligned": "synthetic"}
+# reference dataset modes whose CPU front-end is not built here: their option setter resolves (the reference parser asks for it
+# while gathering options, options/base_options.py:238-240) but create_dataset refuses them
+_UNBUILT = ("singleskit", "skit", "patchskit", "aligned")
 
 
 def find_dataset_using_name(dataset_name):
-    resolved = _ALIASES.get(dataset_name, dataset_name)
-    lib = importlib.import_module("data." + resolved + "_dataset")
-    target = resolved.replace("_", "") + "dataset"
+    if dataset_name in _UNBUILT:
+        raise NotImplementedError(
+            "--dataset_mode %s: this dataset front-end is not built in the MI355X package (SURVEY.md 8f-3). Use --dataset_mode "
+            "singleskit for TouchClothing material folders or --dataset_mode synthetic for the seeded generator." % dataset_name)
+    try:
+        lib = importlib.import_module("data." + dataset_name + "_dataset")
+    except ImportError as e:
+        raise NotImplementedError("--dataset_mode %s: no module data/%s_dataset.py (%s)" % (dataset_name, dataset_name, e))
+    target = dataset_name.replace("_", "") + "dataset"
     for name, cls in lib.__dict__.items():
         if name.lower() == target.lower() and isinstance(cls, type):
             return cls
-    raise NotImplementedError("no dataset class matching %s in data/%s_dataset.py" % (target, resolved))
+    raise NotImplementedError("no dataset class matching %s in data/%s_dataset.py" % (target, dataset_name))
 
 
 def get_option_setter(dataset_name):
+    if dataset_name in _UNBUILT:
+        return lambda parser, is_train: parser   # flags of an unbuilt front-end: none; creating the dataset raises
     return find_dataset_using_name(dataset_name).modify_commandline_options
 
 

@@ -148,6 +148,11 @@ class BaseOptions:
         self.print_options(opt)
         ids = [int(s) for s in opt.gpu_ids.split(",")]
         opt.gpu_ids = [i for i in ids if i >= 0]
+        # one process per GPU (torchrun): the rank's device is LOCAL_RANK, whatever --gpu_ids says (its default "0" would
+        # otherwise put every rank of a data-parallel launch on GPU 0)
+        if opt.gpu_ids and int(os.environ.get("WORLD_SIZE", "1")) > 1 and "LOCAL_RANK" in os.environ:
+            ndev = torch.cuda.device_count() if torch.cuda.is_available() else 1
+            opt.gpu_ids = [int(os.environ["LOCAL_RANK"]) % max(ndev, 1)]
         if opt.gpu_ids and torch.cuda.is_available():
             torch.cuda.set_device(opt.gpu_ids[0])
         self.opt = opt

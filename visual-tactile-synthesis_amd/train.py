@@ -55,8 +55,8 @@ if __name__ == "__main__":
     rank, world = ddp.init_from_env("cuda")
     opt = TrainOptions().parse()
     opt.rank, opt.world_size = rank, world
-    if world > 1:
-        opt.gpu_ids = [torch.cuda.current_device()]
+    # parse() bound this process to cuda:LOCAL_RANK; every rank draws its own DiffAugment / sampler stream
+    torch.manual_seed(1234 + rank)
     dataset = create_dataset(opt)
     dataset_size = len(dataset)
     model = create_model(opt)
