@@ -10,6 +10,8 @@
 // combined through LDS in a fixed order; the PW partials are summed by a second kernel in
 // a fixed order, so the result is deterministic (no float atomics).
 // Both operands are (dual-source, normalise-on-load) like in vts_conv.hip.
+#include <stdlib.h>
+
 #include "vts_internal.h"
 
 namespace {
@@ -21,6 +23,7 @@ struct Src {
   int act;
   float slope;         // activation as t > 0 ? t : slope * t
   const float* ident;  // {1, 0}
+  int plain;           // neither source has an affine and there is no activation: values are used as loaded
 };
 
 struct WgK {
@@ -29,6 +32,7 @@ struct WgK {
   int cl_groups, ch_groups;
   int tiles_y, tiles_x, ntiles;
   float* part;  // [PW][CL][CH][16]
+  int ablate;   // profiling only (env VTS_ABLATE): 1 skip the global loads, 2 skip the MFMA phase, 4 skip the LDS staging stores
 };
 
 // Staging discipline as in vts_conv.hip: every global load is unconditional on a clamped (always valid)
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
 #pragma unroll
     for (int e = 0; e < NHT; ++e) {
       const int idx = min(tid + e * 256, CHT * PRH * TW - 1);
-      const int rr = idx / TW, col = PCM + (idx - rr * TW);
+      const int rr = idx / (TW > 0 ? TW : 1), col = PCM + (idx - rr * (TW > 0 ? TW : 1));
       const int h = rr / PRH, r = rr - h * PRH;
       ht[e] = src_ptr(p.hi, n, ch0 + h, hy0 + r, p.HH, p.HW)[min(max(hx0 + col, 0), p.HW - 1)];
     }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
 #pragma unroll
     for (int e = 0; e < NHT; ++e) {
       const int idx = tid + e * 256;
-      const int rr = min(idx / TW, CHT * PRH - 1), col = PCM + (idx - (idx / TW) * TW);
+      const int rr = min(idx / (TW > 0 ? TW : 1), CHT * PRH - 1), col = PCM + (idx - (idx / (TW > 0 ? TW : 1)) * (TW > 0 ? TW : 1));
       const int h = rr / PRH, r = rr - h * PRH;
       const int iy = hy0 + r, ix = hx0 + col;
       const bool ok = ch0 + h < p.hi.C && iy >= 0 && iy < p.HH && ix >= 0 && ix < p.HW;
@@ -275,6 +279,251 @@ __global__ __launch_bounds__(256) void wgrad4x4_kernel(const WgK p) {
   }
 }
 
+// ---- N-split member -------------------------------------------------------------------------------------------------
+// The four waves of a workgroup share ONE pixel tile (the GEMM's K) and split the high-resolution channels (the GEMM's N):
+// wave w owns channels [w*CHT, (w+1)*CHT) of the workgroup's 4*CHT and all CLT low-resolution channel tiles, so a staged
+// low-resolution tile feeds 4x the MFMA work of the K-split kernel above, the low-resolution operand is re-read by 4x fewer
+// channel groups, and there is no cross-wave reduction at the end (every wave writes its accumulators to its own slice of
+// the partial).  MFMA work of tile rows / column groups beyond the map edge is skipped (wave-uniform loop bounds), so
+// ragged maps (129, 130, 257, 513 wide) do not pay for the padding of their last tile.
+//
+// Staging goes through buffer loads whose descriptor is ONE CHANNEL PLANE (base = plane start, num_records = H*W*4):
+//   byte offset = [lane part: (half-wave row * W + x) * 4, or OOB for a column outside the row] + [uniform part: row * W * 4]
+// A row above / below the map makes the sum negative (= huge unsigned) / >= num_records, a column outside the row carries the
+// OOB sentinel, a channel beyond C gets num_records = 0: the hardware range check returns 0 for all of them (measured on
+// gfx950: per dword, soffset included; tools/probes/buffer_oob.hip).  So zero padding costs no instruction, the per-load
+// address arithmetic is one VALU add plus a handful of SALU instructions, and an operand without affine / activation (every
+// gradient) goes from the load straight to LDS.  The K-split kernel spends ~40 instructions per loaded dword on clamped 64-bit
+// addresses -- measured (ablation, profiles/r02_wgrad_ablation.txt): its loads, LDS stores and MFMAs do not overlap and the
+// first two cost as much as the MFMAs.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+struct TagT { static constexpr bool value = true; };
+struct TagF { static constexpr bool value = false; };
+constexpr unsigned OOB_OFF = 0x40000000u;   // byte offset beyond every channel plane (planes are < 2^26 bytes: checked by the host side)
+
+struct PlaneRef {
+  rsrc_t rs;
+  unsigned nrec;
+};
+
+// uniform: descriptor of channel plane c of one sample of a (dual-source) operand; b0 / b1 are the sample bases of the two sources
+__device__ __forceinline__ PlaneRef plane_ref(const Src& s, const float* b0, const float* b1, int c, int plane) {
+  const bool cok = c < s.C;
+  const int cc = cok ? c : 0;
+  const bool first = cc < s.C0;
+  const float* base = (first ? b0 : b1) + (int64_t)(first ? cc : cc - s.C0) * plane;
+  PlaneRef r;
+  r.nrec = cok ? (unsigned)plane * 4u : 0u;
+  r.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)r.nrec, 0x00020000);
+  return r;
+}
+
+__device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+}
+
+template <int S, int CLT, int CHT>
+__global__ __launch_bounds__(256) void wgrad4x4_ns_kernel(const WgK p) {
+  constexpr int TY = S == 2 ? 2 : 4;          // tile rows (even: a low-resolution wave instruction covers two rows, one per half-wave)
+  constexpr int TX = 28, KSTEPS = TX / 4;     // 28 pixels: the high-resolution patch row (58 / 31 columns) fits one wave / half-wave
+  constexpr int TXLP = 30;                    // A reads: bank = (-2 * channel + k) mod 32 -> conflict-free
+  constexpr int CLP = CLT * 16, CHW = 4 * CHT;
+  constexpr int PRH = (TY - 1) * S + 4;       // 6 / 7 patch rows
+  constexpr int PCH = (TX - 1) * S + 4;       // 58 / 31 patch columns
+  constexpr int PCHP = S == 2 ? 72 : 40;      // = 8 (mod 32): B reads hit banks 8*ky + kx + S*k
+  constexpr int HRP = S == 2 ? 1 : 2;         // patch rows per wave instruction
+  constexpr int HLPC = (PRH + HRP - 1) / HRP; // wave instructions per high-resolution channel: 6 / 4
+  constexpr int NLO = (TY / 2) * CLP / 4;     // low-resolution (row pair, channel) lines per wave
+  constexpr int NHL = (CHW * HLPC + 3) / 4;   // high-resolution lines per wave
+  constexpr int LO_FLOATS = TY * CLP * TXLP;
+  constexpr int HI_FLOATS = CHW * PRH * PCHP;
+  __shared__ float lds[LO_FLOATS + HI_FLOATS + 2 * (CLP + CHW)];
+  float* lo = lds;
+  float* hi = lds + LO_FLOATS;
+  float* aff_sc = hi + HI_FLOATS;
+  float* aff_sh = aff_sc + CLP + CHW;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15, kq = lane >> 4;
+  const int half = lane >> 5, xl = lane & 31;
+  const int clg = blockIdx.y / p.ch_groups, chg = blockIdx.y - clg * p.ch_groups;
+  const int cl0 = clg * CLP, ch0 = chg * CHW;
+  const int lplane = p.LH * p.LW, hplane = p.HH * p.HW;
+  const bool lo_plain = p.lo.plain != 0, hi_plain = p.hi.plain != 0;   // uniform: no affine, no activation
+
+  f32x4 acc[CLT][CHT];
+#pragma unroll
+  for (int t = 0; t < CLT; ++t)
+#pragma unroll
+    for (int h = 0; h < CHT; ++h) acc[t][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float lv[NLO], hv[NHL];
+#pragma unroll
+  for (int i = 0; i < NLO; ++i) lv[i] = 1.f;
+#pragma unroll
+  for (int i = 0; i < NHL; ++i) hv[i] = 1.f;
+  float asc = 1.f, ash = 0.f;
+
+  struct Tile {
+    int n, y0, x0;
+    unsigned lo_vo, hi_vo;   // lane parts of the byte offsets
+  };
+  auto decode = [&](int tile) {
+    Tile t;
+    t.n = tile / (p.tiles_y * p.tiles_x);
+    const int rem = tile - t.n * (p.tiles_y * p.tiles_x);
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    t.y0 = ty * TY;
+    t.x0 = tx * TX;
+    const int x = t.x0 + xl;
+    t.lo_vo = (xl < TX && x < p.LW) ? (unsigned)(half * p.LW + x) * 4u : OOB_OFF;
+    const int col = HRP == 2 ? xl : lane, ix = t.x0 * S - p.padx + col;
+    t.hi_vo = (col < PCH && ix >= 0 && ix < p.HW) ? (unsigned)((HRP == 2 ? half * p.HW : 0) + ix) * 4u : OOB_OFF;
+    return t;
+  };
+  // Each wave stages whole channels (CLP/4 low-resolution, CHT high-resolution ones), so one plane descriptor serves all
+  // lines of a channel.  The channel index carries an opaque zero that is re-read per tile: without it LLVM hoists the
+  // (tile-invariant) per-line descriptors out of the tile loop and spills ~200 SGPRs through v_writelane / v_readlane.
+  auto opaque_zero = []() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+  };
+  constexpr int LCW = CLP / 4;       // low-resolution channels per wave
+  constexpr int LRP = TY / 2;        // row pairs per tile
+  static_assert(NLO == LCW * LRP && NHL == CHT * HLPC, "line counts");
+
+  auto load_tile = [&](const Tile& t) {
+    if (tid < CLP) src_affine(p.lo, t.n, cl0 + tid, asc, ash);
+    else if (tid < CLP + CHW) src_affine(p.hi, t.n, ch0 + tid - CLP, asc, ash);
+    const int z = opaque_zero();
+    const float* lb0 = p.lo.d0 + t.n * p.lo.ns0;
+    const float* lb1 = p.lo.d1 + t.n * p.lo.ns1;
+    const float* hb0 = p.hi.d0 + t.n * p.hi.ns0;
+    const float* hb1 = p.hi.d1 + t.n * p.hi.ns1;
+    const unsigned lrow0 = (unsigned)(t.y0 * p.LW * 4), lstep = (unsigned)(2 * p.LW * 4);
+#pragma unroll
+    for (int j = 0; j < LCW; ++j) {
+      const PlaneRef r = plane_ref(p.lo, lb0, lb1, cl0 + wave + 4 * j + z, lplane);
+#pragma unroll
+      for (int rp = 0; rp < LRP; ++rp) lv[j * LRP + rp] = ld_buf(r.rs, t.lo_vo + lrow0 + rp * lstep);
+    }
+    const unsigned hrow0 = (unsigned)((t.y0 * S - p.pad) * p.HW * 4), hstep = (unsigned)(HRP * p.HW * 4);
+#pragma unroll
+    for (int j = 0; j < CHT; ++j) {
+      const PlaneRef r = plane_ref(p.hi, hb0, hb1, ch0 + wave * CHT + j + z, hplane);
+#pragma unroll
+      for (int q = 0; q < HLPC; ++q) hv[j * HLPC + q] = ld_buf(r.rs, t.hi_vo + hrow0 + q * hstep);
+    }
+  };
+
+  // LDS stores are unconditional: lanes beyond the tile / patch width write the pad column of their line, and the half-wave
+  // whose patch row does not exist (odd PRH, last row pair) writes the pad column of row 0 (no exec-mask branch per store).
+  auto store_lo = [&](const Tile& t, int z, auto plain_tag) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;
+    float* dst = lo + half * CLP * TXLP + min(xl, TX);
+    const unsigned lrow0 = (unsigned)(t.y0 * p.LW * 4), lstep = (unsigned)(2 * p.LW * 4);
+#pragma unroll
+    for (int j = 0; j < LCW; ++j) {
+      const int cl = wave + 4 * j + z;
+      const unsigned nrec = cl0 + cl < p.lo.C ? (unsigned)lplane * 4u : 0u;
+      float sc = 1.f, sh = 0.f;
+      if (!PLAIN) {
+        sc = aff_sc[cl];
+        sh = aff_sh[cl];
+      }
+#pragma unroll
+      for (int rp = 0; rp < LRP; ++rp) {
+        float v = lv[j * LRP + rp];
+        if (!PLAIN) v = finish(v, sc, sh, p.lo.slope, t.lo_vo + lrow0 + rp * lstep < nrec);
+        dst[(2 * rp * CLP + cl) * TXLP] = v;
+      }
+    }
+  };
+  auto store_hi = [&](const Tile& t, int z, auto plain_tag) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;
+    const int col = min(HRP == 2 ? xl : lane, PCH);
+    float* dst = hi + (HRP == 2 ? half * PCHP : 0) + col;
+    float* dst_last = (HRP == 2 && (PRH & 1) && half) ? hi + PCH - (HLPC - 1) * HRP * PCHP : dst;
+    const unsigned hrow0 = (unsigned)((t.y0 * S - p.pad) * p.HW * 4), hstep = (unsigned)(HRP * p.HW * 4);
+#pragma unroll
+    for (int j = 0; j < CHT; ++j) {
+      const int h = wave * CHT + j + z;
+      const unsigned nrec = ch0 + h < p.hi.C ? (unsigned)hplane * 4u : 0u;
+      float sc = 1.f, sh = 0.f;
+      if (!PLAIN) {
+        sc = aff_sc[CLP + h];
+        sh = aff_sh[CLP + h];
+      }
+#pragma unroll
+      for (int q = 0; q < HLPC; ++q) {
+        float v = hv[j * HLPC + q];
+        if (!PLAIN) v = finish(v, sc, sh, p.hi.slope, t.hi_vo + hrow0 + q * hstep < nrec);
+        (q == HLPC - 1 ? dst_last : dst)[(h * PRH + q * HRP) * PCHP] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&](const Tile& t) {
+    if (tid < CLP + CHW) {
+      aff_sc[tid] = asc;
+      aff_sh[tid] = ash;
+    }
+    __syncthreads();
+    const int z = opaque_zero();
+    if (lo_plain) store_lo(t, z, TagT());
+    else store_lo(t, z, TagF());
+    if (hi_plain) store_hi(t, z, TagT());
+    else store_hi(t, z, TagF());
+    __syncthreads();
+  };
+
+  Tile cur = decode(min((int)blockIdx.x, p.ntiles - 1));
+  if (!(p.ablate & 1)) load_tile(cur);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    if (!(p.ablate & 4)) store_tile(cur);
+    const int y0 = cur.y0, x0 = cur.x0;
+    const int next = tile + gridDim.x;
+    if (next < p.ntiles) {
+      cur = decode(next);
+      if (!(p.ablate & 1)) load_tile(cur);
+    }
+    const int nrow = (p.ablate & 2) ? 0 : min(TY, p.LH - y0), nxs = min(KSTEPS, (p.LW - x0 + 3) >> 2);   // uniform: skip the padding of edge tiles
+    for (int row = 0; row < nrow; ++row) {
+      const float* lrow = lo + (row * CLP + m16) * TXLP + kq;
+      const float* hrow = hi + (wave * CHT * PRH + row * S + (m16 >> 2)) * PCHP + kq * S + (m16 & 3);
+      for (int xs = 0; xs < nxs; ++xs) {
+        float a[CLT], b[CHT];
+#pragma unroll
+        for (int t = 0; t < CLT; ++t) a[t] = lrow[t * 16 * TXLP + xs * 4];
+#pragma unroll
+        for (int h = 0; h < CHT; ++h) b[h] = hrow[h * PRH * PCHP + xs * 4 * S];
+#pragma unroll
+        for (int t = 0; t < CLT; ++t)
+#pragma unroll
+          for (int h = 0; h < CHT; ++h) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[h], acc[t][h], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // D layout of a 16x16 tile: row (cl) = (lane>>4)*4 + reg, col (tap) = lane&15 -> 64-byte runs per (cl, ch)
+  const int CL = p.lo.C, CH = p.hi.C;
+  float* part = p.part + (int64_t)blockIdx.x * CL * CH * 16;
+#pragma unroll
+  for (int t = 0; t < CLT; ++t)
+#pragma unroll
+    for (int h = 0; h < CHT; ++h) {
+      const int ch = ch0 + wave * CHT + h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cl = cl0 + t * 16 + kq * 4 + r;
+        if (cl < CL && ch < CH) part[((int64_t)cl * CH + ch) * 16 + m16] = acc[t][h][r];
+      }
+    }
+}
+
 // Fixed-order sum of the PW partials.  64 consecutive elements per workgroup (one coalesced 256-B
 // row per wave-load), 16 waves each summing every 16th partial, combined through LDS in wave order.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int pw, float* __restrict__ dw,
@@ -297,11 +546,39 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 
 struct Plan {
   int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles, txl;
+  int ns;   // 1: N-split kernel (wgrad4x4_ns_kernel), cht = high-res channels per WAVE
 };
 
 Plan make_plan(const vts_wgrad_desc* d) {
   Plan pl;
   const int CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
+  pl.ns = 0;
+  static const int use_ns = getenv("VTS_WGRAD_NS") ? atoi(getenv("VTS_WGRAD_NS")) : 1;
+  // (the buffer-load addressing of the N-split kernel needs channel planes below 2^26 bytes)
+  if (use_ns && CH >= 5 && d->LW > 8 && (int64_t)d->HH * d->HW < (1 << 24) && (int64_t)d->LH * d->LW < (1 << 24)) {
+    // N-split kernel: the waves of a workgroup split 4*cht high-res channels; groups are balanced so that the last one is not mostly empty
+    pl.ns = 1;
+    pl.cl_groups = cdiv(CL, 80);
+    pl.clt = cdiv(CL, 16 * pl.cl_groups);
+    pl.ch_groups = cdiv(CH, 20);
+    pl.cht = cdiv(CH, 4 * pl.ch_groups);
+    if (pl.cht < 2) pl.cht = 2;
+    const int ty = d->stride == 2 ? 2 : 4;
+    pl.tiles_y = cdiv(d->LH, ty);
+    pl.txl = 28;
+    pl.tiles_x = cdiv(d->LW, 28);
+    pl.ntiles = d->N * pl.tiles_y * pl.tiles_x;
+    const int groups = pl.cl_groups * pl.ch_groups;
+    static const int ns_wgs = getenv("VTS_WGRAD_NS_WGS") ? atoi(getenv("VTS_WGRAD_NS_WGS")) : 512;
+    int pw = ns_wgs / groups;
+    const int64_t nel = (int64_t)CL * CH * 16;
+    const int64_t cap = (16 << 20) / nel;   // partials <= 64 MB
+    if (pw > cap) pw = (int)cap;
+    if (pw < 1) pw = 1;
+    if (pw > pl.ntiles) pw = pl.ntiles;
+    pl.pw = pw;
+    return pl;
+  }
   pl.clt = CL <= 16 ? 1 : CL <= 32 ? 2 : CL <= 48 ? 3 : 5;
   pl.cht = (CH <= 4 || CH > 10 || pl.clt == 5) ? 4 : 10;
   pl.cl_groups = cdiv(CL, pl.clt * 16);
@@ -328,6 +605,7 @@ void fill_src(Src& s, const vts_operand& a, const vts_operand& b, int act) {
   s.act = act;
   s.slope = vts_slope(act);
   s.ident = vts_ident();
+  s.plain = (act == VTS_ACT_NONE && !a.scale && !a.shift && !(b.data && (b.scale || b.shift))) ? 1 : 0;
 }
 
 template <int S, int CLT, int CHT>
@@ -336,6 +614,23 @@ void launch_wg(const WgK& k, const Plan& pl, hipStream_t st) {
   if (pl.txl == 8) hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT, 8>), grid, dim3(256), 0, st, k);
   else hipLaunchKernelGGL((wgrad4x4_kernel<S, CLT, CHT, 32>), grid, dim3(256), 0, st, k);
   vts_set_kernel("wgrad4x4_kernel<%d, %d, %d, %d>", S, CLT, CHT, pl.txl);
+}
+
+template <int S, int CLT, int CHT>
+void launch_ns(const WgK& k, const Plan& pl, hipStream_t st) {
+  hipLaunchKernelGGL((wgrad4x4_ns_kernel<S, CLT, CHT>), dim3(pl.pw, pl.cl_groups * pl.ch_groups), dim3(256), 0, st, k);
+  vts_set_kernel("wgrad4x4_ns_kernel<%d, %d, %d>", S, CLT, CHT);
+}
+
+template <int S>
+bool dispatch_ns(const WgK& k, const Plan& pl, hipStream_t st) {
+#define NS_CASE(CLT, CHT) \
+  if (pl.clt == CLT && pl.cht == CHT) { launch_ns<S, CLT, CHT>(k, pl, st); return true; }
+#define NS_ROW(CLT) NS_CASE(CLT, 2) NS_CASE(CLT, 3) NS_CASE(CLT, 4) NS_CASE(CLT, 5)
+  NS_ROW(1) NS_ROW(2) NS_ROW(3) NS_ROW(4) NS_ROW(5)
+#undef NS_ROW
+#undef NS_CASE
+  return false;
 }
 
 }  // namespace
@@ -361,10 +656,20 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   k.cl_groups = pl.cl_groups; k.ch_groups = pl.ch_groups;
   k.tiles_y = pl.tiles_y; k.tiles_x = pl.tiles_x; k.ntiles = pl.ntiles;
   k.part = ws;
+  static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
+  k.ablate = ablate;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nel = (int64_t)k.lo.C * k.hi.C * 16;
   // groups that end beyond CL/CH never write their out-of-range rows, and every in-range element is
   // written by exactly one (cl-group, ch-group) workgroup of every pixel worker.
+  if (pl.ns) {
+    const bool ok = d->stride == 2 ? dispatch_ns<2>(k, pl, st) : dispatch_ns<1>(k, pl, st);
+    VTS_CHECK_ARG(ok, "vts_wgrad4x4: no N-split instance for clt %d cht %d", pl.clt, pl.cht);
+    VTS_CHECK_LAUNCH("vts_wgrad4x4 (N-split)");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 64)), dim3(1024), 0, st, ws, nel, pl.pw, d->dw, d->accumulate);
+    VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
+    return VTS_OK;
+  }
 #define WG_CASE(S, CLT, CHT) \
   if (d->stride == S && pl.clt == CLT && pl.cht == CHT) launch_wg<S, CLT, CHT>(k, pl, st);
   WG_CASE(2, 1, 4) WG_CASE(2, 1, 10) WG_CASE(2, 2, 4) WG_CASE(2, 2, 10) WG_CASE(2, 3, 4) WG_CASE(2, 3, 10) WG_CASE(2, 5, 4)
