@@ -46,7 +46,16 @@ struct ConvK {
   float slope_in;      // input activation as t > 0 ? t : slope * t
   int identity_in;     // no affine on either source and no input activation
   int ablate;       // profiling only (env VTS_ABLATE): 1 skip global loads, 2 skip MFMA, 4 skip epilogue
+  int wbytes;       // extent of the weight tensor view in bytes (buffer descriptor of the weight loads)
 };
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned OOB_OFF = 0x40000000u;   // byte offset beyond every channel plane / weight tensor (the host side checks the sizes)
+struct TagT { static constexpr bool value = true; };
+struct TagF { static constexpr bool value = false; };
+__device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+}
 
 // Output staging region of one epilogue pass: 16 output channels x ER rows x EC columns, plane pitch odd
 // so that the 16 channel planes land on distinct LDS banks.
@@ -129,181 +138,144 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   const int nchunks = (p.Cin + CK - 1) / CK;
   const int chunk_begin = ks * p.cps;
   const int chunk_end = min(nchunks, (ks + 1) * p.cps);
-  const bool co_major = p.ws_co >= p.ws_ci;  // Conv2d layout: taps of (co, ci..ci+CK) are contiguous
 
-  // Software pipeline: the global loads of chunk k+1 (normalise + activate + concat applied on the
-  // fly) are issued into registers before the MFMA phase of chunk k and written to LDS after it.
-  float pv[NPV], tv[NTV], wv[NWV];
+  // Software pipeline: the global loads of chunk k+1 are issued into registers before the MFMA phase of chunk k and
+  // written to LDS (normalise + activate + concat resolved on the way) after it.
+  //
+  // Staging discipline (round 2; what it replaced spent ~40 instructions per loaded dword on clamped 64-bit addresses and
+  // spilled 35..150 SGPRs per instance through v_writelane / v_readlane):
+  //  * every load is a buffer load whose descriptor is ONE CHANNEL PLANE (base = plane start, num_records = IH*IW*4), with
+  //    byte offset = [lane part: column * 4, or the OOB sentinel for a column outside the row] + [uniform part: row * IW * 4].
+  //    A row above / below the map makes the sum negative (= huge unsigned) / >= num_records, a channel beyond Cin gets
+  //    num_records = 0: the hardware range check returns 0 (per dword, soffset included: tools/probes/buffer_oob.hip), so
+  //    zero padding costs no instruction and an operand without affine / activation goes straight from the load to LDS;
+  //  * wave w owns channel w of the chunk: one descriptor per wave and chunk, rows differ by a multiple of the row pitch;
+  //    the <= 3 columns beyond the 64-lane pieces of all rows are one extra load (lane -> (row, column));
+  //  * the chunk's channel index carries an opaque zero, re-read per chunk, so that LLVM cannot hoist the per-row address
+  //    arithmetic out of the chunk loop (that is what used to spill);
+  //  * weights: a thread loads the four kx taps of one (cout, cin, ky) as one 16-byte buffer load, threads of a wave differ
+  //    in cout, so the LDS stores ([tap][cout], cout fastest) are bank-conflict-free (the old tap-fastest mapping was 16-way).
+  constexpr int TPR = TW > 0 ? 64 / TW : 1;            // patch rows per tail load
+  static_assert(TW == 0 || PR <= TPR, "one tail load covers all patch rows");
+  float pv[NPV], tv = 0.f;
+  f32x4 wv[NR];
 #pragma unroll
   for (int i = 0; i < NPV; ++i) pv[i] = 0.f;
 #pragma unroll
-  for (int i = 0; i < NTV; ++i) tv[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < NWV; ++i) wv[i] = 1.f;
+  for (int i = 0; i < NR; ++i) wv[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
 
-  // Staging discipline (this is what makes the kernel stream and keeps it off the issue limit):
-  //  * load_chunk issues ONLY loads: every address is clamped into the tensor, so no load sits under a
-  //    data-dependent branch (hipcc would branch around it and drain vmcnt per element), and the raw
-  //    values stay in registers across the MFMA phase of the previous chunk;
-  //  * all address arithmetic is hoisted: wave w owns channel w of the chunk, so per chunk a wave needs
-  //    one base pointer (SGPRs) and its rows differ by compile-time multiples of the row pitch; column
-  //    offsets / masks are per-lane constants computed once per workgroup;
-  //  * store_chunk applies normalisation + activation + zero padding branch-free and writes LDS.
-  float csc[CK], csh[CK];
-#pragma unroll
-  for (int c = 0; c < CK; ++c) {
-    csc[c] = 1.f;
-    csh[c] = 0.f;
-  }
-  int colofs[NCM > 0 ? NCM : 1];
-  bool colok[NCM > 0 ? NCM : 1];
+  const int iplane = p.IH * p.IW;
+  const float* sb0 = p.s0 + n * p.ns0;
+  const float* sb1 = p.s1 + n * p.ns1;
+  const unsigned row0 = (unsigned)(iy0 * p.IW * 4), rstep = (unsigned)(p.IW * 4);
+  unsigned vo_m[NCM > 0 ? NCM : 1];   // lane parts of the byte offsets of the row-wise pieces
+  int colw[NCM > 0 ? NCM : 1];        // LDS column a lane writes (lanes beyond the piece write the pad column PC)
 #pragma unroll
   for (int cm = 0; cm < NCM; ++cm) {
     const int col = cm * 64 + lane, ix = ix0 + col;
-    colofs[cm] = min(max(ix, 0), p.IW - 1);
-    colok[cm] = col < PCM && ix >= 0 && ix < p.IW;
+    vo_m[cm] = (col < PCM && ix >= 0 && ix < p.IW) ? (unsigned)ix * 4u : OOB_OFF;
+    colw[cm] = col < PCM ? col : PC;
   }
-  const float* wbase = nullptr;   // this wave's channel plane (clamped)
+  unsigned vo_t = OOB_OFF;
+  int dst_t = PC;
+  if (TW > 0) {
+    const int r_t = lane / (TW > 0 ? TW : 1), c_t = lane - r_t * (TW > 0 ? TW : 1), ix = ix0 + PCM + c_t;
+    const bool live = r_t < PR;
+    vo_t = (live && ix >= 0 && ix < p.IW) ? (unsigned)(r_t * p.IW + ix) * 4u : OOB_OFF;
+    dst_t = live ? r_t * PCP + PCM + c_t : PC;
+  }
   float wsc = 1.f, wsh = 0.f;
+  unsigned cur_nrec = 0;
 
-  // weights: chunk-invariant part of the per-thread element decode
-  int wgo[NWV], wlo[NWV], wmeta[NWV];
-  {
-    constexpr int NCO = NR * 16;
+  // weights: chunk-invariant part of the per-thread unit decode (unit = the 4 kx taps of one (cout, chunk channel, ky))
+  constexpr int NCO = NR * 16;
+  unsigned wvo[NR];
+  int wc[NR], wld[NR][4];
 #pragma unroll
-    for (int e = 0; e < NWV; ++e) {
-      const int idx = tid + e * 256;
-      int co, c, slot;
-      if (co_major) {
-        co = idx / (CK * 16);
-        const int rem = idx - co * (CK * 16);
-        c = rem >> 4;
-        slot = rem & 15;
-      } else {
-        c = idx / (NCO * 16);
-        const int rem = idx - c * (NCO * 16);
-        co = rem >> 4;
-        slot = rem & 15;
-      }
-      int tap = slot;
-      if (MODE == 1 && S == 2) {
-        const int ph = slot >> 2, a = (slot >> 1) & 1, b = slot & 1;
-        const int ky = (((ph >> 1) + p.pad) & 1) + 2 * a, kx = (((ph & 1) + p.pad) & 1) + 2 * b;
-        tap = ky * 4 + kx;
-      }
-      wgo[e] = min(co0 + co, p.Cout - 1) * p.ws_co + tap;
-      wlo[e] = (c * 16 + slot) * COP + co;
-      wmeta[e] = (c << 16) | (co0 + co < p.Cout ? 1 : 0);
+  for (int e = 0; e < NR; ++e) {
+    const int u = tid + e * 256;
+    const int co = u % NCO, rest = u / NCO;
+    const int ky = rest & 3, c = rest >> 2;
+    wc[e] = c;
+    wvo[e] = co0 + co < p.Cout ? (unsigned)((co0 + co) * p.ws_co + c * p.ws_ci + ky * 4) * 4u : OOB_OFF;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      int slot = ky * 4 + kx;
+      if (MODE == 1 && S == 2) slot = ((((ky + p.pad) & 1) * 2 + ((kx + p.pad) & 1)) * 4) + (ky >> 1) * 2 + (kx >> 1);
+      wld[e][kx] = (c * 16 + slot) * COP + co;
     }
   }
+  const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
 
-  auto chunk_affine = [&](int cbase) {
-#pragma unroll
-    for (int c = 0; c < CK; ++c) {
-      const int cic = min(cbase + c, p.Cin - 1);
-      const bool first = cic < p.C0;
-      const int cl = first ? cic : cic - p.C0;
-      const float* scp = first ? p.sc0 : p.sc1;
-      const float* shp = first ? p.sh0 : p.sh1;
-      const int aidx = n * (first ? p.C0 : p.C1) + cl;
-      const bool hsc = scp != nullptr, hsh = shp != nullptr;
-      csc[c] = (hsc ? scp : p.ident)[hsc ? aidx : 0];
-      csh[c] = (hsh ? shp : p.ident)[hsh ? aidx : 1];
-    }
-  };
-
-  auto chan_ptr = [&](int ci) -> const float* {
-    const int cic = min(ci, p.Cin - 1);
-    const bool first = cic < p.C0;
-    const int cl = first ? cic : cic - p.C0;
-    const float* base = first ? p.s0 + n * p.ns0 : p.s1 + n * p.ns1;
-    return base + cl * plane;
+  auto opaque_zero = []() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
   };
 
   auto load_chunk = [&](int chunk) {
     const int cbase = chunk * CK;
-    if (TW > 0) chunk_affine(cbase);
-    if (NCM > 0) {
-      const int cic = min(cbase + wave, p.Cin - 1);
-      const bool first = cic < p.C0;
-      const int cl = first ? cic : cic - p.C0;
+    const int cic = cbase + wave + opaque_zero();
+    {
+      const int ccl = min(cic, p.Cin - 1);
+      const bool first = ccl < p.C0;
+      const int cl = first ? ccl : ccl - p.C0;
       const float* scp = first ? p.sc0 : p.sc1;
       const float* shp = first ? p.sh0 : p.sh1;
       const int aidx = n * (first ? p.C0 : p.C1) + cl;
       const bool hsc = scp != nullptr, hsh = shp != nullptr;
       wsc = (hsc ? scp : p.ident)[hsc ? aidx : 0];
       wsh = (hsh ? shp : p.ident)[hsh ? aidx : 1];
-      wbase = chan_ptr(cbase + wave);
-#pragma unroll
-      for (int r = 0; r < PR; ++r) {
-        const float* src = wbase + (int64_t)min(max(iy0 + r, 0), p.IH - 1) * p.IW;
-#pragma unroll
-        for (int cm = 0; cm < NCM; ++cm) pv[r * NCM + cm] = src[colofs[cm]];
-      }
     }
-    if (TW > 0) {
+    const bool cok = cic < p.Cin;
+    const int cc = cok ? cic : 0;
+    const bool first = cc < p.C0;
+    const float* base = (first ? sb0 : sb1) + (int64_t)(first ? cc : cc - p.C0) * iplane;
+    cur_nrec = cok ? (unsigned)iplane * 4u : 0u;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)cur_nrec, 0x00020000);
 #pragma unroll
-      for (int e = 0; e < NTV; ++e) {
-        const int idx = min(tid + e * 256, NROWS * TW - 1);
-        const int rr = idx / TW, col = PCM + (idx - rr * TW);
-        const int c = rr / PR, r = rr - c * PR;
-        tv[e] = chan_ptr(cbase + c)[(int64_t)min(max(iy0 + r, 0), p.IH - 1) * p.IW + min(max(ix0 + col, 0), p.IW - 1)];
-      }
-    }
+    for (int r = 0; r < PR; ++r)
 #pragma unroll
-    for (int e = 0; e < NWV; ++e) {
-      const int c = wmeta[e] >> 16;
-      wv[e] = p.w[wgo[e] + (int64_t)min(cbase + c, p.Cin - 1) * p.ws_ci];
-    }
+      for (int cm = 0; cm < NCM; ++cm) pv[r * NCM + cm] = ld_buf(rs, vo_m[cm] + row0 + r * rstep);
+    if (TW > 0) tv = ld_buf(rs, vo_t + row0);
+    const int wsoff = cbase * p.ws_ci * 4;
+#pragma unroll
+    for (int e = 0; e < NR; ++e)
+      wv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(cbase + wc[e] < p.Cin ? wvo[e] : OOB_OFF), wsoff, 0));
   };
 
   // branch-free  pad( act( x * scale + shift ) )
   auto finish = [&](float x, float sc, float sh, bool inside) -> float {
-    if (p.identity_in) return inside ? x : 0.f;   // uniform: gradients and raw inputs carry no affine / activation
     const float t = fmaf(x, sc, sh);
     const float a = fmaxf(t, 0.f) + p.slope_in * fminf(t, 0.f);
     return inside ? a : 0.f;
   };
 
-  auto store_chunk = [&](int chunk) {
-    const int cbase = chunk * CK;
-    if (NCM > 0) {
-      const bool cok = cbase + wave < p.Cin;
-      float* dst = lds_patch + wave * PR * PCP + lane;
+  auto store_patch = [&](auto plain_tag) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;
+    float* dst = lds_patch + wave * PR * PCP;
 #pragma unroll
-      for (int r = 0; r < PR; ++r) {
-        const int iy = iy0 + r;
-        const bool rok = cok && iy >= 0 && iy < p.IH;
+    for (int r = 0; r < PR; ++r)
 #pragma unroll
-        for (int cm = 0; cm < NCM; ++cm) {
-          const float v = finish(pv[r * NCM + cm], wsc, wsh, rok && colok[cm]);
-          if (cm * 64 + 63 < PCM) dst[r * PCP + cm * 64] = v;          // full piece
-          else if (cm * 64 + lane < PCM) dst[r * PCP + cm * 64] = v;   // partial last piece
-        }
+      for (int cm = 0; cm < NCM; ++cm) {
+        float v = pv[r * NCM + cm];
+        if (!PLAIN) v = finish(v, wsc, wsh, vo_m[cm] + row0 + r * rstep < cur_nrec);
+        dst[r * PCP + colw[cm]] = v;
       }
-    }
     if (TW > 0) {
-#pragma unroll
-      for (int e = 0; e < NTV; ++e) {
-        const int idx = tid + e * 256;
-        const int rr = idx / TW, col = PCM + (idx - rr * TW);
-        const int c = rr / PR, r = rr - c * PR;
-        const int iy = iy0 + r, ix = ix0 + col;
-        float sc = csc[0], sh = csh[0];
-#pragma unroll
-        for (int q = 1; q < CK; ++q) {
-          sc = (c == q) ? csc[q] : sc;
-          sh = (c == q) ? csh[q] : sh;
-        }
-        const bool ok = cbase + c < p.Cin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        if (rr < NROWS) lds_patch[rr * PCP + col] = finish(tv[e], sc, sh, ok);
-      }
+      float v = tv;
+      if (!PLAIN) v = finish(v, wsc, wsh, vo_t + row0 < cur_nrec);
+      dst[dst_t] = v;
     }
+  };
+
+  auto store_chunk = [&](int chunk) {
+    if (p.identity_in) store_patch(TagT());   // uniform: gradients and raw inputs carry no affine / activation
+    else store_patch(TagF());
 #pragma unroll
-    for (int e = 0; e < NWV; ++e) {
-      const int c = wmeta[e] >> 16;
-      lds_w[wlo[e]] = ((wmeta[e] & 1) && cbase + c < p.Cin) ? wv[e] : 0.f;
-    }
+    for (int e = 0; e < NR; ++e)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) lds_w[wld[e][kx]] = wv[e][kx];
   };
 
   if (chunk_begin < chunk_end) {
@@ -584,6 +556,11 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.ablate = ablate;
   k.ident = vts_ident();
   VTS_CHECK_ARG(k.ident, "vts_conv4x4: could not allocate the identity constants");
+  {
+    const int64_t wfl = (int64_t)(d->Cout - 1) * d->ws_co + (int64_t)(k.Cin - 1) * d->ws_ci + 16;
+    VTS_CHECK_ARG(wfl * 4 < (int64_t)OOB_OFF && (int64_t)d->IH * d->IW * 4 < (int64_t)OOB_OFF, "vts_conv4x4: tensor too large for 30-bit buffer offsets");
+    k.wbytes = (int)(wfl * 4);
+  }
   k.slope_in = vts_slope(d->act_in);
   k.identity_in = (d->act_in == VTS_ACT_NONE && !d->in0.scale && !d->in0.shift && !(d->in1.data && (d->in1.scale || d->in1.shift))) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
