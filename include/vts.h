@@ -142,6 +142,23 @@ typedef struct vts_norm_desc {
                       workgroup of each group finalises (one launch instead of two: same arithmetic, same order).  One buffer
                       per concurrently running stream.  Measured SLOWER on MI355X inside a busy step (device-scope fences
                       flush the per-XCD L2): leave NULL unless the launch count matters more than the time. */
+  /* BatchNorm over SEVERAL forward passes batched into one launch (mode 1 only; ngroups <= 1: one group = the whole batch).
+   * The reference runs the discriminator on fake and real batches one after the other (sinskitG_model.py:1361,1374,1490,
+   * 1567,1584): each call normalises with its own batch statistics and advances the running statistics once.  Batched,
+   * samples [gstart[g], gstart[g+1]) form pass g: statistics, scale/shift and the running-statistics recurrence are per
+   * pass, applied in pass order, so the result equals the sequential calls. */
+  int ngroups;
+  int gstart[9];
+  /* running-statistics bookkeeping of a pass that ran as its OWN launch but belongs into the sequence of this one
+   * (the full-resolution visualisation pass between the fake and the "more fake" patch passes, sinskitG_model.py:1495):
+   *   stat_mean_out / stat_uvar_out [C]: this launch only records its batch mean and unbiased variance (no running update
+   *                                      when running_mean is NULL);
+   *   ext_mean / ext_uvar [C], ext_after: statistics recorded that way, applied after pass `ext_after` of this launch. */
+  float* stat_mean_out;
+  float* stat_uvar_out;
+  const float* ext_mean;
+  const float* ext_uvar;
+  int ext_after;
 } vts_norm_desc;
 
 int64_t vts_norm_ws_floats(int N, int C, int HW);
@@ -163,6 +180,8 @@ typedef struct vts_norm_bwd_desc {
   float* dbeta;
   int accumulate_param_grads;
   int* counters; /* optional, as in vts_norm_desc */
+  int ngroups;   /* batched passes, as in vts_norm_desc: coefficients per pass, dgamma / dbeta summed over the passes */
+  int gstart[9];
 } vts_norm_bwd_desc;
 
 int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream);

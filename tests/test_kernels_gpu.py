@@ -315,6 +315,48 @@ def test_norm_forward_backward(shape, mode, fuse_finalize):
         assert rel(dg, gamma.grad) < 1e-4 and rel(db, beta.grad) < 1e-4
 
 
+@pytest.mark.parametrize("shape,groups", [((7, 6, 9, 9), [0, 3, 5]), ((5, 4, 70, 61), [0, 2]), ((640, 8, 5, 5), [0, 256, 384]),
+                                          ((6, 3, 150, 140), [0, 1, 4])])
+def test_batchnorm_batched_passes_equal_sequential_calls(shape, groups):
+    """several discriminator passes in ONE launch (vts_norm_desc.ngroups): per-pass batch statistics, running statistics advanced
+    in pass order with a separately launched pass spliced in after pass 0 -- equal to sequential F.batch_norm calls"""
+    from vts import ops
+
+    dev = _dev()
+    n, c, h, w = shape
+    x = (detrand.uniform(shape, 17, "x") * 2 + 0.3).requires_grad_(True)
+    xe = detrand.uniform((2, c, h + 3, w + 1), 17, "xe") * 3 - 0.4          # the spliced pass (its own launch, other spatial size)
+    gamma = (1 + 0.2 * detrand.uniform((c,), 17, "g")).requires_grad_(True)
+    beta = (0.1 * detrand.uniform((c,), 17, "b")).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    bounds = list(groups) + [n]
+    ys = []
+    for gi in range(len(groups)):
+        ys.append(F.batch_norm(x[bounds[gi]:bounds[gi + 1]], rm, rv, gamma, beta, True, 0.1, 1e-5))
+        if gi == 0:
+            F.batch_norm(xe, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    y = torch.cat(ys)
+    cot = detrand.uniform(shape, 17, "cot")
+    (y * cot).sum().backward()
+
+    gd, bd = gamma.detach().to(dev), beta.detach().to(dev)
+    rmd, rvd = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    nbt = torch.zeros((), dtype=torch.long, device=dev)
+    stat = (torch.empty(c, device=dev), torch.empty(c, device=dev))
+    ops.norm_stats(xe.to(dev), 1, gamma=gd, beta=bd, stat_out=stat)          # records its statistics, no running update
+    xd = x.detach().to(dev)
+    a = ops.norm_stats(xd, 1, gamma=gd, beta=bd, running_mean=rmd, running_var=rvd, nbt=nbt, groups=groups, ext=(stat[0], stat[1], 0))
+    yk = xd * a.scale.view(n, c, 1, 1) + a.shift.view(n, c, 1, 1)
+    assert rel(yk, y) < 1e-5
+    assert rel(rmd, rm) < 1e-5 and rel(rvd, rv) < 1e-5
+    assert int(nbt) == len(groups) + 1
+    dy = cot.to(dev).clone()
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    ops.norm_bwd(dy, a, 1, gamma=gd, dgamma=dg, dbeta=db, groups=groups)
+    assert rel(dy, x.grad) < 2e-4
+    assert rel(dg, gamma.grad) < 1e-4 and rel(db, beta.grad) < 1e-4
+
+
 def test_norm_large_mean_is_robust():
     from vts import ops
 

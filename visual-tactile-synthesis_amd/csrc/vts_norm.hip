@@ -92,7 +92,25 @@ struct NormK {
   float *running_mean, *running_var;
   int64_t* nbt;
   float *scale, *shift, *mean_out, *rstd_out;
+  int ngroups;          // BatchNorm: passes batched into this launch (>= 1)
+  int gstart[9];
+  float *stat_mean, *stat_uvar;          // optional [C]: record batch mean / unbiased variance of group 0
+  const float *ext_mean, *ext_uvar;      // optional [C]: statistics of a separately launched pass ...
+  int ext_after;                         // ... whose running-statistics update follows pass `ext_after`
 };
+
+// running-statistics recurrence of one pass (PyTorch BatchNorm2d, momentum form, unbiased variance)
+__device__ __forceinline__ void running_update(const NormK& k, int c, float mean, float uvar) {
+  if (k.running_mean) k.running_mean[c] = (1.f - k.momentum) * k.running_mean[c] + k.momentum * mean;
+  if (k.running_var) k.running_var[c] = (1.f - k.momentum) * k.running_var[c] + k.momentum * uvar;
+}
+__device__ __forceinline__ void after_group(const NormK& k, int c, int g, float mean, float uvar) {
+  if (g == 0 && k.stat_mean) k.stat_mean[c] = mean;
+  if (g == 0 && k.stat_uvar) k.stat_uvar[c] = uvar;
+  running_update(k, c, mean, uvar);
+  if (k.ext_mean && g == k.ext_after) running_update(k, c, k.ext_mean[c], k.ext_uvar[c]);
+  if (k.nbt && c == 0) k.nbt[0] += 1 + ((k.ext_mean && g == k.ext_after) ? 1 : 0);
+}
 
 // IN: one wave per (n,c).  BN: one wave per c, merging N*spl partials, writing all n.
 __device__ __forceinline__ void norm_finalize_group(const volatile float* part, const NormK& k, int group) {
@@ -110,40 +128,39 @@ __device__ __forceinline__ void norm_finalize_group(const volatile float* part, 
     }
   } else {
     const int c = group;
-    // partials of channel c: for n in N, s in spl -> index ((n*C + c)*spl + s); merge in two levels per n
-    float sn = 0.f, sm = 0.f;
-    const int np = k.N * k.spl;
-    for (int i = lane; i < np; i += 64) {
-      const int n = i / k.spl, s = i - n * k.spl;
-      const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
-      sn += q[2];
-      sm += q[2] * q[0];
-    }
-    sn = wave_sum(sn);
-    sm = wave_sum(sm);
-    const float mean = sm / sn;
-    float acc = 0.f;
-    for (int i = lane; i < np; i += 64) {
-      const int n = i / k.spl, s = i - n * k.spl;
-      const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
-      const float d = q[0] - mean;
-      acc += q[1] + q[2] * d * d;
-    }
-    const float m2 = wave_sum(acc);
-    const float var = m2 / sn;
-    const float rstd = 1.f / sqrtf(var + k.eps);
-    const float g = k.gamma ? k.gamma[c] : 1.f, b = k.beta ? k.beta[c] : 0.f;
-    for (int n = lane; n < k.N; n += 64) {
-      const int idx = n * k.C + c;
-      k.scale[idx] = g * rstd;
-      k.shift[idx] = b - mean * g * rstd;
-      if (k.mean_out) k.mean_out[idx] = mean;
-      if (k.rstd_out) k.rstd_out[idx] = rstd;
-    }
-    if (lane == 0) {
-      if (k.running_mean) k.running_mean[c] = (1.f - k.momentum) * k.running_mean[c] + k.momentum * mean;
-      if (k.running_var) k.running_var[c] = (1.f - k.momentum) * k.running_var[c] + k.momentum * (m2 / (sn - 1.f));
-      if (k.nbt && c == 0) k.nbt[0] += 1;
+    // partials of channel c: for n in a pass, s in spl -> index ((n*C + c)*spl + s); passes in order (running statistics)
+    for (int gi = 0; gi < k.ngroups; ++gi) {
+      const int n0 = k.gstart[gi], n1 = k.gstart[gi + 1];
+      float sn = 0.f, sm = 0.f;
+      const int np = (n1 - n0) * k.spl;
+      for (int i = lane; i < np; i += 64) {
+        const int n = n0 + i / k.spl, s = i - (i / k.spl) * k.spl;
+        const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+        sn += q[2];
+        sm += q[2] * q[0];
+      }
+      sn = wave_sum(sn);
+      sm = wave_sum(sm);
+      const float mean = sm / sn;
+      float acc = 0.f;
+      for (int i = lane; i < np; i += 64) {
+        const int n = n0 + i / k.spl, s = i - (i / k.spl) * k.spl;
+        const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+        const float d = q[0] - mean;
+        acc += q[1] + q[2] * d * d;
+      }
+      const float m2 = wave_sum(acc);
+      const float var = m2 / sn;
+      const float rstd = 1.f / sqrtf(var + k.eps);
+      const float g = k.gamma ? k.gamma[c] : 1.f, b = k.beta ? k.beta[c] : 0.f;
+      for (int n = n0 + lane; n < n1; n += 64) {
+        const int idx = n * k.C + c;
+        k.scale[idx] = g * rstd;
+        k.shift[idx] = b - mean * g * rstd;
+        if (k.mean_out) k.mean_out[idx] = mean;
+        if (k.rstd_out) k.rstd_out[idx] = rstd;
+      }
+      if (lane == 0) after_group(k, c, gi, mean, m2 / (sn - 1.f));
     }
   }
 }
@@ -201,6 +218,8 @@ struct NormBwdK {
   float *dgamma, *dbeta;
   int acc;
   float* coef;  // [N*C][3]
+  int ngroups;  // BatchNorm: passes batched into this launch (>= 1)
+  int gstart[9];
 };
 
 __device__ __forceinline__ void norm_bwd_finalize_group(const volatile float* part, const NormBwdK& k, int group) {
@@ -223,29 +242,35 @@ __device__ __forceinline__ void norm_bwd_finalize_group(const volatile float* pa
     }
   } else {
     const int c = group;
-    float s1 = 0.f, s2 = 0.f;
-    const int np = k.N * k.spl;
-    for (int i = lane; i < np; i += 64) {
-      const int n = i / k.spl, s = i - n * k.spl;
-      const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 2;
-      s1 += q[0];
-      s2 += q[1];
-    }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    const float m = (float)k.N * (float)k.HW;
-    const float rs = k.rstd[c], mu = k.mean[c];  // identical for every n
-    const float g = k.gamma ? k.gamma[c] : 1.f;
-    const float B = -g * rs * rs * s2 / m;
-    for (int n = lane; n < k.N; n += 64) {
-      const int idx = n * k.C + c;
-      k.coef[idx * 3 + 0] = g * rs;
-      k.coef[idx * 3 + 1] = B;
-      k.coef[idx * 3 + 2] = -g * rs * s1 / m - B * mu;
+    float dg = 0.f, db = 0.f;
+    for (int gi = 0; gi < k.ngroups; ++gi) {
+      const int n0 = k.gstart[gi], n1 = k.gstart[gi + 1];
+      float s1 = 0.f, s2 = 0.f;
+      const int np = (n1 - n0) * k.spl;
+      for (int i = lane; i < np; i += 64) {
+        const int n = n0 + i / k.spl, s = i - (i / k.spl) * k.spl;
+        const volatile float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 2;
+        s1 += q[0];
+        s2 += q[1];
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      const float m = (float)(n1 - n0) * (float)k.HW;
+      const float rs = k.rstd[n0 * k.C + c], mu = k.mean[n0 * k.C + c];  // identical for every n of a pass
+      const float g = k.gamma ? k.gamma[c] : 1.f;
+      const float B = -g * rs * rs * s2 / m;
+      for (int n = n0 + lane; n < n1; n += 64) {
+        const int idx = n * k.C + c;
+        k.coef[idx * 3 + 0] = g * rs;
+        k.coef[idx * 3 + 1] = B;
+        k.coef[idx * 3 + 2] = -g * rs * s1 / m - B * mu;
+      }
+      dg += s2;
+      db += s1;
     }
     if (lane == 0) {
-      if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + s2;
-      if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + s1;
+      if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + dg;
+      if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + db;
     }
   }
 }
@@ -274,8 +299,9 @@ constexpr int64_t FUSED_MAX_GROUP = 8192;
 __device__ __forceinline__ int64_t fused_off(int j, int HW, int n0, int c, int64_t nstride, bool bn) {
   int n = n0, i = j;
   if (bn) {
-    n = j / HW;
-    i = j - n * HW;
+    const int q = j / HW;
+    n = n0 + q;
+    i = j - q * HW;
   }
   return n * nstride + (int64_t)c * HW + i;
 }
@@ -285,31 +311,30 @@ __global__ __launch_bounds__(1024) void norm_stats_fused_kernel(const float* __r
   const int g = blockIdx.x;
   const bool bn = k.mode == 1;
   const int c = bn ? g : g % k.C;
-  const int n0 = bn ? 0 : g / k.C, n1 = bn ? k.N : n0 + 1;
-  const int total = (n1 - n0) * k.HW;
-  const float cnt = (float)total;
-  float s = 0.f;
-  for (int j = threadIdx.x; j < total; j += blockDim.x) s += x[fused_off(j, k.HW, n0, c, nstride, bn)];
-  const float mean = block_sum(s, red) / cnt;
-  float m2 = 0.f;
-  for (int j = threadIdx.x; j < total; j += blockDim.x) {
-    const float d = x[fused_off(j, k.HW, n0, c, nstride, bn)] - mean;
-    m2 += d * d;
-  }
-  m2 = block_sum(m2, red);
-  const float rstd = 1.f / sqrtf(m2 / cnt + k.eps);
-  const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f, be = (bn && k.beta) ? k.beta[c] : 0.f;
-  for (int n = n0 + threadIdx.x; n < n1; n += blockDim.x) {
-    const int idx = n * k.C + c;
-    k.scale[idx] = ga * rstd;
-    k.shift[idx] = be - mean * ga * rstd;
-    if (k.mean_out) k.mean_out[idx] = mean;
-    if (k.rstd_out) k.rstd_out[idx] = rstd;
-  }
-  if (bn && threadIdx.x == 0) {
-    if (k.running_mean) k.running_mean[c] = (1.f - k.momentum) * k.running_mean[c] + k.momentum * mean;
-    if (k.running_var) k.running_var[c] = (1.f - k.momentum) * k.running_var[c] + k.momentum * (m2 / (cnt - 1.f));
-    if (k.nbt && c == 0) k.nbt[0] += 1;
+  const int ngr = bn ? k.ngroups : 1;
+  for (int gi = 0; gi < ngr; ++gi) {   // BatchNorm: the passes of this channel in order (running statistics)
+    const int n0 = bn ? k.gstart[gi] : g / k.C, n1 = bn ? k.gstart[gi + 1] : n0 + 1;
+    const int total = (n1 - n0) * k.HW;
+    const float cnt = (float)total;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < total; j += blockDim.x) s += x[fused_off(j, k.HW, n0, c, nstride, bn)];
+    const float mean = block_sum(s, red) / cnt;
+    float m2 = 0.f;
+    for (int j = threadIdx.x; j < total; j += blockDim.x) {
+      const float d = x[fused_off(j, k.HW, n0, c, nstride, bn)] - mean;
+      m2 += d * d;
+    }
+    m2 = block_sum(m2, red);
+    const float rstd = 1.f / sqrtf(m2 / cnt + k.eps);
+    const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f, be = (bn && k.beta) ? k.beta[c] : 0.f;
+    for (int n = n0 + threadIdx.x; n < n1; n += blockDim.x) {
+      const int idx = n * k.C + c;
+      k.scale[idx] = ga * rstd;
+      k.shift[idx] = be - mean * ga * rstd;
+      if (k.mean_out) k.mean_out[idx] = mean;
+      if (k.rstd_out) k.rstd_out[idx] = rstd;
+    }
+    if (bn && threadIdx.x == 0) after_group(k, c, gi, mean, m2 / (cnt - 1.f));
   }
 }
 
@@ -319,28 +344,34 @@ __global__ __launch_bounds__(1024) void norm_bwd_fused_kernel(float* __restrict_
   const int g = blockIdx.x;
   const bool bn = k.mode == 1;
   const int c = bn ? g : g % k.C;
-  const int n0 = bn ? 0 : g / k.C, n1 = bn ? k.N : n0 + 1;
-  const int total = (n1 - n0) * k.HW;
-  const float m = (float)total;
-  const float mu = k.mean[n0 * k.C + c], rs = k.rstd[n0 * k.C + c];  // identical for every n of a BN group
-  float s1 = 0.f, s2 = 0.f;
-  for (int j = threadIdx.x; j < total; j += blockDim.x) {
-    const int64_t off = fused_off(j, k.HW, n0, c, nstride, bn);
-    const float gdy = dy[off];
-    s1 += gdy;
-    s2 += gdy * ((x[off] - mu) * rs);
-  }
-  s1 = block_sum(s1, red);
-  s2 = block_sum(s2, red);
-  const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f;
-  const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m - B * mu;
-  for (int j = threadIdx.x; j < total; j += blockDim.x) {
-    const int64_t off = fused_off(j, k.HW, n0, c, nstride, bn);
-    dy[off] = A * dy[off] + B * x[off] + Cc;
+  const int ngr = bn ? k.ngroups : 1;
+  float dg = 0.f, db = 0.f;
+  for (int gi = 0; gi < ngr; ++gi) {
+    const int n0 = bn ? k.gstart[gi] : g / k.C, n1 = bn ? k.gstart[gi + 1] : n0 + 1;
+    const int total = (n1 - n0) * k.HW;
+    const float m = (float)total;
+    const float mu = k.mean[n0 * k.C + c], rs = k.rstd[n0 * k.C + c];  // identical for every n of a BN pass
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = threadIdx.x; j < total; j += blockDim.x) {
+      const int64_t off = fused_off(j, k.HW, n0, c, nstride, bn);
+      const float gdy = dy[off];
+      s1 += gdy;
+      s2 += gdy * ((x[off] - mu) * rs);
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f;
+    const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m - B * mu;
+    for (int j = threadIdx.x; j < total; j += blockDim.x) {
+      const int64_t off = fused_off(j, k.HW, n0, c, nstride, bn);
+      dy[off] = A * dy[off] + B * x[off] + Cc;
+    }
+    dg += s2;
+    db += s1;
   }
   if (bn && threadIdx.x == 0) {
-    if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + s2;
-    if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + s1;
+    if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + dg;
+    if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + db;
   }
 }
 
@@ -426,6 +457,24 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// pass groups of a batched BatchNorm launch: validated copy; maxg = samples of the largest pass
+bool fill_groups(int mode, int N, int ngroups, const int* gstart, int& out_n, int* out_start, int& maxg) {
+  out_n = 1;
+  out_start[0] = 0;
+  out_start[1] = N;
+  maxg = N;
+  if (mode != 1 || ngroups <= 1) return true;
+  if (ngroups > 8 || gstart[0] != 0 || gstart[ngroups] != N) return false;
+  maxg = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    if (gstart[g + 1] <= gstart[g]) return false;
+    if (gstart[g + 1] - gstart[g] > maxg) maxg = gstart[g + 1] - gstart[g];
+  }
+  out_n = ngroups;
+  for (int g = 0; g <= ngroups; ++g) out_start[g] = gstart[g];
+  return true;
+}
+
 }  // namespace
 
 extern "C" int64_t vts_norm_ws_floats(int N, int C, int HW) { return (int64_t)N * C * splits_for(HW) * 3 + (int64_t)N * C * 3; }
@@ -438,7 +487,15 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
   const int spl = splits_for(d->HW);
   NormK k{d->N, d->C, d->HW, spl, d->mode, d->eps, d->momentum, d->gamma, d->beta, d->running_mean, d->running_var,
           d->num_batches_tracked, d->scale, d->shift, d->mean_out, d->rstd_out};
-  const int64_t group = (int64_t)(d->mode == 0 ? 1 : d->N) * d->HW;
+  int maxg = d->N;
+  if (!fill_groups(d->mode, d->N, d->ngroups, d->gstart, k.ngroups, k.gstart, maxg)) {
+    vts_set_error("vts_norm_stats: bad pass groups (ngroups %d)", d->ngroups);
+    return VTS_ERR_ARG;
+  }
+  k.stat_mean = d->stat_mean_out; k.stat_uvar = d->stat_uvar_out; k.ext_mean = d->ext_mean; k.ext_uvar = d->ext_uvar; k.ext_after = d->ext_after;
+  VTS_CHECK_ARG(!(k.ext_mean && !k.ext_uvar) && !(k.stat_mean && !k.stat_uvar), "vts_norm_stats: ext / stat outputs come in pairs");
+  const bool grouped = k.ngroups > 1 || k.stat_mean || k.ext_mean;
+  const int64_t group = (int64_t)(d->mode == 0 ? 1 : maxg) * d->HW;
   if (group <= FUSED_MAX_GROUP) {  // small groups: one launch, one workgroup per group (two passes, L2-resident)
     hipLaunchKernelGGL(norm_stats_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
                        d->x, d->nstride, k);
@@ -446,7 +503,7 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
     vts_set_kernel("norm_stats_fused_kernel");
     return VTS_OK;
   }
-  if (d->counters) {
+  if (d->counters && !grouped) {
     hipLaunchKernelGGL(stats_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->x, d->nstride, ws, k, d->counters);
     VTS_CHECK_LAUNCH("vts_norm_stats");
     vts_set_kernel("stats_fin_kernel");
@@ -467,17 +524,23 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   const int spl = splits_for(d->HW);
   float* part = ws;
   float* coef = ws + (int64_t)d->N * d->C * spl * 3;  // same split as vts_norm_ws_floats
-  const int64_t group = (int64_t)(d->mode == 0 ? 1 : d->N) * d->HW;
+  NormBwdK k{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, coef};
+  int maxg = d->N;
+  if (!fill_groups(d->mode, d->N, d->ngroups, d->gstart, k.ngroups, k.gstart, maxg)) {
+    vts_set_error("vts_norm_bwd: bad pass groups (ngroups %d)", d->ngroups);
+    return VTS_ERR_ARG;
+  }
+  const bool grouped = k.ngroups > 1;
+  const int64_t group = (int64_t)(d->mode == 0 ? 1 : maxg) * d->HW;
   if (group <= FUSED_MAX_GROUP) {
-    NormBwdK kf{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, coef};
+    const NormBwdK& kf = k;
     hipLaunchKernelGGL(norm_bwd_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
                        d->dy, d->x, d->nstride, kf);
     VTS_CHECK_LAUNCH("vts_norm_bwd fused");
     vts_set_kernel("norm_bwd_fused_kernel");
     return VTS_OK;
   }
-  NormBwdK k{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, coef};
-  if (d->counters) {
+  if (d->counters && !grouped) {
     hipLaunchKernelGGL(norm_bwd_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, part, k, d->counters);
     VTS_CHECK_LAUNCH("vts_norm_bwd partial+finalize");
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, coef);

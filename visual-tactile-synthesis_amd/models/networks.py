@@ -479,15 +479,16 @@ class GANLoss:
     def to(self, device):
         return self
 
-    def accumulate(self, preds, target_is_real, coeff, slot, grad_coeff=None, want_grad=True):
-        """slot += coeff * sum_scales mean_batch(loss); returns [dpred per scale] scaled by grad_coeff."""
+    def accumulate(self, preds, target_is_real, coeff, slot, grad_coeff=None, want_grad=True, out_grads=None):
+        """slot += coeff * sum_scales mean_batch(loss); returns [dpred per scale] scaled by grad_coeff (written into out_grads
+        -- e.g. batch slices of one gradient buffer -- when given)."""
         from vts import ops
 
         grads = []
         label = self.real_label if target_is_real else self.fake_label
-        for p in preds:
+        for i, p in enumerate(preds):
             p = p[-1] if isinstance(p, (list, tuple)) else p
-            g = torch.empty_like(p) if want_grad else None
+            g = (out_grads[i] if out_grads is not None else torch.empty_like(p)) if want_grad else None
             ops.ganloss(p, self.gan_mode, target_is_real, coeff, slot, g, label=label, grad_coeff=grad_coeff)
             grads.append(g)
         return grads

@@ -261,15 +261,30 @@ class SinSKITGModel(BaseModel):
         self.augmentation_params = input.get("augmentation_params")
         S = self._load(phase + "_S", input["S"])
         n, _, h, w = S.shape
+        # The D1 update runs the discriminator on [fake | real] in ONE batched launch per layer (engine.msd_multi, `groups`):
+        # sketch and image live in persistent [2n, C, H, W] buffers -- rows [0, n) are the fake pass (S, fake_I written by the
+        # forward), rows [n, 2n) the real pass (S again, real_I).
+        self._pair = bool(self.isTrain and phase == "train" and "I" in input)
+        S2 = self._buf(phase + "_S2", (2 * n if self._pair else n, 1, h, w))
+        self.real_S = S2[:n]
         if self.opt.use_bg_mask:
             self.M = self._load(phase + "_M", input["M"])
-            self.real_S = ops.mask_mul(S, self.M, out=self._buf(phase + "_real_S", S.shape))
+            ops.mask_mul(S, self.M, out=self.real_S)
             self.M_T = self.M  # nearest resize at multiplier 1 is the identity
         else:
-            self.real_S = S
+            self.real_S.copy_(S)
+        if self._pair:
+            S2[n:].copy_(self.real_S)
+        self._S2 = S2
         if "I" in input:
             I = self._load(phase + "_I", input["I"])
-            self.real_I = ops.mask_mul(I, self.M, out=self._buf(phase + "_real_I", I.shape)) if self.opt.use_bg_mask else I
+            I2 = self._buf(phase + "_I2", (2 * n if self._pair else n, 3, h, w))
+            self.real_I = I2[n:] if self._pair else I2
+            if self.opt.use_bg_mask:
+                ops.mask_mul(I, self.M, out=self.real_I)
+            else:
+                self.real_I.copy_(I)
+            self._I2 = I2
             self.full_T_coords = input.get("full_T_coords")
         elif hasattr(self, "real_I"):
             del self.real_I
@@ -311,9 +326,9 @@ class SinSKITGModel(BaseModel):
         else:
             g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep)
         self.g_out = g_out
-        self.fake_I = torch.empty(n, 3, h, w, device=dev)
-        self.fake_N = torch.empty(n, 3, h, w, device=dev)
         has_real = hasattr(self, "real_I") and not self.test_edit_S
+        self.fake_I = self._I2[:n] if (has_real and getattr(self, "_pair", False)) else torch.empty(n, 3, h, w, device=dev)
+        self.fake_N = torch.empty(n, 3, h, w, device=dev)
         # the D2 full-resolution stack [fake_T(2), S(1), aug_fake_I(3), M(1)] is filled in place
         self._full_stack = torch.empty(n, 7, h, w, device=dev)
         self.fake_T = self._full_stack[:, 0:2]
@@ -393,8 +408,12 @@ class SinSKITGModel(BaseModel):
         self._loss_buf.zero_()
         self.forward(keep=True)
         # patches (compute_additional_output :1268-1291)
-        fake_stack = torch.empty(P, 7, 32, 32, device=dev)    # [fake_T, S, aug_fake_I, mask]
-        real_stack = torch.empty(P, 7, 32, 32, device=dev)    # [real_T, S, aug_real_I, mask]
+        # the patch stacks of the D2 update in ONE buffer, [fake | more fake | real] along the batch (batched passes)
+        K = self.real_S.shape[0] * opt.add_fake_T_sample_size if (opt.use_more_fakeT and "D2" in self.model_names) else 0
+        self._stack_all = torch.empty(2 * P + K, 7, 32, 32, device=dev)
+        fake_stack = self._stack_all[:P]                      # [fake_T, S, aug_fake_I, mask]
+        real_stack = self._stack_all[P + K:]                  # [real_T, S, aug_real_I, mask]
+        self._more_stack = self._stack_all[P:P + K]
         self._gather(self.fake_T, ts, fake_stack, 0, channels=2)
         self._gather(self.real_S, ts, fake_stack, 2)
         self._gather(self.aug_fake_I, ts, fake_stack, 3, channels=3)
@@ -414,41 +433,61 @@ class SinSKITGModel(BaseModel):
         opt, dev, slot = self.opt, self.device, self._slot
         jobs = []
         p_fake_I = p_full = None
+        n = self.real_S.shape[0]
         if "D" in self.model_names:      # compute_D1_loss
             lam = opt.lambda_G1_GAN
-            p_fake_I = dict(in0=self.real_S, in1=self.fake_I, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)
-            jobs.append((self.netD, [p_fake_I, dict(in0=self.real_S, in1=self.real_I, real=True, coeff=lam, slot=slot["D_real_I"],
-                                                    grad_coeff=0.5 * lam, accumulate=True)]))
+            if getattr(self.netD, "is_stylegan2_d", False) or not self._pair:
+                p_fake_I = dict(in0=self.real_S, in1=self.fake_I, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)
+                jobs.append((self.netD, [p_fake_I, dict(in0=self.real_S, in1=self.real_I, real=True, coeff=lam, slot=slot["D_real_I"],
+                                                        grad_coeff=0.5 * lam, accumulate=True)]))
+            else:   # fake | real batched: rows [0, n) / [n, 2n) of the persistent pair buffers
+                p_fake_I = dict(in0=self._S2, in1=self._I2, groups=[
+                    dict(n0=0, n1=n, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam),
+                    dict(n0=n, n1=2 * n, real=True, coeff=lam, slot=slot["D_real_I"], grad_coeff=0.5 * lam)])
+                jobs.append((self.netD, [p_fake_I]))
         if "D2" in self.model_names:     # compute_D2_loss
-            n = self.real_S.shape[0]
             lam2 = opt.lambda_G2_GAN
-            passes = [dict(in0=self._fake_stack, real=False, coeff=lam2, slot=slot["D_fake_T_concat"], grad_coeff=0.5 * lam2)]
+            batched = not getattr(self.netD2, "is_stylegan2_d", False)
+            P = self._fake_stack.shape[0]
+            passes = [] if batched else [dict(in0=self._fake_stack, real=False, coeff=lam2, slot=slot["D_fake_T_concat"], grad_coeff=0.5 * lam2)]
             # full-resolution pass: visualisation only, but it advances the BatchNorm running statistics
             # (opt.skip_D2_visualisation_pass is a measurement switch of bench.py --no_viz, not a reference option: SURVEY §8d asks
             # for the step rate with and without this pass)
             if not getattr(opt, "skip_D2_visualisation_pass", False):
                 self._full_stack[:, 2:3].copy_(self.real_S)
                 self._full_stack[:, 6:7].copy_(self.M)
-                p_full = dict(in0=self._full_stack, loss=False)
+                # batched: it runs first and only records its BatchNorm statistics; the patch pass splices its running-statistics
+                # update in after the fake patches, i.e. at the reference's position (sinskitG_model.py:1490-1501)
+                p_full = dict(in0=self._full_stack, loss=False, stat_only=batched)
                 passes.append(p_full)
+            K = 0
             if opt.use_more_fakeT:
                 k = opt.add_fake_T_sample_size
+                K = n * k
                 h, w = self.real_S.shape[2:]
                 mox, moy = ops.mask_select(self._cand, self._cand_prefix, self._ranks, h, w)
                 self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
-                more = torch.empty(n * k, 7, 32, 32, device=dev)
+                more = self._more_stack
                 mset = dict(img=self._more_img, offx=mox, offy=moy)
                 self._gather(self.fake_T, mset, more, 0, channels=2)
                 self._gather(self.real_S, mset, more, 2)
                 self._gather(self.fake_I, mset, more, 3)
                 more[:, 6:7].fill_(1.0)
-                passes.append(dict(in0=more, real=False, coeff=lam2, slot=slot["D_more_fake_T"], grad_coeff=0.5 * lam2, accumulate=True))
-            passes.append(dict(in0=self._real_stack, real=True, coeff=lam2, slot=slot["D_real_T_concat"], grad_coeff=0.5 * lam2,
-                               accumulate=True))
+                if not batched:
+                    passes.append(dict(in0=more, real=False, coeff=lam2, slot=slot["D_more_fake_T"], grad_coeff=0.5 * lam2, accumulate=True))
+            if batched:
+                groups = [dict(n0=0, n1=P, real=False, coeff=lam2, slot=slot["D_fake_T_concat"], grad_coeff=0.5 * lam2)]
+                if K:
+                    groups.append(dict(n0=P, n1=P + K, real=False, coeff=lam2, slot=slot["D_more_fake_T"], grad_coeff=0.5 * lam2))
+                groups.append(dict(n0=P + K, n1=2 * P + K, real=True, coeff=lam2, slot=slot["D_real_T_concat"], grad_coeff=0.5 * lam2))
+                passes.append(dict(in0=self._stack_all, groups=groups, ext_from=p_full if (p_full is not None) else None, ext_after=0))
+            else:
+                passes.append(dict(in0=self._real_stack, real=True, coeff=lam2, slot=slot["D_real_T_concat"], grad_coeff=0.5 * lam2,
+                                   accumulate=True))
             jobs.append((self.netD2, passes))
         engine.msd_multi(jobs, self.criterionGAN)
         if p_fake_I is not None:
-            self.pred_fake_I = p_fake_I["preds"][-1]
+            self.pred_fake_I = p_fake_I["preds"][-1][:n]
         if p_full is not None:
             self.pred_fake_T_full = p_full["preds"][-1]
 

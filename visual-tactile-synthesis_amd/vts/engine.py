@@ -679,8 +679,11 @@ def _packed4(conv, mode, cache):
     return buf
 
 
-def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None):
-    """one PatchGAN of the pyramid: returns the list of layer outputs (Act), the last one is the prediction"""
+def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None, groups=None, stat_rec=None, ext=None):
+    """one PatchGAN of the pyramid: returns the list of layer outputs (Act), the last one is the prediction.
+    groups: sample indices where the passes batched into this call start (BatchNorm statistics per pass: ops.norm_stats);
+    stat_rec: dict filled with {bn layer: (mean, unbiased var)} of this call; ext: (such a dict, after) whose running-statistics
+    updates are spliced in after pass `after`."""
     n, dev = a0.data.shape[0], a0.data.device
     layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
     acts = []
@@ -702,10 +705,14 @@ def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None):
                         act_in=LRELU if j else 0)
         if ci in D.BN_IDX:
             bn = getattr(layer, str(D.BN_IDX[ci]))
+            stat_out = None
+            if stat_rec is not None:
+                stat_out = stat_rec[ci] = (torch.empty(cout, dtype=torch.float32, device=dev), torch.empty(cout, dtype=torch.float32, device=dev))
             a = ops.norm_stats(out, 1, gamma=bn.weight, beta=bn.bias,
                                running_mean=bn.running_mean if update_stats else None,
                                running_var=bn.running_var if update_stats else None,
-                               nbt=bn.num_batches_tracked if update_stats else None)
+                               nbt=bn.num_batches_tracked if update_stats else None, groups=groups, stat_out=stat_out,
+                               ext=(ext[0][ci][0], ext[0][ci][1], ext[1]) if ext is not None else None)
         else:
             a = Act(out)
         acts.append(a)
@@ -714,7 +721,7 @@ def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None):
     return acts
 
 
-def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad, cache=None):
+def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad, cache=None, groups=None):
     """backward of one PatchGAN; returns the gradient w.r.t. the second concat source (or None)"""
     layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
     for j in range(len(D.CONV_IDX) - 1, -1, -1):
@@ -725,7 +732,7 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
         if ci in D.BN_IDX:
             bn = getattr(layer, str(D.BN_IDX[ci]))
             ops.norm_bwd(g, acts[j], 1, gamma=bn.weight, dgamma=bn.weight.grad if param_grads else None,
-                         dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate)
+                         dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate, groups=groups)
         src0, src1 = (a0, a1) if j == 0 else (acts[j - 1], None)
         if param_grads:
             pp = src0.padded if j else None
@@ -817,6 +824,11 @@ def msd_multi(jobs, criterion):
     accumulation are order dependent), different D's and different scales are independent lanes.
     pass: dict(in0, in1=None, real: bool, coeff, slot, grad_coeff=None (None: no gradient / no backward),
                param_grads=True, accumulate=False, input_grad=None, loss=True); `preds` is filled in.
+    A pass may BATCH several of the reference's discriminator calls (same weights, same input shape) along the sample axis:
+      groups=[dict(n0, n1, real, coeff, slot, grad_coeff), ...]  -- samples [n0, n1) are one reference call: own BatchNorm batch
+      statistics and running-statistics update (in list order), own loss term; one backward for all of them.
+    stat_only=True: a forward-only pass that only RECORDS its BatchNorm statistics; ext_from=<that pass>, ext_after=k splices
+    its running-statistics update after group k of this pass (keeps the reference's call order: sinskitG_model.py:1490-1584).
     The first job's first scale (put the full-resolution discriminator first) runs on the launch stream.
     A StyleGAN2 discriminator (`--netD stylegan2`) in `jobs` runs its passes on the launch stream after the lanes have joined."""
     sg_jobs = [j for j in jobs if getattr(j[0], "is_stylegan2_d", False)]
@@ -870,9 +882,27 @@ def _msd_multi(jobs, criterion):
         cache = {}      # packed weights of this scale: shared by its passes (they run in order in this lane)
         for p in passes:
             a0, a1 = p["_pyr"][s]
-            acts = _msd_scale_forward(D, s, a0, a1, True, cache)
+            groups = p.get("groups")
+            gstarts = [gr["n0"] for gr in groups] if groups else None
+            stat_rec = p.setdefault("_stats", {}).setdefault(s, {}) if p.get("stat_only") else None
+            src = p.get("ext_from")
+            ext = (src["_stats"][s], p.get("ext_after", 0)) if src is not None else None
+            acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext)
             pred = acts[-1].data
             p["preds"][s] = pred
+            if groups:
+                want = any(gr.get("grad_coeff") is not None for gr in groups)
+                g = torch.empty_like(pred) if want else None
+                for gr in groups:
+                    gc = gr.get("grad_coeff")
+                    if want and gc is None:
+                        g[gr["n0"]:gr["n1"]].zero_()
+                    criterion.accumulate([pred[gr["n0"]:gr["n1"]]], gr["real"], gr["coeff"], gr["slot"], grad_coeff=gc,
+                                         want_grad=gc is not None, out_grads=[g[gr["n0"]:gr["n1"]]] if gc is not None else None)
+                if want:
+                    p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
+                                                       p.get("input_grad") is not None, cache, gstarts)
+                continue
             if not p.get("loss", True):
                 continue
             gc = p.get("grad_coeff")
@@ -887,6 +917,7 @@ def _msd_multi(jobs, criterion):
             if p.get("input_grad") is not None:
                 _merge_input_grads(p["_din"], p["input_grad"])
             p.pop("_pyr"), p.pop("_din")
+            p.pop("_stats", None)
 
 
 # ======================================================================================================================

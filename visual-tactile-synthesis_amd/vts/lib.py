@@ -54,6 +54,8 @@ class NormDesc(C.Structure):
         ("eps", C.c_float), ("momentum", C.c_float), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean_out", C.c_void_p), ("rstd_out", C.c_void_p), ("counters", C.c_void_p),
+        ("ngroups", C.c_int), ("gstart", C.c_int * 9),
+        ("stat_mean_out", C.c_void_p), ("stat_uvar_out", C.c_void_p), ("ext_mean", C.c_void_p), ("ext_uvar", C.c_void_p), ("ext_after", C.c_int),
     ]
 
 
@@ -62,6 +64,7 @@ class NormBwdDesc(C.Structure):
         ("dy", C.c_void_p), ("x", C.c_void_p), ("nstride", C.c_int64), ("N", C.c_int), ("C", C.c_int), ("HW", C.c_int),
         ("mode", C.c_int), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p),
         ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate_param_grads", C.c_int), ("counters", C.c_void_p),
+        ("ngroups", C.c_int), ("gstart", C.c_int * 9),
     ]
 
 

@@ -541,9 +541,22 @@ def channel_sum(x, out, accumulate=False):
     return out
 
 
+def _set_groups(d, groups, n):
+    """groups: sample indices where the passes of a batched BatchNorm launch start, e.g. [0, 4] for fake | real"""
+    if not groups or len(groups) <= 1:
+        d.ngroups = 1
+        return
+    assert len(groups) <= 8 and groups[0] == 0 and all(b > a for a, b in zip(groups, list(groups[1:]) + [n]))
+    d.ngroups = len(groups)
+    for i, g in enumerate(list(groups) + [n]):
+        d.gstart[i] = int(g)
+
+
 def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var=None, nbt=None, eps=1e-5,
-               momentum=0.1):
-    """Returns Act(x, scale, shift, mean, rstd) -- x itself is not rewritten."""
+               momentum=0.1, groups=None, stat_out=None, ext=None):
+    """Returns Act(x, scale, shift, mean, rstd) -- x itself is not rewritten.
+    groups: batched passes (BatchNorm); stat_out = (mean [C], uvar [C]) tensors to record this launch's batch statistics;
+    ext = (mean [C], uvar [C], after) statistics of a separately launched pass to splice into the running-statistics sequence."""
     lib = L.load()
     n, c, h, w = x.shape
     st = torch.empty(4, n * c, dtype=torch.float32, device=x.device)
@@ -553,13 +566,18 @@ def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var
     d.gamma, d.beta = L.ptr(gamma), L.ptr(beta)
     d.running_mean, d.running_var, d.num_batches_tracked = L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt)
     d.scale, d.shift, d.mean_out, d.rstd_out = st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr()
+    _set_groups(d, groups, n)
+    if stat_out is not None:
+        d.stat_mean_out, d.stat_uvar_out = stat_out[0].data_ptr(), stat_out[1].data_ptr()
+    if ext is not None:
+        d.ext_mean, d.ext_uvar, d.ext_after = ext[0].data_ptr(), ext[1].data_ptr(), int(ext[2])
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), x.device)
     d.counters = L.ptr(counters(x.device)) if n * c <= (1 << 16) else None
     _run("norm_stats", 4.0 * n * c * h * w, 0.0, lib.vts_norm_stats, C.byref(d), ws.data_ptr(), L.stream())
     return Act(x, st[0], st[1], st[2], st[3])
 
 
-def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=False):
+def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=False, groups=None):
     """In place: dy (grad wrt normalised output) -> grad wrt the raw tensor act.data."""
     lib = L.load()
     n, c, h, w = dy.shape
@@ -568,6 +586,7 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
     d.mean, d.rstd = act.mean.data_ptr(), act.rstd.data_ptr()
     d.gamma, d.dgamma, d.dbeta = L.ptr(gamma), L.ptr(dgamma), L.ptr(dbeta)
     d.accumulate_param_grads = int(accumulate)
+    _set_groups(d, groups, n)
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
     d.counters = L.ptr(counters(dy.device)) if n * c <= (1 << 16) else None
     _run("norm_bwd", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
