@@ -107,10 +107,27 @@ typedef struct vts_wgrad_desc {
   float* dw;
   int accumulate;
   int pad_dx; /* horizontal padding = pad + pad_dx */
+  int defer;  /* 1: leave the per-workgroup partials in `ws` ([pw][CL][CH][16], pw = vts_wgrad4x4_ws_floats / (CL*CH*16)) and do not
+                 reduce them: the caller reduces the partials of many weight gradients at once with vts_wgrad_reduce_batch */
 } vts_wgrad_desc;
 
 int64_t vts_wgrad4x4_ws_floats(const vts_wgrad_desc* d);
 int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream);
+
+/* Deferred, batched form of the deterministic partial reduction: dw[i] (+)= sum over the segments, in order, of
+ * sum_{k < pw} part[k*nel + i] (fixed summation order, no float atomics).  One launch reduces the partials of every weight
+ * gradient of a backward pass (the headline step used to launch ~117 single reductions).  A weight gradient that receives
+ * several contributions (accumulation over passes) lists them as segments of ONE job, so jobs never share a dw. */
+#define VTS_REDUCE_MAX_SEG 4
+typedef struct vts_reduce_job {
+  float* dw;
+  int64_t nel;
+  int accumulate; /* add to the existing dw instead of overwriting it */
+  int nseg;
+  const float* part[VTS_REDUCE_MAX_SEG];
+  int pw[VTS_REDUCE_MAX_SEG];
+} vts_reduce_job;
+int vts_wgrad_reduce_batch(const vts_reduce_job* jobs /* host array */, int njobs, void* stream);
 
 /* Per-channel sum over (N, H, W): out[c] (+)= sum x[n,c,:,:]  (bias gradients). */
 int vts_channel_sum(const float* x, int64_t nstride, int N, int C, int HW, float* out, int accumulate,

@@ -1,0 +1,44 @@
+"""Micro-benchmark of vts_norm_stats / vts_norm_bwd / vts_channel_sum (HIP events): achieved GB/s vs algorithmic bytes."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "visual-tactile-synthesis_amd"))
+import torch  # noqa: E402
+
+from vts import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+for shape, mode in [((4, 10, 512, 512), 0), ((4, 20, 256, 256), 0), ((4, 40, 128, 128), 0), ((4, 80, 64, 64), 0), ((4, 80, 32, 32), 0),
+                    ((8, 16, 257, 257), 1), ((8, 32, 129, 129), 1), ((8, 64, 130, 130), 1), ((4, 16, 257, 257), 1), ((640, 16, 9, 9), 1),
+                    ((640, 64, 6, 6), 1)]:
+    x = torch.randn(shape, device=dev)
+    n, c, h, w = shape
+    gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    kw = dict(gamma=gamma, beta=beta) if mode else {}
+    us = timeit(lambda: ops.norm_stats(x, mode, **kw))
+    a = ops.norm_stats(x, mode, **kw)
+    dy = torch.randn(shape, device=dev)
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    kb = dict(gamma=gamma, dgamma=dg, dbeta=db) if mode else {}
+    ub = timeit(lambda: ops.norm_bwd(dy, a, mode, **kb))
+    out = torch.zeros(c, device=dev)
+    uc = timeit(lambda: ops.channel_sum(x, out))
+    by = x.numel() * 4.0
+    print("%-22s mode %d : stats %7.1f us %7.1f GB/s | bwd %7.1f us %7.1f GB/s (5 passes) | chsum %7.1f us %7.1f GB/s" % (
+        shape, mode, us, by / us / 1e3, ub, 5 * by / ub / 1e3, uc, by / uc / 1e3))

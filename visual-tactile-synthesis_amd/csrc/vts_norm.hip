@@ -294,6 +294,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* __restrict__
 // (the second pass hits L2) and finishes in place.  Most normalisation calls of the step are this small
 // (inner U-Net layers, every D2 patch pass), where three launches cost more than the arithmetic.
 constexpr int64_t FUSED_MAX_GROUP = 8192;
+constexpr int FUSED_BN_MAX_HW = 400;            // BatchNorm over many small maps (>= 32 channels): one workgroup per channel up to this map size ...
+constexpr int64_t FUSED_BN_MAX_GROUP = 1 << 17;  // ... and this many elements per pass
 
 // element j of group (c; n0..) -> offset into the NCHW tensor; BN groups flatten (n, i) so that every thread has work
 __device__ __forceinline__ int64_t fused_off(int j, int HW, int n0, int c, int64_t nstride, bool bn) {
@@ -496,7 +498,9 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
   VTS_CHECK_ARG(!(k.ext_mean && !k.ext_uvar) && !(k.stat_mean && !k.stat_uvar), "vts_norm_stats: ext / stat outputs come in pairs");
   const bool grouped = k.ngroups > 1 || k.stat_mean || k.ext_mean;
   const int64_t group = (int64_t)(d->mode == 0 ? 1 : maxg) * d->HW;
-  if (group <= FUSED_MAX_GROUP) {  // small groups: one launch, one workgroup per group (two passes, L2-resident)
+  // small groups: one launch, one workgroup per group (two passes, L2-resident).  BatchNorm over many tiny maps (the D2 passes:
+  // 640 patches of 6x6 .. 9x9) also goes here: the partial kernel would launch N*C workgroups of a few dozen elements each.
+  if (group <= FUSED_MAX_GROUP || (d->mode == 1 && d->C >= 32 && d->HW <= FUSED_BN_MAX_HW && group <= FUSED_BN_MAX_GROUP)) {
     hipLaunchKernelGGL(norm_stats_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
                        d->x, d->nstride, k);
     VTS_CHECK_LAUNCH("vts_norm_stats fused");
@@ -532,7 +536,7 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   }
   const bool grouped = k.ngroups > 1;
   const int64_t group = (int64_t)(d->mode == 0 ? 1 : maxg) * d->HW;
-  if (group <= FUSED_MAX_GROUP) {
+  if (group <= FUSED_MAX_GROUP || (d->mode == 1 && d->C >= 32 && d->HW <= FUSED_BN_MAX_HW && group <= FUSED_BN_MAX_GROUP)) {
     const NormBwdK& kf = k;
     hipLaunchKernelGGL(norm_bwd_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
                        d->dy, d->x, d->nstride, kf);

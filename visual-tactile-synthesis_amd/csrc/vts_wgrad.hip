@@ -544,6 +544,41 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// Batched form: blockIdx.x -> (job, 64-element block) through a table in the kernel arguments.
+constexpr int RB_JOBS = 40;
+struct ReduceTable {
+  int njobs;
+  int blk_start[RB_JOBS + 1];
+  vts_reduce_job job[RB_JOBS];
+};
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceTable t) {
+  __shared__ float red[16][64];
+  int lo = 0, hi = t.njobs - 1;   // uniform binary search: last job with blk_start <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.blk_start[mid] <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const vts_reduce_job& j = t.job[lo];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)(blockIdx.x - t.blk_start[lo]) * 64 + lane;
+  float s = 0.f;
+  if (i < j.nel)
+    for (int sg = 0; sg < j.nseg; ++sg) {
+      const float* part = j.part[sg];
+      for (int k = w; k < j.pw[sg]; k += 16) s += part[(int64_t)k * j.nel + i];
+    }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < j.nel) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][lane];
+    j.dw[i] = j.accumulate ? j.dw[i] + v : v;
+  }
+}
+
 struct Plan {
   int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles, txl;
   int ns;   // 1: N-split kernel (wgrad4x4_ns_kernel), cht = high-res channels per WAVE
@@ -554,15 +589,16 @@ Plan make_plan(const vts_wgrad_desc* d) {
   const int CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
   pl.ns = 0;
   static const int use_ns = getenv("VTS_WGRAD_NS") ? atoi(getenv("VTS_WGRAD_NS")) : 1;
+  static const int ns_min_ch = getenv("VTS_WGRAD_NS_MINCH") ? atoi(getenv("VTS_WGRAD_NS_MINCH")) : 5;
+  static const int ns_min_w = getenv("VTS_WGRAD_NS_MINW") ? atoi(getenv("VTS_WGRAD_NS_MINW")) : 8;
   // (the buffer-load addressing of the N-split kernel needs channel planes below 2^26 bytes)
-  if (use_ns && CH >= 5 && d->LW > 8 && (int64_t)d->HH * d->HW < (1 << 24) && (int64_t)d->LH * d->LW < (1 << 24)) {
+  if (use_ns && CH >= ns_min_ch && d->LW > ns_min_w && (int64_t)d->HH * d->HW < (1 << 24) && (int64_t)d->LH * d->LW < (1 << 24)) {
     // N-split kernel: the waves of a workgroup split 4*cht high-res channels; groups are balanced so that the last one is not mostly empty
     pl.ns = 1;
     pl.cl_groups = cdiv(CL, 80);
     pl.clt = cdiv(CL, 16 * pl.cl_groups);
     pl.ch_groups = cdiv(CH, 20);
     pl.cht = cdiv(CH, 4 * pl.ch_groups);
-    if (pl.cht < 2) pl.cht = 2;
     const int ty = d->stride == 2 ? 2 : 4;
     pl.tiles_y = cdiv(d->LH, ty);
     pl.txl = 28;
@@ -572,7 +608,11 @@ Plan make_plan(const vts_wgrad_desc* d) {
     static const int ns_wgs = getenv("VTS_WGRAD_NS_WGS") ? atoi(getenv("VTS_WGRAD_NS_WGS")) : 512;
     int pw = ns_wgs / groups;
     const int64_t nel = (int64_t)CL * CH * 16;
-    const int64_t cap = (16 << 20) / nel;   // partials <= 64 MB
+    // every pixel worker writes (and the reduction re-reads) a full copy of dw: keep that traffic below ~2x the operand bytes
+    // (inner U-Net layers: 80..592 x 80 channels on <= 32x32 maps would otherwise move 50 MB of partials for 8 MB of operands)
+    const int64_t operand = (int64_t)d->N * ((int64_t)CL * d->LH * d->LW + (int64_t)CH * d->HH * d->HW);
+    int64_t cap = (2 * operand > (1 << 20) ? 2 * operand : (1 << 20)) / nel;
+    if (cap > (16 << 20) / nel) cap = (16 << 20) / nel;   // and never more than 64 MB
     if (pw > cap) pw = (int)cap;
     if (pw < 1) pw = 1;
     if (pw > pl.ntiles) pw = pl.ntiles;
@@ -626,7 +666,7 @@ template <int S>
 bool dispatch_ns(const WgK& k, const Plan& pl, hipStream_t st) {
 #define NS_CASE(CLT, CHT) \
   if (pl.clt == CLT && pl.cht == CHT) { launch_ns<S, CLT, CHT>(k, pl, st); return true; }
-#define NS_ROW(CLT) NS_CASE(CLT, 2) NS_CASE(CLT, 3) NS_CASE(CLT, 4) NS_CASE(CLT, 5)
+#define NS_ROW(CLT) NS_CASE(CLT, 1) NS_CASE(CLT, 2) NS_CASE(CLT, 3) NS_CASE(CLT, 4) NS_CASE(CLT, 5)
   NS_ROW(1) NS_ROW(2) NS_ROW(3) NS_ROW(4) NS_ROW(5)
 #undef NS_ROW
 #undef NS_CASE
@@ -666,6 +706,7 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
     const bool ok = d->stride == 2 ? dispatch_ns<2>(k, pl, st) : dispatch_ns<1>(k, pl, st);
     VTS_CHECK_ARG(ok, "vts_wgrad4x4: no N-split instance for clt %d cht %d", pl.clt, pl.cht);
     VTS_CHECK_LAUNCH("vts_wgrad4x4 (N-split)");
+    if (d->defer) return VTS_OK;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 64)), dim3(1024), 0, st, ws, nel, pl.pw, d->dw, d->accumulate);
     VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
     return VTS_OK;
@@ -676,8 +717,31 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   WG_CASE(1, 1, 4) WG_CASE(1, 1, 10) WG_CASE(1, 2, 4) WG_CASE(1, 2, 10) WG_CASE(1, 3, 4) WG_CASE(1, 3, 10) WG_CASE(1, 5, 4)
 #undef WG_CASE
   VTS_CHECK_LAUNCH("vts_wgrad4x4");
+  if (d->defer) return VTS_OK;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 64)), dim3(1024), 0, st, ws, nel, pl.pw, d->dw,
                      d->accumulate);
   VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
+  return VTS_OK;
+}
+
+extern "C" int vts_wgrad_reduce_batch(const vts_reduce_job* jobs, int njobs, void* stream) {
+  VTS_CHECK_ARG(jobs && njobs >= 0, "vts_wgrad_reduce_batch: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += RB_JOBS) {
+    ReduceTable t;
+    t.njobs = njobs - j0 < RB_JOBS ? njobs - j0 : RB_JOBS;
+    int blocks = 0;
+    for (int j = 0; j < t.njobs; ++j) {
+      const vts_reduce_job& q = jobs[j0 + j];
+      VTS_CHECK_ARG(q.dw && q.nel > 0 && q.nseg >= 1 && q.nseg <= VTS_REDUCE_MAX_SEG, "vts_wgrad_reduce_batch: bad job %d", j0 + j);
+      for (int sg = 0; sg < q.nseg; ++sg) VTS_CHECK_ARG(q.part[sg] && q.pw[sg] >= 1, "vts_wgrad_reduce_batch: bad segment %d of job %d", sg, j0 + j);
+      t.job[j] = q;
+      t.blk_start[j] = blocks;
+      blocks += (int)cdiv64(q.nel, 64);
+    }
+    t.blk_start[t.njobs] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, t);
+    VTS_CHECK_LAUNCH("vts_wgrad_reduce_batch");
+  }
   return VTS_OK;
 }

@@ -117,7 +117,13 @@ def unet_forward(G, x, style_code=None, keep=True):
 
 def unet_backward(G, ctx, d_raw):
     """d_raw: [N,5,H,W] gradient wrt the pre-tanh outputs of up0 / up0_T.
-    Writes every parameter's .grad (overwrite) -- the G step has a single backward."""
+    Writes every parameter's .grad (overwrite) -- the G step has a single backward.
+    The deterministic reduction of all weight-gradient partials is ONE launch at the end (ops.deferred_wgrad)."""
+    with ops.deferred_wgrad():
+        _unet_backward(G, ctx, d_raw)
+
+
+def _unet_backward(G, ctx, d_raw):
     nd, ch = G.num_downs, G.channels
     n = d_raw.shape[0]
     dev = d_raw.device
@@ -485,7 +491,7 @@ def _seq_backward(steps, g, sq, bn_of):
             else:
                 co, ci = conv.weight.shape[:2]
                 dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
-                sq.run(lambda: (ops.wgrad4x4(g, hi, dw4, stride=2, pad=1, act_hi=inp_act), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
+                sq.run(lambda: (ops.wgrad4x4(g, hi, dw4, stride=2, pad=1, act_hi=inp_act, defer=False), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
                 w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
                 ops.conv4x4(g, w4, 16, ci * 16, ci, din, stride=2, pad=1, transposed=True)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
@@ -501,7 +507,7 @@ def _seq_backward(steps, g, sq, bn_of):
                 ops.conv3x3s2_wide(gp, ops.w3x3_pack(conv.weight, "convT_adj"), None, din)
             else:
                 dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
-                sq.run(lambda: (ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
+                sq.run(lambda: (ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act, defer=False), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
                 w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
                 ops.conv4x4(g, w4, co * 16, 16, ci, din, stride=2, pad=1)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
@@ -609,6 +615,10 @@ class SideQueue:
 
     def join(self):
         if self.on:
+            lane, ops.WS_LANE = ops.WS_LANE, SideQueue.LANE
+            with torch.cuda.stream(self.stream):
+                ops.wgrad_flush(SideQueue.LANE)     # this lane's deferred weight-gradient reduction, on its own stream
+            ops.WS_LANE = lane
             self.main.wait_stream(self.stream)
         self.keep = []
 
@@ -634,8 +644,10 @@ def _run_lanes(n_lanes, body):
         ops.WS_LANE = lane
         with torch.cuda.stream(side[lane - 1]):
             body(lane)
+            ops.wgrad_flush(lane)       # deferred weight-gradient reductions of this lane, on its own stream
     ops.WS_LANE = 0
     body(0)
+    ops.wgrad_flush(0)
     for st in side[:n_lanes - 1]:
         main.wait_stream(st)
 
@@ -811,7 +823,8 @@ def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=
         a0, a1, acts = ctx.scales[s]
         din_scales[s] = _msd_scale_backward(D, s, a0, a1, acts, dpreds[s], param_grads, accumulate, input_grad is not None)
 
-    _run_lanes(D.num_D, lane)
+    with ops.deferred_wgrad():
+        _run_lanes(D.num_D, lane)
     if input_grad is not None:
         _merge_input_grads(din_scales, input_grad)
     return None
@@ -911,7 +924,8 @@ def _msd_multi(jobs, criterion):
                 p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
                                                    p.get("input_grad") is not None, cache)
 
-    _run_lanes(len(lanes), lane)
+    with ops.deferred_wgrad():    # one reduction launch for the weight-gradient partials of all lanes, after they have joined
+        _run_lanes(len(lanes), lane)
     for D, passes in jobs:
         for p in passes:
             if p.get("input_grad") is not None:

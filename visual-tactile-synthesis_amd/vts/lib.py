@@ -44,8 +44,12 @@ class WgradDesc(C.Structure):
         ("lo0", Operand), ("lo1", Operand), ("hi0", Operand), ("hi1", Operand),
         ("act_lo", C.c_int), ("act_hi", C.c_int),
         ("N", C.c_int), ("LH", C.c_int), ("LW", C.c_int), ("HH", C.c_int), ("HW", C.c_int),
-        ("stride", C.c_int), ("pad", C.c_int), ("dw", C.c_void_p), ("accumulate", C.c_int), ("pad_dx", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("dw", C.c_void_p), ("accumulate", C.c_int), ("pad_dx", C.c_int), ("defer", C.c_int),
     ]
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [("dw", C.c_void_p), ("nel", C.c_int64), ("accumulate", C.c_int), ("nseg", C.c_int), ("part", C.c_void_p * 4), ("pw", C.c_int * 4)]
 
 
 class NormDesc(C.Structure):
@@ -72,7 +76,7 @@ _lib = None
 
 # every symbol include/vts.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
-    "vts_last_error", "vts_last_kernel", "vts_version", "vts_conv4x4", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_channel_sum",
+    "vts_last_error", "vts_last_kernel", "vts_version", "vts_conv4x4", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_wgrad_reduce_batch", "vts_channel_sum",
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
@@ -119,6 +123,7 @@ def load():
         "vts_conv4x4": [C.POINTER(ConvDesc), vp],
         "vts_wgrad4x4_ws_floats": [C.POINTER(WgradDesc)],
         "vts_wgrad4x4": [C.POINTER(WgradDesc), vp, vp],
+        "vts_wgrad_reduce_batch": [C.POINTER(ReduceJob), i, vp],
         "vts_channel_sum": [vp, i64, i, i, i, vp, i, vp, vp, vp],
         "vts_norm_stats": [C.POINTER(NormDesc), vp, vp],
         "vts_norm_bwd": [C.POINTER(NormBwdDesc), vp, vp],

@@ -37,8 +37,15 @@ TIMER = None
 DETAIL = None  # shape string of the launch being issued (only filled while TIMER is on)
 
 
+# timing experiments only (results are wrong): VTS_KNOCKOUT=norm_stats,wgrad4x4 skips every launch whose label starts with one of
+# the prefixes -- what a category of kernels contributes to the critical path of the laned step
+KNOCKOUT = tuple(k for k in os.environ.get("VTS_KNOCKOUT", "").split(",") if k)
+
+
 def _run(label, nbytes, flops, fn, *args):
     global DETAIL
+    if KNOCKOUT and label.startswith(KNOCKOUT):
+        return
     if TIMER is None:
         L.check(fn(*args), label)
         return
@@ -147,7 +154,98 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     return out
 
 
-def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, pad=1, accumulate=False, pad_dx=0):
+# ---- deferred weight-gradient reduction -------------------------------------------------------------------------------
+# Inside `with deferred_wgrad():` every wgrad4x4 leaves its per-workgroup partials in a per-lane arena and the deterministic
+# reduction of ALL of them is one vts_wgrad_reduce_batch launch when the outermost context exits (the engine exits it after
+# its side streams have joined the launch stream).  Outside the context wgrad4x4 reduces immediately.
+_DEFER_DEPTH = 0
+_pending = []        # ReduceJob-like dicts, in enqueue order
+_pending_by_dw = {}
+_arenas = {}
+
+
+class _Arena:
+    """bump allocator over grow-only blocks; the allocation sequence of a training step is the same every step, so a reset
+    at every flush hands out the same addresses again (captured HIP graphs stay valid; blocks are never freed)"""
+
+    def __init__(self, device):
+        self.device, self.blocks, self.cur, self.off = device, [], 0, 0
+
+    def alloc(self, nfloats):
+        nfloats = (int(nfloats) + 63) // 64 * 64
+        while True:
+            if self.cur < len(self.blocks):
+                b = self.blocks[self.cur]
+                if self.off + nfloats <= b.numel():
+                    t = b[self.off:self.off + nfloats]
+                    self.off += nfloats
+                    return t
+                if self.off == 0:      # an empty block that is too small: replace it by a larger one (the old one stays alive)
+                    _retired.append(b)
+                    self.blocks[self.cur] = torch.empty(max(nfloats, 2 * b.numel()), dtype=torch.float32, device=self.device)
+                    continue
+                self.cur, self.off = self.cur + 1, 0
+            else:
+                self.blocks.append(torch.empty(max(nfloats, 16 << 20), dtype=torch.float32, device=self.device))
+
+    def reset(self):
+        self.cur, self.off = 0, 0
+
+
+def _arena(device):
+    key = (str(device), WS_LANE)
+    a = _arenas.get(key)
+    if a is None:
+        a = _arenas[key] = _Arena(device)
+    return a
+
+
+DEFER_WGRAD = os.environ.get("VTS_WGRAD_DEFER", "1") != "0"
+FLUSH_BYTES = int(os.environ.get("VTS_WGRAD_FLUSH_MB", "96")) << 20   # a lane reduces its pending partials once they exceed this (keeps the reduction spread over the backward)
+
+
+def wgrad_flush(lane=None):
+    """Reduce pending weight-gradient partials on the CURRENT stream: those of one lane (the caller is on that lane's stream, or
+    has joined it), or of every lane (lane None: call on the launch stream after all lanes have joined)."""
+    global _pending
+    todo = [q for q in _pending if lane is None or q["lane"] == lane]
+    if not todo:
+        return
+    jobs = (L.ReduceJob * len(todo))()
+    nbytes = 0.0
+    for j, q in zip(jobs, todo):
+        j.dw, j.nel, j.accumulate, j.nseg = q["dw"].data_ptr(), q["nel"], int(q["accumulate"]), len(q["segs"])
+        for i, (part, pw) in enumerate(q["segs"]):
+            j.part[i], j.pw[i] = part.data_ptr(), pw
+            nbytes += 4.0 * pw * q["nel"]
+        _pending_by_dw.pop(q["dw"].data_ptr(), None)
+    _run("wgrad_reduce_batch", nbytes, 0.0, L.load().vts_wgrad_reduce_batch, jobs, len(todo), L.stream())
+    _pending = [q for q in _pending if not (lane is None or q["lane"] == lane)]
+    for (dev, ln), a in _arenas.items():
+        if lane is None or ln == lane:
+            a.reset()
+
+
+def wgrad_pending_bytes(lane):
+    return sum(4.0 * pw * q["nel"] for q in _pending if q["lane"] == lane for _, pw in q["segs"])
+
+
+class deferred_wgrad:
+    def __enter__(self):
+        global _DEFER_DEPTH
+        _DEFER_DEPTH += 1
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _DEFER_DEPTH
+        _DEFER_DEPTH -= 1
+        if _DEFER_DEPTH == 0 and exc_type is None:
+            wgrad_flush()
+        return False
+
+
+def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, pad=1, accumulate=False, pad_dx=0, defer=None):
+    """defer: None = follow the enclosing deferred_wgrad() context; False = reduce now (the caller reads dw right away)"""
     lib = L.load()
     d = L.WgradDesc()
     d.lo0, d.lo1, d.hi0, d.hi1 = _op(lo0), _op(lo1), _op(hi0), _op(hi1)
@@ -160,14 +258,32 @@ def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, 
     d.dw = dw.data_ptr()
     d.accumulate = int(accumulate)
     n = lib.vts_wgrad4x4_ws_floats(C.byref(d))
-    ws = workspace(n, lo.device)
     cl, chn = d.lo0.C + d.lo1.C, d.hi0.C + d.hi1.C
+    nel = cl * chn * 16
+    if defer is None:
+        defer = _DEFER_DEPTH > 0 and DEFER_WGRAD
+    prev = _pending_by_dw.get(dw.data_ptr()) if defer else None
+    if prev is not None and (len(prev["segs"]) >= 4 or prev["nel"] != nel):
+        raise RuntimeError("wgrad4x4: more than 4 deferred contributions to one weight gradient")
+    ws = _arena(lo.device).alloc(n) if defer else workspace(n, lo.device)
+    d.defer = int(bool(defer))
     flops = 2.0 * d.N * d.LH * d.LW * cl * chn * 16
     nbytes = 4.0 * (d.N * cl * d.LH * d.LW + d.N * chn * d.HH * d.HW + cl * chn * 16)
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d lo %dx%dx%d hi %dx%dx%d p%d" % (d.N, cl, d.LH, d.LW, chn, d.HH, d.HW, pad)
     _run("wgrad4x4<s%d>" % stride, nbytes, flops, lib.vts_wgrad4x4, C.byref(d), ws.data_ptr(), L.stream())
+    if defer:
+        seg = (ws, int(n // nel))
+        if prev is not None:
+            assert accumulate, "a second deferred contribution to a weight gradient must accumulate"
+            prev["segs"].append(seg)
+        else:
+            q = dict(dw=dw, nel=nel, accumulate=accumulate, segs=[seg], lane=WS_LANE)
+            _pending.append(q)
+            _pending_by_dw[dw.data_ptr()] = q
+        if wgrad_pending_bytes(WS_LANE) > FLUSH_BYTES:
+            wgrad_flush(WS_LANE)      # on this lane's stream, in stream order behind the launches that wrote the partials
     return dw
 
 
@@ -225,7 +341,7 @@ def wgradk(dout, x, dw, *, pad=0, act_hi=0, accumulate=False):
     co, ci, K, _ = dw.shape
     dw4 = _w4_scratch(dw, K, "grad")
     for i, (a, b) in enumerate(_tap_blocks(K)):
-        wgrad4x4(dout, x, dw4[i], stride=1, pad=pad - 4 * a, pad_dx=4 * (a - b), act_hi=act_hi)
+        wgrad4x4(dout, x, dw4[i], stride=1, pad=pad - 4 * a, pad_dx=4 * (a - b), act_hi=act_hi, defer=False)
         tap_extract(dw4[i], K, a, b, dw, accumulate=accumulate)
     return dw
 
@@ -267,7 +383,7 @@ def wgradk_s2(dout, x, dw, *, act_hi=0, accumulate=False):
     xs = x.data.shape if isinstance(x, Act) else x.shape
     o = _s2_origin(K, xs[2], xs[3])
     dw4 = _w4_scratch(dw, K, "grad_s2")[0]
-    wgrad4x4(dout, x, dw4, stride=2, pad=o, act_hi=act_hi)
+    wgrad4x4(dout, x, dw4, stride=2, pad=o, act_hi=act_hi, defer=False)
     _run("tap_extract", 0.0, 0.0, L.load().vts_tap_extract_at, dw4.data_ptr(), dw.numel() // (K * K), K, -o, -o, dw.data_ptr(),
          int(accumulate), L.stream())
     return dw
