@@ -268,6 +268,25 @@ def main():
         dt = float(t.item())
     losses = model.get_current_losses()
     finite = all(v == v and abs(v) < 1e30 for v in losses.values())
+    comm = None
+    if world > 1:
+        # exposed communication: the same K steps without the gradient all-reduces (the replicas drift apart: timing only, last)
+        ddp.COMM_OFF = True
+        for _ in range(2):
+            model.optimize_parameters(epoch=1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            model.optimize_parameters(epoch=1)
+        barrier()
+        dt_off = time.perf_counter() - t1
+        t = torch.tensor([dt_off], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_off = float(t.item())
+        ddp.COMM_OFF = False
+        comm = {"ms_per_step_without_allreduce": dt_off / args.steps * 1e3,
+                "exposed_allreduce_ms_per_step": (dt - dt_off) / args.steps * 1e3,
+                "buckets": {k: int(b.buf.numel()) * 4 for k, b in model.ddp.buckets.items()} if getattr(model, "ddp", None) else None}
 
     if rank == 0:
         roof = kernel_roofline(model, batch, args.detail) if world == 1 else None
@@ -300,6 +319,8 @@ def main():
             },
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if comm is not None:
+            out["comm"] = comm
         emit(json.dumps(out))
     elif world > 1:
         pass

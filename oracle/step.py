@@ -113,8 +113,19 @@ def _d1(sdD, x, opt):
     return nets.msd_forward(sdD, x, opt.num_D)
 
 
-def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, record=True):
+def _exchange(sd, name, exchange):
+    """data-parallel runs replace every local gradient by the mean over the ranks between backward and Adam; `exchange(name, grads)`
+    returns that mean for network `name` given this rank's gradients (the test harness supplies it: tests/test_ddp_step_gpu.py)"""
+    if exchange is None:
+        return
+    new = exchange(name, _grads(sd))
+    for k, g in new.items():
+        sd[k].grad = g.clone()
+
+
+def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, record=True, exchange=None):
     """One G+D1+D2 update, in place on the three state dicts and `adam` (dict of 3 Adam states).
+    exchange: optional hook emulating the data-parallel gradient exchange (see _exchange); recorded gradients are the LOCAL ones.
 
     Returns a dict with losses, outputs and (if record) the gradients taken at each of
     the three backward points.
@@ -156,6 +167,7 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     if record:
         out["grad_D"] = _grads(sdD)
         out["pred_fake_I"] = [p[-1].detach().clone() for p in pred_fake]
+    _exchange(sdD, "D", exchange)
     _adam(sdD, adam["D"], opt.lr * opt.lr_scale, opt)
     _req(sdD, False)
 
@@ -188,6 +200,7 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     if record:
         out["grad_D2"] = _grads(sdD2)
         out["pred_fake_T_full"] = pred_full[-1][-1].detach().clone()
+    _exchange(sdD2, "D2", exchange)
     _adam(sdD2, adam["D2"], opt.lr_G2 * opt.lr_scale, opt)
     _req(sdD2, False)
 
@@ -204,6 +217,7 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     loss_G.backward()
     if record:
         out["grad_G"] = _grads(sdG)
+    _exchange(sdG, "G", exchange)
     _adam(sdG, adam["G"], opt.lr * opt.lr_scale, opt)
     _req(sdG, False)
 

@@ -150,7 +150,8 @@ class SinSKITGModel(BaseModel):
         self.netG = networks.define_G(input_nc, opt.image_nc + opt.touch_nc, opt.ngf, opt.netG, opt.normG, not opt.no_dropout,
                                       opt.init_type, opt.init_gain, opt.no_antialias, opt.no_antialias_up, self.gpu_ids, opt,
                                       num_layer_separate=opt.num_layer_separate)
-        self.flatG = FlatParams(self.netG)
+        # decoder parameters first in the flat buffers: their gradients form the bucket that is all-reduced under the encoder's backward
+        self.flatG = FlatParams(self.netG, first=(lambda k: k.startswith("up")) if isinstance(self.netG, networks.CustomUnetGenerator) else None)
         self.use_cGAN_G2_S = bool(opt.use_cGAN_G2_S)
         self.use_cGAN_G2_I = bool(opt.use_cGAN_G2_I)
         if self.isTrain:
@@ -491,30 +492,17 @@ class SinSKITGModel(BaseModel):
         if p_full is not None:
             self.pred_fake_T_full = p_full["preds"][-1]
 
-    def _seg_g_update(self):
-        """Adam for D / D2, then the generator's loss terms (compute_G1_loss / compute_G2_loss) and its backward"""
+    def _seg_g_pre(self):
+        """the generator's loss terms that need no discriminator (compute_G1_loss / compute_G2_loss: the L1 terms).  In a data-parallel
+        run this segment is what the D / D2 gradient all-reduces travel under."""
         opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
         n, _, h, w = self.real_S.shape
         nt, P = ts["NT"], ts["real_T"].shape[0]
-        jobs = []
         self._d_fake_I = torch.empty(n, 3, h, w, device=dev)
-        have = False
-        if "D" in self.model_names:
-            self.optimizer_D.step(self._gscale)
-            lam = opt.lambda_G1_GAN
-            jobs.append((self.netD, [dict(in0=self.real_S, in1=self.fake_I, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
-                                          param_grads=False, input_grad=(self._d_fake_I, False))]))
-            have = True
-        if "D2" in self.model_names:
-            self.optimizer_D2.step(self._gscale)
-            # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
-            jobs.append((self.netD2, [dict(in0=self._fake_stack, real=True, coeff=opt.lambda_G2_GAN * nt, slot=slot["G2_GAN"])]))
-        if jobs:
-            engine.msd_multi(jobs, self.criterionGAN)
+        self._have_dI = False
         if opt.lambda_G1_L1 > 0.0:
-            ops.l1(self.fake_I, self.real_I, opt.lambda_G1_L1 / self.fake_I.numel(), slot["G_L1"], self._d_fake_I, accumulate=have)
-            have = True
-        self._have_dI = have
+            ops.l1(self.fake_I, self.real_I, opt.lambda_G1_L1 / self.fake_I.numel(), slot["G_L1"], self._d_fake_I, accumulate=False)
+            self._have_dI = True
         d_fake_T = None
         if opt.lambda_G2_L1 > 0.0:
             d_patch = torch.empty(P, 2, 32, 32, device=dev)
@@ -522,14 +510,43 @@ class SinSKITGModel(BaseModel):
             d_fake_T = torch.empty(n, 2, h, w, device=dev)
             ops.patch_scatter_bwd(d_patch, 0, 2, ts["offx"], ts["offy"], nt, 32, d_fake_T)
         self._d_fake_T = d_fake_T
-        self._g_backward()
 
-    def _g_backward(self):
+    def _seg_g_main(self, part="all"):
+        """Adam for D / D2, then the generator's GAN terms and its backward (part 'decoder': only the decoder half; the encoder half
+        is _seg_g_enc, so that the decoder's gradient bucket can be all-reduced under it)"""
+        opt, ts, slot = self.opt, self.train_set, self._slot
+        nt = ts["NT"]
+        jobs = []
+        if "D" in self.model_names:
+            self.optimizer_D.step(self._gscale)
+            lam = opt.lambda_G1_GAN
+            jobs.append((self.netD, [dict(in0=self.real_S, in1=self.fake_I, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
+                                          param_grads=False, input_grad=(self._d_fake_I, self._have_dI))]))
+            self._have_dI = True
+        if "D2" in self.model_names:
+            self.optimizer_D2.step(self._gscale)
+            # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
+            jobs.append((self.netD2, [dict(in0=self._fake_stack, real=True, coeff=opt.lambda_G2_GAN * nt, slot=slot["G2_GAN"])]))
+        if jobs:
+            engine.msd_multi(jobs, self.criterionGAN)
+        self._g_backward(part)
+
+    def _seg_g_update(self):
+        self._seg_g_pre()
+        self._seg_g_main()
+
+    def _seg_g_enc(self):
+        engine.unet_backward_encoder(self.netG, self._g_ctx, self._g_bwd_state)
+        self._g_bwd_state = None
+
+    def _g_backward(self, part="all"):
         n, _, h, w = self.real_S.shape
         d_raw = torch.empty(n, 5, h, w, device=self.device)
         ops.g_out_grad(self._d_fake_I if self._have_dI else None, self._d_fake_T, self.M, self.g_out, d_raw)
         if isinstance(self.netG, networks.ResnetGenerator):
             engine.resnet_backward(self.netG, self._g_ctx, d_raw)
+        elif part == "decoder":
+            self._g_bwd_state = engine.unet_backward_decoder(self.netG, self._g_ctx, d_raw)
         else:
             engine.unet_backward(self.netG, self._g_ctx, d_raw)
 
@@ -537,8 +554,22 @@ class SinSKITGModel(BaseModel):
         self.optimizer_G.step(self._gscale)
 
     def _segments(self):
-        """(segment, buckets to wait for before it, buckets to start after it)"""
-        return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_update, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
+        """(segment, buckets to wait for before it, buckets to start after it).  Single GPU: three segments.  Data parallel: the
+        step is cut where a gradient bucket becomes complete, and every all-reduce gets compute to travel under --
+          D, D2 buckets (complete after the discriminator updates)      under the generator's L1 terms (_seg_g_pre),
+          G_dec (decoder gradients, complete halfway through the backward) under the encoder's backward (_seg_g_enc),
+          G_enc is the exposed one (waited for right before Adam(G)).
+        The reference has no counterpart (nn.DataParallel, base_model.py:104-108, reduces inside autograd)."""
+        buckets = self.ddp.buckets if self.ddp is not None else {}
+        from vts import ddp as _ddp
+        if not (_ddp.active() and buckets):
+            return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_update, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
+        if "G_dec" in buckets:
+            return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_pre, (), ()),
+                    (lambda: self._seg_g_main("decoder"), ("D", "D2"), ("G_dec",)), (self._seg_g_enc, (), ("G_enc",)),
+                    (self._seg_adam_g, ("G_dec", "G_enc"), ())]
+        return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_pre, (), ()), (self._seg_g_main, ("D", "D2"), ("G",)),
+                (self._seg_adam_g, ("G",), ())]
 
     def _comm(self, name, start):
         if self.ddp is None or name not in self.ddp.buckets:

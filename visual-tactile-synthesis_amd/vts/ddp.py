@@ -3,10 +3,11 @@
 The hot path shards by image: every rank holds full replicas of G, D and D2
 and draws its own samples.  The only exchange is a sum-all-reduce of ONE flat fp32 gradient
 bucket per network (G 5.9 MB, D and D2 0.54 MB each); the division by world size is folded
-into the fused Adam kernel (`grad_scale`).  The all-reduce is issued asynchronously right
-after a network's backward and waited for just before that network's Adam step, so it
-overlaps the next phase's forward (D bucket under the D2 step, D2 bucket under the G-step
-discriminator forward).  BatchNorm statistics stay per rank, like per-replica BN under the
+into the fused Adam kernel (`grad_scale`).  Each all-reduce is issued asynchronously at the end of the
+captured segment that completes its bucket and waited for just before that network's Adam step
+(models/sinskitG_model.py:_segments): the D / D2 buckets travel under the generator's L1 terms, the
+generator's DECODER bucket (its gradients are complete halfway through the backward) under the
+encoder's backward; what stays exposed is the encoder bucket (bench.py reports the exposed time).  BatchNorm statistics stay per rank, like per-replica BN under the
 reference's nn.DataParallel (base_model.py:104-108).
 """
 import os
@@ -18,6 +19,14 @@ import torch.distributed as dist
 # VTS_DDP_FORCE=1: create the process group and run the bucket all-reduces even with ONE rank, so that the RCCL path
 # (async all-reduce on RCCL's stream between the captured segments of the step) can be exercised on a 1-GPU box.
 FORCE = os.environ.get("VTS_DDP_FORCE", "0") == "1"
+
+
+# measurement switch (bench.py): skip the all-reduces so that (time with) - (time without) = the exposed communication per step
+COMM_OFF = False
+
+
+def active():
+    return _active()
 
 
 def _active():
@@ -51,7 +60,7 @@ class GradBucket:
         self.work = None
 
     def start(self):
-        if _active():
+        if _active() and not COMM_OFF:
             self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, async_op=True)
 
     def wait(self):
@@ -88,5 +97,6 @@ def attach(model):
                 broadcast_module(net, 0)
         flat = getattr(model, "flat" + name, None)
         if flat is not None:
-            buckets[name] = GradBucket(flat.grad)
+            for bname, view in flat.buckets(name).items():
+                buckets[bname] = GradBucket(view)
     return DDPState(world, buckets)

@@ -123,7 +123,26 @@ def unet_backward(G, ctx, d_raw):
         _unet_backward(G, ctx, d_raw)
 
 
-def _unet_backward(G, ctx, d_raw):
+def unet_backward_decoder(G, ctx, d_raw):
+    """first half of unet_backward: every decoder (up*) gradient is complete when it returns (data-parallel runs all-reduce that
+    bucket while unet_backward_encoder runs).  Returns the state the second half needs."""
+    with ops.deferred_wgrad():
+        return _unet_backward(G, ctx, d_raw, part="decoder")
+
+
+def unet_backward_encoder(G, ctx, state):
+    with ops.deferred_wgrad():
+        _unet_backward(G, ctx, None, part="encoder", state=state)
+
+
+def _unet_backward(G, ctx, d_raw, part="all", state=None):
+    if part == "encoder":
+        dfeat = state
+        feats = ctx.feats
+        nd = G.num_downs
+        dev = dfeat[nd - 1].device
+        sq = SideQueue()
+        return _unet_backward_encoder(G, ctx, dfeat, feats, nd, dev, sq)
     nd, ch = G.num_downs, G.channels
     n = d_raw.shape[0]
     dev = d_raw.device
@@ -204,6 +223,13 @@ def _unet_backward(G, ctx, d_raw):
         for name in names:
             up_bwd(i, name, dx, dfeat, sq.run)
 
+    if part == "decoder":
+        sq.join()
+        return dfeat
+    return _unet_backward_encoder(G, ctx, dfeat, feats, nd, dev, sq)
+
+
+def _unet_backward_encoder(G, ctx, dfeat, feats, nd, dev, sq):
     for i in range(nd - 1, -1, -1):
         blk = getattr(G, "down%d" % i).conv
         g = dfeat[i]

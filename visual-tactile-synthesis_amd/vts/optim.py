@@ -14,8 +14,15 @@ from . import ops
 
 
 class FlatParams:
-    def __init__(self, module):
-        params = [p for p in module.parameters()]
+    def __init__(self, module, first=None):
+        """first: optional predicate on parameter names; matching parameters are laid out first in the flat buffers and
+        `self.split` is the offset where the rest starts (two contiguous gradient buckets: the generator's decoder gradients are
+        complete halfway through its backward and can be all-reduced under the encoder's).  state_dict order is unaffected."""
+        named = list(module.named_parameters())
+        if first is not None:
+            named = [kv for kv in named if first(kv[0])] + [kv for kv in named if not first(kv[0])]
+        self.split = sum(p.numel() for k, p in named if first(k)) if first is not None else None
+        params = [p for _, p in named]
         dev = params[0].device
         total = sum(p.numel() for p in params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
@@ -31,6 +38,12 @@ class FlatParams:
             p.requires_grad_(False)  # no autograd anywhere on the hot path
             o += n
         self.numel = total
+
+    def buckets(self, name):
+        """gradient buckets of this network for the data-parallel all-reduce: {bucket name: contiguous view of the flat gradient}"""
+        if self.split is None or self.split in (0, self.numel):
+            return {name: self.grad}
+        return {name + "_dec": self.grad[:self.split], name + "_enc": self.grad[self.split:]}
 
 
 class FlatAdam(torch.optim.Optimizer):
