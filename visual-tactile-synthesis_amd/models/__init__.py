@@ -5,11 +5,11 @@ it returns through the BaseModel method set.
 """
 import importlib
 
-from models.base_model import BaseModel
+from .base_model import BaseModel
 
 
 def find_model_using_name(model_name):
-    modellib = importlib.import_module("models." + model_name + "_model")
+    modellib = importlib.import_module("." + model_name + "_model", __package__)
     target = model_name.replace("_", "") + "model"
     for name, cls in modellib.__dict__.items():
         if name.lower() == target.lower() and isinstance(cls, type) and issubclass(cls, BaseModel):

@@ -427,6 +427,8 @@ def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, in
                               down="stride" if no_antialias else "blur", up="convT" if no_antialias_up else "blur", opt=opt)
     elif norm != "instance":
         raise NotImplementedError("unet256_custom is built for normG=instance only")
+    elif use_dropout:
+        raise NotImplementedError("unet256_custom: Dropout(0.5) in the Up blocks (--no_dropout False) is not built; pass --no_dropout True")
     else:
         net = CustomUnetGenerator(input_nc, output_nc, num_downs=8, ngf=ngf, num_layer_separate=num_layer_separate, opt=opt)
     return init_net(net, init_type, init_gain, gpu_ids)

@@ -15,7 +15,7 @@ pretrained weights that cannot exist offline: requesting them raises (`--no_vgg_
 """
 import torch
 
-import util.util as util
+from vts.misc import str2bool
 from vts import engine, ops
 from vts.ops import Act
 from vts.optim import FlatAdam, FlatParams
@@ -24,7 +24,7 @@ from . import networks
 from .base_model import BaseModel
 from .sinskitG_model import add_model_flags
 
-B = util.str2bool
+B = str2bool
 
 # (flag, type, default[, choices])  -- reference: pix2pixHD_model.py:45-200
 MODEL_FLAGS = [

@@ -21,7 +21,7 @@ import random
 import numpy as np
 import torch
 
-from util import util
+from vts.misc import str2bool
 from vts import engine, ops
 from vts.ops import Act
 from vts.optim import FlatAdam, FlatParams
@@ -29,7 +29,7 @@ from vts.optim import FlatAdam, FlatParams
 from . import networks
 from .base_model import BaseModel
 
-B = util.str2bool
+B = str2bool
 
 # (flag, type, default[, choices])  -- reference: sinskitG_model.py:52-296
 MODEL_FLAGS = [
@@ -583,6 +583,10 @@ class SinSKITGModel(BaseModel):
             self._graphs = None
             ops.FROZEN_WS = False
 
+    _STEP_OUTPUTS = ("g_out", "fake_I", "fake_T", "fake_N", "fake_gx", "fake_gy", "aug_fake_I", "aug_real_I", "_full_stack", "_stack_all",
+                     "_fake_stack", "_real_stack", "_more_stack", "fake_T_concat", "pred_fake_I", "pred_fake_T_full", "_g_ctx",
+                     "fake_sample_offset_x", "fake_sample_offset_y")
+
     def _capture_graphs(self):
         """Capture the segments as HIP graphs sharing one memory pool (torch.cuda.CUDAGraph over
         the launch stream our ctypes kernels use).  Capturing records work without executing it."""
@@ -604,6 +608,9 @@ class SinSKITGModel(BaseModel):
         for o, c in zip(self.optimizers, counts):
             o.step_count = c   # host mirrors moved during capture; the device counters did not
         self._graphs = graphs
+        # the tensors the captured step writes (visuals, predictions, patch stacks): a validation test() in between rebinds these
+        # attributes to ITS outputs, so every replay re-attaches the training ones (get_current_visuals / compute_metrics('train_'))
+        self._graph_attrs = {k: getattr(self, k) for k in self._STEP_OUTPUTS if hasattr(self, k)}
 
     def optimize_parameters(self, epoch=0, timing=False):
         if self.train_set is None:
@@ -626,6 +633,7 @@ class SinSKITGModel(BaseModel):
             for nme in start_after:
                 self._comm(nme, start=True)
         if replay:
+            self.__dict__.update(self._graph_attrs)
             for o in self.optimizers:
                 o.step_count += 1
         else:

@@ -8,11 +8,11 @@ schedule, as the survey prescribes.  The style code is produced upstream by a fr
 ViT-B/32 (`net_style`, :484-489) whose weights cannot exist offline: this class consumes a
 ready 512-d `style_code` from the batch (the synthetic dataset emits a seeded unit vector).
 """
-from util import util
+from vts.misc import str2bool
 
 from .sinskitG_model import SinSKITGModel, add_model_flags
 
-B = util.str2bool
+B = str2bool
 
 STYLE_FLAGS = [
     ("use_style_code", B, False), ("style_code_mode", str, "concat", ["concat", "adain"]),

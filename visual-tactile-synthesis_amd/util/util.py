@@ -8,15 +8,7 @@ import argparse
 import os
 
 
-def str2bool(v):
-    if isinstance(v, bool):
-        return v
-    s = v.lower()
-    if s in ("yes", "true", "t", "y", "1"):
-        return True
-    if s in ("no", "false", "f", "n", "0"):
-        return False
-    raise argparse.ArgumentTypeError("Boolean value expected.")
+from vts.misc import str2bool  # noqa: E402,F401  (one definition; the models package imports it from vts.misc)
 
 
 def mkdirs(paths):
