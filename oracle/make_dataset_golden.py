@@ -1,0 +1,116 @@
+"""Golden vectors of the dataset front-end (TEST INFRASTRUCTURE, build container only): runs the REFERENCE's SingleSkitDataset
+(/root/reference/data/singleskit_dataset.py) on a seeded synthetic material (data/synthetic_material.py) and stores what it caches.
+
+    python -m oracle.make_dataset_golden        ->  tests/golden/singleskit_dataset.npz
+
+The reference module imports cv2 and torchvision, which this image lacks (oracle/ref_import.py stubs them as empty modules).  The
+dataset USES three torchvision transforms; they are installed into the stub with their documented semantics:
+    ToTensor   uint8 HWC / PIL -> float CHW / 255; float ndarray [H, W] -> [1, H, W] unchanged      Normalize(m, s)  (x - m) / s
+    Compose    apply in order
+cv2 is only reached through util.variance_of_laplacian when --w_resampling is on: the fixture is generated with w_resampling False
+(that function stays parity-unpinned and says so).  Seeds: random.seed(s), numpy.random.seed(s) right before construction."""
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "visual-tactile-synthesis_amd")
+
+
+def dataset_opt(dataroot, phase, **kw):
+    train = phase == "train"
+    d = dict(dataroot=dataroot, max_dataset_size=float("inf"), sketch_nc=1, image_nc=3, use_bg_mask=True, is_train=train, random_scale_max=3.0,
+             batch_size=1, data_len=2, preprocess="crop" if train else "none", crop_size=256, center_w=200, center_h=160, T_resolution_multiplier=1,
+             sample_bbox_per_patch=2 if train else 1, w_resampling=False, resampling_w_min=1, resampling_w_max=10, batch_size_G2=8,
+             batch_size_G2_val=6, subdir_S="trainS" if train else "testS", subdir_I="trainI" if train else "testI",
+             subdir_T="trainT" if train else "testT", subdir_M="trainM" if train else "testM", subdir_valT="valT" if train else None)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def dump(ds, prefix, out):
+    for index in range(len(ds)):
+        item = ds[index]
+        for k, v in item.items():
+            key = "%s/%d/%s" % (prefix, index, k)
+            if torch.is_tensor(v) and k in ("S", "I", "M"):      # full-size images: every 4th pixel + sum / sum of squares
+                a = v.numpy().astype(np.float64)
+                out[key + "/sub"] = v.numpy()[:, ::4, ::4]
+                out[key + "/shape_sum_sq"] = np.array(list(a.shape) + [a.sum(), (a * a).sum()])
+            elif torch.is_tensor(v):
+                out[key] = v.numpy()
+            elif isinstance(v, np.ndarray):
+                out[key] = v
+            elif isinstance(v, dict):
+                for kk, vv in v.items():
+                    out[key + "/" + kk] = np.asarray(vv, dtype=np.float64)
+            elif isinstance(v, str):
+                out[key] = np.array(os.path.basename(v) if "paths" in k else v)
+            elif isinstance(v, list):
+                out[key] = np.asarray(v, dtype=np.float64) if len(v) else np.zeros((0,))
+
+
+def main():
+    from oracle import ref_import
+    ref_import.load()
+    for name in ("gspread", "oauth2client", "oauth2client.service_account"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["oauth2client.service_account"].ServiceAccountCredentials = object
+    tr = sys.modules["torchvision.transforms"]
+
+    class ToTensor:
+        def __call__(self, pic):
+            a = np.asarray(pic)
+            a = a[:, :, None] if a.ndim == 2 else a
+            t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+            return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.m, self.s = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.m) / self.s
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    tr.ToTensor, tr.Normalize, tr.Compose = ToTensor, Normalize, Compose
+    spec_dir = os.path.join(PKG, "data")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vts_synth_material", os.path.join(spec_dir, "synthetic_material.py"))
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+    from data.singleskit_dataset import SingleSkitDataset     # the REFERENCE's
+
+    out = {"meta": np.array("reference SingleSkitDataset on data/synthetic_material.write_material(seed 11 train / 12 test); seeds 5 / 6; "
+                            "w_resampling False; torch %s" % torch.__version__)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)      # the reference creates logs/<date> in the working directory
+        try:
+            for phase, mseed, seed in (("train", 11, 5), ("test", 12, 6)):
+                root = sm.write_material(os.path.join(tmp, "mat_" + phase), seed=mseed, phase=phase)
+                random.seed(seed)
+                np.random.seed(seed)
+                dump(SingleSkitDataset(dataset_opt(root, phase)), phase, out)
+        finally:
+            os.chdir(cwd)
+    path = os.path.join(ROOT, "tests", "golden", "singleskit_dataset.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Dataset front-end against the REFERENCE's SingleSkitDataset: tests/golden/singleskit_dataset.npz holds what the
+reference class cached for a seeded synthetic material (oracle/make_dataset_golden.py, build container); here the same material is
+written again and data/singleskit_dataset.py must reproduce every array -- images, tactile squares, contact masks, coordinates,
+augmentation parameters -- bit for bit under the same `random` / `numpy.random` seeds (train: random crop + sampled squares + sampled
+batch; test: centre crop, middle squares, all patches)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from data.singleskit_dataset import SingleSkitDataset, touch_data_loader, variance_of_laplacian
+from data.synthetic_material import write_material
+from oracle.make_dataset_golden import dataset_opt
+
+
+@pytest.mark.parametrize("phase,mseed,seed", [("train", 11, 5), ("test", 12, 6)])
+def test_singleskit_dataset_matches_reference_cache(phase, mseed, seed, tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, "singleskit_dataset.npz"))
+    root = write_material(str(tmp_path / ("mat_" + phase)), seed=mseed, phase=phase)
+    random.seed(seed)
+    np.random.seed(seed)
+    ds = SingleSkitDataset(dataset_opt(root, phase))
+    keys = [k for k in g.files if k.startswith(phase + "/")]
+    assert len(ds) == 2 and keys
+    seen = set()
+    for index in range(len(ds)):
+        item = ds[index]
+        for k, v in item.items():
+            key = "%s/%d/%s" % (phase, index, k)
+            if torch.is_tensor(v) and k in ("S", "I", "M"):
+                a = v.numpy().astype(np.float64)
+                assert np.array_equal(v.numpy()[:, ::4, ::4], g[key + "/sub"]), key
+                assert np.allclose(np.array(list(a.shape) + [a.sum(), (a * a).sum()]), g[key + "/shape_sum_sq"], rtol=1e-12), key
+                seen.update((key + "/sub", key + "/shape_sum_sq"))
+            elif torch.is_tensor(v) or isinstance(v, np.ndarray):
+                ref = g[key]
+                a = v.numpy() if torch.is_tensor(v) else v
+                assert a.shape == ref.shape and a.dtype == ref.dtype and np.array_equal(a, ref), key
+                seen.add(key)
+            elif isinstance(v, dict):
+                for kk, vv in v.items():
+                    assert float(np.asarray(vv, dtype=np.float64)) == float(g[key + "/" + kk]), (key, kk)
+                    seen.add(key + "/" + kk)
+            elif isinstance(v, str):
+                assert (os.path.basename(v) if "paths" in k else v) == str(g[key]), key
+                seen.add(key)
+            elif isinstance(v, list):
+                assert np.array_equal(np.asarray(v, dtype=np.float64) if len(v) else np.zeros((0,)), g[key]), key
+                seen.add(key)
+    assert seen == set(keys), set(keys) ^ seen
+    b = ds[0]
+    if phase == "train":
+        assert b["T_images"].shape == (8, 2, 32, 32) and b["T_coords"].shape == (8, 8) and b["I_masks"].shape == (8, 32, 32)
+        assert b["I_masks"].dtype == torch.float64 and b["val_T_images"].shape[0] == 6 and b["name"] == ""      # the reference's name quirk
+
+
+def test_collated_batch_feeds_the_training_step_contract(tmp_path):
+    """default_collate of the cached items gives the post-collate batch dict of SURVEY.md 8b (what SinSKITGModel.set_input consumes)"""
+    from torch.utils.data import default_collate
+
+    root = write_material(str(tmp_path / "m"), seed=3)
+    random.seed(1)
+    np.random.seed(1)
+    ds = SingleSkitDataset(dataset_opt(root, "train", w_resampling=True))
+    b = default_collate([ds[0]])
+    assert b["S"].shape == (1, 1, 256, 256) and b["I"].shape == (1, 3, 256, 256) and b["M"].shape == (1, 1, 256, 256)
+    assert float(b["S"].min()) >= -1 and float(b["S"].max()) <= 1 and set(np.unique(b["M"].numpy())) <= {0.0, 1.0}
+    assert b["T_images"].shape == (1, 8, 2, 32, 32) and b["T_coords"].shape == (1, 8, 8) and b["I_masks"].shape == (1, 8, 32, 32)
+    c = b["T_coords"][0].numpy()
+    assert (c[:, 4] == 32).all() and (c[:, 5] == 1).all() and (c[:, 0] + c[:, 6] + 32 <= 256).all() and (c[:, 1] + c[:, 7] + 32 <= 256).all()
+    assert set(b["augmentation_params"]) >= {"H", "W", "crop_pos_x", "crop_pos_y", "resize_ratio_w", "patch_crop_size"}
+
+
+def test_touch_npz_reader_and_laplacian_weight(tmp_path):
+    root = write_material(str(tmp_path / "m"), seed=4)
+    path = sorted(os.listdir(os.path.join(root, "trainT")))[0]
+    gx, gy, x, y, h, w, tm, cm = touch_data_loader(os.path.join(root, "trainT", path), convert2im=False)
+    assert gx.shape == gy.shape == tm.shape == cm.shape == (72, 88) and tm.max() == 1.0 and cm.max() == 1.0 and (int(h), int(w)) == (48, 56)
+    im, _, *_ = touch_data_loader(os.path.join(root, "trainT", path), convert2im=True, return_mask=False)
+    assert im.size == (88, 72) and im.mode == "L"
+    # 4-neighbour Laplacian with reflect-101 borders on (patch - 255) evaluated in uint8 (wraps): a white patch has zero variance, a
+    # single black pixel gives the variance of the kernel's impulse response
+    white = np.full((32, 32), 255, np.uint8)
+    assert variance_of_laplacian(white, ref=np.ones_like(white) * 255) == 0.0
+    one = white.copy()
+    one[10, 10] = 254                      # (254 - 255) wraps to 255
+    lap = np.zeros((32, 32))
+    lap[10, 10], lap[9, 10], lap[11, 10], lap[10, 9], lap[10, 11] = -4 * 255, 255, 255, 255, 255
+    assert abs(variance_of_laplacian(one, ref=np.ones_like(one) * 255) - lap.var()) < 1e-9
