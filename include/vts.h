@@ -416,11 +416,22 @@ int vts_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, c
                       float eps, const int* step_dev, float grad_scale, void* stream);
 
 /* PatchNCE loss forward+backward (models/patchnce.py:13-55): B groups of P patches, dim D.
- * loss[b*P+i] = CE([q_i.k_i, q_i.k_j (j != i; diagonal -> -10)] / T, 0); dq = d sum(loss*gscale) / dq. */
+ * loss[b*P+i] = CE([q_i.k_i, q_i.k_j (j != i; diagonal -> -10)] / T, 0); dq = d sum(loss*gscale) / dq.
+ * P, D <= 256 (the reference's 256 patches x 256 dims): one workgroup per (image, 64 queries), q k^T and the gradient W k on
+ * v_mfma_f32_16x16x4_f32, logits in LDS only, wave-shuffle softmax; larger P (all negatives of a minibatch) take a
+ * one-query-per-workgroup kernel. */
 int vts_patchnce(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq,
                  void* stream);
 /* Row L2 normalisation x / (||x|| + 1e-7) (models/networks.py:585-594). */
 int vts_l2norm_rows(const float* x, int rows, int D, float* y, void* stream);
+
+/* PatchSampleF (models/networks.py:667-719):
+ *   vts_patch_sample: out[(b*P + p)*C + c] = feat[b, c, ids[p]]   (feat.permute(0,2,3,1).flatten(1,2)[:, ids, :].flatten(0,1); the same
+ *                     ids for every image of the batch, as in the reference), feat [B, C, HW], ids int64 [P];
+ *   vts_linear_rows:  y[R x O] = act(x[R x I] W[O x I]^T + bias)  -- the nn.Linear layers of its optional 2-layer MLP (relu: 0 / 1),
+ *                     on the MFMA tile routine of the PatchNCE kernel. */
+int vts_patch_sample(const float* feat, const int64_t* ids, int B, int C, int HW, int P, float* out, void* stream);
+int vts_linear_rows(const float* x, const float* w, const float* bias, int R, int I, int O, int relu, float* y, void* stream);
 
 #ifdef __cplusplus
 }

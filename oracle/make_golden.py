@@ -102,6 +102,50 @@ def probes(sd, tag):
     return {"%s/%s" % (tag, k): detrand.probe(v, k) for k, v in sd.items() if v.dtype.is_floating_point}
 
 
+def golden_patchsample():
+    """PatchSampleF (with and without its MLP) + PatchNCELoss at the reference's working size: 256 patches x 256 dims, batch 2"""
+    from oracle import detrand, ref_import
+
+    ref_import.load()
+    from models import networks
+    from models.patchnce import PatchNCELoss
+    from types import SimpleNamespace
+
+    out = {"meta": np.array("reference PatchSampleF / PatchNCELoss; torch %s" % torch.__version__)}
+    feats = [detrand.uniform((2, 24, 20, 18), 41, "f0"), detrand.uniform((2, 40, 9, 11), 41, "f1")]
+    ids = [np.random.RandomState(3).permutation(20 * 18)[:256], np.random.RandomState(4).permutation(9 * 11)[:256]]
+    out["ids0"], out["ids1"] = ids[0], ids[1]
+    plain = networks.PatchSampleF(use_mlp=False, gpu_ids=[])
+    fo, _ = plain(feats, 256, ids)
+    out["plain0"], out["plain1"] = fo[0].numpy(), fo[1].numpy()
+    torch.manual_seed(17)
+    mlp = networks.PatchSampleF(use_mlp=True, init_type="normal", init_gain=0.02, nc=256, gpu_ids=[])
+    with torch.no_grad():
+        fm, _ = mlp(feats, 256, ids)
+    for i in range(2):
+        m = getattr(mlp, "mlp_%d" % i)
+        # the reference initialises N(0, 0.02): stored so that the build loads exactly these weights
+        out["mlp%d_w0" % i], out["mlp%d_b0" % i] = m[0].weight.detach().numpy(), m[0].bias.detach().numpy()
+        out["mlp%d_w2" % i], out["mlp%d_b2" % i] = m[2].weight.detach().numpy().astype(np.float16), m[2].bias.detach().numpy()
+        m[2].weight.data = torch.from_numpy(out["mlp%d_w2" % i].astype(np.float32))     # fp16-representable second layer: small fixture
+    with torch.no_grad():
+        fm, _ = mlp(feats, 256, ids)
+    out["mlp0_sub"], out["mlp1_sub"] = fm[0][::8].numpy(), fm[1][::8].numpy()
+    out["mlp_keys"] = np.array(sorted(mlp.state_dict().keys()))
+    # PatchNCE at 2 x 256 patches x 256 dims on the MLP features of map 0 (q) and a second sampler call on other features (k)
+    fk, _ = mlp([detrand.uniform((2, 24, 20, 18), 43, "k0"), feats[1]], 256, ids)
+    q, k = fm[0].detach().clone().requires_grad_(True), fk[0].detach()
+    for allneg in (False, True):
+        nce = PatchNCELoss(SimpleNamespace(nce_includes_all_negatives_from_minibatch=allneg, batch_size=2, nce_T=0.07))
+        loss = nce(q, k)
+        g, = torch.autograd.grad(loss.sum(), q)
+        out["nce_loss_%d" % allneg] = loss.detach().numpy()
+        out["nce_dq_sub_%d" % allneg] = g[::8, ::4].numpy()
+        out["nce_dq_probe_%d" % allneg] = np.array(detrand.probe(g, "dq"))
+    np.savez_compressed(os.path.join(GOLD, "patchsample.npz"), **out)
+    print("wrote patchsample.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
 def golden_ops():
     """Operator-level vectors: SPE, DiffAugment, GANLoss (all modes), PatchNCE, patch gather, normals."""
     from oracle import detrand, ref_import
@@ -552,6 +596,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step", "style", "io"]
+    if "patchsample" in which:
+        golden_patchsample()
     if "ops" in which:
         golden_ops()
     if "nets" in which:

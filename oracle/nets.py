@@ -534,6 +534,19 @@ def patchnce_loss(feat_q, feat_k, batch_size, nce_T=0.07, all_negatives_from_min
     return F.cross_entropy(out, torch.zeros(out.size(0), dtype=torch.long, device=q.device), reduction="none")
 
 
+def patch_sample_f(feats, patch_ids, mlps=None):
+    """PatchSampleF.forward with given ids (networks.py:687-719): feats list of [B, C, H, W]; mlps: None or a list of
+    (w0 [nc, C], b0, w2 [nc, nc], b2) per feature map.  Returns the list of L2-normalised [B * P, C | nc] rows."""
+    outs = []
+    for i, feat in enumerate(feats):
+        x = feat.permute(0, 2, 3, 1).flatten(1, 2)[:, torch.as_tensor(patch_ids[i], dtype=torch.long), :].flatten(0, 1)
+        if mlps is not None:
+            w0, b0, w2, b2 = mlps[i]
+            x = F.linear(F.relu(F.linear(x, w0, b0)), w2, b2)
+        outs.append(l2_normalize(x))
+    return outs
+
+
 # ----------------------------------------------------------------------------
 # Adam (torch.optim.Adam semantics used at sinskitG_model.py:589-599)
 # ----------------------------------------------------------------------------

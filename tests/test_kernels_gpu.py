@@ -1,6 +1,7 @@
 """Kernel-level parity: every vts_* entry point (through the C ABI) vs a plain PyTorch fp32
 CPU evaluation of the same op on the same seeded inputs.  Tolerances: rel-L2 <= 1e-5 for
 single ops (fp32 accumulation order differs), exact for pure data movement."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -545,3 +546,70 @@ def test_patchnce(allneg):
     ref.sum().backward()
     loss, dq = ops.patchnce(q.detach().to(dev), k.to(dev), 1 if allneg else B, 0.07)
     assert rel(loss, ref) < 1e-5 and rel(dq, q.grad) < 1e-5
+
+
+def test_patchsample_f_and_patchnce_at_reference_size(golden_dir):
+    """PatchSampleF (gather, MLP on the MFMA tile routine, L2 norm) and PatchNCE at the reference's 256 patches x 256 dims (both
+    negative modes: per image on the MFMA kernel, whole minibatch on the one-query-per-workgroup kernel) against the vectors the
+    REFERENCE modules produced (tests/golden/patchsample.npz) and against the oracle for the full gradient"""
+    import os
+
+    from models.networks import PatchNCELoss, PatchSampleF
+    from types import SimpleNamespace
+    from vts import lib as L
+
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "patchsample.npz"))
+    feats = [detrand.uniform((2, 24, 20, 18), 41, "f0"), detrand.uniform((2, 40, 9, 11), 41, "f1")]
+    ids = [g["ids0"], g["ids1"]]
+    fd = [f.to(dev) for f in feats]
+    plain, rid = PatchSampleF(use_mlp=False)(fd, 256, ids)
+    assert rel(plain[0], torch.from_numpy(g["plain0"])) < 1e-6 and rel(plain[1], torch.from_numpy(g["plain1"])) < 1e-6
+    assert rid[0].cpu().tolist() == ids[0].tolist()
+    f = PatchSampleF(use_mlp=True, nc=256)
+    f.create_mlp(fd)
+    assert sorted(f.state_dict().keys()) == [str(k) for k in g["mlp_keys"]]
+    for i in range(2):
+        m = getattr(f, "mlp_%d" % i)
+        assert abs(float(m[0].weight.std()) - 0.02) < 0.004 and float(m[0].bias.abs().max()) == 0.0      # init_net normal / 0.02
+        for idx, (kw, kb) in ((0, ("w0", "b0")), (2, ("w2", "b2"))):
+            m[idx].weight.data.copy_(torch.from_numpy(g["mlp%d_%s" % (i, kw)].astype(np.float32)))
+            m[idx].bias.data.copy_(torch.from_numpy(g["mlp%d_%s" % (i, kb)]))
+    fm, _ = f(fd, 256, ids)
+    assert rel(fm[0][::8], torch.from_numpy(g["mlp0_sub"])) < 1e-5 and rel(fm[1][::8], torch.from_numpy(g["mlp1_sub"])) < 1e-5
+    fk, _ = f([detrand.uniform((2, 24, 20, 18), 43, "k0").to(dev), fd[1]], 256, ids)
+    for allneg in (False, True):
+        crit = PatchNCELoss(SimpleNamespace(nce_includes_all_negatives_from_minibatch=allneg, batch_size=2, nce_T=0.07))
+        loss, dq = crit(fm[0], fk[0], want_grad=True)
+        assert L.load().vts_last_kernel().decode() == ("patchnce_kernel" if allneg else "patchnce_mfma_kernel")
+        assert rel(loss, torch.from_numpy(g["nce_loss_%d" % allneg])) < 2e-5
+        assert rel(dq[::8, ::4], torch.from_numpy(g["nce_dq_sub_%d" % allneg])) < 1e-4
+        q = fm[0].cpu().clone().requires_grad_(True)
+        ref = nets.patchnce_loss(q, fk[0].cpu(), 2, 0.07, allneg)
+        gref, = torch.autograd.grad(ref.sum(), q)
+        assert rel(dq, gref) < 1e-4 and rel(loss, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,P,D", [(3, 48, 40), (1, 200, 100), (2, 17, 256), (2, 256, 19)])
+def test_patchnce_mfma_ragged_sizes(B, P, D):
+    from vts import ops
+
+    dev = _dev()
+    q = nets.l2_normalize(detrand.uniform((B * P, D), 5, "q") - 0.5).requires_grad_(True)
+    k = nets.l2_normalize(detrand.uniform((B * P, D), 5, "k") - 0.5)
+    ref = nets.patchnce_loss(q, k, B, 0.07, False)
+    gref, = torch.autograd.grad((ref * 0.5).sum(), q)
+    loss, dq = ops.patchnce(q.detach().to(dev), k.to(dev), B, 0.07, gscale=0.5)
+    assert rel(loss, ref) < 2e-5 and rel(dq, gref) < 1e-4
+
+
+def test_linear_rows_matches_torch():
+    from vts import ops
+
+    dev = _dev()
+    for r, i, o in ((512, 24, 256), (70, 300, 33), (64, 4, 600)):
+        x, w, b = detrand.uniform((r, i), 6, "x") - 0.5, detrand.uniform((o, i), 6, "w") - 0.5, detrand.uniform((o,), 6, "b")
+        for relu in (False, True):
+            y = ops.linear_rows(x.to(dev), w.to(dev), b.to(dev), relu=relu)
+            ref = F.linear(x, w, b)
+            assert rel(y, F.relu(ref) if relu else ref) < 1e-5

@@ -403,3 +403,24 @@ def test_style_code_generator_fwd_bwd(golden_dir):
     _close(sc.grad.numpy(), g["G_dstyle"], rtol=2e-3, atol=1e-6)
     for k, v in sd.items():
         _probe_close(v.grad, g["G_grad/" + k], k)
+
+
+def test_patchsample_and_patchnce_at_reference_size(golden_dir):
+    """oracle PatchSampleF (gather / MLP / L2 norm) and PatchNCE at 2 x 256 patches x 256 dims against the reference modules"""
+    g = np.load(os.path.join(golden_dir, "patchsample.npz"))
+    feats = [detrand.uniform((2, 24, 20, 18), 41, "f0"), detrand.uniform((2, 40, 9, 11), 41, "f1")]
+    ids = [g["ids0"], g["ids1"]]
+    plain = nets.patch_sample_f(feats, ids)
+    _close(plain[0].numpy(), g["plain0"], rtol=1e-6, atol=1e-7)
+    _close(plain[1].numpy(), g["plain1"], rtol=1e-6, atol=1e-7)
+    mlps = [tuple(torch.from_numpy(g["mlp%d_%s" % (i, k)].astype(np.float32)) for k in ("w0", "b0", "w2", "b2")) for i in range(2)]
+    fm = nets.patch_sample_f(feats, ids, mlps)
+    _close(fm[0][::8].numpy(), g["mlp0_sub"], rtol=1e-5, atol=1e-6)
+    _close(fm[1][::8].numpy(), g["mlp1_sub"], rtol=1e-5, atol=1e-6)
+    fk = nets.patch_sample_f([detrand.uniform((2, 24, 20, 18), 43, "k0"), feats[1]], ids, mlps)
+    for allneg in (False, True):
+        q = fm[0].detach().clone().requires_grad_(True)
+        loss = nets.patchnce_loss(q, fk[0].detach(), 2, 0.07, allneg)
+        dq, = torch.autograd.grad(loss.sum(), q)
+        _close(loss.detach().numpy(), g["nce_loss_%d" % allneg], rtol=1e-5, atol=1e-5)
+        _close(dq[::8, ::4].numpy(), g["nce_dq_sub_%d" % allneg], rtol=1e-4, atol=1e-6)

@@ -17,6 +17,9 @@ const float* vts_ident();
 int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st);
 // thin (Cout <= 16) stride-2 transposed layers on full-size maps: direct packed-FMA kernel; VTS_ERR_UNSUPPORTED otherwise
 int vts_conv_thin_try(const vts_conv_desc* d, hipStream_t st);
+// PatchNCE on the MFMA path (vts_patchnce.hip): P, D <= 256
+bool vts_patchnce_mfma_ok(int P, int D);
+int vts_patchnce_mfma(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq, hipStream_t st);
 // LeakyReLU slope that expresses the activation codes as  t > 0 ? t : slope * t
 static inline float vts_slope(int act) { return act == VTS_ACT_LRELU ? 0.2f : (act == VTS_ACT_RELU ? 0.f : 1.f); }
 

@@ -2,6 +2,8 @@
 // AvgPool pyramid, GAN loss, L1, patch gather / deterministic scatter, generator output
 // post-processing (mask, normals, DiffAugment), positional encoding, "more fake T" sampler
 // support, fused Adam, PatchNCE.
+#include <stdlib.h>
+
 #include "vts_internal.h"
 
 namespace {
@@ -611,9 +613,12 @@ extern "C" int vts_l2norm_rows(const float* x, int rows, int D, float* y, void* 
 extern "C" int vts_patchnce(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq,
                             void* stream) {
   VTS_CHECK_ARG(q && k && B >= 1 && P >= 1 && D >= 1 && T > 0.f, "vts_patchnce: bad args");
+  static const int use_mfma = getenv("VTS_PATCHNCE_MFMA") ? atoi(getenv("VTS_PATCHNCE_MFMA")) : 1;
+  if (use_mfma && vts_patchnce_mfma_ok(P, D)) return vts_patchnce_mfma(q, k, B, P, D, T, gscale, loss, dq, (hipStream_t)stream);
   const size_t sm = (size_t)(D + P + 1) * sizeof(float);
   VTS_CHECK_ARG(sm <= 64 * 1024, "vts_patchnce: D + P too large for one LDS tile");
   hipLaunchKernelGGL(patchnce_kernel, dim3(P, B), dim3(256), sm, (hipStream_t)stream, q, k, P, D, 1.f / T, gscale, loss, dq);
+  vts_set_kernel("patchnce_kernel");
   VTS_CHECK_LAUNCH("vts_patchnce");
   return VTS_OK;
 }

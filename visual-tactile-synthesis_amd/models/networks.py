@@ -501,3 +501,73 @@ class GANLoss:
         plist = preds if isinstance(preds[0], (list, tuple)) else [preds[-1]]
         self.accumulate(plist, target_is_real, 1.0, slot, want_grad=False)
         return slot
+
+
+class PatchSampleF(nn.Module):
+    """PatchSampleF (reference networks.py:667-719) on the HIP path, forward: per feature map pick `num_patches` spatial positions
+    (given `patch_ids`, else a numpy permutation like the reference -- the same ids for every image of the batch), gather them as rows
+    [B * P, C] (vts_patch_sample), optionally run the 2-layer MLP Linear(C, nc) - ReLU - Linear(nc, nc) (vts_linear_rows; created on
+    first use and initialised like the reference: init_net normal / 0.02, bias 0), L2-normalise the rows (vts_l2norm_rows).
+    state_dict keys match the reference's (mlp_<i>.0.weight, mlp_<i>.0.bias, mlp_<i>.2.weight, mlp_<i>.2.bias).
+    num_patches == 0 (whole map, reshaped back to NCHW) is not built."""
+
+    def __init__(self, use_mlp=False, init_type="normal", init_gain=0.02, nc=256, gpu_ids=()):
+        super().__init__()
+        self.use_mlp, self.nc, self.mlp_init, self.init_type, self.init_gain, self.gpu_ids = use_mlp, nc, False, init_type, init_gain, gpu_ids
+
+    def create_mlp(self, feats):
+        for mlp_id, feat in enumerate(feats):
+            mlp = nn.Sequential(nn.Linear(feat.shape[1], self.nc), nn.ReLU(), nn.Linear(self.nc, self.nc)).to(feat.device)
+            for m in mlp:
+                if isinstance(m, nn.Linear):
+                    if self.init_type == "normal":
+                        nn.init.normal_(m.weight.data, 0.0, self.init_gain)
+                    elif self.init_type == "xavier":
+                        nn.init.xavier_normal_(m.weight.data, gain=self.init_gain)
+                    else:
+                        raise NotImplementedError("PatchSampleF: init_type %s is not built" % self.init_type)
+                    nn.init.constant_(m.bias.data, 0.0)
+            setattr(self, "mlp_%d" % mlp_id, mlp)
+        self.mlp_init = True
+
+    @torch.no_grad()
+    def forward(self, feats, num_patches=64, patch_ids=None):
+        import numpy as np
+
+        from vts import ops
+
+        if num_patches <= 0:
+            raise NotImplementedError("PatchSampleF with num_patches = 0 (whole feature map) is not built")
+        if self.use_mlp and not self.mlp_init:
+            self.create_mlp(feats)
+        return_ids, return_feats = [], []
+        for feat_id, feat in enumerate(feats):
+            hw = feat.shape[2] * feat.shape[3]
+            if patch_ids is not None:
+                patch_id = patch_ids[feat_id]
+            else:
+                patch_id = np.random.permutation(hw)
+                patch_id = patch_id[:int(min(num_patches, patch_id.shape[0]))]
+            patch_id = torch.as_tensor(patch_id, dtype=torch.long, device=feat.device)
+            x = ops.patch_sample(feat.contiguous(), patch_id)
+            if self.use_mlp:
+                mlp = getattr(self, "mlp_%d" % feat_id)
+                x = ops.linear_rows(x, mlp[0].weight, mlp[0].bias, relu=True)
+                x = ops.linear_rows(x, mlp[2].weight, mlp[2].bias)
+            return_ids.append(patch_id)
+            return_feats.append(ops.l2norm_rows(x))
+        return return_feats, return_ids
+
+
+class PatchNCELoss:
+    """PatchNCELoss (reference models/patchnce.py:6-55): per-patch loss [B * P] and, with want_grad, d sum(loss) / d feat_q"""
+
+    def __init__(self, opt):
+        self.opt = opt
+
+    def __call__(self, feat_q, feat_k, want_grad=False):
+        from vts import ops
+
+        groups = 1 if self.opt.nce_includes_all_negatives_from_minibatch else self.opt.batch_size
+        loss, dq = ops.patchnce(feat_q.contiguous(), feat_k.contiguous(), groups, self.opt.nce_T, want_grad=want_grad)
+        return (loss, dq) if want_grad else loss

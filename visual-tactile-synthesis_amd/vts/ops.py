@@ -893,3 +893,22 @@ def patchnce(q, k, groups, T, gscale=1.0, want_grad=True):
     dq = torch.empty_like(q) if want_grad else None
     L.check(lib.vts_patchnce(q.data_ptr(), k.data_ptr(), groups, p, d, T, gscale, loss.data_ptr(), L.ptr(dq), L.stream()), "vts_patchnce")
     return loss, dq
+
+
+def patch_sample(feat, ids):
+    """PatchSampleF's gather (networks.py:689-701): feat [B, C, H, W], ids int64 [P] -> [B * P, C]"""
+    b, c, h, w = feat.shape
+    assert feat.is_contiguous() and ids.dtype == torch.int64
+    out = torch.empty(b * ids.numel(), c, dtype=torch.float32, device=feat.device)
+    L.check(L.load().vts_patch_sample(feat.data_ptr(), ids.data_ptr(), b, c, h * w, ids.numel(), out.data_ptr(), L.stream()), "vts_patch_sample")
+    return out
+
+
+def linear_rows(x, weight, bias=None, relu=False):
+    """act(x @ weight.T + bias) for row-major x [R, I], nn.Linear weight [O, I]"""
+    r, i = x.shape
+    o = weight.shape[0]
+    assert weight.shape[1] == i and x.is_contiguous() and weight.is_contiguous()
+    y = torch.empty(r, o, dtype=torch.float32, device=x.device)
+    L.check(L.load().vts_linear_rows(x.data_ptr(), weight.data_ptr(), L.ptr(bias), r, i, o, int(relu), y.data_ptr(), L.stream()), "vts_linear_rows")
+    return y
