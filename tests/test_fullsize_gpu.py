@@ -140,3 +140,66 @@ def test_full_size_step_matches_oracle_batch1():
                                        (nm != "G" and k.split(".")[1] in ("2", "5", "8"))):
                 continue    # bias in front of a normalisation: mathematically zero gradient (rounding noise in autograd)
             assert rel(p.grad, r) < 2e-3, (nm, k, rel(p.grad, r))
+
+
+def test_headline_config_step_matches_oracle():
+    """BASELINE config 1 itself -- skitG (512-d style code tiled into the innermost up block), 4 images of 1024 x 1024, 64 tactile
+    patches each -- one whole training step against the CPU oracle: all logged losses, both outputs, the gradient of every parameter
+    of G / D / D2 at its backward point, BatchNorm running statistics (the batched D passes must advance them in the reference's
+    order).  The oracle needs ~10 s for this step."""
+    from data.synthetic_dataset import make_sample
+    model, opt = make_model("skitG", 4)
+    assert opt.use_style_code and opt.style_code_dim == 512
+    seed, n = 321, 4
+    sds = (detrand.test_weights(nets.g_param_shapes(style_nc=opt.style_code_dim), seed), detrand.test_weights(nets.d_param_shapes(4), seed + 1),
+           detrand.test_weights(nets.d_param_shapes(7), seed + 2))
+    for net, sd in zip((model.netG, model.netD, model.netD2), sds):
+        net.load_state_dict(sd)
+    batch = default_collate([make_sample(SIZE, 64, 64, seed + i, style_dim=opt.style_code_dim) for i in range(n)])
+    random.seed(6)
+    counts = [int(nets.dilated_mask_positions(batch["M"][i:i + 1].float()).shape[0]) for i in range(n)]
+    draws = {"aug": detrand.uniform((4, n), 4, "aug") * 0.5 + 0.5, "more_idx": torch.tensor([random.sample(range(c), 32) for c in counts])}
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    ref = step.train_step(sds[0], sds[1], sds[2], adam, batch, draws, style_code=batch["style_code"].float())
+    model._draws = draws
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    for k, v in ref["losses"].items():
+        assert abs(losses["l_" + k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses["l_" + k], v)
+    assert rel(model.fake_I, ref["fake_I"]) < 1e-3 and rel(model.fake_T, ref["fake_T"]) < 1e-3
+    worst = (0.0, None)
+    for nm, net, sd in (("G", model.netG, sds[0]), ("D", model.netD, sds[1]), ("D2", model.netD2, sds[2])):
+        for k, p in net.named_parameters():
+            if k.endswith("bias") and ((nm == "G" and not k.startswith(("down0.", "down7.", "up0.", "up0_T."))) or
+                                       (nm != "G" and k.split(".")[1] in ("2", "5", "8"))):
+                continue    # bias in front of a normalisation: mathematically zero gradient
+            e = rel(p.grad, ref["grad_" + nm][k])
+            worst = max(worst, (e, nm + "." + k))
+            assert e < 2e-3, (nm, k, e)
+        for k, b in net.named_buffers():    # the oracle updated its state dicts in place: running statistics after the step
+            if k.endswith("running_mean"):
+                scale = float(sd[k.replace("running_mean", "running_var")].max().sqrt())
+                assert (b.cpu() - sd[k]).abs().max().item() < 1e-3 * scale, (nm, k)
+            elif b.dtype.is_floating_point:
+                assert rel(b, sd[k]) < 1e-3, (nm, k)
+            else:
+                assert int(b) == int(sd[k]), (nm, k)
+    print("worst gradient rel-L2", worst)
+
+
+def test_inference_batch16_matches_oracle():
+    """BASELINE config 4's shape: generator forward (test()) on 16 images of 1024 x 1024, every image against the CPU oracle"""
+    from data.synthetic_dataset import make_sample
+    model, opt = make_model("skitG", 16)
+    sdG = detrand.test_weights(nets.g_param_shapes(style_nc=opt.style_code_dim), 55)
+    model.netG.load_state_dict(sdG)
+    model.eval()
+    batch = default_collate([make_sample(SIZE, 64, 64, 700 + i, style_dim=opt.style_code_dim) for i in range(16)])
+    model.set_input(batch, phase="test")
+    for _ in range(3):          # eager, capture, replay: the captured forward must give the same images
+        model.test()
+    torch.cuda.synchronize()
+    fake_I, fake_T = step.inference(sdG, batch, style_code=batch["style_code"].float())
+    for i in range(16):
+        assert rel(model.fake_I[i], fake_I[i]) < 1e-3 and rel(model.fake_T[i], fake_T[i]) < 1e-3, i

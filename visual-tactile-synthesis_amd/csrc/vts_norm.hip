@@ -217,7 +217,7 @@ struct NormBwdK {
   const float *mean, *rstd, *gamma;
   float *dgamma, *dbeta;
   int acc;
-  float* coef;  // [N*C][3]
+  float* coef;  // [N*C][4]: A, B, C, mean
   int ngroups;  // BatchNorm: passes batched into this launch (>= 1)
   int gstart[9];
 };
@@ -236,9 +236,10 @@ __device__ __forceinline__ void norm_bwd_finalize_group(const volatile float* pa
     if (lane == 0) {
       const float m = (float)k.HW, rs = k.rstd[g], mu = k.mean[g];
       const float B = -rs * rs * s2 / m;
-      k.coef[g * 3 + 0] = rs;
-      k.coef[g * 3 + 1] = B;
-      k.coef[g * 3 + 2] = -rs * s1 / m - B * mu;
+      k.coef[g * 4 + 0] = rs;
+      k.coef[g * 4 + 1] = B;
+      k.coef[g * 4 + 2] = -rs * s1 / m;
+      k.coef[g * 4 + 3] = mu;
     }
   } else {
     const int c = group;
@@ -261,9 +262,10 @@ __device__ __forceinline__ void norm_bwd_finalize_group(const volatile float* pa
       const float B = -g * rs * rs * s2 / m;
       for (int n = n0 + lane; n < n1; n += 64) {
         const int idx = n * k.C + c;
-        k.coef[idx * 3 + 0] = g * rs;
-        k.coef[idx * 3 + 1] = B;
-        k.coef[idx * 3 + 2] = -g * rs * s1 / m - B * mu;
+        k.coef[idx * 4 + 0] = g * rs;
+        k.coef[idx * 4 + 1] = B;
+        k.coef[idx * 4 + 2] = -g * rs * s1 / m;
+        k.coef[idx * 4 + 3] = mu;
       }
       dg += s2;
       db += s1;
@@ -278,14 +280,14 @@ __device__ __forceinline__ void norm_bwd_finalize_group(const volatile float* pa
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
                                                              int C, int HW, const float* __restrict__ coef) {
   const int c = blockIdx.y, n = blockIdx.z;
-  const float* q = coef + (n * C + c) * 3;
-  const float A = q[0], B = q[1], Cc = q[2];
+  const float* q = coef + (n * C + c) * 4;
+  const float A = q[0], B = q[1], Cc = q[2], mu = q[3];   // dx = A dy + B (x - mean) + C: centred, no cancellation against B * mean
   const int64_t off = n * nstride + (int64_t)c * HW;
   const int base = blockIdx.x * CHUNK;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int i = base + e * 256 + threadIdx.x;
-    if (i < HW) dy[off + i] = A * dy[off + i] + B * x[off + i] + Cc;
+    if (i < HW) dy[off + i] = A * dy[off + i] + B * (x[off + i] - mu) + Cc;
   }
 }
 
@@ -363,10 +365,10 @@ __global__ __launch_bounds__(1024) void norm_bwd_fused_kernel(float* __restrict_
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f;
-    const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m - B * mu;
+    const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m;
     for (int j = threadIdx.x; j < total; j += blockDim.x) {
       const int64_t off = fused_off(j, k.HW, n0, c, nstride, bn);
-      dy[off] = A * dy[off] + B * x[off] + Cc;
+      dy[off] = A * dy[off] + B * (x[off] - mu) + Cc;
     }
     dg += s2;
     db += s1;
@@ -479,7 +481,7 @@ bool fill_groups(int mode, int N, int ngroups, const int* gstart, int& out_n, in
 
 }  // namespace
 
-extern "C" int64_t vts_norm_ws_floats(int N, int C, int HW) { return (int64_t)N * C * splits_for(HW) * 3 + (int64_t)N * C * 3; }
+extern "C" int64_t vts_norm_ws_floats(int N, int C, int HW) { return (int64_t)N * C * splits_for(HW) * 3 + (int64_t)N * C * 4; }
 
 extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
   VTS_CHECK_ARG(d && d->x && d->scale && d->shift && ws, "vts_norm_stats: null pointer");
