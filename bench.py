@@ -66,6 +66,31 @@ def make_patch_batch(batch, rank, patch=32):
     return default_collate([make_patch_sample(1234 + 100003 * rank + i, patch=patch) for i in range(batch)])
 
 
+def csrc_sha16():
+    """hash of the kernel sources: PMC summaries under profiles/ carry the hash they were measured on, and are only quoted while it matches"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "visual-tactile-synthesis_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "visual-tactile-synthesis_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest_profile(pattern):
+    """newest profiles/<pattern> JSON measured on the CURRENT kernel sources (tools/pmc_summary.py / tools/pmc_mfma.py stamp csrc_sha16), or None"""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("csrc_sha16") == csrc_sha16():
+            return os.path.basename(f), d
+    return None, None
+
+
 def kernel_roofline(model, batch_dict, detail_path=None):
     """One extra (untimed-for-throughput) step with HIP events around every launch, on the launch stream."""
     from vts import ops
@@ -109,19 +134,24 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     else:
         roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    # HBM bytes per launch of this kernel family from the committed PMC passes (profiles/*_traffic_pmc.json:
-    # separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md)
+    # HBM bytes per launch of this kernel instance from the PMC passes of tools/pmc_traffic.sh (separate FETCH_SIZE / WRITE_SIZE runs of
+    # this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so the
+    # figure comes from profiles/ -- but ONLY from a summary measured on exactly these kernel sources (csrc_sha16); otherwise null.
     roof["traffic"] = None
-    try:
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_pmc.json")))
-        if files:
-            ent = json.load(open(files[-1]))["kernels"].get(label.split("+")[0])
-            if ent:
-                roof["traffic"] = ent["hbm_bytes_per_launch"]
-                roof["traffic_source"] = os.path.basename(files[-1])
-    except Exception:
-        pass
+    src, prof = newest_profile("*_traffic_pmc.json")
+    if prof is not None:
+        ent = prof["kernels"].get(label.split("+")[0])
+        if ent:
+            roof["traffic"] = ent["hbm_bytes_per_launch"]
+            roof["traffic_source"] = src
+    # MFMA pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs), tools/pmc_mfma.sh), same staleness rule
+    roof["mfma_util"] = roof["mfma_util_step"] = None
+    src, prof = newest_profile("*_mfma_util.json")
+    if prof is not None:
+        ent = prof["kernels"].get(label.split("+")[0])
+        roof["mfma_util"] = ent["mfma_util"] if ent else None
+        roof["mfma_util_step"] = prof.get("step_mfma_util")
+        roof["mfma_util_source"] = src
     roof["kernel"] = label
     roof["launches_per_step"] = cnt
     roof["avg_launch_us"] = t / cnt * 1e6
@@ -133,8 +163,9 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     return roof
 
 
-def cpu_baseline(size, style_dim, steps=3, netG="unet256_custom"):
-    """The CPU oracle (PyTorch-CPU restatement pinned to the reference) on this host's cores, N=1."""
+def cpu_baseline(size, style_dim, netG="unet256_custom", warmup=3, steps=10, budget_s=60.0):
+    """The CPU oracle (PyTorch-CPU restatement pinned to the reference) on this host's cores, N=1: BASELINE.md's protocol, 3 warm-up +
+    10 timed steps, median (bounded: stops early if the budget runs out and says how many steps it timed)."""
     from torch.utils.data import default_collate
 
     from data.synthetic_dataset import make_sample
@@ -155,18 +186,18 @@ def cpu_baseline(size, style_dim, steps=3, netG="unet256_custom"):
     cnt = int(nets.dilated_mask_positions(batch["M"].float()).shape[0])
     adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
     style = batch.get("style_code")
-    times = []
-    for it in range(steps + 1):
+    times, t_start = [], time.time()
+    for it in range(warmup + steps):
         draws = {"aug": torch.rand(4, 1), "more_idx": torch.tensor([random.sample(range(cnt), 32)])}
         t0 = time.time()
         step.train_step(sd[0], sd[1], sd[2], adam, batch, draws, opt=step.hp(netG=netG), style_code=style, record=False)
         times.append(time.time() - t0)
-        if it >= 1 and sum(times) > 45.0:   # keep the default run bounded
+        if it >= warmup and time.time() - t_start > budget_s:
             break
-    steps = max(1, len(times) - 1)
-    t = sum(times[1:]) / steps if len(times) > 1 else times[0]
+    timed = sorted(times[warmup:]) or sorted(times[-1:])
+    t = timed[len(timed) // 2]
     return {"value": 1.0 / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d oracle train steps after 1 warm-up, N=1, %dx%d, same flags" % (steps, size, size)}
+            "sample": "median of %d oracle train steps after %d warm-up, N=1, %dx%d, same flags" % (len(timed), min(warmup, len(times) - len(timed)), size, size)}
 
 
 def infer_bench(args):
@@ -268,6 +299,25 @@ def main():
         dt = float(t.item())
     losses = model.get_current_losses()
     finite = all(v == v and abs(v) < 1e30 for v in losses.values())
+    # the same K steps with a FRESH host batch per step: set_input (H2D of S / I / M / patches, masking, candidate map) inside the timed
+    # region, as a train.py loop pays it (`value` keeps the contract: inputs resident in HBM)
+    fresh_ms = None
+    if world == 1 and args.model != "pix2pixHD":
+        def pinned(b):   # what the package's DataLoader hands over (data/__init__.py: pin_memory=True)
+            return {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+        batches = [pinned(batch), pinned(make_batch(args.size, args.batch, rank + 1, style_dim))]
+        for i in range(2):
+            model.set_input(batches[i % 2], phase="train")
+            model.optimize_parameters(epoch=1)
+        barrier()
+        tf = time.perf_counter()
+        for i in range(args.steps):
+            model.set_input(batches[i % 2], phase="train")
+            model.optimize_parameters(epoch=1)
+        barrier()
+        fresh_ms = (time.perf_counter() - tf) / args.steps * 1e3
+        model.set_input(batch, phase="train")
     comm = None
     if world > 1:
         # exposed communication: the same K steps without the gradient all-reduces (the replicas drift apart: timing only, last)
@@ -306,7 +356,7 @@ def main():
         ms = dt / args.steps * 1e3
         out = {
             "metric": "train_images_per_sec", "value": world * args.batch * args.steps / dt, "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_fresh_input": fresh_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": ("pix2pixHD G+D+D2 train step (GlobalGenerator ngf 64, ndf 64), %d %dx%d images/GPU, VGG term off "

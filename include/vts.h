@@ -433,6 +433,9 @@ int vts_l2norm_rows(const float* x, int rows, int D, float* y, void* stream);
 int vts_patch_sample(const float* feat, const int64_t* ids, int B, int C, int HW, int P, float* out, void* stream);
 int vts_linear_rows(const float* x, const float* w, const float* bias, int R, int I, int O, int relu, float* y, void* stream);
 
+/* dst[i] = src[i] for i < nwords (4-byte words) as a kernel on `stream`; src may be pinned host memory. */
+int vts_copy_words(const void* src, void* dst, int64_t nwords, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,12 @@ def collect(d, counter):
     return acc
 
 
+def csrc_sha16():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.csrc_sha16()
+
+
 def main(fetch_dir, write_dir, dst, note=""):
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     kernels = {}
@@ -47,7 +53,7 @@ def main(fetch_dir, write_dir, dst, note=""):
     out = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) over "
                   "`python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_graph`; mean per launch of each kernel "
                   "instance; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)",
-           "note": note, "kernels": kernels}
+           "note": note, "csrc_sha16": csrc_sha16(), "kernels": kernels}
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote %s (%d kernels)" % (dst, len(kernels)))

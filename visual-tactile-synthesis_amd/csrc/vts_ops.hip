@@ -622,3 +622,18 @@ extern "C" int vts_patchnce(const float* q, const float* k, int B, int P, int D,
   VTS_CHECK_LAUNCH("vts_patchnce");
   return VTS_OK;
 }
+
+// plain word copy on the compute queue.  The source may be PINNED HOST memory (device-accessible under unified addressing): uploads of
+// the per-batch patch bookkeeping go through this kernel instead of an SDMA copy, which keeps them in stream order with the HIP-graph
+// replays without a cross-engine dependency (models/sinskitG_model.py:_patch_set).
+__global__ __launch_bounds__(256) void copy_words_kernel(const int* __restrict__ src, int* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int vts_copy_words(const void* src, void* dst, int64_t nwords, void* stream) {
+  VTS_CHECK_ARG(src && dst && nwords >= 0, "vts_copy_words: bad args");
+  if (nwords == 0) return VTS_OK;
+  hipLaunchKernelGGL(copy_words_kernel, dim3(blocks_for(nwords, 1024)), dim3(256), 0, (hipStream_t)stream, (const int*)src, (int*)dst, nwords);
+  VTS_CHECK_LAUNCH("vts_copy_words");
+  return VTS_OK;
+}

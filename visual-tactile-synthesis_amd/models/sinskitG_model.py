@@ -16,6 +16,7 @@ What is different on this side of the boundary:
   * third-party terms whose weights cannot exist offline (LPIPS-VGG, CLIP vision-aided D3)
     must be disabled by flag -- requesting them raises instead of silently dropping them.
 """
+import os
 import random
 
 import numpy as np
@@ -183,6 +184,7 @@ class SinSKITGModel(BaseModel):
         self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
         self._spe_cache = {}
         self._bufs = {}         # persistent input buffers (stable addresses for captured HIP graphs)
+        self._pins, self._pin_evt = {}, {}   # pinned staging buffers of pageable host inputs (see _load)
         self._graphs = None     # the captured segments of the step, or None
         self._infer_graph, self._infer_eager_done = None, False   # captured inference forward (test())
         self._eager_steps_done = 0
@@ -217,9 +219,24 @@ class SinSKITGModel(BaseModel):
         return t
 
     def _load(self, name, host, dtype=torch.float32):
+        """host array -> persistent device buffer, asynchronously.  A pageable source would make the copy synchronous AND wait for the
+        work already queued on the stream (the previous training step): such sources are staged through a persistent pinned buffer
+        (a DataLoader with pin_memory=True hands over pinned tensors already; the small patch bookkeeping arrays never are)."""
         t = torch.as_tensor(host)
         buf = self._buf(name, t.shape, dtype)
-        buf.copy_(t.to(dtype), non_blocking=True)
+        if t.device.type == "cpu" and not (t.is_pinned() and t.dtype == dtype):
+            pin = self._pins.get(name)
+            if pin is None or pin.shape != t.shape or pin.dtype != dtype:
+                pin = self._pins[name] = torch.empty(t.shape, dtype=dtype).pin_memory()
+                self._pin_evt[name] = torch.cuda.Event()
+            else:
+                self._pin_evt[name].synchronize()     # the previous upload from this staging buffer has been read
+            pin.copy_(t)
+            t = pin
+            buf.copy_(t, non_blocking=True)
+            self._pin_evt[name].record()
+            return buf
+        buf.copy_(t, non_blocking=True)
         return buf
 
     def _spe(self, n, h, w):
@@ -241,19 +258,39 @@ class SinSKITGModel(BaseModel):
         return ox.astype(np.float32).astype(np.int32), oy.astype(np.float32).astype(np.int32), cs.astype(np.int32)
 
     def _patch_set(self, tag, T_images, I_masks, T_coords):
+        """Upload one patch set (tactile squares, contact masks, gather offsets, image indices).  All five arrays travel as ONE
+        pinned block and ONE H2D copy; the device tensors are views into one persistent block.  (A dozen small staged uploads per
+        batch made every ~3rd graph-replayed step stall for ~70 ms on this stack: tools/probes/stall_bisect.py.)"""
         T = torch.as_tensor(T_images)
         n, nt = T.shape[0], T.shape[1]
         ox, oy, cs = self._patch_offsets(torch.as_tensor(T_coords).numpy())
         if not (cs == 32).all():
             raise NotImplementedError("patch cutout != 32 px needs the bicubic resampler; not built")
-        raw = self._load(tag + "_T_raw", T.reshape(-1, 2, 32, 32))
-        masks = self._load(tag + "_masks", torch.as_tensor(I_masks).reshape(-1, 1, 32, 32))
-        real_T = ops.mask_mul(raw, masks, out=self._buf(tag + "_real_T", raw.shape))
-        return dict(
-            real_T=real_T, masks=masks, NT=nt,
-            offx=self._load(tag + "_offx", ox.reshape(-1), torch.int32), offy=self._load(tag + "_offy", oy.reshape(-1), torch.int32),
-            img=self._load(tag + "_img", torch.arange(n, dtype=torch.int32).repeat_interleave(nt), torch.int32),
-            coords=np.asarray(T_coords))
+        P = n * nt
+        parts = [("raw", T.reshape(P, 2, 32, 32).to(torch.float32)), ("masks", torch.as_tensor(I_masks).reshape(P, 1, 32, 32).to(torch.float32)),
+                 ("offx", torch.from_numpy(np.ascontiguousarray(ox.reshape(-1)))), ("offy", torch.from_numpy(np.ascontiguousarray(oy.reshape(-1)))),
+                 ("img", torch.arange(n, dtype=torch.int32).repeat_interleave(nt))]
+        words = sum((t.numel() + 63) // 64 * 64 for _, t in parts)       # all fields are 4-byte types; 256-byte aligned slots
+        dev = self._buf(tag + "_block", (words,), torch.int32)
+        pin = self._pins.get(tag)
+        if pin is None or pin.numel() != words:
+            pin = self._pins[tag] = torch.empty(words, dtype=torch.int32).pin_memory()
+            self._pin_evt[tag] = torch.cuda.Event()
+        else:
+            while not self._pin_evt[tag].query():     # the previous upload from this staging block has been read (spin: no sleeping wait)
+                pass
+        views, o = {}, 0
+        for name, t in parts:
+            k = t.numel()
+            pin[o:o + k].view(t.dtype).view(t.shape).copy_(t)
+            views[name] = dev[o:o + k].view(t.dtype).view(t.shape)
+            o += (k + 63) // 64 * 64
+        from vts import lib as L
+        L.check(L.load().vts_copy_words(pin.data_ptr(), dev.data_ptr(), words, L.stream()), "vts_copy_words")   # kernel reads the pinned block
+        self._pin_evt[tag].record()
+        real_T = ops.mask_mul(views["raw"], views["masks"], out=self._buf(tag + "_real_T", views["raw"].shape))
+        return dict(real_T=real_T, masks=views["masks"], NT=nt, offx=views["offx"], offy=views["offy"], img=views["img"],
+                    coords=np.asarray(T_coords))
 
     def set_input(self, input, phase="train", timing=False, verbose=False):
         self.data_phase = phase
@@ -307,7 +344,15 @@ class SinSKITGModel(BaseModel):
             # where the host already synchronises for the H2D copies (model_utils.py:212-216)
             self._cand, self._cand_prefix = ops.mask_candidates(
                 self.M, self._buf("cand", (n, h - 14, w - 14), torch.uint8), self._buf("cand_prefix", (n, h - 14 + 1), torch.int32))
-            self._cand_count = self._cand_prefix[:, -1].cpu().tolist()
+            # the candidate counts go to the host for random.sample: asynchronously into pinned memory; the host waits for them only
+            # when it draws the ranks (_prepare_ranks), so the H2D copies of this batch are already queued behind the previous step
+            pin = self._bufs.get("cand_count_pin")
+            if pin is None or pin.numel() != n:
+                pin = self._bufs["cand_count_pin"] = torch.empty(n, dtype=torch.int32).pin_memory()
+                self._cand_evt = torch.cuda.Event()
+            pin.copy_(self._cand_prefix[:, -1], non_blocking=True)
+            self._cand_evt.record()
+            self._cand_count = None
             k = self.opt.add_fake_T_sample_size
             self._ranks = self._buf("more_ranks", (n, k), torch.int64)
             self._more_img = self._load("more_img", torch.arange(n, dtype=torch.int32).repeat_interleave(k), torch.int32)
@@ -389,8 +434,23 @@ class SinSKITGModel(BaseModel):
         if self._draws is not None:
             ranks = torch.as_tensor(self._draws["more_idx"]).long()
         else:
+            if self._cand_count is None:
+                if os.environ.get("VTS_EVT_SPIN", "1") == "1":
+                    while not self._cand_evt.query():   # spin: a sleeping event wait was measured to stall ~70 ms every few iterations on this stack
+                        pass
+                else:
+                    self._cand_evt.synchronize()
+                self._cand_count = self._bufs["cand_count_pin"].tolist()
             ranks = torch.tensor([random.sample(range(c), k) for c in self._cand_count], dtype=torch.int64)
-        self._ranks.copy_(ranks, non_blocking=True)
+        pin = self._bufs.get("ranks_pin")
+        if pin is None or pin.shape != ranks.shape:
+            pin = self._bufs["ranks_pin"] = torch.empty(ranks.shape, dtype=torch.int64).pin_memory()
+            self._ranks_evt = torch.cuda.Event()
+        else:
+            self._ranks_evt.synchronize()
+        pin.copy_(ranks)
+        self._ranks.copy_(pin, non_blocking=True)     # pinned source: a pageable one would make this copy wait for the queued work
+        self._ranks_evt.record()
 
     def _d_pass(self, net, in0, in1, target_real, coeff, slot, accumulate, backward=True):
         """One discriminator forward (+ backward into its parameter grads).  Returns preds."""

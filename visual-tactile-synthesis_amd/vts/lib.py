@@ -82,7 +82,7 @@ SYMBOLS = [
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
     "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract", "vts_tap_embed_at", "vts_tap_extract_at", "vts_w3x3_pack", "vts_conv3x3_wide", "vts_conv3x3_wide_ws_floats", "vts_conv3x3s2_wide", "vts_tconv3x3s2_wide", "vts_wgrad3x3_wide", "vts_wgrad3x3_wide_ws_floats", "vts_upfirdn2d_out_size", "vts_upfirdn2d", "vts_upfirdn2d_bwd", "vts_bias_act", "vts_bias_act_bwd", "vts_modconv_demod", "vts_w4x4_pack", "vts_conv4x4_flat_ok", "vts_conv4x4_wide_ws_floats", "vts_conv4x4_wide", "vts_wgrad4x4_wide_ws_floats", "vts_wgrad4x4_wide",
     "vts_metric_ws_floats", "vts_minmax", "vts_metric_psnr", "vts_metric_tactile", "vts_metric_ssim", "vts_frechet_ws_floats", "vts_frechet_distance",
-    "vts_mask_select", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows",
+    "vts_mask_select", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
 ]
 
 
@@ -145,6 +145,7 @@ def load():
         "vts_adam_flat_dev": [vp, vp, vp, vp, i64, vp, f, f, f, vp, f, vp],
         "vts_patchnce": [vp, vp, i, i, i, f, f, vp, vp, vp],
         "vts_l2norm_rows": [vp, i, i, vp, vp],
+        "vts_copy_words": [vp, vp, i64, vp],
         "vts_patch_sample": [vp, vp, i, i, i, i, vp, vp],
         "vts_linear_rows": [vp, vp, vp, i, i, i, i, vp, vp],
         "vts_minmax": [vp, i64, vp, vp, vp],
