@@ -576,7 +576,7 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
     const int GH = ph4 ? (d->OH + 1) / 2 : d->OH, GW = ph4 ? (d->OW + 1) / 2 : d->OW;
     const int full_wgs = cdiv(GW, 16 * mt) * cdiv(GH, 4 * rw) * N;
     const int nchunks = (k.Cin + 3) / 4;
-    static const int small_thr = getenv("VTS_SMALL_WGS") ? atoi(getenv("VTS_SMALL_WGS")) : 128;
+    static const int small_thr = getenv("VTS_SMALL_WGS") ? atoi(getenv("VTS_SMALL_WGS")) : 300;   // < ~1.2 workgroups per CU: split (measured: 128 -> 300 = step 7.88 -> 7.51 ms)
     static const int target_wgs = getenv("VTS_TARGET_WGS") ? atoi(getenv("VTS_TARGET_WGS")) : 320;
     if (full_wgs < small_thr && (nr > 1 || nchunks >= 8)) {
       const int base = cdiv(GW, 32) * cdiv(GH, 4) * N * nr;

@@ -611,7 +611,8 @@ Plan make_plan(const vts_wgrad_desc* d) {
     // every pixel worker writes (and the reduction re-reads) a full copy of dw: keep that traffic below ~2x the operand bytes
     // (inner U-Net layers: 80..592 x 80 channels on <= 32x32 maps would otherwise move 50 MB of partials for 8 MB of operands)
     const int64_t operand = (int64_t)d->N * ((int64_t)CL * d->LH * d->LW + (int64_t)CH * d->HH * d->HW);
-    int64_t cap = (2 * operand > (1 << 20) ? 2 * operand : (1 << 20)) / nel;
+    static const int64_t cap_floor = (int64_t)(getenv("VTS_WGRAD_CAP_MB") ? atoi(getenv("VTS_WGRAD_CAP_MB")) : 1) << 18;   // floats
+    int64_t cap = (2 * operand > cap_floor ? 2 * operand : cap_floor) / nel;
     if (cap > (16 << 20) / nel) cap = (16 << 20) / nel;   // and never more than 64 MB
     if (pw > cap) pw = (int)cap;
     if (pw < 1) pw = 1;
