@@ -47,6 +47,8 @@ struct ConvK {
   int identity_in;     // no affine on either source and no input activation
   int ablate;       // profiling only (env VTS_ABLATE): 1 skip global loads, 2 skip MFMA, 4 skip epilogue
   int wbytes;       // extent of the weight tensor view in bytes (buffer descriptor of the weight loads)
+  int direct_epi;   // 1: stores straight from the accumulator registers (default); 0: through LDS (VTS_DIRECT_EPI=0)
+  int stagger;      // start-up stagger in units of ~3.4 us (s_sleep 127): workgroup w of a co-resident set waits (w % 3) * stagger units
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -87,6 +89,12 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   float* lds_patch = lds;
   float* lds_w = lds + PATCH_FLOATS;
 
+  if (p.stagger > 0) {
+    // co-resident workgroups start in lock-step and would load / multiply / store in phase; shift every third one
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int units = ((lin >> 8) % 3) * p.stagger;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   // provably wave-uniform wave index: all per-row staging state (bounds, row pointers, normalisation
   // scale/shift) then lives in SGPRs / scalar loads instead of per-lane VGPRs and branches
@@ -347,6 +355,73 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   const int64_t oplane = (int64_t)p.OH * p.OW;
   constexpr int PY = (P == 4) ? 2 : 1;
   const int oy0 = (P == 4) ? ty0 * 2 : ty0, ox0 = (P == 4) ? tx0 * 2 : tx0;
+  if (!p.part && p.direct_epi) {
+    // ---- direct epilogue (round 2): a lane's four accumulator registers are four consecutive pixels of ONE output channel
+    // (two parity phases interleave to eight), so every tile row goes out as 16-byte buffer stores straight from the registers --
+    // no LDS transposition, no barriers.  Lanes outside the tensor / beyond Cout carry the OOB offset (the hardware drops the
+    // store and returns 0 for the derivative-mask / accumulate loads); a vector that would cross the end of an output row (the
+    // range check cannot see row ends) falls back to per-dword stores on that lane.  16 channels x 64-byte runs per instruction.
+    const int onb = (int)((int64_t)p.Cout * oplane * 4);
+    const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + n * p.ons), 0, onb, 0x00020000);
+    const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? (int)((int64_t)p.dmC * oplane * 4) : 0, 0x00020000);
+    auto emit = [&](int co, int y, int x, float bias, float dsc, float dsh, f32x4 v) {
+      const bool ok = co < p.Cout && y < p.OH && x < p.OW;
+      const bool full = ok && x + 4 <= p.OW;
+      const unsigned off = (unsigned)((co * (int)oplane + y * p.OW + x) * 4);
+      const unsigned vo = full ? off : OOB_OFF;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = v[j] + bias;
+        if (p.act_out == VTS_ACT_TANH) t = tanhf(t);
+        v[j] = t;
+      }
+      const f32x4 base = v;   // bias + activation applied; the edge path below redoes mask / accumulate per element
+      if (p.dm) {
+        const f32x4 d = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, (int)vo, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= vts_act_grad(d[j] * dsc + dsh, p.dm_act);
+      }
+      if (p.accumulate) {
+        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (int)vo, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += q[j];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ors, (int)vo, 0, 0);
+      if (ok && !full) {   // right edge of an output row: per element
+        float* ob = p.out + n * p.ons + co * oplane + (int64_t)y * p.OW + x;
+        const float* db = p.dm ? p.dm + n * p.dmns + co * oplane + (int64_t)y * p.OW + x : nullptr;
+        for (int j = 0; j < p.OW - x; ++j) {
+          float t = base[j];
+          if (db) t *= vts_act_grad(db[j] * dsc + dsh, p.dm_act);
+          ob[j] = p.accumulate ? ob[j] + t : t;
+        }
+      }
+    };
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      const int co = co0 + nr * 16 + m16;
+      const int coc = min(co, p.Cout - 1);
+      const float bias = p.bias ? p.bias[coc] : 0.f;
+      const float dsc = (p.dm && p.dmsc) ? p.dmsc[n * p.dmC + coc] : 1.f, dsh = (p.dm && p.dmsh) ? p.dmsh[n * p.dmC + coc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
+          if (P == 1) {
+            emit(co, gy, gx, bias, dsc, dsh, acc[r][mt][0][nr]);
+          } else {
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              const f32x4 a = acc[r][mt][P == 4 ? py * 2 : 0][nr], b = acc[r][mt][P == 4 ? py * 2 + 1 : 0][nr];
+              emit(co, gy * 2 + py, gx * 2, bias, dsc, dsh, (f32x4){a[0], b[0], a[1], b[1]});
+              emit(co, gy * 2 + py, gx * 2 + 4, bias, dsc, dsh, (f32x4){a[2], b[2], a[3], b[3]});
+            }
+          }
+        }
+    }
+    return;
+  }
   float* so = lds;
   const bool vec_ok = ((p.OW & 3) == 0) && ((p.ons & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
                       (!p.part || (reinterpret_cast<uintptr_t>(p.part) & 15) == 0) &&
@@ -554,6 +629,10 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr;
   static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
   k.ablate = ablate;
+  static const int stagger = getenv("VTS_STAGGER") ? atoi(getenv("VTS_STAGGER")) : 0;
+  k.stagger = stagger;
+  static const int direct_epi = getenv("VTS_DIRECT_EPI") ? atoi(getenv("VTS_DIRECT_EPI")) : 1;
+  k.direct_epi = direct_epi && (int64_t)d->Cout * d->OH * d->OW * 4 < (int64_t)OOB_OFF && (!d->dmask.data || (int64_t)d->dmask.C * d->OH * d->OW * 4 < (int64_t)OOB_OFF);
   k.ident = vts_ident();
   VTS_CHECK_ARG(k.ident, "vts_conv4x4: could not allocate the identity constants");
   {
