@@ -126,7 +126,7 @@ def kernel_roofline(model, batch_dict, detail_path=None):
                 f.write("%4d %8.3f %8.1f %8.2f %8.1f  %s\n" % (c, t * 1e3, t / c * 1e6, fl / t / 1e12, nb / t / 1e9, k))
     total = sum(a[1] for a in agg.values())
     # the dominant KERNEL: labels naming several kernels of one C call ("a_kernel+b_kernel") are not one kernel
-    single = {k: v for k, v in agg.items() if "_kernel+" not in k}
+    single = {k: v for k, v in agg.items() if "_kernel" in k and "_kernel+" not in k}
     label, (cnt, t, nbytes, flops) = max(single.items(), key=lambda kv: kv[1][1])
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
     if t_hbm >= t_mfma:

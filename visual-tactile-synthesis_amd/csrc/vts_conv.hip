@@ -685,6 +685,12 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
     default: return launch<MODE, S, 5, RW5, MT5, 4>(k, N, st);                  \
   }
   if (!d->transposed) {
+    if (d->stride == 2 && nr == 1) {   // tile of the thin forward layers: 8x32 outputs (measured best of 8x64 / 4x64 / 4x32 / 8x32); VTS_TILE01=rw*10+mt
+      static const int tile01 = getenv("VTS_TILE01") ? atoi(getenv("VTS_TILE01")) : 22;
+      if (tile01 == 14) return launch<0, 2, 1, 1, 4, 4>(k, N, st);
+      if (tile01 == 12) return launch<0, 2, 1, 1, 2, 4>(k, N, st);
+      if (tile01 == 22) return launch<0, 2, 1, 2, 2, 4>(k, N, st);
+    }
     if (d->stride == 2) { VTS_DISPATCH(0, 2, 2, 4, 1, 4, 1, 4, 1, 2, 1, 2) }
     VTS_DISPATCH(0, 1, 2, 4, 1, 4, 1, 4, 1, 2, 1, 2)
   } else {
