@@ -1,11 +1,27 @@
-# end-of-round measurement pass (run through gpurun): headline bench + rocprof kernel stats, pix2pixHD patch / full-size benches
+# end-of-round measurement pass (run through gpurun): headline bench + per-shape table + rocprof kernel stats + PMC traffic / MFMA utilisation
+# + per-layer generator roofline table + secondary workloads.   bash tools/prof_round.sh [tag]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r1k; rm -rf $O; mkdir -p $O
-python bench.py --detail $O/detail.txt > $O/bench.json 2>$O/bench.err
+T=${1:-r02}
+O=gpurun_out/prof_$T; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python bench.py --steps 10 --warmup 3 --no_cpu_baseline > $O/stats.log 2>&1
-python bench.py --model pix2pixHD --batch 32 --no_cpu_baseline --detail $O/p2p_patch_detail.txt > $O/p2p_patch_bench.json 2>$O/p2p_patch.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p2p_stats -o run -- python bench.py --model pix2pixHD --batch 32 --steps 10 --warmup 3 --no_cpu_baseline > $O/p2p_stats.log 2>&1
-python bench.py --model pix2pixHD --p2p_size 1024 --batch 2 --steps 5 --warmup 3 --no_cpu_baseline --detail $O/p2p_full_detail.txt > $O/p2p_full_bench.json 2>$O/p2p_full.err
-python bench.py --infer > $O/infer.json 2>$O/infer.err
-python bench.py --model sinskitG --netG resnet_9blocks --no_cpu_baseline > $O/resnet9.json 2>$O/resnet9.err
-tail -c 300 $O/bench.json; ls $O/stats $O/p2p_stats
+cp $O/stats/run_kernel_stats.csv $O/kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_graph > $O/$c.log 2>&1
+done
+python tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_pmc.json "$T"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o run -- python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_graph > $O/mfma.log 2>&1
+python tools/pmc_mfma.py $O/pmc_mfma $O/mfma_util.json "$T"
+# the bench line reads the two summaries from profiles/: install them first so that the line and the summaries belong together
+cp $O/traffic_pmc.json profiles/${T}_traffic_pmc.json; cp $O/mfma_util.json profiles/${T}_mfma_util.json
+python bench.py --detail $O/kernel_shape_table.txt > $O/bench.json 2>$O/bench.err
+python bench.py --batch 1 --no_cpu_baseline > $O/bench_batch1.json 2>/dev/null
+python bench.py --no_viz --no_cpu_baseline > $O/bench_no_viz.json 2>/dev/null
+python bench.py --infer > $O/infer_bench.json 2>/dev/null
+python tools/g_layer_table.py $O/g_layer_table.md > /dev/null 2>&1
+python tools/mb_wgrad.py > $O/wgrad_microbench.txt 2>&1
+VTS_MB=top python tools/microbench_conv.py > $O/conv_microbench.txt 2>&1
+python bench.py --model pix2pixHD --batch 32 --no_cpu_baseline > $O/pix2pixHD_patch_bench.json 2>/dev/null
+python bench.py --model pix2pixHD --p2p_size 1024 --batch 2 --steps 5 --warmup 3 --no_cpu_baseline > $O/pix2pixHD_2x1024_bench.json 2>/dev/null
+python bench.py --model sinskitG --netG resnet_9blocks --no_cpu_baseline > $O/resnet9_bench.json 2>/dev/null
+rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
+head -c 1500 $O/bench.json; echo; for f in bench_batch1 bench_no_viz infer_bench pix2pixHD_patch_bench pix2pixHD_2x1024_bench resnet9_bench; do python -c "import json,sys; d=json.load(open('$O/$f.json')); print('$f', d['metric'], round(d['value'],2), d['unit'], round(d['ms_per_step'],3), 'ms')"; done

@@ -47,6 +47,7 @@ struct ConvK {
   int identity_in;     // no affine on either source and no input activation
   int ablate;       // profiling only (env VTS_ABLATE): 1 skip global loads, 2 skip MFMA, 4 skip epilogue
   int wbytes;       // extent of the weight tensor view in bytes (buffer descriptor of the weight loads)
+  int xcd_swizzle;  // 1: XCD-aware workgroup order (default); VTS_XCD_SWIZZLE=0 keeps the hardware order
   int direct_epi;   // 1: stores straight from the accumulator registers (default); 0: through LDS (VTS_DIRECT_EPI=0)
   int stagger;      // start-up stagger in units of ~3.4 us (s_sleep 127): workgroup w of a co-resident set waits (w % 3) * stagger units
 };
@@ -100,10 +101,24 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   // scale/shift) then lives in SGPRs / scalar loads instead of per-lane VGPRs and branches
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, kq = lane >> 4;
-  const int n = blockIdx.z % p.N;
-  const int cg = (blockIdx.z / p.N) % p.CG, ks = blockIdx.z / (p.N * p.CG);
+  // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2, so spatially adjacent tiles
+  // would fetch their shared halo rows / columns from HBM once per XCD.  Remap ids so that every XCD walks one contiguous run of
+  // tiles (bijective for any grid size): neighbours in x and y then meet in the same L2.  (PMC: 1.5x -> measured in DESIGN.md.)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_swizzle) {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * (int)gridDim.z;
+    const int lin = bx + gx * (by + gy * bz);
+    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+    const int lin2 = xcd * q + min(xcd, r) + idx;
+    bz = lin2 / (gx * gy);
+    const int rem = lin2 - bz * (gx * gy);
+    by = rem / gx;
+    bx = rem - by * gx;
+  }
+  const int n = bz % p.N;
+  const int cg = (bz / p.N) % p.CG, ks = bz / (p.N * p.CG);
   const int co0 = cg * NR * 16;
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  const int tx0 = bx * TX, ty0 = by * TY;
   const int podd = p.pad & 1;
 
   int iy0, ix0;
@@ -631,6 +646,8 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.ablate = ablate;
   static const int stagger = getenv("VTS_STAGGER") ? atoi(getenv("VTS_STAGGER")) : 0;
   k.stagger = stagger;
+  static const int xcd_swizzle = getenv("VTS_XCD_SWIZZLE") ? atoi(getenv("VTS_XCD_SWIZZLE")) : 1;
+  k.xcd_swizzle = xcd_swizzle;
   static const int direct_epi = getenv("VTS_DIRECT_EPI") ? atoi(getenv("VTS_DIRECT_EPI")) : 1;
   k.direct_epi = direct_epi && (int64_t)d->Cout * d->OH * d->OW * 4 < (int64_t)OOB_OFF && (!d->dmask.data || (int64_t)d->dmask.C * d->OH * d->OW * 4 < (int64_t)OOB_OFF);
   k.ident = vts_ident();
