@@ -36,6 +36,7 @@ struct SmallK {
   int IPB, PWi, plane;  // images per block, padded row pitch, padded plane size (floats)
   int GH, GW, PPI, MTP; // phase-grid dims, pixels per image per phase, M-tiles per phase
   int ablate;           // profiling only (env VTS_ABLATE)
+  int wbytes;           // extent of the weight view in bytes (buffer descriptor)
 };
 
 template <int MODE, int S, int NR, int UMAX, int CK>
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallK p) {
 
   const int64_t iplane = (int64_t)p.IH * p.IW;
   const int nchunks = (p.Cin + CK - 1) / CK;
-  const bool co_major = p.ws_co >= p.ws_ci;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
   const int half = lane >> 5, xl = lane & 31;
   const int nlines = p.IPB * CK * p.IH;   // (image, channel, row) lines of the inner region
   __syncthreads();
@@ -161,32 +162,26 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallK p) {
         }
       }
     }
-    // ---- stage the weight slice: lds_w[c][slot][co] ----
+    // ---- stage the weight slice: lds_w[c][slot][co].  A thread loads the four kx taps of one (cout, channel, ky) as one 16-byte
+    // buffer load (out-of-range couts / channels carry the OOB offset: the hardware returns 0); threads of a wave differ in cout, so
+    // the four LDS stores are bank-conflict-free (the former tap-fastest mapping was 16-way conflicted).
     {
       constexpr int NCO = NR * 16;
+      constexpr int UNITS = CK * 4 * NCO;
 #pragma unroll
-      for (int e = 0; e < CK * NR; ++e) {
-        const int idx = tid + e * 256;
-        int co, c, slot;
-        if (co_major) {
-          co = idx / (CK * 16);
-          const int rem = idx - co * (CK * 16);
-          c = rem >> 4;
-          slot = rem & 15;
-        } else {
-          c = idx / (NCO * 16);
-          const int rem = idx - c * (NCO * 16);
-          co = rem >> 4;
-          slot = rem & 15;
+      for (int e = 0; e < UNITS / 256; ++e) {
+        const int u = tid + e * 256;
+        const int co = u % NCO, rest = u / NCO;
+        const int ky = rest & 3, c = rest >> 2;
+        const bool ok = co0 + co < p.Cout && cbase + c < p.Cin;
+        const unsigned vo = ok ? (unsigned)((co0 + co) * p.ws_co + (cbase + c) * p.ws_ci + ky * 4) * 4u : 0x40000000u;
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)vo, 0, 0));
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          int slot = ky * 4 + kx;
+          if (MODE == 1 && S == 2) slot = ((((ky + p.pad) & 1) * 2 + ((kx + p.pad) & 1)) * 4) + (ky >> 1) * 2 + (kx >> 1);
+          lds_w[(c * 16 + slot) * COP + co] = v[kx];
         }
-        int tap = slot;
-        if (MODE == 1 && S == 2) {
-          const int ph = slot >> 2, a = (slot >> 1) & 1, b = slot & 1;
-          const int ky = (((ph >> 1) + p.pad) & 1) + 2 * a, kx = (((ph & 1) + p.pad) & 1) + 2 * b;
-          tap = ky * 4 + kx;
-        }
-        const float v = p.w[(int64_t)min(co0 + co, p.Cout - 1) * p.ws_co + (int64_t)min(cbase + c, p.Cin - 1) * p.ws_ci + tap];
-        lds_w[(c * 16 + slot) * COP + co] = (co0 + co < p.Cout && cbase + c < p.Cin) ? v : 0.f;
       }
     }
     __syncthreads();
@@ -294,6 +289,7 @@ int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st) {
   k.slope_in = vts_slope(d->act_in);
   static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
   k.ablate = ablate;
+  k.wbytes = (int)(((int64_t)(d->Cout - 1) * d->ws_co + (int64_t)(k.Cin - 1) * d->ws_ci + 16) * 4);
   k.PWi = d->IW + 2 * HALO + 1;
   k.plane = (d->IH + 2 * HALO) * k.PWi;
   k.GH = ph4 ? (d->OH + 1) / 2 : d->OH;
