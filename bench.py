@@ -20,6 +20,10 @@ for p in (os.path.join(ROOT, "visual-tactile-synthesis_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# Host threads: torch's CPU ops fan out over an OpenMP pool (128 workers on the MI355X hosts) whose workers SPIN after each
+# parallel region; that starved the HIP runtime's completion thread and stalled graph-replayed steps by 70..170 ms
+# (tools/probes/stall_bisect2.py).  Passive waiting must be chosen before libgomp starts, i.e. before `import torch`.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -307,7 +311,7 @@ def main():
             return {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
 
         batches = [pinned(batch), pinned(make_batch(args.size, args.batch, rank + 1, style_dim))]
-        for i in range(2):
+        for i in range(max(2, args.warmup)):
             model.set_input(batches[i % 2], phase="train")
             model.optimize_parameters(epoch=1)
         barrier()

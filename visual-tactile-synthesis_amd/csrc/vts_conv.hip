@@ -18,7 +18,9 @@
 // LDS reads are conflict-free by construction: A fragments read stride-S words of one patch
 // row (32 lanes -> 32 distinct banks or broadcast), B fragments read [k][cout] with the cout
 // pitch = 16 (mod 32).
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "vts_internal.h"
 
@@ -50,6 +52,8 @@ struct ConvK {
   int xcd_swizzle;  // 1: XCD-aware workgroup order (default); VTS_XCD_SWIZZLE=0 keeps the hardware order
   int direct_epi;   // 1: stores straight from the accumulator registers (default); 0: through LDS (VTS_DIRECT_EPI=0)
   int stagger;      // start-up stagger in units of ~3.4 us (s_sleep 127): workgroup w of a co-resident set waits (w % 3) * stagger units
+  unsigned long long* trace;   // profiling only (env VTS_CONV_TRACE): per workgroup 8 x 64-bit: hw id, then s_memrealtime (100 MHz) at the phase boundaries
+  int tiles_x;      // tiles per row band; a workgroup walks the run [bx * tiles_x / gridDim.x, (bx + 1) * tiles_x / gridDim.x) of them
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -62,7 +66,7 @@ __device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
 
 // Output staging region of one epilogue pass: 16 output channels x ER rows x EC columns, plane pitch odd
 // so that the 16 channel planes land on distinct LDS banks.
-template <int MODE, int S, int NR, int RW, int MT, int CK>
+template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN>
 __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
   constexpr int TY = 4 * RW, TX = 16 * MT;
@@ -97,6 +101,12 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
   }
   const int tid = threadIdx.x, lane = tid & 63;
+  const int trace_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  auto stamp = [&](int i) {
+    if (p.trace && tid == 0) p.trace[(int64_t)trace_wg * 8 + i] = i == 0 ? (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) : __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
+  stamp(1);
   // provably wave-uniform wave index: all per-row staging state (bounds, row pointers, normalisation
   // scale/shift) then lives in SGPRs / scalar loads instead of per-lane VGPRs and branches
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,20 +128,19 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   const int n = bz % p.N;
   const int cg = (bz / p.N) % p.CG, ks = bz / (p.N * p.CG);
   const int co0 = cg * NR * 16;
-  const int tx0 = bx * TX, ty0 = by * TY;
+  // Tile run of this workgroup (round 2): thin layers have one or two input-channel chunks per tile, so a workgroup that owned a
+  // single tile would load, multiply and store strictly one after the other (measured: the phases add up, co-resident workgroups
+  // run in lock-step).  A run of tiles along x turns the chunk pipeline into a tile pipeline: the loads of the next tile are in
+  // flight during the MFMA phase and the stores of the current one.
+  // (RUN instances only; the others keep one tile per workgroup and the epilogue outside the chunk loop.)
+  const int tile_begin = RUN ? bx * p.tiles_x / (int)gridDim.x : bx, tile_end = RUN ? (bx + 1) * p.tiles_x / (int)gridDim.x : bx + 1;
+  const int ty0 = by * TY;
   const int podd = p.pad & 1;
 
-  int iy0, ix0;
-  if (MODE == 0) {
-    iy0 = ty0 * S - p.pad;
-    ix0 = tx0 * S - p.padx;
-  } else if (S == 2) {
-    iy0 = ty0 + (p.pad >> 1) - 1;
-    ix0 = tx0 + (p.pad >> 1) - 1;
-  } else {
-    iy0 = ty0 + p.pad - 3;
-    ix0 = tx0 + p.padx - 3;
-  }
+  int iy0;
+  if (MODE == 0) iy0 = ty0 * S - p.pad;
+  else if (S == 2) iy0 = ty0 + (p.pad >> 1) - 1;
+  else iy0 = ty0 + p.pad - 3;
 
   // per-lane A-fragment base offsets inside one channel plane of the patch
   int aoff[P];
@@ -191,22 +200,34 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   const float* sb0 = p.s0 + n * p.ns0;
   const float* sb1 = p.s1 + n * p.ns1;
   const unsigned row0 = (unsigned)(iy0 * p.IW * 4), rstep = (unsigned)(p.IW * 4);
-  unsigned vo_m[NCM > 0 ? NCM : 1];   // lane parts of the byte offsets of the row-wise pieces
+  unsigned vo_m[NCM > 0 ? NCM : 1];   // lane parts of the byte offsets of the row-wise pieces (of the tile being loaded)
   int colw[NCM > 0 ? NCM : 1];        // LDS column a lane writes (lanes beyond the piece write the pad column PC)
 #pragma unroll
   for (int cm = 0; cm < NCM; ++cm) {
-    const int col = cm * 64 + lane, ix = ix0 + col;
-    vo_m[cm] = (col < PCM && ix >= 0 && ix < p.IW) ? (unsigned)ix * 4u : OOB_OFF;
+    const int col = cm * 64 + lane;
+    vo_m[cm] = OOB_OFF;
     colw[cm] = col < PCM ? col : PC;
   }
   unsigned vo_t = OOB_OFF;
   int dst_t = PC;
-  if (TW > 0) {
-    const int r_t = lane / (TW > 0 ? TW : 1), c_t = lane - r_t * (TW > 0 ? TW : 1), ix = ix0 + PCM + c_t;
-    const bool live = r_t < PR;
-    vo_t = (live && ix >= 0 && ix < p.IW) ? (unsigned)(r_t * p.IW + ix) * 4u : OOB_OFF;
-    dst_t = live ? r_t * PCP + PCM + c_t : PC;
-  }
+  const int r_t = lane / (TW > 0 ? TW : 1), c_t = lane - r_t * (TW > 0 ? TW : 1);
+  if (TW > 0) dst_t = r_t < PR ? r_t * PCP + PCM + c_t : PC;
+  auto set_tile = [&](int tile) {   // column offsets of the tile whose patch is loaded next
+    const int tx0 = tile * TX;
+    int ix0;
+    if (MODE == 0) ix0 = tx0 * S - p.padx;
+    else if (S == 2) ix0 = tx0 + (p.pad >> 1) - 1;
+    else ix0 = tx0 + p.padx - 3;
+#pragma unroll
+    for (int cm = 0; cm < NCM; ++cm) {
+      const int col = cm * 64 + lane, ix = ix0 + col;
+      vo_m[cm] = (col < PCM && ix >= 0 && ix < p.IW) ? (unsigned)ix * 4u : OOB_OFF;
+    }
+    if (TW > 0) {
+      const int ix = ix0 + PCM + c_t;
+      vo_t = (r_t < PR && ix >= 0 && ix < p.IW) ? (unsigned)(r_t * p.IW + ix) * 4u : OOB_OFF;
+    }
+  };
   float wsc = 1.f, wsh = 0.f;
   unsigned cur_nrec = 0;
 
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     return z;
   };
 
-  auto load_chunk = [&](int chunk) {
+  auto load_chunk = [&](int chunk, bool with_w) {
     const int cbase = chunk * CK;
     const int cic = cbase + wave + opaque_zero();
     {
@@ -261,10 +282,12 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
 #pragma unroll
       for (int cm = 0; cm < NCM; ++cm) pv[r * NCM + cm] = ld_buf(rs, vo_m[cm] + row0 + r * rstep);
     if (TW > 0) tv = ld_buf(rs, vo_t + row0);
-    const int wsoff = cbase * p.ws_ci * 4;
+    if (with_w) {
+      const int wsoff = cbase * p.ws_ci * 4;
 #pragma unroll
-    for (int e = 0; e < NR; ++e)
-      wv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(cbase + wc[e] < p.Cin ? wvo[e] : OOB_OFF), wsoff, 0));
+      for (int e = 0; e < NR; ++e)
+        wv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(cbase + wc[e] < p.Cin ? wvo[e] : OOB_OFF), wsoff, 0));
+    }
   };
 
   // branch-free  pad( act( x * scale + shift ) )
@@ -292,90 +315,25 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     }
   };
 
-  auto store_chunk = [&](int chunk) {
+  auto store_chunk = [&](bool with_w) {
     if (p.identity_in) store_patch(TagT());   // uniform: gradients and raw inputs carry no affine / activation
     else store_patch(TagF());
+    if (with_w) {
 #pragma unroll
-    for (int e = 0; e < NR; ++e)
+      for (int e = 0; e < NR; ++e)
 #pragma unroll
-      for (int kx = 0; kx < 4; ++kx) lds_w[wld[e][kx]] = wv[e][kx];
+        for (int kx = 0; kx < 4; ++kx) lds_w[wld[e][kx]] = wv[e][kx];
+    }
   };
 
-  if (chunk_begin < chunk_end) {
-    if (!(p.ablate & 1)) load_chunk(chunk_begin);
-    store_chunk(chunk_begin);
-  }
-  __syncthreads();
-  for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
-    const bool more = chunk + 1 < chunk_end;
-    if (more && !(p.ablate & 1)) load_chunk(chunk + 1);
-    // ---- MFMA accumulate ----
-    const int cvalid = (p.ablate & 2) ? 0 : min(CK, p.Cin - chunk * CK);   // channels beyond Cin are zero: skip them
-    for (int c = 0; c < cvalid; ++c) {
-      const float* pp = lds_patch + c * PR * PCP;
-      const float* ww = lds_w + c * 16 * COP + kq * COP + m16;
-      if (MODE == 1 && S == 2) {
-#pragma unroll
-        for (int ph = 0; ph < P; ++ph) {
-          float b[NR];
-#pragma unroll
-          for (int nr = 0; nr < NR; ++nr) b[nr] = ww[ph * 4 * COP + nr * 16];
-#pragma unroll
-          for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              const float a = pp[aoff[ph] + r * PCP + mt * 16];
-#pragma unroll
-              for (int nr = 0; nr < NR; ++nr)
-                acc[r][mt][ph][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nr], acc[r][mt][ph][nr], 0, 0, 0);
-            }
-        }
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float b[NR];
-#pragma unroll
-          for (int nr = 0; nr < NR; ++nr) b[nr] = ww[g * 4 * COP + nr * 16];
-#pragma unroll
-          for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              float a;
-              if (MODE == 0)
-                a = pp[aoff[0] + (r * S + g) * PCP + mt * 16 * S];
-              else
-                a = pp[aoff[0] + (r - g) * PCP + mt * 16];
-#pragma unroll
-              for (int nr = 0; nr < NR; ++nr)
-                acc[r][mt][0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nr], acc[r][mt][0][nr], 0, 0, 0);
-            }
-        }
-      }
-    }
-    __syncthreads();
-    if (more) {
-      store_chunk(chunk + 1);
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: accumulators -> LDS (channel planes) -> coalesced, vectorised global stores.
-  // C/D layout of a 16x16 tile: col (cout) = lane&15, row (pixel) = (lane>>4)*4 + reg.
-  // One pass handles 16 output channels and, for transposed s2, one output row parity (both column
-  // parities interleaved, so rows are contiguous in x).
-  if (p.ablate & 4) {
-    if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
-    return;
-  }
+  // ---- direct epilogue (round 2): a lane's four accumulator registers are four consecutive pixels of ONE output channel
+  // (two parity phases interleave to eight), so every tile row goes out as 16-byte buffer stores straight from the registers --
+  // no LDS transposition, no barriers.  Lanes outside the tensor / beyond Cout carry the OOB offset (the hardware drops the
+  // store and returns 0 for the derivative-mask / accumulate loads); a vector that would cross the end of an output row (the
+  // range check cannot see row ends) falls back to per-dword stores on that lane.  16 channels x 64-byte runs per instruction.
   const int64_t oplane = (int64_t)p.OH * p.OW;
-  constexpr int PY = (P == 4) ? 2 : 1;
-  const int oy0 = (P == 4) ? ty0 * 2 : ty0, ox0 = (P == 4) ? tx0 * 2 : tx0;
-  if (!p.part && p.direct_epi) {
-    // ---- direct epilogue (round 2): a lane's four accumulator registers are four consecutive pixels of ONE output channel
-    // (two parity phases interleave to eight), so every tile row goes out as 16-byte buffer stores straight from the registers --
-    // no LDS transposition, no barriers.  Lanes outside the tensor / beyond Cout carry the OOB offset (the hardware drops the
-    // store and returns 0 for the derivative-mask / accumulate loads); a vector that would cross the end of an output row (the
-    // range check cannot see row ends) falls back to per-dword stores on that lane.  16 channels x 64-byte runs per instruction.
+  const bool direct = !p.part && p.direct_epi;
+  auto epilogue_direct = [&](int tx0) {
     const int onb = (int)((int64_t)p.Cout * oplane * 4);
     const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + n * p.ons), 0, onb, 0x00020000);
     const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? (int)((int64_t)p.dmC * oplane * 4) : 0, 0x00020000);
@@ -433,10 +391,126 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
               emit(co, gy * 2 + py, gx * 2 + 4, bias, dsc, dsh, (f32x4){a[2], b[2], a[3], b[3]});
             }
           }
+#pragma unroll
+          for (int ph = 0; ph < P; ++ph) acc[r][mt][ph][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
+  };
+
+  // units of the pipeline: (tile of the run, input-channel chunk); a single-chunk layer keeps its weights in LDS for the whole run
+  const int nch = chunk_end - chunk_begin;
+  const int units = nch > 0 ? nch * (tile_end - tile_begin) : 0;
+  const bool reload_w = !RUN || nch > 1;
+  stamp(2);
+  if (units > 0) {
+    set_tile(tile_begin);
+    if (!(p.ablate & 1)) load_chunk(chunk_begin, true);
+    stamp(3);
+    store_chunk(true);
+  }
+  __syncthreads();
+  stamp(4);
+  int chunk = chunk_begin, tile = tile_begin;
+  for (int u = 0; u < units; ++u) {
+    const bool more = u + 1 < units;
+    int chunk_n = chunk + 1, tile_n = tile;
+    if (chunk_n == chunk_end) {
+      chunk_n = chunk_begin;
+      tile_n = tile + 1;
+    }
+    if (more) {
+      if (RUN && tile_n != tile) set_tile(tile_n);
+      if (!(p.ablate & 1)) load_chunk(chunk_n, reload_w);
+    }
+    // ---- MFMA accumulate ----
+    // One group = the four taps (K = 4) of one (channel, ky) or (channel, phase): NR weight fragments + RW x MT patch fragments,
+    // then RW x MT x NR MFMAs.  The fragments of the NEXT group are read (two register sets, ping-pong) before the MFMAs of the
+    // current one are issued, so LDS latency hides behind 32-cycle MFMAs even with one wave on the SIMD; the scheduling barriers
+    // keep the compiler from sinking the reads back to their first use (it did: read -> wait -> 2 MFMA, 70 % issue rate).
+    const int cvalid = (p.ablate & 2) ? 0 : min(CK, p.Cin - chunk * CK);   // channels beyond Cin are zero: skip them
+    {
+      constexpr int NA = RW * MT;
+      auto rd = [&](int c, int g, float (&av)[NA], float (&bv)[NR]) {
+        const float* pp = lds_patch + c * PR * PCP;
+        const float* ww = lds_w + c * 16 * COP + kq * COP + m16;
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) bv[nr] = ww[g * 4 * COP + nr * 16];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            if (MODE == 1 && S == 2) av[r * MT + mt] = pp[aoff[P == 4 ? g : 0] + r * PCP + mt * 16];
+            else if (MODE == 0) av[r * MT + mt] = pp[aoff[0] + (r * S + g) * PCP + mt * 16 * S];
+            else av[r * MT + mt] = pp[aoff[0] + (r - g) * PCP + mt * 16];
+          }
+      };
+      auto mm = [&](int g, const float (&av)[NA], const float (&bv)[NR]) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+              acc[r][mt][P == 4 ? g : 0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r * MT + mt], bv[nr], acc[r][mt][P == 4 ? g : 0][nr], 0, 0, 0);
+      };
+      float ax[NA], bx[NR], ay[NA], by_[NR];
+      if (cvalid > 0) rd(0, 0, ax, bx);
+      for (int c = 0; c < cvalid; ++c) {
+        rd(c, 1, ay, by_);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0, ax, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(c, 2, ax, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1, ay, by_);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(c, 3, ay, by_);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(2, ax, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < cvalid) rd(c + 1, 0, ax, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(3, ay, by_);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (u == 0) stamp(5);
+    if (RUN && direct && tile_n != tile) {   // tile complete: its accumulators go out while the next tile's loads are in flight
+      if (p.ablate & 4) {
+        if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
+      } else {
+        epilogue_direct(tile * TX);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk(reload_w);
+      __syncthreads();
+    }
+    chunk = chunk_n;
+    tile = tile_n;
+  }
+  stamp(6);
+  if (RUN) return;   // (the host launches RUN instances only with the direct epilogue)
+  const int tx0 = tile_begin * TX;
+  if (direct) {
+    if (!(p.ablate & 4)) epilogue_direct(tx0);
+    else if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
+    stamp(7);
     return;
   }
+  // the LDS epilogue below serves one tile per workgroup (k-split partials, VTS_DIRECT_EPI=0)
+
+  // ---- epilogue: accumulators -> LDS (channel planes) -> coalesced, vectorised global stores.
+  // C/D layout of a 16x16 tile: col (cout) = lane&15, row (pixel) = (lane>>4)*4 + reg.
+  // One pass handles 16 output channels and, for transposed s2, one output row parity (both column
+  // parities interleaved, so rows are contiguous in x).
+  if (p.ablate & 4) {
+    if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
+    return;
+  }
+  constexpr int PY = (P == 4) ? 2 : 1;
+  const int oy0 = (P == 4) ? ty0 * 2 : ty0, ox0 = (P == 4) ? tx0 * 2 : tx0;
   float* so = lds;
   const bool vec_ok = ((p.OW & 3) == 0) && ((p.ons & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
                       (!p.part || (reinterpret_cast<uintptr_t>(p.part) & 15) == 0) &&
@@ -552,13 +626,63 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_kernel(const ConvK p,
 }
 
 template <int MODE, int S, int NR, int RW, int MT, int CK>
-int launch(const ConvK& k, int N, hipStream_t st, int CG = 1, int KS = 1) {
+int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
+  ConvK k = k0;
   const int GH = P == 4 ? (k.OH + 1) / 2 : k.OH, GW = P == 4 ? (k.OW + 1) / 2 : k.OW;
-  dim3 grid(cdiv(GW, 16 * MT), cdiv(GH, 4 * RW), N * CG * KS);
-  hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK>), grid, dim3(256), 0, st, k);
-  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d>%s", MODE, S, NR, RW, MT, CK, KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
+  const int tiles_x = cdiv(GW, 16 * MT), tiles_y = cdiv(GH, 4 * RW);
+  k.tiles_x = tiles_x;
+  // Tile runs: only where the per-tile chunk pipeline is too short to overlap anything (<= run_max_chunks chunks per tile) and
+  // the grid stays several workgroups per CU deep after the cut.  VTS_TILE_RUN=<n> forces a run length (1 = one tile per workgroup).
+  static const int run_force = getenv("VTS_TILE_RUN") ? atoi(getenv("VTS_TILE_RUN")) : 0;
+  static const int run_wgs = getenv("VTS_TILE_RUN_WGS") ? atoi(getenv("VTS_TILE_RUN_WGS")) : 2048;
+  static const int run_max_chunks = getenv("VTS_TILE_RUN_CHUNKS") ? atoi(getenv("VTS_TILE_RUN_CHUNKS")) : 4;
+  int run = 1;
+  if (NR <= 2 && !k.part && k.direct_epi && KS == 1) {
+    const int64_t total = (int64_t)tiles_x * tiles_y * N * CG;
+    const int nchunks = (k.Cin + CK - 1) / CK;
+    if (run_force > 0) run = run_force;
+    else if (nchunks <= run_max_chunks) run = (int)(total / run_wgs);
+    if (run > tiles_x) run = tiles_x;
+    if (run < 1) run = 1;
+  }
+  dim3 grid(cdiv(tiles_x, run), tiles_y, N * CG * KS);
+  // VTS_CONV_TRACE=<file>: phase time stamps of every workgroup of the launches whose kernel matches VTS_CONV_TRACE_KERNEL
+  // ("MODE,S,NR,RW,MT"), appended as text rows (tools/conv_trace.py draws the occupancy / phase overlap from them)
+  static const char* trace_path = getenv("VTS_CONV_TRACE");
+  unsigned long long* trace_dev = nullptr;
+  const int64_t trace_wgs = (int64_t)grid.x * grid.y * grid.z;
+  if (trace_path) {
+    char tag[64];
+    snprintf(tag, sizeof tag, "%d,%d,%d,%d,%d", MODE, S, NR, RW, MT);
+    const char* want = getenv("VTS_CONV_TRACE_KERNEL");
+    if (!want || strcmp(want, tag) == 0) {
+      if (hipMalloc(&trace_dev, trace_wgs * 64) != hipSuccess) trace_dev = nullptr;
+      if (trace_dev) (void)hipMemsetAsync(trace_dev, 0, trace_wgs * 64, st);
+    }
+  }
+  k.trace = trace_dev;
+  if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2)>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false>), grid, dim3(256), 0, st, k);
+  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d>%s%s", MODE, S, NR, RW, MT, CK, KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""), run > 1 ? "+run" : "");
   VTS_CHECK_LAUNCH("vts_conv4x4");
+  if (trace_dev) {
+    (void)hipStreamSynchronize(st);
+    unsigned long long* h = (unsigned long long*)malloc(trace_wgs * 64);
+    (void)hipMemcpy(h, trace_dev, trace_wgs * 64, hipMemcpyDeviceToHost);
+    FILE* f = fopen(trace_path, "a");
+    if (f) {
+      fprintf(f, "# conv4x4_kernel<%d,%d,%d,%d,%d> run %d grid %u %u %u Cin %d Cout %d OH %d OW %d\n", MODE, S, NR, RW, MT, run, grid.x, grid.y, grid.z, k.Cin, k.Cout, k.OH, k.OW);
+      for (int64_t w = 0; w < trace_wgs; ++w) {
+        fprintf(f, "%lld %llx", (long long)w, h[w * 8]);
+        for (int i = 1; i < 8; ++i) fprintf(f, " %llu", h[w * 8 + i]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    free(h);
+    (void)hipFree(trace_dev);
+  }
   return VTS_OK;
 }
 
@@ -641,7 +765,7 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
   k.dm = d->dmask.data; k.dmsc = d->dmask.scale; k.dmsh = d->dmask.shift; k.dmns = d->dmask.nstride;
   k.dm_act = d->dmask_act; k.dmC = d->dmask.C;
   k.accumulate = d->accumulate;
-  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr;
+  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.trace = nullptr;
   static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
   k.ablate = ablate;
   static const int stagger = getenv("VTS_STAGGER") ? atoi(getenv("VTS_STAGGER")) : 0;

@@ -218,6 +218,14 @@ class SinSKITGModel(BaseModel):
             self._drop_graphs()
         return t
 
+    @staticmethod
+    def _stage(pin, src):
+        """Fill a pinned staging view from a host tensor with ONE thread (numpy; casts on the way).  torch's CPU copy_ fans out over
+        every core (128 OpenMP workers on the MI355X hosts) and their post-region spinning starved the HIP runtime's completion
+        thread: every ~3rd graph-replayed step then stalled 70..170 ms (tools/probes/stall_bisect2.py: torch copy_ stalls, the numpy
+        copy and torch.set_num_threads(1) do not)."""
+        np.copyto(pin.numpy(), src.numpy() if torch.is_tensor(src) else np.asarray(src), casting="unsafe")
+
     def _load(self, name, host, dtype=torch.float32):
         """host array -> persistent device buffer, asynchronously.  A pageable source would make the copy synchronous AND wait for the
         work already queued on the stream (the previous training step): such sources are staged through a persistent pinned buffer
@@ -231,7 +239,7 @@ class SinSKITGModel(BaseModel):
                 self._pin_evt[name] = torch.cuda.Event()
             else:
                 self._pin_evt[name].synchronize()     # the previous upload from this staging buffer has been read
-            pin.copy_(t)
+            self._stage(pin, t)
             t = pin
             buf.copy_(t, non_blocking=True)
             self._pin_evt[name].record()
@@ -259,18 +267,19 @@ class SinSKITGModel(BaseModel):
 
     def _patch_set(self, tag, T_images, I_masks, T_coords):
         """Upload one patch set (tactile squares, contact masks, gather offsets, image indices).  All five arrays travel as ONE
-        pinned block and ONE H2D copy; the device tensors are views into one persistent block.  (A dozen small staged uploads per
-        batch made every ~3rd graph-replayed step stall for ~70 ms on this stack: tools/probes/stall_bisect.py.)"""
+        pinned block and ONE H2D copy; the device tensors are views into one persistent block, filled by _stage (one host thread: the
+        many-threaded torch copy_ this used to be is what stalled every ~3rd graph-replayed step, tools/probes/stall_bisect2.py)."""
         T = torch.as_tensor(T_images)
         n, nt = T.shape[0], T.shape[1]
         ox, oy, cs = self._patch_offsets(torch.as_tensor(T_coords).numpy())
         if not (cs == 32).all():
             raise NotImplementedError("patch cutout != 32 px needs the bicubic resampler; not built")
         P = n * nt
-        parts = [("raw", T.reshape(P, 2, 32, 32).to(torch.float32)), ("masks", torch.as_tensor(I_masks).reshape(P, 1, 32, 32).to(torch.float32)),
-                 ("offx", torch.from_numpy(np.ascontiguousarray(ox.reshape(-1)))), ("offy", torch.from_numpy(np.ascontiguousarray(oy.reshape(-1)))),
-                 ("img", torch.arange(n, dtype=torch.int32).repeat_interleave(nt))]
-        words = sum((t.numel() + 63) // 64 * 64 for _, t in parts)       # all fields are 4-byte types; 256-byte aligned slots
+        f32 = torch.float32      # (the casts happen in _stage; .to() on the host would be another many-threaded torch op)
+        parts = [("raw", T.reshape(P, 2, 32, 32), f32), ("masks", torch.as_tensor(I_masks).reshape(P, 1, 32, 32), f32),
+                 ("offx", torch.from_numpy(np.ascontiguousarray(ox.reshape(-1))), torch.int32), ("offy", torch.from_numpy(np.ascontiguousarray(oy.reshape(-1))), torch.int32),
+                 ("img", torch.from_numpy(np.repeat(np.arange(n, dtype=np.int32), nt)), torch.int32)]
+        words = sum((t.numel() + 63) // 64 * 64 for _, t, _ in parts)       # all fields are 4-byte types; 256-byte aligned slots
         dev = self._buf(tag + "_block", (words,), torch.int32)
         pin = self._pins.get(tag)
         if pin is None or pin.numel() != words:
@@ -280,10 +289,10 @@ class SinSKITGModel(BaseModel):
             while not self._pin_evt[tag].query():     # the previous upload from this staging block has been read (spin: no sleeping wait)
                 pass
         views, o = {}, 0
-        for name, t in parts:
+        for name, t, dt in parts:
             k = t.numel()
-            pin[o:o + k].view(t.dtype).view(t.shape).copy_(t)
-            views[name] = dev[o:o + k].view(t.dtype).view(t.shape)
+            self._stage(pin[o:o + k].view(dt).view(t.shape), t)
+            views[name] = dev[o:o + k].view(dt).view(t.shape)
             o += (k + 63) // 64 * 64
         from vts import lib as L
         L.check(L.load().vts_copy_words(pin.data_ptr(), dev.data_ptr(), words, L.stream()), "vts_copy_words")   # kernel reads the pinned block
@@ -448,7 +457,7 @@ class SinSKITGModel(BaseModel):
             self._ranks_evt = torch.cuda.Event()
         else:
             self._ranks_evt.synchronize()
-        pin.copy_(ranks)
+        self._stage(pin, ranks)
         self._ranks.copy_(pin, non_blocking=True)     # pinned source: a pageable one would make this copy wait for the queued work
         self._ranks_evt.record()
 

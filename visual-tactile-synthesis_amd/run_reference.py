@@ -21,6 +21,9 @@ def main(argv):
     ref_dir = os.path.dirname(script)
     sys.path[:] = [HERE] + [p for p in sys.path if os.path.abspath(p or os.getcwd()) not in (HERE, ref_dir)]
     sys.argv = [script] + list(argv[2:])
+    # torch's OpenMP workers spin after every host-side parallel region and starve the HIP runtime's completion thread (stalls of
+    # 70..170 ms per step, tools/probes/stall_bisect2.py); the choice must be made before the script imports torch
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     runpy.run_path(script, run_name="__main__")
 
 

@@ -15,6 +15,10 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
+# Host threads: torch's CPU ops fan out over an OpenMP pool (128 workers on the MI355X hosts) whose workers SPIN after each
+# parallel region; that starved the HIP runtime's completion thread and stalled graph-replayed steps by 70..170 ms
+# (tools/probes/stall_bisect2.py).  Passive waiting must be chosen before libgomp starts, i.e. before `import torch`.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 import torch  # noqa: E402
 
 from data import create_dataset  # noqa: E402
