@@ -129,39 +129,88 @@ def kernel_roofline(model, batch_dict, detail_path=None):
             for k, (c, t, nb, fl) in rows:
                 f.write("%4d %8.3f %8.1f %8.2f %8.1f  %s\n" % (c, t * 1e3, t / c * 1e6, fl / t / 1e12, nb / t / 1e9, k))
     total = sum(a[1] for a in agg.values())
-    # the dominant KERNEL: labels naming several kernels of one C call ("a_kernel+b_kernel") are not one kernel
-    single = {k: v for k, v in agg.items() if "_kernel" in k and "_kernel+" not in k}
-    label, (cnt, t, nbytes, flops) = max(single.items(), key=lambda kv: kv[1][1])
-    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
-    if t_hbm >= t_mfma:
+    # The dominant KERNEL = the kernel template (all of its instances: tile shapes are a dispatch detail) with the largest total time.
+    # Labels naming several kernels of one C call ("a_kernel+b_kernel") are not one kernel.  Its launches are HBM-bound on some
+    # shapes and MFMA-bound on others (per-launch t_roof = max(bytes / BW, flops / P)); `bound` is the class holding more of the
+    # family's time, `achieved` = that class's algorithmic work / that class's measured time, and `frac_all_launches` =
+    # sum(t_roof) / sum(t) over every launch of the family, whatever its bound.
+    def fam_of(lbl):
+        return lbl.split("<")[0].split("+")[0]
+
+    fams = {}
+    for label, nbytes, flops, e0, e1, detail in rec:
+        if "_kernel" not in label or "_kernel+" in label:
+            continue
+        dt = e0.elapsed_time(e1) * 1e-3
+        t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
+        cls = "hbm" if t_hbm >= t_mfma else "mfma"
+        f = fams.setdefault(fam_of(label), {"t": 0.0, "n": 0, "t_roof": 0.0, "bytes": 0.0, "flops": 0.0,
+                                            "hbm": [0, 0.0, 0.0, 0.0], "mfma": [0, 0.0, 0.0, 0.0], "inst": {}})
+        f["t"] += dt
+        f["n"] += 1
+        f["t_roof"] += max(t_hbm, t_mfma)
+        f["bytes"] += nbytes
+        f["flops"] += flops
+        c = f[cls]
+        c[0] += 1
+        c[1] += dt
+        c[2] += nbytes
+        c[3] += flops
+        i = f["inst"].setdefault(label, [0, 0.0, 0.0, 0.0, 0.0])
+        i[0] += 1
+        i[1] += dt
+        i[2] += nbytes
+        i[3] += flops
+        i[4] += max(t_hbm, t_mfma)
+    fam, f = max(fams.items(), key=lambda kv: kv[1]["t"])
+    bound = "hbm" if f["hbm"][1] >= f["mfma"][1] else "mfma"
+    cnt, t, nbytes, flops = f[bound]
+    if bound == "hbm":
         roof = {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     else:
         roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    # HBM bytes per launch of this kernel instance from the PMC passes of tools/pmc_traffic.sh (separate FETCH_SIZE / WRITE_SIZE runs of
-    # this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so the
-    # figure comes from profiles/ -- but ONLY from a summary measured on exactly these kernel sources (csrc_sha16); otherwise null.
+    roof["frac_all_launches"] = f["t_roof"] / f["t"]
+    # HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh (separate FETCH_SIZE / WRITE_SIZE runs of this same command,
+    # FETCH_SIZE doubled per MI355X_MICROARCH.md), mean over ALL launches of the family (PMC rows are per instance, not per shape);
+    # compare with algorithmic_bytes_per_launch_family.  PMC counters cannot be read from inside this process, so the figure comes
+    # from profiles/ -- but ONLY from a summary measured on exactly these kernel sources (csrc_sha16); otherwise null.
     roof["traffic"] = None
     src, prof = newest_profile("*_traffic_pmc.json")
     if prof is not None:
-        ent = prof["kernels"].get(label.split("+")[0])
-        if ent:
-            roof["traffic"] = ent["hbm_bytes_per_launch"]
+        num = den = 0.0
+        for lbl, i in f["inst"].items():
+            ent = prof["kernels"].get(lbl.split("+")[0])
+            if ent:
+                num += i[0] * ent["hbm_bytes_per_launch"]
+                den += i[0]
+        if den == f["n"]:
+            roof["traffic"] = num / den
             roof["traffic_source"] = src
     # MFMA pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs), tools/pmc_mfma.sh), same staleness rule
     roof["mfma_util"] = roof["mfma_util_step"] = None
     src, prof = newest_profile("*_mfma_util.json")
     if prof is not None:
-        ent = prof["kernels"].get(label.split("+")[0])
-        roof["mfma_util"] = ent["mfma_util"] if ent else None
+        num = den = 0.0
+        for lbl, i in f["inst"].items():
+            ent = prof["kernels"].get(lbl.split("+")[0])
+            if ent:
+                num += i[1] * ent["mfma_util"]
+                den += i[1]
+        roof["mfma_util"] = num / den if den > 0 else None   # time-weighted over the family's instances
         roof["mfma_util_step"] = prof.get("step_mfma_util")
         roof["mfma_util_source"] = src
-    roof["kernel"] = label
+    roof["kernel"] = fam
     roof["launches_per_step"] = cnt
     roof["avg_launch_us"] = t / cnt * 1e6
     roof["algorithmic_bytes_per_launch"] = nbytes / cnt
     roof["algorithmic_flops_per_launch"] = flops / cnt
-    roof["share_of_timed_kernels"] = t / total
+    roof["launches_per_step_family"] = f["n"]
+    roof["algorithmic_bytes_per_launch_family"] = f["bytes"] / f["n"]
+    roof["share_of_timed_kernels"] = f["t"] / total
+    inst = sorted(f["inst"].items(), key=lambda kv: -kv[1][1])[:6]
+    roof["instances"] = [{"kernel": k, "launches": v[0], "avg_us": round(v[1] / v[0] * 1e6, 2), "bytes_per_launch": round(v[2] / v[0]),
+                          "flops_per_launch": round(v[3] / v[0]), "frac": round(v[4] / v[1], 4)} for k, v in inst]
     breakdown = sorted(((k, v[1] * 1e3, v[0]) for k, v in agg.items()), key=lambda x: -x[1])
     roof["breakdown_ms"] = {k: round(ms, 3) for k, ms, _ in breakdown[:8]}
     return roof

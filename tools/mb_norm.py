@@ -24,18 +24,24 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for shape, mode in [((4, 10, 512, 512), 0), ((4, 20, 256, 256), 0), ((4, 40, 128, 128), 0), ((4, 80, 64, 64), 0), ((4, 80, 32, 32), 0),
-                    ((8, 16, 257, 257), 1), ((8, 32, 129, 129), 1), ((8, 64, 130, 130), 1), ((4, 16, 257, 257), 1), ((640, 16, 9, 9), 1),
-                    ((640, 64, 6, 6), 1)]:
+G8, G640 = [0, 4], [0, 256, 384]   # pass groups of the batched discriminator launches (fake | real; fake | more fake | real)
+for shape, mode, groups in [((4, 10, 512, 512), 0, None), ((4, 20, 256, 256), 0, None), ((4, 40, 128, 128), 0, None), ((4, 80, 64, 64), 0, None),
+                            ((4, 80, 32, 32), 0, None), ((4, 80, 16, 16), 0, None), ((4, 80, 8, 8), 0, None),
+                            ((8, 16, 257, 257), 1, G8), ((8, 32, 129, 129), 1, G8), ((8, 64, 130, 130), 1, G8), ((8, 16, 129, 129), 1, G8),
+                            ((8, 32, 65, 65), 1, G8), ((8, 64, 66, 66), 1, G8), ((8, 16, 65, 65), 1, G8), ((8, 32, 33, 33), 1, G8),
+                            ((8, 64, 34, 34), 1, G8), ((4, 16, 257, 257), 1, None),
+                            ((640, 16, 9, 9), 1, G640), ((640, 32, 5, 5), 1, G640), ((640, 64, 6, 6), 1, G640), ((640, 16, 5, 5), 1, G640),
+                            ((640, 32, 3, 3), 1, G640), ((640, 64, 4, 4), 1, G640), ((640, 16, 3, 3), 1, G640), ((640, 32, 2, 2), 1, G640),
+                            ((640, 64, 3, 3), 1, G640)]:
     x = torch.randn(shape, device=dev)
     n, c, h, w = shape
     gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
-    kw = dict(gamma=gamma, beta=beta) if mode else {}
+    kw = dict(gamma=gamma, beta=beta, groups=groups) if mode else {}
     us = timeit(lambda: ops.norm_stats(x, mode, **kw))
     a = ops.norm_stats(x, mode, **kw)
     dy = torch.randn(shape, device=dev)
     dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-    kb = dict(gamma=gamma, dgamma=dg, dbeta=db) if mode else {}
+    kb = dict(gamma=gamma, dgamma=dg, dbeta=db, groups=groups) if mode else {}
     ub = timeit(lambda: ops.norm_bwd(dy, a, mode, **kb))
     out = torch.zeros(c, device=dev)
     uc = timeit(lambda: ops.channel_sum(x, out))

@@ -1,6 +1,8 @@
 // InstanceNorm / BatchNorm statistics and backward, channel sums, activation backward.
 // All of these are HBM-bound streaming reductions: one coalesced pass, wave64 shuffle
 // reductions, fixed-order second stage (deterministic, no float atomics).
+#include <stdlib.h>
+
 #include "vts_internal.h"
 
 namespace {
@@ -291,6 +293,69 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* __restrict__
   }
 }
 
+// apply with the finalize folded in (round 2: one launch and one dependency hop fewer per normalisation backward): every workgroup
+// reduces the partial sums of ITS group itself, in the order of norm_bwd_finalize_group (bit-identical coefficients in every
+// workgroup), the BatchNorm parameter gradients are written by the first workgroup of each channel.
+__device__ __forceinline__ void bwd_group_sums(const float* __restrict__ part, const NormBwdK& k, int c, int n0, int n1, float& s1, float& s2) {
+  const int lane = threadIdx.x & 63;
+  const int np = (n1 - n0) * k.spl;
+  s1 = 0.f;
+  s2 = 0.f;
+  for (int i = lane; i < np; i += 64) {
+    const int n = n0 + i / k.spl, s = i - (i / k.spl) * k.spl;
+    const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 2;
+    s1 += q[0];
+    s2 += q[1];
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_fin_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
+                                                                 const float* __restrict__ part, const NormBwdK k) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  int n0 = n, n1 = n + 1;
+  if (k.mode == 1) {
+    int gi = 0;
+    while (gi + 1 < k.ngroups && n >= k.gstart[gi + 1]) ++gi;
+    n0 = k.gstart[gi];
+    n1 = k.gstart[gi + 1];
+  }
+  float s1, s2;
+  bwd_group_sums(part, k, c, n0, n1, s1, s2);
+  const float m = (float)(n1 - n0) * (float)k.HW;
+  const float rs = k.rstd[n0 * k.C + c], mu = k.mean[n0 * k.C + c];
+  const float ga = (k.mode == 1 && k.gamma) ? k.gamma[c] : 1.f;
+  const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m;
+  if (k.mode == 1 && blockIdx.x == 0 && n == 0 && threadIdx.x < 64 && (k.dgamma || k.dbeta)) {
+    float dg = 0.f, db = 0.f;
+    for (int gi = 0; gi < k.ngroups; ++gi) {
+      float t1, t2;
+      bwd_group_sums(part, k, c, k.gstart[gi], k.gstart[gi + 1], t1, t2);
+      dg += t2;
+      db += t1;
+    }
+    if (threadIdx.x == 0) {
+      if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + dg;
+      if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + db;
+    }
+  }
+  const int64_t off = n * nstride + (int64_t)c * k.HW;
+  const int base = blockIdx.x * CHUNK;
+  float g[EPT], xv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = base + e * 256 + threadIdx.x;
+    g[e] = i < k.HW ? dy[off + i] : 0.f;
+    xv[e] = i < k.HW ? x[off + i] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = base + e * 256 + threadIdx.x;
+    if (i < k.HW) dy[off + i] = A * g[e] + B * (xv[e] - mu) + Cc;
+  }
+}
+
 // ---- single-launch variants for small groups (<= FUSED_MAX_GROUP elements per normalisation group):
 // one workgroup owns a whole group (IN: one (n,c) plane; BN: channel c of every image), reads it twice
 // (the second pass hits L2) and finishes in place.  Most normalisation calls of the step are this small
@@ -310,13 +375,81 @@ __device__ __forceinline__ int64_t fused_off(int j, int HW, int n0, int c, int64
   return n * nstride + (int64_t)c * HW + i;
 }
 
-__global__ __launch_bounds__(1024) void norm_stats_fused_kernel(const float* __restrict__ x, int64_t nstride, const NormK k) {
+// (n, i) of flattened element j of a BatchNorm group without an integer division: j < 2^24, so the float quotient is off by at most one
+__device__ __forceinline__ int64_t fused_off_fast(int j, int HW, float inv_hw, int n0, int c, int64_t nstride, bool bn) {
+  int n = n0, i = j;
+  if (bn) {
+    int q = (int)((float)j * inv_hw);
+    i = j - q * HW;
+    if (i < 0) { --q; i += HW; }
+    if (i >= HW) { ++q; i -= HW; }
+    n = n0 + q;
+  }
+  return n * nstride + (int64_t)c * HW + i;
+}
+
+// Register-resident form (round 2): a group of <= EPT * BLOCK elements is read ONCE, all loads of a pass group in flight together
+// (the loop form below issued one dependent load per iteration and read every element twice: 15 us average, 50 us on the D2 patch
+// layers).  The loads of the next BatchNorm pass group are issued before the reductions of the current one.  Same thread <-> element
+// mapping and summation order as the loop form: bit-identical statistics.
+template <int EPT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void norm_stats_fused_kernel(const float* __restrict__ x, int64_t nstride, const NormK k) {
   __shared__ float red[16];
   const int g = blockIdx.x;
   const bool bn = k.mode == 1;
   const int c = bn ? g : g % k.C;
   const int ngr = bn ? k.ngroups : 1;
+  const float inv_hw = 1.f / (float)k.HW;
+  float v[EPT], vn[EPT] = {};
+  auto load = [&](int gi, float (&dst)[EPT]) {
+    const int n0 = bn ? k.gstart[gi] : g / k.C, n1 = bn ? k.gstart[gi + 1] : n0 + 1;
+    const int total = (n1 - n0) * k.HW;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int j = e * BLOCK + threadIdx.x;
+      dst[e] = j < total ? x[fused_off_fast(j, k.HW, inv_hw, n0, c, nstride, bn)] : 0.f;
+    }
+  };
+  load(0, v);
   for (int gi = 0; gi < ngr; ++gi) {   // BatchNorm: the passes of this channel in order (running statistics)
+    const int n0 = bn ? k.gstart[gi] : g / k.C, n1 = bn ? k.gstart[gi + 1] : n0 + 1;
+    const int total = (n1 - n0) * k.HW;
+    const float cnt = (float)total;
+    if (gi + 1 < ngr) load(gi + 1, vn);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) s += v[e];
+    const float mean = block_sum(s, red) / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const float d = v[e] - mean;
+      if (e * BLOCK + (int)threadIdx.x < total) m2 += d * d;
+    }
+    m2 = block_sum(m2, red);
+    const float rstd = 1.f / sqrtf(m2 / cnt + k.eps);
+    const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f, be = (bn && k.beta) ? k.beta[c] : 0.f;
+    for (int n = n0 + threadIdx.x; n < n1; n += BLOCK) {
+      const int idx = n * k.C + c;
+      k.scale[idx] = ga * rstd;
+      k.shift[idx] = be - mean * ga * rstd;
+      if (k.mean_out) k.mean_out[idx] = mean;
+      if (k.rstd_out) k.rstd_out[idx] = rstd;
+    }
+    if (bn && threadIdx.x == 0) after_group(k, c, gi, mean, m2 / (cnt - 1.f));
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) v[e] = vn[e];
+  }
+}
+
+// loop form: groups beyond the register budget
+__global__ __launch_bounds__(1024) void norm_stats_fused_loop_kernel(const float* __restrict__ x, int64_t nstride, const NormK k) {
+  __shared__ float red[16];
+  const int g = blockIdx.x;
+  const bool bn = k.mode == 1;
+  const int c = bn ? g : g % k.C;
+  const int ngr = bn ? k.ngroups : 1;
+  for (int gi = 0; gi < ngr; ++gi) {
     const int n0 = bn ? k.gstart[gi] : g / k.C, n1 = bn ? k.gstart[gi + 1] : n0 + 1;
     const int total = (n1 - n0) * k.HW;
     const float cnt = (float)total;
@@ -342,8 +475,62 @@ __global__ __launch_bounds__(1024) void norm_stats_fused_kernel(const float* __r
   }
 }
 
-__global__ __launch_bounds__(1024) void norm_bwd_fused_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
-                                                              const NormBwdK k) {
+template <int EPT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void norm_bwd_fused_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
+                                                                const NormBwdK k) {
+  __shared__ float red[16];
+  const int g = blockIdx.x;
+  const bool bn = k.mode == 1;
+  const int c = bn ? g : g % k.C;
+  const int ngr = bn ? k.ngroups : 1;
+  const float inv_hw = 1.f / (float)k.HW;
+  float dg = 0.f, db = 0.f;
+  float gv[EPT], xv[EPT];
+  auto load = [&](int gi, float (&gd)[EPT], float (&xd)[EPT]) {
+    const int n0 = bn ? k.gstart[gi] : g / k.C, n1 = bn ? k.gstart[gi + 1] : n0 + 1;
+    const int total = (n1 - n0) * k.HW;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int j = e * BLOCK + threadIdx.x;
+      const int64_t off = fused_off_fast(j < total ? j : 0, k.HW, inv_hw, n0, c, nstride, bn);
+      gd[e] = j < total ? dy[off] : 0.f;
+      xd[e] = j < total ? x[off] : 0.f;
+    }
+  };
+  for (int gi = 0; gi < ngr; ++gi) {
+    load(gi, gv, xv);   // (no cross-group prefetch here: two operands x two buffers spill at 1024 threads)
+    const int n0 = bn ? k.gstart[gi] : g / k.C, n1 = bn ? k.gstart[gi + 1] : n0 + 1;
+    const int total = (n1 - n0) * k.HW;
+    const float m = (float)total;
+    const float mu = k.mean[n0 * k.C + c], rs = k.rstd[n0 * k.C + c];  // identical for every n of a BN pass
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      if (e * BLOCK + (int)threadIdx.x < total) {
+        s1 += gv[e];
+        s2 += gv[e] * ((xv[e] - mu) * rs);
+      }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float ga = (bn && k.gamma) ? k.gamma[c] : 1.f;
+    const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int j = e * BLOCK + threadIdx.x;
+      if (j < total) dy[fused_off_fast(j, k.HW, inv_hw, n0, c, nstride, bn)] = A * gv[e] + B * (xv[e] - mu) + Cc;
+    }
+    dg += s2;
+    db += s1;
+  }
+  if (bn && threadIdx.x == 0) {
+    if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + dg;
+    if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + db;
+  }
+}
+
+__global__ __launch_bounds__(1024) void norm_bwd_fused_loop_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
+                                                                   const NormBwdK k) {
   __shared__ float red[16];
   const int g = blockIdx.x;
   const bool bn = k.mode == 1;
@@ -503,10 +690,13 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
   // small groups: one launch, one workgroup per group (two passes, L2-resident).  BatchNorm over many tiny maps (the D2 passes:
   // 640 patches of 6x6 .. 9x9) also goes here: the partial kernel would launch N*C workgroups of a few dozen elements each.
   if (group <= FUSED_MAX_GROUP || (d->mode == 1 && d->C >= 32 && d->HW <= FUSED_BN_MAX_HW && group <= FUSED_BN_MAX_GROUP)) {
-    hipLaunchKernelGGL(norm_stats_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
-                       d->x, d->nstride, k);
+    const dim3 fg(d->mode == 0 ? d->N * d->C : d->C);
+    if (group <= 4096) hipLaunchKernelGGL((norm_stats_fused_kernel<16, 256>), fg, dim3(256), 0, st, d->x, d->nstride, k);
+    else if (group <= 8192) hipLaunchKernelGGL((norm_stats_fused_kernel<8, 1024>), fg, dim3(1024), 0, st, d->x, d->nstride, k);
+    else if (group <= 16384) hipLaunchKernelGGL((norm_stats_fused_kernel<16, 1024>), fg, dim3(1024), 0, st, d->x, d->nstride, k);
+    else hipLaunchKernelGGL(norm_stats_fused_loop_kernel, fg, dim3(1024), 0, st, d->x, d->nstride, k);
     VTS_CHECK_LAUNCH("vts_norm_stats fused");
-    vts_set_kernel("norm_stats_fused_kernel");
+    vts_set_kernel(group <= 16384 ? "norm_stats_fused_kernel" : "norm_stats_fused_loop_kernel");
     return VTS_OK;
   }
   if (d->counters && !grouped) {
@@ -540,10 +730,13 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   const int64_t group = (int64_t)(d->mode == 0 ? 1 : maxg) * d->HW;
   if (group <= FUSED_MAX_GROUP || (d->mode == 1 && d->C >= 32 && d->HW <= FUSED_BN_MAX_HW && group <= FUSED_BN_MAX_GROUP)) {
     const NormBwdK& kf = k;
-    hipLaunchKernelGGL(norm_bwd_fused_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(group <= 4096 ? 256 : 1024), 0, st,
-                       d->dy, d->x, d->nstride, kf);
+    const dim3 fg(d->mode == 0 ? d->N * d->C : d->C);
+    if (group <= 4096) hipLaunchKernelGGL((norm_bwd_fused_kernel<16, 256>), fg, dim3(256), 0, st, d->dy, d->x, d->nstride, kf);
+    else if (group <= 8192) hipLaunchKernelGGL((norm_bwd_fused_kernel<8, 1024>), fg, dim3(1024), 0, st, d->dy, d->x, d->nstride, kf);
+    else if (group <= 16384) hipLaunchKernelGGL((norm_bwd_fused_kernel<16, 1024>), fg, dim3(1024), 0, st, d->dy, d->x, d->nstride, kf);
+    else hipLaunchKernelGGL(norm_bwd_fused_loop_kernel, fg, dim3(1024), 0, st, d->dy, d->x, d->nstride, kf);
     VTS_CHECK_LAUNCH("vts_norm_bwd fused");
-    vts_set_kernel("norm_bwd_fused_kernel");
+    vts_set_kernel(group <= 16384 ? "norm_bwd_fused_kernel" : "norm_bwd_fused_loop_kernel");
     return VTS_OK;
   }
   if (d->counters && !grouped) {
@@ -557,6 +750,13 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, spl,
                      d->mean, d->rstd, part);
   VTS_CHECK_LAUNCH("vts_norm_bwd partial");
+  static const int three = getenv("VTS_NORM_BWD_3K") ? atoi(getenv("VTS_NORM_BWD_3K")) : 0;   // 1: the separate finalize launch (A/B timing)
+  if (!three) {
+    hipLaunchKernelGGL(norm_bwd_apply_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, part, k);
+    VTS_CHECK_LAUNCH("vts_norm_bwd apply");
+    vts_set_kernel("norm_bwd_partial_kernel+norm_bwd_apply_fin_kernel");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, part, k);
   VTS_CHECK_LAUNCH("vts_norm_bwd finalize");
   hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, coef);
