@@ -552,8 +552,15 @@ struct ReduceTable {
   vts_reduce_job job[RB_JOBS];
 };
 
+// 256 elements per workgroup (round 2; was 64 elements by 1024 threads with one 4-byte load in flight per thread: 43 us per launch):
+// a lane owns four elements -- one 16-byte load per partial copy when the copies are 16-byte aligned (they are whenever nel % 4 == 0:
+// every 4x4 weight tensor), four 4-byte loads otherwise -- the sixteen waves take every sixteenth copy with eight independent
+// accumulators (eight loads in flight per lane: thin layers have ~1000 copies of a few hundred elements, the chain of dependent
+// loads is what bounds them), and everything is combined in a fixed order: pairwise over a0..a7 per wave, then waves 0..15.
+// Deterministic, no float atomics.
+constexpr int RB_ELEMS = 256;
 __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceTable t) {
-  __shared__ float red[16][64];
+  __shared__ f32x4 red[16][64];
   int lo = 0, hi = t.njobs - 1;   // uniform binary search: last job with blk_start <= blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -562,20 +569,46 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceTa
   }
   const vts_reduce_job& j = t.job[lo];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t i = (int64_t)(blockIdx.x - t.blk_start[lo]) * 64 + lane;
-  float s = 0.f;
-  if (i < j.nel)
-    for (int sg = 0; sg < j.nseg; ++sg) {
-      const float* part = j.part[sg];
-      for (int k = w; k < j.pw[sg]; k += 16) s += part[(int64_t)k * j.nel + i];
+  const int64_t base = (int64_t)(blockIdx.x - t.blk_start[lo]) * RB_ELEMS;
+  const bool tail = base + RB_ELEMS > j.nel;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sg = 0; sg < j.nseg; ++sg) {
+    const float* part = j.part[sg];
+    const int pw = j.pw[sg];
+    const bool vec = !tail && (j.nel & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+    f32x4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = w; k < pw; k += 128) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = k + 16 * u;
+        if (kk < pw) {
+          const float* row = part + (int64_t)kk * j.nel + base;
+          f32x4 v;
+          if (vec) {
+            v = *reinterpret_cast<const f32x4*>(row + lane * 4);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (base + lane * 4 + e < j.nel) ? row[lane * 4 + e] : 0.f;
+          }
+          a[u] += v;
+        }
+      }
     }
+    s += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
   red[w][lane] = s;
   __syncthreads();
-  if (w == 0 && i < j.nel) {
-    float v = 0.f;
+  if (w == 0) {
+    f32x4 v = red[0][lane];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v += red[k][lane];
-    j.dw[i] = j.accumulate ? j.dw[i] + v : v;
+    for (int k = 1; k < 16; ++k) v += red[k][lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = base + lane * 4 + e;
+      if (i < j.nel) j.dw[i] = j.accumulate ? j.dw[i] + v[e] : v[e];
+    }
   }
 }
 
@@ -738,7 +771,7 @@ extern "C" int vts_wgrad_reduce_batch(const vts_reduce_job* jobs, int njobs, voi
       for (int sg = 0; sg < q.nseg; ++sg) VTS_CHECK_ARG(q.part[sg] && q.pw[sg] >= 1, "vts_wgrad_reduce_batch: bad segment %d of job %d", sg, j0 + j);
       t.job[j] = q;
       t.blk_start[j] = blocks;
-      blocks += (int)cdiv64(q.nel, 64);
+      blocks += (int)cdiv64(q.nel, RB_ELEMS);
     }
     t.blk_start[t.njobs] = blocks;
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, t);

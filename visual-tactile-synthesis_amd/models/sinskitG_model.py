@@ -333,6 +333,19 @@ class SinSKITGModel(BaseModel):
                 self.real_I.copy_(I)
             self._I2 = I2
             self.full_T_coords = input.get("full_T_coords")
+            # Input pyramid of the multiscale D1 (AvgPool2d(3, 2, 1) per level, networks.py:1670,1692): the sketch and real-image levels
+            # depend on the batch only, so they are pooled here, once; the fake-image rows are pooled once per step (_d1_pyramid) and
+            # serve both the D update and the generator's GAN term (the reference pools all of them again in each of its three D1 calls).
+            self._S2_pyr = self._I2_pyr = None
+            if self._pair and "D" in self.model_names and hasattr(self.netD, "num_D") and not getattr(self.netD, "is_stylegan2_d", False):
+                self._S2_pyr, self._I2_pyr = [S2], [I2]
+                for s in range(1, self.netD.num_D):
+                    hs, ws = (self._S2_pyr[-1].shape[2] - 1) // 2 + 1, (self._S2_pyr[-1].shape[3] - 1) // 2 + 1
+                    Sp = ops.avgpool(self._S2_pyr[-1], y=self._buf("%s_S2_p%d" % (phase, s), (2 * n, 1, hs, ws)))
+                    Ip = self._buf("%s_I2_p%d" % (phase, s), (2 * n, 3, hs, ws))
+                    ops.avgpool(self._I2_pyr[-1][n:], y=Ip[n:])
+                    self._S2_pyr.append(Sp)
+                    self._I2_pyr.append(Ip)
         elif hasattr(self, "real_I"):
             del self.real_I
         self.S_pe = self._spe(n, h, w) if self.pe_channels else None
@@ -511,7 +524,7 @@ class SinSKITGModel(BaseModel):
                 jobs.append((self.netD, [p_fake_I, dict(in0=self.real_S, in1=self.real_I, real=True, coeff=lam, slot=slot["D_real_I"],
                                                         grad_coeff=0.5 * lam, accumulate=True)]))
             else:   # fake | real batched: rows [0, n) / [n, 2n) of the persistent pair buffers
-                p_fake_I = dict(in0=self._S2, in1=self._I2, groups=[
+                p_fake_I = dict(in0=self._S2, in1=self._I2, pyr=self._d1_pyramid(2 * n, pool_fake=True), groups=[
                     dict(n0=0, n1=n, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam),
                     dict(n0=n, n1=2 * n, real=True, coeff=lam, slot=slot["D_real_I"], grad_coeff=0.5 * lam)])
                 jobs.append((self.netD, [p_fake_I]))
@@ -561,6 +574,17 @@ class SinSKITGModel(BaseModel):
         if p_full is not None:
             self.pred_fake_T_full = p_full["preds"][-1]
 
+    def _d1_pyramid(self, rows, pool_fake):
+        """input pyramid of D1 over the first `rows` samples of the pair buffers, or None (engine pools itself).  pool_fake: pool the
+        fake-image rows now (the D update, right after the forward); the generator step reuses those levels."""
+        if getattr(self, "_I2_pyr", None) is None or not self._pair or self.fake_I.data_ptr() != self._I2.data_ptr():
+            return None
+        n = self.real_S.shape[0]
+        if pool_fake:
+            for s in range(1, len(self._I2_pyr)):
+                ops.avgpool(self._I2_pyr[s - 1][:n], y=self._I2_pyr[s][:n])
+        return [(Act(S[:rows]), Act(I[:rows])) for S, I in zip(self._S2_pyr, self._I2_pyr)]
+
     def _seg_g_pre(self):
         """the generator's loss terms that need no discriminator (compute_G1_loss / compute_G2_loss: the L1 terms).  In a data-parallel
         run this segment is what the D / D2 gradient all-reduces travel under."""
@@ -590,7 +614,8 @@ class SinSKITGModel(BaseModel):
             self.optimizer_D.step(self._gscale)
             lam = opt.lambda_G1_GAN
             jobs.append((self.netD, [dict(in0=self.real_S, in1=self.fake_I, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
-                                          param_grads=False, input_grad=(self._d_fake_I, self._have_dI))]))
+                                          param_grads=False, input_grad=(self._d_fake_I, self._have_dI),
+                                          pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False))]))
             self._have_dI = True
         if "D2" in self.model_names:
             self.optimizer_D2.step(self._gscale)

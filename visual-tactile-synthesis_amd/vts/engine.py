@@ -862,7 +862,9 @@ def msd_multi(jobs, criterion):
     jobs: [(D, [pass, ...]), ...]; the passes of one D run in order (BatchNorm running statistics and gradient
     accumulation are order dependent), different D's and different scales are independent lanes.
     pass: dict(in0, in1=None, real: bool, coeff, slot, grad_coeff=None (None: no gradient / no backward),
-               param_grads=True, accumulate=False, input_grad=None, loss=True); `preds` is filled in.
+               param_grads=True, accumulate=False, input_grad=None, loss=True, pyr=None); `preds` is filled in.
+    pyr: [(Act, Act | None)] * num_D, the average-pooled input pyramid when the caller already holds it (the sketch / real-image
+    levels do not change within a step, the fake-image levels are shared by the D update and the G step).
     A pass may BATCH several of the reference's discriminator calls (same weights, same input shape) along the sample axis:
       groups=[dict(n0, n1, real, coeff, slot, grad_coeff), ...]  -- samples [n0, n1) are one reference call: own BatchNorm batch
       statistics and running-statistics update (in list order), own loss term; one backward for all of them.
@@ -910,7 +912,7 @@ def _msd_multi(jobs, criterion):
     lanes = []
     for D, passes in jobs:
         for p in passes:
-            p["_pyr"] = _pyramid(D, p["in0"], p.get("in1"))
+            p["_pyr"] = p.get("pyr") or _pyramid(D, p["in0"], p.get("in1"))   # `pyr`: the caller's precomputed input pyramid
             p["preds"] = [None] * D.num_D
             p["_din"] = [None] * D.num_D
         for s in range(D.num_D):

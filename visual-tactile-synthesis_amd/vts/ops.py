@@ -219,6 +219,10 @@ def wgrad_flush(lane=None):
             j.part[i], j.pw[i] = part.data_ptr(), pw
             nbytes += 4.0 * pw * q["nel"]
         _pending_by_dw.pop(q["dw"].data_ptr(), None)
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "%d jobs %.1f MB partials, copies per job %d..%d" % (len(todo), nbytes / 1e6, min(pw for q in todo for _, pw in q["segs"]),
+                                                                     max(pw for q in todo for _, pw in q["segs"]))
     _run("wgrad_reduce_batch", nbytes, 0.0, L.load().vts_wgrad_reduce_batch, jobs, len(todo), L.stream())
     _pending = [q for q in _pending if not (lane is None or q["lane"] == lane)]
     for (dev, ln), a in _arenas.items():
@@ -689,6 +693,9 @@ def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var
         d.ext_mean, d.ext_uvar, d.ext_after = ext[0].data_ptr(), ext[1].data_ptr(), int(ext[2])
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), x.device)
     d.counters = L.ptr(counters(x.device)) if n * c <= (1 << 16) else None
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "%s N%d %dx%dx%d%s" % ("BN" if mode else "IN", n, c, h, w, " groups %s" % list(groups) if groups else "")
     _run("norm_stats", 4.0 * n * c * h * w, 0.0, lib.vts_norm_stats, C.byref(d), ws.data_ptr(), L.stream())
     return Act(x, st[0], st[1], st[2], st[3])
 
@@ -705,6 +712,9 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
     _set_groups(d, groups, n)
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
     d.counters = L.ptr(counters(dy.device)) if n * c <= (1 << 16) else None
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "%s N%d %dx%dx%d%s" % ("BN" if mode else "IN", n, c, h, w, " groups %s" % list(groups) if groups else "")
     _run("norm_bwd", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
     return dy
 
