@@ -483,6 +483,42 @@ def golden_io():
     print("wrote image_io.npz", {k: v.shape for k, v in out.items()})
 
 
+def friction_inputs(seed=515, h=40, w=56):
+    """seeded stand-ins for the saved outputs the rendering post-processing reads: raw gx / gy arrays in (-1, 1), a uint8 image and mask"""
+    from oracle import detrand
+    gx = (0.4 * detrand.uniform((h, w), seed, "gx")).numpy().astype(np.float64)
+    gy = (0.4 * detrand.uniform((h, w), seed, "gy")).numpy().astype(np.float64)
+    img = ((detrand.uniform((h, w, 3), seed, "I").numpy() + 1) * 127.5).astype(np.uint8)
+    m = np.where(detrand.uniform((h, w), seed, "M").numpy() > -0.5, 255, 127).astype(np.uint8)
+    return gx, gy, img, m
+
+
+def golden_friction():
+    """postprocess_gz of the reference (Step2_Postprocessing_for_Rendering.py:18-140), mappings log10 / exp2, raw-array and PNG inputs"""
+    from PIL import Image
+
+    from oracle import ref_import
+
+    # The upstream script does not import (IndentationError at its line 340, and it needs cv2 / skimage at module level): run the text
+    # of its postprocess_gz function only, read from the reference tree at generation time (nothing of it is kept here).
+    src = open(os.path.join(ref_import.REF_ROOT, "Step2_Postprocessing_for_Rendering.py")).read()
+    body = src[src.index("def postprocess_gz("):src.index("def generate_Tanvas_images(")]
+    ns = {"np": np, "Image": Image}
+    exec(compile(body, "Step2_Postprocessing_for_Rendering.py:postprocess_gz", "exec"), ns)
+    step2 = type("step2", (), {"postprocess_gz": staticmethod(ns["postprocess_gz"])})
+
+    gx, gy, img, m = friction_inputs()
+    out = {}
+    for tag, kw in (("log10_raw", dict(method="log10", use_raw_arr=True)),
+                    ("exp2_png_thr", dict(method="exp2", use_raw_arr=False, thresholding=True, threshold_quantile=0.8, change_bg_color=True, bg_color=(1, 2, 3)))):
+        a, b = (gx, gy) if kw["use_raw_arr"] else (np.round((gx + 1) * 127.5), np.round((gy + 1) * 127.5))
+        res = step2.postprocess_gz(img.copy(), m, a.copy(), b.copy(), Tanvas_width=48, Tanvas_height=32, **kw)
+        for k, v in zip(("gz", "I", "post", "gz_T", "I_T", "post_T"), res):
+            out["%s/%s" % (tag, k)] = v
+    np.savez_compressed(os.path.join(GOLD, "friction.npz"), **out)
+    print("wrote friction.npz", {k: v.shape for k, v in out.items()})
+
+
 def golden_sg2(size=32, seed=808, ndf=8, input_nc=4, n=3):
     """StyleGAN2 blocks: the reference's StyleGAN2Discriminator forward + gradients, upfirdn2d in several
     up / down / pad configurations, fused_leaky_relu, ModulatedConv2d (plain / upsample / downsample) with a style vector."""
@@ -622,3 +658,5 @@ if __name__ == "__main__":
         golden_nets_style()
     if "io" in which:
         golden_io()
+    if "friction" in which:
+        golden_friction()

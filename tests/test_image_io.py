@@ -42,3 +42,61 @@ def test_tensor2im_matches_reference(golden_dir):
     assert np.array_equal(tensor2im(x), g["im_rgb"]) and np.array_equal(tensor2im(x[:, :1]), g["im_gray"])
     assert np.array_equal(tensor2im(x[0, 0]), g["im_2d"])
     assert np.array_equal(tensor2arr(x[:1, :1], imtype=np.float32), g["arr_gray"]) and np.array_equal(tensor2arr(x[:1]), g["arr_rgb"])
+
+
+def test_exr_writer_layout_and_round_trip(tmp_path):
+    """write_exr emits the OpenEXR 2 single-part scanline layout (magic, version 2, the eight required attributes, alphabetical FLOAT
+    channels, one 64-bit offset per scanline, uncompressed rows): the bytes are checked field by field and read back exactly.  (The
+    reference writes these files through skimage.io.imsave, visualizer.py:146; no OpenEXR reader exists in this image to cross-check.)"""
+    import struct
+
+    from util.image_io import read_exr, save_images, write_exr
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((5, 7)).astype(np.float32)
+    rgb = rng.standard_normal((4, 6, 3)).astype(np.float32)
+    py, prgb = str(tmp_path / "y.exr"), str(tmp_path / "rgb.exr")
+    write_exr(py, y)
+    write_exr(prgb, rgb)
+    assert np.array_equal(read_exr(py), y) and np.array_equal(read_exr(prgb), rgb)
+    b = open(prgb, "rb").read()
+    assert b[:4] == bytes([0x76, 0x2F, 0x31, 0x01]) and struct.unpack_from("<i", b, 4)[0] == 2
+    for name in (b"channels\0chlist\0", b"compression\0compression\0", b"dataWindow\0box2i\0", b"displayWindow\0box2i\0", b"lineOrder\0lineOrder\0",
+                 b"pixelAspectRatio\0float\0", b"screenWindowCenter\0v2f\0", b"screenWindowWidth\0float\0"):
+        assert name in b
+    ch = b.index(b"channels\0chlist\0") + len(b"channels\0chlist\0")
+    assert struct.unpack_from("<i", b, ch)[0] == 3 * 18 + 1 and b[ch + 4:ch + 6] == b"B\0" and b[ch + 4 + 18:ch + 6 + 18] == b"G\0"
+    dw = b.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    assert struct.unpack_from("<4i", b, dw) == (0, 0, 5, 3)
+    # offset table -> every chunk starts with its scanline number and byte count; B, G, R rows in that order
+    end = b.index(b"screenWindowWidth\0float\0") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1
+    offs = struct.unpack_from("<4Q", b, end)
+    assert offs[0] == end + 4 * 8 and len(b) == offs[3] + 8 + 4 * 6 * 3
+    for yy, o in enumerate(offs):
+        assert struct.unpack_from("<ii", b, o) == (yy, 4 * 6 * 3)
+        row = np.frombuffer(b, "<f4", 18, o + 8).reshape(3, 6)
+        assert np.array_equal(row[0], rgb[yy, :, 2]) and np.array_equal(row[2], rgb[yy, :, 0])
+    # save_images writes the .exr beside the .npy (save_raw_arr_vis), same array
+    x = torch.linspace(-1.5, 1.5, 20).reshape(1, 1, 4, 5)
+    out = str(tmp_path / "web")
+    os.makedirs(out)
+    save_images(out, {"fake_gx": x}, ["s.png"], save_raw_arr_vis=True)
+    assert np.array_equal(read_exr(os.path.join(out, "fake_gx", "s.exr")), np.load(os.path.join(out, "fake_gx", "s.npy")))
+
+
+def test_friction_map_matches_reference(golden_dir):
+    """postprocess_gz against what the reference's function returned for the same seeded inputs (tests/golden/friction.npz, made by
+    oracle/make_golden.py friction): raw-array inputs + log10, PNG inputs + quantile clipping + exp2 + background recolouring"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle.make_golden import friction_inputs
+    from util.image_io import postprocess_gz
+    g = np.load(os.path.join(golden_dir, "friction.npz"))
+    gx, gy, img, m = friction_inputs()
+    for tag, kw in (("log10_raw", dict(method="log10", use_raw_arr=True)),
+                    ("exp2_png_thr", dict(method="exp2", use_raw_arr=False, thresholding=True, threshold_quantile=0.8, change_bg_color=True, bg_color=(1, 2, 3)))):
+        a, b = (gx, gy) if kw["use_raw_arr"] else (np.round((gx + 1) * 127.5), np.round((gy + 1) * 127.5))
+        res = postprocess_gz(img.copy(), m, a.copy(), b.copy(), Tanvas_width=48, Tanvas_height=32, **kw)
+        for k, v in zip(("gz", "I", "post", "gz_T", "I_T", "post_T"), res):
+            assert v.dtype == np.uint8 and np.array_equal(v, g["%s/%s" % (tag, k)]), (tag, k)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        postprocess_gz(img, m, gx, gy, method="equalize", use_raw_arr=True)

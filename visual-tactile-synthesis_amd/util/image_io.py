@@ -1,11 +1,14 @@
 """Output writers of the inference flow (reference util/visualizer.py:30-148 save_images, util/util.py:58-122 tensor2im / tensor2arr)
 without the HTML page / wandb: per visual a PNG under <image_dir>/<label>/<name>.png, the raw tactile gradients of every 'gx' / 'gy'
 visual in <image_dir>/fake_gxgy_raw/fake_gxgy_raw.npz (what the 3-D reconstruction / rendering post-processing reads), and with
-save_raw_arr_vis the float arrays next to the PNGs as .npy.  The reference's .exr copies need skimage / OpenEXR, which this image does
-not have: they are skipped (the .npy holds the same array)."""
+save_raw_arr_vis the float arrays next to the PNGs as .npy and .exr.  The reference writes the .exr through skimage / imageio
+(visualizer.py:146); neither is in this image, so write_exr below emits the OpenEXR 2 scanline layout itself (uncompressed 32-bit
+float channels: Y for one channel, B/G/R for three) -- the file any OpenEXR reader opens; read_exr reads that subset back (tests).
+postprocess_gz is the friction map of the rendering post-processing (Step2_Postprocessing_for_Rendering.py:18-140)."""
 import json
 import ntpath
 import os
+import struct
 
 import numpy as np
 import torch
@@ -76,4 +79,134 @@ def save_images(image_dir, visuals, image_path, save_raw_gxgy=False, save_raw_ar
             a = tensor2arr(v, imtype=np.float32)
             a = a[0] if a.shape[0] == 1 else (a.transpose(1, 2, 0) if a.shape[0] == 3 else a)
             np.save(path.replace(".png", ".npy"), a)
+            write_exr(path.replace(".png", ".exr"), a)
     return written
+
+
+# ---- OpenEXR 2.0 single-part scanline files, NO_COMPRESSION, FLOAT channels (the subset skimage.io.imsave(..., '.exr') of a float32
+# array needs: visualizer.py:146).  Layout (openexr.com "OpenEXR File Layout"): magic, version, attributes (name\0 type\0 size value)
+# closed by \0, one 64-bit offset per scanline, then per scanline: y, byte count, the row of every channel in alphabetical order.
+_EXR_MAGIC = 20000630
+
+
+def _exr_attr(name, typ, payload):
+    return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+
+
+def write_exr(path, arr):
+    """arr: float array [H, W] (channel Y) or [H, W, 3] (R, G, B)"""
+    a = np.asarray(arr, dtype=np.float32)
+    if a.ndim == 2:
+        planes = {"Y": a}
+    elif a.ndim == 3 and a.shape[2] == 3:
+        planes = {"R": a[:, :, 0], "G": a[:, :, 1], "B": a[:, :, 2]}
+    else:
+        raise ValueError("write_exr: expected [H, W] or [H, W, 3], got %s" % (a.shape,))
+    h, w = a.shape[:2]
+    names = sorted(planes)       # channels are stored in alphabetical order
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for n in names) + b"\0"   # 2 = FLOAT, linear 0, sampling 1 x 1
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    head = struct.pack("<ii", _EXR_MAGIC, 2)
+    head += _exr_attr("channels", "chlist", chlist)
+    head += _exr_attr("compression", "compression", b"\0")
+    head += _exr_attr("dataWindow", "box2i", box)
+    head += _exr_attr("displayWindow", "box2i", box)
+    head += _exr_attr("lineOrder", "lineOrder", b"\0")
+    head += _exr_attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    head += _exr_attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0))
+    head += _exr_attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    head += b"\0"
+    row_bytes = 4 * w * len(names)
+    first = len(head) + 8 * h
+    offsets = struct.pack("<%dQ" % h, *[first + y * (8 + row_bytes) for y in range(h)])
+    rows = np.stack([np.ascontiguousarray(planes[n]) for n in names], axis=1).astype("<f4")   # [H, channel, W]
+    with open(path, "wb") as f:
+        f.write(head)
+        f.write(offsets)
+        for y in range(h):
+            f.write(struct.pack("<ii", y, row_bytes))
+            f.write(rows[y].tobytes())
+
+
+def read_exr(path):
+    """reads the files write_exr writes (uncompressed FLOAT scanlines); returns [H, W] (Y) or [H, W, 3] (R, G, B)"""
+    b = open(path, "rb").read()
+    magic, version = struct.unpack_from("<ii", b, 0)
+    if magic != _EXR_MAGIC or (version & 0xFF) != 2 or version & 0x200:
+        raise ValueError("read_exr: not a single-part scanline OpenEXR 2 file")
+    o, attrs = 8, {}
+    while b[o] != 0:
+        e = b.index(b"\0", o)
+        name = b[o:e].decode()
+        o = e + 1
+        e = b.index(b"\0", o)
+        typ = b[o:e].decode()
+        o = e + 1
+        (size,) = struct.unpack_from("<i", b, o)
+        o += 4
+        attrs[name] = (typ, b[o:o + size])
+        o += size
+    o += 1
+    if attrs["compression"][1] != b"\0":
+        raise ValueError("read_exr: only uncompressed files")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    names, c, q = [], attrs["channels"][1], 0
+    while c[q] != 0:
+        e = c.index(b"\0", q)
+        names.append(c[q:e].decode())
+        (ptype,) = struct.unpack_from("<i", c, e + 1)
+        if ptype != 2:
+            raise ValueError("read_exr: only FLOAT channels")
+        q = e + 1 + 16
+    offs = struct.unpack_from("<%dQ" % h, b, o)
+    planes = {n: np.empty((h, w), np.float32) for n in names}
+    for y in range(h):
+        yy, nbytes = struct.unpack_from("<ii", b, offs[y])
+        row = np.frombuffer(b, "<f4", w * len(names), offs[y] + 8).reshape(len(names), w)
+        for i, n in enumerate(names):
+            planes[n][yy - y0] = row[i]
+    if names == ["Y"]:
+        return planes["Y"]
+    return np.stack([planes["R"], planes["G"], planes["B"]], axis=2)
+
+
+def postprocess_gz(fake_I, M, gx, gy, Tanvas_width=1280, Tanvas_height=800, use_raw_arr=False, thresholding=False, threshold_quantile=0.9,
+                   method="log10", compute_gz=True, gz=None, change_bg_color=False, bg_color=(255, 255, 255)):
+    """Friction map for haptic rendering from the tactile output (Step2_Postprocessing_for_Rendering.py:18-140): gz = gx^2 + gy^2,
+    optional quantile clipping, min-max normalisation, a non-linear mapping ('log10' / 'exp2'), uint8 images and their resized copies
+    for the TanvasTouch screen.  The reference's 'equalize' (OpenCV CLAHE through myutils.equalize_this) and 'dilation' (skimage Sobel +
+    OpenCV morphology) mappings depend on libraries this image does not have and are not built.
+    Returns (gz_im, fake_I_im, gz_postprocess_im, gz_im_Tanvas, fake_I_im_Tanvas, gz_postprocess_im_Tanvas) like the reference."""
+    from PIL import Image
+    if compute_gz:
+        gx, gy = np.asarray(gx, dtype=np.float64), np.asarray(gy, dtype=np.float64)
+        if not use_raw_arr:        # PNG inputs, range (0, 255)
+            gx = gx / 255.0 * 2.0 - 1
+            gy = gy / 255.0 * 2.0 - 1
+        gz = gx ** 2 + gy ** 2
+    elif gz is None:
+        raise ValueError("postprocess_gz: pass gz, or gx and gy with compute_gz=True")
+    else:
+        gz = np.array(gz, dtype=np.float64)
+    if thresholding:
+        t = np.quantile(gz, threshold_quantile)
+        gz[gz > t] = t
+    gz = (gz - np.min(gz)) / (np.max(gz) - np.min(gz))
+    if gz.ndim == 2:
+        gz = np.tile(gz[:, :, None], (1, 1, 3))
+    if method == "log10":
+        post = np.log10(gz * 9.0 + 1.0)      # [0, 1] -> [1, 10] -> log in [0, 1]
+    elif method == "exp2":
+        post = np.exp2(gz * 3.0 - 3.0)       # [0, 1] -> [-3, 0]
+    else:
+        raise NotImplementedError("friction-map mapping '%s' is not built (needs OpenCV / skimage); use 'log10' or 'exp2'" % method)
+    post = (post - post.min()) / (np.max(post) - post.min())
+    gz_im = np.uint8(gz * 255)
+    fake_I_im = np.uint8(fake_I)
+    if change_bg_color:
+        fake_I_im[np.asarray(M) < 255] = bg_color
+    post_im = np.uint8(post * 255)
+    size = (Tanvas_width, Tanvas_height)
+    return (gz_im, fake_I_im, post_im, np.array(Image.fromarray(gz_im).resize(size)), np.array(Image.fromarray(fake_I_im).resize(size)),
+            np.array(Image.fromarray(post_im).resize(size)))
