@@ -664,7 +664,8 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   k.trace = trace_dev;
   if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2)>), grid, dim3(256), 0, st, k);
   else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false>), grid, dim3(256), 0, st, k);
-  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d>%s%s", MODE, S, NR, RW, MT, CK, KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""), run > 1 ? "+run" : "");
+  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d, %s>%s", MODE, S, NR, RW, MT, CK, (run > 1 && NR <= 2) ? "true" : "false",   // as rocprofv3 names the instance
+                 KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
   VTS_CHECK_LAUNCH("vts_conv4x4");
   if (trace_dev) {
     (void)hipStreamSynchronize(st);
