@@ -17,6 +17,8 @@ const float* vts_ident();
 int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st);
 // thin (Cout <= 16) stride-2 transposed layers on full-size maps: direct packed-FMA kernel; VTS_ERR_UNSUPPORTED otherwise
 int vts_conv_thin_try(const vts_conv_desc* d, hipStream_t st);
+// single-output-channel stride-1 layers (PatchGAN prediction heads) on full-size maps: LDS-tiled vector-ALU kernel; VTS_ERR_UNSUPPORTED otherwise
+int vts_conv_head_try(const vts_conv_desc* d, hipStream_t st);
 // PatchNCE on the MFMA path (vts_patchnce.hip): P, D <= 256
 bool vts_patchnce_mfma_ok(int P, int D);
 int vts_patchnce_mfma(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq, hipStream_t st);
