@@ -351,6 +351,14 @@ int vts_metric_ssim(const float* real, const float* fake, int NC, int H, int W, 
 int64_t vts_frechet_ws_floats(void);
 int vts_frechet_distance(const float* feat1, const float* feat2, int D, int64_t P1, int64_t P2, float* out, float* ws, void* stream);
 
+/* Network input of the SIFID metrics (models/model_utils.py:481-488 I_SIFID, :541-555 T_SIFID; InceptionV3.forward's 2x - 1,
+ * models/inception.py:135): out [N,3,OH,OW] from channels c0.. of src [N,*,IH,IW] (C = 3, or C = 1 tiled three times), nearest
+ * resize as F.interpolate's default.  lohi != NULL (device {min, max} of the real image): v -> 2 * clamp?((v - lo) / (hi - lo)) - 1
+ * (clamp01: the fake image's clamp); lohi == NULL: v -> clamp01 ? clamp(v, 0, 1) : v (tactile patches; their normalisation and the
+ * network's 2x - 1 cancel). */
+int vts_sifid_input(const float* src, int64_t nstride, int N, int c0, int C, int IH, int IW, const float* lohi, int clamp01,
+                    float* out, int OH, int OW, void* stream);
+
 /* AvgPool2d(3, stride 2, padding 1, count_include_pad=False) forward / backward
  * (models/networks.py:1670).  Backward accumulates into dx when accumulate != 0. */
 int vts_avgpool3s2(const float* x, int64_t x_nstride, int N, int C, int H, int W, float* y, void* stream);

@@ -642,3 +642,48 @@ def d_param_shapes(input_nc, ndf=8, num_D=3):
                 shapes[b + ".running_var"] = (c,)
                 shapes[b + ".num_batches_tracked"] = ()
     return shapes
+
+
+# ---- SIFID chain (models/sifid.py:38-101, 156-233; models/inception.py:57-67, 113-147; models/model_utils.py:481-488, 541-555) -------
+def inception_block0(x, sd):
+    """the reference's InceptionV3(output_blocks=[0]) forward AFTER its `2 * x - 1` on a state dict with the wrapper's keys
+    (blocks.0.k.conv.weight / bn.*): three torchvision BasicConv2d = Conv2d(3x3, bias=False) -> BatchNorm2d(eval, eps 0.001) -> ReLU with
+    (stride, padding) = (2, 0), (1, 0), (1, 1).  torchvision is absent from this image: this restates its published layer definition
+    (parity unpinned for that third-party architecture; the statistics / Frechet arithmetic behind it IS pinned, tests/golden/metrics.npz)"""
+    import torch.nn.functional as F
+    for k, (stride, pad) in enumerate(((2, 0), (1, 0), (1, 1))):
+        pre = "blocks.0.%d." % k
+        x = F.conv2d(x, sd[pre + "conv.weight"], None, stride=stride, padding=pad)
+        x = F.batch_norm(x, sd[pre + "bn.running_mean"], sd[pre + "bn.running_var"], sd[pre + "bn.weight"], sd[pre + "bn.bias"], False, 0.0, 0.001)
+        x = F.relu(x)
+    return x
+
+
+def sifid_pairs(a, b, sd):
+    """calculate_sifid_given_arrays (sifid.py:205-233) on network inputs a, b [N,3,H,W]: per image, activations = positions x 64
+    (get_activations :96), mean / np.cov, Frechet distance"""
+    out = []
+    for i in range(a.shape[0]):
+        fa, fb = inception_block0(a[i:i + 1], sd)[0], inception_block0(b[i:i + 1], sd)[0]
+        out.append(frechet_distance(fa.reshape(fa.shape[0], -1), fb.reshape(fb.shape[0], -1)))
+    return out
+
+
+def sifid_images(real_I, fake_I, sd):
+    """I_SIFID (model_utils.py:481-488)"""
+    lo, hi = real_I.min(), real_I.max()
+    r = (real_I - lo) / (hi - lo)
+    f = torch.clamp((fake_I - lo) / (hi - lo), 0, 1)
+    v = sifid_pairs(2 * r - 1, 2 * f - 1, sd)
+    return v[0] if len(v) == 1 else float(np.mean(v))
+
+
+def sifid_tactile(real_T, fake_T, sd, size=299):
+    """T_SIFID (model_utils.py:519, 541-555); convert2tensor's (x + 1) / 2 and the network's 2x - 1 cancel"""
+    import torch.nn.functional as F
+    fake_T = torch.clamp(fake_T, 0, 1)
+    r, f = F.interpolate(real_T, (size, size)), F.interpolate(fake_T, (size, size))
+    vals = []
+    for c in (0, 1):
+        vals.append(np.array(sifid_pairs(r[:, c:c + 1].repeat(1, 3, 1, 1), f[:, c:c + 1].repeat(1, 3, 1, 1), sd)))
+    return float(np.mean((vals[0] + vals[1]) / 2))

@@ -424,3 +424,16 @@ def test_patchsample_and_patchnce_at_reference_size(golden_dir):
         dq, = torch.autograd.grad(loss.sum(), q)
         _close(loss.detach().numpy(), g["nce_loss_%d" % allneg], rtol=1e-5, atol=1e-5)
         _close(dq[::8, ::4].numpy(), g["nce_dq_sub_%d" % allneg], rtol=1e-4, atol=1e-6)
+
+
+def test_sifid_chain_matches_reference_glue(golden_dir):
+    """oracle.nets.sifid_images / sifid_tactile against the values the REFERENCE's compute_evaluation_metric -> calculate_sifid_given_arrays
+    chain produced for the same seeded inputs (tests/golden/sifid.npz; the network object was the only stand-in, see
+    oracle/make_golden.py:golden_sifid)"""
+    from models import inception
+    from oracle.make_golden import sifid_inputs
+    g = np.load(os.path.join(golden_dir, "sifid.npz"))
+    sd = inception.InceptionBlock0().state_dict()
+    real_I, fake_I, real_T, fake_T = sifid_inputs(int(g["seed"]))
+    assert abs(nets.sifid_images(real_I, fake_I, sd) - float(g["I_SIFID"])) <= 1e-6 * abs(float(g["I_SIFID"]))
+    assert abs(nets.sifid_tactile(real_T, fake_T, sd) - float(g["T_SIFID"])) <= 1e-6 * abs(float(g["T_SIFID"]))

@@ -328,6 +328,54 @@ def test_eval_metrics_match_oracle():
     assert set(model.get_current_metrics().keys()) == {"m_I_PSNR", "m_T_AE", "m_T_MSE", "m_I_SSIM"}
 
 
+def test_sifid_chain_matches_oracle_and_reference_golden(golden_dir, monkeypatch):
+    """I_SIFID / T_SIFID on the HIP path (vts_sifid_input, Inception block 0 on the conv kernels, device Frechet distance) vs (i) the
+    values the REFERENCE's compute_evaluation_metric chain produced for the same seeded inputs and stand-in weights
+    (tests/golden/sifid.npz), (ii) the oracle on a second input set, feature maps included, (iii) through the model's compute_metrics"""
+    from data.synthetic_dataset import make_sample
+    from models import inception
+    from oracle.make_golden import sifid_inputs
+    from vts import engine, ops
+    dev = torch.device("cuda:0")
+    net = inception.InceptionBlock0()
+    sd = net.state_dict()
+    net = net.to(dev)
+    g = np.load(os.path.join(golden_dir, "sifid.npz"))
+    real_I, fake_I, real_T, fake_T = sifid_inputs(int(g["seed"]))
+    got_i = float(engine.sifid_images(net, real_I.to(dev), fake_I.to(dev)))
+    got_t = float(engine.sifid_tactile(net, real_T.to(dev), fake_T.to(dev)))
+    assert abs(got_i - float(g["I_SIFID"])) <= 2e-3 * abs(float(g["I_SIFID"])), (got_i, float(g["I_SIFID"]))
+    assert abs(got_t - float(g["T_SIFID"])) <= 2e-3 * abs(float(g["T_SIFID"])), (got_t, float(g["T_SIFID"]))
+    # feature maps and the input preparation against the oracle (odd sizes, two images)
+    x = detrand.uniform((2, 3, 75, 101), 31, "x")
+    f = engine.inception_block0(net, x.to(dev))
+    ref = nets.inception_block0(x, sd)
+    assert f.shape == ref.shape and rel(f, ref) < 1e-5
+    lohi = ops.minmax(x.to(dev))
+    prep = ops.sifid_input((1.2 * x).to(dev), 0, 3, lohi=lohi, clamp01=True)
+    assert rel(prep, 2 * torch.clamp((1.2 * x - x.min()) / (x.max() - x.min()), 0, 1) - 1) < 1e-6
+    t = detrand.uniform((3, 2, 32, 32), 32, "t")
+    up = ops.sifid_input(t.to(dev), 1, 1, size=(299, 299), clamp01=True)
+    want = torch.nn.functional.interpolate(torch.clamp(t[:, 1:2], 0, 1), (299, 299)).repeat(1, 3, 1, 1)
+    assert torch.equal(up.cpu(), want)
+    # through the model: the two names appear beside the four weight-free metrics
+    monkeypatch.setenv("VTS_SIFID", "1")
+    model, opt = make_model(256, 1)
+    sdG, _, _ = load_test_weights(model, 13)
+    batch = default_collate([make_sample(256, 16, 24, 13)])
+    model.set_input(batch, phase="val")
+    model.test()
+    m = model.compute_metrics()
+    fi, ft = step.inference(sdG, batch)
+    ox, oy, _ = nets.find_coords_for_patch(batch["val_T_coords"][0])
+    fake_T_concat = nets.gather_patches(ft, ox, oy, 32)
+    real_T_val = batch["val_T_images"][0].float() * batch["val_I_masks"][0].float()[:, None]
+    inp = step.prepare_input(batch)
+    assert abs(m["I_SIFID"] - nets.sifid_images(inp.real_I, fi, sd)) <= 5e-3 * abs(m["I_SIFID"]) + 1e-6
+    assert abs(m["T_SIFID"] - nets.sifid_tactile(real_T_val, fake_T_concat, sd)) <= 5e-3 * abs(m["T_SIFID"]) + 1e-6
+    assert {"m_I_SIFID", "m_T_SIFID"} <= set(model.get_current_metrics().keys()) and model.metric_sifid_pretrained is False
+
+
 def test_style_code_generator_matches_reference_golden(golden_dir):
     """the skitG generator (CustomUnetGenerator + style code, the network of the headline configuration) on the HIP engine vs the
     REFERENCE module run on CPU (tests/golden/nets_style_256.npz): outputs and every parameter gradient"""

@@ -362,3 +362,38 @@ extern "C" int vts_frechet_distance(const float* feat1, const float* feat2, int 
   VTS_CHECK_LAUNCH("vts_frechet_distance");
   return VTS_OK;
 }
+
+
+// ---- SIFID input preparation (models/model_utils.py:481-488 for images, :541-549 for tactile patches): three-channel network
+// input from C = 3 channels (or one channel tiled three times) of `src`, optional {lo, hi} min-max normalisation to (0, 1) with the
+// fake image's clamp, optional clamp to (0, 1) of raw values, nearest-neighbour resize (F.interpolate default: source index =
+// floor(dst * in / out) in float, as PyTorch's legacy nearest), and the 2x - 1 scaling of InceptionV3.forward (models/inception.py:135).
+namespace {
+__global__ __launch_bounds__(256) void sifid_input_kernel(const float* __restrict__ src, int64_t nstride, int c0, int C, int IH, int IW,
+                                                          const float* __restrict__ lohi, int clamp01, float* __restrict__ out, int OH, int OW) {
+  const int n = blockIdx.z, k = blockIdx.y;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= OH * OW) return;
+  const int y = o / OW, x = o - y * OW;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  const int iy = min((int)floorf((float)y * sy), IH - 1), ix = min((int)floorf((float)x * sx), IW - 1);
+  float v = src[n * nstride + (int64_t)(c0 + (C == 1 ? 0 : k)) * IH * IW + (int64_t)iy * IW + ix];
+  if (lohi) {
+    v = (v - lohi[0]) / (lohi[1] - lohi[0]);
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    v = 2.f * v - 1.f;
+  } else if (clamp01) {
+    v = fminf(fmaxf(v, 0.f), 1.f);
+  }
+  out[((int64_t)n * 3 + k) * OH * OW + o] = v;
+}
+}  // namespace
+
+extern "C" int vts_sifid_input(const float* src, int64_t nstride, int N, int c0, int C, int IH, int IW, const float* lohi, int clamp01,
+                               float* out, int OH, int OW, void* stream) {
+  VTS_CHECK_ARG(src && out && N >= 1 && (C == 1 || C == 3) && c0 >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1, "vts_sifid_input: bad args");
+  hipLaunchKernelGGL(sifid_input_kernel, dim3((unsigned)cdiv64((int64_t)OH * OW, 256), 3, N), dim3(256), 0, (hipStream_t)stream, src, nstride, c0, C,
+                     IH, IW, lohi, clamp01, out, OH, OW);
+  VTS_CHECK_LAUNCH("vts_sifid_input");
+  return VTS_OK;
+}

@@ -81,6 +81,9 @@ class SinSKITGModel(BaseModel):
         cls.add_extra_flags(parser)
         # not a reference flag: replay the training step from captured HIP graphs (after one eager step)
         parser.add_argument("--use_hip_graph", type=B, default=True)
+        # not a reference flag: state dict of torchvision's Inception-v3 (or pytorch-fid's) for the I_SIFID / T_SIFID metrics; the
+        # reference downloads it (models/inception.py:58), which cannot happen offline
+        parser.add_argument("--inception_weights", type=str, default="")
         parser.set_defaults(model=cls.MODEL_NAME, dataset_mode=cls.DATASET_MODE, netG="unet256_custom", netD="multiscale",
                             netD2="multiscale", gan_mode="nonsaturating", ngf=10, ndf=8, lr=0.001, beta1=0.0, beta2=0.99,
                             crop_size=1536, no_flip=True, dataroot=cls.DATAROOT, data_len=cls.DATA_LEN)
@@ -737,11 +740,21 @@ class SinSKITGModel(BaseModel):
     # ------------------------------------------------------------------ evaluation metrics
     METRICS = ("I_PSNR", "T_AE", "T_MSE", "I_SSIM")
 
+    def _sifid_net(self):
+        """Inception block 0 for I_SIFID / T_SIFID, or None: built when --inception_weights (a torchvision / pytorch-fid state dict) is
+        given, or with VTS_SIFID=1 on the seeded stand-in weights (values then only compare builds on the same seed)."""
+        if not hasattr(self, "_inception"):
+            self._inception = None
+            if getattr(self.opt, "inception_weights", "") or os.environ.get("VTS_SIFID", "0") == "1":
+                from . import inception
+                self._inception = inception.build(self.opt, self.device)
+        return self._inception
+
     def compute_metrics(self, prefix=""):
-        """The evaluation metrics that need no pretrained network (reference: compute_evaluation_metric,
-        models/model_utils.py:431-561, called from compute_visuals sinskitG_model.py:889-925) for the current outputs:
-        I_PSNR, I_SSIM, T_AE, T_MSE on the validation patches (the training patches with prefix 'train_').  I_SIFID / *_LPIPS /
-        T_SIFID need Inception / VGG / AlexNet weights and are not built."""
+        """Evaluation metrics of the current outputs (reference: compute_evaluation_metric, models/model_utils.py:431-561, called from
+        compute_visuals sinskitG_model.py:889-925): I_PSNR, I_SSIM, T_AE, T_MSE on the validation patches (the training patches with
+        prefix 'train_'), and I_SIFID / T_SIFID when an Inception block is available (_sifid_net).  *_LPIPS need VGG / AlexNet weights
+        and are not built."""
         pset = self.train_set if prefix == "train_" else self.val_set
         if pset is None or not hasattr(self, "real_I") or self.test_edit_S:
             return {}
@@ -749,11 +762,18 @@ class SinSKITGModel(BaseModel):
         fake_T_concat = torch.empty(P, 2, 32, 32, device=self.device)
         self._gather(self.fake_T, pset, fake_T_concat, 0, channels=2)
         vals = ops.eval_metrics(self.real_I, self.fake_I, pset["real_T"], fake_T_concat).cpu().tolist()
-        for name, v in zip(self.METRICS, vals):
+        names = list(self.METRICS)
+        net = self._sifid_net()
+        if net is not None:
+            names += ["I_SIFID", "T_SIFID"]
+            vals += [float(engine.sifid_images(net, self.real_I.contiguous(), self.fake_I.contiguous())),
+                     float(engine.sifid_tactile(net, pset["real_T"], fake_T_concat))]
+            self.metric_sifid_pretrained = bool(net.pretrained)
+        for name, v in zip(names, vals):
             setattr(self, "metric_%s%s" % (prefix, name), v)
             if prefix + name not in self.metric_names:
                 self.metric_names.append(prefix + name)
-        return {prefix + n: v for n, v in zip(self.METRICS, vals)}
+        return {prefix + n: v for n, v in zip(names, vals)}
 
     # ------------------------------------------------------------------ logging
     def get_current_losses(self):

@@ -1132,3 +1132,60 @@ def modulated_conv2d(x, style, weight, mod_weight, mod_bias, demodulate=True, do
         return out
     demod = ops.modconv_demod(wt, s.view(n, ci), scale)
     return ops.pad_affine(Act(out, demod.view(-1), _const(n * co, 0.0, x.device)), (0, 0, 0, 0), 0)
+
+
+# ======================================================================================================================
+# SIFID (reference models/sifid.py:205-233, models/inception.py:57-67, models/model_utils.py:481-488, 541-555): Inception-v3 block 0
+# on the convolution kernels of this library + the Frechet distance of the activation statistics, per image
+# ======================================================================================================================
+def inception_block0(net, x):
+    """x [N,3,H,W] (network input, i.e. after InceptionV3.forward's 2x - 1) -> [N,64,h,w] features.  BatchNorm (eval, eps 0.001) and
+    ReLU of a layer are applied by the next convolution on load; the last layer's are materialised."""
+    n, dev = x.shape[0], x.device
+    cur, act = x, 0
+    for m, (ci, co, stride, pad) in zip(net.blocks[0], _INCEPTION_SPEC):
+        h, w = (cur.data if isinstance(cur, Act) else cur).shape[2:]
+        oh, ow = (h + 2 * pad - 3) // stride + 1, (w + 2 * pad - 3) // stride + 1
+        out = _empty(n, co, oh, ow, dev)
+        if stride == 2:
+            ops.convk_s2(cur, m.conv.weight, out, act_in=act)
+        else:
+            ops.convk(cur, m.conv.weight, out, pad=pad, act_in=act)
+        sc = m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)      # [C] vectors: plumbing, not arithmetic on activations
+        sh = m.bn.bias - m.bn.running_mean * sc
+        cur, act = Act(out, sc.repeat(n).contiguous(), sh.repeat(n).contiguous()), RELU
+    return ops.pad_affine(cur, (0, 0, 0, 0), 0, act=RELU)
+
+
+_INCEPTION_SPEC = ((3, 32, 2, 0), (32, 32, 1, 0), (32, 64, 1, 1))   # (cin, cout, stride, padding): torchvision's Conv2d_1a / 2a / 2b
+
+
+def sifid_pairs(net, a, b, batch=16):
+    """per-image SIFID of two stacks of network inputs [N,3,H,W] (calculate_sifid_given_arrays: the statistics are taken over the
+    positions of ONE image's feature map): device tensor [N]"""
+    n = a.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=a.device)
+    for i0 in range(0, n, batch):
+        fa, fb = inception_block0(net, a[i0:i0 + batch]), inception_block0(net, b[i0:i0 + batch])
+        for j in range(fa.shape[0]):
+            out[i0 + j:i0 + j + 1].copy_(ops.frechet_distance(fa[j].reshape(fa.shape[1], -1), fb[j].reshape(fb.shape[1], -1)))
+    return out
+
+
+def sifid_images(net, real_I, fake_I):
+    """I_SIFID (model_utils.py:481-488): both images min-max normalised by the REAL image's range, the fake one clamped; mean over images"""
+    lohi = ops.minmax(real_I)
+    a = ops.sifid_input(real_I, 0, 3, lohi=lohi)
+    b = ops.sifid_input(fake_I, 0, 3, lohi=lohi, clamp01=True)
+    return sifid_pairs(net, a, b, batch=1).mean()
+
+
+def sifid_tactile(net, real_T, fake_T, size=299):
+    """T_SIFID (model_utils.py:541-555): fake patches clamped to (0, 1) (:519), nearest resize to 299 x 299, gx and gy each tiled to
+    three channels, per-patch SIFID, mean of (gx + gy) / 2"""
+    vals = []
+    for c in (0, 1):
+        a = ops.sifid_input(real_T, c, 1, size=(size, size))
+        b = ops.sifid_input(fake_T, c, 1, size=(size, size), clamp01=True)
+        vals.append(sifid_pairs(net, a, b))
+    return ((vals[0] + vals[1]) * 0.5).mean()

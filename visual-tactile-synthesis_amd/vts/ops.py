@@ -875,6 +875,28 @@ def frechet_distance(f1, f2):
     return out
 
 
+def minmax(x):
+    """device tensor {min x, max x}"""
+    lib = L.load()
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.vts_metric_ws_floats(), x.device)
+    L.check(lib.vts_minmax(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), L.stream()), "vts_minmax")
+    return out
+
+
+def sifid_input(src, c0, channels, size=None, lohi=None, clamp01=False):
+    """[N,3,OH,OW] network input of the SIFID metrics from channels c0.. of src (3 channels, or 1 tiled three times): optional min-max
+    normalisation by the device pair lohi (+ clamp), optional clamp of raw values, nearest resize to `size` (include/vts.h)"""
+    lib = L.load()
+    n, _, h, w = src.shape
+    assert src.stride(1) == h * w and src.stride(3) == 1
+    oh, ow = size if size else (h, w)
+    out = torch.empty(n, 3, oh, ow, dtype=torch.float32, device=src.device)
+    L.check(lib.vts_sifid_input(src.data_ptr(), src.stride(0), n, c0, channels, h, w, L.ptr(lohi), int(clamp01), out.data_ptr(), oh, ow,
+                                L.stream()), "vts_sifid_input")
+    return out
+
+
 def adam_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     lib = L.load()
     L.check(lib.vts_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, step, grad_scale,
