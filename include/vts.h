@@ -324,6 +324,13 @@ int vts_bias_act_bwd(const float* g, const float* x, const float* bias, int N, i
                      void* stream);
 int vts_modconv_demod(const float* w, const float* s, int N, int Cout, int Cin, int KK, float scale, float eps, float* demod,
                       void* stream);
+/* Style-free ModulatedConv2d weight of the StyleGAN2 generator's StyledConv layers (style = None -> s = 1, stylegan_networks.py:307-317,
+ * 399-407): wout[co,ci,k] = v d[co], v = scale w, d[co] = rsqrt(sum_{ci,k} v^2 + eps); transpose != 0 stores [Ci,Co,KK] (the weight of
+ * the stride-2 convolution whose input adjoint is the upsampling transposed convolution :320-330).  _bwd: dw (+)= scale (d g - d^3 v sum(g v))
+ * for g = dL/dwout in the same layout. */
+int vts_modconv_weight(const float* w, int Cout, int Cin, int KK, float scale, float eps, int transpose, float* wout, void* stream);
+int vts_modconv_weight_bwd(const float* w, const float* g, int Cout, int Cin, int KK, float scale, float eps, int transpose, float* dw,
+                           int accumulate, void* stream);
 
 /* ---- Evaluation metrics that need no pretrained network (models/model_utils.py:431-561 compute_evaluation_metric) ----
  * vts_minmax:          out2 = {min x, max x}

@@ -615,6 +615,43 @@ def golden_sg2(size=32, seed=808, ndf=8, input_nc=4, n=3):
     print("wrote stylegan2_%d.npz (%d entries)" % (size, len(out)))
 
 
+SG2G_CFG = dict(ngf=2, size=32, n_blocks=2, num_downsampling=2)
+
+
+def golden_sg2g(seed=909, input_nc=4, n=2):
+    """StyleGAN2Generator of the reference (`--netG smallstylegan2`: encoder + decoder without noise injection, stylegan_networks.py:
+    800-930) on CPU with seeded weights: output, input gradient, every parameter gradient.  Its ModulatedConv2d builds the style-free
+    modulation with `.cuda()` (:310); Tensor.cuda is made a no-op for this run -- nothing else is touched."""
+    import argparse
+
+    from oracle import detrand, ref_import, stylegan2 as sg
+
+    ref_import.load()
+    from models import stylegan_networks as R
+
+    cfg = SG2G_CFG
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        opt = argparse.Namespace(load_size=cfg["size"], crop_size=cfg["size"], stylegan2_G_num_downsampling=cfg["num_downsampling"], netG="smallstylegan2")
+        G = R.StyleGAN2Generator(input_nc, 3, ngf=cfg["ngf"], n_blocks=cfg["n_blocks"], opt=opt)
+        shapes = sg.g_param_shapes(input_nc, **cfg)
+        assert {k: tuple(v.shape) for k, v in G.named_parameters()} == shapes, "StyleGAN2 G key/shape mismatch"
+        G.load_state_dict(sg.test_weights(shapes, seed), strict=False)
+        x = detrand.uniform((n, input_nc, cfg["size"], cfg["size"]), seed, "g_in").requires_grad_(True)
+        y = G(x)
+        (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    finally:
+        torch.Tensor.cuda = cuda
+    out = {"seed": seed, "input_nc": input_nc, "n": n, "ref_keys": np.array(sorted(G.state_dict().keys())), "G_out": y.detach().numpy(),
+           "G_dx_sub": x.grad[:, :, ::4, ::4].numpy(), "G_dx_probe": detrand.probe(x.grad, "g_dx")}
+    for k, p in G.named_parameters():
+        if p.grad is not None:
+            out["G_grad/" + k] = detrand.probe(p.grad, k)
+    np.savez_compressed(os.path.join(GOLD, "stylegan2_g_32.npz"), **out)
+    print("wrote stylegan2_g_32.npz (%d entries)" % len(out))
+
+
 def golden_step(size=256, seed=202, steps=2, nt=64):
     """Full SinSKITGModel.optimize_parameters x `steps` on one synthetic sample (BASELINE config 0)."""
     from oracle import detrand, nets, ref_import
@@ -706,3 +743,5 @@ if __name__ == "__main__":
         golden_friction()
     if "sifid" in which:
         golden_sifid()
+    if "sg2g" in which:
+        golden_sg2g()

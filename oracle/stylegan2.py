@@ -181,3 +181,106 @@ def modulated_conv2d(x, style, weight, mod_weight, mod_bias, demodulate=True, up
         return out.view(n, co, out.shape[2], out.shape[3])
     out = F.conv2d(x.reshape(1, n * ci, h, w), wgt.view(n * co, ci, k, k), padding=k // 2, groups=n)
     return out.view(n, co, out.shape[2], out.shape[3])
+
+
+
+# ---- generator side (stylegan_networks.py:351-407, 800-930) -------------------------------------------------------------------------
+def g_channels(ngf):
+    """stylegan_networks.py:805-816"""
+    m = ngf / 32
+    return {4: min(512, int(round(4096 * m))), 8: min(512, int(round(2048 * m))), 16: min(512, int(round(1024 * m))),
+            32: min(512, int(round(512 * m))), 64: int(round(256 * m)), 128: int(round(128 * m)), 256: int(round(64 * m)),
+            512: int(round(32 * m)), 1024: int(round(16 * m))}
+
+
+def styled_conv_up(sd, prefix, x, noise=None):
+    """StyledConv(upsample=True).forward with style None (:399-407): ModulatedConv2d with s = 1 (the reference builds the ones tensor
+    with .cuda(), :309-310), Blur(kernel * 4, pad (1, 1)), optional NoiseInjection (:351-363), FusedLeakyReLU"""
+    w = sd[prefix + "conv.weight"]
+    n, ci = x.shape[0], x.shape[1]
+    out = modulated_conv2d_nostyle_up(x, w)
+    if noise is not None:
+        out = out + sd[prefix + "noise.weight"] * noise
+    return fused_leaky_relu(out, sd[prefix + "activate.bias"])
+
+
+def modulated_conv2d_nostyle_up(x, weight):
+    n, ci, h, w = x.shape
+    _, co, _, k, _ = weight.shape
+    wgt = (1.0 / math.sqrt(ci * k * k)) * weight * torch.ones(n, 1, ci, 1, 1)
+    wgt = wgt * torch.rsqrt(wgt.pow(2).sum([2, 3, 4]) + 1e-8).view(n, co, 1, 1, 1)
+    p = (4 - 2) - (k - 1)
+    wt = wgt.transpose(1, 2).reshape(n * ci, co, k, k)
+    out = F.conv_transpose2d(x.reshape(1, n * ci, h, w), wt, padding=0, stride=2, groups=n)
+    out = out.view(n, co, out.shape[2], out.shape[3])
+    return upfirdn2d(out, make_kernel() * 4, pad=((p + 1) // 2 + 1, p // 2 + 1))
+
+
+def g_layout(ngf, size, n_blocks, num_downsampling):
+    """(encoder entries, decoder entries): ('conv', cin, cout, k) | ('res', cin, cout, downsample) | ('up', cin, cout)"""
+    ch = g_channels(ngf)
+    res = 2 ** int(round(math.log2(size)))
+    enc, dec = [], []
+    for _ in range(num_downsampling):
+        enc.append(("res", ch[res], ch[res // 2], True))
+        res //= 2
+    for _ in range(n_blocks // 2):
+        enc.append(("res", ch[res], ch[res], False))
+    for _ in range(n_blocks // 2):
+        dec.append(("res", ch[res], ch[res], False))
+    for _ in range(num_downsampling):
+        dec.append(("up", ch[res], ch[res * 2]))
+        res *= 2
+    return ch[2 ** int(round(math.log2(size)))], enc, dec, ch[res]
+
+
+def g_param_shapes(input_nc, ngf, size, n_blocks, num_downsampling):
+    """learnable parameters of StyleGAN2Generator, reference key names (probe: state_dict of the reference module)"""
+    c0, enc, dec, clast = g_layout(ngf, size, n_blocks, num_downsampling)
+    shapes = {"encoder.convs.1.0.weight": (c0, input_nc, 1, 1), "encoder.convs.1.1.bias": (1, c0, 1, 1)}
+
+    def res(p, cin, cout, down):
+        i = 1 if down else 0
+        shapes[p + "conv1.0.weight"] = (cin, cin, 3, 3)
+        shapes[p + "conv1.1.bias"] = (1, cin, 1, 1)
+        shapes[p + "conv2.%d.weight" % i] = (cout, cin, 3, 3)
+        shapes[p + "conv2.%d.bias" % (i + 1)] = (1, cout, 1, 1)
+        if down or cin != cout:
+            shapes[p + "skip.%d.weight" % i] = (cout, cin, 1, 1)
+
+    for j, (_, cin, cout, down) in enumerate(enc):
+        res("encoder.convs.%d." % (j + 2), cin, cout, down)
+    for j, e in enumerate(dec):
+        p = "decoder.convs.%d." % j
+        if e[0] == "res":
+            res(p, e[1], e[2], e[3])
+        else:
+            shapes[p + "conv.weight"] = (1, e[2], e[1], 3, 3)
+            shapes[p + "noise.weight"] = (1,)
+            shapes[p + "activate.bias"] = (1, e[2], 1, 1)
+    p = "decoder.convs.%d." % len(dec)
+    shapes[p + "0.weight"] = (3, clast, 1, 1)
+    shapes[p + "1.bias"] = (1, 3, 1, 1)
+    return shapes
+
+
+def generator_forward(sd, x, ngf, size, n_blocks, num_downsampling, noises=None):
+    """StyleGAN2Generator.forward (:922-930) = encoder (:838-851) then decoder (:897-912)"""
+    sd = dict(sd)
+    _, enc, dec, _ = g_layout(ngf, size, n_blocks, num_downsampling)
+    k = make_kernel()
+    out = conv_layer(sd, "encoder.convs.1.", x, 1)
+    for j, (_, cin, cout, down) in enumerate(enc):
+        p = "encoder.convs.%d." % (j + 2)
+        sd.setdefault(p + "conv2.0.kernel", k)
+        sd.setdefault(p + "skip.0.kernel", k)
+        out = res_block(sd, p, out, downsample=down, has_skip=down or cin != cout)
+    u = 0
+    for j, e in enumerate(dec):
+        p = "decoder.convs.%d." % j
+        if e[0] == "res":
+            out = res_block(sd, p, out, downsample=False, has_skip=e[1] != e[2])
+        else:
+            out = styled_conv_up(sd, p, out, None if noises is None else noises[u])
+            u += 1
+    return conv_layer(sd, "decoder.convs.%d." % len(dec), out, 1)

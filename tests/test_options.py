@@ -90,3 +90,20 @@ def test_rank_device_comes_from_local_rank(monkeypatch):
     monkeypatch.setattr(torch.cuda, "set_device", lambda i: chosen.append(i))
     opt = parse(TrainOptions, "--model skitG --gpu_ids 0 --dataset_mode synthetic --checkpoints_dir /tmp/vts_opt")
     assert opt.gpu_ids == [5] and chosen == [5]
+
+
+def test_define_G_builds_the_stylegan2_generators_with_reference_keys():
+    """networks.define_G(netG='smallstylegan2' | 'stylegan2') (reference networks.py:297-300): parameter container with the reference's
+    state-dict keys (the list the reference module reported is in tests/golden/stylegan2_g_32.npz); CPU-safe (no compute)"""
+    import argparse
+    import os
+
+    import numpy as np
+
+    from models import networks
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stylegan2_g_32.npz"))
+    opt = argparse.Namespace(load_size=32, crop_size=32, stylegan2_G_num_downsampling=2)
+    small = networks.define_G(4, 3, 2, "smallstylegan2", opt=opt)
+    assert sorted(small.state_dict().keys()) == sorted(g["ref_keys"].tolist()) and small.inject_noise is False and small.n_blocks == 2
+    full = networks.define_G(4, 3, 2, "stylegan2", opt=opt)
+    assert full.inject_noise is True and full.n_blocks == 6 and len(full.decoder.convs) == 3 + 2 + 1

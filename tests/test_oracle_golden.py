@@ -437,3 +437,22 @@ def test_sifid_chain_matches_reference_glue(golden_dir):
     real_I, fake_I, real_T, fake_T = sifid_inputs(int(g["seed"]))
     assert abs(nets.sifid_images(real_I, fake_I, sd) - float(g["I_SIFID"])) <= 1e-6 * abs(float(g["I_SIFID"]))
     assert abs(nets.sifid_tactile(real_T, fake_T, sd) - float(g["T_SIFID"])) <= 1e-6 * abs(float(g["T_SIFID"]))
+
+
+def test_stylegan2_generator_oracle_matches_reference(golden_dir):
+    """oracle.stylegan2.generator_forward (+ autograd) vs the reference's StyleGAN2Generator run on CPU (tests/golden/stylegan2_g_32.npz)"""
+    from oracle import stylegan2 as sg
+    from oracle.make_golden import SG2G_CFG as cfg
+    g = np.load(os.path.join(golden_dir, "stylegan2_g_32.npz"))
+    seed, cin, n = int(g["seed"]), int(g["input_nc"]), int(g["n"])
+    shapes = sg.g_param_shapes(cin, **cfg)
+    sd = {k: v.requires_grad_(True) for k, v in sg.test_weights(shapes, seed).items()}
+    x = detrand.uniform((n, cin, cfg["size"], cfg["size"]), seed, "g_in").requires_grad_(True)
+    y = sg.generator_forward(sd, x, **cfg)
+    assert np.abs(y.detach().numpy() - g["G_out"]).max() <= 1e-5 * np.abs(g["G_out"]).max()
+    (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+    assert np.allclose(x.grad[:, :, ::4, ::4].numpy(), g["G_dx_sub"], rtol=1e-3, atol=1e-5 * np.abs(g["G_dx_sub"]).max())
+    for k, v in sd.items():
+        if "G_grad/" + k in g.files:
+            p, rp = detrand.probe(v.grad, k), g["G_grad/" + k]
+            assert abs(p[1] - rp[1]) <= 2e-4 * max(abs(rp[1]), 1e-12), (k, p, rp)

@@ -258,3 +258,61 @@ def test_train_step_with_stylegan2_discriminator_matches_reference_golden(golden
             pr, rp = detrand.probe(p.grad.cpu(), k), g["grad_%s/%s" % (nm, k)]
             scale = max(abs(rp[1]), 1e-12)
             assert abs(pr[1] - rp[1]) <= 2e-3 * scale and abs(pr[2] - rp[2]) <= 8e-3 * scale, (nm, k, pr, rp)
+
+
+def test_stylegan2_generator_matches_reference_and_oracle(golden_dir):
+    """`--netG smallstylegan2` (StyleGAN2Encoder + StyleGAN2Decoder: ConvLayer, ResBlocks with and without downsampling, StyledConv with
+    the upsampling ModulatedConv2d and its demodulation backward) on the HIP engine: output, input gradient and every parameter gradient
+    vs the REFERENCE module run on CPU (tests/golden/stylegan2_g_32.npz) and vs the oracle; then the noise-injecting variant (`stylegan2`)
+    against the oracle with the noise draws passed in."""
+    import os
+
+    import numpy as np
+
+    from models.stylegan2_blocks import StyleGAN2Generator
+    from oracle.make_golden import SG2G_CFG as cfg
+    from vts import engine
+    from vts.optim import FlatParams
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "stylegan2_g_32.npz"))
+    seed, cin, n = int(g["seed"]), int(g["input_nc"]), int(g["n"])
+    shapes = sg.g_param_shapes(cin, **cfg)
+    for noise in (False, True):
+        G = StyleGAN2Generator(cin, 3, ngf=cfg["ngf"], n_blocks=cfg["n_blocks"], size=cfg["size"], num_downsampling=cfg["num_downsampling"],
+                               inject_noise=noise).to(dev)
+        assert {k: tuple(v.shape) for k, v in G.named_parameters()} == shapes
+        assert sorted(G.state_dict().keys()) == sorted(g["ref_keys"].tolist())          # checkpoint compatible with the reference
+        flat = FlatParams(G)
+        sd = sg.test_weights(shapes, seed)
+        G.load_state_dict(sd, strict=False)
+        x = detrand.uniform((n, cin, cfg["size"], cfg["size"]), seed, "g_in")
+        noises = None
+        if noise:
+            noises = [detrand.uniform((n, 1, cfg["size"] >> (cfg["num_downsampling"] - 1 - i), cfg["size"] >> (cfg["num_downsampling"] - 1 - i)), seed, "nz%d" % i)
+                      for i in range(cfg["num_downsampling"])]
+        y, ctx = engine.sg2g_forward(G, x.to(dev), noises=None if noises is None else [t.to(dev) for t in noises])
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xo = x.clone().requires_grad_(True)
+        yo = sg.generator_forward(sdo, xo, noises=noises, **cfg)
+        assert rel(y, yo) < 2e-5
+        cot = detrand.uniform(tuple(yo.shape), seed, "g_cot")
+        (yo * cot).sum().backward()
+        flat.grad.zero_()
+        dx = engine.sg2g_backward(G, ctx, cot.to(dev), input_grad=True)
+        assert rel(dx, xo.grad) < 2e-4
+        named = dict(G.named_parameters())
+        for k, v in sdo.items():
+            if k.endswith("noise.weight") and not noise:
+                continue
+            assert rel(named[k].grad, v.grad) < 3e-4, (k, rel(named[k].grad, v.grad))
+        if not noise:      # the reference's own numbers
+            assert rel(y, torch.from_numpy(g["G_out"])) < 2e-5
+            assert rel(dx[:, :, ::4, ::4], torch.from_numpy(g["G_dx_sub"])) < 2e-4
+            for k in sdo:
+                if "G_grad/" + k in g.files and not k.endswith("noise.weight"):
+                    p, rp = detrand.probe(named[k].grad.cpu(), k), g["G_grad/" + k]
+                    assert abs(p[1] - rp[1]) <= 5e-4 * max(abs(rp[1]), 1e-12), (k, p, rp)
+            engine.sg2g_backward(G, ctx, cot.to(dev), accumulate=True)     # a second backward doubles the gradients
+            for k, v in sdo.items():
+                if not k.endswith("noise.weight"):
+                    assert rel(named[k].grad, 2 * v.grad) < 3e-4, k

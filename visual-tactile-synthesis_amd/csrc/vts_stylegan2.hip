@@ -106,6 +106,52 @@ __global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ w,
   if (threadIdx.x == 0) demod[n * Cout + co] = rsqrtf(scale * scale * acc + eps);
 }
 
+// Style-free ModulatedConv2d weight (StyleGAN2Decoder's StyledConv layers call the convolution with style = None, i.e. s = 1:
+// stylegan_networks.py:307-317): wout = v * d[co], v = scale * w, d[co] = rsqrt(sum_{ci,k} v^2 + eps); `transpose` writes
+// [Ci, Co, KK] (the conv-layout weight whose input adjoint is the upsampling transposed convolution, :320-330).  One workgroup per co.
+__global__ __launch_bounds__(256) void modw_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, float scale, float eps, int transpose,
+                                                    float* __restrict__ wout) {
+  __shared__ float red[16];
+  const int co = blockIdx.x;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < Cin * KK; e += 256) {
+    const float v = scale * w[(int64_t)co * Cin * KK + e];
+    acc += v * v;
+  }
+  const float d = rsqrtf(block_sum(acc, red) + eps);
+  for (int e = threadIdx.x; e < Cin * KK; e += 256) {
+    const int ci = e / KK, k = e - ci * KK;
+    const float v = scale * w[(int64_t)co * Cin * KK + e] * d;
+    wout[transpose ? ((int64_t)ci * Cout + co) * KK + k : (int64_t)co * Cin * KK + e] = v;
+  }
+}
+
+// gradient through it: with G = dL/dwout, S[co] = sum_{ci,k} G v:  dL/dw = scale * (d G - d^3 v S)
+__global__ __launch_bounds__(256) void modw_bwd_kernel(const float* __restrict__ w, const float* __restrict__ g, int Cout, int Cin, int KK, float scale,
+                                                        float eps, int transpose, float* __restrict__ dw, int accumulate) {
+  __shared__ float red[16];
+  const int co = blockIdx.x;
+  float q = 0.f, sgv = 0.f;
+  for (int e = threadIdx.x; e < Cin * KK; e += 256) {
+    const int ci = e / KK, k = e - ci * KK;
+    const float v = scale * w[(int64_t)co * Cin * KK + e];
+    const float gv = g[transpose ? ((int64_t)ci * Cout + co) * KK + k : (int64_t)co * Cin * KK + e];
+    q += v * v;
+    sgv += gv * v;
+  }
+  q = block_sum(q, red);
+  sgv = block_sum(sgv, red);
+  const float d = rsqrtf(q + eps), d3 = d * d * d;
+  for (int e = threadIdx.x; e < Cin * KK; e += 256) {
+    const int ci = e / KK, k = e - ci * KK;
+    const int64_t i = (int64_t)co * Cin * KK + e;
+    const float v = scale * w[i];
+    const float gv = g[transpose ? ((int64_t)ci * Cout + co) * KK + k : i];
+    const float r = scale * (d * gv - d3 * v * sgv);
+    dw[i] = accumulate ? dw[i] + r : r;
+  }
+}
+
 int ufd_fill(UfdK& p, const char* who, const float* in, int64_t NC, int IH, int IW, const float* kernel, int KH, int KW, int up, int down,
              int px0, int px1, int py0, int py1, float* out, int accumulate) {
   VTS_CHECK_ARG(in && out && kernel && NC >= 1 && IH >= 1 && IW >= 1 && KH >= 1 && KW >= 1 && KH * KW <= 64 && up >= 1 && down >= 1,
@@ -162,6 +208,21 @@ extern "C" int vts_bias_act_bwd(const float* g, const float* x, const float* bia
   hipLaunchKernelGGL(bias_act_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, g, x, bias, total, C, (int)HW,
                      slope, gain, dx);
   VTS_CHECK_LAUNCH("vts_bias_act_bwd");
+  return VTS_OK;
+}
+
+extern "C" int vts_modconv_weight(const float* w, int Cout, int Cin, int KK, float scale, float eps, int transpose, float* wout, void* stream) {
+  VTS_CHECK_ARG(w && wout && Cout >= 1 && Cin >= 1 && KK >= 1, "vts_modconv_weight: bad args");
+  hipLaunchKernelGGL(modw_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, KK, scale, eps, transpose, wout);
+  VTS_CHECK_LAUNCH("vts_modconv_weight");
+  return VTS_OK;
+}
+
+extern "C" int vts_modconv_weight_bwd(const float* w, const float* g, int Cout, int Cin, int KK, float scale, float eps, int transpose, float* dw,
+                                      int accumulate, void* stream) {
+  VTS_CHECK_ARG(w && g && dw && Cout >= 1 && Cin >= 1 && KK >= 1, "vts_modconv_weight_bwd: bad args");
+  hipLaunchKernelGGL(modw_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, g, Cout, Cin, KK, scale, eps, transpose, dw, accumulate);
+  VTS_CHECK_LAUNCH("vts_modconv_weight_bwd");
   return VTS_OK;
 }
 

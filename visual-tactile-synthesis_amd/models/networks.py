@@ -405,8 +405,19 @@ def init_net(net, init_type="normal", init_gain=0.02, gpu_ids=(), initialize_wei
 def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, init_type="normal", init_gain=0.02,
              no_antialias=False, no_antialias_up=False, gpu_ids=(), opt=None, generate_T_imgs=False, num_layer_separate=0):
     resnet_blocks = {"resnet_9blocks": 9, "resnet_6blocks": 6, "resnet_4blocks": 4}
+    if netG in ("stylegan2", "smallstylegan2"):
+        # networks.py:297-300: StyleGAN2Generator(n_blocks 6 | 2); noise injection unless 'small' is in the name (stylegan_networks.py:886);
+        # no init_weights for StyleGAN2 nets (:325).  The module emits THREE channels whatever output_nc is (:892).
+        import math
+
+        from .stylegan2_blocks import StyleGAN2Generator
+        size = 2 ** int(round(math.log2(min(opt.load_size, opt.crop_size))))            # stylegan_networks.py:820
+        net = StyleGAN2Generator(input_nc, output_nc, ngf, n_blocks=2 if netG == "smallstylegan2" else 6, size=size,
+                                 num_downsampling=getattr(opt, "stylegan2_G_num_downsampling", 1), inject_noise="small" not in netG)
+        return init_net(net, init_type, init_gain, gpu_ids, initialize_weights=False)
     if netG not in resnet_blocks and netG not in ("unet256_custom", "global", "local"):
-        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom, resnet_{4,6,9}blocks, global, local)" % netG)
+        raise NotImplementedError("Generator model name [%s] is not recognized (built: unet256_custom, resnet_{4,6,9}blocks, global, local, "
+                                  "stylegan2, smallstylegan2)" % netG)
     if netG == "local":    # pix2pixHD LocalEnhancer (networks.py:311-313)
         if norm not in ("batch", "instance"):
             raise NotImplementedError("local enhancer: norm %s is not built" % norm)

@@ -151,6 +151,12 @@ class SinSKITGModel(BaseModel):
         if opt.use_positional_encoding and opt.positional_encoding_mode != "spe":
             raise NotImplementedError("positional_encoding_mode %s is not built" % opt.positional_encoding_mode)
         input_nc = opt.sketch_nc + self.pe_channels
+        if opt.netG in ("stylegan2", "smallstylegan2"):
+            # the reference's StyleGAN2Decoder ends in ConvLayer(.., 3, 1) (stylegan_networks.py:892): three output channels cannot
+            # feed this model's 3 + 2 channel split (the reference fails the same way at sinskitG_model.py:1309-1319); the generator
+            # itself is built and tested as a network (networks.define_G, engine.sg2g_forward / sg2g_backward)
+            raise NotImplementedError("--netG %s emits 3 channels (reference stylegan_networks.py:892); %s needs image_nc + touch_nc = %d"
+                                      % (opt.netG, self.MODEL_NAME, opt.image_nc + opt.touch_nc))
         self.netG = networks.define_G(input_nc, opt.image_nc + opt.touch_nc, opt.ngf, opt.netG, opt.normG, not opt.no_dropout,
                                       opt.init_type, opt.init_gain, opt.no_antialias, opt.no_antialias_up, self.gpu_ids, opt,
                                       num_layer_separate=opt.num_layer_separate)

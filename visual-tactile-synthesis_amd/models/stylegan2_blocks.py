@@ -55,11 +55,12 @@ class ConvLayer(nn.Module):
 
 
 class ResBlock(nn.Module):
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, downsample=True):
         super().__init__()
         self.conv1 = ConvLayer(cin, cin, 3)
-        self.conv2 = ConvLayer(cin, cout, 3, downsample=True)
-        self.skip = ConvLayer(cin, cout, 1, downsample=True, activate=False, bias=False)
+        self.conv2 = ConvLayer(cin, cout, 3, downsample=downsample)
+        # stylegan_networks.py:679-684: a 1x1 skip convolution only when the shape changes, nn.Identity otherwise
+        self.skip = ConvLayer(cin, cout, 1, downsample=downsample, activate=False, bias=False) if (cin != cout or downsample) else None
 
 
 class _Linear(nn.Module):
@@ -95,3 +96,66 @@ class StyleGAN2Discriminator(nn.Module):
     def forward(self, x):
         from vts import engine
         return engine.sg2d_forward(self, x, keep=False)[0]
+
+
+
+# ---- generator side (`--netG stylegan2 | smallstylegan2`, stylegan_networks.py:800-930): parameter containers with the reference's keys
+# (encoder.convs.N.*, decoder.convs.N.{conv.weight, conv.blur.kernel, noise.weight, activate.bias}); arithmetic in vts/engine.py
+# (sg2g_forward / sg2g_backward).
+class StyledConvUp(nn.Module):
+    """StyledConv(cin, cout, 3, upsample=True) :378-407 as the decoder uses it (style = None)"""
+
+    def __init__(self, cin, cout, inject_noise):
+        super().__init__()
+        self.cin, self.cout, self.inject_noise = cin, cout, inject_noise
+        self.conv = _Holder()
+        self.conv.weight = nn.Parameter(torch.randn(1, cout, cin, 3, 3))
+        self.conv.blur = _Holder()
+        self.conv.blur.register_buffer("kernel", make_kernel() * 4)
+        self.noise = _Holder()
+        self.noise.weight = nn.Parameter(torch.zeros(1))
+        self.activate = _Holder()
+        self.activate.bias = nn.Parameter(torch.zeros(1, cout, 1, 1))
+
+
+def g_channels(ngf):
+    """stylegan_networks.py:805-816"""
+    m = ngf / 32
+    return {4: min(512, int(round(4096 * m))), 8: min(512, int(round(2048 * m))), 16: min(512, int(round(1024 * m))),
+            32: min(512, int(round(512 * m))), 64: int(round(256 * m)), 128: int(round(128 * m)), 256: int(round(64 * m)),
+            512: int(round(32 * m)), 1024: int(round(16 * m))}
+
+
+class _Convs(nn.Module):
+    def __init__(self, convs):
+        super().__init__()
+        self.convs = nn.Sequential(*convs)
+
+
+class StyleGAN2Generator(nn.Module):
+    """StyleGAN2Generator :915-930 = StyleGAN2Encoder :800-851 (Identity, ConvLayer 1x1, ResBlock(down) x num_downsampling, ResBlock x
+    n_blocks / 2) + StyleGAN2Decoder :854-912 (ResBlock x n_blocks / 2, StyledConv(up) x num_downsampling, ConvLayer -> 3 channels).
+    The reference emits THREE channels whatever output_nc says (:892)."""
+    is_stylegan2_g = True
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_blocks=6, size=256, num_downsampling=1, inject_noise=True):
+        super().__init__()
+        ch = g_channels(ngf)
+        res = 2 ** int(round(math.log2(size)))
+        self.n_blocks, self.num_downsampling, self.inject_noise = n_blocks, num_downsampling, inject_noise
+        enc = [nn.Identity(), ConvLayer(input_nc, ch[res], 1)]
+        for _ in range(num_downsampling):
+            enc.append(ResBlock(ch[res], ch[res // 2], downsample=True))
+            res //= 2
+        for _ in range(n_blocks // 2):
+            enc.append(ResBlock(ch[res], ch[res], downsample=False))
+        dec = [ResBlock(ch[res], ch[res], downsample=False) for _ in range(n_blocks // 2)]
+        for _ in range(num_downsampling):
+            dec.append(StyledConvUp(ch[res], ch[res * 2], inject_noise))
+            res *= 2
+        dec.append(ConvLayer(ch[res], 3, 1))
+        self.encoder, self.decoder = _Convs(enc), _Convs(dec)
+
+    def forward(self, x):
+        from vts import engine
+        return engine.sg2g_forward(self, x, keep=False)[0]

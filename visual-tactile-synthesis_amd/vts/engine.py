@@ -1134,6 +1134,116 @@ def modulated_conv2d(x, style, weight, mod_weight, mod_bias, demodulate=True, do
     return ops.pad_affine(Act(out, demod.view(-1), _const(n * co, 0.0, x.device)), (0, 0, 0, 0), 0)
 
 
+# ---- generator side (`--netG stylegan2 | smallstylegan2`; reference stylegan_networks.py:800-930) ------------------------------------
+def _sg_resblock_forward(blk, y):
+    """ResBlock :671-693 with skip_gain 1: (conv2(conv1(x)) + skip(x)) / sqrt 2; the 1 / sqrt 2 rides on conv2's activation gain and on
+    the skip operand (identity skip: one scaled copy)"""
+    y1, s1 = _sg_layer_forward(blk.conv1, y)
+    if blk.skip is not None:
+        sk, ss = _sg_layer_forward(blk.skip, y, extra_scale=1.0 / SQRT2)
+    else:
+        sk, ss = ops.pad_affine(_scaled(y, 1.0 / SQRT2), (0, 0, 0, 0), 0), None
+    out, s2 = _sg_layer_forward(blk.conv2, y1, gain=1.0, res=sk)
+    return out, (tuple(y.shape), s1, tuple(y1.shape), s2, ss)
+
+
+def _sg_resblock_backward(blk, saved, g, accumulate, pg=True):
+    x_shape, s1, y1_shape, s2, ss = saved
+    dy1 = _sg_layer_backward(blk.conv2, y1_shape, s2, g, 1.0, accumulate, param_grads=pg)
+    if blk.skip is not None:
+        dx = _sg_layer_backward(blk.skip, x_shape, ss, g, 1.0, accumulate, param_grads=pg)
+    else:
+        dx = ops.pad_affine(_scaled(g, 1.0 / SQRT2), (0, 0, 0, 0), 0)
+    return _sg_layer_backward(blk.conv1, x_shape, s1, dy1, SQRT2, accumulate, dx=dx, dx_accumulate=True, param_grads=pg)
+
+
+def _k4():
+    from models.stylegan2_blocks import BLUR_KERNEL
+    return [[4.0 * v for v in row] for row in BLUR_KERNEL]
+
+
+def _styled_up_forward(m, x, noise=None):
+    """StyledConv(upsample=True) with style None (:399-407 -> ModulatedConv2d :304-330 -> Blur -> NoiseInjection -> FusedLeakyReLU):
+    the demodulated weight depends on the parameters only (vts_modconv_weight); the transposed stride-2 convolution is the input
+    adjoint of the stride-2 K x K convolution the library already has (ops.convk_s2_bwd_data), then Blur with the 4x kernel, pad (1, 1)."""
+    n, ci, h, w = x.shape
+    wt = ops.modconv_weight(m.conv.weight, transpose=True)            # [Ci, Co, 3, 3]
+    pre = _empty(n, m.cout, 2 * h + 1, 2 * w + 1, x.device)
+    ops.convk_s2_bwd_data(x, wt, pre)
+    z = ops.upfirdn2d(pre, _k4(), pad=(1, 1))
+    if m.inject_noise:
+        # image + weight * noise (:358-363); the reference draws fresh N(0, 1) noise per call -- the draw is an input here (tests pass it)
+        if noise is None:
+            noise = torch.randn(n, 1, z.shape[2], z.shape[3], device=x.device)
+        z = ops.pad_affine(z, (0, 0, 0, 0), 0, res=(noise * m.noise.weight).expand(-1, m.cout, -1, -1).contiguous())
+    y = ops.bias_act(z, m.activate.bias, 0.2, SQRT2)
+    return y, (x, wt, z, noise)
+
+
+def _styled_up_backward(m, saved, g, accumulate, pg=True, want_dx=True):
+    x, wt, z, noise = saved
+    dz = ops.bias_act_bwd(g, z, m.activate.bias, 0.2, SQRT2)
+    n, co = dz.shape[0], dz.shape[1]
+    if pg:
+        ops.channel_sum(dz, m.activate.bias.grad.view(-1), accumulate=accumulate)
+        if m.inject_noise:
+            gw = (dz.sum(1, keepdim=True) * noise).sum().view(1)       # one scalar parameter: d weight = <dz summed over channels, noise>
+            m.noise.weight.grad.copy_(m.noise.weight.grad + gw if accumulate else gw)
+    dpre = _empty(n, co, 2 * x.shape[2] + 1, 2 * x.shape[3] + 1, x.device)
+    ops.upfirdn2d_bwd(dz, dpre, _k4(), pad=(1, 1))
+    if pg:
+        dwt = torch.empty_like(wt)
+        ops.wgradk_s2(x, dpre, dwt)                                    # weight gradient of the stride-2 convolution pairing (dpre -> x)
+        ops.modconv_weight_bwd(m.conv.weight, dwt, m.conv.weight.grad, transpose=True, accumulate=accumulate)
+    if not want_dx:
+        return None
+    dx = torch.empty_like(x)
+    ops.convk_s2(dpre, wt, dx)
+    return dx
+
+
+class Sg2gCtx:
+    __slots__ = ("x_shape", "first", "enc", "dec", "ups", "last")
+
+
+def sg2g_forward(G, x, keep=True, noises=None):
+    """StyleGAN2Generator.forward (:922-930): encoder -> decoder.  x [N, C, size, size] -> ([N, 3, size, size], ctx)"""
+    ctx = Sg2gCtx()
+    ctx.x_shape = tuple(x.shape)
+    enc, dec = list(G.encoder.convs), list(G.decoder.convs)
+    y, ctx.first = _sg_layer_forward(enc[1], x)
+    ctx.enc, ctx.dec, ctx.ups = [], [], []
+    for blk in enc[2:]:
+        y, sv = _sg_resblock_forward(blk, y)
+        ctx.enc.append(sv)
+    nb = G.n_blocks // 2
+    for blk in dec[:nb]:
+        y, sv = _sg_resblock_forward(blk, y)
+        ctx.dec.append(sv)
+    for i, m in enumerate(dec[nb:-1]):
+        y, sv = _styled_up_forward(m, y, None if noises is None else noises[i])
+        ctx.ups.append(sv)
+    shape = tuple(y.shape)
+    out, sv = _sg_layer_forward(dec[-1], y)
+    ctx.last = (shape, sv)
+    return out, (ctx if keep else None)
+
+
+def sg2g_backward(G, ctx, dout, accumulate=False, input_grad=False):
+    """gradients of all parameters into .grad; returns d/dx when input_grad"""
+    enc, dec = list(G.encoder.convs), list(G.decoder.convs)
+    nb = G.n_blocks // 2
+    shape, sv = ctx.last
+    g = _sg_layer_backward(dec[-1], shape, sv, dout, SQRT2, accumulate)
+    for m, sv in zip(reversed(dec[nb:-1]), reversed(ctx.ups)):
+        g = _styled_up_backward(m, sv, g, accumulate)
+    for blk, sv in zip(reversed(dec[:nb]), reversed(ctx.dec)):
+        g = _sg_resblock_backward(blk, sv, g, accumulate)
+    for blk, sv in zip(reversed(enc[2:]), reversed(ctx.enc)):
+        g = _sg_resblock_backward(blk, sv, g, accumulate)
+    return _sg_layer_backward(enc[1], ctx.x_shape, ctx.first, g, SQRT2, accumulate, want_dx=input_grad)
+
+
 # ======================================================================================================================
 # SIFID (reference models/sifid.py:205-233, models/inception.py:57-67, models/model_utils.py:481-488, 541-555): Inception-v3 block 0
 # on the convolution kernels of this library + the Frechet distance of the activation statistics, per image

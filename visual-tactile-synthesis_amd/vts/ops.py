@@ -451,6 +451,25 @@ def bias_act_bwd(g, x, bias, slope=0.2, gain=2.0 ** 0.5, dx=None):
     return dx
 
 
+def modconv_weight(w, transpose=False, eps=1e-8):
+    """style-free demodulated weight of ModulatedConv2d (stylegan_networks.py:307-317 with style None): w [1,Co,Ci,K,K] -> [Co,Ci,K,K],
+    or [Ci,Co,K,K] with transpose (include/vts.h)"""
+    co, ci, k = w.shape[-4], w.shape[-3], w.shape[-1]
+    out = torch.empty((ci, co, k, k) if transpose else (co, ci, k, k), dtype=torch.float32, device=w.device)
+    L.check(L.load().vts_modconv_weight(w.data_ptr(), co, ci, k * k, 1.0 / (ci * k * k) ** 0.5, eps, int(transpose), out.data_ptr(), L.stream()),
+            "vts_modconv_weight")
+    return out
+
+
+def modconv_weight_bwd(w, g, dw, transpose=False, accumulate=False, eps=1e-8):
+    """dw (+)= gradient w.r.t. the raw weight given g = dL/d(modconv_weight(w, transpose))"""
+    co, ci, k = w.shape[-4], w.shape[-3], w.shape[-1]
+    assert g.is_contiguous() and dw.is_contiguous() and g.numel() == w.numel() == dw.numel()
+    L.check(L.load().vts_modconv_weight_bwd(w.data_ptr(), g.data_ptr(), co, ci, k * k, 1.0 / (ci * k * k) ** 0.5, eps, int(transpose), dw.data_ptr(),
+                                            int(accumulate), L.stream()), "vts_modconv_weight_bwd")
+    return dw
+
+
 def modconv_demod(w, s, scale, eps=1e-8):
     """demod [N, Co] of ModulatedConv2d (stylegan_networks.py:311-317); w [Co,Ci,K,K] (or [1,Co,Ci,K,K]), s [N,Ci]"""
     co, ci, kk = w.shape[-4], w.shape[-3], w.shape[-1] * w.shape[-2]
