@@ -2,8 +2,11 @@
 // (:38-76, used by Blur :140-156 in front of every stride-2 EqualConv2d and behind the transposed ModulatedConv2d),
 // the fused bias + LeakyReLU + gain (:18-35) with an optional residual add (ResBlock's (out + skip) / sqrt 2, :686-693) and
 // its derivative, and the demodulation coefficients of ModulatedConv2d (:311-317).  All of these are HBM-bound elementwise /
-// short-FIR passes: one thread per output element, rows of a plane on consecutive lanes, no LDS needed (the 4 x 4 FIR window of
-// neighbouring lanes overlaps in L1 / the texture cache; algorithmic bytes = 4 (in + out) per element).
+// short-FIR passes (algorithmic bytes = 4 (in + out) per element).  Blur -- upfirdn2d with up = down = 1, every use in the networks of
+// this path -- and its adjoint run on an LDS-tiled kernel (ufd_tile_kernel: a 16 x 64 output tile per workgroup, the haloed input
+// tile staged once with the zero padding resolved, four outputs per thread from 16-byte LDS reads; the role the reference's CUDA
+// upfirdn2d plays, thirdparty/stylegan2_ada/torch_utils/ops/upfirdn2d.cu).  The general up / down form keeps the one-thread-per-output
+// gather (Upsample / Downsample modules: not used by the networks built here).
 // The convolutions of the blocks run on the conv kernels of this library with the equalised-learning-rate scale folded into the
 // operand affine (normalise-on-load), see vts/engine.py:sg2d_forward.
 #include "vts_internal.h"
@@ -45,6 +48,47 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UfdK p) {
     }
   }
   p.out[i] = p.accumulate ? p.out[i] + acc : acc;
+}
+
+// up = down = 1 (Blur) and its adjoint: out[oy, ox] = sum k[ky][kx] * in[oy + ky - py0, ox + kx - px0], zero outside the input.
+// Workgroup = 16 x 64 outputs of one plane; LDS tile (16 + KH - 1) x (64 + KW - 1), row pitch 72 (16-byte aligned rows).
+constexpr int UT_Y = 16, UT_X = 64, UT_PITCH = 72, UT_MAXK = 8;
+__global__ __launch_bounds__(256) void ufd_tile_kernel(const UfdK p) {
+  __shared__ __attribute__((aligned(16))) float tile[(UT_Y + UT_MAXK - 1) * UT_PITCH];
+  const int tid = threadIdx.x;
+  const int64_t nc = blockIdx.z;
+  const int oy0 = blockIdx.y * UT_Y, ox0 = blockIdx.x * UT_X;
+  const int rows = UT_Y + p.KH - 1, cols = UT_X + p.KW - 1;
+  const float* src = p.in + nc * p.IH * p.IW;
+  for (int e = tid; e < rows * UT_PITCH; e += 256) {
+    const int r = e / UT_PITCH, c = e - r * UT_PITCH;
+    const int iy = oy0 + r - p.py0, ix = ox0 + c - p.px0;
+    tile[e] = (c < cols && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) ? src[(int64_t)iy * p.IW + ix] : 0.f;
+  }
+  __syncthreads();
+  const int tx = (tid & 15) * 4, ty = tid >> 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ky = 0; ky < p.KH; ++ky) {
+    const float* row = tile + (ty + ky) * UT_PITCH + tx;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row), b = *reinterpret_cast<const f32x4*>(row + 4), c = *reinterpret_cast<const f32x4*>(row + 8);
+    const float v[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+    for (int kx = 0; kx < UT_MAXK; ++kx) {
+      if (kx < p.KW) {
+        const float w = p.k[ky * p.KW + kx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, v[j + kx], acc[j]);
+      }
+    }
+  }
+  const int oy = oy0 + ty;
+  if (oy >= p.OH) return;
+  float* o = p.out + (nc * p.OH + oy) * p.OW;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ox = ox0 + tx + j;
+    if (ox < p.OW) o[ox] = p.accumulate ? o[ox] + acc[j] : acc[j];
+  }
 }
 
 // adjoint: din[nc, iy, ix] = sum_{ky,kx} k[ky][kx] * dout[nc, oy, ox]  with  oy*down + ky - py0 = iy*up  (gather: deterministic)
@@ -175,7 +219,10 @@ extern "C" int vts_upfirdn2d(const float* in, int64_t NC, int IH, int IW, const 
   const int rc = ufd_fill(p, "vts_upfirdn2d", in, NC, IH, IW, kernel, KH, KW, up, down, px0, px1, py0, py1, out, accumulate);
   if (rc != VTS_OK) return rc;
   p.in = in; p.out = out;
-  hipLaunchKernelGGL(upfirdn2d_kernel, dim3((unsigned)cdiv64(NC * p.OH * p.OW, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  if (up == 1 && down == 1 && KH <= UT_MAXK && KW <= UT_MAXK && NC <= 65535)   // Blur: LDS-tiled
+    hipLaunchKernelGGL(ufd_tile_kernel, dim3(cdiv(p.OW, UT_X), cdiv(p.OH, UT_Y), (unsigned)NC), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3((unsigned)cdiv64(NC * p.OH * p.OW, 256)), dim3(256), 0, (hipStream_t)stream, p);
   VTS_CHECK_LAUNCH("vts_upfirdn2d");
   return VTS_OK;
 }
@@ -186,6 +233,17 @@ extern "C" int vts_upfirdn2d_bwd(const float* dout, int64_t NC, int IH, int IW, 
   const int rc = ufd_fill(p, "vts_upfirdn2d_bwd", dout, NC, IH, IW, kernel, KH, KW, up, down, px0, px1, py0, py1, din, accumulate);
   if (rc != VTS_OK) return rc;
   p.in = dout; p.out = din;
+  if (up == 1 && down == 1 && KH <= UT_MAXK && KW <= UT_MAXK && NC <= 65535) {
+    // the adjoint of a correlation is the correlation with the point-reflected taps and the complementary padding: same tiled kernel
+    UfdK q = p;
+    q.IH = p.OH; q.IW = p.OW; q.OH = IH; q.OW = IW;
+    q.py0 = KH - 1 - p.py0; q.px0 = KW - 1 - p.px0;
+    for (int a = 0; a < KH; ++a)
+      for (int b = 0; b < KW; ++b) q.k[a * KW + b] = p.k[(KH - 1 - a) * KW + (KW - 1 - b)];
+    hipLaunchKernelGGL(ufd_tile_kernel, dim3(cdiv(IW, UT_X), cdiv(IH, UT_Y), (unsigned)NC), dim3(256), 0, (hipStream_t)stream, q);
+    VTS_CHECK_LAUNCH("vts_upfirdn2d_bwd");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(upfirdn2d_adj_kernel, dim3((unsigned)cdiv64(NC * IH * IW, 256)), dim3(256), 0, (hipStream_t)stream, p);
   VTS_CHECK_LAUNCH("vts_upfirdn2d_bwd");
   return VTS_OK;
