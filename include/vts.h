@@ -332,6 +332,13 @@ int vts_modconv_weight(const float* w, int Cout, int Cin, int KK, float scale, f
 int vts_modconv_weight_bwd(const float* w, const float* g, int Cout, int Cin, int KK, float scale, float eps, int transpose, float* dw,
                            int accumulate, void* stream);
 
+/* Adaptive instance normalisation of the style-code conditioning (thirdparty/AdaIN/function.py:4-23; CustomUnetGenerator.forward with
+ * --style_code_mode adain, models/networks.py:1624-1630): per (n, c) group of HW positions
+ *   out = (x - mean x) / std x * std s + mean s,  std = sqrt(unbiased variance + eps), eps = 1e-5 upstream.
+ * x, s, out (and g, dx, ds of the backward) are [NC, HW] contiguous; the backward writes both operand gradients. */
+int vts_adain(const float* x, const float* s, int NC, int HW, float eps, float* out, void* stream);
+int vts_adain_bwd(const float* g, const float* x, const float* s, int NC, int HW, float eps, float* dx, float* ds, void* stream);
+
 /* ---- Evaluation metrics that need no pretrained network (models/model_utils.py:431-561 compute_evaluation_metric) ----
  * vts_minmax:          out2 = {min x, max x}
  * vts_metric_psnr:     I_PSNR (:481-496): both images mapped with the REAL image's range {lo, hi} (range2, device memory) to

@@ -47,6 +47,8 @@ def test_weights(shapes, seed, bn_keys=()):
             if "up" in k:  # ConvTranspose2d weight [Cin, Cout, k, k]: each output sums Cin*4 taps
                 fan_in = shp[0] * 4
             sd[k] = uniform(shp, seed, k) * float(np.sqrt(3.0 / fan_in))
+        elif len(shp) == 2:         # Linear weight [out, in]
+            sd[k] = uniform(shp, seed, k) * float(np.sqrt(3.0 / shp[1]))
         elif k.endswith("weight"):  # BatchNorm gamma
             sd[k] = 1.0 + 0.1 * uniform(shp, seed, k)
         else:  # biases

@@ -294,6 +294,52 @@ def golden_nets_style(size=256, seed=111, n=2):
     print("wrote nets_style_%d.npz (%d entries)" % (size, len(out)))
 
 
+STYLE_MODE_CASES = (("concat", "project", 2), ("adain", "project", 1))     # (style_code_mode, style_code_mapping_mode, batch)
+
+
+def style_mode_shapes(mode, n):
+    from oracle import nets
+    nc = 80 if mode == "adain" else 5      # ngf * 8 | ngf // 2 at ngf = 10 (networks.py:1446-1457)
+    return nets.g_param_shapes(style_nc=0 if mode == "adain" else nc, num_layer_style_code=1, style_map_nc=nc, style_bn=n > 1)
+
+
+def golden_nets_style_modes(size=1536, seed=117):
+    """CustomUnetGenerator with the projected style code: style_code_mapping0 (Linear -> BatchNorm1d at batch 2 | InstanceNorm1d at
+    batch 1 -> ReLU) concatenated into up7, and the adain mode (thirdparty/AdaIN) -- reference networks.py:1444-1465, 1608-1632.  The
+    reference builds the mapping for a 1536-pixel input (input_size=1536, :1432), so this runs at 1536 x 1536."""
+    from oracle import detrand, ref_import
+
+    ref_import.load()
+    from models import networks
+
+    out = {"size": size, "seed": seed}
+    for mode, mapping, n in STYLE_MODE_CASES:
+        opt = _ref_opt("skitG", True, ["--use_style_code", "True", "--batch_size", str(n), "--style_code_mode", mode, "--style_code_mapping_mode", mapping])
+        G = networks.define_G(9, 5, 10, "unet256_custom", "instance", False, "xavier", 0.02, False, False, [], opt, num_layer_separate=4)
+        mine = style_mode_shapes(mode, n)
+        assert {k: tuple(v.shape) for k, v in G.named_parameters()} == {k: tuple(v) for k, v in mine.items()}, "style-mode G key/shape mismatch"
+        G.load_state_dict(detrand.test_weights(mine, seed), strict=False)
+        G.train()
+        x = detrand.uniform((n, 9, size, size), seed, "g_in").requires_grad_(True)
+        sc = detrand.uniform((n, opt.style_code_dim), seed, "style")
+        sc = (sc / sc.norm(dim=1, keepdim=True)).requires_grad_(True)
+        y = G(x, style_code=sc)
+        (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+        t = "%s/" % mode
+        out[t + "keys"] = np.array(sorted(G.state_dict().keys()))
+        out[t + "G_out_sub"] = y.detach()[:, :, ::16, ::16].numpy()
+        out[t + "G_out_probe"] = detrand.probe(y, "g_out")
+        out[t + "G_dx_probe"] = detrand.probe(x.grad, "g_dx")
+        out[t + "G_dstyle"] = sc.grad.numpy()
+        for k, p in G.named_parameters():
+            out[t + "G_grad/" + k] = detrand.probe(p.grad, k)
+        if n > 1:
+            out[t + "bn_running_mean"] = G.state_dict()["style_code_mapping0.1.running_mean"].numpy()
+            out[t + "bn_running_var"] = G.state_dict()["style_code_mapping0.1.running_var"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "nets_style_modes_%d.npz" % size), **out)
+    print("wrote nets_style_modes_%d.npz (%d entries)" % (size, len(out)))
+
+
 def golden_resnet(size=64, seed=303, n_blocks=9, ngf=10):
     """ResnetGenerator (--netG resnet_9blocks, reference defaults) forward + gradients with seeded test weights."""
     from oracle import detrand, nets, ref_import
@@ -745,3 +791,5 @@ if __name__ == "__main__":
         golden_sifid()
     if "sg2g" in which:
         golden_sg2g()
+    if "stylemodes" in which:
+        golden_nets_style_modes()

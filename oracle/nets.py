@@ -171,9 +171,37 @@ def _inorm(x):
     return F.instance_norm(x, eps=1e-5)
 
 
+def style_map(sd, j, style_code, h, w, bn_train=True):
+    """style_code_mapping<j> (networks.py:1459-1465, 1611-1615): Linear(bias=False) -> BatchNorm1d (keys present) | InstanceNorm1d -> ReLU,
+    reshaped to [N, -1, h, w].  BatchNorm1d in training mode (batch statistics; the running buffers are not tracked here)."""
+    p = "style_code_mapping%d." % j
+    z = F.linear(style_code.to(torch.float32), sd[p + "0.weight"])
+    if p + "1.weight" in sd:
+        if bn_train:
+            z = F.batch_norm(z, None, None, sd[p + "1.weight"], sd[p + "1.bias"], True, 0.1, 1e-5)
+        else:
+            z = F.batch_norm(z, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"], sd[p + "1.bias"], False, 0.1, 1e-5)
+    else:
+        z = F.instance_norm(z[None], eps=1e-5)[0]     # InstanceNorm1d on a 2-D tensor: an unbatched (C = N, L = P) input
+    return F.relu(z).reshape(style_code.shape[0], -1, h, w)
+
+
+def adain(content, style, eps=1e-5):
+    """adaptive_instance_normalization (thirdparty/AdaIN/function.py:4-23): unbiased variance + eps under the square root"""
+    n, c = content.shape[:2]
+
+    def ms(t):
+        v = t.reshape(n, c, -1)
+        return v.mean(2).view(n, c, 1, 1), (v.var(dim=2) + eps).sqrt().view(n, c, 1, 1)
+
+    sm, ss = ms(style)
+    cm, cs = ms(content)
+    return (content - cm) / cs * ss + sm
+
+
 def unet_forward(sd, x, num_downs=8, num_layer_separate=4, style_code=None, num_layer_style_code=1,
-                 return_feats=False):
-    """CustomUnetGenerator.forward, instance norm, style mode concat/tile only."""
+                 return_feats=False, style_mode="concat", style_mapping="tile"):
+    """CustomUnetGenerator.forward (networks.py:1576-1645), instance norm; style code concat / adain x tile / project (:1600-1632)"""
     feats = []
     for i in range(num_downs):
         key = "down%d.model.%d" % (i, 0 if i == 0 else 1)
@@ -188,10 +216,18 @@ def unet_forward(sd, x, num_downs=8, num_layer_separate=4, style_code=None, num_
     for i in range(num_downs - 1, -1, -1):
         skip = feats[i]
         if style_code is not None and i >= num_downs - num_layer_style_code:
-            sc = style_code.to(torch.float32)[..., None, None].expand(-1, -1, skip.shape[2], skip.shape[3])
-            x = torch.cat([x, sc], 1)
-            if x_t is not None:
-                x_t = torch.cat([x_t, sc], 1)
+            if style_mapping == "tile":
+                sc = style_code.to(torch.float32)[..., None, None].expand(-1, -1, skip.shape[2], skip.shape[3])
+            else:
+                sc = style_map(sd, num_downs - i - 1, style_code, skip.shape[2], skip.shape[3])
+            if style_mode == "concat":
+                x = torch.cat([x, sc], 1)
+                if x_t is not None:
+                    x_t = torch.cat([x_t, sc], 1)
+            else:
+                x = adain(x, sc)
+                if x_t is not None:
+                    x_t = adain(x_t, sc)
 
         def up(name, inp):
             if i == 0 or i == num_downs - 1:  # outermost / innermost: no skip concat
@@ -568,10 +604,19 @@ def adam_update(p, g, m, v, step, lr, beta1, beta2, eps=1e-8):
 # ----------------------------------------------------------------------------
 
 
-def g_param_shapes(input_nc=9, ngf=10, num_downs=8, num_layer_separate=4, style_nc=0, num_layer_style_code=1):
-    """Ordered {key: shape} of CustomUnetGenerator (instance norm => conv bias present)."""
+def g_param_shapes(input_nc=9, ngf=10, num_downs=8, num_layer_separate=4, style_nc=0, num_layer_style_code=1, style_map_nc=0,
+                   style_dim=512, style_bn=False):
+    """Ordered {key: shape} of CustomUnetGenerator (instance norm => conv bias present).  style_nc: extra input channels of the styled
+    up layers (concat mode); style_map_nc > 0: style_code_mapping<j> layers emitting that many channels on the (1536 >> (num_downs - j))^2
+    map (project mapping, networks.py:1444-1465), with BatchNorm1d parameters when style_bn (batch_size > 1)."""
     ch = [ngf * min(2 ** i, 8) for i in range(num_downs)]  # out channels of down_i
     shapes = {}
+    for j in range(num_layer_style_code if style_map_nc else 0):
+        side = 1536 // (2 ** (num_downs - j))
+        shapes["style_code_mapping%d.0.weight" % j] = (side * side * style_map_nc, style_dim)
+        if style_bn:
+            shapes["style_code_mapping%d.1.weight" % j] = (side * side * style_map_nc,)
+            shapes["style_code_mapping%d.1.bias" % j] = (side * side * style_map_nc,)
     shapes["down0.model.0.weight"] = (ch[0], input_nc, 4, 4)
     shapes["down0.model.0.bias"] = (ch[0],)
 

@@ -456,3 +456,32 @@ def test_stylegan2_generator_oracle_matches_reference(golden_dir):
         if "G_grad/" + k in g.files:
             p, rp = detrand.probe(v.grad, k), g["G_grad/" + k]
             assert abs(p[1] - rp[1]) <= 2e-4 * max(abs(rp[1]), 1e-12), (k, p, rp)
+
+
+def test_style_code_project_and_adain_modes(golden_dir):
+    """oracle CustomUnetGenerator with the projected style code (concat + BatchNorm1d at batch 2; adain + InstanceNorm1d at batch 1)
+    vs the reference module at its 1536-pixel design size (tests/golden/nets_style_modes_1536.npz)"""
+    from oracle.make_golden import STYLE_MODE_CASES, style_mode_shapes
+    g = _load(golden_dir, "nets_style_modes_1536.npz")
+    size, seed = int(g["size"]), int(g["seed"])
+    for mode, mapping, n in STYLE_MODE_CASES:
+        sd = detrand.test_weights(style_mode_shapes(mode, n), seed)
+        for v in sd.values():
+            v.requires_grad_(True)
+        x = detrand.uniform((n, 9, size, size), seed, "g_in").requires_grad_(True)
+        sc = detrand.uniform((n, 512), seed, "style")
+        sc = (sc / sc.norm(dim=1, keepdim=True)).requires_grad_(True)
+        y = nets.unet_forward(sd, x, style_code=sc, style_mode=mode, style_mapping=mapping)
+        t = mode + "/"
+        _close(y.detach()[:, :, ::16, ::16].numpy(), g[t + "G_out_sub"], rtol=1e-4, atol=2e-5)
+        (y * detrand.uniform(tuple(y.shape), seed, "g_cot")).sum().backward()
+        _probe_close(x.grad, g[t + "G_dx_probe"], "g_dx")
+        _close(sc.grad.numpy(), g[t + "G_dstyle"], rtol=5e-3, atol=1e-5 * np.abs(g[t + "G_dstyle"]).max())
+        for k, v in sd.items():
+            # conv biases in front of an InstanceNorm (and the Linear-less BatchNorm1d input) have an analytically zero gradient: both
+            # sides hold rounding noise there, 1e-2 of a real gradient at this map size
+            if k.endswith("bias") and not any(k.startswith(p) for p in ("down0.", "down7.", "up0.", "up0_T.", "style_code_mapping")):
+                continue
+            if mode == "adain" and k == "down7.model.1.bias":      # AdaIN removes the per-channel constant of its content
+                continue
+            _probe_close(v.grad, g[t + "G_grad/" + k], k)

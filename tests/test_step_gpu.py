@@ -408,6 +408,62 @@ def test_style_code_generator_matches_reference_golden(golden_dir):
         probe_close(p.grad, g["G_grad/" + k], k, 1e-3)
 
 
+def test_style_code_project_and_adain_modes_match_reference_golden(golden_dir):
+    """--style_code_mapping_mode project with --style_code_mode concat (BatchNorm1d, batch 2) and adain (InstanceNorm1d, batch 1) on the
+    HIP engine at the reference's 1536-pixel design size vs the REFERENCE module run on CPU (tests/golden/nets_style_modes_1536.npz):
+    outputs, style-code gradient, every parameter gradient incl. style_code_mapping0, BatchNorm1d running statistics; AdaIN operator vs
+    the oracle"""
+    from models import create_model
+    from options.train_options import TrainOptions
+    from oracle.make_golden import STYLE_MODE_CASES, style_mode_shapes
+    from vts import engine, ops
+
+    g = np.load(os.path.join(golden_dir, "nets_style_modes_1536.npz"))
+    size, seed = int(g["size"]), int(g["seed"])
+    dev = torch.device("cuda:0")
+    xa, sa = detrand.uniform((2, 7, 6, 6), 3, "ax"), 0.5 + detrand.uniform((2, 7, 6, 6), 3, "as")
+    xo, so = xa.clone().requires_grad_(True), sa.clone().requires_grad_(True)
+    yo = nets.adain(xo, so)
+    cot = detrand.uniform(tuple(yo.shape), 3, "ac")
+    (yo * cot).sum().backward()
+    assert rel(ops.adain(xa.to(dev), sa.to(dev)), yo) < 1e-6
+    dxa, dsa = ops.adain_bwd(cot.to(dev), xa.to(dev), sa.to(dev))
+    assert rel(dxa, xo.grad) < 1e-5 and rel(dsa, so.grad) < 1e-5
+    for mode, mapping, n in STYLE_MODE_CASES:
+        flags = (FLAGS % (size, n)).replace("--model sinskitG", "--model skitG") + " --style_code_mode %s --style_code_mapping_mode %s" % (mode, mapping)
+        opt = TrainOptions(cmd_line=flags).parse()
+        model = create_model(opt)
+        model.setup(opt)
+        model.parallelize()
+        G = model.netG
+        t = mode + "/"
+        assert sorted(G.state_dict().keys()) == sorted(g[t + "keys"].tolist())          # checkpoint compatible with the reference
+        G.load_state_dict(detrand.test_weights(style_mode_shapes(mode, n), seed), strict=False)
+        G.train()
+        x = detrand.uniform((n, 9, size, size), seed, "g_in").to(dev)
+        sc = detrand.uniform((n, 512), seed, "style")
+        sc = (sc / sc.norm(dim=1, keepdim=True)).to(dev)
+        y, ctx = engine.unet_forward(G, x, style_code=sc)
+        assert rel(y[:, :, ::16, ::16], torch.from_numpy(g[t + "G_out_sub"])) < 1e-4
+        probe_close(y, g[t + "G_out_probe"], "g_out", 2e-4)
+        cot = detrand.uniform(tuple(y.shape), seed, "g_cot").to(dev)
+        model.flatG.grad.zero_()
+        engine.unet_backward(G, ctx, (cot * (1.0 - y * y)).contiguous())
+        assert rel(ctx.dstyle, torch.from_numpy(g[t + "G_dstyle"])) < 5e-3
+        for k, p in G.named_parameters():
+            if null_grad_bias("G", k) and not k.startswith("style_code_mapping"):
+                continue
+            if mode == "adain" and k == "down7.model.1.bias":
+                continue
+            probe_close(p.grad, g[t + "G_grad/" + k], k, 1e-3)
+        if n > 1:
+            sdict = G.state_dict()
+            assert rel(sdict["style_code_mapping0.1.running_mean"], torch.from_numpy(g[t + "bn_running_mean"])) < 1e-5
+            assert rel(sdict["style_code_mapping0.1.running_var"], torch.from_numpy(g[t + "bn_running_var"])) < 1e-5
+        del model, G, ctx, y
+        torch.cuda.empty_cache()
+
+
 def test_frechet_distance_matches_reference(golden_dir):
     """vts_frechet_distance (float64 moments + Newton-Schulz matrix square root) vs the REFERENCE's calculate_frechet_distance on
     synthetic features (tests/golden/metrics.npz) and vs the oracle restatement (scipy sqrtm)"""

@@ -43,6 +43,22 @@ class _BNParams(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
 
+class _LinearParams(nn.Module):
+    """nn.Linear(.., bias=False): initialised like the convolutions by init_weights (networks.py:200: 'Conv' or 'Linear' in the class name)"""
+
+    def __init__(self, out_f, in_f):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(out_f, in_f))
+        self.bias = None
+
+
+class _BN1dParams(_BNParams):
+    """nn.BatchNorm1d: init_weights leaves it at weight 1 / bias 0 (networks.py:218 matches 'BatchNorm2d' only)"""
+
+
+STYLE_INPUT_SIZE = 1536    # CustomUnetGenerator(input_size=1536) (networks.py:1432); define_G never passes another value (:307)
+
+
 class _Block(nn.Module):
     """`downN` / `upN` wrapper whose only child is `model` (keys 'downN.model.K.weight')."""
 
@@ -70,19 +86,34 @@ class CustomUnetGenerator(nn.Module):
         self.use_style = use_style
         self.num_layer_style_code = 0
         self.style_nc = 0
+        self.style_mode, self.style_mapping = "concat", "tile"
         if use_style:
-            if getattr(opt, "style_code_mode", "concat") != "concat" or getattr(opt, "style_code_mapping_mode", "tile") != "tile":
-                raise NotImplementedError("style code: only mode=concat / mapping=tile is built (SURVEY.md §8 a5)")
+            self.style_mode = getattr(opt, "style_code_mode", "concat")
+            self.style_mapping = getattr(opt, "style_code_mapping_mode", "tile")
+            if self.style_mode not in ("concat", "adain") or self.style_mapping not in ("tile", "project"):
+                raise NotImplementedError("style code mode %s / mapping %s (networks.py:1608-1632)" % (self.style_mode, self.style_mapping))
+            if self.style_mode == "adain" and self.style_mapping == "tile":
+                raise ValueError("style_code_mode adain needs style_code_mapping_mode project: the tiled 512-channel code cannot match the "
+                                 "content's channels (thirdparty/AdaIN/function.py:16)")
             nl = getattr(opt, "num_layer_style_code", -1)
             self.num_layer_style_code = num_downs if nl == -1 else nl
-            self.style_nc = opt.style_code_dim
-            # the reference also constructs (never uses) Linear style_code_mapping<i> layers in tile mode
-            # (networks.py:1446-1465); they are dead parameters and are not created here.
+            # channels of the style map of layer i (networks.py:1446-1457): the code itself (tile), ngf // 2 (project), ngf * 8 (adain)
+            self.style_nc = ngf * 8 if self.style_mode == "adain" else (opt.style_code_dim if self.style_mapping == "tile" else ngf // 2)
+            if self.style_mapping == "project":
+                # style_code_mapping<j> = Linear(style_dim, out_size^2 * nc, bias=False) -> BatchNorm1d | InstanceNorm1d -> ReLU for
+                # up layer i = num_downs - 1 - j (networks.py:1444-1465).  In tile mode the reference creates the same Linear layers
+                # and never uses them (dead parameters: not created here).
+                for j in range(self.num_layer_style_code):
+                    side = STYLE_INPUT_SIZE // (2 ** (num_downs - j))
+                    mods = {0: _LinearParams(side * side * self.style_nc, opt.style_code_dim)}
+                    if getattr(opt, "batch_size", 1) > 1:
+                        mods[1] = _BN1dParams(side * side * self.style_nc)
+                    setattr(self, "style_code_mapping%d" % j, _Holder(mods))
         ch = [ngf * min(2 ** i, 8) for i in range(num_downs)]
         self.channels = ch
 
-        def style_extra(i):
-            return self.style_nc if (use_style and i >= num_downs - self.num_layer_style_code) else 0
+        def style_extra(i):     # extra input channels of up layer i: none in adain mode (networks.py:1477-1480)
+            return self.style_nc if (use_style and self.style_mode != "adain" and i >= num_downs - self.num_layer_style_code) else 0
 
         def up(i, outer):
             inner = ch[i] * (1 if i in (0, num_downs - 1) else 2) + style_extra(i)
@@ -375,7 +406,7 @@ class MultiscaleDiscriminatorIF(MultiscaleDiscriminator):
 def init_weights(net, init_type="normal", init_gain=0.02):
     """networks.py:191-231: conv weights by `init_type`, biases 0, BatchNorm weight ~ N(1, gain)."""
     for m in net.modules():
-        if isinstance(m, _ConvParams):
+        if isinstance(m, (_ConvParams, _LinearParams)):
             if init_type == "normal":
                 nn.init.normal_(m.weight.data, 0.0, init_gain)
             elif init_type == "xavier":
@@ -388,7 +419,7 @@ def init_weights(net, init_type="normal", init_gain=0.02):
                 raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
             if m.bias is not None:
                 nn.init.constant_(m.bias.data, 0.0)
-        elif isinstance(m, _BNParams):
+        elif isinstance(m, _BNParams) and not isinstance(m, _BN1dParams):
             nn.init.normal_(m.weight.data, 1.0, init_gain)
             nn.init.constant_(m.bias.data, 0.0)
 

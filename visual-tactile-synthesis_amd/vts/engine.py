@@ -37,7 +37,7 @@ def _as_act(x):
 # =====================================================================================
 
 class UnetCtx:
-    __slots__ = ("x", "feats", "ups", "g_out", "style")
+    __slots__ = ("x", "feats", "ups", "g_out", "style", "style_ctx", "adain_in", "dstyle")
 
 
 def unet_forward(G, x, style_code=None, keep=True):
@@ -73,11 +73,20 @@ def unet_forward(G, x, style_code=None, keep=True):
     g_out = _empty(n, 5, h, w, dev)
     ups = {}
     extras = {}
+    style_ctx = {}
     for i in range(nd):
         if style is not None and i >= nd - G.num_layer_style_code:
             if i not in (0, nd - 1):
                 raise NotImplementedError("style code on a skip-connected layer needs a third concat source")
-            extras[i] = Act(style[:, :, None, None].expand(-1, -1, h >> (i + 1), w >> (i + 1)).contiguous())
+            hh, ww = h >> (i + 1), w >> (i + 1)
+            if G.style_mapping == "tile":
+                extras[i] = Act(style[:, :, None, None].expand(-1, -1, hh, ww).contiguous())
+            else:
+                smap, style_ctx[i] = _style_map_forward(G, nd - 1 - i, style, hh, ww)
+                if G.style_mode == "concat":
+                    extras[i] = Act(smap)
+                else:
+                    style_ctx[i] += (smap,)
 
     def up(i, name, inp):
         hh, ww = h >> (i + 1), w >> (i + 1)
@@ -98,7 +107,14 @@ def unet_forward(G, x, style_code=None, keep=True):
 
     nls = G.num_layer_separate
     xm = feats[nd - 1]
+    adain_in = {}
     for i in range(nd - 1, nls - 1, -1):      # shared trunk
+        if i in style_ctx and G.style_mode == "adain":     # x = adaptive_instance_normalization(x, style map) (networks.py:1624-1630)
+            if i != nd - 1:
+                raise NotImplementedError("adain style conditioning is built for the innermost layer (num_layer_style_code 1)")
+            x_raw = ops.pad_affine(xm, (0, 0, 0, 0), 0) if (xm.scale is not None) else xm.data
+            adain_in[i] = x_raw
+            xm = Act(ops.adain(x_raw, style_ctx[i][-1]))
         xm = up(i, "up%d" % i, xm)
 
     def chain(lane):                          # the visual (lane 0) and tactile (lane 1) decoders are independent chains
@@ -112,7 +128,63 @@ def unet_forward(G, x, style_code=None, keep=True):
         return g_out, None
     ctx = UnetCtx()
     ctx.x, ctx.feats, ctx.ups, ctx.g_out, ctx.style = (x, x_extra), feats, ups, g_out, style
+    ctx.style_ctx, ctx.adain_in, ctx.dstyle = style_ctx, adain_in, None
     return g_out, ctx
+
+
+def _style_map_forward(G, j, style, hh, ww):
+    """style_code_mapping<j> (networks.py:1459-1465, 1611-1615): Linear(style_dim, P, bias=False) -> BatchNorm1d (batch_size > 1) |
+    InstanceNorm1d -> ReLU, reshaped to [N, P / (h w), h, w].  The Linear is a 1 x 1 convolution on a 1 x 1 map; BatchNorm1d over
+    [N, P] is BatchNorm2d on [N, P, 1, 1]; InstanceNorm1d on the 2-D tensor normalises every row over its P features (torch treats
+    [N, P] as an unbatched (C = N, L = P) input), i.e. InstanceNorm2d on [N, 1, P, 1]."""
+    m = getattr(G, "style_code_mapping%d" % j)
+    lin = getattr(m, "0")
+    bn = getattr(m, "1", None)
+    n, k = style.shape
+    P = lin.weight.shape[0]
+    if P % (hh * ww):
+        raise ValueError("style_code_mapping%d emits %d features, not a multiple of the %d x %d map: the reference builds it for a %d-pixel "
+                         "input (networks.py:1432, 1458)" % (j, P, hh, ww, 1536))
+    z = _empty(n, P, 1, 1, style.device)
+    sv = style.reshape(n, k, 1, 1).contiguous()
+    ops.convk(sv, lin.weight.view(P, k, 1, 1), z, pad=0)
+    if bn is not None:
+        if G.training:
+            a = ops.norm_stats(z, 1, gamma=bn.weight, beta=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var, nbt=bn.num_batches_tracked)
+        else:
+            sc = bn.weight / torch.sqrt(bn.running_var + 1e-5)
+            a = Act(z, sc.repeat(n).contiguous(), (bn.bias - bn.running_mean * sc).repeat(n).contiguous())
+        y = ops.pad_affine(a, (0, 0, 0, 0), 0, act=RELU)
+    else:
+        a = ops.norm_stats(z.view(n, 1, P, 1), 0)
+        y = ops.pad_affine(a, (0, 0, 0, 0), 0, act=RELU)
+    return y.view(n, P // (hh * ww), hh, ww), (j, sv, a, bn)
+
+
+def _style_map_backward(G, sctx, d_map, want_dstyle=False):
+    """parameter gradients of style_code_mapping<j> from the gradient w.r.t. its output map; returns d/d style_code when asked"""
+    j, sv, a, bn = sctx[:4]
+    m = getattr(G, "style_code_mapping%d" % j)
+    lin = getattr(m, "0")
+    n, k = sv.shape[0], sv.shape[1]
+    P = lin.weight.shape[0]
+    g = d_map.reshape(a.data.shape).contiguous()
+    dz = torch.empty_like(g)
+    ops.act_bwd(g, a, RELU, dz)
+    if bn is not None:
+        if G.training:
+            ops.norm_bwd(dz, a, 1, gamma=bn.weight, dgamma=bn.weight.grad, dbeta=bn.bias.grad)
+        else:
+            raise NotImplementedError("backward through an eval-mode BatchNorm1d")
+    else:
+        ops.norm_bwd(dz, a, 0)
+    dz = dz.view(n, P, 1, 1)
+    ops.wgradk(dz, sv, lin.weight.grad.view(P, k, 1, 1), pad=0)
+    if not want_dstyle:
+        return None
+    ds = torch.empty_like(sv)
+    ops.convk_bwd_data(dz, lin.weight.view(P, k, 1, 1), ds, pad=0)
+    return ds.view(n, k)
 
 
 def unet_backward(G, ctx, d_raw):
@@ -192,6 +264,12 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
             wv = blk.weight.view(-1)[c_in0 * outer * 16:]
             ops.conv4x4(gop, wv, outer * 16, 16, skip.data.shape[1], tgt, stride=2, pad=1, dmask=skip, dmask_act=RELU,
                         accumulate=acc)
+        elif extra is not None and i in ctx.style_ctx and G.style_mode == "concat":
+            # projected style map as the second concat source: its gradient feeds style_code_mapping<j>'s parameters
+            d_map = torch.empty_like(extra.data)
+            wv = blk.weight.view(-1)[c_in0 * outer * 16:]
+            ops.conv4x4(gop, wv, outer * 16, 16, extra.data.shape[1], d_map, stride=2, pad=1, dmask=extra, dmask_act=RELU)
+            ctx.dstyle = _style_map_backward(G, ctx.style_ctx[i], d_map, want_dstyle=True)
 
     nls = G.num_layer_separate
     if nls > 0 and PARALLEL_SCALES:
@@ -230,6 +308,12 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
 
 
 def _unet_backward_encoder(G, ctx, dfeat, feats, nd, dev, sq):
+    if (nd - 1) in ctx.adain_in:      # up7 consumed adain(feats[7], style map): split its input gradient into content and style parts
+        x_raw = ctx.adain_in[nd - 1]
+        smap = ctx.style_ctx[nd - 1][-1]
+        dxr, dsm = ops.adain_bwd(dfeat[nd - 1].contiguous(), x_raw, smap)
+        dfeat[nd - 1] = dxr
+        ctx.dstyle = _style_map_backward(G, ctx.style_ctx[nd - 1], dsm, want_dstyle=True)
     for i in range(nd - 1, -1, -1):
         blk = getattr(G, "down%d" % i).conv
         g = dfeat[i]

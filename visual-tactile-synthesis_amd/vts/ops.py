@@ -451,6 +451,24 @@ def bias_act_bwd(g, x, bias, slope=0.2, gain=2.0 ** 0.5, dx=None):
     return dx
 
 
+def adain(x, s, eps=1e-5):
+    """adaptive_instance_normalization(content x, style s) (thirdparty/AdaIN/function.py:15-23), [N,C,H,W] both"""
+    n, c, h, w = x.shape
+    assert s.shape == x.shape and x.is_contiguous() and s.is_contiguous()
+    out = torch.empty_like(x)
+    L.check(L.load().vts_adain(x.data_ptr(), s.data_ptr(), n * c, h * w, eps, out.data_ptr(), L.stream()), "vts_adain")
+    return out
+
+
+def adain_bwd(g, x, s, eps=1e-5):
+    """(dx, ds) of adain for the output gradient g"""
+    n, c, h, w = x.shape
+    assert g.is_contiguous() and x.is_contiguous() and s.is_contiguous()
+    dx, ds = torch.empty_like(x), torch.empty_like(s)
+    L.check(L.load().vts_adain_bwd(g.data_ptr(), x.data_ptr(), s.data_ptr(), n * c, h * w, eps, dx.data_ptr(), ds.data_ptr(), L.stream()), "vts_adain_bwd")
+    return dx, ds
+
+
 def modconv_weight(w, transpose=False, eps=1e-8):
     """style-free demodulated weight of ModulatedConv2d (stylegan_networks.py:307-317 with style None): w [1,Co,Ci,K,K] -> [Co,Ci,K,K],
     or [Ci,Co,K,K] with transpose (include/vts.h)"""
