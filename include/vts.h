@@ -221,6 +221,16 @@ int vts_pad_affine(const vts_operand* in, int N, int H, int W, int pt, int pb, i
 int vts_pad_bwd(const float* dpad, int N, int C, int H, int W, int pt, int pb, int pl, int pr, int mode, float* din,
                 int accumulate, void* stream);
 
+/* Separable windowed resampling from host-built tables: out[nc, y, x] (+)= sum_j wy[y*KY+j] * sum_i wx[x*KX+i] * in[nc, ymin[y]+j, xmin[x]+i]
+ * with j < ysize[y], i < xsize[x] (device int / float arrays).  With the index / weight tables of PyTorch's anti-aliased bicubic filter
+ * (cubic a = -0.5, support scaled by the downsampling factor, windows truncated at the border and renormalised) this is
+ * F.interpolate(mode="bicubic", align_corners=False, antialias=True) -- the patch / image resampling of compute_D2_loss and
+ * get_patch_in_input for T_resolution_multiplier 2 / 4 or patch cut-outs that are not 32 px (sinskitG_model.py:1440-1476, 1531-1557,
+ * model_utils.py:300-340); the adjoint is the same call on the transposed tables (vts/ops.py:bicubic_aa_tables builds both). */
+int vts_resample_table(const float* in, int64_t NC, int IH, int IW, const int* ymin, const int* ysize, const float* wy, int KY,
+                       const int* xmin, const int* xsize, const float* wx, int KX, float* out, int OH, int OW, int accumulate,
+                       void* stream);
+
 /* Anti-aliased resampling (networks.py:51-74 Downsample filt 3 / stride 2 / reflect; :87-107 Upsample filt 4 /
  * stride 2 / replicate), depthwise, with normalise-on-load of the input.  Down: [H,W] -> [(H-1)/2+1, (W-1)/2+1];
  * up: [H,W] -> [2H,2W].  The *_bwd entry points are the adjoints (gradient w.r.t. the activated input). */

@@ -613,3 +613,25 @@ def test_linear_rows_matches_torch():
             y = ops.linear_rows(x.to(dev), w.to(dev), b.to(dev), relu=relu)
             ref = F.linear(x, w, b)
             assert rel(y, F.relu(ref) if relu else ref) < 1e-5
+
+
+@pytest.mark.parametrize("geom", [(32, 32, 64, 64), (40, 40, 32, 32), (37, 53, 32, 32), (32, 32, 128, 128), (96, 80, 24, 20), (32, 32, 32, 32)])
+def test_bicubic_antialias_resampler_and_adjoint(geom):
+    """vts_resample_table with PyTorch's anti-aliased bicubic tables vs F.interpolate(mode="bicubic", align_corners=False,
+    antialias=True) -- the resampling the reference applies to patches / images when T_resolution_multiplier is 2 or 4 or a patch
+    cut-out is not 32 px (sinskitG_model.py:1440-1476, 1531-1557) -- and its adjoint vs autograd; equal sizes are the identity"""
+    from vts import ops
+    ih, iw, oh, ow = geom
+    x = detrand.uniform((3, 2, ih, iw), 77, "rs_x")
+    xo = x.clone().requires_grad_(True)
+    ref = F.interpolate(xo, (oh, ow), mode="bicubic", align_corners=False, antialias=True)
+    got = ops.bicubic_aa(x.to(_dev()), (oh, ow))
+    assert rel(got, ref) < 2e-6
+    cot = detrand.uniform(tuple(ref.shape), 77, "rs_c")
+    (ref * cot).sum().backward()
+    din = ops.bicubic_aa_bwd(cot.to(_dev()), (ih, iw))
+    assert rel(din, xo.grad) < 2e-6
+    acc = ops.bicubic_aa_bwd(cot.to(_dev()), (ih, iw), din=din.clone(), accumulate=True)
+    assert rel(acc, 2 * xo.grad) < 2e-6
+    if (ih, iw) == (oh, ow):
+        assert torch.equal(got.cpu(), x)

@@ -28,12 +28,25 @@ void vts_set_kernel(const char* fmt, ...) {
 extern "C" const char* vts_last_kernel(void) { return g_kernel; }
 extern "C" int vts_version(void) { return 1; }
 
+// one {1, 0} constant per DEVICE (a host process that drives several GPUs gets the copy that lives on the current one), created on
+// first use under a lock; device memory of a process is never freed here (process lifetime)
+#include <mutex>
+
 const float* vts_ident() {
-  static float* dev = nullptr;
-  if (!dev) {
+  static float* dev[64] = {nullptr};
+  static std::mutex mu;
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!dev[d]) {
     const float h[2] = {1.f, 0.f};
-    if (hipMalloc(&dev, sizeof(h)) != hipSuccess) return nullptr;
-    hipMemcpy(dev, h, sizeof(h), hipMemcpyHostToDevice);
+    float* p = nullptr;
+    if (hipMalloc(&p, sizeof(h)) != hipSuccess) return nullptr;
+    if (hipMemcpy(p, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    dev[d] = p;
   }
-  return dev;
+  return dev[d];
 }

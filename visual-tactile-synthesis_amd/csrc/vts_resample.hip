@@ -300,3 +300,44 @@ extern "C" int vts_tap_extract_at(const float* dw4, int64_t rows, int K, int oy,
   VTS_CHECK_LAUNCH("vts_tap_extract_at");
   return VTS_OK;
 }
+
+
+// ---- separable windowed resampling from host-built tables (F.interpolate(mode="bicubic", antialias=True) of the patch / image
+// resampling in compute_D2_loss and get_patch_in_input: reference sinskitG_model.py:1440-1476, 1531-1557, model_utils.py:300-340).
+// Output (y, x) = sum_j wy[y][j] * sum_i wx[x][i] * in[ymin[y] + j][xmin[x] + i]; tables = (first index, window length, K weights per
+// output index).  The adjoint is the same operator on the transposed tables (windows of a monotone resampling are intervals, so the
+// outputs that read an input sample also form an interval): a gather, deterministic.
+namespace {
+__global__ __launch_bounds__(256) void resample_table_kernel(const float* __restrict__ in, int64_t NC, int IH, int IW, const int* __restrict__ ymin,
+                                                              const int* __restrict__ ysize, const float* __restrict__ wy, int KY,
+                                                              const int* __restrict__ xmin, const int* __restrict__ xsize,
+                                                              const float* __restrict__ wx, int KX, float* __restrict__ out, int OH, int OW,
+                                                              int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= NC * OH * OW) return;
+  const int x = (int)(i % OW);
+  const int64_t r = i / OW;
+  const int y = (int)(r % OH);
+  const int64_t nc = r / OH;
+  const float* src = in + nc * IH * IW;
+  const int y0 = ymin[y], ny = ysize[y], x0 = xmin[x], nx = xsize[x];
+  float acc = 0.f;
+  for (int j = 0; j < ny; ++j) {
+    float row = 0.f;
+    for (int k = 0; k < nx; ++k) row = fmaf(wx[x * KX + k], src[(int64_t)(y0 + j) * IW + x0 + k], row);
+    acc = fmaf(wy[y * KY + j], row, acc);
+  }
+  out[i] = accumulate ? out[i] + acc : acc;
+}
+}  // namespace
+
+extern "C" int vts_resample_table(const float* in, int64_t NC, int IH, int IW, const int* ymin, const int* ysize, const float* wy, int KY,
+                                  const int* xmin, const int* xsize, const float* wx, int KX, float* out, int OH, int OW, int accumulate,
+                                  void* stream) {
+  VTS_CHECK_ARG(in && out && ymin && ysize && wy && xmin && xsize && wx && NC >= 1 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1 && KY >= 1 && KX >= 1,
+                "vts_resample_table: bad args");
+  hipLaunchKernelGGL(resample_table_kernel, dim3((unsigned)cdiv64(NC * OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, in, NC, IH, IW, ymin, ysize,
+                     wy, KY, xmin, xsize, wx, KX, out, OH, OW, accumulate);
+  VTS_CHECK_LAUNCH("vts_resample_table");
+  return VTS_OK;
+}

@@ -451,6 +451,95 @@ def bias_act_bwd(g, x, bias, slope=0.2, gain=2.0 ** 0.5, dx=None):
     return dx
 
 
+# ---- anti-aliased bicubic resampling (F.interpolate(mode="bicubic", align_corners=False, antialias=True)) ----------------------------
+_AA_TABLES = {}
+
+
+def _aa_axis(n_in, n_out):
+    """index / weight table of one axis as PyTorch builds it (aten/native/cpu/UpSampleKernel.cpp, _compute_indices_min_size_weights_aa
+    with the cubic filter a = -0.5 of _upsample_bicubic2d_aa): float32 arithmetic; returns (min [n_out], size [n_out], w [n_out, K])"""
+    import numpy as np
+    f32 = np.float32
+    scale = f32(n_in) / f32(n_out)
+    support = f32(2.0) * scale if scale >= 1.0 else f32(2.0)
+    invscale = f32(1.0) / scale if scale >= 1.0 else f32(1.0)
+    K = int(np.ceil(support)) * 2 + 1
+    mins, sizes, w = np.zeros(n_out, np.int32), np.zeros(n_out, np.int32), np.zeros((n_out, K), np.float32)
+    a = f32(-0.5)
+    for i in range(n_out):
+        center = scale * (f32(i) + f32(0.5))
+        lo = max(int(center - support + f32(0.5)), 0)
+        size = min(max(min(int(center + support + f32(0.5)), n_in) - lo, 0), K)
+        t = np.abs((np.arange(size, dtype=np.float32) + f32(lo) - center + f32(0.5)) * invscale).astype(np.float32)
+        wt = np.where(t < 1.0, ((a + f32(2.0)) * t - (a + f32(3.0))) * t * t + f32(1.0),
+                      np.where(t < 2.0, (((t - f32(5.0)) * t + f32(8.0)) * t - f32(4.0)) * a, f32(0.0))).astype(np.float32)
+        tot = wt.sum(dtype=np.float32)
+        if tot != 0:
+            wt = (wt / tot).astype(np.float32)
+        mins[i], sizes[i] = lo, size
+        w[i, :size] = wt
+    return mins, sizes, w
+
+
+def _aa_transpose(mins, sizes, w, n_in):
+    """tables of the adjoint: for every input index the interval of outputs whose window holds it, with those weights"""
+    import numpy as np
+    n_out = len(mins)
+    first = np.full(n_in, n_out, np.int64)
+    last = np.full(n_in, -1, np.int64)
+    for o in range(n_out):
+        lo, hi = mins[o], mins[o] + sizes[o]
+        first[lo:hi] = np.minimum(first[lo:hi], o)
+        last[lo:hi] = np.maximum(last[lo:hi], o)
+    cnt = np.maximum(last - first + 1, 0)
+    K = max(int(cnt.max()), 1)
+    tm, ts, tw = np.zeros(n_in, np.int32), cnt.astype(np.int32), np.zeros((n_in, K), np.float32)
+    for i in range(n_in):
+        if cnt[i] <= 0:
+            continue
+        tm[i] = first[i]
+        for k in range(int(cnt[i])):
+            o = first[i] + k
+            j = i - mins[o]
+            tw[i, k] = w[o, j] if 0 <= j < sizes[o] else 0.0
+    return tm, ts, tw
+
+
+def bicubic_aa_tables(ih, iw, oh, ow, device):
+    """device tables ((ymin, ysize, wy), (xmin, xsize, wx)) forward and adjoint, cached per geometry"""
+    key = (ih, iw, oh, ow, str(device))
+    if key not in _AA_TABLES:
+        def dev(t):
+            return tuple(torch.from_numpy(a).to(device) for a in t)
+        ay, ax = _aa_axis(ih, oh), _aa_axis(iw, ow)
+        _AA_TABLES[key] = ((dev(ay), dev(ax)), (dev(_aa_transpose(*ay, ih)), dev(_aa_transpose(*ax, iw))))
+    return _AA_TABLES[key]
+
+
+def _resample(x, tabs, oh, ow, out, accumulate):
+    (ymin, ysize, wy), (xmin, xsize, wx) = tabs
+    n, c, h, w = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+    L.check(L.load().vts_resample_table(x.data_ptr(), n * c, h, w, ymin.data_ptr(), ysize.data_ptr(), wy.data_ptr(), wy.shape[1], xmin.data_ptr(),
+                                        xsize.data_ptr(), wx.data_ptr(), wx.shape[1], out.data_ptr(), oh, ow, int(accumulate), L.stream()),
+            "vts_resample_table")
+    return out
+
+
+def bicubic_aa(x, size, out=None):
+    """F.interpolate(x, size, mode="bicubic", align_corners=False, antialias=True) (sinskitG_model.py:1440-1476, 1531-1557)"""
+    oh, ow = size
+    return _resample(x, bicubic_aa_tables(x.shape[2], x.shape[3], oh, ow, x.device)[0], oh, ow, out, False)
+
+
+def bicubic_aa_bwd(dout, in_size, din=None, accumulate=False):
+    """din (+)= adjoint of bicubic_aa (input size in_size) applied to dout"""
+    ih, iw = in_size
+    return _resample(dout, bicubic_aa_tables(ih, iw, dout.shape[2], dout.shape[3], dout.device)[1], ih, iw, din, accumulate)
+
+
 def adain(x, s, eps=1e-5):
     """adaptive_instance_normalization(content x, style s) (thirdparty/AdaIN/function.py:15-23), [N,C,H,W] both"""
     n, c, h, w = x.shape
