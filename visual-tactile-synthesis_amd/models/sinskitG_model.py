@@ -235,12 +235,25 @@ class SinSKITGModel(BaseModel):
         copy and torch.set_num_threads(1) do not)."""
         np.copyto(pin.numpy(), src.numpy() if torch.is_tensor(src) else np.asarray(src), casting="unsafe")
 
-    def _load(self, name, host, dtype=torch.float32):
+    def _load(self, name, host, dtype=torch.float32, staged=False):
         """host array -> persistent device buffer, asynchronously.  A pageable source would make the copy synchronous AND wait for the
         work already queued on the stream (the previous training step): such sources are staged through a persistent pinned buffer
-        (a DataLoader with pin_memory=True hands over pinned tensors already; the small patch bookkeeping arrays never are)."""
+        (a DataLoader with pin_memory=True hands over pinned tensors already; the small patch bookkeeping arrays never are).
+
+        staged=True (the full-size S / I / M images): the H2D copy runs on a COPY STREAM into one of two device staging buffers, so the
+        upload of batch i+1 travels over PCIe while the captured graphs of step i execute; the launch stream only waits for the copy's
+        event, and what it reads from then on is the staging buffer (the masking kernels of set_input write the persistent tensors the
+        graphs read).  A staging buffer is reused two batches later, after the event recorded at the end of the set_input that consumed
+        it (_stage_done)."""
         t = torch.as_tensor(host)
-        buf = self._buf(name, t.shape, dtype)
+        if staged:
+            par = self._stage_parity
+            buf = self._bufs.get("%s_stage%d" % (name, par))
+            if buf is None or tuple(buf.shape) != tuple(t.shape) or buf.dtype != dtype:     # staging buffers are not read by graphs: no _drop_graphs
+                buf = self._bufs["%s_stage%d" % (name, par)] = torch.empty(tuple(t.shape), dtype=dtype, device=self.device)
+        else:
+            buf = self._buf(name, t.shape, dtype)
+        src = t
         if t.device.type == "cpu" and not (t.is_pinned() and t.dtype == dtype):
             pin = self._pins.get(name)
             if pin is None or pin.shape != t.shape or pin.dtype != dtype:
@@ -249,11 +262,22 @@ class SinSKITGModel(BaseModel):
             else:
                 self._pin_evt[name].synchronize()     # the previous upload from this staging buffer has been read
             self._stage(pin, t)
-            t = pin
-            buf.copy_(t, non_blocking=True)
-            self._pin_evt[name].record()
+            src = pin
+        if not staged:
+            buf.copy_(src, non_blocking=True)
+            if src is not t:
+                self._pin_evt[name].record()
             return buf
-        buf.copy_(t, non_blocking=True)
+        cs = self._copy_stream
+        if self._stage_done[par] is not None:
+            cs.wait_event(self._stage_done[par])      # the kernels that read this staging buffer two batches ago
+        with torch.cuda.stream(cs):
+            buf.copy_(src, non_blocking=True)
+            if src is not t:
+                self._pin_evt[name].record(cs)
+        evt = torch.cuda.Event()
+        evt.record(cs)
+        torch.cuda.current_stream().wait_event(evt)
         return buf
 
     def _spe(self, n, h, w):
@@ -315,7 +339,10 @@ class SinSKITGModel(BaseModel):
         self.name = input.get("name")
         self.image_paths = input.get("S_paths")
         self.augmentation_params = input.get("augmentation_params")
-        S = self._load(phase + "_S", input["S"])
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream, self._stage_parity, self._stage_done = torch.cuda.Stream(), 0, [None, None]
+        self._stage_parity ^= 1
+        S = self._load(phase + "_S", input["S"], staged=True)
         n, _, h, w = S.shape
         # The D1 update runs the discriminator on [fake | real] in ONE batched launch per layer (engine.msd_multi, `groups`):
         # sketch and image live in persistent [2n, C, H, W] buffers -- rows [0, n) are the fake pass (S, fake_I written by the
@@ -324,7 +351,8 @@ class SinSKITGModel(BaseModel):
         S2 = self._buf(phase + "_S2", (2 * n if self._pair else n, 1, h, w))
         self.real_S = S2[:n]
         if self.opt.use_bg_mask:
-            self.M = self._load(phase + "_M", input["M"])
+            self.M = self._buf(phase + "_M", tuple(torch.as_tensor(input["M"]).shape))      # read by the captured graphs: persistent; filled from the staging copy
+            self.M.copy_(self._load(phase + "_M", input["M"], staged=True))
             ops.mask_mul(S, self.M, out=self.real_S)
             self.M_T = self.M  # nearest resize at multiplier 1 is the identity
         else:
@@ -333,7 +361,7 @@ class SinSKITGModel(BaseModel):
             S2[n:].copy_(self.real_S)
         self._S2 = S2
         if "I" in input:
-            I = self._load(phase + "_I", input["I"])
+            I = self._load(phase + "_I", input["I"], staged=True)
             I2 = self._buf(phase + "_I2", (2 * n if self._pair else n, 3, h, w))
             self.real_I = I2[n:] if self._pair else I2
             if self.opt.use_bg_mask:
@@ -381,12 +409,23 @@ class SinSKITGModel(BaseModel):
             if pin is None or pin.numel() != n:
                 pin = self._bufs["cand_count_pin"] = torch.empty(n, dtype=torch.int32).pin_memory()
                 self._cand_evt = torch.cuda.Event()
-            pin.copy_(self._cand_prefix[:, -1], non_blocking=True)
-            self._cand_evt.record()
+            # the COUNTS the host needs for random.sample come from a second evaluation on the copy stream (0.15 ms), right behind
+            # the mask's upload: queued on the launch stream they would sit behind the previous step's graphs, the host would wait for
+            # that whole step before it could enqueue the next one, and the GPU would idle for the enqueue time in between
+            cs = self._copy_stream
+            with torch.cuda.stream(cs):
+                _, pre2 = ops.mask_candidates(self._bufs["%s_M_stage%d" % (phase, self._stage_parity)],
+                                              self._buf("cand_side", (n, h - 14, w - 14), torch.uint8),
+                                              self._buf("cand_prefix_side", (n, h - 14 + 1), torch.int32))
+                pin.copy_(pre2[:, -1], non_blocking=True)
+                self._cand_evt.record(cs)
             self._cand_count = None
             k = self.opt.add_fake_T_sample_size
             self._ranks = self._buf("more_ranks", (n, k), torch.int64)
             self._more_img = self._load("more_img", torch.arange(n, dtype=torch.int32).repeat_interleave(k), torch.int32)
+        done = torch.cuda.Event()
+        done.record()        # every reader of this batch's staging buffers has been queued on the launch stream
+        self._stage_done[self._stage_parity] = done
 
     # ------------------------------------------------------------------ forward
     def _g_input(self):
