@@ -524,6 +524,132 @@ __global__ __launch_bounds__(256) void wgrad4x4_ns_kernel(const WgK p) {
     }
 }
 
+// ---- small-map member (round 2): the D2 discriminator's weight gradients over hundreds of 32x32 patches whose maps shrink to
+// 2x2 .. 17x17.  Tiling single images (the kernels above) leaves most of every 4x8 pixel tile empty and pays the per-tile staging
+// overhead per image (80 us for 64 x 32 channels on 640 maps of 6x6: 19 TFLOP/s); here the reduction dimension of the GEMM is the
+// FLATTENED (image, y, x) position index of IPB whole images per workgroup step: both operands of those images are staged once
+// (normalise + activate on load; the high-res planes zero-haloed so that taps outside the map read zeros), a position table gives
+// the plane offset of every position's window, and the four waves split the high-res channels while each holds all low-res
+// channel tiles: per group of four positions CLT + CHW LDS reads feed CLT x CHW MFMAs.  A workgroup keeps the whole CL x CH x 16
+// result in registers across its image blocks and writes ONE partial copy (reduced by wgrad_reduce_batch_kernel as for the others).
+struct SmallWK {
+  const float *lo, *losc, *losh, *hi, *hisc, *hish;
+  int64_t lons, hins;
+  int CL, CH, N, LH, LW, HH, HW, S, pad, padx;
+  float lo_slope, hi_slope;
+  int IPB, nblocks, POS, POSP, PW_, PLANE;   // positions per block (multiple of 4), lo row pitch, hi row pitch / plane (floats)
+  float* part;
+};
+constexpr int SW_HALO = 2;
+
+// e / d for 0 <= e < 2^23 through the float reciprocal (off by at most one: fixed up); ~8 instructions instead of the ~40 of a 32-bit division
+__device__ __forceinline__ int fdiv(int e, int d, float inv, int& rem) {
+  int q = (int)((float)e * inv);
+  int r = e - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+  rem = r;
+  return q;
+}
+
+template <int CLT, int CHW>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const SmallWK p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* lo_t = smem;                                   // [CLT*16][POSP]
+  float* hi_t = lo_t + CLT * 16 * p.POSP;               // [IPB][CH][PLANE]
+  int* postab = reinterpret_cast<int*>(hi_t + p.IPB * p.CH * p.PLANE);   // [POS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15, kq = lane >> 4;
+  const int lhw = p.LH * p.LW, hhw = p.HH * p.HW;
+  const int imgstride = p.CH * p.PLANE;
+  const float inv_blk = 1.f / (float)(p.IPB * lhw), inv_lhw = 1.f / (float)lhw, inv_hhw = 1.f / (float)hhw, inv_ch = 1.f / (float)p.CH,
+              inv_hw = 1.f / (float)p.HW;
+  // zero everything once: halos, padded positions and absent channel rows stay zero
+  for (int i = tid; i < CLT * 16 * p.POSP + p.IPB * imgstride; i += 256) smem[i] = 0.f;
+  for (int q = tid; q < p.POS; q += 256) {
+    const int img = q / lhw, rem = q - img * lhw;
+    const int y = rem / p.LW, x = rem - y * p.LW;
+    postab[q] = img < p.IPB ? img * imgstride + (y * p.S - p.pad + SW_HALO) * p.PW_ + (x * p.S - p.padx + SW_HALO) : 0;
+  }
+  const int tapoff = (m16 >> 2) * p.PW_ + (m16 & 3);     // B fragment: column n = tap (ky, kx)
+  f32x4 acc[CLT][CHW];
+#pragma unroll
+  for (int t = 0; t < CLT; ++t)
+#pragma unroll
+    for (int c = 0; c < CHW; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int blk = blockIdx.x; blk < p.nblocks; blk += gridDim.x) {
+    const int n0 = blk * p.IPB;
+    const int nimg = min(p.IPB, p.N - n0);
+    // ---- stage lo [cl][pos] (positions of absent images: zero) and the interior of the hi planes
+    for (int e = tid; e < p.CL * p.IPB * lhw; e += 256) {
+      int q, r;
+      const int c = fdiv(e, p.IPB * lhw, inv_blk, q);
+      const int img = fdiv(q, lhw, inv_lhw, r);
+      float v = 0.f;
+      if (img < nimg) {
+        const int n = n0 + img;
+        const float sc = p.losc ? p.losc[n * p.CL + c] : 1.f, sh = p.losh ? p.losh[n * p.CL + c] : 0.f;
+        const float t = fmaf(p.lo[n * p.lons + (int64_t)c * lhw + r], sc, sh);
+        v = fmaxf(t, 0.f) + p.lo_slope * fminf(t, 0.f);
+      }
+      lo_t[c * p.POSP + q] = v;
+    }
+    for (int e = tid; e < nimg * p.CH * hhw; e += 256) {
+      int r, c, x;
+      const int ic = fdiv(e, hhw, inv_hhw, r);
+      const int img = fdiv(ic, p.CH, inv_ch, c);
+      const int y = fdiv(r, p.HW, inv_hw, x);
+      const int n = n0 + img;
+      const float sc = p.hisc ? p.hisc[n * p.CH + c] : 1.f, sh = p.hish ? p.hish[n * p.CH + c] : 0.f;
+      const float t = fmaf(p.hi[n * p.hins + (int64_t)c * hhw + r], sc, sh);
+      hi_t[img * imgstride + c * p.PLANE + (y + SW_HALO) * p.PW_ + x + SW_HALO] = fmaxf(t, 0.f) + p.hi_slope * fminf(t, 0.f);
+    }
+    __syncthreads();
+    // ---- MFMA over groups of four positions, UG groups per iteration: all LDS reads of an iteration are issued before its MFMAs (one
+    // wave per SIMD at this LDS footprint: nothing else hides the read latency)
+    const int ngroups = (nimg * lhw + 3) >> 2;
+    constexpr int UG = (CLT * CHW >= 16) ? 2 : 4;
+    for (int g0 = 0; g0 < ngroups; g0 += UG) {
+      float a[UG][CLT], b[UG][CHW];
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const int pos = min(g0 + u, ngroups - 1) * 4 + kq;
+#pragma unroll
+        for (int t = 0; t < CLT; ++t) a[u][t] = lo_t[(t * 16 + m16) * p.POSP + pos];
+        const int base = postab[pos] + tapoff;
+#pragma unroll
+        for (int c = 0; c < CHW; ++c) b[u][c] = hi_t[base + min(wave * CHW + c, p.CH - 1) * p.PLANE];
+      }
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        if (g0 + u < ngroups) {
+#pragma unroll
+          for (int t = 0; t < CLT; ++t)
+#pragma unroll
+            for (int c = 0; c < CHW; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b[u][c], acc[t][c], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- this workgroup's partial copy [CL][CH][16]: C/D layout col = lane & 15 (tap), row = (lane >> 4) * 4 + r (low-res channel)
+  float* part = p.part + (int64_t)blockIdx.x * p.CL * p.CH * 16;
+#pragma unroll
+  for (int t = 0; t < CLT; ++t)
+#pragma unroll
+    for (int c = 0; c < CHW; ++c) {
+      const int ch = wave * CHW + c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cl = t * 16 + kq * 4 + r;
+        if (cl < p.CL && ch < p.CH) part[((int64_t)cl * p.CH + ch) * 16 + m16] = acc[t][c][r];
+      }
+    }
+}
+
 // Fixed-order sum of the PW partials.  64 consecutive elements per workgroup (one coalesced 256-B
 // row per wave-load), 16 waves each summing every 16th partial, combined through LDS in wave order.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int pw, float* __restrict__ dw,
@@ -615,12 +741,42 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceTa
 struct Plan {
   int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles, txl;
   int ns;   // 1: N-split kernel (wgrad4x4_ns_kernel), cht = high-res channels per WAVE
+  int small;   // 1: small-map kernel (wgrad_small_kernel<clt, cht>): flattened positions of ipb whole images per workgroup step
+  int ipb, nblocks, pos, posp, pwf, plane, lds_bytes;
 };
 
 Plan make_plan(const vts_wgrad_desc* d) {
   Plan pl;
   const int CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
   pl.ns = 0;
+  pl.small = 0;
+  static const int use_small = getenv("VTS_WGRAD_SMALL") ? atoi(getenv("VTS_WGRAD_SMALL")) : 1;
+  if (use_small && !d->lo1.data && !d->hi1.data && d->N >= 32 && d->LH * d->LW <= 324 && d->HH * d->HW <= 324 && CL <= 64 && CH <= 64 &&   // (32 x 32 inputs: staging-bound, measured 110 vs 31 us)
+      d->pad >= 0 && d->pad <= SW_HALO && d->pad + d->pad_dx >= 0 && d->pad + d->pad_dx <= SW_HALO) {
+    const int clt = CL <= 16 ? 1 : (CL <= 32 ? 2 : 4);
+    const int need = cdiv(CH, 4);
+    const int chw = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 16));
+    if (clt * chw <= 32) {
+      const int ph = d->HH + 2 * SW_HALO > (d->LH - 1) * d->stride - d->pad + SW_HALO + 4 ? d->HH + 2 * SW_HALO : (d->LH - 1) * d->stride - d->pad + SW_HALO + 4;
+      const int padx = d->pad + d->pad_dx;
+      const int pwf = d->HW + 2 * SW_HALO > (d->LW - 1) * d->stride - padx + SW_HALO + 4 ? d->HW + 2 * SW_HALO : (d->LW - 1) * d->stride - padx + SW_HALO + 4;
+      const int plane = ph * pwf;
+      int ipb = cdiv(d->N, 256);
+      for (; ipb >= 1; --ipb) {
+        const int pos = (ipb * d->LH * d->LW + 3) & ~3;
+        const int posp = pos + ((4 - pos) & 31);       // row pitch = 4 (mod 32): the 16 channel rows of an A fragment land on distinct banks
+        const int64_t floats = (int64_t)clt * 16 * posp + (int64_t)ipb * CH * plane + pos;
+        if (floats * 4 <= 150 * 1024) {
+          pl.small = 1; pl.clt = clt; pl.cht = chw; pl.ipb = ipb; pl.pos = pos; pl.posp = posp; pl.pwf = pwf; pl.plane = plane;
+          pl.lds_bytes = (int)(floats * 4);
+          pl.nblocks = cdiv(d->N, ipb);
+          pl.pw = pl.nblocks < 256 ? pl.nblocks : 256;
+          pl.cl_groups = pl.ch_groups = 1; pl.tiles_y = pl.tiles_x = pl.ntiles = 0; pl.txl = 0;
+          return pl;
+        }
+      }
+    }
+  }
   static const int use_ns = getenv("VTS_WGRAD_NS") ? atoi(getenv("VTS_WGRAD_NS")) : 1;
   static const int ns_min_ch = getenv("VTS_WGRAD_NS_MINCH") ? atoi(getenv("VTS_WGRAD_NS_MINCH")) : 5;
   static const int ns_min_w = getenv("VTS_WGRAD_NS_MINW") ? atoi(getenv("VTS_WGRAD_NS_MINW")) : 8;
@@ -734,6 +890,37 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   k.ablate = ablate;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nel = (int64_t)k.lo.C * k.hi.C * 16;
+  if (pl.small) {
+    SmallWK q;
+    q.lo = d->lo0.data; q.losc = d->lo0.scale; q.losh = d->lo0.shift; q.lons = d->lo0.nstride;
+    q.hi = d->hi0.data; q.hisc = d->hi0.scale; q.hish = d->hi0.shift; q.hins = d->hi0.nstride;
+    q.CL = k.lo.C; q.CH = k.hi.C; q.N = d->N; q.LH = d->LH; q.LW = d->LW; q.HH = d->HH; q.HW = d->HW; q.S = d->stride; q.pad = d->pad;
+    q.padx = d->pad + d->pad_dx;
+    q.lo_slope = vts_slope(d->act_lo); q.hi_slope = vts_slope(d->act_hi);
+    q.IPB = pl.ipb; q.nblocks = pl.nblocks; q.POS = pl.pos; q.POSP = pl.posp; q.PW_ = pl.pwf; q.PLANE = pl.plane;
+    q.part = ws;
+    bool ok = false;
+#define SW_CASE(CLT, CHW)                                                                                                      \
+  if (pl.clt == CLT && pl.cht == CHW) {                                                                                        \
+    static bool attr = false;                                                                                                  \
+    if (!attr) {                                                                                                               \
+      (void)hipFuncSetAttribute((const void*)wgrad_small_kernel<CLT, CHW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                             \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((wgrad_small_kernel<CLT, CHW>), dim3(pl.pw), dim3(256), pl.lds_bytes, st, q);                           \
+    vts_set_kernel("wgrad_small_kernel<%d, %d>", CLT, CHW);                                                                    \
+    ok = true;                                                                                                                 \
+  }
+    SW_CASE(1, 2) SW_CASE(1, 4) SW_CASE(1, 8) SW_CASE(1, 16) SW_CASE(2, 2) SW_CASE(2, 4) SW_CASE(2, 8) SW_CASE(2, 16) SW_CASE(4, 2) SW_CASE(4, 4)
+    SW_CASE(4, 8)
+#undef SW_CASE
+    VTS_CHECK_ARG(ok, "vts_wgrad4x4: no small-map instance for clt %d chw %d", pl.clt, pl.cht);
+    VTS_CHECK_LAUNCH("vts_wgrad4x4 (small maps)");
+    if (d->defer) return VTS_OK;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 64)), dim3(1024), 0, st, ws, nel, pl.pw, d->dw, d->accumulate);
+    VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
+    return VTS_OK;
+  }
   // groups that end beyond CL/CH never write their out-of-range rows, and every in-range element is
   // written by exactly one (cl-group, ch-group) workgroup of every pixel worker.
   if (pl.ns) {
