@@ -746,6 +746,8 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
                   d->IW, d->stride, d->pad);
   }
   {
+    const int rh0 = vts_conv_head_try(d, (hipStream_t)stream);      // Cout = 1 prediction heads: full-size and small-map members
+    if (rh0 != VTS_ERR_UNSUPPORTED) return rh0;
     static const int use_small = getenv("VTS_NO_SMALL") ? 0 : 1;
     if (use_small) {
       const int rc = vts_conv_small_try(d, (hipStream_t)stream);
@@ -753,8 +755,6 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
     }
     const int rc = vts_conv_thin_try(d, (hipStream_t)stream);
     if (rc != VTS_ERR_UNSUPPORTED) return rc;
-    const int rh = vts_conv_head_try(d, (hipStream_t)stream);
-    if (rh != VTS_ERR_UNSUPPORTED) return rh;
   }
   ConvK k;
   k.s0 = d->in0.data; k.sc0 = d->in0.scale; k.sh0 = d->in0.shift; k.ns0 = d->in0.nstride; k.C0 = d->in0.C;

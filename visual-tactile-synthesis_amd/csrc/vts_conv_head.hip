@@ -11,6 +11,7 @@
 // fully exposed: measured 65 us with 256 threads) the workgroup has 1024 threads -- four groups of 256 share the staged patch and
 // split the channels of a chunk; their partial sums are combined through LDS in group order at the end.
 // Algorithmic bytes = 4 (in + out + w).  Exact fp32; the summation order over (channel, ky, kx) is fixed.
+#include <limits.h>
 #include <stdlib.h>
 
 #include "vts_internal.h"
@@ -149,14 +150,116 @@ __global__ __launch_bounds__(1024) void conv_head_kernel(const HeadK p) {
   }
 }
 
+// ---- small maps (the same heads on the D2 patch passes: 640 maps of 6x6 / 4x4 / 3x3 -> 7x7 / 5x5 / 4x4): one thread per output of
+// IPB whole images per workgroup (IPB * OH * OW <= 256), the zero-haloed input planes of 16 channels at a time in LDS
+// (normalise + LeakyReLU on load), taps as wave-uniform LDS broadcast reads.  The flattened-batch MFMA kernel took 73 us for the
+// 640-patch pass (one of sixteen output-channel columns carries work); this is ~1 MFLOP per workgroup of plain FMAs.
+struct HeadSK {
+  const float* x;
+  const float *sc, *sh;
+  int64_t ns;
+  int C, N, IH, IW, OH, OW, pad, padx;
+  const float* w;
+  int ws_ci;
+  const float* bias;
+  float* out;
+  int64_t ons;
+  float slope;
+  int IPB, PH, PW, CK;   // CK: channels staged per pass (all of them when two images' worth fits in LDS: one pass, one latency chain)
+};
+
+__global__ __launch_bounds__(256) void conv_head_small_kernel(const HeadSK p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;                                   // [IPB][p.CK][PH * PW]
+  float* wl = smem + p.IPB * p.CK * p.PH * p.PW;       // [CK][16]
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * p.IPB;
+  const int nimg = min(p.IPB, p.N - n0);
+  const int plane = p.PH * p.PW, ohw = p.OH * p.OW, ihw = p.IH * p.IW;
+  const int img = tid / ohw, r = tid - img * ohw;
+  const int oy = r / p.OW, ox = r - oy * p.OW;
+  const bool active = img < nimg;
+  const int base = img * p.CK * plane + oy * p.PW + ox;          // window origin of this output inside channel 0 of its image
+  for (int i = tid; i < p.IPB * p.CK * plane; i += 256) tile[i] = 0.f;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < p.C; c0 += p.CK) {
+    __syncthreads();
+    // batches of 8 elements per thread: all global loads of a batch are issued before the first LDS store (a load -> store loop
+    // exposes the full memory latency per element: measured 52 us for this kernel)
+    const int total = nimg * p.CK * ihw;
+    for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+      float raw[8], fsc[8], fsh[8];
+      int dst[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * 256;
+        const int ee = min(e, total - 1);
+        const int ic = ee / ihw, q = ee - ic * ihw;
+        const int im = ic / p.CK, c = ic - im * p.CK;
+        const int y = q / p.IW, x = q - y * p.IW;
+        const int cc = min(c0 + c, p.C - 1), n = n0 + im;
+        raw[j] = p.x[n * p.ns + (int64_t)cc * ihw + q];
+        fsc[j] = p.sc ? p.sc[n * p.C + cc] : 1.f;
+        fsh[j] = p.sh ? p.sh[n * p.C + cc] : 0.f;
+        dst[j] = (e < total && c0 + c < p.C) ? (im * p.CK + c) * plane + (y + p.pad) * p.PW + x + p.padx : -1 - ((im * p.CK + c) * plane + (y + p.pad) * p.PW + x + p.padx);
+        if (e >= total) dst[j] = INT_MIN;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = fmaf(raw[j], fsc[j], fsh[j]);
+        if (dst[j] >= 0) tile[dst[j]] = fmaxf(t, 0.f) + p.slope * fminf(t, 0.f);
+        else if (dst[j] != INT_MIN) tile[-1 - dst[j]] = 0.f;      // channel beyond C inside the last chunk
+      }
+    }
+    for (int e = tid; e < p.CK * 16; e += 256) wl[e] = (c0 + (e >> 4) < p.C) ? p.w[(int64_t)(c0 + (e >> 4)) * p.ws_ci + (e & 15)] : 0.f;
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int c = 0; c < p.CK; ++c) {
+        const float* t = tile + base + c * plane;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) acc = fmaf(t[ky * p.PW + kx], wl[c * 16 + ky * 4 + kx], acc);
+      }
+    }
+  }
+  if (active) p.out[(n0 + img) * p.ons + r] = acc + (p.bias ? p.bias[0] : 0.f);
+}
+
 }  // namespace
 
 int vts_conv_head_try(const vts_conv_desc* d, hipStream_t st) {
   static const int off = getenv("VTS_NO_HEAD") ? 1 : 0;
   if (off || d->transposed || d->stride != 1 || d->Cout != 1 || d->in1.data || d->dmask.data || d->accumulate || d->act_out != VTS_ACT_NONE)
     return VTS_ERR_UNSUPPORTED;
-  if (d->in0.C > HK_MAXC || d->in0.C < 8 || (int64_t)d->OH * d->OW < 1024 || (int64_t)d->IH * d->IW * d->in0.C >= (1ll << 31))
-    return VTS_ERR_UNSUPPORTED;
+  if (d->in0.C > HK_MAXC || d->in0.C < 8 || (int64_t)d->IH * d->IW * d->in0.C >= (1ll << 31)) return VTS_ERR_UNSUPPORTED;
+  if ((int64_t)d->OH * d->OW < 1024) {
+    // small maps with a large batch (D2 patch passes)
+    const int padx = d->pad + d->pad_dx;
+    if (d->N < 32 || d->OH * d->OW > 256 || d->pad < 0 || padx < 0 || d->IH + d->pad < d->OH + 3 - d->pad || d->IW + padx < d->OW + 3 - padx)
+      return VTS_ERR_UNSUPPORTED;
+    HeadSK q;
+    q.x = d->in0.data; q.sc = d->in0.scale; q.sh = d->in0.shift; q.ns = d->in0.nstride; q.C = d->in0.C; q.N = d->N;
+    q.IH = d->IH; q.IW = d->IW; q.OH = d->OH; q.OW = d->OW; q.pad = d->pad; q.padx = padx;
+    q.w = d->w; q.ws_ci = d->ws_ci; q.bias = d->bias; q.out = d->out; q.ons = d->out_nstride; q.slope = vts_slope(d->act_in);
+    q.PH = d->IH + 2 * d->pad; q.PW = d->IW + 2 * padx;
+    q.IPB = 256 / (d->OH * d->OW);
+    q.CK = d->in0.C;
+    auto bytes = [&]() { return (int64_t)(q.IPB * q.CK * q.PH * q.PW + q.CK * 16) * 4; };
+    while (q.IPB > 2 && bytes() > 60 * 1024) --q.IPB;
+    if (bytes() > 60 * 1024) {      // not even two images with all channels: 16 channels per pass
+      q.CK = 16;
+      q.IPB = 256 / (d->OH * d->OW);
+      while (q.IPB > 1 && bytes() > 60 * 1024) --q.IPB;
+    }
+    const int lds = (int)bytes();
+    if (lds > 64 * 1024) return VTS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_head_small_kernel, dim3(cdiv(d->N, q.IPB)), dim3(256), lds, st, q);
+    vts_set_kernel("conv_head_small_kernel");
+    VTS_CHECK_LAUNCH("vts_conv4x4 (head, small maps)");
+    return VTS_OK;
+  }
   HeadK k;
   k.x = d->in0.data; k.sc = d->in0.scale; k.sh = d->in0.shift; k.ns = d->in0.nstride; k.C = d->in0.C;
   k.IH = d->IH; k.IW = d->IW; k.OH = d->OH; k.OW = d->OW; k.pad = d->pad; k.padx = d->pad + d->pad_dx;

@@ -584,28 +584,53 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const SmallWK p) {
     const int n0 = blk * p.IPB;
     const int nimg = min(p.IPB, p.N - n0);
     // ---- stage lo [cl][pos] (positions of absent images: zero) and the interior of the hi planes
-    for (int e = tid; e < p.CL * p.IPB * lhw; e += 256) {
-      int q, r;
-      const int c = fdiv(e, p.IPB * lhw, inv_blk, q);
-      const int img = fdiv(q, lhw, inv_lhw, r);
-      float v = 0.f;
-      if (img < nimg) {
-        const int n = n0 + img;
-        const float sc = p.losc ? p.losc[n * p.CL + c] : 1.f, sh = p.losh ? p.losh[n * p.CL + c] : 0.f;
-        const float t = fmaf(p.lo[n * p.lons + (int64_t)c * lhw + r], sc, sh);
-        v = fmaxf(t, 0.f) + p.lo_slope * fminf(t, 0.f);
+    // (batches of 8 elements per thread: the global loads of a batch are all in flight before the first LDS store)
+    const int lo_total = p.CL * p.IPB * lhw;
+    for (int e0 = tid; e0 < lo_total; e0 += 256 * 8) {
+      float raw[8], fsc[8], fsh[8];
+      int dst[8];
+      bool live[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = min(e0 + j * 256, lo_total - 1);
+        int q, r;
+        const int c = fdiv(e, p.IPB * lhw, inv_blk, q);
+        const int img = fdiv(q, lhw, inv_lhw, r);
+        const int n = n0 + min(img, nimg - 1);
+        raw[j] = p.lo[n * p.lons + (int64_t)c * lhw + r];
+        fsc[j] = p.losc ? p.losc[n * p.CL + c] : 1.f;
+        fsh[j] = p.losh ? p.losh[n * p.CL + c] : 0.f;
+        dst[j] = e0 + j * 256 < lo_total ? c * p.POSP + q : -1;
+        live[j] = img < nimg;
       }
-      lo_t[c * p.POSP + q] = v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = fmaf(raw[j], fsc[j], fsh[j]);
+        if (dst[j] >= 0) lo_t[dst[j]] = live[j] ? fmaxf(t, 0.f) + p.lo_slope * fminf(t, 0.f) : 0.f;
+      }
     }
-    for (int e = tid; e < nimg * p.CH * hhw; e += 256) {
-      int r, c, x;
-      const int ic = fdiv(e, hhw, inv_hhw, r);
-      const int img = fdiv(ic, p.CH, inv_ch, c);
-      const int y = fdiv(r, p.HW, inv_hw, x);
-      const int n = n0 + img;
-      const float sc = p.hisc ? p.hisc[n * p.CH + c] : 1.f, sh = p.hish ? p.hish[n * p.CH + c] : 0.f;
-      const float t = fmaf(p.hi[n * p.hins + (int64_t)c * hhw + r], sc, sh);
-      hi_t[img * imgstride + c * p.PLANE + (y + SW_HALO) * p.PW_ + x + SW_HALO] = fmaxf(t, 0.f) + p.hi_slope * fminf(t, 0.f);
+    const int hi_total = nimg * p.CH * hhw;
+    for (int e0 = tid; e0 < hi_total; e0 += 256 * 8) {
+      float raw[8], fsc[8], fsh[8];
+      int dst[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = min(e0 + j * 256, hi_total - 1);
+        int r, c, x;
+        const int ic = fdiv(e, hhw, inv_hhw, r);
+        const int img = fdiv(ic, p.CH, inv_ch, c);
+        const int y = fdiv(r, p.HW, inv_hw, x);
+        const int n = n0 + img;
+        raw[j] = p.hi[n * p.hins + (int64_t)c * hhw + r];
+        fsc[j] = p.hisc ? p.hisc[n * p.CH + c] : 1.f;
+        fsh[j] = p.hish ? p.hish[n * p.CH + c] : 0.f;
+        dst[j] = e0 + j * 256 < hi_total ? img * imgstride + c * p.PLANE + (y + SW_HALO) * p.PW_ + x + SW_HALO : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = fmaf(raw[j], fsc[j], fsh[j]);
+        if (dst[j] >= 0) hi_t[dst[j]] = fmaxf(t, 0.f) + p.hi_slope * fminf(t, 0.f);
+      }
     }
     __syncthreads();
     // ---- MFMA over groups of four positions, UG groups per iteration: all LDS reads of an iteration are issued before its MFMAs (one
@@ -751,7 +776,7 @@ Plan make_plan(const vts_wgrad_desc* d) {
   pl.ns = 0;
   pl.small = 0;
   static const int use_small = getenv("VTS_WGRAD_SMALL") ? atoi(getenv("VTS_WGRAD_SMALL")) : 1;
-  if (use_small && !d->lo1.data && !d->hi1.data && d->N >= 32 && d->LH * d->LW <= 324 && d->HH * d->HW <= 324 && CL <= 64 && CH <= 64 &&   // (32 x 32 inputs: staging-bound, measured 110 vs 31 us)
+  if (use_small && !d->lo1.data && !d->hi1.data && d->N >= 32 && d->LH * d->LW <= 324 && d->HH <= 34 && d->HW <= 34 && CL <= 64 && CH <= 64 &&
       d->pad >= 0 && d->pad <= SW_HALO && d->pad + d->pad_dx >= 0 && d->pad + d->pad_dx <= SW_HALO) {
     const int clt = CL <= 16 ? 1 : (CL <= 32 ? 2 : 4);
     const int need = cdiv(CH, 4);
