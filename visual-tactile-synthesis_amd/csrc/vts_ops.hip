@@ -312,12 +312,27 @@ __global__ __launch_bounds__(64) void mask_rowcount_kernel(const uint8_t* __rest
   if (lane == 0) rc[n * (Hc + 1) + y + 1] = s;
 }
 
-__global__ void mask_prefix_kernel(int* __restrict__ rc, int Hc) {  // in-place inclusive scan -> rc[n][0..Hc] exclusive prefix
-  const int n = blockIdx.x;
+// in-place inclusive scan -> rc[n][0..Hc] exclusive prefix.  One wavefront per image: every lane scans a contiguous run of rows, the run
+// totals are scanned across the wave with shuffles (integers: exact and order independent).  (The single-thread loop this replaces
+// took 186 us for 1010 rows: a dependent global read-modify-write per row.)
+__global__ __launch_bounds__(64) void mask_prefix_kernel(int* __restrict__ rc, int Hc) {
+  const int n = blockIdx.x, lane = threadIdx.x;
   int* p = rc + n * (Hc + 1);
-  if (threadIdx.x == 0) {
-    p[0] = 0;
-    for (int y = 1; y <= Hc; ++y) p[y] += p[y - 1];
+  const int per = (Hc + 63) / 64;
+  const int y0 = 1 + lane * per, y1 = min(y0 + per, Hc + 1);
+  int run = 0;
+  for (int y = y0; y < y1; ++y) run += p[y];
+  int incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  int acc = incl - run;      // total of the lanes before this one
+  if (lane == 0) p[0] = 0;
+  for (int y = y0; y < y1; ++y) {
+    acc += p[y];
+    p[y] = acc;
   }
 }
 
