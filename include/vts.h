@@ -389,16 +389,20 @@ int vts_avgpool3s2(const float* x, int64_t x_nstride, int N, int C, int H, int W
 int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, float* dx, int64_t dx_nstride, int accumulate,
                        void* stream);
 
+/* Loss slots: 64-bit fixed point, VTS_LOSS_SCALE units per 1.0 (value = slot / VTS_LOSS_SCALE).  Integer atomic adds commute, so a
+ * logged loss is bitwise reproducible whatever order workgroups and concurrent streams add to a slot in. */
+#define VTS_LOSS_SCALE 1099511627776.0 /* 2^40 */
+
 /* GANLoss on one scale (models/networks.py:497-521), forward value and gradient in one pass.
  *   mode: 0 nonsaturating, 1 lsgan, 2 vanilla(BCE logits), 3 wgan, 4 hinge
  *   loss_out[0] += coeff * mean_over_batch( per-sample loss )   (lsgan/vanilla/wgan: global mean)
  *   dpred (if non-NULL) = grad_coeff * d(mean_over_batch(per-sample loss)) / dpred   */
 int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
-                float grad_coeff, float* loss_out, float* dpred, void* stream);
+                float grad_coeff, int64_t* loss_out, float* dpred, void* stream);
 
 /* loss_out[0] += coeff * sum|a-b| ;  grad (+)= coeff * sign(a-b)   (nn.L1Loss pieces,
  * sinskitG_model.py:1702, 1812-1814; the caller folds 1/numel into coeff). */
-int vts_l1(const float* a, const float* b, int64_t n, float coeff, float* loss_out, float* grad, int accumulate,
+int vts_l1(const float* a, const float* b, int64_t n, float coeff, int64_t* loss_out, float* grad, int accumulate,
            void* stream);
 
 /* Patch gather with clamp-to-border (models/model_utils.py:252-333), for P patches of

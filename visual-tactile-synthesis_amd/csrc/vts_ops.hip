@@ -66,8 +66,14 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 __device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus, threshold 20
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Loss slots are 64-bit fixed point (VTS_LOSS_SCALE = 2^40 units per 1.0): integer atomic adds commute, so a logged loss is bitwise
+// reproducible whatever order the workgroups -- and the concurrent lanes that share a slot -- arrive in (float atomics were not).
+__device__ __forceinline__ void loss_add(long long* slot, double v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)llrint(v * VTS_LOSS_SCALE));
+}
+
 __global__ __launch_bounds__(256) void ganloss_kernel(const float* __restrict__ pred, int64_t total, int mode, int real, float label,
-                                                      float inv_count, float coeff, float gcoeff, float* __restrict__ loss, float* __restrict__ dpred) {
+                                                      float inv_count, float coeff, float gcoeff, long long* __restrict__ loss, float* __restrict__ dpred) {
   __shared__ float red[16];
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -88,12 +94,12 @@ __global__ __launch_bounds__(256) void ganloss_kernel(const float* __restrict__ 
     if (dpred) dpred[i] = g * inv_count * gcoeff;
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0 && loss) atomicAdd(loss, acc * inv_count * coeff);
+  if (threadIdx.x == 0 && loss) loss_add(loss, (double)acc * (double)inv_count * (double)coeff);
 }
 
 // ------------------------------------------------------------------ L1
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float coeff,
-                                                 float* __restrict__ loss, float* __restrict__ grad, int accumulate) {
+                                                 long long* __restrict__ loss, float* __restrict__ grad, int accumulate) {
   __shared__ float red[16];
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, co
     }
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0 && loss) atomicAdd(loss, acc * coeff);
+  if (threadIdx.x == 0 && loss) loss_add(loss, (double)acc * (double)coeff);
 }
 
 // ------------------------------------------------------------------ patches
@@ -497,19 +503,19 @@ extern "C" int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, f
 }
 
 extern "C" int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
-                           float grad_coeff, float* loss_out, float* dpred, void* stream) {
+                           float grad_coeff, int64_t* loss_out, float* dpred, void* stream) {
   VTS_CHECK_ARG(pred && N >= 1 && M >= 1 && mode >= 0 && mode <= 4, "vts_ganloss: bad args");
   const int64_t total = (int64_t)N * M;
   hipLaunchKernelGGL(ganloss_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, total, mode, target_is_real,
-                     target_label, 1.f / (float)total, coeff, grad_coeff, loss_out, dpred);
+                     target_label, 1.f / (float)total, coeff, grad_coeff, reinterpret_cast<long long*>(loss_out), dpred);
   VTS_CHECK_LAUNCH("vts_ganloss");
   return VTS_OK;
 }
 
-extern "C" int vts_l1(const float* a, const float* b, int64_t n, float coeff, float* loss_out, float* grad, int accumulate,
+extern "C" int vts_l1(const float* a, const float* b, int64_t n, float coeff, int64_t* loss_out, float* grad, int accumulate,
                       void* stream) {
   VTS_CHECK_ARG(a && b && n >= 1, "vts_l1: bad args");
-  hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, coeff, loss_out, grad, accumulate);
+  hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, coeff, reinterpret_cast<long long*>(loss_out), grad, accumulate);
   VTS_CHECK_LAUNCH("vts_l1");
   return VTS_OK;
 }

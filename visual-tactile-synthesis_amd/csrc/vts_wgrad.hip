@@ -791,7 +791,8 @@ Plan make_plan(const vts_wgrad_desc* d) {
         const int pos = (ipb * d->LH * d->LW + 3) & ~3;
         const int posp = pos + ((4 - pos) & 31);       // row pitch = 4 (mod 32): the 16 channel rows of an A fragment land on distinct banks
         const int64_t floats = (int64_t)clt * 16 * posp + (int64_t)ipb * CH * plane + pos;
-        if (floats * 4 <= 150 * 1024) {
+        static const int lds_cap_kb = getenv("VTS_WGRAD_SMALL_LDS_KB") ? atoi(getenv("VTS_WGRAD_SMALL_LDS_KB")) : 150;
+        if (floats * 4 <= (int64_t)lds_cap_kb * 1024 || (ipb == 1 && floats * 4 <= 150 * 1024)) {
           pl.small = 1; pl.clt = clt; pl.cht = chw; pl.ipb = ipb; pl.pos = pos; pl.posp = posp; pl.pwf = pwf; pl.plane = plane;
           pl.lds_bytes = (int)(floats * 4);
           pl.nblocks = cdiv(d->N, ipb);

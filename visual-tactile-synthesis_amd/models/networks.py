@@ -539,10 +539,11 @@ class GANLoss:
 
     def __call__(self, preds, target_is_real):
         first = preds[0][-1] if isinstance(preds[0], (list, tuple)) else preds[-1]
-        slot = torch.zeros(1, device=first.device)
+        from vts import ops
+        slot = ops.loss_slots(1, first.device)
         plist = preds if isinstance(preds[0], (list, tuple)) else [preds[-1]]
         self.accumulate(plist, target_is_real, 1.0, slot, want_grad=False)
-        return slot
+        return (slot.double() / ops.LOSS_SCALE).float()
 
 
 class PatchSampleF(nn.Module):

@@ -96,7 +96,7 @@ class Pix2PixHDModel(BaseModel):
             self.optimizer_D = FlatAdam(self.flatD, opt.lr, betas)
             self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr, betas)
             self.optimizers += [self.optimizer_G, self.optimizer_D, self.optimizer_D2]
-        self._loss_buf = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
+        self._loss_buf = ops.loss_slots(len(LOSS_SLOTS), self.device)     # int64 fixed point (order-independent accumulation)
         self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
         self._bufs = {}
         self._graphs = None
@@ -258,7 +258,7 @@ class Pix2PixHDModel(BaseModel):
 
     # ------------------------------------------------------------------ logging
     def get_current_losses(self):
-        vals = self._loss_buf.cpu().tolist()
+        vals = ops.loss_values(self._loss_buf)
         for i, name in enumerate(LOSS_SLOTS):
             setattr(self, "loss_" + name, vals[i])
         return BaseModel.get_current_losses(self)

@@ -189,7 +189,7 @@ class SinSKITGModel(BaseModel):
             if "D2" in self.model_names:
                 self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr_G2, betas)
                 self.optimizers.append(self.optimizer_D2)
-        self._loss_buf = torch.zeros(len(LOSS_SLOTS), dtype=torch.float32, device=self.device)
+        self._loss_buf = ops.loss_slots(len(LOSS_SLOTS), self.device)     # int64 fixed point (order-independent accumulation)
         self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
         self._spe_cache = {}
         self._bufs = {}         # persistent input buffers (stable addresses for captured HIP graphs)
@@ -822,7 +822,7 @@ class SinSKITGModel(BaseModel):
 
     # ------------------------------------------------------------------ logging
     def get_current_losses(self):
-        vals = self._loss_buf.cpu().tolist()   # the only device->host sync of the loss path
+        vals = ops.loss_values(self._loss_buf)   # the only device->host sync of the loss path
         for i, name in enumerate(LOSS_SLOTS):
             setattr(self, "loss_" + name, vals[i])
         return BaseModel.get_current_losses(self)

@@ -871,8 +871,21 @@ def avgpool_bwd(dy, dx, accumulate=False, channels=None, dx_nstride=None):
     return dx
 
 
+LOSS_SCALE = float(2 ** 40)     # include/vts.h VTS_LOSS_SCALE: loss slots are int64 fixed point
+
+
+def loss_slots(n, device):
+    return torch.zeros(n, dtype=torch.int64, device=device)
+
+
+def loss_values(slots):
+    """host floats of a slot tensor (one device -> host copy)"""
+    return [v / LOSS_SCALE for v in slots.cpu().tolist()]
+
+
 def ganloss(pred, mode, target_is_real, coeff, loss_slot, dpred=None, label=None, grad_coeff=None):
     lib = L.load()
+    assert loss_slot is None or loss_slot.dtype == torch.int64
     n = pred.shape[0]
     m = pred.numel() // n
     if label is None:
@@ -884,6 +897,7 @@ def ganloss(pred, mode, target_is_real, coeff, loss_slot, dpred=None, label=None
 
 def l1(a, b, coeff, loss_slot, grad=None, accumulate=False):
     lib = L.load()
+    assert loss_slot is None or loss_slot.dtype == torch.int64
     L.check(lib.vts_l1(a.data_ptr(), b.data_ptr(), a.numel(), coeff, L.ptr(loss_slot), L.ptr(grad), int(accumulate), L.stream()),
             "vts_l1")
 
