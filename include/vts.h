@@ -181,6 +181,12 @@ typedef struct vts_norm_desc {
 int64_t vts_norm_ws_floats(int N, int C, int HW);
 int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream);
 
+/* vts_conv4x4 followed by the InstanceNorm statistics of its output (Down / Up blocks: conv -> InstanceNorm2d,
+ * thirdparty/unet/unet_parts_custom.py:24-37, 66-79) with the chance to fuse them: when the convolution takes its k-split path on a
+ * map of <= 4096 pixels, the slice-summing epilogue also computes the statistics (one launch instead of two, bit-identical) and
+ * *fused = 1; otherwise the convolution runs as vts_conv4x4, *fused = 0 and the caller calls vts_norm_stats.  nd: mode 0, x = d->out. */
+int vts_conv4x4_in(const vts_conv_desc* d, const vts_norm_desc* nd, int* fused, void* stream);
+
 /* Backward of the same normalisation (in place on dy):
  *   dx = A*dy + B*x + C  with the per-group coefficients of InstanceNorm / BatchNorm backward;
  * BN additionally writes dgamma/dbeta (accumulate flag).  */

@@ -625,6 +625,53 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_kernel(const ConvK p,
   *ob = p.accumulate ? *ob + v : v;
 }
 
+// Split epilogue + InstanceNorm statistics in one launch (round 2): the six innermost U-Net layers run k-split on maps of <= 64 x 64,
+// where "sum the partials" and "statistics of the result" are two latency-bound launches on the forward's critical chain.  One
+// workgroup owns a (n, channel) plane of <= 4096 elements: it sums the slices in slice order, adds the bias, stores the raw output
+// and computes mean / biased variance from its registers -- same thread <-> element mapping and reduction order as
+// norm_stats_fused_kernel<16, 256> (vts_norm.hip), so the statistics are bit-identical to the two-launch form.
+struct InStatsOut {
+  float *scale, *shift, *mean, *rstd;
+  float eps;
+};
+__global__ __launch_bounds__(256) void conv_split_epilogue_in_kernel(const ConvK p, int KS, const InStatsOut q) {
+  __shared__ float red[16];
+  const int g = blockIdx.x, n = g / p.Cout, co = g - n * p.Cout;
+  const int HW = p.OH * p.OW;
+  const float bias = p.bias ? p.bias[co] : 0.f;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int o = e * 256 + threadIdx.x;
+    float a = 0.f;
+    if (o < HW) {
+      for (int ks = 0; ks < KS; ++ks) a += p.part[(((int64_t)ks * p.N + n) * p.Cout + co) * HW + o];
+      a += bias;
+      p.out[n * p.ons + (int64_t)co * HW + o] = a;
+    }
+    v[e] = a;
+  }
+  const float cnt = (float)HW;
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += v[e];
+  const float mean = block_sum(s, red) / cnt;
+  float m2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float d = v[e] - mean;
+    if (e * 256 + (int)threadIdx.x < HW) m2 += d * d;
+  }
+  m2 = block_sum(m2, red);
+  if (threadIdx.x == 0) {
+    const float rstd = 1.f / sqrtf(m2 / cnt + q.eps);
+    q.scale[g] = rstd;
+    q.shift[g] = -mean * rstd;
+    if (q.mean) q.mean[g] = mean;
+    if (q.rstd) q.rstd[g] = rstd;
+  }
+}
+
 template <int MODE, int S, int NR, int RW, int MT, int CK>
 int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
@@ -705,7 +752,17 @@ extern "C" int64_t vts_conv4x4_ws_floats(const vts_conv_desc* d) {
   return (int64_t)ks_max * d->N * d->Cout * d->OH * d->OW;
 }
 
-extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused);
+
+extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) { return conv4x4_impl(d, stream, nullptr, nullptr); }
+
+extern "C" int vts_conv4x4_in(const vts_conv_desc* d, const vts_norm_desc* nd, int* fused, void* stream) {
+  VTS_CHECK_ARG(nd && fused && nd->scale && nd->shift && nd->mode == 0, "vts_conv4x4_in: InstanceNorm descriptor with scale / shift outputs required");
+  *fused = 0;
+  return conv4x4_impl(d, stream, nd, fused);
+}
+
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused) {
   VTS_CHECK_ARG(d && d->in0.data && d->w && d->out, "vts_conv4x4: null pointer");
   VTS_CHECK_ARG(d->stride == 1 || d->stride == 2, "vts_conv4x4: stride %d unsupported", d->stride);
   VTS_CHECK_ARG(d->Cout >= 1, "vts_conv4x4: Cout %d", d->Cout);
@@ -725,7 +782,7 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
         g.dmask.scale = d->dmask.scale ? d->dmask.scale + c0 : nullptr;
         g.dmask.shift = d->dmask.shift ? d->dmask.shift + c0 : nullptr;
       }
-      const int rc = vts_conv4x4(&g, stream);
+      const int rc = conv4x4_impl(&g, stream, nullptr, nullptr);
       if (rc != VTS_OK) return rc;
     }
     return VTS_OK;
@@ -815,6 +872,16 @@ extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) {
       if (!d->transposed) rc = d->stride == 2 ? launch<0, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<0, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
       else rc = d->stride == 2 ? launch<1, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<1, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
       if (rc != VTS_OK || KS == 1) return rc;
+      static const int fuse_in = getenv("VTS_FUSE_SPLIT_IN") ? atoi(getenv("VTS_FUSE_SPLIT_IN")) : 1;
+      if (nd && fuse_in && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
+          nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride) {
+        const InStatsOut q{nd->scale, nd->shift, nd->mean_out, nd->rstd_out, nd->eps};
+        hipLaunchKernelGGL(conv_split_epilogue_in_kernel, dim3(N * d->Cout), dim3(256), 0, st, k, KS, q);
+        VTS_CHECK_LAUNCH("vts_conv4x4 split epilogue + instance norm");
+        vts_set_kernel("conv4x4_kernel<%d, %d, 1, 1, 2, 4, false>+ksplit+in", d->transposed ? 1 : 0, d->stride);
+        *fused = 1;
+        return VTS_OK;
+      }
       hipLaunchKernelGGL(conv_split_epilogue_kernel, dim3((unsigned)cdiv64((int64_t)d->OH * d->OW, 256), d->Cout, N), dim3(256), 0, st, k, KS);
       VTS_CHECK_LAUNCH("vts_conv4x4 split epilogue");
       return VTS_OK;

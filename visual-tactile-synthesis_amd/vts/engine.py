@@ -60,9 +60,10 @@ def unet_forward(G, x, style_code=None, keep=True):
         cin = blk.weight.shape[1]
         hh, ww = h >> (i + 1), w >> (i + 1)
         out = _empty(n, ch[i], hh, ww, dev)
-        ops.conv4x4(a, blk.weight, cin * 16, 16, ch[i], out, in1=x_extra if i == 0 else None, bias=blk.bias, stride=2, pad=1,
-                    act_in=LRELU if i else 0)
-        a = ops.norm_stats(out, 0) if 0 < i < nd - 1 else Act(out)
+        normed = 0 < i < nd - 1
+        r = ops.conv4x4(a, blk.weight, cin * 16, 16, ch[i], out, in1=x_extra if i == 0 else None, bias=blk.bias, stride=2, pad=1,
+                        act_in=LRELU if i else 0, instance_norm=normed)
+        a = r if normed else Act(out)
         feats.append(a)
 
     style = None
@@ -99,9 +100,9 @@ def unet_forward(G, x, style_code=None, keep=True):
             out = g_out[:, c0:c0 + outer]
         else:
             out = _empty(n, outer, hh * 2, ww * 2, dev)
-        ops.conv4x4(inp, blk.weight, 16, outer * 16, outer, out, in1=skip if skip is not None else extra, bias=blk.bias,
-                    stride=2, pad=1, transposed=True, act_in=RELU, act_out=TANH if i == 0 else 0)
-        res = Act(out) if i == 0 else ops.norm_stats(out, 0)
+        r = ops.conv4x4(inp, blk.weight, 16, outer * 16, outer, out, in1=skip if skip is not None else extra, bias=blk.bias,
+                        stride=2, pad=1, transposed=True, act_in=RELU, act_out=TANH if i == 0 else 0, instance_norm=i != 0)
+        res = Act(out) if i == 0 else r
         ups[name] = (inp, res, extra)
         return res
 

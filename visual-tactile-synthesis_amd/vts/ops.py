@@ -116,8 +116,10 @@ def _op(a):
 
 
 def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, pad=1, transposed=False, act_in=0,
-            act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None, pad_dx=0):
-    """out <- conv-family(in0 ++ in1).  `w` may be an offset view into a weight tensor."""
+            act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None, pad_dx=0, instance_norm=False):
+    """out <- conv-family(in0 ++ in1).  `w` may be an offset view into a weight tensor.
+    instance_norm=True: returns Act(out, scale, shift, mean, rstd) of InstanceNorm2d(out) -- through vts_conv4x4_in, which fuses the
+    statistics into the k-split epilogue where it can (inner U-Net layers) and otherwise runs vts_norm_stats afterwards."""
     lib = L.load()
     d = L.ConvDesc()
     d.in0, d.in1 = _op(in0), _op(in1)
@@ -150,8 +152,21 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d p%d%s%s" % (d.N, cin, d.IH, d.IW, cout, d.OH, d.OW, pad, " dmask" if dmask is not None else "",
                                                       " acc" if accumulate else "")
-    _run(label, nbytes, flops, lib.vts_conv4x4, C.byref(d), L.stream())
-    return out
+    if not instance_norm:
+        _run(label, nbytes, flops, lib.vts_conv4x4, C.byref(d), L.stream())
+        return out
+    n, c, h, wd = out.shape
+    st = torch.empty(4, n * c, dtype=torch.float32, device=out.device)
+    nd = L.NormDesc()
+    nd.x, nd.nstride, nd.N, nd.C, nd.HW, nd.mode = out.data_ptr(), out.stride(0), n, c, h * wd, 0
+    nd.eps, nd.momentum = 1e-5, 0.1
+    nd.scale, nd.shift, nd.mean_out, nd.rstd_out = st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr()
+    nd.ngroups = 1
+    fused = C.c_int(0)
+    _run(label, nbytes, flops, lib.vts_conv4x4_in, C.byref(d), C.byref(nd), C.byref(fused), L.stream())
+    if fused.value:
+        return Act(out, st[0], st[1], st[2], st[3])
+    return norm_stats(out, 0)
 
 
 # ---- deferred weight-gradient reduction -------------------------------------------------------------------------------
