@@ -18,6 +18,8 @@ from options.train_options import TrainOptions  # noqa: E402
 BASE = ("--gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False --checkpoints_dir /tmp/vts_rob --name r ")
 CASES = [
     ("skitG 1536 b1", "--model skitG --crop_size 1536 --batch_size 1", 1536, 1),
+    ("skitG 1536 b2 style project+concat", "--model skitG --crop_size 1536 --batch_size 2 --style_code_mapping_mode project", 1536, 2),
+    ("skitG 1536 b1 style project+adain", "--model skitG --crop_size 1536 --batch_size 1 --style_code_mapping_mode project --style_code_mode adain", 1536, 1),
     ("skitG 512 b8", "--model skitG --crop_size 512 --batch_size 8", 512, 8),
     ("sinskitG 768 b2", "--model sinskitG --crop_size 768 --batch_size 2", 768, 2),
     ("sinskitG lsgan", "--model sinskitG --crop_size 256 --batch_size 2 --gan_mode lsgan", 256, 2),
