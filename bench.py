@@ -1,7 +1,9 @@
 """Headline benchmark: train images/sec of one full G+D step at 1024x1024 (BASELINE.json configs[1]).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, the driver's form)
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (re-exec under
+torch.distributed.run on 127.0.0.1); rank 0 prints the line.
 
 A step = SKITGModel.optimize_parameters on one synthetic batch (4 images / GPU, 64 tactile
 patches each) that is already resident in HBM: generator forward, patch gather, D1 update,
@@ -289,6 +291,24 @@ def emit(line):
     os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: re-exec this command line under torch.distributed.run, one rank per GPU of this
+    node (rendezvous on 127.0.0.1, a free port).  Rank 0's JSON line reaches the real stdout through the inherited descriptor."""
+    import socket
+    import subprocess
+
+    if torch.cuda.device_count() < n:
+        raise SystemExit("bench.py: --gpus %d but this node exposes %d GPU(s)" % (n, torch.cuda.device_count()))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.dup2(_JSON_FD, 1)      # the children write the line themselves
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     global _JSON_FD
     sys.stdout.flush()
@@ -296,8 +316,9 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: the timed region is >= 1.5 s of steady state (20 steps = 0.14 s was too short for the driver's clock / gpu_busy sampling)
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU")
     ap.add_argument("--model", type=str, default="skitG")
@@ -314,12 +335,14 @@ def main():
     ap.add_argument("--detail", type=str, default=None, help="write a per-(kernel, shape) timing table to this path")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+
     from vts import ddp
 
     rank, world = ddp.init_from_env("cuda")
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus and not (world == 1 and ddp.FORCE):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(1234 + rank)      # per-rank DiffAugment draws (the default generator is seeded identically on every rank)
     if args.infer:
@@ -341,11 +364,16 @@ def main():
     for _ in range(args.warmup):
         model.optimize_parameters(epoch=1)
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step on the launch stream: spread, no sync
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         model.optimize_parameters(epoch=1)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    spread = {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1], "p90": per_step[int(0.9 * (len(per_step) - 1))]}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -364,12 +392,13 @@ def main():
             model.set_input(batches[i % 2], phase="train")
             model.optimize_parameters(epoch=1)
         barrier()
+        fresh_steps = min(args.steps, 100)
         tf = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(fresh_steps):
             model.set_input(batches[i % 2], phase="train")
             model.optimize_parameters(epoch=1)
         barrier()
-        fresh_ms = (time.perf_counter() - tf) / args.steps * 1e3
+        fresh_ms = (time.perf_counter() - tf) / fresh_steps * 1e3
         model.set_input(batch, phase="train")
     comm = None
     if world > 1:
@@ -409,7 +438,9 @@ def main():
         ms = dt / args.steps * 1e3
         out = {
             "metric": "train_images_per_sec", "value": world * args.batch * args.steps / dt, "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_fresh_input": fresh_ms, "higher_is_better": True,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_spread": {k: round(v, 4) for k, v in spread.items()},
+            "ms_per_step_fresh_input": fresh_ms, "images_per_sec_fresh_input": (args.batch * 1e3 / fresh_ms) if fresh_ms else None,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": ("pix2pixHD G+D+D2 train step (GlobalGenerator ngf 64, ndf 64), %d %dx%d images/GPU, VGG term off "

@@ -296,6 +296,38 @@ def test_inference_graph_replay_equals_eager_and_follows_new_inputs():
     assert not torch.equal(outs[2][0], outs[1][0])
 
 
+def test_validation_replay_between_training_replays_reads_its_own_outputs():
+    """train.py's loop: training steps replayed from HIP graphs, a validation test() in between (eager, then captured, then replayed).
+    After every test() the model's outputs / metrics must be the VALIDATION batch's -- a replayed training step rebinds fake_I / fake_T
+    to the training graphs' tensors, so the inference replay has to re-attach its own (round-2 advisor finding)."""
+    import random
+
+    from data.synthetic_dataset import make_sample
+    model, opt = make_model(256, 1)
+    load_test_weights(model, 21)
+    random.seed(3)
+    train_b = [default_collate([make_sample(256, 64, 64, 300 + i)]) for i in range(2)]
+    val_b = default_collate([make_sample(256, 16, 24, 77)])
+    for it in range(5):
+        model.train()
+        model.set_input(train_b[it % 2], phase="train")
+        model.optimize_parameters(epoch=1)
+        model.eval()
+        model.set_input(val_b, phase="val")
+        model.test()
+        got_I, got_T = model.fake_I.clone(), model.fake_T.clone()
+        got_m = model.compute_metrics()
+        # the same weights through an eager forward
+        keep, opt.use_hip_graph = opt.use_hip_graph, False
+        model.test()
+        opt.use_hip_graph = keep
+        assert torch.equal(got_I, model.fake_I) and torch.equal(got_T, model.fake_T), "validation %d read another batch's outputs" % it
+        ref_m = model.compute_metrics()
+        for k in ref_m:
+            assert got_m[k] == ref_m[k] or (got_m[k] != got_m[k] and ref_m[k] != ref_m[k]), (it, k, got_m[k], ref_m[k])
+    assert model._graphs is not None and model._infer_graph is not None     # both kinds of replay really happened
+
+
 def test_eval_metrics_match_oracle():
     """I_PSNR / T_AE / T_MSE kernels vs the oracle (pinned to the reference's compute_evaluation_metric), and through the model"""
     from data.synthetic_dataset import make_sample

@@ -54,6 +54,12 @@ struct ConvK {
   int stagger;      // start-up stagger in units of ~3.4 us (s_sleep 127): workgroup w of a co-resident set waits (w % 3) * stagger units
   unsigned long long* trace;   // profiling only (env VTS_CONV_TRACE): per workgroup 8 x 64-bit: hw id, then s_memrealtime (100 MHz) at the phase boundaries
   int tiles_x;      // tiles per row band; a workgroup walks the run [bx * tiles_x / gridDim.x, (bx + 1) * tiles_x / gridDim.x) of them
+  // round 3: statistics of the output fused into the direct epilogue.  Every WAVE writes (mean, M2, count) of its rows of the tile per
+  // output channel -- the partial format of stats_partial_kernel (vts_norm.hip), slot = (tile row * tiles_x + tile) * 4 + wave of
+  // stat_spl slots per (n, channel) -- and norm_finalize_kernel merges them (Chan) exactly as it merges the partials of the
+  // stand-alone statistics pass: the normalised layers lose one full read of their output and one launch.
+  float* stat_part;
+  int stat_spl;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -337,6 +343,58 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     const int onb = (int)((int64_t)p.Cout * oplane * 4);
     const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + n * p.ons), 0, onb, 0x00020000);
     const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? (int)((int64_t)p.dmC * oplane * 4) : 0, 0x00020000);
+    if (p.stat_part) {
+      // (the host enables this only without output activation / derivative mask / accumulation: the stored value is acc + bias)
+      // A lane holds RW x MT x P x 4 values of ONE channel (m16); the four kq lane groups of the wave hold the rest of the wave's rows.
+      const int slot = (by * p.tiles_x + tx0 / TX) * 4 + wave;
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr) {
+        const int co = co0 + nr * 16 + m16;
+        const float bias = p.bias ? p.bias[min(co, p.Cout - 1)] : 0.f;
+        float sum = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ph = 0; ph < P; ++ph)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4 + j;
+                const int y = P == 4 ? gy * 2 + (ph >> 1) : gy, x = P == 4 ? gx * 2 + (ph & 1) : gx;
+                const bool ok = y < p.OH && x < p.OW;
+                sum += ok ? acc[r][mt][ph][nr][j] + bias : 0.f;
+                cnt += ok ? 1.f : 0.f;
+              }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        cnt += __shfl_xor(cnt, 16, 64);
+        cnt += __shfl_xor(cnt, 32, 64);
+        const float mean = sum / fmaxf(cnt, 1.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ph = 0; ph < P; ++ph)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4 + j;
+                const int y = P == 4 ? gy * 2 + (ph >> 1) : gy, x = P == 4 ? gx * 2 + (ph & 1) : gx;
+                const float dv = acc[r][mt][ph][nr][j] + bias - mean;
+                m2 += (y < p.OH && x < p.OW) ? dv * dv : 0.f;
+              }
+        m2 += __shfl_xor(m2, 16, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        if (kq == 0 && co < p.Cout) {
+          float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
+          o[0] = mean;
+          o[1] = m2;
+          o[2] = cnt;
+        }
+      }
+    }
     auto emit = [&](int co, int y, int x, float bias, float dsc, float dsh, f32x4 v) {
       const bool ok = co < p.Cout && y < p.OH && x < p.OW;
       const bool full = ok && x + 4 <= p.OW;
@@ -672,6 +730,8 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_in_kernel(const ConvK
   }
 }
 
+thread_local int t_stat_spl = 0;   // statistics slots per (n, channel) of the last launch (conv4x4_impl -> vts_norm_finalize_partials)
+
 template <int MODE, int S, int NR, int RW, int MT, int CK>
 int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
@@ -679,6 +739,8 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   const int GH = P == 4 ? (k.OH + 1) / 2 : k.OH, GW = P == 4 ? (k.OW + 1) / 2 : k.OW;
   const int tiles_x = cdiv(GW, 16 * MT), tiles_y = cdiv(GH, 4 * RW);
   k.tiles_x = tiles_x;
+  k.stat_spl = tiles_x * tiles_y * 4;
+  t_stat_spl = k.stat_spl;
   // Tile runs: only where the per-tile chunk pipeline is too short to overlap anything (<= run_max_chunks chunks per tile) and
   // the grid stays several workgroups per CU deep after the cut.  VTS_TILE_RUN=<n> forces a run length (1 = one tile per workgroup).
   static const int run_force = getenv("VTS_TILE_RUN") ? atoi(getenv("VTS_TILE_RUN")) : 0;
@@ -752,17 +814,38 @@ extern "C" int64_t vts_conv4x4_ws_floats(const vts_conv_desc* d) {
   return (int64_t)ks_max * d->N * d->Cout * d->OH * d->OW;
 }
 
-static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused);
+struct StatWs {
+  float* p;
+  int64_t floats;
+};
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw);
+int vts_norm_finalize_partials(const vts_norm_desc* d, const float* part, int spl, hipStream_t st);   // vts_norm.hip
 
-extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) { return conv4x4_impl(d, stream, nullptr, nullptr); }
+extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) { return conv4x4_impl(d, stream, nullptr, nullptr, StatWs{nullptr, 0}); }
 
 extern "C" int vts_conv4x4_in(const vts_conv_desc* d, const vts_norm_desc* nd, int* fused, void* stream) {
   VTS_CHECK_ARG(nd && fused && nd->scale && nd->shift && nd->mode == 0, "vts_conv4x4_in: InstanceNorm descriptor with scale / shift outputs required");
   *fused = 0;
-  return conv4x4_impl(d, stream, nd, fused);
+  return conv4x4_impl(d, stream, nd, fused, StatWs{nullptr, 0});
 }
 
-static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused) {
+// worst case over the tile shapes of the dispatch table (smallest tile: 4 x 16 positions of the phase grid), 4 wave slots per tile
+extern "C" int64_t vts_conv4x4_norm_ws_floats(const vts_conv_desc* d) {
+  if (!d) return 0;
+  const bool ph4 = d->transposed && d->stride == 2;
+  const int GH = ph4 ? (d->OH + 1) / 2 : d->OH, GW = ph4 ? (d->OW + 1) / 2 : d->OW;
+  return (int64_t)d->N * d->Cout * 3 * 4 * cdiv(GH, 4) * cdiv(GW, 16);
+}
+
+extern "C" int vts_conv4x4_norm(const vts_conv_desc* d, const vts_norm_desc* nd, float* stat_ws, int64_t stat_ws_floats, int* fused, void* stream) {
+  VTS_CHECK_ARG(nd && fused && nd->scale && nd->shift && (nd->mode == 0 || nd->mode == 1), "vts_conv4x4_norm: norm descriptor with scale / shift outputs required");
+  *fused = 0;
+  return conv4x4_impl(d, stream, nd, fused, StatWs{stat_ws, stat_ws_floats});
+}
+
+static int dispatch_full(const vts_conv_desc* d, const ConvK& k, int nr, int N, hipStream_t st);
+
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw) {
   VTS_CHECK_ARG(d && d->in0.data && d->w && d->out, "vts_conv4x4: null pointer");
   VTS_CHECK_ARG(d->stride == 1 || d->stride == 2, "vts_conv4x4: stride %d unsupported", d->stride);
   VTS_CHECK_ARG(d->Cout >= 1, "vts_conv4x4: Cout %d", d->Cout);
@@ -782,7 +865,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
         g.dmask.scale = d->dmask.scale ? d->dmask.scale + c0 : nullptr;
         g.dmask.shift = d->dmask.shift ? d->dmask.shift + c0 : nullptr;
       }
-      const int rc = conv4x4_impl(&g, stream, nullptr, nullptr);
+      const int rc = conv4x4_impl(&g, stream, nullptr, nullptr, StatWs{nullptr, 0});
       if (rc != VTS_OK) return rc;
     }
     return VTS_OK;
@@ -825,7 +908,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   k.dm = d->dmask.data; k.dmsc = d->dmask.scale; k.dmsh = d->dmask.shift; k.dmns = d->dmask.nstride;
   k.dm_act = d->dmask_act; k.dmC = d->dmask.C;
   k.accumulate = d->accumulate;
-  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.trace = nullptr;
+  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.trace = nullptr; k.stat_part = nullptr; k.stat_spl = 0;
   static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
   k.ablate = ablate;
   static const int stagger = getenv("VTS_STAGGER") ? atoi(getenv("VTS_STAGGER")) : 0;
@@ -887,6 +970,21 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       return VTS_OK;
     }
   }
+  // statistics of the output in the epilogue (round 3): only the plain "store acc + bias" form through the direct epilogue
+  static const int fuse_stats = getenv("VTS_FUSE_STATS") ? atoi(getenv("VTS_FUSE_STATS")) : 1;
+  const bool want_stats = nd && fused && sw.p && fuse_stats && k.direct_epi && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
+                          nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride &&
+                          sw.floats >= vts_conv4x4_norm_ws_floats(d);
+  if (want_stats) k.stat_part = sw.p;
+  const int rc = dispatch_full(d, k, nr, N, st);
+  if (rc != VTS_OK || !want_stats) return rc;
+  const int rf = vts_norm_finalize_partials(nd, sw.p, t_stat_spl, st);
+  if (rf != VTS_OK) return rf;
+  *fused = 1;
+  return VTS_OK;
+}
+
+static int dispatch_full(const vts_conv_desc* d, const ConvK& k, int nr, int N, hipStream_t st) {
 #define VTS_DISPATCH(MODE, S, RW1, MT1, RW2, MT2, RW3, MT3, RW4, MT4, RW5, MT5) \
   switch (nr) {                                                                 \
     case 1: return launch<MODE, S, 1, RW1, MT1, 4>(k, N, st);                   \

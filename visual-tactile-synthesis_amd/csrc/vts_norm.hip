@@ -713,6 +713,24 @@ extern "C" int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream) {
   return VTS_OK;
 }
 
+// second stage of vts_norm_stats on partials produced elsewhere (the convolution's epilogue, vts_conv.hip): `spl` (mean, M2, count)
+// slots per (n, channel) in the layout of stats_partial_kernel
+int vts_norm_finalize_partials(const vts_norm_desc* d, const float* part, int spl, hipStream_t st) {
+  VTS_CHECK_ARG(d && d->scale && d->shift && part && spl >= 1, "vts_norm_finalize_partials: null pointer");
+  NormK k{d->N, d->C, d->HW, spl, d->mode, d->eps, d->momentum, d->gamma, d->beta, d->running_mean, d->running_var,
+          d->num_batches_tracked, d->scale, d->shift, d->mean_out, d->rstd_out};
+  int maxg = d->N;
+  if (!fill_groups(d->mode, d->N, d->ngroups, d->gstart, k.ngroups, k.gstart, maxg)) {
+    vts_set_error("vts_norm_finalize_partials: bad pass groups (ngroups %d)", d->ngroups);
+    return VTS_ERR_ARG;
+  }
+  k.stat_mean = d->stat_mean_out; k.stat_uvar = d->stat_uvar_out; k.ext_mean = d->ext_mean; k.ext_uvar = d->ext_uvar; k.ext_after = d->ext_after;
+  VTS_CHECK_ARG(!(k.ext_mean && !k.ext_uvar) && !(k.stat_mean && !k.stat_uvar), "vts_norm_finalize_partials: ext / stat outputs come in pairs");
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, part, k);
+  VTS_CHECK_LAUNCH("vts_norm_finalize_partials");
+  return VTS_OK;
+}
+
 extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream) {
   VTS_CHECK_ARG(d && d->dy && d->x && d->mean && d->rstd && ws, "vts_norm_bwd: null pointer");
   VTS_CHECK_ARG(d->mode == 0 || d->mode == 1, "vts_norm_bwd: mode %d", d->mode);

@@ -123,7 +123,7 @@ class Pix2PixHDModel(BaseModel):
     def _drop_graphs(self):
         if self._graphs is not None:
             self._graphs = None
-            ops.FROZEN_WS = False
+            ops.release_ws((id(self), "train"))
 
     def _load(self, name, host):
         t = torch.as_tensor(host)
@@ -219,7 +219,7 @@ class Pix2PixHDModel(BaseModel):
         stream = torch.cuda.Stream()
         counts = [o.step_count for o in self.optimizers]
         graphs = []
-        ops.FROZEN_WS = True
+        ops.freeze_ws((id(self), "train"))
         try:
             for seg, _, _ in self._segments():
                 g = torch.cuda.CUDAGraph()
@@ -227,7 +227,7 @@ class Pix2PixHDModel(BaseModel):
                     seg()
                 graphs.append(g)
         except Exception:
-            ops.FROZEN_WS = False
+            ops.release_ws((id(self), "train"))
             raise
         for o, c in zip(self.optimizers, counts):
             o.step_count = c

@@ -251,6 +251,9 @@ class SinSKITGModel(BaseModel):
             buf = self._bufs.get("%s_stage%d" % (name, par))
             if buf is None or tuple(buf.shape) != tuple(t.shape) or buf.dtype != dtype:     # staging buffers are not read by graphs: no _drop_graphs
                 buf = self._bufs["%s_stage%d" % (name, par)] = torch.empty(tuple(t.shape), dtype=dtype, device=self.device)
+                # the caching allocator may hand back a block whose earlier launch-stream users are still queued: the copy stream
+                # writes it right away, so it waits once for the launch stream (first allocation / re-allocation only)
+                self._copy_stream.wait_stream(torch.cuda.current_stream())
         else:
             buf = self._buf(name, t.shape, dtype)
         src = t
@@ -479,15 +482,25 @@ class SinSKITGModel(BaseModel):
             if not getattr(self.opt, "use_hip_graph", False) or self._draws is not None:
                 return self.forward(keep=False)
             if self._infer_graph is not None:
-                return self._infer_graph.replay()
+                self._infer_graph.replay()
+                # a training replay in between rebinds fake_I / fake_T / ... to the TRAINING graphs' tensors (_graph_attrs):
+                # re-attach the tensors this graph writes, or metrics / visuals of a validation pass would read the last training batch
+                self.__dict__.update(self._infer_attrs)
+                return
             if self._infer_eager_done:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                ops.FROZEN_WS = True
-                with torch.cuda.graph(g, stream=torch.cuda.Stream(), capture_error_mode="thread_local"):
-                    self.forward(keep=False)
+                ops.freeze_ws((id(self), "infer"))
+                try:
+                    with torch.cuda.graph(g, stream=torch.cuda.Stream(), capture_error_mode="thread_local"):
+                        self.forward(keep=False)
+                except Exception:
+                    ops.release_ws((id(self), "infer"))
+                    raise
                 self._infer_graph = g
-                return g.replay()
+                self._infer_attrs = {k: getattr(self, k) for k in self._INFER_OUTPUTS if hasattr(self, k)}
+                g.replay()
+                return
             self.forward(keep=False)
             self._infer_eager_done = True
 
@@ -721,9 +734,12 @@ class SinSKITGModel(BaseModel):
 
     def _drop_graphs(self):
         self._infer_graph, self._infer_eager_done = None, False
+        ops.release_ws((id(self), "infer"))
         if getattr(self, "_graphs", None) is not None:
             self._graphs = None
-            ops.FROZEN_WS = False
+            ops.release_ws((id(self), "train"))
+
+    _INFER_OUTPUTS = ("g_out", "fake_I", "fake_T", "fake_N", "fake_gx", "fake_gy", "aug_fake_I", "aug_real_I", "_full_stack", "_g_ctx")
 
     _STEP_OUTPUTS = ("g_out", "fake_I", "fake_T", "fake_N", "fake_gx", "fake_gy", "aug_fake_I", "aug_real_I", "_full_stack", "_stack_all",
                      "_fake_stack", "_real_stack", "_more_stack", "fake_T_concat", "pred_fake_I", "pred_fake_T_full", "_g_ctx",
@@ -737,7 +753,7 @@ class SinSKITGModel(BaseModel):
         stream = torch.cuda.Stream()
         counts = [o.step_count for o in self.optimizers]
         graphs = []
-        ops.FROZEN_WS = True
+        ops.freeze_ws((id(self), "train"))
         try:
             for seg, _, _ in self._segments():
                 g = torch.cuda.CUDAGraph()
@@ -745,7 +761,7 @@ class SinSKITGModel(BaseModel):
                     seg()
                 graphs.append(g)
         except Exception:
-            ops.FROZEN_WS = False
+            ops.release_ws((id(self), "train"))
             raise
         for o, c in zip(self.optimizers, counts):
             o.step_count = c   # host mirrors moved during capture; the device counters did not

@@ -719,8 +719,14 @@ class SideQueue:
             return fn()
         self.stream.wait_stream(self.main)
         lane, ops.WS_LANE = ops.WS_LANE, SideQueue.LANE
-        with torch.cuda.stream(self.stream):
-            fn()
+        try:
+            with torch.cuda.stream(self.stream):
+                fn()
+        except BaseException:
+            ops.WS_LANE = lane
+            ops.wgrad_discard()
+            self.main.wait_stream(self.stream)
+            raise
         ops.WS_LANE = lane
         self.keep.extend(tensors)
 
@@ -751,16 +757,22 @@ def _run_lanes(n_lanes, body):
         side.append(torch.cuda.Stream())
     for st in side[:n_lanes - 1]:
         st.wait_stream(main)
-    for lane in range(1, n_lanes):
-        ops.WS_LANE = lane
-        with torch.cuda.stream(side[lane - 1]):
-            body(lane)
-            ops.wgrad_flush(lane)       # deferred weight-gradient reductions of this lane, on its own stream
-    ops.WS_LANE = 0
-    body(0)
-    ops.wgrad_flush(0)
-    for st in side[:n_lanes - 1]:
-        main.wait_stream(st)
+    try:
+        for lane in range(1, n_lanes):
+            ops.WS_LANE = lane
+            with torch.cuda.stream(side[lane - 1]):
+                body(lane)
+                ops.wgrad_flush(lane)       # deferred weight-gradient reductions of this lane, on its own stream
+        ops.WS_LANE = 0
+        body(0)
+        ops.wgrad_flush(0)
+    except BaseException:
+        ops.WS_LANE = 0
+        ops.wgrad_discard()                 # a lane body raised: no stale partial jobs for the next backward
+        raise
+    finally:
+        for st in side[:n_lanes - 1]:       # the side streams are joined back in every case (a capture must not end with a dangling fork)
+            main.wait_stream(st)
 
 
 def _pyramid(D, in0, in1):

@@ -72,7 +72,7 @@ def workspace(nfloats, device):
     key = (str(device), WS_LANE)   # one scratch per concurrent lane (engine._run_lanes / SideQueue)
     t = _ws.get(key)
     if t is None or t.numel() < nfloats:
-        if t is not None and FROZEN_WS:
+        if t is not None and frozen_ws():
             _retired.append(t)   # captured HIP graphs hold the old pointer: keep that buffer alive, never reuse it
         t = torch.empty(max(int(nfloats), 2 * (t.numel() if t is not None else 0), 1 << 20), dtype=torch.float32, device=device)
         _ws[key] = t
@@ -101,7 +101,24 @@ def counters(device):
     return t
 
 
-FROZEN_WS = False  # set while HIP graphs that captured the workspace pointer are alive
+# The workspace is frozen (a grown buffer is retired, never freed) while any captured HIP graph that holds its pointer is alive.
+# Ownership is tracked per holder (a model's training graphs, its inference graph, another model's graphs ...): a bare boolean was
+# cleared by whichever model dropped its graphs first while another still replayed graphs with the old pointer.
+_WS_HOLDERS = set()
+
+
+def freeze_ws(owner):
+    _WS_HOLDERS.add(owner)
+
+
+def release_ws(owner):
+    _WS_HOLDERS.discard(owner)
+
+
+def frozen_ws():
+    return bool(_WS_HOLDERS)
+
+
 WS_LANE = 0        # which scratch buffer the wrappers use: 0 = the launch stream, i = side lane i (engine._run_lanes)
 
 
@@ -245,6 +262,15 @@ def wgrad_flush(lane=None):
             a.reset()
 
 
+def wgrad_discard():
+    """drop every pending partial job and rewind the arenas (exceptional exit of a backward: nothing is reduced)"""
+    global _pending
+    _pending = []
+    _pending_by_dw.clear()
+    for a in _arenas.values():
+        a.reset()
+
+
 def wgrad_pending_bytes(lane):
     return sum(4.0 * pw * q["nel"] for q in _pending if q["lane"] == lane for _, pw in q["segs"])
 
@@ -258,8 +284,11 @@ class deferred_wgrad:
     def __exit__(self, exc_type, exc, tb):
         global _DEFER_DEPTH
         _DEFER_DEPTH -= 1
-        if _DEFER_DEPTH == 0 and exc_type is None:
-            wgrad_flush()
+        if _DEFER_DEPTH == 0:
+            if exc_type is None:
+                wgrad_flush()
+            else:
+                wgrad_discard()     # a failed backward must not leave stale partial jobs for the next one to reduce
         return False
 
 
