@@ -187,6 +187,16 @@ int vts_norm_stats(const vts_norm_desc* d, float* ws, void* stream);
  * *fused = 1; otherwise the convolution runs as vts_conv4x4, *fused = 0 and the caller calls vts_norm_stats.  nd: mode 0, x = d->out. */
 int vts_conv4x4_in(const vts_conv_desc* d, const vts_norm_desc* nd, int* fused, void* stream);
 
+/* The general form (round 3): convolution + InstanceNorm (mode 0) or training-mode BatchNorm (mode 1: pass groups, running statistics,
+ * recorded / spliced statistics exactly as vts_norm_stats) of its output.  On top of the k-split fusion of vts_conv4x4_in, the tiled
+ * kernel's epilogue emits per-wave (mean, M2, count) partials of the values it stores into stat_ws (vts_conv4x4_norm_ws_floats floats)
+ * and only the merging second stage of vts_norm_stats runs afterwards: the layer's output is not read again for its statistics
+ * (Down / Up blocks as above; Conv2d -> BatchNorm2d of NLayerDiscriminator, models/networks.py:1716-1738).  *fused = 0: the
+ * convolution ran as vts_conv4x4 (small-map / thin / head members, output activation, mask or accumulation) and the caller calls
+ * vts_norm_stats. */
+int64_t vts_conv4x4_norm_ws_floats(const vts_conv_desc* d);
+int vts_conv4x4_norm(const vts_conv_desc* d, const vts_norm_desc* nd, float* stat_ws, int64_t stat_ws_floats, int* fused, void* stream);
+
 /* Backward of the same normalisation (in place on dy):
  *   dx = A*dy + B*x + C  with the per-group coefficients of InstanceNorm / BatchNorm backward;
  * BN additionally writes dgamma/dbeta (accumulate flag).  */

@@ -316,6 +316,85 @@ def test_norm_forward_backward(shape, mode, fuse_finalize):
         assert rel(dg, gamma.grad) < 1e-4 and rel(db, beta.grad) < 1e-4
 
 
+FUSED_NORM_CASES = [
+    # (N, Cin, Cout, H, W, stride, pad, transposed, mode, groups, offset)
+    (2, 10, 20, 256, 256, 2, 1, False, 0, None, 0.0),      # down1-like: tiled kernel, NR 2
+    (1, 20, 40, 200, 136, 2, 1, False, 0, None, 0.0),      # ragged edges in both directions, NR 3
+    (2, 40, 10, 130, 150, 2, 1, True, 0, None, 0.0),       # up1-like: four parity phases, NR 1
+    (1, 80, 20, 96, 100, 2, 1, True, 0, None, 0.0),        # up2-like, NR 2
+    (4, 8, 16, 259, 257, 2, 2, False, 1, [0, 1, 3], 0.0),  # D layer 1: BatchNorm over pass groups, pad 2 (odd output size 130 x 129)
+    (2, 16, 32, 131, 129, 2, 2, False, 1, None, 0.0),      # D layer 2
+    (2, 32, 64, 129, 130, 1, 2, False, 1, [0, 1], 0.0),    # D layer 3: stride 1, NR 4
+    (2, 10, 20, 256, 256, 2, 1, False, 0, None, 40.0),     # |mean| >> sigma: the per-wave two-pass partials must stay robust
+    (1, 160, 80, 32, 32, 2, 1, True, 0, None, 0.0),        # inner layer: k-split epilogue fusion (InstanceNorm only)
+    (3, 32, 64, 20, 20, 1, 2, False, 1, None, 0.0),        # small grid + BatchNorm: must NOT take the InstanceNorm k-split fusion
+]
+
+
+@pytest.mark.parametrize("case", FUSED_NORM_CASES)
+def test_conv_with_statistics_from_the_epilogue(case):
+    """vts_conv4x4_norm: the statistics the convolution's epilogue emits (per-wave partials merged by the second stage of
+    vts_norm_stats) against the stand-alone statistics pass on the same output and against F.instance_norm / F.batch_norm of a
+    PyTorch evaluation of the convolution: scale / shift, saved mean / rstd, running statistics, num_batches_tracked"""
+    from vts import lib as L, ops
+
+    dev = _dev()
+    N, Cin, Cout, H, W, stride, pad, transposed, mode, groups, offset = case
+    x = detrand.uniform((N, Cin, H, W), 31, "x")
+    wshape = (Cin, Cout, 4, 4) if transposed else (Cout, Cin, 4, 4)
+    w = detrand.uniform(wshape, 31, "w") * (1.0 / (Cin * 16) ** 0.5)
+    b = 0.1 * detrand.uniform((Cout,), 31, "b") + offset
+    if transposed:
+        ref = F.conv_transpose2d(F.leaky_relu(x, 0.2), w, b, stride=stride, padding=pad)
+    else:
+        ref = F.conv2d(F.leaky_relu(x, 0.2), w, b, stride=stride, padding=pad)
+    OH, OW = ref.shape[2:]
+    gamma, beta = 1 + 0.2 * detrand.uniform((Cout,), 31, "g"), 0.1 * detrand.uniform((Cout,), 31, "bt")
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+
+    def run(fuse):
+        import os
+        out = torch.empty(N, Cout, OH, OW, device=dev)
+        rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        nbt = torch.zeros((), dtype=torch.long, device=dev)
+        kw = dict(gamma=gamma.to(dev), beta=beta.to(dev), running_mean=rm, running_var=rv, nbt=nbt, groups=groups) if mode else None
+        args = (16, Cout * 16) if transposed else (Cin * 16, 16)
+        if fuse:
+            calls, keep = [], ops.norm_stats
+            ops.norm_stats = lambda *a_, **k_: (calls.append(1), keep(*a_, **k_))[1]
+            try:
+                a = ops.conv4x4(xd, wd, args[0], args[1], Cout, out, bias=bd, stride=stride, pad=pad, transposed=transposed, act_in=L.ACT_LRELU,
+                                instance_norm=mode == 0, batch_norm=kw)
+            finally:
+                ops.norm_stats = keep
+            kern = "standalone" if calls else "fused"
+        else:
+            ops.conv4x4(xd, wd, args[0], args[1], Cout, out, bias=bd, stride=stride, pad=pad, transposed=transposed, act_in=L.ACT_LRELU)
+            a = ops.norm_stats(out, mode, **(kw or {}))
+            kern = ""
+        return out, a, rm, rv, nbt, kern
+
+    out_f, a_f, rm_f, rv_f, nbt_f, kern = run(True)
+    out_u, a_u, rm_u, rv_u, nbt_u, _ = run(False)
+    assert torch.equal(out_f, out_u)                        # the convolution itself is untouched by the fusion
+    assert rel(out_f, ref) < 1e-5
+    # against the stand-alone pass: same Chan merge, other partition of the plane -> equal to rounding
+    for name in ("scale", "shift", "mean", "rstd"):
+        assert rel(getattr(a_f, name), getattr(a_u, name)) < 2e-6, name
+    # against PyTorch
+    bounds = (list(groups) if groups else [0]) + [N]
+    if mode == 0:
+        y = F.instance_norm(ref, eps=1e-5)
+    else:
+        rm, rv = torch.zeros(Cout), torch.ones(Cout)
+        y = torch.cat([F.batch_norm(ref[bounds[i]:bounds[i + 1]], rm, rv, gamma, beta, True, 0.1, 1e-5) for i in range(len(bounds) - 1)])
+        assert rel(rm_f, rm) < 1e-5 and rel(rv_f, rv) < 1e-5 and int(nbt_f) == len(bounds) - 1 == int(nbt_u)
+    yk = out_f * a_f.scale.view(N, Cout, 1, 1) + a_f.shift.view(N, Cout, 1, 1)
+    assert rel(yk, y) < (2e-4 if offset else 1e-5)
+    # no stand-alone statistics pass followed, except where a BatchNorm layer runs on the small-grid (k-split) path
+    assert kern == ("standalone" if (mode == 1 and OH * OW <= 4096) else "fused"), kern
+
+
 @pytest.mark.parametrize("shape,groups", [((7, 6, 9, 9), [0, 3, 5]), ((5, 4, 70, 61), [0, 2]), ((640, 8, 5, 5), [0, 256, 384]),
                                           ((6, 3, 150, 140), [0, 1, 4])])
 def test_batchnorm_batched_passes_equal_sequential_calls(shape, groups):

@@ -72,7 +72,7 @@ __device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
 
 // Output staging region of one epilogue pass: 16 output channels x ER rows x EC columns, plane pitch odd
 // so that the 16 channel planes land on distinct LDS banks.
-template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN>
+template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN, bool STATS>
 __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
   constexpr int TY = 4 * RW, TX = 16 * MT;
@@ -343,54 +343,46 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     const int onb = (int)((int64_t)p.Cout * oplane * 4);
     const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + n * p.ons), 0, onb, 0x00020000);
     const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? (int)((int64_t)p.dmC * oplane * 4) : 0, 0x00020000);
-    if (p.stat_part) {
+    if (STATS) {
       // (the host enables this only without output activation / derivative mask / accumulation: the stored value is acc + bias)
       // A lane holds RW x MT x P x 4 values of ONE channel (m16); the four kq lane groups of the wave hold the rest of the wave's rows.
+      // One pass over the accumulators: sum and sum of squares of the values BEFORE the bias (the variance does not see a constant,
+      // so a large bias costs no precision; what is left of |mean| / sigma inside a wave's 64 .. 512 values is what a convolution of
+      // zero-mean-ish weights produces), M2 = q - s * mean.  The Chan merge of the second stage handles the spread BETWEEN partials.
       const int slot = (by * p.tiles_x + tx0 / TX) * 4 + wave;
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr) {
         const int co = co0 + nr * 16 + m16;
-        const float bias = p.bias ? p.bias[min(co, p.Cout - 1)] : 0.f;
-        float sum = 0.f, cnt = 0.f;
+        float sum = 0.f, sq = 0.f, cnt = 0.f;
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int ph = 0; ph < P; ++ph)
+            for (int ph = 0; ph < P; ++ph) {
+              const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
+              const int y = P == 4 ? gy * 2 + (ph >> 1) : gy, x = P == 4 ? gx * 2 + (ph & 1) : gx;
+              const int nv = y < p.OH ? min(4, P == 4 ? (p.OW - x + 1) >> 1 : p.OW - x) : 0;   // valid elements of this lane's 4-vector
+              const f32x4 a = acc[r][mt][ph][nr];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4 + j;
-                const int y = P == 4 ? gy * 2 + (ph >> 1) : gy, x = P == 4 ? gx * 2 + (ph & 1) : gx;
-                const bool ok = y < p.OH && x < p.OW;
-                sum += ok ? acc[r][mt][ph][nr][j] + bias : 0.f;
-                cnt += ok ? 1.f : 0.f;
+                const float v = j < nv ? a[j] : 0.f;
+                sum += v;
+                sq = fmaf(v, v, sq);
               }
+              cnt += (float)max(nv, 0);
+            }
         sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sq += __shfl_xor(sq, 16, 64);
         cnt += __shfl_xor(cnt, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
         cnt += __shfl_xor(cnt, 32, 64);
-        const float mean = sum / fmaxf(cnt, 1.f);
-        float m2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int ph = 0; ph < P; ++ph)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4 + j;
-                const int y = P == 4 ? gy * 2 + (ph >> 1) : gy, x = P == 4 ? gx * 2 + (ph & 1) : gx;
-                const float dv = acc[r][mt][ph][nr][j] + bias - mean;
-                m2 += (y < p.OH && x < p.OW) ? dv * dv : 0.f;
-              }
-        m2 += __shfl_xor(m2, 16, 64);
-        m2 += __shfl_xor(m2, 32, 64);
         if (kq == 0 && co < p.Cout) {
+          const float mean = sum / fmaxf(cnt, 1.f);
           float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
-          o[0] = mean;
-          o[1] = m2;
+          o[0] = mean + (p.bias ? p.bias[co] : 0.f);
+          o[1] = fmaxf(sq - sum * mean, 0.f);
           o[2] = cnt;
         }
       }
@@ -771,10 +763,17 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
     }
   }
   k.trace = trace_dev;
-  if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2)>), grid, dim3(256), 0, st, k);
-  else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false>), grid, dim3(256), 0, st, k);
-  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d, %s>%s", MODE, S, NR, RW, MT, CK, (run > 1 && NR <= 2) ? "true" : "false",   // as rocprofv3 names the instance
-                 KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
+  // (the statistics epilogue is its own instantiation: inside the shared one it raised the register count of EVERY launch of the
+  //  template -- e.g. 110 -> 199 VGPRs and occupancy 2 -> 1 on the 40 -> 10 transposed layer -- whether statistics were asked for or not)
+  if (k.stat_part) {
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, true>), grid, dim3(256), 0, st, k);
+  } else {
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), false>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, false>), grid, dim3(256), 0, st, k);
+  }
+  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d, %s, %s>%s", MODE, S, NR, RW, MT, CK, (run > 1 && NR <= 2) ? "true" : "false",   // as rocprofv3 names the instance
+                 k.stat_part ? "true" : "false", KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
   VTS_CHECK_LAUNCH("vts_conv4x4");
   if (trace_dev) {
     (void)hipStreamSynchronize(st);
@@ -929,6 +928,11 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   hipStream_t st = (hipStream_t)stream;
   const int nr = (d->Cout + 15) / 16;
   const int N = d->N;
+  // statistics of the output in the epilogue (round 3): only the plain "store acc + bias" form through the direct epilogue
+  static const int fuse_stats = getenv("VTS_FUSE_STATS") ? atoi(getenv("VTS_FUSE_STATS")) : 1;
+  const bool want_stats = nd && fused && sw.p && fuse_stats && k.direct_epi && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
+                          nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride &&
+                          sw.floats >= vts_conv4x4_norm_ws_floats(d);
   {
     // Small grids (inner U-Net layers: <= 32x32 maps, 80..592 channels) cannot fill 256 CUs with one
     // workgroup per spatial tile: split the output channels over workgroups (no reduction needed) and,
@@ -951,17 +955,24 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       const int64_t need = (int64_t)KS * N * d->Cout * d->OH * d->OW;
       if (KS > 1 && (!d->ws || d->ws_floats < need)) { KS = 1; cps = nchunks; }
       k.CG = nr; k.cps = cps; k.part = KS > 1 ? d->ws : nullptr;
+      const bool cg_stats = want_stats && KS == 1;    // output-channel split only: every workgroup still stores final values
+      if (cg_stats) k.stat_part = sw.p;
       int rc;
       if (!d->transposed) rc = d->stride == 2 ? launch<0, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<0, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
       else rc = d->stride == 2 ? launch<1, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<1, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
+      if (rc == VTS_OK && cg_stats) {
+        const int rf = vts_norm_finalize_partials(nd, sw.p, t_stat_spl, st);
+        if (rf != VTS_OK) return rf;
+        *fused = 1;
+      }
       if (rc != VTS_OK || KS == 1) return rc;
       static const int fuse_in = getenv("VTS_FUSE_SPLIT_IN") ? atoi(getenv("VTS_FUSE_SPLIT_IN")) : 1;
-      if (nd && fuse_in && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
+      if (nd && nd->mode == 0 && fuse_in && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
           nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride) {
         const InStatsOut q{nd->scale, nd->shift, nd->mean_out, nd->rstd_out, nd->eps};
         hipLaunchKernelGGL(conv_split_epilogue_in_kernel, dim3(N * d->Cout), dim3(256), 0, st, k, KS, q);
         VTS_CHECK_LAUNCH("vts_conv4x4 split epilogue + instance norm");
-        vts_set_kernel("conv4x4_kernel<%d, %d, 1, 1, 2, 4, false>+ksplit+in", d->transposed ? 1 : 0, d->stride);
+        vts_set_kernel("conv4x4_kernel<%d, %d, 1, 1, 2, 4, false, false>+ksplit+in", d->transposed ? 1 : 0, d->stride);
         *fused = 1;
         return VTS_OK;
       }
@@ -970,11 +981,6 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       return VTS_OK;
     }
   }
-  // statistics of the output in the epilogue (round 3): only the plain "store acc + bias" form through the direct epilogue
-  static const int fuse_stats = getenv("VTS_FUSE_STATS") ? atoi(getenv("VTS_FUSE_STATS")) : 1;
-  const bool want_stats = nd && fused && sw.p && fuse_stats && k.direct_epi && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
-                          nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride &&
-                          sw.floats >= vts_conv4x4_norm_ws_floats(d);
   if (want_stats) k.stat_part = sw.p;
   const int rc = dispatch_full(d, k, nr, N, st);
   if (rc != VTS_OK || !want_stats) return rc;

@@ -169,6 +169,73 @@ __device__ __forceinline__ void norm_finalize_group(const volatile float* part, 
 
 __global__ __launch_bounds__(64) void norm_finalize_kernel(const float* __restrict__ part, const NormK k) { norm_finalize_group(part, k, blockIdx.x); }
 
+// The same second stage for MANY partials per group (round 3: the convolution's epilogue emits one partial per wave and tile, i.e.
+// 1 000 .. 10 000 per group instead of HW / 2048): a 256-thread workgroup per group, plain (cached) loads, two block reductions per
+// pass group.  Fixed order -> deterministic.
+__global__ __launch_bounds__(256) void norm_finalize_wide_kernel(const float* __restrict__ part, const NormK k) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  if (k.mode == 0) {
+    const int g = blockIdx.x;
+    const float* q0 = part + (int64_t)g * k.spl * 3;
+    float sn = 0.f, sm = 0.f;
+    for (int i = tid; i < k.spl; i += 256) {
+      sn += q0[i * 3 + 2];
+      sm += q0[i * 3 + 2] * q0[i * 3];
+    }
+    sn = block_sum(sn, red);
+    sm = block_sum(sm, red);
+    const float mean = sm / sn;
+    float acc = 0.f;
+    for (int i = tid; i < k.spl; i += 256) {
+      const float d = q0[i * 3] - mean;
+      acc += q0[i * 3 + 1] + q0[i * 3 + 2] * d * d;
+    }
+    const float m2 = block_sum(acc, red);
+    if (tid == 0) {
+      const float rstd = 1.f / sqrtf(m2 / sn + k.eps);
+      k.scale[g] = rstd;
+      k.shift[g] = -mean * rstd;
+      if (k.mean_out) k.mean_out[g] = mean;
+      if (k.rstd_out) k.rstd_out[g] = rstd;
+    }
+    return;
+  }
+  const int c = blockIdx.x;
+  for (int gi = 0; gi < k.ngroups; ++gi) {
+    const int n0 = k.gstart[gi], n1 = k.gstart[gi + 1];
+    const int np = (n1 - n0) * k.spl;
+    float sn = 0.f, sm = 0.f;
+    for (int i = tid; i < np; i += 256) {
+      const int n = n0 + i / k.spl, s = i - (i / k.spl) * k.spl;
+      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+      sn += q[2];
+      sm += q[2] * q[0];
+    }
+    sn = block_sum(sn, red);
+    sm = block_sum(sm, red);
+    const float mean = sm / sn;
+    float acc = 0.f;
+    for (int i = tid; i < np; i += 256) {
+      const int n = n0 + i / k.spl, s = i - (i / k.spl) * k.spl;
+      const float* q = part + (((int64_t)n * k.C + c) * k.spl + s) * 3;
+      const float d = q[0] - mean;
+      acc += q[1] + q[2] * d * d;
+    }
+    const float m2 = block_sum(acc, red);
+    const float rstd = 1.f / sqrtf(m2 / sn + k.eps);
+    const float g = k.gamma ? k.gamma[c] : 1.f, b = k.beta ? k.beta[c] : 0.f;
+    for (int n = n0 + tid; n < n1; n += 256) {
+      const int idx = n * k.C + c;
+      k.scale[idx] = g * rstd;
+      k.shift[idx] = b - mean * g * rstd;
+      if (k.mean_out) k.mean_out[idx] = mean;
+      if (k.rstd_out) k.rstd_out[idx] = rstd;
+    }
+    if (tid == 0) after_group(k, c, gi, mean, m2 / (sn - 1.f));
+  }
+}
+
 __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, int64_t nstride, int C, int HW, int spl,
                                                             float* __restrict__ part) {
   stats_partial_body(x, nstride, C, HW, spl, part);
@@ -726,7 +793,7 @@ int vts_norm_finalize_partials(const vts_norm_desc* d, const float* part, int sp
   }
   k.stat_mean = d->stat_mean_out; k.stat_uvar = d->stat_uvar_out; k.ext_mean = d->ext_mean; k.ext_uvar = d->ext_uvar; k.ext_after = d->ext_after;
   VTS_CHECK_ARG(!(k.ext_mean && !k.ext_uvar) && !(k.stat_mean && !k.stat_uvar), "vts_norm_finalize_partials: ext / stat outputs come in pairs");
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(64), 0, st, part, k);
+  hipLaunchKernelGGL(norm_finalize_wide_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(256), 0, st, part, k);
   VTS_CHECK_LAUNCH("vts_norm_finalize_partials");
   return VTS_OK;
 }

@@ -219,7 +219,12 @@ int vts_patchnce_mfma(const float* q, const float* k, int B, int P, int D, float
   const size_t sm = (RB * LP + stage + RB) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)patchnce_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // 160 KB of dynamic LDS is the whole CU: a refusal here must not pass silently (the launch below would then fail or be clipped)
+    const hipError_t ea = hipFuncSetAttribute((const void*)patchnce_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (ea != hipSuccess) {
+      vts_set_error("vts_patchnce (mfma): hipFuncSetAttribute(max dynamic LDS 160 KB) failed: %s", hipGetErrorString(ea));
+      return VTS_ERR_LAUNCH;
+    }
     attr = true;
   }
   hipLaunchKernelGGL(patchnce_mfma_kernel, dim3(cdiv(P, RB), B), dim3(256), sm, st, q, k, P, D, 1.f / T, gscale, loss, dq);

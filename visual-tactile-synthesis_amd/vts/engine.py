@@ -835,19 +835,26 @@ def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None, groups=None, stat
             p = ops.pad_affine(cur0, (2, ph - h - 2, 2, pw - w - 2), 0, act=LRELU)
             cur0.padded = p
             ops.conv4x4_wide(p, _packed4(conv, "conv_fwd", cache), conv.bias, out, stride=st)
+            flat = True
         else:
-            ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
-                        act_in=LRELU if j else 0)
+            flat = False
+        bnkw = None
         if ci in D.BN_IDX:
             bn = getattr(layer, str(D.BN_IDX[ci]))
             stat_out = None
             if stat_rec is not None:
                 stat_out = stat_rec[ci] = (torch.empty(cout, dtype=torch.float32, device=dev), torch.empty(cout, dtype=torch.float32, device=dev))
-            a = ops.norm_stats(out, 1, gamma=bn.weight, beta=bn.bias,
-                               running_mean=bn.running_mean if update_stats else None,
-                               running_var=bn.running_var if update_stats else None,
-                               nbt=bn.num_batches_tracked if update_stats else None, groups=groups, stat_out=stat_out,
-                               ext=(ext[0][ci][0], ext[0][ci][1], ext[1]) if ext is not None else None)
+            bnkw = dict(gamma=bn.weight, beta=bn.bias, running_mean=bn.running_mean if update_stats else None,
+                        running_var=bn.running_var if update_stats else None,
+                        nbt=bn.num_batches_tracked if update_stats else None, groups=groups, stat_out=stat_out,
+                        ext=(ext[0][ci][0], ext[0][ci][1], ext[1]) if ext is not None else None)
+        if not flat:     # Conv2d -> BatchNorm2d: the statistics come out of the convolution's epilogue where the tiled kernel runs
+            a = ops.conv4x4(cur0, conv.weight, cin * 16, 16, cout, out, in1=cur1, bias=conv.bias, stride=st, pad=2,
+                            act_in=LRELU if j else 0, batch_norm=bnkw)
+            if bnkw is None:
+                a = Act(out)
+        elif bnkw is not None:
+            a = ops.norm_stats(out, 1, **bnkw)
         else:
             a = Act(out)
         acts.append(a)

@@ -132,11 +132,29 @@ def _op(a):
     return L.operand(a)
 
 
+_stat_ws = {}
+
+
+def stat_workspace(nfloats, device):
+    """scratch for the epilogue statistics partials of vts_conv4x4_norm: one per lane, separate from `workspace` (the k-split
+    partials of the same call live there)"""
+    key = (str(device), WS_LANE)
+    t = _stat_ws.get(key)
+    if t is None or t.numel() < nfloats:
+        if t is not None and frozen_ws():
+            _retired.append(t)
+        t = _stat_ws[key] = torch.empty(max(int(nfloats), 2 * (t.numel() if t is not None else 0), 1 << 18), dtype=torch.float32, device=device)
+    return t
+
+
 def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, pad=1, transposed=False, act_in=0,
-            act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None, pad_dx=0, instance_norm=False):
+            act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None, pad_dx=0, instance_norm=False,
+            batch_norm=None):
     """out <- conv-family(in0 ++ in1).  `w` may be an offset view into a weight tensor.
-    instance_norm=True: returns Act(out, scale, shift, mean, rstd) of InstanceNorm2d(out) -- through vts_conv4x4_in, which fuses the
-    statistics into the k-split epilogue where it can (inner U-Net layers) and otherwise runs vts_norm_stats afterwards."""
+    instance_norm=True / batch_norm=dict(keyword arguments of norm_stats: gamma, beta, running_mean, ..., groups, stat_out, ext):
+    returns Act(out, scale, shift, mean, rstd) of InstanceNorm2d(out) / training-mode BatchNorm2d(out) -- through vts_conv4x4_norm, which
+    takes the statistics from the convolution's epilogue (tiled kernel) or its k-split epilogue (inner U-Net layers) where it can,
+    and otherwise runs vts_norm_stats afterwards."""
     lib = L.load()
     d = L.ConvDesc()
     d.in0, d.in1 = _op(in0), _op(in1)
@@ -169,21 +187,18 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d p%d%s%s" % (d.N, cin, d.IH, d.IW, cout, d.OH, d.OW, pad, " dmask" if dmask is not None else "",
                                                       " acc" if accumulate else "")
-    if not instance_norm:
+    if not instance_norm and batch_norm is None:
         _run(label, nbytes, flops, lib.vts_conv4x4, C.byref(d), L.stream())
         return out
-    n, c, h, wd = out.shape
-    st = torch.empty(4, n * c, dtype=torch.float32, device=out.device)
-    nd = L.NormDesc()
-    nd.x, nd.nstride, nd.N, nd.C, nd.HW, nd.mode = out.data_ptr(), out.stride(0), n, c, h * wd, 0
-    nd.eps, nd.momentum = 1e-5, 0.1
-    nd.scale, nd.shift, nd.mean_out, nd.rstd_out = st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr()
-    nd.ngroups = 1
+    kw = dict(batch_norm) if batch_norm is not None else {}
+    mode = 1 if batch_norm is not None else 0
+    nd, st = _norm_desc(out, mode, **kw)
+    sws = stat_workspace(lib.vts_conv4x4_norm_ws_floats(C.byref(d)), x.device)
     fused = C.c_int(0)
-    _run(label, nbytes, flops, lib.vts_conv4x4_in, C.byref(d), C.byref(nd), C.byref(fused), L.stream())
+    _run(label, nbytes, flops, lib.vts_conv4x4_norm, C.byref(d), C.byref(nd), sws.data_ptr(), sws.numel(), C.byref(fused), L.stream())
     if fused.value:
         return Act(out, st[0], st[1], st[2], st[3])
-    return norm_stats(out, 0)
+    return norm_stats(out, mode, **kw)
 
 
 # ---- deferred weight-gradient reduction -------------------------------------------------------------------------------
@@ -840,6 +855,25 @@ def _set_groups(d, groups, n):
     d.ngroups = len(groups)
     for i, g in enumerate(list(groups) + [n]):
         d.gstart[i] = int(g)
+
+
+def _norm_desc(x, mode, *, gamma=None, beta=None, running_mean=None, running_var=None, nbt=None, eps=1e-5,
+               momentum=0.1, groups=None, stat_out=None, ext=None):
+    """(vts_norm_desc of the statistics of x, its [4, N*C] output tensor) -- arguments as norm_stats"""
+    n, c, h, w = x.shape
+    st = torch.empty(4, n * c, dtype=torch.float32, device=x.device)
+    d = L.NormDesc()
+    d.x, d.nstride, d.N, d.C, d.HW, d.mode = x.data_ptr(), x.stride(0), n, c, h * w, mode
+    d.eps, d.momentum = eps, momentum
+    d.gamma, d.beta = L.ptr(gamma), L.ptr(beta)
+    d.running_mean, d.running_var, d.num_batches_tracked = L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt)
+    d.scale, d.shift, d.mean_out, d.rstd_out = st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr()
+    _set_groups(d, groups, n)
+    if stat_out is not None:
+        d.stat_mean_out, d.stat_uvar_out = stat_out[0].data_ptr(), stat_out[1].data_ptr()
+    if ext is not None:
+        d.ext_mean, d.ext_uvar, d.ext_after = ext[0].data_ptr(), ext[1].data_ptr(), int(ext[2])
+    return d, st
 
 
 def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var=None, nbt=None, eps=1e-5,
