@@ -405,6 +405,28 @@ int vts_avgpool3s2(const float* x, int64_t x_nstride, int N, int C, int H, int W
 int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, float* dx, int64_t dx_nstride, int accumulate,
                        void* stream);
 
+/* ---- perceptual terms (round 3): the glue around the frozen VGG feature stacks, whose 3x3 convolutions run on vts_conv3x3_wide.
+ * LPIPS-VGG16 = lpips.LPIPS(net="vgg") as called at models/sinskitG_model.py:495, 1639-1646, 1711 and models/model_utils.py:477,
+ * 523-527 (third-party package: algorithm restated in oracle/perceptual.py); VGG19 features = Vgg19 / VGGLoss, models/networks.py:
+ * 2021-2067.  Activations are RAW convolution outputs z; every consumer applies relu on load. ---- */
+/* out [NC][H/2 + 2 pad][W/2 + 2 pad] = zero-padded MaxPool2d(2, 2)(relu(z)), z [NC][H][W]: replaces ReLU + MaxPool2d + the next
+ * convolution's padding (torchvision vgg features) */
+int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream);
+/* gz [NC][H][W] = adjoint of relu -> MaxPool2d(2, 2) applied to g [NC][H/2][W/2] (first-maximum tie rule of PyTorch) */
+int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int H, int W, float* gz, void* stream);
+/* out [NC][H + 2 pad][W + 2 pad] = zero-padded (g + g2) * (z > 0); g or g2 may be NULL: ReLU backward + the padding of the adjoint conv */
+int vts_relu_mask_pad(const float* g, const float* g2, const float* z, int NC, int H, int W, int pad, float* out, void* stream);
+/* one LPIPS tap: loss_slot += coeff * sum_n mean_pixels sum_c w[c] (f0n - f1n)^2 with f = relu(z), fn = f / (|f|_channels + 1e-10);
+ * dz0 (optional) = grad_coeff * d(that sum)/d relu(z0)  (lpips.LPIPS.forward: normalize_tensor, lin layers, spatial_average) */
+int vts_lpips_layer(const float* z0, const float* z1, int N, int C, int HW, const float* w, float coeff, int64_t* loss_slot, float* dz0,
+                    float grad_coeff, void* stream);
+/* loss_slot += coeff * sum |relu(za) - relu(zb)|;  grad (optional) = coeff * sign(.)  (VGGLoss: nn.L1Loss on ReLU features) */
+int vts_l1_relu(const float* za, const float* zb, int64_t n, float coeff, int64_t* loss_slot, float* grad, void* stream);
+/* LPIPS ScalingLayer: y [N][3][HW] = (x - shift_c) / scale_c; Cx = 1 broadcasts the single channel (tactile gx / gy); shift3 / scale3
+ * are HOST triples.  vts_lpips_input_bwd: dx (+)= adjoint applied to g [N][3][HW] */
+int vts_lpips_input(const float* x, int64_t x_nstride, int N, int Cx, int HW, const float* shift3, const float* scale3, float* y, void* stream);
+int vts_lpips_input_bwd(const float* g, int N, int Cx, int HW, const float* scale3, float* dx, int64_t dx_nstride, int accumulate, void* stream);
+
 /* Loss slots: 64-bit fixed point, VTS_LOSS_SCALE units per 1.0 (value = slot / VTS_LOSS_SCALE).  Integer atomic adds commute, so a
  * logged loss is bitwise reproducible whatever order workgroups and concurrent streams add to a slot in. */
 #define VTS_LOSS_SCALE 1099511627776.0 /* 2^40 */

@@ -491,6 +491,100 @@ def golden_p2p_step(size=32, seed=505, n=4, steps=2):
     print({k: float(v) for k, v in losses.items()})
 
 
+def golden_lpips_step(size=256, seed=212, nt=64):
+    """One SinSKITGModel.optimize_parameters of the REFERENCE with the LPIPS terms ON (the reference's default flags:
+    lambda_G1_lpips 1, lambda_G2_lpips 10).  The `lpips` package is third-party and absent here: `lpips.LPIPS` is replaced by the
+    restatement of its published algorithm (oracle/perceptual.py) on seeded stand-in weights, so what this fixture pins is the
+    reference's own call sites and reductions around the network (sinskitG_model.py:1709-1716, 1619-1658, 1819-1838) and their
+    gradient path into the generator."""
+    from oracle import detrand, nets, perceptual, ref_import
+
+    ref_import.load()
+    sys.modules["lpips"].LPIPS = perceptual.LPIPS
+    import models.sinskitG_model as ref_mod
+    ref_mod.lpips.LPIPS = perceptual.LPIPS
+    flags = ["--lambda_G1_lpips", "1", "--lambda_G2_lpips", "10", "--use_vision_aided_loss", "False",
+             "--lambda_G2_GAN_feat", "0", "--checkpoints_dir", "/tmp/vts_golden_ckpt", "--name", "golden_lpips"]
+    opt = _ref_opt("sinskitG", True, flags)
+    model = ref_mod.SinSKITGModel(opt)
+    model.setup(opt)
+    model.netG.load_state_dict(detrand.test_weights(nets.g_param_shapes(), seed))
+    model.netD.load_state_dict(detrand.test_weights(nets.d_param_shapes(4), seed + 1))
+    model.netD2.load_state_dict(detrand.test_weights(nets.d_param_shapes(7), seed + 2))
+    model.train()
+    batch = _synthetic_batch(size, nt, seed)
+    out = {"size": size, "seed": seed, "nt": nt, "flags": json.dumps(flags)}
+    model.set_input(batch, phase="train")
+    k = int(nets.dilated_mask_positions(model.M).shape[0])
+    torch.manual_seed(seed)
+    aug = torch.stack([torch.rand(1, 1, 1, 1).flatten() for _ in range(4)])
+    random.seed(seed)
+    more = np.array(random.sample(range(k), opt.add_fake_T_sample_size), dtype=np.int64)[None]
+    torch.manual_seed(seed)
+    random.seed(seed)
+    model.optimize_parameters(epoch=1)
+    out["s0/aug"], out["s0/more_idx"] = aug.numpy(), more
+    losses = model.get_current_losses()
+    out["s0/loss_names"] = np.array(list(losses.keys()))
+    out["s0/loss_values"] = np.array(list(losses.values()), dtype=np.float64)
+    for kk, p in model.netG.named_parameters():
+        out["s0/grad_G/%s" % kk] = detrand.probe(p.grad, kk)
+    out["s0/fake_I_probe"] = detrand.probe(model.fake_I, "fake_I")
+    # the module alone on seeded inputs: values per sample (3-channel and 1-channel inputs) and the input gradient
+    lp = perceptual.LPIPS()
+    a = (detrand.uniform((2, 3, 64, 64), seed, "lp_a")).requires_grad_(True)
+    b = detrand.uniform((2, 3, 64, 64), seed, "lp_b")
+    v = lp(a, b)
+    v.sum().backward()
+    out["module/val3"] = v.detach().flatten().double().numpy()
+    out["module/grad3_probe"] = detrand.probe(a.grad, "lp_ga")
+    a1 = (0.3 * detrand.uniform((5, 1, 32, 32), seed, "lp_a1")).requires_grad_(True)
+    b1 = 0.3 * detrand.uniform((5, 1, 32, 32), seed, "lp_b1")
+    v1 = lp(a1, b1)
+    v1.sum().backward()
+    out["module/val1"] = v1.detach().flatten().double().numpy()
+    out["module/grad1_probe"] = detrand.probe(a1.grad, "lp_ga1")
+    np.savez_compressed(os.path.join(GOLD, "sinskitG_lpips_step_%d.npz" % size), **out)
+    print("wrote sinskitG_lpips_step_%d.npz" % size, {k: float(v) for k, v in losses.items()})
+
+
+def golden_p2p_vgg_step(size=32, seed=515, n=4):
+    """One Pix2PixHDModel.optimize_parameters of the REFERENCE with its VGG feature term ON (lambda_vgg 10, the default).  torchvision
+    is absent: `networks.VGGLoss` is replaced by the restatement of the reference's own VGGLoss / Vgg19 (oracle/perceptual.py,
+    networks.py:2021-2067) on seeded stand-in weights; pinned are the call sites (pix2pixHD_model.py:680-693) and the gradient into G."""
+    from oracle import detrand, nets, perceptual, ref_import
+
+    ref_import.load()
+    import models
+    from models import networks as ref_networks
+    ref_networks.VGGLoss = lambda gpu_ids=None: perceptual.VGGLoss()
+    flags = [f for f in P2P_FLAGS]
+    flags[flags.index("--no_vgg_loss") + 1] = "False"
+    opt = _ref_opt("pix2pixHD", True, flags)
+    opt.checkpoints_dir, opt.name = "/tmp/vts_golden_ckpt", "p2p_vgg"
+    os.makedirs(os.path.join(opt.checkpoints_dir, opt.name), exist_ok=True)
+    model = models.create_model(opt)
+    model.setup(opt)
+    shG = nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True)
+    shD, shD2 = nets.d_if_param_shapes(4, 8, 2), nets.d_if_param_shapes(3, 8, 2)
+    model.netG.load_state_dict(detrand.test_weights(shG, seed))
+    model.netD.load_state_dict(detrand.test_weights(shD, seed + 1))
+    model.netD2.load_state_dict(detrand.test_weights(shD2, seed + 2))
+    model.train()
+    batch = p2p_batch(n, size, seed)
+    out = {"size": size, "seed": seed, "n": n, "flags": np.array(flags), "lambda_vgg": float(opt.lambda_vgg)}
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    out["s0/loss_names"] = np.array(list(losses.keys()))
+    out["s0/loss_values"] = np.array([float(v) for v in losses.values()], dtype=np.float64)
+    for kk, p in model.netG.named_parameters():
+        out["s0/grad_G/%s" % kk] = detrand.probe(p.grad, kk)
+    out["s0/fake_I"] = model.fake_I.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, "pix2pixHD_vgg_step_%d.npz" % size), **out)
+    print("wrote pix2pixHD_vgg_step_%d.npz" % size, {k: float(v) for k, v in losses.items()})
+
+
 def golden_metrics(seed=606):
     """T_AE / T_MSE from the reference's compute_evaluation_metric (I_PSNR needs torchmetrics, which is not installed:
     the oracle restates torchmetrics' published formula for it)"""
@@ -793,3 +887,7 @@ if __name__ == "__main__":
         golden_sg2g()
     if "stylemodes" in which:
         golden_nets_style_modes()
+    if "lpips" in which:
+        golden_lpips_step()
+    if "p2pvgg" in which:
+        golden_p2p_vgg_step()

@@ -31,6 +31,7 @@ DEFAULT_HP = dict(
     lr=1e-3, lr_G2=5e-4, beta1=0.0, beta2=0.99, gan_mode="nonsaturating",
     batch_size_G2=64, add_fake_T_sample_size=32, scale_nz=0.25, num_D=3,
     use_more_fakeT=True, use_diffaug=True, lr_scale=1.0, netG="unet256_custom",
+    lambda_G1_lpips=0.0, lambda_G2_lpips=0.0,
 )
 
 
@@ -123,9 +124,11 @@ def _exchange(sd, name, exchange):
         sd[k].grad = g.clone()
 
 
-def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, record=True, exchange=None):
+def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, record=True, exchange=None, lpips=None):
     """One G+D1+D2 update, in place on the three state dicts and `adam` (dict of 3 Adam states).
     exchange: optional hook emulating the data-parallel gradient exchange (see _exchange); recorded gradients are the LOCAL ones.
+    lpips: the LPIPS module (oracle.perceptual.LPIPS) when opt.lambda_G1_lpips / lambda_G2_lpips > 0 (compute_G1_loss :1709-1716,
+    compute_G2_loss :1819-1838 -> _compute_touch_lpips_loss :1619-1658).
 
     Returns a dict with losses, outputs and (if record) the gradients taken at each of
     the three backward points.
@@ -213,7 +216,13 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     loss_G2_GAN = (gl(pred_g2, True) * lamD2).view(-1, NT).mean(dim=0).sum()  # logged only: no gradient path
     l1 = (fake_T_concat - inp.real_T).abs() * opt.lambda_G2_L1
     loss_G2_L1 = l1.view(-1, NT, 2, 32, 32).sum(dim=1).mean()
-    loss_G = loss_G_GAN + loss_G_L1 + loss_G2_L1 + loss_G2_GAN.detach() * 0
+    loss_G_lpips = loss_G2_lpips = torch.zeros(())
+    if getattr(opt, "lambda_G1_lpips", 0.0) > 0.0:
+        loss_G_lpips = lpips(fake_I, inp.real_I).mean() * opt.lambda_G1_lpips
+    if getattr(opt, "lambda_G2_lpips", 0.0) > 0.0:
+        from oracle import perceptual
+        loss_G2_lpips = perceptual.touch_lpips(lpips, fake_T_concat, inp.real_T, NT, opt.lambda_G2_lpips)
+    loss_G = loss_G_GAN + loss_G_L1 + loss_G2_L1 + loss_G2_GAN.detach() * 0 + loss_G_lpips + loss_G2_lpips
     loss_G.backward()
     if record:
         out["grad_G"] = _grads(sdG)
@@ -226,6 +235,10 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
         "G_L1": float(loss_G_L1.detach()), "G2_GAN": float(loss_G2_GAN.detach()), "D_real_T_concat": float(loss_D_real_T.detach()),
         "D_fake_T_concat": float(loss_D_fake_T.detach()), "D_more_fake_T": float(loss_D_more.detach()), "G2_L1": float(loss_G2_L1.detach()),
     }
+    if getattr(opt, "lambda_G1_lpips", 0.0) > 0.0:
+        out["losses"]["G_lpips"] = float(loss_G_lpips.detach())
+    if getattr(opt, "lambda_G2_lpips", 0.0) > 0.0:
+        out["losses"]["G2_lpips"] = float(loss_G2_lpips.detach())
     if record:
         out["g_out"] = g_out.detach().clone()
         out["fake_I"] = fake_I.detach().clone()
@@ -281,8 +294,10 @@ def p2p_generator(sdG, inp, opt, training=True):
     return out, out[:, :3] * inp.M, out[:, -2:] * inp.M
 
 
-def p2p_train_step(sdG, sdD, sdD2, adam, batch, opt=None, record=True):
-    """One D + D2 + G update in place on the three state dicts (D / D2 in the getIntermFeat key style) and `adam`."""
+def p2p_train_step(sdG, sdD, sdD2, adam, batch, opt=None, record=True, vgg_loss=None, lambda_vgg=10.0):
+    """One D + D2 + G update in place on the three state dicts (D / D2 in the getIntermFeat key style) and `adam`.
+    vgg_loss: oracle.perceptual.VGGLoss for the VGG feature term (pix2pixHD_model.py:680-693: the image, and gx / gy tiled to three
+    channels), None = --no_vgg_loss True."""
     opt = opt or p2p_hp()
     inp = p2p_prepare(batch)
     pD, pD2 = nets.d_if_to_plain(sdD), nets.d_if_to_plain(sdD2)     # views onto the same tensors
@@ -307,7 +322,12 @@ def p2p_train_step(sdG, sdD, sdD2, adam, batch, opt=None, record=True):
     # ---- G ----
     loss_G_I = gl(nets.msd_forward(pD, torch.cat((inp.real_S, fake_I), 1), opt.num_D_D1), True)
     loss_G_T = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, fake_T), 1), opt.num_D_D2), True)
-    (loss_G_I + loss_G_T).backward()
+    loss_vgg_I = loss_vgg_T = torch.zeros(())
+    if vgg_loss is not None:
+        loss_vgg_I = vgg_loss(fake_I, inp.real_I) * lambda_vgg
+        t3 = lambda t, c: t[:, c:c + 1].expand(-1, 3, -1, -1)
+        loss_vgg_T = (vgg_loss(t3(fake_T, 0), t3(inp.real_T, 0)) + vgg_loss(t3(fake_T, 1), t3(inp.real_T, 1))) * lambda_vgg
+    (loss_G_I + loss_G_T + loss_vgg_I + loss_vgg_T).backward()
     if record:
         out["grad_G"] = _grads(sdG)
     _adam(sdG, adam["G"], opt.lr, opt)
@@ -315,6 +335,8 @@ def p2p_train_step(sdG, sdD, sdD2, adam, batch, opt=None, record=True):
     out["losses"] = {"G_GAN_I": float(loss_G_I.detach()), "G_GAN_T": float(loss_G_T.detach()), "G_GAN": float((loss_G_I + loss_G_T).detach()),
                      "D_real": float(loss_D_real.detach()), "D_fake": float(loss_D_fake.detach()), "D2_real": float(loss_D2_real.detach()),
                      "D2_fake": float(loss_D2_fake.detach()), "G_GAN_Feat": 0.0, "G_GAN_Feat_I": 0.0, "G_GAN_Feat_T": 0.0}
+    if vgg_loss is not None:
+        out["losses"].update({"G_VGG_I": float(loss_vgg_I.detach()), "G_VGG_T": float(loss_vgg_T.detach()), "G_VGG": float((loss_vgg_I + loss_vgg_T).detach())})
     if record:
         out["fake_I"], out["fake_T"] = fake_I.detach().clone(), fake_T.detach().clone()
         out["fake_N"] = nets.compute_normal(fake_T.detach(), opt.scale_nz)

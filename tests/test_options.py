@@ -46,8 +46,12 @@ def test_unbuilt_third_party_terms_raise():
     from options.train_options import TrainOptions
 
     opt = parse(TrainOptions, "--model sinskitG --gpu_ids 0 --checkpoints_dir /tmp/vts_opt")
-    with pytest.raises(NotImplementedError, match="LPIPS"):
+    with pytest.raises(NotImplementedError, match="CLIP vision-aided"):      # the reference's default flags: the CLIP discriminator is not built
         SinSKITGModel._check_unbuilt_terms(opt)
+    # LPIPS is built since round 3: the reference's default lambdas pass the check once the CLIP term is switched off
+    opt = parse(TrainOptions, "--model sinskitG --gpu_ids 0 --checkpoints_dir /tmp/vts_opt --use_vision_aided_loss False")
+    assert opt.lambda_G1_lpips == 1.0 and opt.lambda_G2_lpips == 10.0
+    SinSKITGModel._check_unbuilt_terms(opt)
 
 
 def test_synthetic_dataset_contract():

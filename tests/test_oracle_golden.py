@@ -485,3 +485,75 @@ def test_style_code_project_and_adain_modes(golden_dir):
             if mode == "adain" and k == "down7.model.1.bias":      # AdaIN removes the per-channel constant of its content
                 continue
             _probe_close(v.grad, g[t + "G_grad/" + k], k)
+
+
+def test_train_step_with_lpips_terms_matches_reference(golden_dir):
+    """oracle.step.train_step with the LPIPS terms on (the reference's default lambdas) vs the reference's optimize_parameters run with
+    `lpips.LPIPS` replaced by oracle.perceptual.LPIPS on the seeded stand-in weights: the call sites / reductions around the third-party
+    network (sinskitG_model.py:1709-1716, 1619-1658, 1819-1838) and the gradient into the generator"""
+    from oracle import perceptual
+
+    g = _load(golden_dir, "sinskitG_lpips_step_256.npz")
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    sdG = detrand.test_weights(nets.g_param_shapes(), seed)
+    sdD = detrand.test_weights(nets.d_param_shapes(4), seed + 1)
+    sdD2 = detrand.test_weights(nets.d_param_shapes(7), seed + 2)
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    draws = {"aug": torch.from_numpy(g["s0/aug"]), "more_idx": torch.from_numpy(g["s0/more_idx"])}
+    lp = perceptual.LPIPS()
+    out = step.train_step(sdG, sdD, sdD2, adam, _batch(size, nt, seed), draws, opt=step.hp(lambda_G1_lpips=1.0, lambda_G2_lpips=10.0), lpips=lp)
+    ref = dict(zip([str(s) for s in g["s0/loss_names"]], g["s0/loss_values"]))
+    assert "G_lpips" in out["losses"] and "G2_lpips" in out["losses"]
+    for k, v in out["losses"].items():
+        assert abs(v - ref["l_" + k]) <= 2e-4 * max(1.0, abs(ref["l_" + k])), (k, v, ref["l_" + k])
+    _probe_close(out["fake_I"], g["s0/fake_I_probe"], "fake_I")
+    for k, gr in out["grad_G"].items():
+        if k.endswith("bias") and not k.startswith(("down0.", "down7.", "up0.", "up0_T.")):
+            continue        # a bias in front of an InstanceNorm: analytically zero gradient, rounding noise on both sides
+        _probe_close(gr, g["s0/grad_G/%s" % k], k, rtol=5e-4)
+    # the module alone (3-channel and broadcast 1-channel inputs)
+    a = detrand.uniform((2, 3, 64, 64), seed, "lp_a").requires_grad_(True)
+    v = lp(a, detrand.uniform((2, 3, 64, 64), seed, "lp_b"))
+    v.sum().backward()
+    _close(v.detach().flatten().double().numpy(), g["module/val3"], rtol=1e-5)
+    _probe_close(a.grad, g["module/grad3_probe"], "lp_ga")
+    a1 = (0.3 * detrand.uniform((5, 1, 32, 32), seed, "lp_a1")).requires_grad_(True)
+    v1 = lp(a1, 0.3 * detrand.uniform((5, 1, 32, 32), seed, "lp_b1"))
+    v1.sum().backward()
+    _close(v1.detach().flatten().double().numpy(), g["module/val1"], rtol=1e-5)
+    _probe_close(a1.grad, g["module/grad1_probe"], "lp_ga1")
+
+
+def test_pix2pixHD_step_with_vgg_term_matches_reference(golden_dir):
+    """oracle.step.p2p_train_step with the VGG feature term vs the reference's Pix2PixHDModel step with networks.VGGLoss replaced by
+    the restatement of the reference's own VGGLoss / Vgg19 on stand-in weights (pix2pixHD_model.py:680-693)"""
+    from oracle import perceptual
+
+    g = _load(golden_dir, "pix2pixHD_vgg_step_32.npz")
+    size, seed, n = int(g["size"]), int(g["seed"]), int(g["n"])
+    sdG = detrand.test_weights(nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True), seed)
+    sdD, sdD2 = detrand.test_weights(nets.d_if_param_shapes(4, 8, 2), seed + 1), detrand.test_weights(nets.d_if_param_shapes(3, 8, 2), seed + 2)
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    opt = step.p2p_hp(n_blocks_global=2, n_downsample_global=3)
+    out = step.p2p_train_step(sdG, sdD, sdD2, adam, p2p_batch(n, size, seed), opt, vgg_loss=perceptual.VGGLoss(), lambda_vgg=float(g["lambda_vgg"]))
+    ref = dict(zip([str(k) for k in g["s0/loss_names"]], g["s0/loss_values"]))
+    for k, v in out["losses"].items():
+        assert abs(ref["l_" + k] - v) <= 2e-4 * max(1.0, abs(v)), (k, ref["l_" + k], v)
+    _close(out["fake_I"].numpy(), g["s0/fake_I"], rtol=1e-3, atol=1e-4)
+    for k, gr in out["grad_G"].items():
+        rp = g["s0/grad_G/%s" % k]
+        if k.endswith(".bias") and abs(rp[1]) < 1e-4:
+            continue
+        _probe_close(gr, rp, k, rtol=1e-3)
+
+
+def test_perceptual_standin_weights_agree_between_product_and_checker():
+    """the product's stand-in generator (models/perceptual.py) and the checker's (oracle/perceptual.py) draw the same numbers"""
+    from models import perceptual as prod
+    from oracle import perceptual as chk
+
+    for cfg, taps, seed, lin in ((prod.VGG16_CFG, prod.LPIPS_TAPS, prod.LpipsVgg16.SEED, True), (prod.VGG19_CFG, prod.VGG19_TAPS, prod.Vgg19Features.SEED, False)):
+        a, b = prod.standin_state(cfg, taps, seed, lin), chk.standin_state(cfg, taps, seed, lin)
+        assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    assert prod.feature_indices(prod.VGG16_CFG) == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]      # torchvision vgg16.features conv indices
+    assert [chk.feature_index(chk.VGG19_CFG, k) for k in chk.VGG19_TAPS] == [0, 5, 10, 19, 28]           # convs in front of relu{1..5}_1 (Vgg19 slices end at 2, 7, 12, 21, 30)

@@ -1,0 +1,276 @@
+"""Perceptual terms on the HIP path: LPIPS-VGG16 (the reference's default lambda_G1_lpips / lambda_G2_lpips terms and the *_LPIPS
+metrics) and the pix2pixHD VGG19 feature loss.
+
+Checker = oracle/perceptual.py (restatement of lpips.LPIPS's published algorithm and of the reference's own Vgg19 / VGGLoss) with the
+product's stand-in weights, plus the fixtures made by running the REFERENCE's call sites on that restatement
+(tests/golden/sinskitG_lpips_step_256.npz, pix2pixHD_vgg_step_32.npz).  Tolerances: kernels 1e-5 rel-L2; network values 1e-4; input
+gradients 1e-3 (fp32 through 13 convolutions); step losses 1e-3."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch.utils.data import default_collate
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, nets, perceptual as chk, step  # noqa: E402  (checker only)
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 12), (1, 64, 32, 32), (3, 7, 2, 2)])
+def test_maxpool_relu_pad_and_adjoint(shape):
+    from vts import ops
+
+    n, c, h, w = shape
+    z = detrand.uniform(shape, 3, "z").requires_grad_(True)
+    z.data[0, 0, 0:2, 0:2] = 0.37          # a tie inside one window: the first element takes the gradient (PyTorch's rule)
+    z.data[0, 1, 0:2, 0:2] = -0.5          # a window without a positive element: no gradient at all
+    y = F.max_pool2d(F.relu(z), 2, 2)
+    cot = detrand.uniform(tuple(y.shape), 3, "cot")
+    (y * cot).sum().backward()
+    zd = z.detach().to(_dev())
+    for pad in (0, 1):
+        out = ops.maxpool2_relu_pad(zd, pad)
+        assert torch.equal(out.cpu(), F.pad(y.detach(), (pad,) * 4))
+    gz = ops.maxpool2_relu_bwd(cot.to(_dev()), zd)
+    # through relu as well: the product applies the ReLU mask in the next kernel (relu_mask_pad), PyTorch's z.grad has it already
+    masked = ops.relu_mask_pad(gz, None, zd, pad=0)
+    assert torch.equal(masked.cpu(), z.grad)
+
+
+def test_relu_mask_pad_and_l1_relu():
+    from vts import ops
+
+    dev = _dev()
+    shape = (2, 6, 9, 11)
+    z, g, g2 = detrand.uniform(shape, 5, "z"), detrand.uniform(shape, 5, "g"), detrand.uniform(shape, 5, "g2")
+    out = ops.relu_mask_pad(g.to(dev), g2.to(dev), z.to(dev), pad=1)
+    assert torch.equal(out.cpu(), F.pad((g + g2) * (z > 0), (1, 1, 1, 1)))
+    out = ops.relu_mask_pad(None, g2.to(dev), z.to(dev), pad=0)
+    assert torch.equal(out.cpu(), g2 * (z > 0))
+    za = detrand.uniform(shape, 6, "za").requires_grad_(True)
+    zb = detrand.uniform(shape, 6, "zb")
+    ra = F.relu(za)
+    ra.retain_grad()
+    loss = 0.7 * F.l1_loss(ra, F.relu(zb))
+    loss.backward()
+    slot = ops.loss_slots(1, dev)
+    grad = torch.empty(shape, device=dev)
+    ops.l1_relu(za.detach().to(dev), zb.to(dev), 0.7 / za.numel(), slot, grad=grad)
+    assert abs(ops.loss_values(slot)[0] - float(loss)) < 1e-6
+    assert rel(grad, ra.grad) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 512, 2, 2), (1, 128, 9, 7)])
+def test_lpips_layer_value_and_gradient(shape):
+    from vts import ops
+
+    dev = _dev()
+    n, c, h, w = shape
+    z0 = detrand.uniform(shape, 7, "z0").requires_grad_(True)
+    z1 = detrand.uniform(shape, 7, "z1")
+    wl = torch.rand(c, generator=torch.Generator().manual_seed(1)) * 0.1
+    f0 = F.relu(z0)
+    f0.retain_grad()
+    d = (chk.LPIPS.normalize_tensor(f0) - chk.LPIPS.normalize_tensor(F.relu(z1))) ** 2
+    val = F.conv2d(d, wl.view(1, c, 1, 1)).mean([2, 3]).sum() * 0.3
+    val.backward()
+    slot = ops.loss_slots(1, dev)
+    dz = torch.empty(shape, device=dev)
+    ops.lpips_layer(z0.detach().to(dev), z1.to(dev), wl.to(dev), 0.3, slot, dz0=dz, grad_coeff=0.3)
+    assert abs(ops.loss_values(slot)[0] - float(val)) <= 1e-5 * max(1e-3, abs(float(val)))
+    assert rel(dz, f0.grad) < 1e-5
+
+
+def _lpips_pair():
+    from models import perceptual
+
+    net = perceptual.LpipsVgg16().to(_dev())
+    return net, chk.LPIPS(sd=net.own_state())
+
+
+def test_lpips_network_matches_checker_and_reference_fixture(golden_dir):
+    """values per sample and the input gradient: 3-channel images and broadcast 1-channel tactile patches; the fixture values come
+    from the module the reference's own step ran on (oracle/make_golden.py lpips)"""
+    from vts import ops, perceptual as P
+
+    dev = _dev()
+    g = np.load(golden_dir + "/sinskitG_lpips_step_256.npz")
+    seed = int(g["seed"])
+    net, lp = _lpips_pair()
+    for shape, sc, ta, tb, key in (((2, 3, 64, 64), 1.0, "lp_a", "lp_b", "3"), ((5, 1, 32, 32), 0.3, "lp_a1", "lp_b1", "1")):
+        a, b = sc * detrand.uniform(shape, seed, ta), sc * detrand.uniform(shape, seed, tb)
+        ar = a.clone().requires_grad_(True)
+        vref = lp(ar, b)
+        vref.sum().backward()
+        np.testing.assert_allclose(vref.detach().flatten().double().numpy(), g["module/val" + key], rtol=1e-5)
+        ad, bd = a.to(dev), b.to(dev)
+        grad = torch.zeros(shape, device=dev)
+        per = []
+        for i in range(shape[0]):            # per-sample values through the slot
+            slot = ops.loss_slots(1, dev)
+            P.lpips_term(net, ad[i:i + 1], bd[i:i + 1], 1.0, slot)
+            per.append(ops.loss_values(slot)[0])
+        np.testing.assert_allclose(per, g["module/val" + key], rtol=2e-4)
+        slot = ops.loss_slots(1, dev)
+        P.lpips_term(net, ad, bd, 1.0, slot, grad_into=grad)
+        assert abs(ops.loss_values(slot)[0] - float(vref.sum())) <= 2e-4 * float(vref.sum())
+        assert rel(grad, ar.grad) < 1e-3
+        p = detrand.probe(grad.cpu(), "lp_ga" if key == "3" else "lp_ga1")
+        rp = g["module/grad%s_probe" % key]
+        assert abs(p[1] - rp[1]) <= 1e-3 * abs(rp[1])
+
+
+def test_lpips_channel_view_of_a_patch_stack():
+    """the tactile term passes 1-channel VIEWS of [P, 2, 32, 32] tensors and accumulates into 1-channel views of the gradient"""
+    from vts import ops, perceptual as P
+
+    dev = _dev()
+    net, lp = _lpips_pair()
+    fake = (0.3 * detrand.uniform((6, 2, 32, 32), 9, "f")).requires_grad_(True)
+    real = 0.3 * detrand.uniform((6, 2, 32, 32), 9, "r")
+    ref = chk.touch_lpips(lp, fake, real, 3, 10.0)
+    ref.backward()
+    fd, rd = fake.detach().to(dev), real.to(dev)
+    grad = torch.full((6, 2, 32, 32), 0.25, device=dev)      # pre-filled: the term accumulates
+    slot = ops.loss_slots(1, dev)
+    for c in (0, 1):
+        P.lpips_term(net, fd[:, c:c + 1], rd[:, c:c + 1], 10.0 / 2, slot, grad_into=grad[:, c:c + 1], grad_accumulate=True)
+    assert abs(ops.loss_values(slot)[0] - float(ref)) <= 2e-4 * float(ref)
+    assert rel(grad - 0.25, fake.grad) < 1e-3
+
+
+def test_vgg19_feature_loss_matches_checker():
+    from models import perceptual
+    from vts import ops, perceptual as P
+
+    dev = _dev()
+    net = perceptual.Vgg19Features().to(dev)
+    vl = chk.VGGLoss(chk.Vgg19(sd=net.own_state()))
+    x = detrand.uniform((2, 3, 32, 32), 11, "x").requires_grad_(True)
+    y = detrand.uniform((2, 3, 32, 32), 11, "y")
+    ref = vl(x, y) * 10.0
+    ref.backward()
+    slot = ops.loss_slots(1, dev)
+    gx = P.vgg_feature_l1(net, x.detach().to(dev), y.to(dev), 10.0, slot)
+    assert abs(ops.loss_values(slot)[0] - float(ref)) <= 2e-4 * float(ref)
+    assert rel(gx, x.grad) < 2e-3       # L1 subgradients: sign flips of near-zero feature differences
+
+
+def _make_lpips_model(size):
+    from models import create_model
+    from options.train_options import TrainOptions
+
+    flags = ("--model sinskitG --gpu_ids 0 --lambda_G1_lpips 1 --lambda_G2_lpips 10 --use_vision_aided_loss False --lambda_G2_GAN_feat 0 "
+             "--checkpoints_dir /tmp/vts_test_ckpt --name tl --crop_size %d --batch_size 1" % size)
+    opt = TrainOptions(cmd_line=flags).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    model.train()
+    return model, opt
+
+
+def test_step_with_lpips_terms_matches_reference_golden(golden_dir):
+    """the HIP training step with the reference's default LPIPS lambdas against the REFERENCE's own step (run on the restated LPIPS
+    module): all logged losses incl. G_lpips / G2_lpips, fake_I, every generator gradient"""
+    from data.synthetic_dataset import make_sample
+    from tests.test_step_gpu import load_test_weights, null_grad_bias, probe_close
+
+    g = np.load(golden_dir + "/sinskitG_lpips_step_256.npz")
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    model, opt = _make_lpips_model(size)
+    assert model.loss_lpips_pretrained is False and "G_lpips" in model.loss_names and "G2_lpips" in model.loss_names
+    load_test_weights(model, seed)
+    model._draws = {"aug": torch.from_numpy(g["s0/aug"]), "more_idx": torch.from_numpy(g["s0/more_idx"])}
+    model.set_input(default_collate([make_sample(size, nt, nt, seed)]), phase="train")
+    model.optimize_parameters(epoch=1)
+    torch.cuda.synchronize()
+    losses = model.get_current_losses()
+    ref = dict(zip([str(s) for s in g["s0/loss_names"]], g["s0/loss_values"]))
+    for k in ("l_G_lpips", "l_G2_lpips", "l_G_L1", "l_G2_L1", "l_G_GAN", "l_D_real_I", "l_D_fake_I", "l_D_fake_T_concat", "l_D_real_T_concat"):
+        assert abs(losses[k] - ref[k]) <= 1e-3 * max(1.0, abs(ref[k])), (k, losses[k], ref[k])
+    probe_close(model.fake_I, g["s0/fake_I_probe"], "fake_I", 1e-3)
+    for k, p in model.netG.named_parameters():
+        if null_grad_bias("G", k):
+            continue
+        probe_close(p.grad, g["s0/grad_G/%s" % k], k, 2e-3)
+
+
+def test_lpips_step_graph_replay_and_metrics():
+    """three steps (eager, capture, replay) with the LPIPS terms inside the captured segments; then the *_LPIPS metrics of the
+    validation patches against the checker"""
+    import random
+
+    from data.synthetic_dataset import make_sample
+    from tests.test_step_gpu import load_test_weights
+    from vts import ops
+
+    model, opt = _make_lpips_model(256)
+    load_test_weights(model, 31)
+    random.seed(5)
+    torch.manual_seed(5)
+    batch = default_collate([make_sample(256, 64, 16, 31)])
+    vals = []
+    for _ in range(3):
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+        vals.append(model.get_current_losses()["l_G_lpips"])
+    assert model._graphs is not None and all(np.isfinite(vals)) and vals[0] > 0
+    model.eval()
+    model.set_input(batch, phase="val")
+    model.test()
+    m = model.compute_metrics()
+    assert m["I_LPIPS"] > 0 and m["T_LPIPS"] > 0 and model.metric_lpips_pretrained is False
+    lp = chk.LPIPS(sd=model.netLPIPS.own_state())
+    with torch.no_grad():
+        ref_I = float(lp(model.real_I.cpu(), model.fake_I.cpu()).mean())
+        pset = model.val_set
+        P = pset["real_T"].shape[0]
+        fake_T = torch.empty(P, 2, 32, 32, device=model.device)
+        model._gather(model.fake_T, pset, fake_T, 0, channels=2)
+        rT = F.interpolate(pset["real_T"].cpu(), (224, 224))
+        fT = F.interpolate(fake_T.cpu().clamp(0, 1), (224, 224))
+        ref_T = float(lp(rT[:, 0:1], fT[:, 0:1]).mean() + lp(rT[:, 1:2], fT[:, 1:2]).mean())     # compute_touch_lpips_loss, batch_size_G2 None
+    assert abs(m["I_LPIPS"] - ref_I) <= 1e-3 * ref_I and abs(m["T_LPIPS"] - ref_T) <= 1e-3 * ref_T
+
+
+def test_pix2pixHD_step_with_vgg_term_matches_reference_golden(golden_dir):
+    from models import create_model
+    from options.train_options import TrainOptions
+    from tests.test_oracle_golden import p2p_batch
+    from tests.test_step_gpu import probe_close
+
+    g = np.load(golden_dir + "/pix2pixHD_vgg_step_32.npz")
+    size, seed, n = int(g["size"]), int(g["seed"]), int(g["n"])
+    flags = " ".join(str(f) for f in g["flags"]) + " --gpu_ids 0 --checkpoints_dir /tmp/vts_test_ckpt --name p2pv --dataset_mode patchskit"
+    opt = TrainOptions(cmd_line=flags).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    model.train()
+    shG = nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True)
+    model.netG.load_state_dict(detrand.test_weights(shG, seed))
+    model.netD.load_state_dict(detrand.test_weights(nets.d_if_param_shapes(4, 8, 2), seed + 1))
+    model.netD2.load_state_dict(detrand.test_weights(nets.d_if_param_shapes(3, 8, 2), seed + 2))
+    model.set_input(p2p_batch(n, size, seed), phase="train")
+    model.optimize_parameters(epoch=1)
+    torch.cuda.synchronize()
+    losses = model.get_current_losses()
+    ref = dict(zip([str(k) for k in g["s0/loss_names"]], g["s0/loss_values"]))
+    for k in ("l_G_VGG", "l_G_VGG_I", "l_G_VGG_T", "l_G_GAN", "l_D_real", "l_D_fake"):
+        assert abs(losses[k] - ref[k]) <= 1e-3 * max(1.0, abs(ref[k])), (k, losses[k], ref[k])
+    np.testing.assert_allclose(model.fake_I.cpu().numpy(), g["s0/fake_I"], rtol=1e-3, atol=1e-4)
+    for k, p in model.netG.named_parameters():
+        rp = g["s0/grad_G/%s" % k]
+        if k.endswith(".bias") and abs(rp[1]) < 1e-4:
+            continue
+        probe_close(p.grad, rp, k, 3e-3)

@@ -1,0 +1,251 @@
+// Kernels around the frozen VGG feature stacks of the perceptual terms (round 3):
+//   LPIPS-VGG16      lpips.LPIPS(net="vgg") as the reference calls it (models/sinskitG_model.py:495, 1639-1646, 1711;
+//                    models/model_utils.py:477, 523-527) -- third-party package, algorithm restated in oracle/perceptual.py
+//   VGG19 features   VGGLoss / Vgg19 of the pix2pixHD baseline (models/networks.py:2021-2067)
+// The 3x3 convolutions run on the GEMM-class kernels (vts_conv3x3_wide.hip, MFMA-bound); everything here is the HBM-bound glue between
+// them, each a single pass: ReLU + 2x2 max-pool + zero padding in one kernel, its adjoint, ReLU mask + padding of a gradient, the
+// LPIPS head (channel unit-normalisation, weighted squared difference, spatial mean) with its gradient, and the ReLU-on-load L1.
+// Activations are kept as RAW convolution outputs z; relu(z) is applied by whoever reads them (normalise-on-load, as everywhere
+// in this library).
+#include "vts_internal.h"
+
+namespace {
+
+__device__ __forceinline__ void loss_add64(long long* slot, double v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)llrint(v * VTS_LOSS_SCALE));
+}
+
+// out[nc][1 + y][1 + x] = max over the 2x2 window of relu(z); the one-pixel border (pad = 1) is written as zeros: the next
+// convolution's pre-padded input in one pass.  pad = 0: plain pooled map.
+__global__ __launch_bounds__(256) void maxpool2_relu_pad_kernel(const float* __restrict__ z, int H, int W, int pad, float* __restrict__ out) {
+  const int OH = H >> 1, OW = W >> 1, PH = OH + 2 * pad, PW = OW + 2 * pad;
+  const int64_t nc = blockIdx.y;
+  const float* zi = z + nc * (int64_t)H * W;
+  float* o = out + nc * (int64_t)PH * PW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < PH * PW; i += gridDim.x * 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int y = py - pad, x = px - pad;
+    float v = 0.f;
+    if (y >= 0 && y < OH && x >= 0 && x < OW) {
+      const float* q = zi + (int64_t)(2 * y) * W + 2 * x;
+      v = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[W], q[W + 1])), 0.f);
+    }
+    o[i] = v;
+  }
+}
+
+// adjoint of (relu -> MaxPool2d(2, 2)) w.r.t. relu(z): the pooled gradient goes to the FIRST element (row-major scan of the
+// window, PyTorch's tie rule) that holds the window maximum of relu(z).  Windows whose maximum is <= 0 route to their first element
+// in PyTorch and the ReLU mask then removes it: zero here.  Elements outside any window (odd H / W) get zero.
+__global__ __launch_bounds__(256) void maxpool2_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z, int H, int W,
+                                                                float* __restrict__ gz) {
+  const int OH = H >> 1, OW = W >> 1;
+  const int64_t nc = blockIdx.y;
+  const float* zi = z + nc * (int64_t)H * W;
+  const float* gi = g + nc * (int64_t)OH * OW;
+  float* o = gz + nc * (int64_t)H * W;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+    const int y = i / W, x = i - y * W;
+    const int wy = y >> 1, wx = x >> 1;
+    float v = 0.f;
+    if (wy < OH && wx < OW) {
+      const float* q = zi + (int64_t)(2 * wy) * W + 2 * wx;
+      const float e[4] = {q[0], q[1], q[W], q[W + 1]};
+      const float m = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+      const int k = (y & 1) * 2 + (x & 1);
+      bool first = e[k] == m && m > 0.f;
+      for (int j = 0; j < k; ++j) first = first && e[j] != m;
+      if (first) v = gi[(int64_t)wy * OW + wx];
+    }
+    o[i] = v;
+  }
+}
+
+// out[nc][pad + y][pad + x] = (g + g2) * (z > 0), zero border: ReLU backward fused with the zero padding the adjoint convolution wants
+__global__ __launch_bounds__(256) void relu_mask_pad_kernel(const float* __restrict__ g, const float* __restrict__ g2, const float* __restrict__ z,
+                                                            int H, int W, int pad, float* __restrict__ out) {
+  const int PH = H + 2 * pad, PW = W + 2 * pad;
+  const int64_t nc = blockIdx.y;
+  const int64_t off = nc * (int64_t)H * W;
+  float* o = out + nc * (int64_t)PH * PW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < PH * PW; i += gridDim.x * 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int y = py - pad, x = px - pad;
+    float v = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const int64_t j = off + (int64_t)y * W + x;
+      const float t = (g ? g[j] : 0.f) + (g2 ? g2[j] : 0.f);
+      v = z[j] > 0.f ? t : 0.f;
+    }
+    o[i] = v;
+  }
+}
+
+// LPIPS head of one tap.  Thread = pixel, loop over channels (coalesced across the wave: channel stride HW).
+//   a = f0 / (|f0| + eps), b = f1 / (|f1| + eps), d = sum_c w_c (a_c - b_c)^2, value = coeff * sum_{n, pixels} d / HW
+//   dz0 (gradient w.r.t. relu(z0), optional) = grad_coeff / HW * d(d)/d(f0)
+__global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ z0, const float* __restrict__ z1, int C, int HW,
+                                                          const float* __restrict__ w, float coeff, long long* __restrict__ loss,
+                                                          float* __restrict__ dz0, float grad_coeff) {
+  __shared__ float red[16];
+  const int n = blockIdx.y;
+  const float* p0 = z0 + (int64_t)n * C * HW;
+  const float* p1 = z1 + (int64_t)n * C * HW;
+  float* pg = dz0 ? dz0 + (int64_t)n * C * HW : nullptr;
+  const float eps = 1e-10f;
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float f0 = fmaxf(p0[(int64_t)c * HW + i], 0.f), f1 = fmaxf(p1[(int64_t)c * HW + i], 0.f);
+      s0 = fmaf(f0, f0, s0);
+      s1 = fmaf(f1, f1, s1);
+    }
+    const float r0 = sqrtf(s0), r1 = sqrtf(s1);
+    const float i0 = 1.f / (r0 + eps), i1 = 1.f / (r1 + eps);
+    float d = 0.f, S = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float f0 = fmaxf(p0[(int64_t)c * HW + i], 0.f), f1 = fmaxf(p1[(int64_t)c * HW + i], 0.f);
+      const float t = f0 * i0 - f1 * i1;
+      const float wt = w[c] * t;
+      d = fmaf(wt, t, d);
+      S = fmaf(wt, f0, S);
+    }
+    acc += d;
+    if (pg) {
+      // d a_k / d f0_c = delta_kc / (r + eps) - f0_k f0_c / ((r + eps)^2 r);  sum_k 2 w_k t_k (.) = 2 w_c t_c i0 - 2 S f0_c i0^2 / r
+      const float k1 = 2.f * grad_coeff / (float)HW * i0;
+      const float k2 = r0 > 0.f ? 2.f * grad_coeff / (float)HW * S * i0 * i0 / r0 : 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float f0 = fmaxf(p0[(int64_t)c * HW + i], 0.f), f1 = fmaxf(p1[(int64_t)c * HW + i], 0.f);
+        const float t = f0 * i0 - f1 * i1;
+        pg[(int64_t)c * HW + i] = k1 * w[c] * t - k2 * f0;
+      }
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) loss_add64(loss, (double)acc * (double)coeff / (double)HW);
+}
+
+// L1 between relu(za) and relu(zb) (VGGLoss: nn.L1Loss on ReLU outputs): value into the fixed-point slot, gradient w.r.t. relu(za)
+__global__ __launch_bounds__(256) void l1_relu_kernel(const float* __restrict__ za, const float* __restrict__ zb, int64_t n, float coeff,
+                                                      long long* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = fmaxf(za[i], 0.f) - fmaxf(zb[i], 0.f);
+    acc += fabsf(d);
+    if (grad) grad[i] = coeff * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) loss_add64(loss, (double)acc * (double)coeff);
+}
+
+// dx[n][c'] = sum over the 3 network channels that image channel c' feeds of g[n][c] * s[c]:  Cx = 3: one to one;
+// Cx = 1 (a tactile channel broadcast to three network channels by the scaling layer): the sum of the three
+__global__ __launch_bounds__(256) void lpips_input_bwd_kernel(const float* __restrict__ g, int HW, int Cx, float s0, float s1, float s2,
+                                                              float* __restrict__ dx, int64_t dx_nstride, int accumulate) {
+  const int n = blockIdx.y;
+  const float* gi = g + (int64_t)n * 3 * HW;
+  float* o = dx + n * dx_nstride;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float a = gi[i] * s0, b = gi[HW + i] * s1, c = gi[2 * (int64_t)HW + i] * s2;
+    if (Cx == 1) {
+      o[i] = (accumulate ? o[i] : 0.f) + (a + b + c);
+    } else {
+      o[i] = (accumulate ? o[i] : 0.f) + a;
+      o[HW + i] = (accumulate ? o[HW + i] : 0.f) + b;
+      o[2 * (int64_t)HW + i] = (accumulate ? o[2 * (int64_t)HW + i] : 0.f) + c;
+    }
+  }
+}
+
+// y[n][c] = (x[n][Cx == 1 ? 0 : c] - shift_c) / scale_c: the LPIPS scaling layer, materialised (3 channels)
+__global__ __launch_bounds__(256) void lpips_input_kernel(const float* __restrict__ x, int64_t x_nstride, int HW, int Cx, float a0, float a1, float a2,
+                                                          float b0, float b1, float b2, float* __restrict__ y) {
+  const int n = blockIdx.y;
+  const float* xi = x + n * x_nstride;
+  float* o = y + (int64_t)n * 3 * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float v0 = xi[i], v1 = Cx == 1 ? v0 : xi[HW + i], v2 = Cx == 1 ? v0 : xi[2 * (int64_t)HW + i];
+    o[i] = fmaf(v0, a0, b0);
+    o[HW + i] = fmaf(v1, a1, b1);
+    o[2 * (int64_t)HW + i] = fmaf(v2, a2, b2);
+  }
+}
+
+inline unsigned blocks_1d(int64_t n) {
+  const int64_t b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream) {
+  VTS_CHECK_ARG(z && out && NC >= 1 && H >= 2 && W >= 2 && (pad == 0 || pad == 1) && NC <= 65535 * 16, "vts_maxpool2_relu_pad: bad args");
+  const int PH = H / 2 + 2 * pad, PW = W / 2 + 2 * pad;
+  for (int c0 = 0; c0 < NC; c0 += 65535) {
+    const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
+    hipLaunchKernelGGL(maxpool2_relu_pad_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream, z + (int64_t)c0 * H * W, H, W, pad,
+                       out + (int64_t)c0 * PH * PW);
+  }
+  VTS_CHECK_LAUNCH("vts_maxpool2_relu_pad");
+  return VTS_OK;
+}
+
+extern "C" int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int H, int W, float* gz, void* stream) {
+  VTS_CHECK_ARG(g && z && gz && NC >= 1 && H >= 2 && W >= 2, "vts_maxpool2_relu_bwd: bad args");
+  for (int c0 = 0; c0 < NC; c0 += 65535) {
+    const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
+    hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3(blocks_1d((int64_t)H * W), nc), dim3(256), 0, (hipStream_t)stream,
+                       g + (int64_t)c0 * (H / 2) * (W / 2), z + (int64_t)c0 * H * W, H, W, gz + (int64_t)c0 * H * W);
+  }
+  VTS_CHECK_LAUNCH("vts_maxpool2_relu_bwd");
+  return VTS_OK;
+}
+
+extern "C" int vts_relu_mask_pad(const float* g, const float* g2, const float* z, int NC, int H, int W, int pad, float* out, void* stream) {
+  VTS_CHECK_ARG((g || g2) && z && out && NC >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad <= 2, "vts_relu_mask_pad: bad args");
+  const int PH = H + 2 * pad, PW = W + 2 * pad;
+  for (int c0 = 0; c0 < NC; c0 += 65535) {
+    const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
+    const int64_t o = (int64_t)c0 * H * W;
+    hipLaunchKernelGGL(relu_mask_pad_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream, g ? g + o : nullptr,
+                       g2 ? g2 + o : nullptr, z + o, H, W, pad, out + (int64_t)c0 * PH * PW);
+  }
+  VTS_CHECK_LAUNCH("vts_relu_mask_pad");
+  return VTS_OK;
+}
+
+extern "C" int vts_lpips_layer(const float* z0, const float* z1, int N, int C, int HW, const float* w, float coeff, int64_t* loss_slot,
+                               float* dz0, float grad_coeff, void* stream) {
+  VTS_CHECK_ARG(z0 && z1 && w && N >= 1 && N <= 65535 && C >= 1 && HW >= 1, "vts_lpips_layer: bad args");
+  hipLaunchKernelGGL(lpips_layer_kernel, dim3(blocks_1d(HW), N), dim3(256), 0, (hipStream_t)stream, z0, z1, C, HW, w, coeff,
+                     reinterpret_cast<long long*>(loss_slot), dz0, grad_coeff);
+  VTS_CHECK_LAUNCH("vts_lpips_layer");
+  return VTS_OK;
+}
+
+extern "C" int vts_l1_relu(const float* za, const float* zb, int64_t n, float coeff, int64_t* loss_slot, float* grad, void* stream) {
+  VTS_CHECK_ARG(za && zb && n >= 1, "vts_l1_relu: bad args");
+  hipLaunchKernelGGL(l1_relu_kernel, dim3(blocks_1d(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, za, zb, n, coeff,
+                     reinterpret_cast<long long*>(loss_slot), grad);
+  VTS_CHECK_LAUNCH("vts_l1_relu");
+  return VTS_OK;
+}
+
+extern "C" int vts_lpips_input(const float* x, int64_t x_nstride, int N, int Cx, int HW, const float* shift3, const float* scale3, float* y, void* stream) {
+  VTS_CHECK_ARG(x && y && shift3 && scale3 && N >= 1 && N <= 65535 && (Cx == 1 || Cx == 3) && HW >= 1, "vts_lpips_input: bad args (host shift / scale triples)");
+  hipLaunchKernelGGL(lpips_input_kernel, dim3(blocks_1d(HW), N), dim3(256), 0, (hipStream_t)stream, x, x_nstride, HW, Cx, 1.f / scale3[0], 1.f / scale3[1],
+                     1.f / scale3[2], -shift3[0] / scale3[0], -shift3[1] / scale3[1], -shift3[2] / scale3[2], y);
+  VTS_CHECK_LAUNCH("vts_lpips_input");
+  return VTS_OK;
+}
+
+extern "C" int vts_lpips_input_bwd(const float* g, int N, int Cx, int HW, const float* scale3, float* dx, int64_t dx_nstride, int accumulate, void* stream) {
+  VTS_CHECK_ARG(g && dx && scale3 && N >= 1 && N <= 65535 && (Cx == 1 || Cx == 3) && HW >= 1, "vts_lpips_input_bwd: bad args");
+  hipLaunchKernelGGL(lpips_input_bwd_kernel, dim3(blocks_1d(HW), N), dim3(256), 0, (hipStream_t)stream, g, HW, Cx, 1.f / scale3[0], 1.f / scale3[1],
+                     1.f / scale3[2], dx, dx_nstride, accumulate);
+  VTS_CHECK_LAUNCH("vts_lpips_input_bwd");
+  return VTS_OK;
+}

@@ -10,8 +10,9 @@ D2: sketch ++ tactile, both with `getIntermFeat`) and the LSGAN objective:
     optimize_parameters :702-722                       D and D2 step, then G step
 
 The GAN feature-matching term of the reference compares every discriminator feature with ITSELF (.detach(),
-:662-680), so its value and gradient are identically zero: it is reported as 0.  The VGG / LPIPS terms need
-pretrained weights that cannot exist offline: requesting them raises (`--no_vgg_loss True` is required).
+:662-680), so its value and gradient are identically zero: it is reported as 0.  The VGG feature term (VGGLoss on torchvision's VGG19,
+networks.py:2021-2067) runs on the GEMM-class kernels (vts/perceptual.py); its pretrained weights cannot exist offline:
+`--vgg_weights` loads them, otherwise seeded stand-ins are used and `loss_vgg_pretrained` is False.
 """
 import torch
 
@@ -41,7 +42,8 @@ MODEL_FLAGS = [
     ("niter_decay", int, 100), ("separate_val_set", B, False), ("fp16", "flag", False),
 ]
 
-LOSS_SLOTS = ["G_GAN_I", "G_GAN_T", "G_GAN", "D_real", "D_fake", "D2_real", "D2_fake", "G_GAN_Feat", "G_GAN_Feat_I", "G_GAN_Feat_T"]
+LOSS_SLOTS = ["G_GAN_I", "G_GAN_T", "G_GAN", "D_real", "D_fake", "D2_real", "D2_fake", "G_GAN_Feat", "G_GAN_Feat_I", "G_GAN_Feat_T",
+              "G_VGG", "G_VGG_I", "G_VGG_T"]
 
 
 class Pix2PixHDModel(BaseModel):
@@ -52,6 +54,9 @@ class Pix2PixHDModel(BaseModel):
         for name, _, _ in [r for r in MODEL_FLAGS if r[1] == "flag"]:
             parser.add_argument("--" + name, action="store_true", default=False)
         parser.add_argument("--use_hip_graph", type=B, default=True)   # not a reference flag: replay captured HIP graphs
+        # not a reference flag: torchvision vgg19 state dict for VGGLoss (the reference downloads it, models/networks.py:2040); without a
+        # file the term runs on seeded stand-in weights and `loss_vgg_pretrained` says so
+        parser.add_argument("--vgg_weights", type=str, default="")
         parser.set_defaults(norm="batch", netG="global", netD="multiscale", ngf=64, dataset_mode="aligned", dataset="patchskit",
                             crop_size=1536, normG="instance", normD="instance", pool_size=0, n_epochs=50, n_epcohs_decay=150,
                             gan_mode="lsgan")
@@ -81,6 +86,8 @@ class Pix2PixHDModel(BaseModel):
                 self.loss_names += ["G_GAN_I", "G_GAN_T", "G_GAN", "D_real", "D_fake", "D2_real", "D2_fake"]
             if not opt.no_ganFeat_loss:
                 self.loss_names += ["G_GAN_Feat", "G_GAN_Feat_I", "G_GAN_Feat_T"]
+            if not opt.no_vgg_loss:
+                self.loss_names += ["G_VGG", "G_VGG_I", "G_VGG_T"]
         self.criterionGAN = networks.GANLoss(opt.gan_mode)
         self.netG = networks.define_G(opt.sketch_nc, opt.image_nc + opt.touch_nc, opt.ngf, opt.netG, opt.norm, gpu_ids=self.gpu_ids,
                                       opt=opt)
@@ -96,6 +103,11 @@ class Pix2PixHDModel(BaseModel):
             self.optimizer_D = FlatAdam(self.flatD, opt.lr, betas)
             self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr, betas)
             self.optimizers += [self.optimizer_G, self.optimizer_D, self.optimizer_D2]
+        self.netVGG = None
+        if self.isTrain and not opt.no_vgg_loss:      # criterionVGG = VGGLoss(gpu_ids) (pix2pixHD_model.py; networks.py:2021-2067): frozen
+            from . import perceptual
+            self.netVGG = perceptual.build_vgg19(opt, self.device)
+            self.loss_vgg_pretrained = bool(self.netVGG.pretrained)
         self._loss_buf = ops.loss_slots(len(LOSS_SLOTS), self.device)     # int64 fixed point (order-independent accumulation)
         self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
         self._bufs = {}
@@ -106,8 +118,6 @@ class Pix2PixHDModel(BaseModel):
     @staticmethod
     def _check_unbuilt(opt):
         bad = []
-        if opt.isTrain and not opt.no_vgg_loss:
-            bad.append("VGG perceptual loss needs pretrained VGG19 weights (--no_vgg_loss True)")
         if not opt.no_instance or opt.instance_feat or opt.label_feat or opt.label_nc != 0 or opt.load_features:
             bad.append("instance / label feature inputs (netE) are not built")
         if opt.netG not in ("global", "local"):
@@ -196,6 +206,17 @@ class Pix2PixHDModel(BaseModel):
                           (self.netD2, [dict(in0=self.real_S, in1=self.fake_T, real=True, coeff=1.0, slot=slot["G_GAN_T"], grad_coeff=1.0,
                                              param_grads=False, input_grad=(d_fake_T, False))])], self.criterionGAN)
         slot["G_GAN"].copy_(slot["G_GAN_I"] + slot["G_GAN_T"])
+        if self.netVGG is not None:
+            # VGG feature matching (pix2pixHD_model.py:680-693): the image, and gx / gy each tiled to three channels
+            from vts import perceptual as P_
+            lam = self.opt.lambda_vgg
+            d_fake_I.add_(P_.vgg_feature_l1(self.netVGG, self.fake_I, self.real_I, lam, slot["G_VGG_I"]))
+            for c in (0, 1):
+                f3 = self.fake_T[:, c:c + 1].expand(-1, 3, -1, -1).contiguous()
+                r3 = self.real_T[:, c:c + 1].expand(-1, 3, -1, -1).contiguous()
+                g3 = P_.vgg_feature_l1(self.netVGG, f3, r3, lam, slot["G_VGG_T"])
+                ops.lpips_input_bwd(g3, (1.0, 1.0, 1.0), d_fake_T[:, c:c + 1], 1, accumulate=True)     # adjoint of the tiling: sum of the three
+            slot["G_VGG"].copy_(slot["G_VGG_I"] + slot["G_VGG_T"])
         d_raw = torch.empty(n, 5, h, w, device=dev)
         ops.g_out_grad(d_fake_I, d_fake_T, self.M, self.g_out, d_raw)
         engine.resnet_backward(self.netG, self._g_ctx, d_raw)

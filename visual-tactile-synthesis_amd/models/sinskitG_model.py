@@ -84,6 +84,10 @@ class SinSKITGModel(BaseModel):
         # not a reference flag: state dict of torchvision's Inception-v3 (or pytorch-fid's) for the I_SIFID / T_SIFID metrics; the
         # reference downloads it (models/inception.py:58), which cannot happen offline
         parser.add_argument("--inception_weights", type=str, default="")
+        # not a reference flag: state-dict file(s) of the LPIPS-VGG16 network (torchvision vgg16 features + lpips v0.1 lin layers, comma
+        # separated); the reference gets them from `lpips.LPIPS(net="vgg")`, which downloads (sinskitG_model.py:495).  Without a file the
+        # perceptual terms run on seeded stand-in weights and `loss_lpips_pretrained` / `metric_lpips_pretrained` say so.
+        parser.add_argument("--lpips_weights", type=str, default="")
         parser.set_defaults(model=cls.MODEL_NAME, dataset_mode=cls.DATASET_MODE, netG="unet256_custom", netD="multiscale",
                             netD2="multiscale", gan_mode="nonsaturating", ngf=10, ndf=8, lr=0.001, beta1=0.0, beta2=0.99,
                             crop_size=1536, no_flip=True, dataroot=cls.DATAROOT, data_len=cls.DATA_LEN)
@@ -137,6 +141,10 @@ class SinSKITGModel(BaseModel):
                     self.loss_names.append("D_more_fake_T")
             if opt.lambda_G2_L1 > 0.0:
                 self.loss_names.append("G2_L1")
+            if opt.lambda_G1_lpips > 0.0:
+                self.loss_names.insert(self.loss_names.index("G_L1") + 1 if "G_L1" in self.loss_names else len(self.loss_names), "G_lpips")
+            if opt.lambda_G2_lpips > 0.0:
+                self.loss_names.append("G2_lpips")
         # evaluation metrics (SIFID / LPIPS / PSNR / SSIM ...) are SURVEY.md §8(f) row 2: not built
         self.metric_names = []
 
@@ -189,6 +197,10 @@ class SinSKITGModel(BaseModel):
             if "D2" in self.model_names:
                 self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr_G2, betas)
                 self.optimizers.append(self.optimizer_D2)
+        # LPIPS-VGG16 (criterionLPIPS_vgg, sinskitG_model.py:495): frozen, not a saved network
+        self.netLPIPS = None
+        if self.isTrain and (opt.lambda_G1_lpips > 0 or opt.lambda_G2_lpips > 0):
+            self._lpips_net()
         self._loss_buf = ops.loss_slots(len(LOSS_SLOTS), self.device)     # int64 fixed point (order-independent accumulation)
         self._slot = {n: self._loss_buf[i:i + 1] for i, n in enumerate(LOSS_SLOTS)}
         self._spe_cache = {}
@@ -206,14 +218,19 @@ class SinSKITGModel(BaseModel):
         if not opt.isTrain:
             return
         bad = []
-        if opt.lambda_G1_lpips > 0 or opt.lambda_G2_lpips > 0:
-            bad.append("LPIPS (--lambda_G1_lpips 0 --lambda_G2_lpips 0)")
         if opt.use_vision_aided_loss:
             bad.append("CLIP vision-aided discriminator (--use_vision_aided_loss False)")
         if bad:
             raise NotImplementedError(
                 "third-party loss terms need pretrained weights that are not available offline and are not built: %s. "
                 "Disable them explicitly (SURVEY.md §7 'Third-party loss terms')." % "; ".join(bad))
+
+    def _lpips_net(self):
+        if self.netLPIPS is None:
+            from . import perceptual
+            self.netLPIPS = perceptual.build_lpips(self.opt, self.device)
+            self.loss_lpips_pretrained = self.metric_lpips_pretrained = bool(self.netLPIPS.pretrained)
+        return self.netLPIPS
 
     # ------------------------------------------------------------------ input
     def _buf(self, name, shape, dtype=torch.float32):
@@ -657,10 +674,28 @@ class SinSKITGModel(BaseModel):
         if opt.lambda_G1_L1 > 0.0:
             ops.l1(self.fake_I, self.real_I, opt.lambda_G1_L1 / self.fake_I.numel(), slot["G_L1"], self._d_fake_I, accumulate=False)
             self._have_dI = True
+        if opt.lambda_G1_lpips > 0.0:
+            # criterionLPIPS_vgg(fake_I, real_I).mean() * lambda (:1711)
+            from vts import perceptual as P_
+            P_.lpips_term(self.netLPIPS, self.fake_I, self.real_I, opt.lambda_G1_lpips / n, slot["G_lpips"], grad_into=self._d_fake_I,
+                          grad_accumulate=self._have_dI)
+            self._have_dI = True
         d_fake_T = None
+        d_patch = None
         if opt.lambda_G2_L1 > 0.0:
             d_patch = torch.empty(P, 2, 32, 32, device=dev)
             ops.l1(self.fake_T_concat, ts["real_T"], opt.lambda_G2_L1 / (n * 2 * 32 * 32), slot["G2_L1"], d_patch)
+        if opt.lambda_G2_lpips > 0.0:
+            # _compute_touch_lpips_loss (:1619-1658): gx and gy as 1-channel images (the ScalingLayer broadcasts them to three channels),
+            # view(-1, NT, 1, 1, 1).sum(1).mean() = sum over all patches / number of images, the two channels added
+            from vts import perceptual as P_
+            have = d_patch is not None
+            if not have:
+                d_patch = torch.empty(P, 2, 32, 32, device=dev)
+            for c in (0, 1):
+                P_.lpips_term(self.netLPIPS, self.fake_T_concat[:, c:c + 1], ts["real_T"][:, c:c + 1], opt.lambda_G2_lpips / n, slot["G2_lpips"],
+                              grad_into=d_patch[:, c:c + 1], grad_accumulate=have)
+        if d_patch is not None:
             d_fake_T = torch.empty(n, 2, h, w, device=dev)
             ops.patch_scatter_bwd(d_patch, 0, 2, ts["offx"], ts["offy"], nt, 32, d_fake_T)
         self._d_fake_T = d_fake_T
@@ -814,8 +849,8 @@ class SinSKITGModel(BaseModel):
     def compute_metrics(self, prefix=""):
         """Evaluation metrics of the current outputs (reference: compute_evaluation_metric, models/model_utils.py:431-561, called from
         compute_visuals sinskitG_model.py:889-925): I_PSNR, I_SSIM, T_AE, T_MSE on the validation patches (the training patches with
-        prefix 'train_'), and I_SIFID / T_SIFID when an Inception block is available (_sifid_net).  *_LPIPS need VGG / AlexNet weights
-        and are not built."""
+        prefix 'train_'), I_SIFID / T_SIFID when an Inception block is available (_sifid_net), I_LPIPS / T_LPIPS when the LPIPS network is
+        (it is whenever an LPIPS loss term is on, with --lpips_weights, or with VTS_LPIPS_METRICS=1 on the stand-in weights)."""
         pset = self.train_set if prefix == "train_" else self.val_set
         if pset is None or not hasattr(self, "real_I") or self.test_edit_S:
             return {}
@@ -830,6 +865,24 @@ class SinSKITGModel(BaseModel):
             vals += [float(engine.sifid_images(net, self.real_I.contiguous(), self.fake_I.contiguous())),
                      float(engine.sifid_tactile(net, pset["real_T"], fake_T_concat))]
             self.metric_sifid_pretrained = bool(net.pretrained)
+        if getattr(self.opt, "lpips_weights", "") or os.environ.get("VTS_LPIPS_METRICS", "0") == "1" or self.netLPIPS is not None:
+            # I_LPIPS / T_LPIPS (model_utils.py:475-478, 521-527).  eval_LPIPS is the VGG network while training (:497-499); the reference
+            # switches to AlexNet at test time (:501) -- not built (11 x 11 stride-4 stem): VGG is used in both phases and
+            # `metric_lpips_backbone` says so.
+            from vts import perceptual as P_
+            net = self._lpips_net()
+            buf = ops.loss_slots(2, self.device)
+            n_img = self.real_I.shape[0]
+            P_.lpips_term(net, self.real_I.contiguous(), self.fake_I.contiguous(), 1.0 / n_img, buf[0:1])
+            for c in (0, 1):     # nearest resize to 224 x 224, fake clamped to [0, 1], each channel tiled to three; mean over patches, gx + gy
+                a = ops.sifid_input(pset["real_T"], c, 1, size=(224, 224))
+                b = ops.sifid_input(fake_T_concat, c, 1, size=(224, 224), clamp01=True)
+                for i0 in range(0, P, 32):
+                    P_.lpips_term(net, a[i0:i0 + 32], b[i0:i0 + 32], 1.0 / P, buf[1:2])
+            lv = ops.loss_values(buf)
+            names += ["I_LPIPS", "T_LPIPS"]
+            vals += [lv[0], lv[1]]
+            self.metric_lpips_pretrained, self.metric_lpips_backbone = bool(net.pretrained), "vgg"
         for name, v in zip(names, vals):
             setattr(self, "metric_%s%s" % (prefix, name), v)
             if prefix + name not in self.metric_names:

@@ -1162,3 +1162,63 @@ def linear_rows(x, weight, bias=None, relu=False):
     y = torch.empty(r, o, dtype=torch.float32, device=x.device)
     L.check(L.load().vts_linear_rows(x.data_ptr(), weight.data_ptr(), L.ptr(bias), r, i, o, int(relu), y.data_ptr(), L.stream()), "vts_linear_rows")
     return y
+
+
+# ---- perceptual terms: glue around the frozen VGG stacks (include/vts.h) ----
+def maxpool2_relu_pad(z, pad=1):
+    n, c, h, w = z.shape
+    assert z.is_contiguous() and h % 2 == 0 and w % 2 == 0, "VGG feature maps are even-sized"
+    out = torch.empty(n, c, h // 2 + 2 * pad, w // 2 + 2 * pad, dtype=torch.float32, device=z.device)
+    _run("maxpool2_relu_pad", 4.0 * (z.numel() + out.numel()), 0.0, L.load().vts_maxpool2_relu_pad, z.data_ptr(), n * c, h, w, pad, out.data_ptr(), L.stream())
+    return out
+
+
+def maxpool2_relu_bwd(g, z):
+    n, c, h, w = z.shape
+    assert g.shape == (n, c, h // 2, w // 2) and g.is_contiguous() and z.is_contiguous()
+    gz = torch.empty_like(z)
+    _run("maxpool2_relu_bwd", 4.0 * (2 * z.numel() + g.numel()), 0.0, L.load().vts_maxpool2_relu_bwd, g.data_ptr(), z.data_ptr(), n * c, h, w, gz.data_ptr(), L.stream())
+    return gz
+
+
+def relu_mask_pad(g, g2, z, pad=1):
+    n, c, h, w = z.shape
+    for t in (g, g2):
+        assert t is None or (t.shape == z.shape and t.is_contiguous())
+    out = torch.empty(n, c, h + 2 * pad, w + 2 * pad, dtype=torch.float32, device=z.device)
+    _run("relu_mask_pad", 4.0 * (z.numel() * (2 + (g is not None and g2 is not None)) + out.numel()), 0.0, L.load().vts_relu_mask_pad, L.ptr(g), L.ptr(g2),
+         z.data_ptr(), n * c, h, w, pad, out.data_ptr(), L.stream())
+    return out
+
+
+def lpips_layer(z0, z1, w, coeff, loss_slot, dz0=None, grad_coeff=0.0):
+    n, c, h, wd = z0.shape
+    assert z1.shape == z0.shape and z0.is_contiguous() and z1.is_contiguous() and w.numel() == c
+    _run("lpips_layer", 4.0 * z0.numel() * (4 + 3 * (dz0 is not None)), 6.0 * z0.numel(), L.load().vts_lpips_layer, z0.data_ptr(), z1.data_ptr(), n, c, h * wd,
+         w.data_ptr(), coeff, L.ptr(loss_slot), L.ptr(dz0), grad_coeff, L.stream())
+
+
+def l1_relu(za, zb, coeff, loss_slot, grad=None):
+    assert za.shape == zb.shape and za.is_contiguous() and zb.is_contiguous()
+    _run("l1_relu", 4.0 * za.numel() * (2 + (grad is not None)), 0.0, L.load().vts_l1_relu, za.data_ptr(), zb.data_ptr(), za.numel(), coeff, L.ptr(loss_slot),
+         L.ptr(grad), L.stream())
+
+
+def _triple(v):
+    return (C.c_float * 3)(*[float(t) for t in v])
+
+
+def lpips_input(x, shift, scale, nstride=None, channels=None):
+    """LPIPS ScalingLayer output [N, 3, H, W] of x [N, 3 | 1, H, W] (a 1-channel VIEW of a wider tensor: pass its batch stride)"""
+    n, cx, h, w = x.shape if channels is None else (x.shape[0], channels, x.shape[2], x.shape[3])
+    y = torch.empty(n, 3, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.load().vts_lpips_input(x.data_ptr(), x.stride(0) if nstride is None else nstride, n, cx, h * w, _triple(shift), _triple(scale), y.data_ptr(), L.stream()),
+            "vts_lpips_input")
+    return y
+
+
+def lpips_input_bwd(g, scale, dx, cx, accumulate=False, nstride=None):
+    n, _, h, w = g.shape
+    L.check(L.load().vts_lpips_input_bwd(g.data_ptr(), n, cx, h * w, _triple(scale), dx.data_ptr(), dx.stride(0) if nstride is None else nstride, int(accumulate),
+                                         L.stream()), "vts_lpips_input_bwd")
+    return dx

@@ -1,0 +1,132 @@
+"""Forward / input-gradient schedules of the frozen VGG feature stacks and the perceptual terms built on them.
+
+  lpips_term      lpips.LPIPS(net="vgg")(fake, real) reduced the way the reference reduces it (models/sinskitG_model.py:1711: mean over
+                  samples; :1648-1657: per-image sum over the NT patches), value into a fixed-point loss slot, gradient w.r.t. `fake`
+  vgg_feature_l1  VGGLoss (models/networks.py:2021-2033): sum_i w_i L1(relu_i(x), relu_i(y)), gradient w.r.t. x
+
+Network layout: torchvision VGG features = 3x3 convolutions (padding 1) + ReLU, MaxPool2d(2, 2) between blocks.  Here every
+convolution's RAW output z is kept and relu is applied by the reader: the next convolution's pre-padded input is one fused pass
+(pad_affine with ReLU, or vts_maxpool2_relu_pad behind a block), the taps read z with relu on load.  The 3 -> 64 first layer runs as
+4x4 tap blocks on the generator's kernel (ops.convk), everything else on the GEMM-class MFMA kernels (ops.conv3x3_wide) with weights
+packed ONCE (the stacks are frozen).  The backward is the input adjoint only (no weight gradients): ReLU mask + padding in one pass
+(vts_relu_mask_pad), the same GEMM kernel on flipped / transposed packing, vts_maxpool2_relu_bwd behind a block.
+"""
+import torch
+
+from . import lib as L
+from . import ops
+
+RELU = L.ACT_RELU
+
+
+def _packed(net, k, mode):
+    key = (k, mode)
+    buf = net._packed.get(key)
+    if buf is None:
+        w = net.convs[k].weight
+        buf = ops.w3x3_pack(w, mode, tag="frozen%d" % id(net))
+        net._packed[key] = buf
+    return buf
+
+
+def _layout(net):
+    """[(conv index, pooled_before?)] in forward order"""
+    out, k, pool = [], 0, False
+    for v in net.cfg:
+        if v == "M":
+            pool = True
+        else:
+            out.append((k, pool))
+            pool = False
+            k += 1
+    return out
+
+
+def vgg_forward(net, x, keep_all=True, last_tap_only_needed=True):
+    """x [N, 3, H, W] (already in the network's input space).  Returns {conv index: raw output z}: every convolution when keep_all
+    (a backward follows), else the tapped ones only.  Stops after the deepest tap."""
+    n, _, h, w = x.shape
+    dev = x.device
+    zs = {}
+    prev = None
+    last = max(net.taps)
+    for k, pooled in _layout(net):
+        if k > last:
+            break
+        conv = net.convs[k]
+        co, ci = conv.weight.shape[:2]
+        if k == 0:
+            z = torch.empty(n, co, h, w, dtype=torch.float32, device=dev)
+            ops.convk(x, conv.weight, z, bias=conv.bias, pad=1)
+        else:
+            p = ops.maxpool2_relu_pad(prev, 1) if pooled else ops.pad_affine(prev, (1, 1, 1, 1), 0, act=RELU)
+            z = torch.empty(n, co, p.shape[2] - 2, p.shape[3] - 2, dtype=torch.float32, device=dev)
+            ops.conv3x3_wide(p, _packed(net, k, "conv_fwd"), conv.bias, z)
+        if keep_all or k in net.taps:
+            zs[k] = z
+        prev = z
+    return zs
+
+
+def vgg_backward(net, zs, tap_grads, x_shape):
+    """gradient w.r.t. the network input given {tap conv index: gradient w.r.t. relu(z_tap)}; zs from vgg_forward(keep_all=True)"""
+    lay = [e for e in _layout(net) if e[0] <= max(net.taps)]
+    g = None            # gradient w.r.t. relu(z_k) arriving from the layers behind, at z_k's resolution
+    n = x_shape[0]
+    for idx in range(len(lay) - 1, -1, -1):
+        k, pooled = lay[idx]
+        z = zs[k]
+        gt = tap_grads.get(k)
+        if g is None and gt is None:
+            continue
+        conv = net.convs[k]
+        co, ci = conv.weight.shape[:2]
+        if k == 0:
+            gm = ops.relu_mask_pad(g, gt, z, pad=0)
+            dx = torch.empty(x_shape, dtype=torch.float32, device=z.device)
+            ops.convk_bwd_data(gm, conv.weight, dx, pad=1)
+            return dx
+        gp = ops.relu_mask_pad(g, gt, z, pad=1)
+        gin = torch.empty(n, ci, z.shape[2], z.shape[3], dtype=torch.float32, device=z.device)
+        ops.conv3x3_wide(gp, _packed(net, k, "conv_adj"), None, gin)
+        g = ops.maxpool2_relu_bwd(gin, zs[lay[idx - 1][0]]) if pooled else gin
+    raise RuntimeError("vgg_backward: no tap gradient given")
+
+
+def lpips_term(net, fake, real, coeff, loss_slot, grad_into=None, grad_accumulate=False, channels=None, nstride_fake=None, nstride_real=None,
+               grad_nstride=None):
+    """loss_slot += coeff * sum_n LPIPS(fake_n, real_n); grad_into (+)= coeff * d(.)/d fake when given.
+    fake / real: [N, 3, H, W], or 1-channel VIEWS (channels=1, nstride_* = batch stride of the tensor they are a channel of):
+    the ScalingLayer broadcasts the single channel to three, as lpips does for the tactile gx / gy images."""
+    cx = fake.shape[1] if channels is None else channels
+    y1 = ops.lpips_input(real, net.shift, net.scale, nstride=nstride_real, channels=cx)
+    z1 = vgg_forward(net, y1, keep_all=False)
+    del y1
+    y0 = ops.lpips_input(fake, net.shift, net.scale, nstride=nstride_fake, channels=cx)
+    want = grad_into is not None
+    z0 = vgg_forward(net, y0, keep_all=want)
+    tap_grads = {}
+    for i, k in enumerate(net.taps):
+        dz = torch.empty_like(z0[k]) if want else None
+        ops.lpips_layer(z0[k], z1[k], net.lins[i].view(-1), coeff, loss_slot, dz0=dz, grad_coeff=coeff)
+        if want:
+            tap_grads[k] = dz
+    if not want:
+        return None
+    gy = vgg_backward(net, z0, tap_grads, tuple(y0.shape))
+    return ops.lpips_input_bwd(gy, net.scale, grad_into, cx, accumulate=grad_accumulate, nstride=grad_nstride)
+
+
+def vgg_feature_l1(net, x, y, coeff, loss_slot, want_grad=True):
+    """VGGLoss: loss_slot += coeff * sum_i w_i mean|relu_i(x) - relu_i(y)|; returns d(.)/dx (or None).  x, y [N, 3, H, W]."""
+    zy = vgg_forward(net, y, keep_all=False)
+    zx = vgg_forward(net, x, keep_all=want_grad)
+    tap_grads = {}
+    for wi, k in zip(net.weights, net.taps):
+        g = torch.empty_like(zx[k]) if want_grad else None
+        ops.l1_relu(zx[k], zy[k], coeff * wi / zx[k].numel(), loss_slot, grad=g)
+        if want_grad:
+            tap_grads[k] = g
+    if not want_grad:
+        return None
+    return vgg_backward(net, zx, tap_grads, tuple(x.shape))
