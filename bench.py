@@ -33,15 +33,16 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s
 MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_16x16x4_f32)
 
 
-def build_model(size, batch, model_name, quiet=True, netG="unet256_custom"):
+def build_model(size, batch, model_name, quiet=True, netG="unet256_custom", lpips=False):
     import contextlib
     import io
 
     from models import create_model
     from options.train_options import TrainOptions
 
-    flags = ("--model %s --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
-             "--checkpoints_dir /tmp/vts_bench --name bench --crop_size %d --batch_size %d --netG %s" % (model_name, size, batch, netG))
+    flags = ("--model %s --gpu_ids 0 %s--use_vision_aided_loss False "
+             "--checkpoints_dir /tmp/vts_bench --name bench --crop_size %d --batch_size %d --netG %s"
+             % (model_name, "" if lpips else "--lambda_G1_lpips 0 --lambda_G2_lpips 0 ", size, batch, netG))
     if model_name == "pix2pixHD":   # reference defaults (ngf 64, 4 downsamplings, 9 blocks), VGG term off (no weights offline)
         flags = ("--model pix2pixHD --gpu_ids 0 --no_vgg_loss True --checkpoints_dir /tmp/vts_bench --name bench --batch_size %d "
                  "--dataset_mode patchskit" % batch)
@@ -326,6 +327,9 @@ def main():
                     help="generator: unet256_custom (headline config) | resnet_{4,6,9}blocks (alternate; needs --model sinskitG)")
     ap.add_argument("--p2p_size", type=int, default=32, help="pix2pixHD only: side of the (square) training images / patches")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--lpips", action="store_true",
+                    help="SECONDARY workload: the same step with the reference's default LPIPS-VGG16 terms on (lambda_G1_lpips 1, lambda_G2_lpips 10; "
+                         "stand-in VGG weights -- the arithmetic is the same): ~7.7 TFLOP of 3x3 convolutions per step on the GEMM-class kernels")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--no_viz", action="store_true",
                     help="leave out the reference step's full-resolution D2 visualisation pass (2.85 GFLOP/image, no gradient): SURVEY 8d "
@@ -347,7 +351,9 @@ def main():
     torch.manual_seed(1234 + rank)      # per-rank DiffAugment draws (the default generator is seeded identically on every rank)
     if args.infer:
         return infer_bench(args)
-    model, opt = build_model(args.size, args.batch, args.model, netG=args.netG)
+    model, opt = build_model(args.size, args.batch, args.model, netG=args.netG, lpips=args.lpips)
+    if args.lpips and args.steps == 250:
+        args.steps, args.warmup = 30, 4      # ~70 ms per step
     opt.use_hip_graph = not args.no_graph
     opt.skip_D2_visualisation_pass = bool(args.no_viz)
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
@@ -383,7 +389,7 @@ def main():
     # the same K steps with a FRESH host batch per step: set_input (H2D of S / I / M / patches, masking, candidate map) inside the timed
     # region, as a train.py loop pays it (`value` keeps the contract: inputs resident in HBM)
     fresh_ms = None
-    if world == 1 and args.model != "pix2pixHD":
+    if world == 1 and args.model != "pix2pixHD" and not args.lpips:
         def pinned(b):   # what the package's DataLoader hands over (data/__init__.py: pin_memory=True)
             return {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
 
@@ -433,7 +439,7 @@ def main():
                 torch.cuda.synchronize()
                 model.opt.use_hip_graph = keep
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and args.model != "pix2pixHD":
+        if world == 1 and not args.no_cpu_baseline and args.model != "pix2pixHD" and not args.lpips:
             cpu = cpu_baseline(args.size, style_dim, netG=args.netG)
         ms = dt / args.steps * 1e3
         out = {
@@ -446,8 +452,10 @@ def main():
                 "workload": ("pix2pixHD G+D+D2 train step (GlobalGenerator ngf 64, ndf 64), %d %dx%d images/GPU, VGG term off "
                              "(no weights offline)" % (args.batch, args.p2p_size, args.p2p_size)) if args.model == "pix2pixHD" else
                             "%s%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
-                            "LPIPS/CLIP terms off (no weights offline)" % (args.model, "" if args.netG == "unet256_custom" else " (netG %s)" % args.netG,
-                                                                          args.size, args.size, args.batch),
+                            "%s" % (args.model, "" if args.netG == "unet256_custom" else " (netG %s)" % args.netG,
+                                    args.size, args.size, args.batch,
+                                    "LPIPS-VGG16 terms ON (reference default lambdas; seeded stand-in VGG weights), CLIP term off" if args.lpips
+                                    else "LPIPS/CLIP terms off (no weights offline)"),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world, "losses_finite": finite,
                 "hip_graph": bool(opt.use_hip_graph), "d2_visualisation_pass": not args.no_viz,
             },

@@ -274,3 +274,51 @@ def test_pix2pixHD_step_with_vgg_term_matches_reference_golden(golden_dir):
         if k.endswith(".bias") and abs(rp[1]) < 1e-4:
             continue
         probe_close(p.grad, rp, k, 3e-3)
+
+
+def test_lpips_on_a_full_patch_set_equals_its_halves():
+    """256 patches x 512 channels exceeds the 16-bit grid dimension of the padding kernel (sample chunks): one call on the whole
+    set = the sum of two calls on its halves, values and gradients (the size of the headline step's tactile term)"""
+    from vts import ops, perceptual as P
+
+    dev = _dev()
+    net, _ = _lpips_pair()
+    a, b = (0.3 * detrand.uniform((256, 1, 32, 32), 13, "a")).to(dev), (0.3 * detrand.uniform((256, 1, 32, 32), 13, "b")).to(dev)
+    s_all, s_half = ops.loss_slots(1, dev), ops.loss_slots(1, dev)
+    g_all, g_half = torch.empty_like(a), torch.empty_like(a)
+    P.lpips_term(net, a, b, 1.0, s_all, grad_into=g_all)
+    for h in (slice(0, 128), slice(128, 256)):
+        P.lpips_term(net, a[h], b[h], 1.0, s_half, grad_into=g_half[h])
+    va, vh = ops.loss_values(s_all)[0], ops.loss_values(s_half)[0]
+    assert va > 0 and abs(va - vh) <= 1e-5 * va
+    assert rel(g_all, g_half) < 1e-4      # other k-split plans at the two batch sizes
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 128), (8, 72, 64, 100, 90), (8, 128, 48, 96, 96)])
+def test_conv3x3_wide_64_channel_tile(case):
+    """layers of <= 64 output channels on >= 256 tiles take the 64-channel x 8-row tile (conv3x3_wide64_kernel): against F.conv2d,
+    and bit-identical to the 128-channel tile's result (same per-output summation order)"""
+    import os
+
+    from vts import lib as L, ops
+
+    dev = _dev()
+    n, ci, co, h, w = case
+    x = detrand.uniform((n, ci, h, w), 17, "x")
+    wt = detrand.uniform((co, ci, 3, 3), 17, "w") * (1.0 / (ci * 9) ** 0.5)
+    b = 0.1 * detrand.uniform((co,), 17, "b")
+    ref = F.conv2d(x, wt, b, padding=1)
+    p = F.pad(x, (1, 1, 1, 1)).to(dev)
+    packed = ops.w3x3_pack(wt.to(dev), "conv_fwd", tag="t64")
+    out = torch.empty(n, co, h, w, device=dev)
+    ops.conv3x3_wide(p, packed, b.to(dev), out)
+    assert L.load().vts_last_kernel().decode() == "conv3x3_wide64_kernel"
+    assert rel(out, ref) < 1e-5
+    os.environ["VTS_NO_WIDE64"] = "1"
+    try:
+        out2 = torch.empty_like(out)
+        ops.conv3x3_wide(p, packed, b.to(dev), out2)
+        assert L.load().vts_last_kernel().decode().startswith("conv3x3_wide_kernel")
+    finally:
+        del os.environ["VTS_NO_WIDE64"]
+    assert torch.equal(out, out2)

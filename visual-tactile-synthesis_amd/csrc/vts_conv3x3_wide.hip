@@ -46,21 +46,27 @@ struct WideK {
 // K: kernel extent (3 | 4: taps of the packed weight = K * K), CKT: input channels per chunk, LIVE: most taps one launch uses
 // (K * K, or 4 for the parity phases of the transposed stride-2 layers, which then stage 16 channels per chunk: with 1-4 taps
 // a chunk of 4-8 channels is too few MFMAs per barrier)
-template <int S, int K, int CKT, int LIVE = K * K>
+// MS: how the four waves split the workgroup's tile -- 2: two 64-channel halves x two row pairs (128 channels x 4 rows, the default);
+// 1 (round 3, layers of <= 64 output channels: the VGG stacks' first block and its input adjoint): ONE 64-channel group x four row
+// pairs (64 channels x 8 rows) -- with the 128-channel tile half of every MFMA of such a layer multiplied zero rows (59 TFLOP/s on
+// 64 -> 64 at 1024 x 1024 against 124-131 TFLOP/s on the 128..512-channel layers)
+template <int S, int K, int CKT, int LIVE = K * K, int MS = 2>
 __device__ __forceinline__ void wide_body(const WideK& p) {
   constexpr int CK = CKT, TWT = K * K;
+  constexpr int TCO = 64 * MS, TY = 8 / MS;            // (shadow the file-level tile constants)
+  constexpr int QPR = TCO / 4, QSH = MS == 2 ? 5 : 4;  // weight quads per (channel, tap) row and its log2
   constexpr int PR = S * (TY - 1) + K, PC = S * (TX - 1) + K, PCP = (PC + 3) / 4 * 4;
   constexpr int PATCH_FLOATS = CK * PR * PCP;
   constexpr int W_FLOATS = CK * LIVE * TCO;
   constexpr int PQ_ROW = PCP / 4;
   constexpr int NPQ = (CK * PR * PQ_ROW + 255) / 256;
-  constexpr int NWQ = W_FLOATS / 4 / 256;               // 9 (8 for K = 4) weight quads per thread (fewer taps: fewer are live)
+  constexpr int NWQ = (W_FLOATS / 4 + 255) / 256;       // 9 (8 for K = 4) weight quads per thread (fewer taps: fewer are live)
   __shared__ __attribute__((aligned(16))) float lds[PATCH_FLOATS + W_FLOATS];
   float* lds_p = lds;
   float* lds_w = lds + PATCH_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave & 1, wpx = wave >> 1;
+  const int wco = MS == 2 ? (wave & 1) : 0, wpx = MS == 2 ? (wave >> 1) : wave;
   const int tiles_x = (p.W + TX - 1) / TX;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int x0 = tx * TX, y0 = ty * TY, co0 = blockIdx.y * TCO, n = blockIdx.z % p.N, ks = blockIdx.z / p.N;
@@ -84,7 +90,7 @@ __device__ __forceinline__ void wide_body(const WideK& p) {
 #pragma unroll
   for (int e = 0; e < NWQ; ++e) {
     const int q = tid + e * 256;
-    const int row = q >> 5, cq = q & 31;                    // row = ci * ntaps + t
+    const int row = q >> QSH, cq = q & (QPR - 1);           // row = ci * ntaps + t
     const int ci = row / ntaps, t = row - ci * ntaps;
     const bool live = row < CK * ntaps;
     wvoff[e] = live ? ((ci * TWT + p.wt_tap[live ? t : 0]) * p.Cout + co0 + 4 * cq) * 4 : 0x7ffffff0;   // dead rows: out of range -> 0
@@ -100,14 +106,14 @@ __device__ __forceinline__ void wide_body(const WideK& p) {
     for (int e = 0; e < NPQ; ++e) pq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pvoff[e] + pbase, 0, 0);
 #pragma unroll
     for (int e = 0; e < NWQ; ++e)
-      if (e * 8 < CK * ntaps) wq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[e] + wbase, 0, 0);   // uniform
+      if (e * (256 / QPR) < CK * ntaps) wq[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[e] + wbase, 0, 0);   // uniform
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int e = 0; e < NPQ; ++e) *reinterpret_cast<u32x4*>(lds_p + ploff[e]) = pq[e];
 #pragma unroll
     for (int e = 0; e < NWQ; ++e)
-      if (e * 8 < CK * ntaps && ((tid + e * 256) >> 5) < CK * ntaps) *reinterpret_cast<u32x4*>(lds_w + wloff[e]) = wq[e];
+      if (e * (256 / QPR) < CK * ntaps && ((tid + e * 256) >> QSH) < CK * ntaps) *reinterpret_cast<u32x4*>(lds_w + wloff[e]) = wq[e];
   };
 
   f32x16 acc[2][2];
@@ -169,6 +175,8 @@ __device__ __forceinline__ void wide_body(const WideK& p) {
 
 template <int S>
 __global__ __launch_bounds__(256) void conv3x3_wide_kernel(const WideK p) { wide_body<S, 3, 8>(p); }
+// <= 64 output channels: 64 channels x (8 rows x 32 columns) per workgroup (MS = 1)
+__global__ __launch_bounds__(256) void conv3x3_wide64_kernel(const WideK p) { wide_body<1, 3, 8, 9, 1>(p); }
 
 // the same tiling for 4 x 4 kernels (the ndf = 64 PatchGAN discriminators of pix2pixHD on full-size images): 16-tap packed
 // weights, 4 input channels per chunk (32 KB of weights + a 7 x 36 / 10 x 68 patch per channel in LDS)
@@ -654,6 +662,10 @@ static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_
     if (S == 1) hipLaunchKernelGGL(conv4x4_wide_kernel<1>, grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL(conv4x4_wide_kernel<2>, grid, dim3(256), 0, st, k);
     vts_set_kernel(KS > 1 ? "conv4x4_wide_kernel<%d>+ksplit" : "conv4x4_wide_kernel<%d>", S);
+  } else if (S == 1 && KS == 1 && k.os == 1 && k.Cout <= 64 && cdiv(k.W, TX) * cdiv(k.H, 8) * k.N >= 256 && !getenv("VTS_NO_WIDE64")) {
+    grid = dim3(cdiv(k.W, TX) * cdiv(k.H, 8), 1, k.N);
+    hipLaunchKernelGGL(conv3x3_wide64_kernel, grid, dim3(256), 0, st, k);
+    vts_set_kernel("conv3x3_wide64_kernel");
   } else {
     if (S == 1) hipLaunchKernelGGL(conv3x3_wide_kernel<1>, grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL(conv3x3_wide_kernel<2>, grid, dim3(256), 0, st, k);

@@ -790,9 +790,22 @@ def pad_affine(x, pads, mode, out=None, act=0, res=None, out_nstride=0):
     pt, pb, pl, pr = pads
     if out is None:
         out = torch.empty(n, c, h + pt + pb, w + pl + pr, dtype=torch.float32, device=t.device)
+    if n * c > 65535:      # the kernel's grid carries (n, c) in one 16-bit dimension: sample chunks (VGG features of 256 patches x 512 channels)
+        step = max(1, 65535 // c)
+        ons = out_nstride if out_nstride else out.stride(0)
+        for n0 in range(0, n, step):
+            n1 = min(n, n0 + step)
+            sub = Act(t[n0:n1], op_slice(x, "scale", n0, n1, c), op_slice(x, "shift", n0, n1, c)) if isinstance(x, Act) else t[n0:n1]
+            pad_affine(sub, pads, mode, out=out[n0:n1], act=act, res=None if res is None else res[n0:n1], out_nstride=ons)
+        return out
     _run("pad_affine", 4.0 * (t.numel() + out.numel() * (2 if res is not None else 1)), 0.0, L.load().vts_pad_affine, C.byref(op), n, h, w,
          pt, pb, pl, pr, mode, act, L.ptr(res), out.data_ptr(), out_nstride, L.stream())
     return out
+
+
+def op_slice(a, name, n0, n1, c):
+    v = getattr(a, name, None)
+    return None if v is None else v[n0 * c:n1 * c]
 
 
 def pad_bwd(dpad, pads, mode, din, accumulate=False):
