@@ -328,6 +328,54 @@ def test_validation_replay_between_training_replays_reads_its_own_outputs():
     assert model._graphs is not None and model._infer_graph is not None     # both kinds of replay really happened
 
 
+def test_step_on_a_singleskit_dataset_batch_matches_oracle(tmp_path):
+    """the REAL dataset front-end in front of the HIP step: a TouchClothing-format material on disk (data/synthetic_material.py) ->
+    data/singleskit_dataset.py (bit-identical to the reference class, tests/test_dataset.py) -> default_collate -> set_input ->
+    optimize_parameters, against the oracle on the same collated batch (random crop, 8 sampled tactile squares with their contact
+    masks and crop offsets, real augmentation parameters)"""
+    import random
+
+    from data.singleskit_dataset import SingleSkitDataset
+    from data.synthetic_material import write_material
+    from models import create_model
+    from options.train_options import TrainOptions
+    from oracle.make_dataset_golden import dataset_opt
+
+    root = write_material(str(tmp_path / "m"), seed=3)
+    random.seed(1)
+    np.random.seed(1)
+    ds = SingleSkitDataset(dataset_opt(root, "train", w_resampling=True))
+    batch = default_collate([ds[0]])
+    nt = batch["T_images"].shape[1]
+    assert nt == 8 and batch["S"].shape == (1, 1, 256, 256)
+    opt = TrainOptions(cmd_line=(FLAGS % (256, 1)) + " --batch_size_G2 %d" % nt).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    model.train()
+    sds = load_test_weights(model, 91)
+    random.seed(2)
+    cnt = int(nets.dilated_mask_positions(batch["M"].float()).shape[0])
+    draws = {"aug": detrand.uniform((4, 1), 5, "aug") * 0.5 + 0.5, "more_idx": torch.tensor([random.sample(range(cnt), 32)])}
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    ref = step.train_step(sds[0], sds[1], sds[2], adam, batch, draws, opt=step.hp(batch_size_G2=nt))
+    model._draws = draws
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    torch.cuda.synchronize()
+    losses = model.get_current_losses()
+    for k, v in ref["losses"].items():
+        assert abs(losses["l_" + k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses["l_" + k], v)
+    assert rel(model.fake_I, ref["fake_I"]) < 1e-3 and rel(model.fake_T, ref["fake_T"]) < 1e-3
+    assert rel(model.fake_T_concat, ref["fake_T_concat"]) < 1e-3
+    for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+        named = dict(net.named_parameters())
+        for k, gr in ref["grad_" + nm].items():
+            if null_grad_bias(nm, k):
+                continue
+            assert rel(named[k].grad, gr) < 2e-3, (nm, k)
+
+
 def test_eval_metrics_match_oracle():
     """I_PSNR / T_AE / T_MSE kernels vs the oracle (pinned to the reference's compute_evaluation_metric), and through the model"""
     from data.synthetic_dataset import make_sample

@@ -177,7 +177,16 @@ class SinSKITGModel(BaseModel):
                 raise NotImplementedError("the HIP step is built for the default conditioning "
                                           "(use_cGAN, use_cGAN_G2{,_S,_I}, use_bg_mask all True)")
             if opt.T_resolution_multiplier != 1:
-                raise NotImplementedError("T_resolution_multiplier != 1 needs the bicubic anti-aliased resampler; not built")
+                # Probed on the reference itself (round 3, CPU, 256 x 256, --T_resolution_multiplier 2, netG unet256_custom and
+                # resnet_9blocks): its own optimize_parameters fails with "Sizes of tensors must match except in dimension 1. Expected
+                # size 32 but got size 64" -- get_patch_in_input cuts (32 * multiplier)-pixel fake patches (sinskitG_model.py:1277) that
+                # compute_D2_loss concatenates with the 32-pixel sketch / image / real patches (:1477-1484), and no generator of this
+                # model emits the larger tactile map (networks.py:1101 needs generate_T_imgs).  The anti-aliased bicubic resampler those
+                # branches call exists here (ops.bicubic_aa / bicubic_aa_bwd, pinned to F.interpolate(antialias=True)); there is no
+                # working upstream behaviour to wire it to.
+                raise NotImplementedError("T_resolution_multiplier %d: the reference's sinskitG step cannot run with a multiplier other than 1 "
+                                          "(patch sizes 32 vs %d collide in compute_D2_loss, sinskitG_model.py:1477-1484)"
+                                          % (opt.T_resolution_multiplier, 32 * opt.T_resolution_multiplier))
             if "D" in self.model_names:
                 self.netD = networks.define_D(opt.image_nc + opt.sketch_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.normD,
                                               opt.init_type, opt.init_gain, opt.no_antialias, num_D=opt.num_D_D1,
@@ -326,7 +335,8 @@ class SinSKITGModel(BaseModel):
         n, nt = T.shape[0], T.shape[1]
         ox, oy, cs = self._patch_offsets(torch.as_tensor(T_coords).numpy())
         if not (cs == 32).all():
-            raise NotImplementedError("patch cutout != 32 px needs the bicubic resampler; not built")
+            raise NotImplementedError("patch cutout != 32 px (resize_ratio != 1): the reference asserts it never happens for this dataset "
+                                      "(data/singleskit_dataset.py:874); the resampling branch of get_patch_in_input (model_utils.py:263-300) is not wired")
         P = n * nt
         f32 = torch.float32      # (the casts happen in _stage; .to() on the host would be another many-threaded torch op)
         parts = [("raw", T.reshape(P, 2, 32, 32), f32), ("masks", torch.as_tensor(I_masks).reshape(P, 1, 32, 32), f32),
