@@ -111,6 +111,26 @@ def main():
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "arrays")
 
+    # the paired-patch form of the baselines (data/patchskit_dataset.py): training items = one (S, I, M, T) patch each, test = whole crop
+    from data.patchskit_dataset import PatchSkitDataset     # the REFERENCE's
+    out = {"meta": np.array("reference PatchSkitDataset on data/synthetic_material.write_material(seed 21 train / 22 test); seeds 7 / 8; "
+                            "w_resampling False; torch %s" % torch.__version__)}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for phase, mseed, seed in (("train", 21, 7), ("test", 22, 8)):
+                root = sm.write_material(os.path.join(tmp, "mat_" + phase), seed=mseed, phase=phase)
+                random.seed(seed)
+                np.random.seed(seed)
+                ds = PatchSkitDataset(dataset_opt(root, phase, return_patch=phase == "train"))
+                out[phase + "/len"] = np.array(len(ds))
+                dump(ds, phase, out)
+        finally:
+            os.chdir(cwd)
+    path = os.path.join(ROOT, "tests", "golden", "patchskit_dataset.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "arrays")
+
 
 if __name__ == "__main__":
     main()

@@ -15,15 +15,10 @@ from data.synthetic_material import write_material
 from oracle.make_dataset_golden import dataset_opt
 
 
-@pytest.mark.parametrize("phase,mseed,seed", [("train", 11, 5), ("test", 12, 6)])
-def test_singleskit_dataset_matches_reference_cache(phase, mseed, seed, tmp_path, golden_dir):
-    g = np.load(os.path.join(golden_dir, "singleskit_dataset.npz"))
-    root = write_material(str(tmp_path / ("mat_" + phase)), seed=mseed, phase=phase)
-    random.seed(seed)
-    np.random.seed(seed)
-    ds = SingleSkitDataset(dataset_opt(root, phase))
-    keys = [k for k in g.files if k.startswith(phase + "/")]
-    assert len(ds) == 2 and keys
+def _compare_with_reference_cache(ds, g, phase):
+    """every array / scalar / string the reference class cached, bit for bit"""
+    keys = [k for k in g.files if k.startswith(phase + "/") and k != phase + "/len"]
+    assert keys
     seen = set()
     for index in range(len(ds)):
         item = ds[index]
@@ -50,6 +45,17 @@ def test_singleskit_dataset_matches_reference_cache(phase, mseed, seed, tmp_path
                 assert np.array_equal(np.asarray(v, dtype=np.float64) if len(v) else np.zeros((0,)), g[key]), key
                 seen.add(key)
     assert seen == set(keys), set(keys) ^ seen
+
+
+@pytest.mark.parametrize("phase,mseed,seed", [("train", 11, 5), ("test", 12, 6)])
+def test_singleskit_dataset_matches_reference_cache(phase, mseed, seed, tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, "singleskit_dataset.npz"))
+    root = write_material(str(tmp_path / ("mat_" + phase)), seed=mseed, phase=phase)
+    random.seed(seed)
+    np.random.seed(seed)
+    ds = SingleSkitDataset(dataset_opt(root, phase))
+    assert len(ds) == 2
+    _compare_with_reference_cache(ds, g, phase)
     b = ds[0]
     if phase == "train":
         assert b["T_images"].shape == (8, 2, 32, 32) and b["T_coords"].shape == (8, 8) and b["I_masks"].shape == (8, 32, 32)
@@ -89,3 +95,33 @@ def test_touch_npz_reader_and_laplacian_weight(tmp_path):
     lap = np.zeros((32, 32))
     lap[10, 10], lap[9, 10], lap[11, 10], lap[10, 9], lap[10, 11] = -4 * 255, 255, 255, 255, 255
     assert abs(variance_of_laplacian(one, ref=np.ones_like(one) * 255) - lap.var()) < 1e-9
+
+
+@pytest.mark.parametrize("phase,mseed,seed", [("train", 21, 7), ("test", 22, 8)])
+def test_patchskit_dataset_matches_reference_cache(phase, mseed, seed, tmp_path, golden_dir):
+    """data/patchskit_dataset.py against what the REFERENCE's PatchSkitDataset cached for the same seeded material: training items are
+    single paired (sketch, image, mask, tactile) patches, the test item is the whole crop with all tactile squares"""
+    from data.patchskit_dataset import PatchSkitDataset
+
+    g = np.load(os.path.join(golden_dir, "patchskit_dataset.npz"))
+    root = write_material(str(tmp_path / ("mat_" + phase)), seed=mseed, phase=phase)
+    random.seed(seed)
+    np.random.seed(seed)
+    ds = PatchSkitDataset(dataset_opt(root, phase, return_patch=phase == "train"))
+    assert len(ds) == int(g[phase + "/len"])
+    _compare_with_reference_cache(ds, g, phase)
+    if phase == "train":
+        from torch.utils.data import default_collate
+        b = default_collate([ds[i] for i in range(4)])      # the pix2pixHD step's batch (models/pix2pixHD_model.py:set_input)
+        assert b["S_images"].shape == (4, 1, 32, 32) and b["I_images"].shape == (4, 3, 32, 32) and b["M_images"].shape == (4, 1, 32, 32)
+        assert b["T_images"].shape == (4, 2, 32, 32) and b["I_masks"].shape == (4, 32, 32)
+    else:
+        assert ds[0]["S"].shape == (1, 256, 256) and ds[0]["T_images"].ndim == 4 and ds[0]["I_masks"].shape[1:] == (32, 1, 32)      # sic: the reference unsqueezes axis -2 (patchskit_dataset.py:313, its own TODO)
+
+
+def test_patchskit_is_a_creatable_dataset_mode(tmp_path):
+    """--dataset_mode patchskit resolves through the factory (it used to raise 'not built')"""
+    from data import find_dataset_using_name
+    from data.patchskit_dataset import PatchSkitDataset
+
+    assert find_dataset_using_name("patchskit") is PatchSkitDataset

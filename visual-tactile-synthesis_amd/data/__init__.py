@@ -1,6 +1,7 @@
 """Dataset factory (mirror of /root/reference/data/__init__.py:17-104).
 
-`--dataset_mode singleskit` is the TouchClothing front-end (data/singleskit_dataset.py, pinned to the reference's class);
+`--dataset_mode singleskit` is the TouchClothing front-end (data/singleskit_dataset.py, pinned to the reference's class),
+`--dataset_mode patchskit` its paired-patch form for the pix2pixHD baseline (data/patchskit_dataset.py, pinned likewise);
 `--dataset_mode synthetic` is the seeded generator bench.py / the tests use (same post-collate batch-dict contract).  A dataset mode whose front-end is not built in this package RAISES when a dataset is created -- it is never silently
 replaced by synthetic noise (a maintainer pointing --dataroot at real TouchClothing data must not train on noise).
 """
@@ -10,7 +11,7 @@ import torch.utils.data
 
 # reference dataset modes whose CPU front-end is not built here: their option setter resolves (the reference parser asks for it
 # while gathering options, options/base_options.py:238-240) but create_dataset refuses them
-_UNBUILT = ("skit", "patchskit", "aligned")
+_UNBUILT = ("skit", "aligned")
 
 
 def find_dataset_using_name(dataset_name):

@@ -298,8 +298,9 @@ class SingleSkitDataset(torch.utils.data.Dataset):
         print("Finish preprocessing %d data, takes " % len(self), time.time() - t0)
 
     # ------------------------------------------------------------------------------------------------------------------
-    def find_validate_touch_patches_and_coords(self, T_size, T_paths, aug, S3, M3, is_train=False, is_val=False):
-        """GelSight rectangles through the augmentation (singleskit_dataset.py:434-658) -> (T_images, T_coords, full_T_coords, I_masks)"""
+    def find_validate_touch_patches_and_coords(self, T_size, T_paths, aug, S3, M3, is_train=False, is_val=False, I3=None, compute_SIM_patches=False):
+        """GelSight rectangles through the augmentation (singleskit_dataset.py:434-658) -> (T_images, T_coords, full_T_coords, I_masks);
+        compute_SIM_patches (PatchSkitDataset, :1024-1036): also the sketch / image / mask patches under every tactile square -> 7 values"""
         opt = self.opt
         valid_idx, roi1, roi2, roi3 = [], [], [], []
         for i in range(int(T_size)):
@@ -316,7 +317,8 @@ class SingleSkitDataset(torch.utils.data.Dataset):
                 roi1.append([int(round(x1)), int(round(y1)), int(round(h1)), int(round(w1))])
                 roi2.append([int(round(x2)), int(round(y2)), int(round(h2)), int(round(w2))])
         calc_weight = bool(getattr(opt, "w_resampling", False))
-        all_T, all_C, all_K, weights, roi3_update = self.process_all_valid_patches(valid_idx, roi3, T_paths, aug, S3, M3, calc_weight, is_train)
+        all_T, all_C, all_K, weights, roi3_update, all_S, all_I, all_M = self.process_all_valid_patches(
+            valid_idx, roi3, T_paths, aug, S3, M3, calc_weight, is_train, I3=I3, compute_SIM_patches=compute_SIM_patches)
         total = len(all_T)
         bs = min(opt.batch_size_G2, total) if getattr(opt, "batch_size_G2", 0) > 0 else total
         bs_val = min(opt.batch_size_G2_val, total) if getattr(opt, "batch_size_G2_val", 0) > 0 else total
@@ -331,9 +333,11 @@ class SingleSkitDataset(torch.utils.data.Dataset):
         else:
             print("test set, select all patches")
             sel = range(len(all_C))
+        if compute_SIM_patches:
+            return all_T[sel], all_C[sel], roi3_update, all_K[sel], all_S[sel], all_I[sel], all_M[sel]
         return all_T[sel], all_C[sel], roi3_update, all_K[sel]
 
-    def process_all_valid_patches(self, valid_idx, roi3, T_paths, aug, S3, M3, calc_weight, is_train):
+    def process_all_valid_patches(self, valid_idx, roi3, T_paths, aug, S3, M3, calc_weight, is_train, I3=None, compute_SIM_patches=False):
         """32 x 32 squares of every valid GelSight rectangle (singleskit_dataset.py:660-1128, contact-mask method)"""
         opt = self.opt
         mult = opt.T_resolution_multiplier
@@ -370,23 +374,34 @@ class SingleSkitDataset(torch.utils.data.Dataset):
                 T_images.append(gxy)
                 T_coords.append([nx, ny, nh, nw, aug["patch_crop_size"], 1, int((cx - half) / mult), int((cy - half) / mult)])
                 I_masks.append(masks[k])
-        if calc_weight:
+        S_images, I_images, M_images = [], [], []
+        if calc_weight or compute_SIM_patches:
             for nx, ny, nh, nw, pcs, rr, px, py in T_coords:
                 ox, oy = np.round((nx + px / rr) * mult), np.round((ny + py / rr) * mult)
                 cut = np.round(pcs / rr * mult)
                 S_patch = np.array(S3.crop((ox, oy, ox + cut, oy + cut)))
-                v = variance_of_laplacian(S_patch, ref=np.ones_like(S_patch) * 255)   # the sketch's reference level is white
-                weights.append(min(max(opt.resampling_w_min, v), opt.resampling_w_max))
+                if compute_SIM_patches:      # S_tf / I_tf / M_tf of the caller: ToTensor (+ Normalize 0.5 / 0.5 for S and I), :1024-1033
+                    S_images.append(normalize_half(to_tensor(S_patch)))
+                    I_images.append(normalize_half(to_tensor(np.array(I3.crop((ox, oy, ox + cut, oy + cut))))))
+                    M_images.append(to_tensor(np.array(M3.crop((ox, oy, ox + cut, oy + cut)))))
+                if calc_weight:
+                    v = variance_of_laplacian(S_patch, ref=np.ones_like(S_patch) * 255)   # the sketch's reference level is white
+                    weights.append(min(max(opt.resampling_w_min, v), opt.resampling_w_max))
         if len(T_images) > 1:
             T_images, T_coords = torch.stack(T_images, dim=0), np.stack(T_coords, axis=0)
             I_masks = torch.from_numpy(np.array(I_masks))
         elif len(T_images) == 1:
             T_images, T_coords = torch.unsqueeze(T_images[0], 0), np.array(T_coords)
             I_masks = torch.unsqueeze(torch.from_numpy(I_masks[0]), 0)
+        if compute_SIM_patches:
+            assert len(S_images) == len(I_images) == len(M_images) and len(S_images) > 1, "S_images, I_images, M_images should have the same length and > 1"
+            S_images, I_images, M_images = torch.stack(S_images, dim=0), torch.stack(I_images, dim=0), torch.stack(M_images, dim=0)
+        else:
+            S_images = I_images = M_images = None
         weights = np.array(weights) if calc_weight else None
         if calc_weight:
             assert len(weights) == len(T_coords), "weights and T_coords should have the same length"
-        return T_images, T_coords, I_masks, weights, roi3_update
+        return T_images, T_coords, I_masks, weights, roi3_update, S_images, I_images, M_images
 
     def __getitem__(self, index):
         assert index in self.data_dict.keys(), "Cannot find index %d in dataset" % index
