@@ -408,6 +408,35 @@ def test_eval_metrics_match_oracle():
     assert set(model.get_current_metrics().keys()) == {"m_I_PSNR", "m_T_AE", "m_T_MSE", "m_I_SSIM"}
 
 
+def test_ssim_known_answers():
+    """I_SSIM (torchmetrics' structural_similarity_index_measure, model_utils.py:496-499) is a third-party dependency that is absent
+    here: its kernel stays PARITY-UNPINNED against torchmetrics itself.  What CAN be pinned without it are the closed forms of Wang et
+    al.'s definition that any implementation must reproduce: two constant images a, b give (2ab + C1) / (a^2 + b^2 + C1) in every
+    window (variances and covariance vanish, the contrast-structure factor is C2 / C2), with C1 = (0.01 * data_range)^2; identical
+    images give exactly 1; the measure is symmetric."""
+    from vts import lib as L, ops
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    ws = ops.workspace(lib.vts_metric_ws_floats(), dev)
+    lohi = torch.tensor([-1.0, 1.0], device=dev)        # the normalisation range: x -> (x + 1) / 2, data_range 1
+    out = torch.zeros(1, device=dev)
+
+    def ssim(a, b):
+        L.check(lib.vts_metric_ssim(a.data_ptr(), b.data_ptr(), a.shape[0] * a.shape[1], a.shape[2], a.shape[3], lohi.data_ptr(), out.data_ptr(), ws.data_ptr(), L.stream()),
+                "vts_metric_ssim")
+        return float(out.item())
+
+    for va, vb in ((0.2, -0.4), (-0.9, 0.9), (0.0, 0.5)):
+        a, b = torch.full((1, 3, 40, 52), va, device=dev), torch.full((1, 3, 40, 52), vb, device=dev)
+        x, y = (va + 1) / 2, (vb + 1) / 2
+        want = (2 * x * y + 1e-4) / (x * x + y * y + 1e-4)
+        # 5e-4: the windowed moments are E[x^2] - mu^2 in fp32 (as in torchmetrics), whose rounding residue ~1e-8 sits beside C2 = 9e-4
+        assert abs(ssim(a, b) - want) < 5e-4, (va, vb, ssim(a, b), want)
+    g = torch.Generator().manual_seed(4)
+    p, q = (torch.rand(2, 3, 37, 61, generator=g) * 2 - 1).to(dev), (torch.rand(2, 3, 37, 61, generator=g) * 2 - 1).to(dev)
+    assert abs(ssim(p, p) - 1.0) < 1e-6 and abs(ssim(p, q) - ssim(q, p)) < 1e-6 and ssim(p, q) < 0.2
+
+
 def test_sifid_chain_matches_oracle_and_reference_golden(golden_dir, monkeypatch):
     """I_SIFID / T_SIFID on the HIP path (vts_sifid_input, Inception block 0 on the conv kernels, device Frechet distance) vs (i) the
     values the REFERENCE's compute_evaluation_metric chain produced for the same seeded inputs and stand-in weights
