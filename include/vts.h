@@ -196,6 +196,10 @@ int vts_conv4x4_in(const vts_conv_desc* d, const vts_norm_desc* nd, int* fused, 
  * vts_norm_stats. */
 int64_t vts_conv4x4_norm_ws_floats(const vts_conv_desc* d);
 int vts_conv4x4_norm(const vts_conv_desc* d, const vts_norm_desc* nd, float* stat_ws, int64_t stat_ws_floats, int* fused, void* stream);
+/* *fused after vts_conv4x4_norm: 0 = plain convolution (call vts_norm_stats); 1 = statistics complete (k-split epilogue); 2 + s = the
+ * epilogue wrote s (mean, M2, count) slots per (n, channel) into stat_ws and this second stage merges them into nd's outputs (two
+ * entry points so that a caller timing launches sees the convolution and the merge as what they are: two kernels). */
+int vts_norm_stats_from_partials(const vts_norm_desc* nd, const float* part, int slots, void* stream);
 
 /* Backward of the same normalisation (in place on dy):
  *   dx = A*dy + B*x + C  with the per-group coefficients of InstanceNorm / BatchNorm backward;

@@ -842,6 +842,10 @@ extern "C" int vts_conv4x4_norm(const vts_conv_desc* d, const vts_norm_desc* nd,
   return conv4x4_impl(d, stream, nd, fused, StatWs{stat_ws, stat_ws_floats});
 }
 
+extern "C" int vts_norm_stats_from_partials(const vts_norm_desc* nd, const float* part, int slots, void* stream) {
+  return vts_norm_finalize_partials(nd, part, slots, (hipStream_t)stream);
+}
+
 static int dispatch_full(const vts_conv_desc* d, const ConvK& k, int nr, int N, hipStream_t st);
 
 static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw) {
@@ -960,11 +964,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       int rc;
       if (!d->transposed) rc = d->stride == 2 ? launch<0, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<0, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
       else rc = d->stride == 2 ? launch<1, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<1, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
-      if (rc == VTS_OK && cg_stats) {
-        const int rf = vts_norm_finalize_partials(nd, sw.p, t_stat_spl, st);
-        if (rf != VTS_OK) return rf;
-        *fused = 1;
-      }
+      if (rc == VTS_OK && cg_stats) *fused = 2 + t_stat_spl;    // partials written: the caller merges them (vts_norm_stats_from_partials)
       if (rc != VTS_OK || KS == 1) return rc;
       static const int fuse_in = getenv("VTS_FUSE_SPLIT_IN") ? atoi(getenv("VTS_FUSE_SPLIT_IN")) : 1;
       if (nd && nd->mode == 0 && fuse_in && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
@@ -984,9 +984,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   if (want_stats) k.stat_part = sw.p;
   const int rc = dispatch_full(d, k, nr, N, st);
   if (rc != VTS_OK || !want_stats) return rc;
-  const int rf = vts_norm_finalize_partials(nd, sw.p, t_stat_spl, st);
-  if (rf != VTS_OK) return rf;
-  *fused = 1;
+  *fused = 2 + t_stat_spl;      // partials written: the caller merges them (vts_norm_stats_from_partials)
   return VTS_OK;
 }
 

@@ -196,6 +196,11 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     sws = stat_workspace(lib.vts_conv4x4_norm_ws_floats(C.byref(d)), x.device)
     fused = C.c_int(0)
     _run(label, nbytes, flops, lib.vts_conv4x4_norm, C.byref(d), C.byref(nd), sws.data_ptr(), sws.numel(), C.byref(fused), L.stream())
+    if fused.value >= 2:      # the epilogue wrote statistics partials: merge them (the second stage of norm_stats)
+        if TIMER is not None:
+            DETAIL = "%s N%d %dx%dx%d from %d epilogue slots" % ("BN" if mode else "IN", out.shape[0], cout, d.OH, d.OW, fused.value - 2)
+        _run("norm_from_partials", 12.0 * out.shape[0] * cout * (fused.value - 2), 0.0, lib.vts_norm_stats_from_partials, C.byref(nd), sws.data_ptr(), fused.value - 2, L.stream())
+        return Act(out, st[0], st[1], st[2], st[3])
     if fused.value:
         return Act(out, st[0], st[1], st[2], st[3])
     return norm_stats(out, mode, **kw)
