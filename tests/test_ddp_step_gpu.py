@@ -31,7 +31,11 @@ rank, world = ddp.init_from_env("cuda")
 from tests.test_ddp_step_gpu import build, sample_and_draws, SEED
 from tests.test_step_gpu import load_test_weights
 mode, out_dir = sys.argv[1], sys.argv[2]
-model, opt = build()
+# "oracle" mode: vanishing learning rates.  Adam's first update is lr * sign(g) per element, so with real rates the discriminators the
+# generator's gradient is taken through differ between two implementations by +- lr wherever g is rounding noise (that is what the
+# 6e-3 bound of round 2 absorbed); with a vanishing step the generator gradient is a like-for-like comparison at the 2e-3 of the
+# single-rank tests.  The replica-identity checks run with the real rates in "graph" mode.
+model, opt = build(" --lr 1e-12 --lr_G2 1e-12" if mode == "oracle" else "")
 load_test_weights(model, SEED if rank == 0 else SEED + 10)     # rank 1 starts from OTHER weights: parallelize() must replace them
 model.parallelize()
 assert ddp.active() and set(model.ddp.buckets) == {"D", "D2", "G_dec", "G_enc"}, model.ddp.buckets.keys()
@@ -58,12 +62,12 @@ torch.distributed.destroy_process_group()
 '''
 
 
-def build():
+def build(extra=""):
     from models import create_model
     from options.train_options import TrainOptions
 
     from tests.test_step_gpu import FLAGS
-    opt = TrainOptions(cmd_line=FLAGS % (SIZE, 1)).parse()
+    opt = TrainOptions(cmd_line=(FLAGS % (SIZE, 1)) + extra).parse()
     model = create_model(opt)
     model.setup(opt)
     model.train()
@@ -115,7 +119,7 @@ def test_two_ranks_real_step_matches_mean_of_oracle_gradients(tmp_path):
                detrand.test_weights(nets.d_param_shapes(7), SEED + 2))
         batch, draws = sample_and_draws(rank)
         adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
-        return step.train_step(sds[0], sds[1], sds[2], adam, batch, draws, exchange=exchange), sds
+        return step.train_step(sds[0], sds[1], sds[2], adam, batch, draws, exchange=exchange, opt=step.hp(lr=1e-12, lr_G2=1e-12)), sds
 
     # Data-parallel semantics on the oracle: D and D2 are updated with the MEAN of the ranks' gradients before the generator's loss is
     # evaluated through them.  The D / D2 gradients of a rank do not depend on the other rank (they come first in the step), so a
@@ -139,11 +143,8 @@ def test_two_ranks_real_step_matches_mean_of_oracle_gradients(tmp_path):
             err = (g.double() * r0["scale"] - 0.5 * (g0 + g1)).norm().item()
             worst.append((err / (0.5 * (g0.norm().item() + g1.norm().item())), n, k))
     worst.sort(reverse=True)
-    # D / D2 gradients: 2e-3 as in the single-rank tests.  The generator's gradient is taken THROUGH the discriminator after its Adam
-    # update, and with beta1 = 0 the first update is lr * sign(g): elements whose mean gradient is rounding noise move by +-lr in
-    # either implementation, which the visual decoder's gradient sees at the few-1e-3 level (up3 / up2: 3.7e-3 / 2.8e-3 measured)
-    assert max(w for w, n, _ in worst if n != "G") <= 2e-3, worst[:10]
-    assert max(w for w, n, _ in worst if n == "G") <= 6e-3, worst[:10]
+    # 2e-3 as in the single-rank tests, for all three networks (vanishing learning rates: see WORKER)
+    assert max(w for w, n, _ in worst) <= 2e-3, worst[:10]
     for rank, r in enumerate((r0, r1)):                                               # every rank logs the losses of its OWN sample
         for k, v in refs[rank]["losses"].items():
             assert abs(r["losses"]["l_" + k] - v) <= 1e-3 * max(1.0, abs(v)), (rank, k)

@@ -795,6 +795,7 @@ int vts_norm_finalize_partials(const vts_norm_desc* d, const float* part, int sp
   VTS_CHECK_ARG(!(k.ext_mean && !k.ext_uvar) && !(k.stat_mean && !k.stat_uvar), "vts_norm_finalize_partials: ext / stat outputs come in pairs");
   hipLaunchKernelGGL(norm_finalize_wide_kernel, dim3(d->mode == 0 ? d->N * d->C : d->C), dim3(256), 0, st, part, k);
   VTS_CHECK_LAUNCH("vts_norm_finalize_partials");
+  vts_set_kernel("norm_finalize_wide_kernel");
   return VTS_OK;
 }
 
