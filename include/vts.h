@@ -457,6 +457,23 @@ int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, int C, const
                           const int* offy, int P, int P_per_img, int size, float* dsrc, int64_t dsrc_nstride, int N, int H,
                           int W, int accumulate, void* stream);
 
+/* Batched patch gather / copy / fill (round 3): all channel runs of the D2 patch stacks -- [fake_T | S | aug_fake_I | mask] and its real /
+ * "more fake" counterparts, sinskitG_model.py:1268-1291, 1477-1484, 1506-1560 -- in ONE launch (the step used nine gathers and five
+ * copies).  Job: C channels of P patches into channel slot dst_c0 of dst [P, dst_C, size, size]; img != NULL: gather with
+ * clamp-to-border from src [*, C.., H, W] (batch stride src_nstride) as vts_patch_gather; img == NULL: copy from the patch tensor src
+ * [P, C, size, size] (patch stride src_nstride); src == NULL: fill with `fill`.  At most 16 jobs per call. */
+typedef struct vts_patch_job {
+  const float* src;
+  int64_t src_nstride;
+  int C, H, W;
+  const int *img, *offx, *offy;
+  int P;
+  float* dst;
+  int dst_C, dst_c0;
+  float fill;
+} vts_patch_job;
+int vts_patch_jobs(const vts_patch_job* jobs /* host array */, int njobs, int size, void* stream);
+
 /* Generator output post-processing (sinskitG_model.py:1309-1340), one pass over g_out [N,5,H,W]:
  *   fake_I = g_out[:, :3]*M ; fake_T = g_out[:, 3:]*M ; fake_N = normalize(gx, gy, scale_nz)
  *   aug_fake_I = DiffAugment_bs(fake_I; rb, rs) * M            (thirdparty/DiffAugment.py:25-33)
@@ -465,6 +482,11 @@ int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, int C, const
 int vts_g_post(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
                float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I,
                int64_t aug_nstride, void* stream);
+/* the same pass also writing the sketch and the mask into their channels of the 7-channel full-resolution D2 stack
+ * (stack_S / stack_M: channel-slice pointers with batch stride stack_nstride; sinskitG_model.py:1495-1501 builds that stack with torch.cat) */
+int vts_g_post_stack(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
+                     float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I, int64_t aug_nstride,
+                     const float* S, float* stack_S, float* stack_M, int64_t stack_nstride, void* stream);
 
 /* aug = DiffAugment_bs(x; rb, rs) * M for a 3-channel image. */
 int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, const float* rb, const float* rs, float* aug,

@@ -552,6 +552,33 @@ def test_patch_gather_scatter():
     assert rel(dsrc, src.grad) < 1e-6
 
 
+def test_patch_jobs_equal_single_gathers_copies_and_fill():
+    """vts_patch_jobs (all channel runs of the D2 stacks in one launch) against vts_patch_gather / copy_ / fill_ one by one, including a
+    channel-slice source with a batch stride (the augmented image lives inside the 7-channel full-resolution stack) and border clamps"""
+    from vts import ops
+
+    dev = _dev()
+    n, h, w, P = 2, 70, 90, 10
+    full = detrand.uniform((n, 7, h, w), 41, "full").to(dev)
+    img = torch.tensor([0, 1] * 5, dtype=torch.int32, device=dev)
+    offx = torch.tensor([-3, 0, 10, 60, 70, 85, 5, 33, 58, 1], dtype=torch.int32, device=dev)
+    offy = torch.tensor([0, -5, 40, 50, 3, 60, 38, 39, 12, 69], dtype=torch.int32, device=dev)
+    pt = detrand.uniform((P, 2, 32, 32), 41, "pt").to(dev)
+    msk = (detrand.uniform((P, 1, 32, 32), 41, "m") > 0).float().to(dev)
+    a, b = torch.zeros(P, 7, 32, 32, device=dev), torch.zeros(P, 7, 32, 32, device=dev)
+    g = dict(img=img, offx=offx, offy=offy)
+    ops.patch_jobs([dict(dst=a, c0=0, src=full[:, 0:2], channels=2, **g), dict(dst=a, c0=2, src=full[:, 2:3], **g),
+                    dict(dst=a, c0=3, src=full[:, 3:6], **g), dict(dst=a, c0=6, src=msk)])
+    ops.patch_gather(full[:, 0:2], img, offx, offy, 32, b, c0=0, channels=2)
+    ops.patch_gather(full[:, 2:3], img, offx, offy, 32, b, c0=2, channels=1)
+    ops.patch_gather(full[:, 3:6], img, offx, offy, 32, b, c0=3, channels=3)
+    b[:, 6:7].copy_(msk)
+    assert torch.equal(a, b)
+    c = torch.zeros(P, 3, 32, 32, device=dev)
+    ops.patch_jobs([dict(dst=c, c0=0, src=pt), dict(dst=c, c0=2, channels=1, fill=1.0)])
+    assert torch.equal(c[:, 0:2], pt) and bool((c[:, 2] == 1).all())
+
+
 def test_g_post_diffaug_outgrad_spe():
     from vts import ops
 

@@ -130,6 +130,39 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
   }
 }
 
+// Batched form (round 3): every channel run of the D2 patch stacks in ONE launch.  A job copies C channels of P patches into channel
+// slot c0 of a [P, dstC, size, size] tensor: gathered with clamp-to-border from an image tensor (img / offx / offy given), copied from
+// a [P, C, size, size] patch tensor (img NULL), or filled with a constant (src NULL).  blockIdx.y walks the (job, channel) pairs.
+constexpr int PJ_MAX = 16;
+struct PatchJobs {
+  int njobs;
+  int ch_start[PJ_MAX + 1];
+  vts_patch_job job[PJ_MAX];
+};
+__global__ __launch_bounds__(256) void patch_jobs_kernel(const PatchJobs t, int size) {
+  int j = 0;
+  while (j + 1 < t.njobs && (int)blockIdx.y >= t.ch_start[j + 1]) ++j;   // uniform
+  const vts_patch_job& q = t.job[j];
+  const int p = blockIdx.x, c = blockIdx.y - t.ch_start[j];
+  if (p >= q.P) return;
+  const int S2 = size * size;
+  float* o = q.dst + ((int64_t)p * q.dst_C + q.dst_c0 + c) * S2;
+  if (!q.src) {
+    for (int i = threadIdx.x; i < S2; i += 256) o[i] = q.fill;
+  } else if (!q.img) {
+    const float* s = q.src + (int64_t)p * q.src_nstride + (int64_t)c * S2;
+    for (int i = threadIdx.x; i < S2; i += 256) o[i] = s[i];
+  } else {
+    const float* s = q.src + q.img[p] * q.src_nstride + (int64_t)c * q.H * q.W;
+    const int ox = q.offx[p], oy = q.offy[p];
+    for (int i = threadIdx.x; i < S2; i += 256) {
+      const int y = i / size, x = i - y * size;
+      const int sy = min(max(oy + y, 0), q.H - 1), sx = min(max(ox + x, 0), q.W - 1);
+      o[i] = s[(int64_t)sy * q.W + sx];
+    }
+  }
+}
+
 // range of patch-local indices j in [0,size) with clamp(off + j, 0, L-1) == v
 __device__ __forceinline__ void inv_clamp(int v, int off, int size, int L, int& lo, int& hi) {
   lo = hi = v - off;
@@ -193,11 +226,14 @@ __global__ __launch_bounds__(256) void patch_scatter_kernel(const float* __restr
 __global__ __launch_bounds__(256) void g_post_kernel(const float* __restrict__ g, const float* __restrict__ M, int64_t HW,
                                                      float scale_nz, const float* __restrict__ rb, const float* __restrict__ rs,
                                                      float* __restrict__ fI, float* __restrict__ fT, int64_t fTns,
-                                                     float* __restrict__ fN, float* __restrict__ aI, int64_t aIns) {
+                                                     float* __restrict__ fN, float* __restrict__ aI, int64_t aIns,
+                                                     const float* __restrict__ S, float* __restrict__ stS, float* __restrict__ stM, int64_t stns) {
   const int n = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= HW) return;
   const float m = M[n * HW + i];
+  if (stS) stS[n * stns + i] = S[n * HW + i];     // sketch / mask channels of the 7-channel full-resolution D2 stack
+  if (stM) stM[n * stns + i] = m;
   const float* gp = g + n * 5 * HW + i;
   const float r = gp[0] * m, gg = gp[HW] * m, b = gp[2 * HW] * m, tx = gp[3 * HW] * m, ty = gp[4 * HW] * m;
   if (fI) {
@@ -529,6 +565,25 @@ extern "C" int vts_patch_gather(const float* src, int64_t sns, int C, int H, int
   return VTS_OK;
 }
 
+extern "C" int vts_patch_jobs(const vts_patch_job* jobs, int njobs, int size, void* stream) {
+  VTS_CHECK_ARG(jobs && njobs >= 1 && njobs <= PJ_MAX && size >= 1, "vts_patch_jobs: 1 .. %d jobs", PJ_MAX);
+  PatchJobs t;
+  t.njobs = njobs;
+  int ch = 0, pmax = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const vts_patch_job& q = jobs[j];
+    VTS_CHECK_ARG(q.dst && q.C >= 1 && q.P >= 1 && q.dst_c0 >= 0 && q.dst_c0 + q.C <= q.dst_C && (!q.img || (q.src && q.offx && q.offy)), "vts_patch_jobs: job %d malformed", j);
+    t.ch_start[j] = ch;
+    t.job[j] = q;
+    ch += q.C;
+    pmax = q.P > pmax ? q.P : pmax;
+  }
+  t.ch_start[njobs] = ch;
+  hipLaunchKernelGGL(patch_jobs_kernel, dim3(pmax, ch), dim3(256), 0, (hipStream_t)stream, t, size);
+  VTS_CHECK_LAUNCH("vts_patch_jobs");
+  return VTS_OK;
+}
+
 extern "C" int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, int C, const int* img, const int* offx, const int* offy,
                                      int P, int P_per_img, int size, float* dsrc, int64_t dns, int N, int H, int W, int accumulate,
                                      void* stream) {
@@ -540,15 +595,28 @@ extern "C" int vts_patch_scatter_bwd(const float* dpatch, int dp_C, int dp_c0, i
   return VTS_OK;
 }
 
+static int g_post_impl(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
+                       float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I, int64_t aug_nstride,
+                       const float* S, float* stack_S, float* stack_M, int64_t stack_nstride, void* stream) {
+  VTS_CHECK_ARG(g_out && M && (!aug_fake_I || (rb && rs)) && (!stack_S || S), "vts_g_post: bad args");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(g_post_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, g_out, M, HW, scale_nz, rb, rs,
+                     fake_I, fake_T, fake_T_nstride ? fake_T_nstride : 2 * HW, fake_N, aug_fake_I, aug_nstride ? aug_nstride : 3 * HW,
+                     S, stack_S, stack_M, stack_nstride);
+  VTS_CHECK_LAUNCH("vts_g_post");
+  return VTS_OK;
+}
+
 extern "C" int vts_g_post(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
                           float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I,
                           int64_t aug_nstride, void* stream) {
-  VTS_CHECK_ARG(g_out && M && (!aug_fake_I || (rb && rs)), "vts_g_post: bad args");
-  const int64_t HW = (int64_t)H * W;
-  hipLaunchKernelGGL(g_post_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, g_out, M, HW, scale_nz, rb, rs,
-                     fake_I, fake_T, fake_T_nstride ? fake_T_nstride : 2 * HW, fake_N, aug_fake_I, aug_nstride ? aug_nstride : 3 * HW);
-  VTS_CHECK_LAUNCH("vts_g_post");
-  return VTS_OK;
+  return g_post_impl(g_out, M, N, H, W, scale_nz, rb, rs, fake_I, fake_T, fake_T_nstride, fake_N, aug_fake_I, aug_nstride, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int vts_g_post_stack(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
+                                float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I, int64_t aug_nstride,
+                                const float* S, float* stack_S, float* stack_M, int64_t stack_nstride, void* stream) {
+  return g_post_impl(g_out, M, N, H, W, scale_nz, rb, rs, fake_I, fake_T, fake_T_nstride, fake_N, aug_fake_I, aug_nstride, S, stack_S, stack_M, stack_nstride, stream);
 }
 
 extern "C" int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, const float* rb, const float* rs, float* aug,

@@ -493,8 +493,10 @@ class SinSKITGModel(BaseModel):
             half, one = torch.full((n,), 0.5, device=dev), torch.full((n,), 0.5, device=dev)
             rb, rs = half, one  # brightness shift 0, saturation factor 1
             self.aug_real_I = self.real_I
+        # (training: the same pass writes the sketch and the mask into their channels of the full-resolution D2 stack)
         ops.g_post(g_out, self.M, opt.scale_nz, rb, rs, fake_I=self.fake_I, fake_T=self.fake_T, fake_N=self.fake_N,
-                   aug_fake_I=aug_fake)
+                   aug_fake_I=aug_fake, S=self.real_S if keep else None, stack_S=self._full_stack[:, 2:3] if keep else None,
+                   stack_M=self._full_stack[:, 6:7] if keep else None)
         self.aug_fake_I = aug_fake
         self.fake_gx = self.fake_T[:, 0:1]
         self.fake_gy = self.fake_T[:, 1:2]
@@ -585,16 +587,23 @@ class SinSKITGModel(BaseModel):
         fake_stack = self._stack_all[:P]                      # [fake_T, S, aug_fake_I, mask]
         real_stack = self._stack_all[P + K:]                  # [real_T, S, aug_real_I, mask]
         self._more_stack = self._stack_all[P:P + K]
-        self._gather(self.fake_T, ts, fake_stack, 0, channels=2)
-        self._gather(self.real_S, ts, fake_stack, 2)
-        self._gather(self.aug_fake_I, ts, fake_stack, 3, channels=3)
-        fake_stack[:, 6:7].copy_(ts["masks"])
-        real_stack[:, 0:2].copy_(ts["real_T"])
-        self._gather(self.real_S, ts, real_stack, 2)
-        self._gather(self.aug_real_I, ts, real_stack, 3)
-        real_stack[:, 6:7].copy_(ts["masks"])
         self.fake_T_concat = torch.empty(P, 2, 32, 32, device=dev)
-        self._gather(self.fake_T, ts, self.fake_T_concat, 0, channels=2)
+        g = dict(img=ts["img"], offx=ts["offx"], offy=ts["offy"])
+        # every channel run of the three stacks in ONE launch (ops.patch_jobs; it was nine gathers and five copies)
+        jobs = [dict(dst=fake_stack, c0=0, src=self.fake_T, channels=2, **g), dict(dst=fake_stack, c0=2, src=self.real_S, **g),
+                dict(dst=fake_stack, c0=3, src=self.aug_fake_I, channels=3, **g), dict(dst=fake_stack, c0=6, src=ts["masks"]),
+                dict(dst=real_stack, c0=0, src=ts["real_T"]), dict(dst=real_stack, c0=2, src=self.real_S, **g),
+                dict(dst=real_stack, c0=3, src=self.aug_real_I, **g), dict(dst=real_stack, c0=6, src=ts["masks"]),
+                dict(dst=self.fake_T_concat, c0=0, src=self.fake_T, channels=2, **g)]
+        if K:
+            # the "more fake T" squares at random positions of the dilated mask (model_utils.py:212-222): [fake_T, S, fake_I, 1]
+            h, w = self.real_S.shape[2:]
+            mox, moy = ops.mask_select(self._cand, self._cand_prefix, self._ranks, h, w)
+            self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
+            m = dict(img=self._more_img, offx=mox, offy=moy)
+            jobs += [dict(dst=self._more_stack, c0=0, src=self.fake_T, channels=2, **m), dict(dst=self._more_stack, c0=2, src=self.real_S, **m),
+                     dict(dst=self._more_stack, c0=3, src=self.fake_I, **m), dict(dst=self._more_stack, c0=6, channels=1, fill=1.0)]
+        ops.patch_jobs(jobs)
         self._fake_stack, self._real_stack = fake_stack, real_stack
 
     def _seg_d_updates(self):
@@ -625,8 +634,7 @@ class SinSKITGModel(BaseModel):
             # (opt.skip_D2_visualisation_pass is a measurement switch of bench.py --no_viz, not a reference option: SURVEY §8d asks
             # for the step rate with and without this pass)
             if not getattr(opt, "skip_D2_visualisation_pass", False):
-                self._full_stack[:, 2:3].copy_(self.real_S)
-                self._full_stack[:, 6:7].copy_(self.M)
+                # (the sketch and mask channels of _full_stack were written by the forward's post-processing pass)
                 # batched: it runs first and only records its BatchNorm statistics; the patch pass splices its running-statistics
                 # update in after the fake patches, i.e. at the reference's position (sinskitG_model.py:1490-1501)
                 p_full = dict(in0=self._full_stack, loss=False, stat_only=batched)
@@ -635,15 +643,7 @@ class SinSKITGModel(BaseModel):
             if opt.use_more_fakeT:
                 k = opt.add_fake_T_sample_size
                 K = n * k
-                h, w = self.real_S.shape[2:]
-                mox, moy = ops.mask_select(self._cand, self._cand_prefix, self._ranks, h, w)
-                self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
-                more = self._more_stack
-                mset = dict(img=self._more_img, offx=mox, offy=moy)
-                self._gather(self.fake_T, mset, more, 0, channels=2)
-                self._gather(self.real_S, mset, more, 2)
-                self._gather(self.fake_I, mset, more, 3)
-                more[:, 6:7].fill_(1.0)
+                more = self._more_stack          # built with the other stacks (_forward_and_stacks)
                 if not batched:
                     passes.append(dict(in0=more, real=False, coeff=lam2, slot=slot["D_more_fake_T"], grad_coeff=0.5 * lam2, accumulate=True))
             if batched:

@@ -63,6 +63,12 @@ class NormDesc(C.Structure):
     ]
 
 
+class PatchJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_nstride", C.c_int64), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("img", C.c_void_p), ("offx", C.c_void_p), ("offy", C.c_void_p), ("P", C.c_int), ("dst", C.c_void_p),
+                ("dst_C", C.c_int), ("dst_c0", C.c_int), ("fill", C.c_float)]
+
+
 class NormBwdDesc(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("x", C.c_void_p), ("nstride", C.c_int64), ("N", C.c_int), ("C", C.c_int), ("HW", C.c_int),
@@ -84,6 +90,7 @@ SYMBOLS = [
     "vts_metric_ws_floats", "vts_minmax", "vts_metric_psnr", "vts_metric_tactile", "vts_metric_ssim", "vts_frechet_ws_floats", "vts_frechet_distance", "vts_sifid_input", "vts_modconv_weight", "vts_modconv_weight_bwd", "vts_adain", "vts_adain_bwd", "vts_resample_table",
     "vts_mask_select", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
     "vts_maxpool2_relu_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
+    "vts_patch_jobs", "vts_g_post_stack",
 ]
 
 
@@ -141,6 +148,8 @@ def load():
         "vts_patch_gather": [vp, i64, i, i, i, vp, vp, vp, i, i, vp, i, i, vp],
         "vts_patch_scatter_bwd": [vp, i, i, i, vp, vp, vp, i, i, i, vp, i64, i, i, i, i, vp],
         "vts_g_post": [vp, vp, i, i, i, f, vp, vp, vp, vp, i64, vp, vp, i64, vp],
+        "vts_g_post_stack": [vp, vp, i, i, i, f, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, i64, vp],
+        "vts_patch_jobs": [C.POINTER(PatchJob), i, i, vp],
         "vts_diffaug_bs_mask": [vp, vp, i, i, i, vp, vp, vp, vp],
         "vts_g_out_grad": [vp, vp, vp, vp, i, i, i, vp, vp],
         "vts_mask_mul": [vp, vp, i, i, i, vp, vp],

@@ -1015,12 +1015,36 @@ def patch_scatter_bwd(dpatch, c0, channels, offx, offy, ppi, size, dsrc, accumul
     return dsrc
 
 
-def g_post(g_out, M, scale_nz, rb=None, rs=None, fake_I=None, fake_T=None, fake_N=None, aug_fake_I=None):
+def g_post(g_out, M, scale_nz, rb=None, rs=None, fake_I=None, fake_T=None, fake_N=None, aug_fake_I=None, S=None, stack_S=None, stack_M=None):
+    """stack_S / stack_M: 1-channel slices of the full-resolution D2 stack that also receive the sketch S and the mask"""
     lib = L.load()
     n, _, h, w = g_out.shape
-    L.check(lib.vts_g_post(g_out.data_ptr(), M.data_ptr(), n, h, w, scale_nz, L.ptr(rb), L.ptr(rs), L.ptr(fake_I), L.ptr(fake_T),
-                           0 if fake_T is None else fake_T.stride(0), L.ptr(fake_N), L.ptr(aug_fake_I),
-                           0 if aug_fake_I is None else aug_fake_I.stride(0), L.stream()), "vts_g_post")
+    L.check(lib.vts_g_post_stack(g_out.data_ptr(), M.data_ptr(), n, h, w, scale_nz, L.ptr(rb), L.ptr(rs), L.ptr(fake_I), L.ptr(fake_T),
+                                 0 if fake_T is None else fake_T.stride(0), L.ptr(fake_N), L.ptr(aug_fake_I),
+                                 0 if aug_fake_I is None else aug_fake_I.stride(0), L.ptr(S), L.ptr(stack_S), L.ptr(stack_M),
+                                 0 if stack_S is None else stack_S.stride(0), L.stream()), "vts_g_post")
+
+
+def patch_jobs(jobs, size=32):
+    """ONE launch for a list of patch jobs: dict(dst, c0, src=None, channels=None, img=None, offx=None, offy=None, fill=0.0) --
+    gather (img / offx / offy given) from an image tensor, copy from a [P, C, size, size] patch tensor, or fill (src None)"""
+    arr = (L.PatchJob * len(jobs))()
+    for a, q in zip(arr, jobs):
+        dst, src = q["dst"], q.get("src")
+        a.dst, a.dst_C, a.dst_c0, a.P = dst.data_ptr(), dst.shape[1], q["c0"], dst.shape[0]
+        a.fill = float(q.get("fill", 0.0))
+        if src is None:
+            a.src, a.C = None, q["channels"]
+            continue
+        a.src, a.src_nstride = src.data_ptr(), src.stride(0)
+        a.C = src.shape[1] if q.get("channels") is None else q["channels"]
+        if q.get("img") is not None:
+            a.H, a.W = src.shape[2], src.shape[3]
+            a.img, a.offx, a.offy = q["img"].data_ptr(), q["offx"].data_ptr(), q["offy"].data_ptr()
+            assert q["img"].numel() == dst.shape[0]
+        else:
+            assert src.shape[0] == dst.shape[0] and src.shape[2:] == dst.shape[2:] and src.stride(1) == size * size
+    L.check(L.load().vts_patch_jobs(arr, len(jobs), size, L.stream()), "vts_patch_jobs")
 
 
 def diffaug_bs_mask(x, M, rb, rs, out):
