@@ -431,6 +431,9 @@ int vts_l1_relu(const float* za, const float* zb, int64_t n, float coeff, int64_
 int vts_lpips_input(const float* x, int64_t x_nstride, int N, int Cx, int HW, const float* shift3, const float* scale3, float* y, void* stream);
 int vts_lpips_input_bwd(const float* g, int N, int Cx, int HW, const float* scale3, float* dx, int64_t dx_nstride, int accumulate, void* stream);
 
+/* Start of a training step: loss slots <- 0, every optimiser's device step counter += 1 (vts_adam_flat_dev reads them): one launch */
+int vts_step_begin(int64_t* loss_slots, int nslots, int* step_counters, int ncounters, void* stream);
+
 /* Loss slots: 64-bit fixed point, VTS_LOSS_SCALE units per 1.0 (value = slot / VTS_LOSS_SCALE).  Integer atomic adds commute, so a
  * logged loss is bitwise reproducible whatever order workgroups and concurrent streams add to a slot in. */
 #define VTS_LOSS_SCALE 1099511627776.0 /* 2^40 */

@@ -565,6 +565,21 @@ extern "C" int vts_patch_gather(const float* src, int64_t sns, int C, int H, int
   return VTS_OK;
 }
 
+// start of a training step: zero the loss slots and advance the optimisers' device step counters -- one launch instead of a memset
+// and one increment per optimiser
+__global__ void step_begin_kernel(long long* slots, int nslots, int* counters, int ncounters) {
+  const int i = threadIdx.x;
+  if (i < nslots) slots[i] = 0;
+  if (i < ncounters) counters[i] += 1;
+}
+
+extern "C" int vts_step_begin(int64_t* slots, int nslots, int* counters, int ncounters, void* stream) {
+  VTS_CHECK_ARG(nslots >= 0 && ncounters >= 0 && nslots <= 256 && ncounters <= 256 && (slots || !nslots) && (counters || !ncounters), "vts_step_begin: bad args");
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<long long*>(slots), nslots, counters, ncounters);
+  VTS_CHECK_LAUNCH("vts_step_begin");
+  return VTS_OK;
+}
+
 extern "C" int vts_patch_jobs(const vts_patch_job* jobs, int njobs, int size, void* stream) {
   VTS_CHECK_ARG(jobs && njobs >= 1 && njobs <= PJ_MAX && size >= 1, "vts_patch_jobs: 1 .. %d jobs", PJ_MAX);
   PatchJobs t;

@@ -198,13 +198,15 @@ class SinSKITGModel(BaseModel):
                                                num_D=opt.num_D_D2, gpu_ids=self.gpu_ids, opt=opt)
                 self.flatD2 = FlatParams(self.netD2)
             betas = (opt.beta1, opt.beta2)
-            self.optimizer_G = FlatAdam(self.flatG, opt.lr, betas)
+            # the device step counters of the three optimisers live in one tensor: advanced by ONE launch at the start of a step
+            self._step_counters = torch.zeros(3, dtype=torch.int32, device=self.device)
+            self.optimizer_G = FlatAdam(self.flatG, opt.lr, betas, step_dev=self._step_counters[0:1])
             self.optimizers.append(self.optimizer_G)
             if "D" in self.model_names:
-                self.optimizer_D = FlatAdam(self.flatD, opt.lr, betas)
+                self.optimizer_D = FlatAdam(self.flatD, opt.lr, betas, step_dev=self._step_counters[1:2])
                 self.optimizers.append(self.optimizer_D)
             if "D2" in self.model_names:
-                self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr_G2, betas)
+                self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr_G2, betas, step_dev=self._step_counters[2:3])
                 self.optimizers.append(self.optimizer_D2)
         # LPIPS-VGG16 (criterionLPIPS_vgg, sinskitG_model.py:495): frozen, not a saved network
         self.netLPIPS = None
@@ -416,8 +418,18 @@ class SinSKITGModel(BaseModel):
         elif hasattr(self, "real_I"):
             del self.real_I
         self.S_pe = self._spe(n, h, w) if self.pe_channels else None
+        self._style_tiles = None
         if "style_code" in input:
             self.style_code = self._load(phase + "_style", input["style_code"])
+            G = self.netG
+            if getattr(G, "use_style", False) and getattr(G, "style_mapping", "") == "tile":
+                # the tiled style code (networks.py:1600-1623) depends on the batch only: tiled here, once per batch, into persistent buffers
+                self._style_tiles = {}
+                for i in range(G.num_downs - G.num_layer_style_code, G.num_downs):
+                    hh, ww = h >> (i + 1), w >> (i + 1)
+                    t = self._buf("%s_style_tile%d" % (phase, i), (n, self.style_code.shape[1], hh, ww))
+                    t.copy_(self.style_code.to(torch.float32)[:, :, None, None].expand(-1, -1, hh, ww))
+                    self._style_tiles[i] = t
         self.train_set = self.val_set = None
         if "T_images" in input and len(input["T_images"]) > 0:
             self.train_set = self._patch_set(phase + "_tr", input["T_images"], input["I_masks"], input["T_coords"])
@@ -470,7 +482,8 @@ class SinSKITGModel(BaseModel):
                 raise NotImplementedError("style codes are only built for netG=unet256_custom")
             g_out, self._g_ctx = engine.resnet_forward(self.netG, self._g_input(), keep=keep)
         else:
-            g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep)
+            g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep,
+                                                     style_tiles=getattr(self, "_style_tiles", None))
         self.g_out = g_out
         has_real = hasattr(self, "real_I") and not self.test_edit_S
         self.fake_I = self._I2[:n] if (has_real and getattr(self, "_pair", False)) else torch.empty(n, 3, h, w, device=dev)
@@ -578,7 +591,7 @@ class SinSKITGModel(BaseModel):
     def _forward_and_stacks(self):
         opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
         P = ts["real_T"].shape[0]
-        self._loss_buf.zero_()
+        ops.step_begin(self._loss_buf, self._step_counters)      # loss slots <- 0, optimiser step counters += 1
         self.forward(keep=True)
         # patches (compute_additional_output :1268-1291)
         # the patch stacks of the D2 update in ONE buffer, [fake | more fake | real] along the batch (batched passes)
@@ -621,7 +634,8 @@ class SinSKITGModel(BaseModel):
                 jobs.append((self.netD, [p_fake_I, dict(in0=self.real_S, in1=self.real_I, real=True, coeff=lam, slot=slot["D_real_I"],
                                                         grad_coeff=0.5 * lam, accumulate=True)]))
             else:   # fake | real batched: rows [0, n) / [n, 2n) of the persistent pair buffers
-                p_fake_I = dict(in0=self._S2, in1=self._I2, pyr=self._d1_pyramid(2 * n, pool_fake=True), groups=[
+                pyr = self._d1_pyramid(2 * n, pool_fake=True)
+                p_fake_I = dict(in0=self._S2, in1=self._I2, pyr=pyr, prep=self._d1_pool_prep() if pyr is not None else None, groups=[
                     dict(n0=0, n1=n, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam),
                     dict(n0=n, n1=2 * n, real=True, coeff=lam, slot=slot["D_real_I"], grad_coeff=0.5 * lam)])
                 jobs.append((self.netD, [p_fake_I]))
@@ -667,11 +681,24 @@ class SinSKITGModel(BaseModel):
         fake-image rows now (the D update, right after the forward); the generator step reuses those levels."""
         if getattr(self, "_I2_pyr", None) is None or not self._pair or self.fake_I.data_ptr() != self._I2.data_ptr():
             return None
-        n = self.real_S.shape[0]
-        if pool_fake:
-            for s in range(1, len(self._I2_pyr)):
-                ops.avgpool(self._I2_pyr[s - 1][:n], y=self._I2_pyr[s][:n])
         return [(Act(S[:rows]), Act(I[:rows])) for S, I in zip(self._S2_pyr, self._I2_pyr)]
+
+    def _d1_pool_prep(self):
+        """{scale: callable} pooling the fake-image rows of the D1 input pyramid INSIDE each scale's lane (engine.msd_multi `prep`):
+        scale s pools its own chain from the full-resolution rows (scale 2 repeats the first level into a scratch tensor instead of
+        waiting for scale 1's lane), so the pooling leaves the serial stretch between the generator forward and the lanes."""
+        n = self.real_S.shape[0]
+        pyr = self._I2_pyr
+
+        def chain(s):
+            def run():
+                src = pyr[0][:n]
+                for t in range(1, s + 1):
+                    dst = pyr[t][:n] if t == s else torch.empty(n, 3, pyr[t].shape[2], pyr[t].shape[3], device=self.device)
+                    ops.avgpool(src, y=dst)
+                    src = dst
+            return run
+        return {s: chain(s) for s in range(1, len(pyr))}
 
     def _seg_g_pre(self):
         """the generator's loss terms that need no discriminator (compute_G1_loss / compute_G2_loss: the L1 terms).  In a data-parallel
@@ -717,14 +744,14 @@ class SinSKITGModel(BaseModel):
         nt = ts["NT"]
         jobs = []
         if "D" in self.model_names:
-            self.optimizer_D.step(self._gscale)
+            self.optimizer_D.step(self._gscale, bump=False)
             lam = opt.lambda_G1_GAN
             jobs.append((self.netD, [dict(in0=self.real_S, in1=self.fake_I, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
                                           param_grads=False, input_grad=(self._d_fake_I, self._have_dI),
                                           pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False))]))
             self._have_dI = True
         if "D2" in self.model_names:
-            self.optimizer_D2.step(self._gscale)
+            self.optimizer_D2.step(self._gscale, bump=False)
             # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
             jobs.append((self.netD2, [dict(in0=self._fake_stack, real=True, coeff=opt.lambda_G2_GAN * nt, slot=slot["G2_GAN"])]))
         if jobs:
@@ -751,7 +778,7 @@ class SinSKITGModel(BaseModel):
             engine.unet_backward(self.netG, self._g_ctx, d_raw)
 
     def _seg_adam_g(self):
-        self.optimizer_G.step(self._gscale)
+        self.optimizer_G.step(self._gscale, bump=False)
 
     def _segments(self):
         """(segment, buckets to wait for before it, buckets to start after it).  Single GPU: three segments.  Data parallel: the

@@ -40,9 +40,11 @@ class UnetCtx:
     __slots__ = ("x", "feats", "ups", "g_out", "style", "style_ctx", "adain_in", "dstyle")
 
 
-def unet_forward(G, x, style_code=None, keep=True):
+def unet_forward(G, x, style_code=None, keep=True, style_tiles=None):
     """x: [N, input_nc, H, W] tensor / Act, or a pair (x0, x1) that is concatenated on load
-    (sketch ++ positional grid).  Returns (g_out [N,5,H,W] post-tanh, ctx)."""
+    (sketch ++ positional grid).  Returns (g_out [N,5,H,W] post-tanh, ctx).
+    style_tiles: {layer index: [N, style_dim, h, w]} the tiled style code when the caller holds it (it depends on the batch only: the
+    model tiles it once per set_input instead of once per step)"""
     if isinstance(x, (tuple, list)):
         x, x_extra = _as_act(x[0]), _as_act(x[1])
     else:
@@ -81,7 +83,8 @@ def unet_forward(G, x, style_code=None, keep=True):
                 raise NotImplementedError("style code on a skip-connected layer needs a third concat source")
             hh, ww = h >> (i + 1), w >> (i + 1)
             if G.style_mapping == "tile":
-                extras[i] = Act(style[:, :, None, None].expand(-1, -1, hh, ww).contiguous())
+                t = style_tiles.get(i) if style_tiles else None
+                extras[i] = Act(t if t is not None else style[:, :, None, None].expand(-1, -1, hh, ww).contiguous())
             else:
                 smap, style_ctx[i] = _style_map_forward(G, nd - 1 - i, style, hh, ww)
                 if G.style_mode == "concat":
@@ -863,8 +866,10 @@ def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None, groups=None, stat
     return acts
 
 
-def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad, cache=None, groups=None):
-    """backward of one PatchGAN; returns the gradient w.r.t. the second concat source (or None)"""
+def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad, cache=None, groups=None, into=None):
+    """backward of one PatchGAN; returns the gradient w.r.t. the second concat source (or None).
+    into = (tensor, accumulate?): write / add that gradient straight into the caller's buffer (the full-resolution scale: saves the
+    separate add of the merged pyramid gradient)"""
     layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
     for j in range(len(D.CONV_IDX) - 1, -1, -1):
         ci = D.CONV_IDX[j]
@@ -905,8 +910,8 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
         elif want_input_grad:
             c0 = a0.data.shape[1]
             c1 = a1.data.shape[1]
-            tgt = torch.empty_like(a1.data)
-            ops.conv4x4(Act(g), conv.weight.view(-1)[c0 * 16:], 16, cin * 16, c1, tgt, stride=st, pad=2, transposed=True)
+            tgt, acc_in = (torch.empty_like(a1.data), False) if into is None else into
+            ops.conv4x4(Act(g), conv.weight.view(-1)[c0 * 16:], 16, cin * 16, c1, tgt, stride=st, pad=2, transposed=True, accumulate=acc_in)
             return tgt
     return None
 
@@ -916,6 +921,8 @@ def _merge_input_grads(din_scales, input_grad):
     dst, acc = input_grad
     for s in range(len(din_scales) - 1, 0, -1):
         ops.avgpool_bwd(din_scales[s], din_scales[s - 1], accumulate=True)
+    if din_scales[0] is dst:      # the full-resolution scale already wrote / accumulated into the caller's buffer
+        return
     if acc:
         dst.add_(din_scales[0])
     else:
@@ -1026,7 +1033,12 @@ def _msd_multi(jobs, criterion):
         D, s, passes = lanes[i]
         cache = {}      # packed weights of this scale: shared by its passes (they run in order in this lane)
         for p in passes:
+            prep = p.get("prep")
+            if prep and s in prep:
+                prep[s]()       # per-scale preparation inside the lane (pooling of this scale's input level)
             a0, a1 = p["_pyr"][s]
+            ig = p.get("input_grad")
+            into = (ig[0], ig[1]) if (ig is not None and s == 0 and a1 is not None and ig[0].shape == a1.data.shape and ig[0].is_contiguous()) else None
             groups = p.get("groups")
             gstarts = [gr["n0"] for gr in groups] if groups else None
             stat_rec = p.setdefault("_stats", {}).setdefault(s, {}) if p.get("stat_only") else None
@@ -1046,7 +1058,7 @@ def _msd_multi(jobs, criterion):
                                          want_grad=gc is not None, out_grads=[g[gr["n0"]:gr["n1"]]] if gc is not None else None)
                 if want:
                     p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
-                                                       p.get("input_grad") is not None, cache, gstarts)
+                                                       p.get("input_grad") is not None, cache, gstarts, into=into)
                 continue
             if not p.get("loss", True):
                 continue
@@ -1054,7 +1066,7 @@ def _msd_multi(jobs, criterion):
             g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None)[0]
             if gc is not None:
                 p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
-                                                   p.get("input_grad") is not None, cache)
+                                                   p.get("input_grad") is not None, cache, into=into)
 
     with ops.deferred_wgrad():    # one reduction launch for the weight-gradient partials of all lanes, after they have joined
         _run_lanes(len(lanes), lane)

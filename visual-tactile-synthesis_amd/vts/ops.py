@@ -974,6 +974,11 @@ def loss_slots(n, device):
     return torch.zeros(n, dtype=torch.int64, device=device)
 
 
+def step_begin(slots, counters):
+    """zero the loss slots and advance the optimisers' device step counters (one launch)"""
+    L.check(L.load().vts_step_begin(slots.data_ptr(), slots.numel(), L.ptr(counters), 0 if counters is None else counters.numel(), L.stream()), "vts_step_begin")
+
+
 def loss_values(slots):
     """host floats of a slot tensor (one device -> host copy)"""
     return [v / LOSS_SCALE for v in slots.cpu().tolist()]

@@ -51,14 +51,16 @@ class FlatAdam(torch.optim.Optimizer):
     schedulers (networks.get_scheduler) can drive `param_groups[0]["lr"]`; the update itself
     is one vts_adam_flat_dev launch."""
 
-    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, step_dev=None):
+        """step_dev: optional 1-element int32 device view that holds this optimiser's step counter (a model may keep the counters of
+        all its optimisers in one tensor and advance them with ONE launch per step: step(bump=False))"""
         super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps))
         self.flat = flat
         dev = flat.flat.device
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
         self.step_count = 0
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_dev = step_dev if step_dev is not None else torch.zeros(1, dtype=torch.int32, device=dev)
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self._lr_on_dev = float(lr)
 
@@ -74,10 +76,11 @@ class FlatAdam(torch.optim.Optimizer):
             self._lr_on_dev = lr
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0, closure=None):
-        """Capturable: increments the device step counter and launches the fused update."""
+    def step(self, grad_scale=1.0, closure=None, bump=True):
+        """Capturable: increments the device step counter (bump=False: the owner of the counter already did) and launches the fused update."""
         self.step_count += 1
-        self.step_dev.add_(1)
+        if bump:
+            self.step_dev.add_(1)
         g = self.param_groups[0]
         ops.adam_flat_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.lr_dev, g["betas"][0], g["betas"][1], g["eps"],
                           self.step_dev, grad_scale)
