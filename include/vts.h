@@ -223,6 +223,16 @@ typedef struct vts_norm_bwd_desc {
 
 int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream);
 
+/* Normalisation backward fused with the backward-data convolution that produces its input gradient (round 3).  vts_conv4x4_bsums runs
+ * vts_conv4x4 (d->dmask = the normalised tensor of the layer below, as in every backward-data call of the U-Net / PatchGAN schedules) and,
+ * where the tiled kernel's direct epilogue runs, also emits per wave and tile S1 = sum out, S2' = sum out * (dmask * scale + shift) of the
+ * values it stores (after mask and accumulation) into `part` (vts_conv4x4_norm_ws_floats(d) floats are enough); *slots = pairs per
+ * (n, channel), 0 = not fused (call vts_norm_bwd).  vts_norm_bwd_from_partials then runs ONLY the apply pass of vts_norm_bwd on them
+ * (`beta` = the BatchNorm shift that S2' contains, NULL for InstanceNorm): the partial-sum pass -- one read of dy and of x per
+ * normalised layer, and its launch -- disappears from the backward chains. */
+int vts_conv4x4_bsums(const vts_conv_desc* d, float* part, int64_t part_floats, int* slots, void* stream);
+int vts_norm_bwd_from_partials(const vts_norm_bwd_desc* d, const float* part, int slots, const float* beta, void* stream);
+
 /* dy (+)= g * act'(x*scale+shift): derivative mask as a stand-alone op (used where the
  * producer of g is not one of the conv kernels). */
 int vts_act_bwd(const float* g, const vts_operand* x, int N, int HW, int act, float* dy, int accumulate, void* stream);

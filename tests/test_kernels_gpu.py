@@ -395,6 +395,64 @@ def test_conv_with_statistics_from_the_epilogue(case):
     assert kern == ("standalone" if (mode == 1 and OH * OW <= 4096) else "fused"), kern
 
 
+BWD_SUM_CASES = [
+    # (N, Cg, Cx, GH, GW, stride, pad, transposed, mode, groups, accumulate)   g [N,Cg,GH,GW] -> dx [N,Cx,..] masked by the normalised x
+    (2, 10, 40, 128, 128, 2, 1, False, 0, None, False),    # up-block input gradient: conv s2 of the output gradient, ReLU mask, InstanceNorm below
+    (1, 20, 10, 96, 136, 2, 1, True, 0, None, True),       # encoder: transposed s2, LeakyReLU mask, accumulated onto the skip contribution
+    (4, 32, 16, 66, 65, 2, 2, True, 1, [0, 1, 3], False),  # PatchGAN: transposed s2 pad 2, BatchNorm with pass groups below
+    (2, 64, 32, 130, 131, 1, 2, True, 1, None, False),     # PatchGAN stride-1 layer
+]
+
+
+@pytest.mark.parametrize("case", BWD_SUM_CASES)
+def test_backward_data_conv_emits_the_norm_backward_sums(case):
+    """vts_conv4x4_bsums + vts_norm_bwd_from_partials (the sums of the normalisation backward taken in the epilogue of the
+    convolution that produces its input gradient) against the plain sequence vts_conv4x4 + vts_norm_bwd on the same operands:
+    gradient w.r.t. the raw tensor, dgamma / dbeta"""
+    from vts import lib as L, ops
+
+    dev = _dev()
+    N, Cg, Cx, GH, GW, stride, pad, transposed, mode, groups, accumulate = case
+    g = detrand.uniform((N, Cg, GH, GW), 51, "g").to(dev)
+    if transposed:
+        XH, XW = (GH - 1) * stride + 4 - 2 * pad, (GW - 1) * stride + 4 - 2 * pad
+        if stride == 2:       # the forward conv must map the size back (output_padding ambiguity)
+            XH += (XH + 2 * pad - 4) % 2
+            XW += (XW + 2 * pad - 4) % 2
+        w = (detrand.uniform((Cg, Cx, 4, 4), 51, "w") * 0.05).to(dev)           # Conv2d weight [Cout = Cg, Cin = Cx]
+        wargs = (16, Cx * 16)
+    else:
+        XH, XW = (GH + 2 * pad - 4) // stride + 1, (GW + 2 * pad - 4) // stride + 1
+        w = (detrand.uniform((Cx, Cg, 4, 4), 51, "w") * 0.05).to(dev)           # ConvTranspose2d weight [Cin = Cx, Cout = Cg]
+        wargs = (Cg * 16, 16)
+    x = (detrand.uniform((N, Cx, XH, XW), 51, "x") * 2 + 0.4).to(dev)
+    gamma, beta = (1 + 0.2 * detrand.uniform((Cx,), 51, "ga")).to(dev), (0.1 * detrand.uniform((Cx,), 51, "be")).to(dev)
+    a = ops.norm_stats(x, mode, gamma=gamma if mode else None, beta=beta if mode else None, groups=groups)
+    base = detrand.uniform((N, Cx, XH, XW), 51, "acc").to(dev)
+    act = L.ACT_LRELU if transposed else L.ACT_RELU
+
+    def run(fused):
+        keep, ops.BWD_SUMS = ops.BWD_SUMS, fused
+        try:
+            dx = base.clone() if accumulate else torch.empty_like(base)
+            ops.conv4x4(ops.Act(g), w, wargs[0], wargs[1], Cx, dx, stride=stride, pad=pad, transposed=transposed, dmask=a, dmask_act=act,
+                        accumulate=accumulate, bwd_sums=True)
+            had = dx.data_ptr() in ops.BSUMS
+            dg, db = torch.zeros(Cx, device=dev), torch.zeros(Cx, device=dev)
+            ops.norm_bwd(dx, a, mode, gamma=gamma if mode else None, dgamma=dg if mode else None, dbeta=db if mode else None, groups=groups,
+                         beta=beta if mode else None)
+            return dx, dg, db, had
+        finally:
+            ops.BWD_SUMS = keep
+
+    dx_f, dg_f, db_f, had = run(True)
+    dx_p, dg_p, db_p, had_p = run(False)
+    assert had and not had_p and not ops.BSUMS                # the fused run really took the epilogue sums, and consumed them
+    assert rel(dx_f, dx_p) < 2e-5
+    if mode:
+        assert rel(dg_f, dg_p) < 2e-5 and rel(db_f, db_p) < 2e-5
+
+
 @pytest.mark.parametrize("shape,groups", [((7, 6, 9, 9), [0, 3, 5]), ((5, 4, 70, 61), [0, 2]), ((640, 8, 5, 5), [0, 256, 384]),
                                           ((6, 3, 150, 140), [0, 1, 4])])
 def test_batchnorm_batched_passes_equal_sequential_calls(shape, groups):

@@ -60,6 +60,12 @@ struct ConvK {
   // stand-alone statistics pass: the normalised layers lose one full read of their output and one launch.
   float* stat_part;
   int stat_spl;
+  // round 3: sums of the NORMALISATION BACKWARD fused into the epilogue of the backward-data convolution that produces its input
+  // gradient dy (the masked / accumulated value it stores): S1 = sum dy, S2' = sum dy * t with t = dmask * scale + shift -- the
+  // normalised value of the layer below (InstanceNorm: t = xhat; BatchNorm: t = gamma xhat + beta, undone by the consumer).  One
+  // (S1, S2') pair per wave and tile in the layout of norm_bwd_partial_kernel: the stand-alone partial pass (a read of dy AND x)
+  // and its launch disappear.
+  float* bsum_part;
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -72,7 +78,7 @@ __device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
 
 // Output staging region of one epilogue pass: 16 output channels x ER rows x EC columns, plane pitch odd
 // so that the 16 channel planes land on distinct LDS banks.
-template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN, bool STATS>
+template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN, int STATS>
 __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
   constexpr int TY = 4 * RW, TX = 16 * MT;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     const int onb = (int)((int64_t)p.Cout * oplane * 4);
     const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + n * p.ons), 0, onb, 0x00020000);
     const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? (int)((int64_t)p.dmC * oplane * 4) : 0, 0x00020000);
-    if (STATS) {
+    if (STATS == 1) {
       // (the host enables this only without output activation / derivative mask / accumulation: the stored value is acc + bias)
       // A lane holds RW x MT x P x 4 values of ONE channel (m16); the four kq lane groups of the wave hold the rest of the wave's rows.
       // One pass over the accumulators: sum and sum of squares of the values BEFORE the bias (the variance does not see a constant,
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         }
       }
     }
+    float bs1 = 0.f, bs2 = 0.f;     // STATS == 2: this lane's share of S1 / S2' of the channel it is emitting
     auto emit = [&](int co, int y, int x, float bias, float dsc, float dsh, f32x4 v) {
       const bool ok = co < p.Cout && y < p.OH && x < p.OW;
       const bool full = ok && x + 4 <= p.OW;
@@ -399,15 +406,26 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         v[j] = t;
       }
       const f32x4 base = v;   // bias + activation applied; the edge path below redoes mask / accumulate per element
+      f32x4 tn = {0.f, 0.f, 0.f, 0.f};
       if (p.dm) {
         const f32x4 d = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, (int)vo, 0, 0));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= vts_act_grad(d[j] * dsc + dsh, p.dm_act);
+        for (int j = 0; j < 4; ++j) {
+          tn[j] = d[j] * dsc + dsh;
+          v[j] *= vts_act_grad(tn[j], p.dm_act);
+        }
       }
       if (p.accumulate) {
         const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (int)vo, 0, 0));
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += q[j];
+      }
+      if (STATS == 2 && full) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bs1 += v[j];
+          bs2 = fmaf(v[j], tn[j], bs2);
+        }
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ors, (int)vo, 0, 0);
       if (ok && !full) {   // right edge of an output row: per element
@@ -415,8 +433,14 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         const float* db = p.dm ? p.dm + n * p.dmns + co * oplane + (int64_t)y * p.OW + x : nullptr;
         for (int j = 0; j < p.OW - x; ++j) {
           float t = base[j];
-          if (db) t *= vts_act_grad(db[j] * dsc + dsh, p.dm_act);
-          ob[j] = p.accumulate ? ob[j] + t : t;
+          const float tnj = db ? db[j] * dsc + dsh : 0.f;
+          if (db) t *= vts_act_grad(tnj, p.dm_act);
+          const float fin = p.accumulate ? ob[j] + t : t;
+          ob[j] = fin;
+          if (STATS == 2) {
+            bs1 += fin;
+            bs2 = fmaf(fin, tnj, bs2);
+          }
         }
       }
     };
@@ -444,6 +468,20 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
 #pragma unroll
           for (int ph = 0; ph < P; ++ph) acc[r][mt][ph][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+      if (STATS == 2) {
+        bs1 += __shfl_xor(bs1, 16, 64);
+        bs2 += __shfl_xor(bs2, 16, 64);
+        bs1 += __shfl_xor(bs1, 32, 64);
+        bs2 += __shfl_xor(bs2, 32, 64);
+        if (kq == 0 && co < p.Cout) {
+          const int slot = (by * p.tiles_x + tx0 / TX) * 4 + wave;
+          float* o = p.bsum_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 2;
+          o[0] = bs1;
+          o[1] = bs2;
+        }
+        bs1 = 0.f;
+        bs2 = 0.f;
+      }
     }
   };
 
@@ -766,14 +804,17 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   // (the statistics epilogue is its own instantiation: inside the shared one it raised the register count of EVERY launch of the
   //  template -- e.g. 110 -> 199 VGPRs and occupancy 2 -> 1 on the 40 -> 10 transposed layer -- whether statistics were asked for or not)
   if (k.stat_part) {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), true>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, true>), grid, dim3(256), 0, st, k);
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 1>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 1>), grid, dim3(256), 0, st, k);
+  } else if (k.bsum_part) {
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 2>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 2>), grid, dim3(256), 0, st, k);
   } else {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), false>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, false>), grid, dim3(256), 0, st, k);
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 0>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 0>), grid, dim3(256), 0, st, k);
   }
   vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d, %s, %s>%s", MODE, S, NR, RW, MT, CK, (run > 1 && NR <= 2) ? "true" : "false",   // as rocprofv3 names the instance
-                 k.stat_part ? "true" : "false", KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
+                 k.stat_part ? "1" : (k.bsum_part ? "2" : "0"), KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
   VTS_CHECK_LAUNCH("vts_conv4x4");
   if (trace_dev) {
     (void)hipStreamSynchronize(st);
@@ -817,7 +858,7 @@ struct StatWs {
   float* p;
   int64_t floats;
 };
-static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw);
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw, bool bsums = false);
 int vts_norm_finalize_partials(const vts_norm_desc* d, const float* part, int spl, hipStream_t st);   // vts_norm.hip
 
 extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) { return conv4x4_impl(d, stream, nullptr, nullptr, StatWs{nullptr, 0}); }
@@ -842,13 +883,24 @@ extern "C" int vts_conv4x4_norm(const vts_conv_desc* d, const vts_norm_desc* nd,
   return conv4x4_impl(d, stream, nd, fused, StatWs{stat_ws, stat_ws_floats});
 }
 
+// backward-data convolution whose epilogue also emits the sums of the normalisation backward of the layer below (see ConvK::bsum_part);
+// *slots = 0: plain convolution (the caller runs vts_norm_bwd), else the (S1, S2') pairs per (n, channel) in `part`
+extern "C" int vts_conv4x4_bsums(const vts_conv_desc* d, float* part, int64_t part_floats, int* slots, void* stream) {
+  VTS_CHECK_ARG(d && slots && part, "vts_conv4x4_bsums: null pointer");
+  *slots = 0;
+  int fused = 0;
+  const int rc = conv4x4_impl(d, stream, nullptr, &fused, StatWs{part, part_floats}, true);
+  if (rc == VTS_OK && fused >= 2) *slots = fused - 2;
+  return rc;
+}
+
 extern "C" int vts_norm_stats_from_partials(const vts_norm_desc* nd, const float* part, int slots, void* stream) {
   return vts_norm_finalize_partials(nd, part, slots, (hipStream_t)stream);
 }
 
 static int dispatch_full(const vts_conv_desc* d, const ConvK& k, int nr, int N, hipStream_t st);
 
-static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw) {
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw, bool bsums) {
   VTS_CHECK_ARG(d && d->in0.data && d->w && d->out, "vts_conv4x4: null pointer");
   VTS_CHECK_ARG(d->stride == 1 || d->stride == 2, "vts_conv4x4: stride %d unsupported", d->stride);
   VTS_CHECK_ARG(d->Cout >= 1, "vts_conv4x4: Cout %d", d->Cout);
@@ -911,7 +963,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   k.dm = d->dmask.data; k.dmsc = d->dmask.scale; k.dmsh = d->dmask.shift; k.dmns = d->dmask.nstride;
   k.dm_act = d->dmask_act; k.dmC = d->dmask.C;
   k.accumulate = d->accumulate;
-  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.trace = nullptr; k.stat_part = nullptr; k.stat_spl = 0;
+  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.trace = nullptr; k.stat_part = nullptr; k.stat_spl = 0; k.bsum_part = nullptr;
   static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
   k.ablate = ablate;
   static const int stagger = getenv("VTS_STAGGER") ? atoi(getenv("VTS_STAGGER")) : 0;
@@ -937,6 +989,9 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   const bool want_stats = nd && fused && sw.p && fuse_stats && k.direct_epi && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
                           nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride &&
                           sw.floats >= vts_conv4x4_norm_ws_floats(d);
+  static const int fuse_bsums = getenv("VTS_FUSE_BSUMS") ? atoi(getenv("VTS_FUSE_BSUMS")) : 1;
+  const bool want_bsums = bsums && fused && sw.p && fuse_bsums && k.direct_epi && d->act_out == VTS_ACT_NONE && d->dmask.data &&
+                          sw.floats >= vts_conv4x4_norm_ws_floats(d);
   {
     // Small grids (inner U-Net layers: <= 32x32 maps, 80..592 channels) cannot fill 256 CUs with one
     // workgroup per spatial tile: split the output channels over workgroups (no reduction needed) and,
@@ -961,10 +1016,12 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       k.CG = nr; k.cps = cps; k.part = KS > 1 ? d->ws : nullptr;
       const bool cg_stats = want_stats && KS == 1;    // output-channel split only: every workgroup still stores final values
       if (cg_stats) k.stat_part = sw.p;
+      const bool cg_bsums = want_bsums && KS == 1;
+      if (cg_bsums) k.bsum_part = sw.p;
       int rc;
       if (!d->transposed) rc = d->stride == 2 ? launch<0, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<0, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
       else rc = d->stride == 2 ? launch<1, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<1, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
-      if (rc == VTS_OK && cg_stats) *fused = 2 + t_stat_spl;    // partials written: the caller merges them (vts_norm_stats_from_partials)
+      if (rc == VTS_OK && (cg_stats || cg_bsums)) *fused = 2 + t_stat_spl;    // partials written: the caller merges them
       if (rc != VTS_OK || KS == 1) return rc;
       static const int fuse_in = getenv("VTS_FUSE_SPLIT_IN") ? atoi(getenv("VTS_FUSE_SPLIT_IN")) : 1;
       if (nd && nd->mode == 0 && fuse_in && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
@@ -972,7 +1029,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
         const InStatsOut q{nd->scale, nd->shift, nd->mean_out, nd->rstd_out, nd->eps};
         hipLaunchKernelGGL(conv_split_epilogue_in_kernel, dim3(N * d->Cout), dim3(256), 0, st, k, KS, q);
         VTS_CHECK_LAUNCH("vts_conv4x4 split epilogue + instance norm");
-        vts_set_kernel("conv4x4_kernel<%d, %d, 1, 1, 2, 4, false, false>+ksplit+in", d->transposed ? 1 : 0, d->stride);
+        vts_set_kernel("conv4x4_kernel<%d, %d, 1, 1, 2, 4, false, 0>+ksplit+in", d->transposed ? 1 : 0, d->stride);
         *fused = 1;
         return VTS_OK;
       }
@@ -982,8 +1039,9 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
     }
   }
   if (want_stats) k.stat_part = sw.p;
+  if (want_bsums) k.bsum_part = sw.p;
   const int rc = dispatch_full(d, k, nr, N, st);
-  if (rc != VTS_OK || !want_stats) return rc;
+  if (rc != VTS_OK || !(want_stats || want_bsums)) return rc;
   *fused = 2 + t_stat_spl;      // partials written: the caller merges them (vts_norm_stats_from_partials)
   return VTS_OK;
 }

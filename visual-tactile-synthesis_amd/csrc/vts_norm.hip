@@ -289,6 +289,10 @@ struct NormBwdK {
   float* coef;  // [N*C][4]: A, B, C, mean
   int ngroups;  // BatchNorm: passes batched into this launch (>= 1)
   int gstart[9];
+  // partials from a convolution epilogue (vts_conv4x4_bsums): `pspl` (S1, S2') pairs per (n, channel) with S2' = sum dy * (gamma xhat + beta);
+  // S2 = (S2' - beta S1) / gamma.  pspl = 0: partials of norm_bwd_partial_kernel (spl per (n, channel), S2 as is).
+  int pspl;
+  const float* beta;
 };
 
 __device__ __forceinline__ void norm_bwd_finalize_group(const volatile float* part, const NormBwdK& k, int group) {
@@ -364,6 +368,22 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(float* __restrict__
 // reduces the partial sums of ITS group itself, in the order of norm_bwd_finalize_group (bit-identical coefficients in every
 // workgroup), the BatchNorm parameter gradients are written by the first workgroup of each channel.
 __device__ __forceinline__ void bwd_group_sums(const float* __restrict__ part, const NormBwdK& k, int c, int n0, int n1, float& s1, float& s2) {
+  if (k.pspl > 0) {     // epilogue partials: thousands per group -> the whole workgroup sums them (fixed order), then the affine is undone
+    __shared__ float red[16];
+    const int np = (n1 - n0) * k.pspl;
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) {
+      const int n = n0 + i / k.pspl, s = i - (i / k.pspl) * k.pspl;
+      const float* q = part + (((int64_t)n * k.C + c) * k.pspl + s) * 2;
+      a += q[0];
+      b += q[1];
+    }
+    s1 = block_sum(a, red);
+    const float sp = block_sum(b, red);
+    const float ga = (k.mode == 1 && k.gamma) ? k.gamma[c] : 1.f, be = (k.mode == 1 && k.beta) ? k.beta[c] : 0.f;
+    s2 = (sp - be * s1) / ga;
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int np = (n1 - n0) * k.spl;
   s1 = 0.f;
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fin_kernel(float* __restri
   const float rs = k.rstd[n0 * k.C + c], mu = k.mean[n0 * k.C + c];
   const float ga = (k.mode == 1 && k.gamma) ? k.gamma[c] : 1.f;
   const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m;
-  if (k.mode == 1 && blockIdx.x == 0 && n == 0 && threadIdx.x < 64 && (k.dgamma || k.dbeta)) {
+  if (k.mode == 1 && blockIdx.x == 0 && n == 0 && (threadIdx.x < 64 || k.pspl > 0) && (k.dgamma || k.dbeta)) {    // (uniform per workgroup)
     float dg = 0.f, db = 0.f;
     for (int gi = 0; gi < k.ngroups; ++gi) {
       float t1, t2;
@@ -848,6 +868,25 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, coef);
   VTS_CHECK_LAUNCH("vts_norm_bwd apply");
   vts_set_kernel("norm_bwd_partial_kernel+norm_bwd_finalize_kernel+norm_bwd_apply_kernel");
+  return VTS_OK;
+}
+
+// vts_norm_bwd on sums a convolution epilogue produced (vts_conv4x4_bsums): only the apply pass runs
+extern "C" int vts_norm_bwd_from_partials(const vts_norm_bwd_desc* d, const float* part, int slots, const float* beta, void* stream) {
+  VTS_CHECK_ARG(d && d->dy && d->x && d->mean && d->rstd && part && slots >= 1, "vts_norm_bwd_from_partials: null pointer");
+  VTS_CHECK_ARG(d->mode == 0 || d->mode == 1, "vts_norm_bwd_from_partials: mode %d", d->mode);
+  const int spl = splits_for(d->HW);
+  NormBwdK k{d->N, d->C, d->HW, spl, d->mode, d->mean, d->rstd, d->gamma, d->dgamma, d->dbeta, d->accumulate_param_grads, nullptr};
+  int maxg = d->N;
+  if (!fill_groups(d->mode, d->N, d->ngroups, d->gstart, k.ngroups, k.gstart, maxg)) {
+    vts_set_error("vts_norm_bwd_from_partials: bad pass groups (ngroups %d)", d->ngroups);
+    return VTS_ERR_ARG;
+  }
+  k.pspl = slots;
+  k.beta = beta;
+  hipLaunchKernelGGL(norm_bwd_apply_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, (hipStream_t)stream, d->dy, d->x, d->nstride, part, k);
+  VTS_CHECK_LAUNCH("vts_norm_bwd_from_partials");
+  vts_set_kernel("norm_bwd_apply_fin_kernel");
   return VTS_OK;
 }
 

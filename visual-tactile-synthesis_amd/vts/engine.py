@@ -235,7 +235,7 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
         store[key] = t
         return t, False
 
-    def up_bwd(i, name, dx, dfeat, wq):
+    def up_bwd(i, name, dx, dfeat, wq, lane_mode=False):
         """backward of one up block: weight gradient (through wq: side queue, or inline inside a lane), gradient w.r.t.
         the block input into dx / dfeat[nd-1], gradient w.r.t. the skip feature into dfeat[i]"""
         skip = None if i in (0, nd - 1) else feats[i]
@@ -262,7 +262,10 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
             tgt, acc = add_grad_list(dfeat, nd - 1, inp.data.shape, dev)
         else:
             tgt, acc = add_grad(dx, id(inp), inp.data.shape)
-        ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc)
+        # (the tensor goes straight into the InstanceNorm backward of the block below unless it is the un-normalised innermost feature
+        #  or the split point, whose two lane contributions are summed first: there the epilogue also emits that backward's sums)
+        ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc,
+                    bwd_sums=(i != nd - 1) and not (lane_mode and i == nls - 1))
         if skip is not None:
             tgt, acc = add_grad_list(dfeat, i, skip.data.shape, dev)
             wv = blk.weight.view(-1)[c_in0 * outer * 16:]
@@ -286,7 +289,7 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
 
         def chain(lane):
             for i in range(nls):
-                up_bwd(i, "up%d%s" % (i, "_T" if lane else ""), lane_dx[lane], lane_df[lane], inline)
+                up_bwd(i, "up%d%s" % (i, "_T" if lane else ""), lane_dx[lane], lane_df[lane], inline, lane_mode=True)
 
         _run_lanes(2, chain)
 
@@ -331,7 +334,7 @@ def _unet_backward_encoder(G, ctx, dfeat, feats, nd, dev, sq):
             cin = blk.weight.shape[1]
             tgt, acc = add_grad_list(dfeat, i - 1, feats[i - 1].data.shape, dev)
             ops.conv4x4(Act(g), blk.weight, 16, cin * 16, cin, tgt, stride=2, pad=1, transposed=True, dmask=feats[i - 1],
-                        dmask_act=LRELU, accumulate=acc)
+                        dmask_act=LRELU, accumulate=acc, bwd_sums=i - 1 > 0)     # the last contribution to dfeat[i-1]: its InstanceNorm backward is next
         dfeat[i] = None
     sq.join()
 
@@ -879,7 +882,7 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
         if ci in D.BN_IDX:
             bn = getattr(layer, str(D.BN_IDX[ci]))
             ops.norm_bwd(g, acts[j], 1, gamma=bn.weight, dgamma=bn.weight.grad if param_grads else None,
-                         dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate, groups=groups)
+                         dbeta=bn.bias.grad if param_grads else None, accumulate=accumulate, groups=groups, beta=bn.bias)
         src0, src1 = (a0, a1) if j == 0 else (acts[j - 1], None)
         if param_grads:
             pp = src0.padded if j else None
@@ -905,7 +908,7 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
                 ops.act_bwd(raw, prev, LRELU, tgt)
             else:
                 ops.conv4x4(Act(g), conv.weight, 16, cin * 16, cin, tgt, stride=st, pad=2, transposed=True, dmask=prev,
-                            dmask_act=LRELU)
+                            dmask_act=LRELU, bwd_sums=D.CONV_IDX[j - 1] in D.BN_IDX)
             g = tgt
         elif want_input_grad:
             c0 = a0.data.shape[1]

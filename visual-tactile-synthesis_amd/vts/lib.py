@@ -90,7 +90,7 @@ SYMBOLS = [
     "vts_metric_ws_floats", "vts_minmax", "vts_metric_psnr", "vts_metric_tactile", "vts_metric_ssim", "vts_frechet_ws_floats", "vts_frechet_distance", "vts_sifid_input", "vts_modconv_weight", "vts_modconv_weight_bwd", "vts_adain", "vts_adain_bwd", "vts_resample_table",
     "vts_mask_select", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
     "vts_maxpool2_relu_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
-    "vts_patch_jobs", "vts_g_post_stack", "vts_step_begin",
+    "vts_patch_jobs", "vts_g_post_stack", "vts_step_begin", "vts_conv4x4_bsums", "vts_norm_bwd_from_partials",
 ]
 
 
@@ -151,6 +151,8 @@ def load():
         "vts_g_post_stack": [vp, vp, i, i, i, f, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, i64, vp],
         "vts_patch_jobs": [C.POINTER(PatchJob), i, i, vp],
         "vts_step_begin": [vp, i, vp, i, vp],
+        "vts_conv4x4_bsums": [C.POINTER(ConvDesc), vp, i64, C.POINTER(C.c_int), vp],
+        "vts_norm_bwd_from_partials": [C.POINTER(NormBwdDesc), vp, i, vp, vp],
         "vts_diffaug_bs_mask": [vp, vp, i, i, i, vp, vp, vp, vp],
         "vts_g_out_grad": [vp, vp, vp, vp, i, i, i, vp, vp],
         "vts_mask_mul": [vp, vp, i, i, i, vp, vp],

@@ -132,6 +132,9 @@ def _op(a):
     return L.operand(a)
 
 
+BWD_SUMS = os.environ.get("VTS_BWD_SUMS", "1") != "0"
+BSUMS = {}       # data_ptr of a gradient tensor -> (partials, slots, the tensor): sums its producing convolution left for norm_bwd
+
 _stat_ws = {}
 
 
@@ -149,7 +152,7 @@ def stat_workspace(nfloats, device):
 
 def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, pad=1, transposed=False, act_in=0,
             act_out=0, dmask=None, dmask_act=0, accumulate=False, out_nstride=None, in_hw=None, pad_dx=0, instance_norm=False,
-            batch_norm=None):
+            batch_norm=None, bwd_sums=False):
     """out <- conv-family(in0 ++ in1).  `w` may be an offset view into a weight tensor.
     instance_norm=True / batch_norm=dict(keyword arguments of norm_stats: gamma, beta, running_mean, ..., groups, stat_out, ext):
     returns Act(out, scale, shift, mean, rstd) of InstanceNorm2d(out) / training-mode BatchNorm2d(out) -- through vts_conv4x4_norm, which
@@ -187,7 +190,19 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d p%d%s%s" % (d.N, cin, d.IH, d.IW, cout, d.OH, d.OW, pad, " dmask" if dmask is not None else "",
                                                       " acc" if accumulate else "")
+    if bwd_sums and dmask is not None and BWD_SUMS:
+        # backward-data convolution in front of a normalisation backward: the epilogue also emits that backward's sums; `out` carries
+        # them to norm_bwd (BSUMS: out tensor -> (partials, slots)), which then runs its apply pass only
+        part = torch.empty(int(lib.vts_conv4x4_norm_ws_floats(C.byref(d))), dtype=torch.float32, device=x.device)
+        slots = C.c_int(0)
+        _run(label, nbytes, flops, lib.vts_conv4x4_bsums, C.byref(d), part.data_ptr(), part.numel(), C.byref(slots), L.stream())
+        if slots.value:
+            BSUMS[out.data_ptr()] = (part, slots.value, out)
+        else:
+            BSUMS.pop(out.data_ptr(), None)
+        return out
     if not instance_norm and batch_norm is None:
+        BSUMS.pop(out.data_ptr(), None)      # a plain write into this buffer invalidates sums an earlier convolution left for it
         _run(label, nbytes, flops, lib.vts_conv4x4, C.byref(d), L.stream())
         return out
     kw = dict(batch_norm) if batch_norm is not None else {}
@@ -922,8 +937,9 @@ def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var
     return Act(x, st[0], st[1], st[2], st[3])
 
 
-def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=False, groups=None):
-    """In place: dy (grad wrt normalised output) -> grad wrt the raw tensor act.data."""
+def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=False, groups=None, beta=None):
+    """In place: dy (grad wrt normalised output) -> grad wrt the raw tensor act.data.
+    beta: the BatchNorm shift (only needed when the producer of dy left epilogue sums for it: conv4x4(bwd_sums=True))"""
     lib = L.load()
     n, c, h, w = dy.shape
     d = L.NormBwdDesc()
@@ -932,11 +948,18 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
     d.gamma, d.dgamma, d.dbeta = L.ptr(gamma), L.ptr(dgamma), L.ptr(dbeta)
     d.accumulate_param_grads = int(accumulate)
     _set_groups(d, groups, n)
-    ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
-    d.counters = L.ptr(counters(dy.device)) if n * c <= (1 << 16) else None
     if TIMER is not None:
         global DETAIL
         DETAIL = "%s N%d %dx%dx%d%s" % ("BN" if mode else "IN", n, c, h, w, " groups %s" % list(groups) if groups else "")
+    pre = BSUMS.pop(dy.data_ptr(), None)
+    if pre is not None and pre[2] is dy:
+        if TIMER is not None:
+            DETAIL += " from %d epilogue slots" % pre[1]
+        _run("norm_bwd_from_partials", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd_from_partials, C.byref(d), pre[0].data_ptr(), pre[1], L.ptr(beta) if mode else None,
+             L.stream())
+        return dy
+    ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
+    d.counters = L.ptr(counters(dy.device)) if n * c <= (1 << 16) else None
     _run("norm_bwd", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
     return dy
 
