@@ -302,6 +302,7 @@ def wgrad_discard():
     global _pending
     _pending = []
     _pending_by_dw.clear()
+    BSUMS.clear()
     for a in _arenas.values():
         a.reset()
 
@@ -999,6 +1000,7 @@ def loss_slots(n, device):
 
 def step_begin(slots, counters):
     """zero the loss slots and advance the optimisers' device step counters (one launch)"""
+    BSUMS.clear()      # epilogue sums nobody consumed (a backward that raised) must not outlive their step
     L.check(L.load().vts_step_begin(slots.data_ptr(), slots.numel(), L.ptr(counters), 0 if counters is None else counters.numel(), L.stream()), "vts_step_begin")
 
 
