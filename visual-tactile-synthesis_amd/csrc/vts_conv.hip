@@ -18,682 +18,11 @@
 // LDS reads are conflict-free by construction: A fragments read stride-S words of one patch
 // row (32 lanes -> 32 distinct banks or broadcast), B fragments read [k][cout] with the cout
 // pitch = 16 (mod 32).
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
+#include "vts_conv_kernel.h"
 
-#include "vts_internal.h"
+thread_local int t_stat_spl = 0;   // statistics slots per (n, channel) of the last launch (conv4x4_impl -> vts_norm_finalize_partials)
 
 namespace {
-
-struct ConvK {
-  const float *s0, *s1, *sc0, *sh0, *sc1, *sh1;
-  int64_t ns0, ns1;
-  int C0, C1, Cin;
-  int IH, IW, OH, OW, Cout, pad, padx;   // padx: horizontal padding (pad + pad_dx)
-  const float* w;
-  int ws_co, ws_ci;
-  const float* bias;
-  float* out;
-  int64_t ons;
-  int act_in, act_out;
-  const float *dm, *dmsc, *dmsh;
-  int64_t dmns;
-  int dm_act, dmC;
-  int accumulate;
-  // small-grid decomposition: blockIdx.z = n + N * (cout_group + CG * k_slice)
-  int N, CG, cps;   // cps = input-channel chunks per k-slice
-  float* part;      // k-split partial sums [KS][N][Cout][OH][OW] (raw accumulators), or nullptr
-  const float* ident;  // {1, 0}
-  float slope_in;      // input activation as t > 0 ? t : slope * t
-  int identity_in;     // no affine on either source and no input activation
-  int ablate;       // profiling only (env VTS_ABLATE): 1 skip global loads, 2 skip MFMA, 4 skip epilogue
-  int wbytes;       // extent of the weight tensor view in bytes (buffer descriptor of the weight loads)
-  int xcd_swizzle;  // 1: XCD-aware workgroup order (default); VTS_XCD_SWIZZLE=0 keeps the hardware order
-  int direct_epi;   // 1: stores straight from the accumulator registers (default); 0: through LDS (VTS_DIRECT_EPI=0)
-  int stagger;      // start-up stagger in units of ~3.4 us (s_sleep 127): workgroup w of a co-resident set waits (w % 3) * stagger units
-  unsigned long long* trace;   // profiling only (env VTS_CONV_TRACE): per workgroup 8 x 64-bit: hw id, then s_memrealtime (100 MHz) at the phase boundaries
-  int tiles_x;      // tiles per row band; a workgroup walks the run [bx * tiles_x / gridDim.x, (bx + 1) * tiles_x / gridDim.x) of them
-  // round 3: statistics of the output fused into the direct epilogue.  Every WAVE writes (mean, M2, count) of its rows of the tile per
-  // output channel -- the partial format of stats_partial_kernel (vts_norm.hip), slot = (tile row * tiles_x + tile) * 4 + wave of
-  // stat_spl slots per (n, channel) -- and norm_finalize_kernel merges them (Chan) exactly as it merges the partials of the
-  // stand-alone statistics pass: the normalised layers lose one full read of their output and one launch.
-  float* stat_part;
-  int stat_spl;
-  // round 3: sums of the NORMALISATION BACKWARD fused into the epilogue of the backward-data convolution that produces its input
-  // gradient dy (the masked / accumulated value it stores): S1 = sum dy, S2' = sum dy * t with t = dmask * scale + shift -- the
-  // normalised value of the layer below (InstanceNorm: t = xhat; BatchNorm: t = gamma xhat + beta, undone by the consumer).  One
-  // (S1, S2') pair per wave and tile in the layout of norm_bwd_partial_kernel: the stand-alone partial pass (a read of dy AND x)
-  // and its launch disappear.
-  float* bsum_part;
-};
-
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr unsigned OOB_OFF = 0x40000000u;   // byte offset beyond every channel plane / weight tensor (the host side checks the sizes)
-struct TagT { static constexpr bool value = true; };
-struct TagF { static constexpr bool value = false; };
-__device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
-}
-
-// Output staging region of one epilogue pass: 16 output channels x ER rows x EC columns, plane pitch odd
-// so that the 16 channel planes land on distinct LDS banks.
-template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN, int STATS>
-__global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
-  constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
-  constexpr int TY = 4 * RW, TX = 16 * MT;
-  constexpr int PR = MODE == 0 ? (TY - 1) * S + 4 : (S == 2 ? TY + 2 : TY + 3);
-  constexpr int PC = MODE == 0 ? (TX - 1) * S + 4 : (S == 2 ? TX + 2 : TX + 3);
-  constexpr int PCP = PC + 1;
-  constexpr int COP = (NR % 2 == 1) ? NR * 16 : NR * 16 + 16;
-  static_assert(CK == 4, "staging maps wave w to input channel w of the chunk");
-  // Row-wise staging: wave w stages the PR rows of channel w of the chunk, 64 columns per load.  A short
-  // remainder (<= 16 columns) is staged element-wise instead of by a mostly idle 64-lane piece.
-  constexpr int REM = PC % 64;
-  constexpr int NCM = PC / 64 + ((REM > 16) ? 1 : 0);  // 64-column pieces per row (the last may be partial)
-  constexpr int PCM = (REM > 16) ? PC : (PC / 64) * 64;
-  constexpr int TW = PC - PCM;                          // element-wise tail columns
-  constexpr int NROWS = CK * PR;
-  constexpr int NPV = PR * NCM > 0 ? PR * NCM : 1;      // prefetch registers: row-wise part of the patch
-  constexpr int NTV = (NROWS * TW + 255) / 256 > 0 ? (NROWS * TW + 255) / 256 : 1;  // ... tail columns
-  constexpr int NWV = CK * NR;                         // ... weights (CK*16*NR*16 / 256)
-  constexpr int EC = (P == 4) ? 2 * TX : TX;           // epilogue pass: TY rows x EC columns x 16 channels
-  constexpr int EPL = TY * EC + 1;
-  constexpr int PATCH_FLOATS = CK * PR * PCP, W_FLOATS = CK * 16 * COP, OUT_FLOATS = 16 * EPL;
-  constexpr int LDS_FLOATS = (PATCH_FLOATS + W_FLOATS) > OUT_FLOATS ? (PATCH_FLOATS + W_FLOATS) : OUT_FLOATS;
-
-  __shared__ float lds[LDS_FLOATS];
-  float* lds_patch = lds;
-  float* lds_w = lds + PATCH_FLOATS;
-
-  if (p.stagger > 0) {
-    // co-resident workgroups start in lock-step and would load / multiply / store in phase; shift every third one
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int units = ((lin >> 8) % 3) * p.stagger;
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int trace_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  auto stamp = [&](int i) {
-    if (p.trace && tid == 0) p.trace[(int64_t)trace_wg * 8 + i] = i == 0 ? (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) : __builtin_amdgcn_s_memrealtime();
-  };
-  stamp(0);
-  stamp(1);
-  // provably wave-uniform wave index: all per-row staging state (bounds, row pointers, normalisation
-  // scale/shift) then lives in SGPRs / scalar loads instead of per-lane VGPRs and branches
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m16 = lane & 15, kq = lane >> 4;
-  // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2, so spatially adjacent tiles
-  // would fetch their shared halo rows / columns from HBM once per XCD.  Remap ids so that every XCD walks one contiguous run of
-  // tiles (bijective for any grid size): neighbours in x and y then meet in the same L2.  (PMC: 1.5x -> measured in DESIGN.md.)
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (p.xcd_swizzle) {
-    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * (int)gridDim.z;
-    const int lin = bx + gx * (by + gy * bz);
-    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
-    const int lin2 = xcd * q + min(xcd, r) + idx;
-    bz = lin2 / (gx * gy);
-    const int rem = lin2 - bz * (gx * gy);
-    by = rem / gx;
-    bx = rem - by * gx;
-  }
-  const int n = bz % p.N;
-  const int cg = (bz / p.N) % p.CG, ks = bz / (p.N * p.CG);
-  const int co0 = cg * NR * 16;
-  // Tile run of this workgroup (round 2): thin layers have one or two input-channel chunks per tile, so a workgroup that owned a
-  // single tile would load, multiply and store strictly one after the other (measured: the phases add up, co-resident workgroups
-  // run in lock-step).  A run of tiles along x turns the chunk pipeline into a tile pipeline: the loads of the next tile are in
-  // flight during the MFMA phase and the stores of the current one.
-  // (RUN instances only; the others keep one tile per workgroup and the epilogue outside the chunk loop.)
-  const int tile_begin = RUN ? bx * p.tiles_x / (int)gridDim.x : bx, tile_end = RUN ? (bx + 1) * p.tiles_x / (int)gridDim.x : bx + 1;
-  const int ty0 = by * TY;
-  const int podd = p.pad & 1;
-
-  int iy0;
-  if (MODE == 0) iy0 = ty0 * S - p.pad;
-  else if (S == 2) iy0 = ty0 + (p.pad >> 1) - 1;
-  else iy0 = ty0 + p.pad - 3;
-
-  // per-lane A-fragment base offsets inside one channel plane of the patch
-  int aoff[P];
-  if (MODE == 0) {
-    aoff[0] = (wave * RW * S) * PCP + m16 * S + kq;
-  } else if (S == 2) {
-#pragma unroll
-    for (int ph = 0; ph < P; ++ph) {
-      const int dpy = (ph >> 1) & podd, dpx = (ph & 1) & podd;
-      aoff[ph] = (wave * RW + dpy + 1 - (kq >> 1)) * PCP + m16 + dpx + 1 - (kq & 1);
-    }
-  } else {
-    aoff[0] = (wave * RW + 3) * PCP + m16 + 3 - kq;
-  }
-
-  f32x4 acc[RW][MT][P][NR];
-#pragma unroll
-  for (int r = 0; r < RW; ++r)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int ph = 0; ph < P; ++ph)
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) acc[r][mt][ph][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int64_t plane = (int64_t)p.IH * p.IW;
-  const int nchunks = (p.Cin + CK - 1) / CK;
-  const int chunk_begin = ks * p.cps;
-  const int chunk_end = min(nchunks, (ks + 1) * p.cps);
-
-  // Software pipeline: the global loads of chunk k+1 are issued into registers before the MFMA phase of chunk k and
-  // written to LDS (normalise + activate + concat resolved on the way) after it.
-  //
-  // Staging discipline (round 2; what it replaced spent ~40 instructions per loaded dword on clamped 64-bit addresses and
-  // spilled 35..150 SGPRs per instance through v_writelane / v_readlane):
-  //  * every load is a buffer load whose descriptor is ONE CHANNEL PLANE (base = plane start, num_records = IH*IW*4), with
-  //    byte offset = [lane part: column * 4, or the OOB sentinel for a column outside the row] + [uniform part: row * IW * 4].
-  //    A row above / below the map makes the sum negative (= huge unsigned) / >= num_records, a channel beyond Cin gets
-  //    num_records = 0: the hardware range check returns 0 (per dword, soffset included: tools/probes/buffer_oob.hip), so
-  //    zero padding costs no instruction and an operand without affine / activation goes straight from the load to LDS;
-  //  * wave w owns channel w of the chunk: one descriptor per wave and chunk, rows differ by a multiple of the row pitch;
-  //    the <= 3 columns beyond the 64-lane pieces of all rows are one extra load (lane -> (row, column));
-  //  * the chunk's channel index carries an opaque zero, re-read per chunk, so that LLVM cannot hoist the per-row address
-  //    arithmetic out of the chunk loop (that is what used to spill);
-  //  * weights: a thread loads the four kx taps of one (cout, cin, ky) as one 16-byte buffer load, threads of a wave differ
-  //    in cout, so the LDS stores ([tap][cout], cout fastest) are bank-conflict-free (the old tap-fastest mapping was 16-way).
-  constexpr int TPR = TW > 0 ? 64 / TW : 1;            // patch rows per tail load
-  static_assert(TW == 0 || PR <= TPR, "one tail load covers all patch rows");
-  float pv[NPV], tv = 0.f;
-  f32x4 wv[NR];
-#pragma unroll
-  for (int i = 0; i < NPV; ++i) pv[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < NR; ++i) wv[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
-
-  const int iplane = p.IH * p.IW;
-  const float* sb0 = p.s0 + n * p.ns0;
-  const float* sb1 = p.s1 + n * p.ns1;
-  const unsigned row0 = (unsigned)(iy0 * p.IW * 4), rstep = (unsigned)(p.IW * 4);
-  unsigned vo_m[NCM > 0 ? NCM : 1];   // lane parts of the byte offsets of the row-wise pieces (of the tile being loaded)
-  int colw[NCM > 0 ? NCM : 1];        // LDS column a lane writes (lanes beyond the piece write the pad column PC)
-#pragma unroll
-  for (int cm = 0; cm < NCM; ++cm) {
-    const int col = cm * 64 + lane;
-    vo_m[cm] = OOB_OFF;
-    colw[cm] = col < PCM ? col : PC;
-  }
-  unsigned vo_t = OOB_OFF;
-  int dst_t = PC;
-  const int r_t = lane / (TW > 0 ? TW : 1), c_t = lane - r_t * (TW > 0 ? TW : 1);
-  if (TW > 0) dst_t = r_t < PR ? r_t * PCP + PCM + c_t : PC;
-  auto set_tile = [&](int tile) {   // column offsets of the tile whose patch is loaded next
-    const int tx0 = tile * TX;
-    int ix0;
-    if (MODE == 0) ix0 = tx0 * S - p.padx;
-    else if (S == 2) ix0 = tx0 + (p.pad >> 1) - 1;
-    else ix0 = tx0 + p.padx - 3;
-#pragma unroll
-    for (int cm = 0; cm < NCM; ++cm) {
-      const int col = cm * 64 + lane, ix = ix0 + col;
-      vo_m[cm] = (col < PCM && ix >= 0 && ix < p.IW) ? (unsigned)ix * 4u : OOB_OFF;
-    }
-    if (TW > 0) {
-      const int ix = ix0 + PCM + c_t;
-      vo_t = (r_t < PR && ix >= 0 && ix < p.IW) ? (unsigned)(r_t * p.IW + ix) * 4u : OOB_OFF;
-    }
-  };
-  float wsc = 1.f, wsh = 0.f;
-  unsigned cur_nrec = 0;
-
-  // weights: chunk-invariant part of the per-thread unit decode (unit = the 4 kx taps of one (cout, chunk channel, ky))
-  constexpr int NCO = NR * 16;
-  unsigned wvo[NR];
-  int wc[NR], wld[NR][4];
-#pragma unroll
-  for (int e = 0; e < NR; ++e) {
-    const int u = tid + e * 256;
-    const int co = u % NCO, rest = u / NCO;
-    const int ky = rest & 3, c = rest >> 2;
-    wc[e] = c;
-    wvo[e] = co0 + co < p.Cout ? (unsigned)((co0 + co) * p.ws_co + c * p.ws_ci + ky * 4) * 4u : OOB_OFF;
-#pragma unroll
-    for (int kx = 0; kx < 4; ++kx) {
-      int slot = ky * 4 + kx;
-      if (MODE == 1 && S == 2) slot = ((((ky + p.pad) & 1) * 2 + ((kx + p.pad) & 1)) * 4) + (ky >> 1) * 2 + (kx >> 1);
-      wld[e][kx] = (c * 16 + slot) * COP + co;
-    }
-  }
-  const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
-
-  auto opaque_zero = []() {
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    return z;
-  };
-
-  auto load_chunk = [&](int chunk, bool with_w) {
-    const int cbase = chunk * CK;
-    const int cic = cbase + wave + opaque_zero();
-    {
-      const int ccl = min(cic, p.Cin - 1);
-      const bool first = ccl < p.C0;
-      const int cl = first ? ccl : ccl - p.C0;
-      const float* scp = first ? p.sc0 : p.sc1;
-      const float* shp = first ? p.sh0 : p.sh1;
-      const int aidx = n * (first ? p.C0 : p.C1) + cl;
-      const bool hsc = scp != nullptr, hsh = shp != nullptr;
-      wsc = (hsc ? scp : p.ident)[hsc ? aidx : 0];
-      wsh = (hsh ? shp : p.ident)[hsh ? aidx : 1];
-    }
-    const bool cok = cic < p.Cin;
-    const int cc = cok ? cic : 0;
-    const bool first = cc < p.C0;
-    const float* base = (first ? sb0 : sb1) + (int64_t)(first ? cc : cc - p.C0) * iplane;
-    cur_nrec = cok ? (unsigned)iplane * 4u : 0u;
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)cur_nrec, 0x00020000);
-#pragma unroll
-    for (int r = 0; r < PR; ++r)
-#pragma unroll
-      for (int cm = 0; cm < NCM; ++cm) pv[r * NCM + cm] = ld_buf(rs, vo_m[cm] + row0 + r * rstep);
-    if (TW > 0) tv = ld_buf(rs, vo_t + row0);
-    if (with_w) {
-      const int wsoff = cbase * p.ws_ci * 4;
-#pragma unroll
-      for (int e = 0; e < NR; ++e)
-        wv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(cbase + wc[e] < p.Cin ? wvo[e] : OOB_OFF), wsoff, 0));
-    }
-  };
-
-  // branch-free  pad( act( x * scale + shift ) )
-  auto finish = [&](float x, float sc, float sh, bool inside) -> float {
-    const float t = fmaf(x, sc, sh);
-    const float a = fmaxf(t, 0.f) + p.slope_in * fminf(t, 0.f);
-    return inside ? a : 0.f;
-  };
-
-  auto store_patch = [&](auto plain_tag) {
-    constexpr bool PLAIN = decltype(plain_tag)::value;
-    float* dst = lds_patch + wave * PR * PCP;
-#pragma unroll
-    for (int r = 0; r < PR; ++r)
-#pragma unroll
-      for (int cm = 0; cm < NCM; ++cm) {
-        float v = pv[r * NCM + cm];
-        if (!PLAIN) v = finish(v, wsc, wsh, vo_m[cm] + row0 + r * rstep < cur_nrec);
-        dst[r * PCP + colw[cm]] = v;
-      }
-    if (TW > 0) {
-      float v = tv;
-      if (!PLAIN) v = finish(v, wsc, wsh, vo_t + row0 < cur_nrec);
-      dst[dst_t] = v;
-    }
-  };
-
-  auto store_chunk = [&](bool with_w) {
-    if (p.identity_in) store_patch(TagT());   // uniform: gradients and raw inputs carry no affine / activation
-    else store_patch(TagF());
-    if (with_w) {
-#pragma unroll
-      for (int e = 0; e < NR; ++e)
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) lds_w[wld[e][kx]] = wv[e][kx];
-    }
-  };
-
-  // ---- direct epilogue (round 2): a lane's four accumulator registers are four consecutive pixels of ONE output channel
-  // (two parity phases interleave to eight), so every tile row goes out as 16-byte buffer stores straight from the registers --
-  // no LDS transposition, no barriers.  Lanes outside the tensor / beyond Cout carry the OOB offset (the hardware drops the
-  // store and returns 0 for the derivative-mask / accumulate loads); a vector that would cross the end of an output row (the
-  // range check cannot see row ends) falls back to per-dword stores on that lane.  16 channels x 64-byte runs per instruction.
-  const int64_t oplane = (int64_t)p.OH * p.OW;
-  const bool direct = !p.part && p.direct_epi;
-  auto epilogue_direct = [&](int tx0) {
-    const int onb = (int)((int64_t)p.Cout * oplane * 4);
-    const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + n * p.ons), 0, onb, 0x00020000);
-    const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? (int)((int64_t)p.dmC * oplane * 4) : 0, 0x00020000);
-    if (STATS == 1) {
-      // (the host enables this only without output activation / derivative mask / accumulation: the stored value is acc + bias)
-      // A lane holds RW x MT x P x 4 values of ONE channel (m16); the four kq lane groups of the wave hold the rest of the wave's rows.
-      // One pass over the accumulators: sum and sum of squares of the values BEFORE the bias (the variance does not see a constant,
-      // so a large bias costs no precision; what is left of |mean| / sigma inside a wave's 64 .. 512 values is what a convolution of
-      // zero-mean-ish weights produces), M2 = q - s * mean.  The Chan merge of the second stage handles the spread BETWEEN partials.
-      const int slot = (by * p.tiles_x + tx0 / TX) * 4 + wave;
-#pragma unroll
-      for (int nr = 0; nr < NR; ++nr) {
-        const int co = co0 + nr * 16 + m16;
-        float sum = 0.f, sq = 0.f, cnt = 0.f;
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int ph = 0; ph < P; ++ph) {
-              const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
-              const int y = P == 4 ? gy * 2 + (ph >> 1) : gy, x = P == 4 ? gx * 2 + (ph & 1) : gx;
-              const int nv = y < p.OH ? min(4, P == 4 ? (p.OW - x + 1) >> 1 : p.OW - x) : 0;   // valid elements of this lane's 4-vector
-              const f32x4 a = acc[r][mt][ph][nr];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float v = j < nv ? a[j] : 0.f;
-                sum += v;
-                sq = fmaf(v, v, sq);
-              }
-              cnt += (float)max(nv, 0);
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sq += __shfl_xor(sq, 16, 64);
-        cnt += __shfl_xor(cnt, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        cnt += __shfl_xor(cnt, 32, 64);
-        if (kq == 0 && co < p.Cout) {
-          const float mean = sum / fmaxf(cnt, 1.f);
-          float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
-          o[0] = mean + (p.bias ? p.bias[co] : 0.f);
-          o[1] = fmaxf(sq - sum * mean, 0.f);
-          o[2] = cnt;
-        }
-      }
-    }
-    float bs1 = 0.f, bs2 = 0.f;     // STATS == 2: this lane's share of S1 / S2' of the channel it is emitting
-    auto emit = [&](int co, int y, int x, float bias, float dsc, float dsh, f32x4 v) {
-      const bool ok = co < p.Cout && y < p.OH && x < p.OW;
-      const bool full = ok && x + 4 <= p.OW;
-      const unsigned off = (unsigned)((co * (int)oplane + y * p.OW + x) * 4);
-      const unsigned vo = full ? off : OOB_OFF;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = v[j] + bias;
-        if (p.act_out == VTS_ACT_TANH) t = tanhf(t);
-        v[j] = t;
-      }
-      const f32x4 base = v;   // bias + activation applied; the edge path below redoes mask / accumulate per element
-      f32x4 tn = {0.f, 0.f, 0.f, 0.f};
-      if (p.dm) {
-        const f32x4 d = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, (int)vo, 0, 0));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          tn[j] = d[j] * dsc + dsh;
-          v[j] *= vts_act_grad(tn[j], p.dm_act);
-        }
-      }
-      if (p.accumulate) {
-        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (int)vo, 0, 0));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += q[j];
-      }
-      if (STATS == 2 && full) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bs1 += v[j];
-          bs2 = fmaf(v[j], tn[j], bs2);
-        }
-      }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ors, (int)vo, 0, 0);
-      if (ok && !full) {   // right edge of an output row: per element
-        float* ob = p.out + n * p.ons + co * oplane + (int64_t)y * p.OW + x;
-        const float* db = p.dm ? p.dm + n * p.dmns + co * oplane + (int64_t)y * p.OW + x : nullptr;
-        for (int j = 0; j < p.OW - x; ++j) {
-          float t = base[j];
-          const float tnj = db ? db[j] * dsc + dsh : 0.f;
-          if (db) t *= vts_act_grad(tnj, p.dm_act);
-          const float fin = p.accumulate ? ob[j] + t : t;
-          ob[j] = fin;
-          if (STATS == 2) {
-            bs1 += fin;
-            bs2 = fmaf(fin, tnj, bs2);
-          }
-        }
-      }
-    };
-#pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-      const int co = co0 + nr * 16 + m16;
-      const int coc = min(co, p.Cout - 1);
-      const float bias = p.bias ? p.bias[coc] : 0.f;
-      const float dsc = (p.dm && p.dmsc) ? p.dmsc[n * p.dmC + coc] : 1.f, dsh = (p.dm && p.dmsh) ? p.dmsh[n * p.dmC + coc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
-          if (P == 1) {
-            emit(co, gy, gx, bias, dsc, dsh, acc[r][mt][0][nr]);
-          } else {
-#pragma unroll
-            for (int py = 0; py < 2; ++py) {
-              const f32x4 a = acc[r][mt][P == 4 ? py * 2 : 0][nr], b = acc[r][mt][P == 4 ? py * 2 + 1 : 0][nr];
-              emit(co, gy * 2 + py, gx * 2, bias, dsc, dsh, (f32x4){a[0], b[0], a[1], b[1]});
-              emit(co, gy * 2 + py, gx * 2 + 4, bias, dsc, dsh, (f32x4){a[2], b[2], a[3], b[3]});
-            }
-          }
-#pragma unroll
-          for (int ph = 0; ph < P; ++ph) acc[r][mt][ph][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      if (STATS == 2) {
-        bs1 += __shfl_xor(bs1, 16, 64);
-        bs2 += __shfl_xor(bs2, 16, 64);
-        bs1 += __shfl_xor(bs1, 32, 64);
-        bs2 += __shfl_xor(bs2, 32, 64);
-        if (kq == 0 && co < p.Cout) {
-          const int slot = (by * p.tiles_x + tx0 / TX) * 4 + wave;
-          float* o = p.bsum_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 2;
-          o[0] = bs1;
-          o[1] = bs2;
-        }
-        bs1 = 0.f;
-        bs2 = 0.f;
-      }
-    }
-  };
-
-  // units of the pipeline: (tile of the run, input-channel chunk); a single-chunk layer keeps its weights in LDS for the whole run
-  const int nch = chunk_end - chunk_begin;
-  const int units = nch > 0 ? nch * (tile_end - tile_begin) : 0;
-  const bool reload_w = !RUN || nch > 1;
-  stamp(2);
-  if (units > 0) {
-    set_tile(tile_begin);
-    if (!(p.ablate & 1)) load_chunk(chunk_begin, true);
-    stamp(3);
-    store_chunk(true);
-  }
-  __syncthreads();
-  stamp(4);
-  int chunk = chunk_begin, tile = tile_begin;
-  for (int u = 0; u < units; ++u) {
-    const bool more = u + 1 < units;
-    int chunk_n = chunk + 1, tile_n = tile;
-    if (chunk_n == chunk_end) {
-      chunk_n = chunk_begin;
-      tile_n = tile + 1;
-    }
-    if (more) {
-      if (RUN && tile_n != tile) set_tile(tile_n);
-      if (!(p.ablate & 1)) load_chunk(chunk_n, reload_w);
-    }
-    // ---- MFMA accumulate ----
-    // One group = the four taps (K = 4) of one (channel, ky) or (channel, phase): NR weight fragments + RW x MT patch fragments,
-    // then RW x MT x NR MFMAs.  The fragments of the NEXT group are read (two register sets, ping-pong) before the MFMAs of the
-    // current one are issued, so LDS latency hides behind 32-cycle MFMAs even with one wave on the SIMD; the scheduling barriers
-    // keep the compiler from sinking the reads back to their first use (it did: read -> wait -> 2 MFMA, 70 % issue rate).
-    const int cvalid = (p.ablate & 2) ? 0 : min(CK, p.Cin - chunk * CK);   // channels beyond Cin are zero: skip them
-    {
-      constexpr int NA = RW * MT;
-      auto rd = [&](int c, int g, float (&av)[NA], float (&bv)[NR]) {
-        const float* pp = lds_patch + c * PR * PCP;
-        const float* ww = lds_w + c * 16 * COP + kq * COP + m16;
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr) bv[nr] = ww[g * 4 * COP + nr * 16];
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            if (MODE == 1 && S == 2) av[r * MT + mt] = pp[aoff[P == 4 ? g : 0] + r * PCP + mt * 16];
-            else if (MODE == 0) av[r * MT + mt] = pp[aoff[0] + (r * S + g) * PCP + mt * 16 * S];
-            else av[r * MT + mt] = pp[aoff[0] + (r - g) * PCP + mt * 16];
-          }
-      };
-      auto mm = [&](int g, const float (&av)[NA], const float (&bv)[NR]) {
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
-              acc[r][mt][P == 4 ? g : 0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r * MT + mt], bv[nr], acc[r][mt][P == 4 ? g : 0][nr], 0, 0, 0);
-      };
-      float ax[NA], bx[NR], ay[NA], by_[NR];
-      if (cvalid > 0) rd(0, 0, ax, bx);
-      for (int c = 0; c < cvalid; ++c) {
-        rd(c, 1, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(0, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(c, 2, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(1, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(c, 3, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(2, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < cvalid) rd(c + 1, 0, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(3, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (u == 0) stamp(5);
-    if (RUN && direct && tile_n != tile) {   // tile complete: its accumulators go out while the next tile's loads are in flight
-      if (p.ablate & 4) {
-        if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
-      } else {
-        epilogue_direct(tile * TX);
-      }
-    }
-    __syncthreads();
-    if (more) {
-      store_chunk(reload_w);
-      __syncthreads();
-    }
-    chunk = chunk_n;
-    tile = tile_n;
-  }
-  stamp(6);
-  if (RUN) return;   // (the host launches RUN instances only with the direct epilogue)
-  const int tx0 = tile_begin * TX;
-  if (direct) {
-    if (!(p.ablate & 4)) epilogue_direct(tx0);
-    else if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
-    stamp(7);
-    return;
-  }
-  // the LDS epilogue below serves one tile per workgroup (k-split partials, VTS_DIRECT_EPI=0)
-
-  // ---- epilogue: accumulators -> LDS (channel planes) -> coalesced, vectorised global stores.
-  // C/D layout of a 16x16 tile: col (cout) = lane&15, row (pixel) = (lane>>4)*4 + reg.
-  // One pass handles 16 output channels and, for transposed s2, one output row parity (both column
-  // parities interleaved, so rows are contiguous in x).
-  if (p.ablate & 4) {
-    if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
-    return;
-  }
-  constexpr int PY = (P == 4) ? 2 : 1;
-  const int oy0 = (P == 4) ? ty0 * 2 : ty0, ox0 = (P == 4) ? tx0 * 2 : tx0;
-  float* so = lds;
-  const bool vec_ok = ((p.OW & 3) == 0) && ((p.ons & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
-                      (!p.part || (reinterpret_cast<uintptr_t>(p.part) & 15) == 0) &&
-                      (!p.dm || (((p.dmns & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dm) & 15) == 0)));
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr) {
-#pragma unroll
-    for (int py = 0; py < PY; ++py) {
-      // write this wave's tiles
-#pragma unroll
-      for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int px = 0; px < (P == 4 ? 2 : 1); ++px) {
-            const int ph = py * 2 + px;
-            const int row = wave * RW + r;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int xl = mt * 16 + kq * 4 + j;
-              const int col = (P == 4) ? xl * 2 + px : xl;
-              so[m16 * EPL + row * EC + col] = acc[r][mt][P == 4 ? ph : 0][nr][j];
-            }
-          }
-      __syncthreads();
-      // read back channel-plane rows and store 4 consecutive pixels per thread
-      for (int idx = tid; idx < 16 * TY * (EC / 4); idx += 256) {
-        const int c16 = idx / (TY * (EC / 4));
-        const int rem = idx - c16 * (TY * (EC / 4));
-        const int row = rem / (EC / 4), x4 = (rem - row * (EC / 4)) * 4;
-        const int co = co0 + nr * 16 + c16;
-        const int y = (P == 4) ? oy0 + row * 2 + py : oy0 + row;
-        const int x = ox0 + x4;
-        if (co >= p.Cout || y >= p.OH || x >= p.OW) continue;
-        const float* sp = so + c16 * EPL + row * EC + x4;
-        float v[4] = {sp[0], sp[1], sp[2], sp[3]};
-        const int64_t o = (int64_t)y * p.OW + x;
-        const int nvalid = min(4, p.OW - x);
-        if (p.part) {  // k-split: raw accumulators, the epilogue runs in conv_split_epilogue_kernel
-          float* pb = p.part + (((int64_t)ks * p.N + n) * p.Cout + co) * oplane + o;
-          if (vec_ok && nvalid == 4) {
-            *reinterpret_cast<f32x4*>(pb) = (f32x4){v[0], v[1], v[2], v[3]};
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nvalid) pb[j] = v[j];
-          }
-          continue;
-        }
-        const float bias = p.bias ? p.bias[co] : 0.f;
-        float* ob = p.out + n * p.ons + co * oplane + o;
-        float dv[4] = {1.f, 1.f, 1.f, 1.f}, prev[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool vec = vec_ok && nvalid == 4;
-        if (p.dm) {
-          const float dsc = p.dmsc ? p.dmsc[n * p.dmC + co] : 1.f, dsh = p.dmsh ? p.dmsh[n * p.dmC + co] : 0.f;
-          const float* db = p.dm + n * p.dmns + co * oplane + o;
-          if (vec) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(db);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dv[j] = vts_act_grad(t[j] * dsc + dsh, p.dm_act);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nvalid) dv[j] = vts_act_grad(db[j] * dsc + dsh, p.dm_act);
-          }
-        }
-        if (p.accumulate) {
-          if (vec) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(ob);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) prev[j] = t[j];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < nvalid) prev[j] = ob[j];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float t = v[j] + bias;
-          if (p.act_out == VTS_ACT_TANH) t = tanhf(t);
-          v[j] = t * dv[j] + prev[j];
-        }
-        if (vec) {
-          *reinterpret_cast<f32x4*>(ob) = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < nvalid) ob[j] = v[j];
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
 
 // sums the k-split partials in slice order and applies the epilogue of the main kernel
 __global__ __launch_bounds__(256) void conv_split_epilogue_kernel(const ConvK p, int KS) {
@@ -758,82 +87,6 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_in_kernel(const ConvK
     if (q.mean) q.mean[g] = mean;
     if (q.rstd) q.rstd[g] = rstd;
   }
-}
-
-thread_local int t_stat_spl = 0;   // statistics slots per (n, channel) of the last launch (conv4x4_impl -> vts_norm_finalize_partials)
-
-template <int MODE, int S, int NR, int RW, int MT, int CK>
-int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
-  constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
-  ConvK k = k0;
-  const int GH = P == 4 ? (k.OH + 1) / 2 : k.OH, GW = P == 4 ? (k.OW + 1) / 2 : k.OW;
-  const int tiles_x = cdiv(GW, 16 * MT), tiles_y = cdiv(GH, 4 * RW);
-  k.tiles_x = tiles_x;
-  k.stat_spl = tiles_x * tiles_y * 4;
-  t_stat_spl = k.stat_spl;
-  // Tile runs: only where the per-tile chunk pipeline is too short to overlap anything (<= run_max_chunks chunks per tile) and
-  // the grid stays several workgroups per CU deep after the cut.  VTS_TILE_RUN=<n> forces a run length (1 = one tile per workgroup).
-  static const int run_force = getenv("VTS_TILE_RUN") ? atoi(getenv("VTS_TILE_RUN")) : 0;
-  static const int run_wgs = getenv("VTS_TILE_RUN_WGS") ? atoi(getenv("VTS_TILE_RUN_WGS")) : 2048;
-  static const int run_max_chunks = getenv("VTS_TILE_RUN_CHUNKS") ? atoi(getenv("VTS_TILE_RUN_CHUNKS")) : 4;
-  int run = 1;
-  if (NR <= 2 && !k.part && k.direct_epi && KS == 1) {
-    const int64_t total = (int64_t)tiles_x * tiles_y * N * CG;
-    const int nchunks = (k.Cin + CK - 1) / CK;
-    if (run_force > 0) run = run_force;
-    else if (nchunks <= run_max_chunks) run = (int)(total / run_wgs);
-    if (run > tiles_x) run = tiles_x;
-    if (run < 1) run = 1;
-  }
-  dim3 grid(cdiv(tiles_x, run), tiles_y, N * CG * KS);
-  // VTS_CONV_TRACE=<file>: phase time stamps of every workgroup of the launches whose kernel matches VTS_CONV_TRACE_KERNEL
-  // ("MODE,S,NR,RW,MT"), appended as text rows (tools/conv_trace.py draws the occupancy / phase overlap from them)
-  static const char* trace_path = getenv("VTS_CONV_TRACE");
-  unsigned long long* trace_dev = nullptr;
-  const int64_t trace_wgs = (int64_t)grid.x * grid.y * grid.z;
-  if (trace_path) {
-    char tag[64];
-    snprintf(tag, sizeof tag, "%d,%d,%d,%d,%d", MODE, S, NR, RW, MT);
-    const char* want = getenv("VTS_CONV_TRACE_KERNEL");
-    if (!want || strcmp(want, tag) == 0) {
-      if (hipMalloc(&trace_dev, trace_wgs * 64) != hipSuccess) trace_dev = nullptr;
-      if (trace_dev) (void)hipMemsetAsync(trace_dev, 0, trace_wgs * 64, st);
-    }
-  }
-  k.trace = trace_dev;
-  // (the statistics epilogue is its own instantiation: inside the shared one it raised the register count of EVERY launch of the
-  //  template -- e.g. 110 -> 199 VGPRs and occupancy 2 -> 1 on the 40 -> 10 transposed layer -- whether statistics were asked for or not)
-  if (k.stat_part) {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 1>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 1>), grid, dim3(256), 0, st, k);
-  } else if (k.bsum_part) {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 2>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 2>), grid, dim3(256), 0, st, k);
-  } else {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 0>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 0>), grid, dim3(256), 0, st, k);
-  }
-  vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d, %s, %s>%s", MODE, S, NR, RW, MT, CK, (run > 1 && NR <= 2) ? "true" : "false",   // as rocprofv3 names the instance
-                 k.stat_part ? "1" : (k.bsum_part ? "2" : "0"), KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
-  VTS_CHECK_LAUNCH("vts_conv4x4");
-  if (trace_dev) {
-    (void)hipStreamSynchronize(st);
-    unsigned long long* h = (unsigned long long*)malloc(trace_wgs * 64);
-    (void)hipMemcpy(h, trace_dev, trace_wgs * 64, hipMemcpyDeviceToHost);
-    FILE* f = fopen(trace_path, "a");
-    if (f) {
-      fprintf(f, "# conv4x4_kernel<%d,%d,%d,%d,%d> run %d grid %u %u %u Cin %d Cout %d OH %d OW %d\n", MODE, S, NR, RW, MT, run, grid.x, grid.y, grid.z, k.Cin, k.Cout, k.OH, k.OW);
-      for (int64_t w = 0; w < trace_wgs; ++w) {
-        fprintf(f, "%lld %llx", (long long)w, h[w * 8]);
-        for (int i = 1; i < 8; ++i) fprintf(f, " %llu", h[w * 8 + i]);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-    free(h);
-    (void)hipFree(trace_dev);
-  }
-  return VTS_OK;
 }
 
 // tile shape (RW, MT) of the full-width variants, as instantiated by VTS_DISPATCH below
@@ -1019,8 +272,8 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       const bool cg_bsums = want_bsums && KS == 1;
       if (cg_bsums) k.bsum_part = sw.p;
       int rc;
-      if (!d->transposed) rc = d->stride == 2 ? launch<0, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<0, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
-      else rc = d->stride == 2 ? launch<1, 2, 1, 1, 2, 4>(k, N, st, nr, KS) : launch<1, 1, 1, 1, 2, 4>(k, N, st, nr, KS);
+      if (!d->transposed) rc = d->stride == 2 ? vts_conv_split_m0s2(k, N, st, nr, KS) : vts_conv_split_m0s1(k, N, st, nr, KS);
+      else rc = d->stride == 2 ? vts_conv_split_m1s2(k, N, st, nr, KS) : vts_conv_split_m1s1(k, N, st, nr, KS);
       if (rc == VTS_OK && (cg_stats || cg_bsums)) *fused = 2 + t_stat_spl;    // partials written: the caller merges them
       if (rc != VTS_OK || KS == 1) return rc;
       static const int fuse_in = getenv("VTS_FUSE_SPLIT_IN") ? atoi(getenv("VTS_FUSE_SPLIT_IN")) : 1;
@@ -1047,27 +300,6 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
 }
 
 static int dispatch_full(const vts_conv_desc* d, const ConvK& k, int nr, int N, hipStream_t st) {
-#define VTS_DISPATCH(MODE, S, RW1, MT1, RW2, MT2, RW3, MT3, RW4, MT4, RW5, MT5) \
-  switch (nr) {                                                                 \
-    case 1: return launch<MODE, S, 1, RW1, MT1, 4>(k, N, st);                   \
-    case 2: return launch<MODE, S, 2, RW2, MT2, 4>(k, N, st);                   \
-    case 3: return launch<MODE, S, 3, RW3, MT3, 4>(k, N, st);                   \
-    case 4: return launch<MODE, S, 4, RW4, MT4, 4>(k, N, st);                   \
-    default: return launch<MODE, S, 5, RW5, MT5, 4>(k, N, st);                  \
-  }
-  if (!d->transposed) {
-    if (d->stride == 2 && nr == 1) {   // tile of the thin forward layers: 8x32 outputs (measured best of 8x64 / 4x64 / 4x32 / 8x32); VTS_TILE01=rw*10+mt
-      static const int tile01 = getenv("VTS_TILE01") ? atoi(getenv("VTS_TILE01")) : 22;
-      if (tile01 == 14) return launch<0, 2, 1, 1, 4, 4>(k, N, st);
-      if (tile01 == 12) return launch<0, 2, 1, 1, 2, 4>(k, N, st);
-      if (tile01 == 22) return launch<0, 2, 1, 2, 2, 4>(k, N, st);
-    }
-    if (d->stride == 2) { VTS_DISPATCH(0, 2, 2, 4, 1, 4, 1, 4, 1, 2, 1, 2) }
-    VTS_DISPATCH(0, 1, 2, 4, 1, 4, 1, 4, 1, 2, 1, 2)
-  } else {
-    if (d->stride == 2) { VTS_DISPATCH(1, 2, 1, 4, 1, 2, 1, 2, 1, 1, 1, 1) }
-    VTS_DISPATCH(1, 1, 2, 4, 1, 4, 1, 4, 1, 2, 1, 2)
-  }
-#undef VTS_DISPATCH
-  return VTS_ERR_UNSUPPORTED;
+  if (!d->transposed) return d->stride == 2 ? vts_conv_full_m0s2(k, nr, N, st) : vts_conv_full_m0s1(k, nr, N, st);
+  return d->stride == 2 ? vts_conv_full_m1s2(k, nr, N, st) : vts_conv_full_m1s1(k, nr, N, st);
 }
