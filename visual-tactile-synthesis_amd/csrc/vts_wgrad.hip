@@ -10,6 +10,7 @@
 // combined through LDS in a fixed order; the PW partials are summed by a second kernel in
 // a fixed order, so the result is deterministic (no float atomics).
 // Both operands are (dual-source, normalise-on-load) like in vts_conv.hip.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "vts_internal.h"
@@ -819,20 +820,75 @@ Plan make_plan(const vts_wgrad_desc* d) {
     pl.txl = 28;
     pl.tiles_x = cdiv(d->LW, 28);
     pl.ntiles = d->N * pl.tiles_y * pl.tiles_x;
-    const int groups = pl.cl_groups * pl.ch_groups;
-    static const int ns_wgs = getenv("VTS_WGRAD_NS_WGS") ? atoi(getenv("VTS_WGRAD_NS_WGS")) : 512;
-    int pw = ns_wgs / groups;
     const int64_t nel = (int64_t)CL * CH * 16;
-    // every pixel worker writes (and the reduction re-reads) a full copy of dw: keep that traffic below ~2x the operand bytes
-    // (inner U-Net layers: 80..592 x 80 channels on <= 32x32 maps would otherwise move 50 MB of partials for 8 MB of operands)
-    const int64_t operand = (int64_t)d->N * ((int64_t)CL * d->LH * d->LW + (int64_t)CH * d->HH * d->HW);
-    static const int64_t cap_floor = (int64_t)(getenv("VTS_WGRAD_CAP_MB") ? atoi(getenv("VTS_WGRAD_CAP_MB")) : 1) << 18;   // floats
-    int64_t cap = (2 * operand > cap_floor ? 2 * operand : cap_floor) / nel;
-    if (cap > (16 << 20) / nel) cap = (16 << 20) / nel;   // and never more than 64 MB
-    if (pw > cap) pw = (int)cap;
-    if (pw < 1) pw = 1;
-    if (pw > pl.ntiles) pw = pl.ntiles;
-    pl.pw = pw;
+    static const int old_plan = getenv("VTS_WGRAD_OLDPLAN") ? atoi(getenv("VTS_WGRAD_OLDPLAN")) : 0;
+    if (old_plan) {   // round-2 rule (A/B switch): 512 workgroups, partial copies capped at 2x the operand bytes
+      const int groups = pl.cl_groups * pl.ch_groups;
+      int pw = 512 / groups;
+      const int64_t operand = (int64_t)d->N * ((int64_t)CL * d->LH * d->LW + (int64_t)CH * d->HH * d->HW);
+      int64_t cap = (2 * operand > (1 << 18) ? 2 * operand : (1 << 18)) / nel;
+      if (cap > (16 << 20) / nel) cap = (16 << 20) / nel;
+      if (pw > cap) pw = (int)cap;
+      if (pw < 1) pw = 1;
+      if (pw > pl.ntiles) pw = pl.ntiles;
+      pl.pw = pw;
+    } else {
+      // Round 3 (tools/probes/wgrad_sweep.py, 21 shapes x ~130 plans on the MI355X):
+      //  * a workgroup wants ~5 pixel tiles (fewer: its prologue, partial copy and the copy's reduction dominate);
+      //  * waves with >= 12 accumulator tiles are MFMA-bound: ONE workgroup per CU (256), more only queue on the MFMA pipe and skew
+      //    the finish times; lighter waves are bound by the load -> LDS -> MFMA latency chain and want 3-6 workgroups per CU;
+      //  * when 5 tiles per workgroup leave CUs empty (inner layers: 32-400 tiles), split the CHANNELS over more workgroups rather
+      //    than the pixels: a channel group re-reads an operand from L2, a pixel group writes (and the reduction re-reads) a whole
+      //    copy of dw (0.2-0.8 MB for the 80-160 channel layers).
+      //  * workgroup counts just above a multiple of 256 leave a tail (520 workgroups: 44 us, 512: 37 us), and channel groups
+      //    that pad the channel count (40 channels as 3 x 16) run MFMAs on zeros.
+      int copies = pl.ntiles / 5 > 1 ? pl.ntiles / 5 : 1;
+      auto next_split = [](int C, int unit, int tiles_now, int& groups, int& tiles) {   // fewer tiles per wave without > 12 % padding
+        for (int t = tiles_now - 1; t >= 2; --t) {
+          const int g = cdiv(C, unit * t), tt = cdiv(C, unit * g);
+          if (tt < tiles_now && (int64_t)g * tt * unit * 100 <= (int64_t)C * 112) {
+            groups = g;
+            tiles = tt;
+            return true;
+          }
+        }
+        return false;
+      };
+      while (copies * pl.cl_groups * pl.ch_groups < 224) {
+        if (next_split(CH, 4, pl.cht, pl.ch_groups, pl.cht)) continue;
+        if (next_split(CL, 16, pl.clt, pl.cl_groups, pl.clt)) continue;
+        break;
+      }
+      const int groups = pl.cl_groups * pl.ch_groups, w = pl.clt * pl.cht;
+      // pixel split against copy cost: a tile costs ~1 us of latency chain + 13.3 ns per MFMA of one wave, a copy 2.6 ns per element
+      // (written here, re-read by the reduction); the optimum of tiles/copies * t_tile + copies * t_copy, at least 2 tiles per workgroup
+      const double t_tile = 1.0 + 0.0133 * w * (d->stride == 2 ? 14 : 28), t_copy = 2.6e-6 * (double)nel;
+      int best = (int)__builtin_sqrt((double)pl.ntiles * t_tile / t_copy);
+      if (best > pl.ntiles / 2) best = pl.ntiles / 2;
+      if (best > copies) copies = best;
+      const int wgs_max = w >= 12 ? 256 : (w >= 5 ? 768 : 1536);
+      if (copies * groups > wgs_max) copies = wgs_max / groups;
+      if (copies * groups > 256) {   // whole waves of 256 workgroups
+        const int waves = (copies * groups + 128) / 256;
+        copies = waves * 256 / groups;
+      }
+      if ((int64_t)copies * nel > (16 << 20)) copies = (int)((16 << 20) / nel);   // never more than 64 MB of partial copies
+      if (copies < 1) copies = 1;
+      if (copies > pl.ntiles) copies = pl.ntiles;
+      pl.pw = copies;
+    }
+    static const bool tune = getenv("VTS_WGRAD_TUNE") != nullptr;   // tools/probes/wgrad_sweep.py: "cl_groups,ch_groups,copies" re-read per call
+    if (tune) {
+      const char* e = getenv("VTS_WGRAD_PLAN");
+      int a = 0, b = 0, c = 0;
+      if (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && c >= 1) {
+        pl.cl_groups = a;
+        pl.clt = cdiv(CL, 16 * a);
+        pl.ch_groups = b;
+        pl.cht = cdiv(CH, 4 * b);
+        pl.pw = c > pl.ntiles ? pl.ntiles : c;
+      }
+    }
     return pl;
   }
   pl.clt = CL <= 16 ? 1 : CL <= 32 ? 2 : CL <= 48 ? 3 : 5;

@@ -794,18 +794,22 @@ FLAT_D = os.environ.get("VTS_FLAT_D", "1") != "0"
 FLAT_MIN_C = int(os.environ.get("VTS_FLAT_MIN_C", "64"))   # small maps: channels from which the flattened GEMM-class kernel takes over
 
 
+WIDE_MIN_CI = int(os.environ.get("VTS_WIDE_MIN_CI", "64"))   # round 3 A/B: 32 / 64 (D1 layer 3 on the GEMM-class kernels) costs + 1.0 - 1.4 ms per step
+WIDE_MIN_CO = int(os.environ.get("VTS_WIDE_MIN_CO", "128"))
+
+
 def _flat4(conv, j, h, w, oh, ow, st):
     """whether this PatchGAN layer takes the GEMM-class route with 16-tap packed weights (vts_conv4x4_wide: flattened-batch kernel
     for maps of <= 128 pixels, tiled kernel above): wide layers only; Cout = 1 heads only on small maps"""
     co, ci = conv.weight.shape[0], conv.weight.shape[1]
-    if not FLAT_D or j == 0 or ci < FLAT_MIN_C:
+    if not FLAT_D or j == 0 or ci < min(FLAT_MIN_C, WIDE_MIN_CI):
         return False
     small = ops.conv4x4_flat_ok(oh, ow, st * (oh - 1) + 4, st * (ow - 1) + 4)
     if small:
         return co >= FLAT_MIN_C or ci >= 256
-    if ci < 64:                              # full-size maps of the reference's own ndf = 8 discriminators stay on the 4x4 kernels
+    if ci < WIDE_MIN_CI:                     # full-size maps of the reference's own ndf = 8 discriminators stay on the 4x4 kernels
         return False
-    return co >= 128 and co % 4 == 0 and ci % 4 == 0
+    return co >= WIDE_MIN_CO and co % 4 == 0 and ci % 4 == 0
 
 
 def _packed4(conv, mode, cache):
@@ -1022,6 +1026,9 @@ def _sg2d_passes(D, passes, criterion):
             dst.add_(src) if acc else dst.copy_(src)
 
 
+KO_LANES = tuple(int(k) for k in os.environ.get("VTS_KO_LANES", "").split(",") if k)
+
+
 def _msd_multi(jobs, criterion):
     lanes = []
     for D, passes in jobs:
@@ -1040,6 +1047,11 @@ def _msd_multi(jobs, criterion):
             if prep and s in prep:
                 prep[s]()       # per-scale preparation inside the lane (pooling of this scale's input level)
             a0, a1 = p["_pyr"][s]
+            if i in KO_LANES:   # timing experiment only (VTS_KO_LANES; results are wrong): what a lane costs on the step's critical path
+                p["preds"][s] = torch.zeros(1, 1, 1, 1, device=a0.data.device)
+                if p.get("input_grad") is not None and a1 is not None:
+                    p["_din"][s] = torch.zeros_like(a1.data)
+                continue
             ig = p.get("input_grad")
             into = (ig[0], ig[1]) if (ig is not None and s == 0 and a1 is not None and ig[0].shape == a1.data.shape and ig[0].is_contiguous()) else None
             groups = p.get("groups")
