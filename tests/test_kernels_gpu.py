@@ -529,7 +529,7 @@ def test_channel_sum_and_act_bwd(fuse_finalize):
         assert rel(dy, ref + 1) < 1e-6
 
 
-@pytest.mark.parametrize("hw", [(64, 64), (33, 47), (2, 2), (513, 17)])
+@pytest.mark.parametrize("hw", [(64, 64), (33, 47), (2, 2), (513, 17), (66, 130), (33, 46), (5, 4), (131, 258)])
 def test_avgpool(hw):
     from vts import ops
 

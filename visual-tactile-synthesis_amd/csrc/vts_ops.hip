@@ -32,6 +32,43 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
   y[(((int64_t)n * C + c) * OH + oy) * OW + ox] = s / (float)cnt;
 }
 
+// Even-width planes with 8-byte aligned rows (every level of the discriminators' input pyramids): a lane owns output column ox
+// and FOUR output rows -- nine input rows, each one coalesced 8-byte load of columns (2 ox, 2 ox + 1); column 2 ox - 1 comes from the
+// lane on the left (one extra 4-byte load in lane 0 of the wave).  Every input element is fetched ~1.1 times in full lines; the
+// one-output-per-thread kernel above reads each line three times at half efficiency (57 us for 134 MB; round 3).
+__global__ __launch_bounds__(256) void avgpool_rows4_kernel(const float* __restrict__ x, int64_t xns, int C, int H, int W, int OH, int OW,
+                                                            float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ox = blockIdx.x * 64 + lane, oy0 = (blockIdx.y * 4 + wave) * 4;
+  const int c = blockIdx.z % C, n = blockIdx.z / C;
+  if (oy0 >= OH) return;                                  // wave-uniform
+  const float* p = x + n * xns + (int64_t)c * H * W;
+  const int ixc = min(2 * ox, W - 2);                     // lanes beyond the row re-read its last pair (their outputs are not stored)
+  const bool has_left = 2 * ox - 1 >= 0;
+  float rs[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int iy = 2 * oy0 - 1 + r;
+    const bool rok = iy >= 0 && iy < H;                   // wave-uniform
+    const int iyc = min(max(iy, 0), H - 1);
+    const float2 v = *reinterpret_cast<const float2*>(p + (int64_t)iyc * W + ixc);
+    float l = __shfl_up(v.y, 1);
+    if (lane == 0) l = has_left ? p[(int64_t)iyc * W + ixc - 1] : 0.f;
+    rs[r] = rok ? (has_left ? l : 0.f) + v.x + v.y : 0.f;
+  }
+  if (ox >= OW) return;
+  const int cx = (has_left ? 1 : 0) + 1 + (2 * ox + 1 < W ? 1 : 0);
+  float* q = y + (((int64_t)n * C + c) * OH) * OW + ox;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = oy0 + j;
+    if (oy < OH) {
+      const int cy = (2 * oy - 1 >= 0 ? 1 : 0) + 1 + (2 * oy + 1 < H ? 1 : 0);
+      q[(int64_t)oy * OW] = (rs[2 * j] + rs[2 * j + 1] + rs[2 * j + 2]) / (float)(cx * cy);
+    }
+  }
+}
+
 __device__ __forceinline__ int pool_cnt(int o, int L) {  // valid taps of window o along one axis
   int c = 0;
   for (int d = -1; d <= 1; ++d) {
@@ -523,8 +560,13 @@ inline unsigned blocks_for(int64_t n, int cap = 2048) {
 extern "C" int vts_avgpool3s2(const float* x, int64_t xns, int N, int C, int H, int W, float* y, void* stream) {
   VTS_CHECK_ARG(x && y && N * C <= 65535, "vts_avgpool3s2: bad args");
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-  hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(OW, 64), cdiv(OH, 4), N * C), dim3(256), 0, (hipStream_t)stream, x, xns, C, H, W, OH,
-                     OW, y);
+  static const bool rows4 = !(getenv("VTS_AVGPOOL_ROWS4") && atoi(getenv("VTS_AVGPOOL_ROWS4")) == 0);
+  if (rows4 && W % 2 == 0 && W >= 4 && (reinterpret_cast<uintptr_t>(x) & 7) == 0 && xns % 2 == 0 && ((int64_t)H * W) % 2 == 0)
+    hipLaunchKernelGGL(avgpool_rows4_kernel, dim3(cdiv(OW, 64), cdiv(OH, 16), N * C), dim3(256), 0, (hipStream_t)stream, x, xns, C, H, W,
+                       OH, OW, y);
+  else
+    hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(OW, 64), cdiv(OH, 4), N * C), dim3(256), 0, (hipStream_t)stream, x, xns, C, H, W, OH,
+                       OW, y);
   VTS_CHECK_LAUNCH("vts_avgpool3s2");
   return VTS_OK;
 }
