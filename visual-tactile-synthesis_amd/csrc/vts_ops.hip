@@ -84,17 +84,15 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
   const int c = blockIdx.z % C, n = blockIdx.z / C;
   if (x >= W || y >= H) return;
   const float* g = dy + ((int64_t)n * C + c) * OH * OW;
-  float s = 0.f;
-  // windows covering y: oy with |y - 2 oy| <= 1
-  const int oy_lo = y >> 1, oy_hi = (y + 1) >> 1, ox_lo = x >> 1, ox_hi = (x + 1) >> 1;
-  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-    if (oy >= OH) continue;
-    const int cy = pool_cnt(oy, H);
-    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-      if (ox >= OW) continue;
-      s += g[(int64_t)oy * OW + ox] / (float)(cy * pool_cnt(ox, W));
-    }
-  }
+  // windows covering y: oy with |y - 2 oy| <= 1 (one for even y, two for odd y); a window has 3 taps per axis minus the ones outside
+  // the map, so its weight is 1 / (cy * cx) with cy, cx in {1, 2, 3}
+  const int oy_lo = y >> 1, oy_hi = min((y + 1) >> 1, OH - 1), ox_lo = x >> 1, ox_hi = min((x + 1) >> 1, OW - 1);
+  auto rcnt = [](int o, int L) { return 1.f / (float)(3 - (o == 0) - (2 * o + 1 >= L)); };
+  const float wy0 = rcnt(oy_lo, H), wy1 = oy_hi > oy_lo ? rcnt(oy_hi, H) : 0.f;
+  const float wx0 = rcnt(ox_lo, W), wx1 = ox_hi > ox_lo ? rcnt(ox_hi, W) : 0.f;
+  const float* r0 = g + (int64_t)oy_lo * OW;
+  const float* r1 = g + (int64_t)oy_hi * OW;
+  const float s = wy0 * (r0[ox_lo] * wx0 + r0[ox_hi] * wx1) + wy1 * (r1[ox_lo] * wx0 + r1[ox_hi] * wx1);
   float* o = dx + n * dxns + ((int64_t)c * H + y) * W + x;
   *o = accumulate ? *o + s : s;
 }
@@ -136,15 +134,32 @@ __global__ __launch_bounds__(256) void ganloss_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------ L1
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float coeff,
-                                                 long long* __restrict__ loss, float* __restrict__ grad, int accumulate) {
+                                                 long long* __restrict__ loss, float* __restrict__ grad, int accumulate, int vec) {
   __shared__ float red[16];
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float d = a[i] - b[i];
-    acc += fabsf(d);
-    if (grad) {
-      const float g = coeff * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-      grad[i] = accumulate ? grad[i] + g : g;
+  if (vec) {   // n % 4 == 0 and 16-byte aligned operands: one 16-byte load per operand and lane (round 3: 3.6 -> 5+ TB/s)
+    const int64_t n4 = n >> 2;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    f32x4* g4 = reinterpret_cast<f32x4*>(grad);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const f32x4 d = a4[i] - b4[i];
+      f32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += fabsf(d[e]);
+        g[e] = coeff * (d[e] > 0.f ? 1.f : (d[e] < 0.f ? -1.f : 0.f));
+      }
+      if (grad) g4[i] = accumulate ? g4[i] + g : g;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const float d = a[i] - b[i];
+      acc += fabsf(d);
+      if (grad) {
+        const float g = coeff * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        grad[i] = accumulate ? grad[i] + g : g;
+      }
     }
   }
   acc = block_sum(acc, red);
@@ -593,7 +608,9 @@ extern "C" int vts_ganloss(const float* pred, int N, int M, int mode, int target
 extern "C" int vts_l1(const float* a, const float* b, int64_t n, float coeff, int64_t* loss_out, float* grad, int accumulate,
                       void* stream) {
   VTS_CHECK_ARG(a && b && n >= 1, "vts_l1: bad args");
-  hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, coeff, reinterpret_cast<long long*>(loss_out), grad, accumulate);
+  const int vec = (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(vec ? n / 4 : n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, n, coeff,
+                     reinterpret_cast<long long*>(loss_out), grad, accumulate, vec);
   VTS_CHECK_LAUNCH("vts_l1");
   return VTS_OK;
 }
