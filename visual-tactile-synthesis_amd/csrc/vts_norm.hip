@@ -507,6 +507,121 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fin_kernel(float* __restri
   }
 }
 
+// ---- apply pass on EPILOGUE sums (round 3).  The backward-data convolution leaves thousands of (S1, S2') pairs per group (one per
+// wave and tile); norm_bwd_apply_fin_kernel above makes every 2048-element workgroup re-sum all of them -- 128 workgroups per
+// 512 x 512 plane each reading 32 KB of pairs = more L2 traffic than the tensor itself, behind a chain of dependent loads (45 us for
+// a 126 MB pass).  Here a workgroup owns `chunk` elements (8 - 32 K: 4 - 16x fewer re-summations), sums the pairs with four
+// independent loads in flight per thread and no per-item division, and streams its elements with 16-byte accesses where the
+// planes allow it.  Fixed summation order -> deterministic, identical coefficients in every workgroup of a group.
+__device__ __forceinline__ void bwd_epilogue_sums(const float* __restrict__ part, const NormBwdK& k, int c, int n0, int n1, float* red, float& s1,
+                                                  float& s2) {
+  const int tid = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  if (n1 - n0 == 1) {
+    const float2* q = reinterpret_cast<const float2*>(part) + ((int64_t)n0 * k.C + c) * k.pspl;
+    int i = tid;
+    for (; i + 768 < k.pspl; i += 1024) {
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = q[i + 256 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a += v[u].x;
+        b += v[u].y;
+      }
+    }
+    for (; i < k.pspl; i += 256) {
+      a += q[i].x;
+      b += q[i].y;
+    }
+  } else {
+    const int64_t nstep = (int64_t)k.C * k.pspl;     // float2 records between consecutive samples of one slot
+    const float2* base = reinterpret_cast<const float2*>(part) + ((int64_t)n0 * k.C + c) * k.pspl;
+    for (int sl = tid; sl < k.pspl; sl += 256) {
+      const float2* q = base + sl;
+      int n = n0;
+      for (; n + 3 < n1; n += 4, q += 4 * nstep) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = q[u * nstep];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a += v[u].x;
+          b += v[u].y;
+        }
+      }
+      for (; n < n1; ++n, q += nstep) {
+        a += q->x;
+        b += q->y;
+      }
+    }
+  }
+  s1 = block_sum(a, red);
+  const float sp = block_sum(b, red);
+  const float ga = (k.mode == 1 && k.gamma) ? k.gamma[c] : 1.f, be = (k.mode == 1 && k.beta) ? k.beta[c] : 0.f;
+  s2 = (sp - be * s1) / ga;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_bwd_apply_sums_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t nstride,
+                                                                  const float* __restrict__ part, const NormBwdK k, int chunk) {
+  __shared__ float red[16];
+  const int c = blockIdx.y, n = blockIdx.z;
+  int n0 = n, n1 = n + 1;
+  if (k.mode == 1) {
+    int gi = 0;
+    while (gi + 1 < k.ngroups && n >= k.gstart[gi + 1]) ++gi;
+    n0 = k.gstart[gi];
+    n1 = k.gstart[gi + 1];
+  }
+  float s1, s2;
+  bwd_epilogue_sums(part, k, c, n0, n1, red, s1, s2);
+  const float m = (float)(n1 - n0) * (float)k.HW;
+  const float rs = k.rstd[n0 * k.C + c], mu = k.mean[n0 * k.C + c];
+  const float ga = (k.mode == 1 && k.gamma) ? k.gamma[c] : 1.f;
+  const float A = ga * rs, B = -ga * rs * rs * s2 / m, Cc = -ga * rs * s1 / m;
+  if (k.mode == 1 && blockIdx.x == 0 && n == 0 && (k.dgamma || k.dbeta)) {    // (uniform per workgroup)
+    float dg = 0.f, db = 0.f;
+    for (int gi = 0; gi < k.ngroups; ++gi) {
+      float t1, t2;
+      bwd_epilogue_sums(part, k, c, k.gstart[gi], k.gstart[gi + 1], red, t1, t2);
+      dg += t2;
+      db += t1;
+    }
+    if (threadIdx.x == 0) {
+      if (k.dgamma) k.dgamma[c] = (k.acc ? k.dgamma[c] : 0.f) + dg;
+      if (k.dbeta) k.dbeta[c] = (k.acc ? k.dbeta[c] : 0.f) + db;
+    }
+  }
+  const int64_t off = n * nstride + (int64_t)c * k.HW;
+  const int base = blockIdx.x * chunk, end = min(base + chunk, k.HW);
+  if (VEC) {
+    f32x4* d4 = reinterpret_cast<f32x4*>(dy + off);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + off);
+    const int b4 = base >> 2, e4 = end >> 2;
+    int i = b4 + threadIdx.x;
+    for (; i + 256 < e4; i += 512) {
+      const f32x4 g0 = d4[i], g1 = d4[i + 256], x0 = x4[i], x1 = x4[i + 256];
+      d4[i] = A * g0 + B * (x0 - mu) + Cc;
+      d4[i + 256] = A * g1 + B * (x1 - mu) + Cc;
+    }
+    for (; i < e4; i += 256) d4[i] = A * d4[i] + B * (x4[i] - mu) + Cc;
+  } else {
+    int i = base + threadIdx.x;
+    for (; i + 768 < end; i += 1024) {
+      float g[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = dy[off + i + 256 * u];
+        xv[u] = x[off + i + 256 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dy[off + i + 256 * u] = A * g[u] + B * (xv[u] - mu) + Cc;
+    }
+    for (; i < end; i += 256) dy[off + i] = A * dy[off + i] + B * (x[off + i] - mu) + Cc;
+  }
+}
+
 // ---- single-launch variants for small groups (<= FUSED_MAX_GROUP elements per normalisation group):
 // one workgroup owns a whole group (IN: one (n,c) plane; BN: channel c of every image), reads it twice
 // (the second pass hits L2) and finishes in place.  Most normalisation calls of the step are this small
@@ -948,6 +1063,19 @@ extern "C" int vts_norm_bwd_from_partials(const vts_norm_bwd_desc* d, const floa
   }
   k.pspl = slots;
   k.beta = beta;
+  static const int wide = getenv("VTS_NORM_BWD_SUMS") ? atoi(getenv("VTS_NORM_BWD_SUMS")) : 1;   // 0: the 2048-element apply kernel (A/B)
+  if (wide) {
+    // elements per workgroup: multiples of 2048, as many as leave >= ~768 workgroups, at most 32 K
+    int chunk = CHUNK;
+    while (chunk < 32768 && (int64_t)cdiv(d->HW, 2 * chunk) * d->C * d->N >= 768) chunk *= 2;
+    const bool vec = d->HW % 4 == 0 && d->nstride % 4 == 0 && ((reinterpret_cast<uintptr_t>(d->dy) | reinterpret_cast<uintptr_t>(d->x)) & 15) == 0;
+    const dim3 grid(cdiv(d->HW, chunk), d->C, d->N);
+    if (vec) hipLaunchKernelGGL(norm_bwd_apply_sums_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d->dy, d->x, d->nstride, part, k, chunk);
+    else hipLaunchKernelGGL(norm_bwd_apply_sums_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d->dy, d->x, d->nstride, part, k, chunk);
+    VTS_CHECK_LAUNCH("vts_norm_bwd_from_partials");
+    vts_set_kernel("norm_bwd_apply_sums_kernel");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(norm_bwd_apply_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, (hipStream_t)stream, d->dy, d->x, d->nstride, part, k);
   VTS_CHECK_LAUNCH("vts_norm_bwd_from_partials");
   vts_set_kernel("norm_bwd_apply_fin_kernel");
