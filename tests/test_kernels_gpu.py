@@ -799,3 +799,25 @@ def test_bicubic_antialias_resampler_and_adjoint(geom):
     assert rel(acc, 2 * xo.grad) < 2e-6
     if (ih, iw) == (oh, ow):
         assert torch.equal(got.cpu(), x)
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 257, 8), (4, 10, 200, 9), (2, 3, 97, 5), (4, 80, 32, 40)])
+def test_deferred_weight_gradient_reduction_equals_immediate(shape):
+    """vts_wgrad_reduce_batch (both its 256-element form and the 64-element form for > 256 copies of a small dw, with 16-byte and
+    ragged 4-byte rows) against the single-job reduction of the same partial copies, incl. a second accumulated contribution"""
+    from vts import ops
+
+    n, cl, lh, ch = shape
+    dev = _dev()
+    hh = (lh - 1) * 2 + 4 - 2
+    lo = detrand.uniform((n, cl, lh, lh), 5, "lo").to(dev)
+    hi = detrand.uniform((n, ch, hh, hh), 5, "hi").to(dev)
+    lo2 = detrand.uniform((n, cl, lh, lh), 5, "lo2").to(dev)
+    ref = torch.empty(cl, ch, 4, 4, device=dev)
+    ops.wgrad4x4(lo, hi, ref, stride=2, pad=1, defer=False)
+    ops.wgrad4x4(lo2, hi, ref, stride=2, pad=1, defer=False, accumulate=True)
+    got = torch.full((cl, ch, 4, 4), 7.0, device=dev)
+    with ops.deferred_wgrad():
+        ops.wgrad4x4(lo, hi, got, stride=2, pad=1)
+        ops.wgrad4x4(lo2, hi, got, stride=2, pad=1, accumulate=True)
+    assert rel(got, ref) < 2e-6

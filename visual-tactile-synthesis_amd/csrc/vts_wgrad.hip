@@ -701,6 +701,7 @@ constexpr int RB_JOBS = 40;
 struct ReduceTable {
   int njobs;
   int blk_start[RB_JOBS + 1];
+  unsigned char narrow[RB_JOBS];   // 1: 64 elements per workgroup, the lanes of a wave also split the copies (many copies of a small dw)
   vts_reduce_job job[RB_JOBS];
 };
 
@@ -721,6 +722,60 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceTa
   }
   const vts_reduce_job& j = t.job[lo];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (t.narrow[lo]) {
+    // Thin layers have 500 .. 1500 copies of a few thousand elements: with 256 elements per workgroup six workgroups would each walk
+    // ~100 copies per wave (a chain of a dozen dependent load rounds).  Here a workgroup owns 64 elements, 16 lanes x 16 bytes, and
+    // the four 16-lane groups of each of its 16 waves take every 64th copy: 4x the workgroups, a quarter of the chain.  Combination
+    // order is fixed: accumulators pairwise, lane groups (0+1)+(2+3), then waves 0..15.
+    const int el = lane & 15, cg = lane >> 4;
+    const int64_t nb = (int64_t)(blockIdx.x - t.blk_start[lo]) * 64;
+    f32x4 sn = {0.f, 0.f, 0.f, 0.f};
+    for (int sg = 0; sg < j.nseg; ++sg) {
+      const float* part = j.part[sg];
+      const int pw = j.pw[sg];
+      const bool vec = nb + 64 <= j.nel && (j.nel & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+      f32x4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k = w * 4 + cg; k < pw; k += 512) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kk = k + 64 * u;
+          if (kk < pw) {
+            const float* row = part + (int64_t)kk * j.nel + nb;
+            f32x4 v;
+            if (vec) {
+              v = *reinterpret_cast<const f32x4*>(row + el * 4);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (nb + el * 4 + e < j.nel) ? row[el * 4 + e] : 0.f;
+            }
+            a[u] += v;
+          }
+        }
+      }
+      sn += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p1 = sn[e] + __shfl_xor(sn[e], 16);       // groups (0 + 1) and (2 + 3): the same value in both lanes of a pair
+      o[e] = p1 + __shfl_xor(p1, 32);                       // (0 + 1) + (2 + 3) == (2 + 3) + (0 + 1): fp addition commutes
+    }
+    if (cg == 0) red[w][el] = o;
+    __syncthreads();
+    if (w == 0 && lane < 16) {
+      f32x4 v = red[0][lane];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) v += red[k][lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = nb + lane * 4 + e;
+        if (i < j.nel) j.dw[i] = j.accumulate ? j.dw[i] + v[e] : v[e];
+      }
+    }
+    return;
+  }
   const int64_t base = (int64_t)(blockIdx.x - t.blk_start[lo]) * RB_ELEMS;
   const bool tail = base + RB_ELEMS > j.nel;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -1040,7 +1095,11 @@ extern "C" int vts_wgrad_reduce_batch(const vts_reduce_job* jobs, int njobs, voi
       for (int sg = 0; sg < q.nseg; ++sg) VTS_CHECK_ARG(q.part[sg] && q.pw[sg] >= 1, "vts_wgrad_reduce_batch: bad segment %d of job %d", sg, j0 + j);
       t.job[j] = q;
       t.blk_start[j] = blocks;
-      blocks += (int)cdiv64(q.nel, RB_ELEMS);
+      int maxpw = 0;
+      for (int sg = 0; sg < q.nseg; ++sg) maxpw = q.pw[sg] > maxpw ? q.pw[sg] : maxpw;
+      static const int narrow_min = getenv("VTS_REDUCE_NARROW_MIN") ? atoi(getenv("VTS_REDUCE_NARROW_MIN")) : 256;
+      t.narrow[j] = maxpw > narrow_min ? 1 : 0;      // more than 16 copies per wave of the 256-element form
+      blocks += (int)cdiv64(q.nel, t.narrow[j] ? 64 : RB_ELEMS);
     }
     t.blk_start[t.njobs] = blocks;
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, t);
