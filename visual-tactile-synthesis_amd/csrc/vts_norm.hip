@@ -890,11 +890,18 @@ __global__ __launch_bounds__(256) void chsum_finalize_wide_kernel(const float* _
   __shared__ float red[16];
   const int c = blockIdx.x;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float* q = part + ((int64_t)n * C + c) * spl;
-    int j = threadIdx.x;
-    for (; j + 768 < spl; j += 1024) s += (q[j] + q[j + 256]) + (q[j + 512] + q[j + 768]);
-    for (; j < spl; j += 256) s += q[j];
+  if (spl >= 64) {                      // few samples, many splits: the threads walk the splits of one sample
+    for (int n = 0; n < N; ++n) {
+      const float* q = part + ((int64_t)n * C + c) * spl;
+      int j = threadIdx.x;
+      for (; j + 768 < spl; j += 1024) s += (q[j] + q[j + 256]) + (q[j + 512] + q[j + 768]);
+      for (; j < spl; j += 256) s += q[j];
+    }
+  } else {                              // many samples, few splits (the D2 patch passes: 640 x 1): a thread per sample
+    for (int n = threadIdx.x; n < N; n += 256) {
+      const float* q = part + ((int64_t)n * C + c) * spl;
+      for (int j = 0; j < spl; ++j) s += q[j];
+    }
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
