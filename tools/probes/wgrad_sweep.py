@@ -21,6 +21,7 @@ SHAPES = [  # name, N, CL, LH, CH, stride, pad, affine
     ("up3", 4, 160, 64, 40, 2, 1, 0), ("up2", 4, 80, 128, 20, 2, 1, 0), ("up1", 4, 40, 256, 10, 2, 1, 0),
     ("d1s0l4", 8, 1, 131, 64, 1, 2, 1), ("d1s0l3", 8, 64, 130, 32, 1, 2, 1), ("d1s0l2", 8, 32, 129, 16, 2, 2, 1), ("d1s0l1", 8, 16, 257, 8, 2, 2, 1),
     ("d1s1l3", 8, 64, 66, 32, 1, 2, 1), ("d1s1l2", 8, 32, 65, 16, 2, 2, 1), ("d1s1l1", 8, 16, 129, 8, 2, 2, 1),
+    ("up0", 4, 10, 512, 3, 2, 1, 0), ("up0T", 4, 10, 512, 2, 2, 1, 0), ("d1s0l0", 8, 8, 513, 4, 2, 2, 0), ("d1s1l0", 8, 8, 257, 4, 2, 2, 0),
     ("d1s2l3", 8, 64, 34, 32, 1, 2, 1), ("d1s2l2", 8, 32, 33, 16, 2, 2, 1), ("d1s2l1", 8, 16, 65, 8, 2, 2, 1),
 ]
 cdiv = lambda a, b: (a + b - 1) // b  # noqa: E731

@@ -323,9 +323,13 @@ __device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
 }
 
-template <int S, int CLT, int CHT>
+template <int S, int CLT, int CHT, int TYT = (S == 2 ? 2 : 4)>
 __global__ __launch_bounds__(256) void wgrad4x4_ns_kernel(const WgK p) {
-  constexpr int TY = S == 2 ? 2 : 4;          // tile rows (even: a low-resolution wave instruction covers two rows, one per half-wave)
+  // tile rows (even: a low-resolution wave instruction covers two rows, one per half-wave).  The 2 - 4 channel layers (one
+  // high-resolution channel per wave) take 8 rows: a 2-row tile gives them 14 MFMAs per wave between two barriers -- the per-tile
+  // decode / descriptor / barrier overhead and the unoverlapped load issue were 2/3 of the kernel (ablation, round 3) -- and a taller
+  // tile also re-reads less halo (18 patch rows per 8 output rows instead of 6 per 2).
+  constexpr int TY = TYT;
   constexpr int TX = 28, KSTEPS = TX / 4;     // 28 pixels: the high-resolution patch row (58 / 31 columns) fits one wave / half-wave
   constexpr int TXLP = 30;                    // A reads: bank = (-2 * channel + k) mod 32 -> conflict-free
   constexpr int CLP = CLT * 16, CHW = 4 * CHT;
@@ -822,12 +826,16 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceTa
 struct Plan {
   int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles, txl;
   int ns;   // 1: N-split kernel (wgrad4x4_ns_kernel), cht = high-res channels per WAVE
+  int ty;   // ... its tile rows
   int small;   // 1: small-map kernel (wgrad_small_kernel<clt, cht>): flattened positions of ipb whole images per workgroup step
   int ipb, nblocks, pos, posp, pwf, plane, lds_bytes;
 };
 
+int ns_tile_rows(int clt, int cht, int LH);
+
 Plan make_plan(const vts_wgrad_desc* d) {
   Plan pl;
+  pl.ty = 0;
   const int CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
   pl.ns = 0;
   pl.small = 0;
@@ -860,7 +868,7 @@ Plan make_plan(const vts_wgrad_desc* d) {
     }
   }
   static const int use_ns = getenv("VTS_WGRAD_NS") ? atoi(getenv("VTS_WGRAD_NS")) : 1;
-  static const int ns_min_ch = getenv("VTS_WGRAD_NS_MINCH") ? atoi(getenv("VTS_WGRAD_NS_MINCH")) : 5;
+  static const int ns_min_ch = getenv("VTS_WGRAD_NS_MINCH") ? atoi(getenv("VTS_WGRAD_NS_MINCH")) : 2;   // (5 until round 3: 2 - 4 channel layers on the K-split kernel)
   static const int ns_min_w = getenv("VTS_WGRAD_NS_MINW") ? atoi(getenv("VTS_WGRAD_NS_MINW")) : 8;
   // (the buffer-load addressing of the N-split kernel needs channel planes below 2^26 bytes)
   if (use_ns && CH >= ns_min_ch && d->LW > ns_min_w && (int64_t)d->HH * d->HW < (1 << 24) && (int64_t)d->LH * d->LW < (1 << 24)) {
@@ -870,7 +878,8 @@ Plan make_plan(const vts_wgrad_desc* d) {
     pl.clt = cdiv(CL, 16 * pl.cl_groups);
     pl.ch_groups = cdiv(CH, 20);
     pl.cht = cdiv(CH, 4 * pl.ch_groups);
-    const int ty = d->stride == 2 ? 2 : 4;
+    const int ty = d->stride == 2 ? ns_tile_rows(pl.clt, pl.cht, d->LH) : 4;
+    pl.ty = ty;
     pl.tiles_y = cdiv(d->LH, ty);
     pl.txl = 28;
     pl.tiles_x = cdiv(d->LW, 28);
@@ -909,7 +918,7 @@ Plan make_plan(const vts_wgrad_desc* d) {
         }
         return false;
       };
-      while (copies * pl.cl_groups * pl.ch_groups < 224) {
+      while (pl.ty <= 4 && copies * pl.cl_groups * pl.ch_groups < 224) {      // (tall-tile thin layers keep their tile: their copies are cheap)
         if (next_split(CH, 4, pl.cht, pl.ch_groups, pl.cht)) continue;
         if (next_split(CL, 16, pl.clt, pl.cl_groups, pl.clt)) continue;
         break;
@@ -989,8 +998,31 @@ void launch_ns(const WgK& k, const Plan& pl, hipStream_t st) {
   vts_set_kernel("wgrad4x4_ns_kernel<%d, %d, %d>", S, CLT, CHT);
 }
 
+template <int CLT, int CHT, int TY>
+void launch_ns_tall(const WgK& k, const Plan& pl, hipStream_t st) {
+  hipLaunchKernelGGL((wgrad4x4_ns_kernel<2, CLT, CHT, TY>), dim3(pl.pw, pl.cl_groups * pl.ch_groups), dim3(256), 0, st, k);
+  vts_set_kernel("wgrad4x4_ns_kernel<2, %d, %d, %d>", CLT, CHT, TY);
+}
+
+// tile rows of the stride-2 N-split kernel for (clt, cht) accumulator tiles per wave on an LH-row map
+int ns_tile_rows(int clt, int cht, int LH) {
+  static const int tall = getenv("VTS_WGRAD_TALL") ? atoi(getenv("VTS_WGRAD_TALL")) : 1;
+  // measured (tools/probes/wgrad_sweep.py): 8 rows help only with ONE high-resolution channel per wave (2 - 4 channel layers: up0
+  // 52 -> 42 us, D layer 0 99 -> 77 us); with 2 - 3 channels per wave the 36 - 42 prefetch registers and 30 - 48 KB of patch rows
+  // cost more co-resident workgroups than the longer tile saves (16 -> 8 channel layer: 43 -> 59 us)
+  if (!tall || cht != 1 || clt > 2 || LH < 64) return 2;
+  return 8;
+}
+
 template <int S>
 bool dispatch_ns(const WgK& k, const Plan& pl, hipStream_t st) {
+  if (S == 2 && pl.ty > 2) {
+#define TALL_CASE(CLT, CHT, TY) \
+  if (pl.clt == CLT && pl.cht == CHT && pl.ty == TY) { launch_ns_tall<CLT, CHT, TY>(k, pl, st); return true; }
+    TALL_CASE(1, 1, 8) TALL_CASE(2, 1, 8)
+#undef TALL_CASE
+    return false;
+  }
 #define NS_CASE(CLT, CHT) \
   if (pl.clt == CLT && pl.cht == CHT) { launch_ns<S, CLT, CHT>(k, pl, st); return true; }
 #define NS_ROW(CLT) NS_CASE(CLT, 1) NS_CASE(CLT, 2) NS_CASE(CLT, 3) NS_CASE(CLT, 4) NS_CASE(CLT, 5)
