@@ -306,7 +306,8 @@ int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st) {
   const int groups = cdiv(d->Cout, NR * 16);
   int ipb = (4 * 8 * 16) / (k.PPI * P);                          // fills 8 units per wave
   const int lds_cap = (48 * 1024 / 4 - CK * 16 * COP) / (CK * k.plane);
-  int ipb_par = (d->N * groups) / 256;                           // keeps >= ~256 workgroups
+  static const int small_wgs = getenv("VTS_SMALL_WGS") ? atoi(getenv("VTS_SMALL_WGS")) : 256;
+  int ipb_par = (d->N * groups) / small_wgs;                     // keeps >= ~256 workgroups
   if (ipb_par < 1) ipb_par = 1;
   if (ipb > lds_cap) ipb = lds_cap;
   if (ipb > ipb_par) ipb = ipb_par;
