@@ -821,3 +821,29 @@ def test_deferred_weight_gradient_reduction_equals_immediate(shape):
         ops.wgrad4x4(lo, hi, got, stride=2, pad=1)
         ops.wgrad4x4(lo2, hi, got, stride=2, pad=1, accumulate=True)
     assert rel(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 35, 35, 2, True), (3, 20, 67, 40, 2, True), (2, 5, 16, 33, 1, False), (8, 64, 131, 131, 2, True)])
+def test_single_channel_weight_gradient(shape):
+    """the PatchGAN head's weight gradient (one low-resolution channel) on the vector-ALU member (wgrad_head_kernel) against
+    torch.nn.grad.conv2d_weight, incl. normalise + LeakyReLU on the high-resolution operand and ragged tiles"""
+    from vts import lib as L
+    from vts import ops
+    from vts.ops import Act
+
+    n, ch, lh, lw, pad, affine = shape
+    dev = _dev()
+    hh, hw = lh - 1 + 4 - 2 * pad, lw - 1 + 4 - 2 * pad
+    lo = detrand.uniform((n, 1, lh, lw), 4, "lo")
+    hi = detrand.uniform((n, ch, hh, hw), 4, "hi")
+    if affine:
+        sc, sh = _affine(n, ch, 4, "h")
+        hiv = F.leaky_relu(hi * sc.view(n, ch, 1, 1) + sh.view(n, ch, 1, 1), 0.2)
+        hi_op, act = Act(hi.to(dev), sc.to(dev), sh.to(dev)), L.ACT_LRELU
+    else:
+        hiv, hi_op, act = hi, Act(hi.to(dev)), 0
+    ref = torch.nn.grad.conv2d_weight(hiv.double(), (1, ch, 4, 4), lo.double(), stride=1, padding=pad).float()
+    dw = torch.empty(1, ch, 4, 4, device=dev)
+    ops.wgrad4x4(Act(lo.to(dev)), hi_op, dw, act_hi=act, stride=1, pad=pad, defer=False)
+    assert L.load().vts_last_kernel().decode() == "wgrad_head_kernel"
+    assert rel(dw, ref) < 3e-6

@@ -680,6 +680,117 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const SmallWK p) {
     }
 }
 
+// ---- single-channel member (round 3): the weight gradient of the PatchGAN prediction heads (Conv2d(ndf*8, 1, 4, 1, 2), reference
+// models/networks.py:1739-1741): lo is the ONE-channel output gradient, hi the 64-channel input.  On the MFMA tiles fifteen of
+// the sixteen low-resolution channel rows are zeros (57 us for 8 x 64 x 130^2, against 4.4 us of HBM time); this is a reduction
+// dw[ch][ky][kx] = sum_p lo[p] * hi[ch][p + (ky, kx)], so it runs on the vector ALUs: a workgroup stages a 16 x 32 tile of lo and
+// the 19 x 35 patch of 16 hi channels (normalise + activate + zero padding on the way), a thread owns (channel, ky) and every
+// fourth tile row: per row nine + eight 16-byte LDS reads (conflict-free: lanes of one (channel) differ in row = bank group, equal
+// rows broadcast) feed 128 FMAs for its four kx.  One partial copy [CH][16] per tile, reduced by the batched reduction.
+struct HeadWK {
+  const float* lo;
+  int64_t lons;
+  const float *hi, *hisc, *hish;
+  int64_t hins;
+  int CH, N, LH, LW, HH, HW, pad, padx;
+  float hi_slope;
+  int tiles_y, tiles_x;
+  float* part;
+};
+constexpr int HWG_TY = 16, HWG_TX = 32, HWG_PR = HWG_TY + 3, HWG_PC = HWG_TX + 3, HWG_PCP = 36, HWG_CK = 16, HWG_PLANE = HWG_PR * HWG_PCP;
+
+__global__ __launch_bounds__(256) void wgrad_head_kernel(const HeadWK p) {
+  __shared__ __attribute__((aligned(16))) float patch[HWG_CK * HWG_PLANE];
+  __shared__ __attribute__((aligned(16))) float dyt[HWG_TY * HWG_PCP];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int n = tile / (p.tiles_y * p.tiles_x), rem = tile - n * (p.tiles_y * p.tiles_x);
+  const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+  const int y0 = ty * HWG_TY, x0 = tx * HWG_TX;
+  const int hy0 = y0 - p.pad, hx0 = x0 - p.padx;
+  // the lo tile (zeros beyond the map: those positions then contribute nothing)
+  for (int e = tid; e < HWG_TY * HWG_TX; e += 256) {
+    const int r = e >> 5, c = e & 31;
+    const int y = y0 + r, x = x0 + c;
+    dyt[r * HWG_PCP + c] = (y < p.LH && x < p.LW) ? p.lo[n * p.lons + (int64_t)y * p.LW + x] : 0.f;
+  }
+  const int rg = tid & 3, ky = (tid >> 2) & 3, chl = tid >> 4;
+  const int64_t hplane = (int64_t)p.HH * p.HW;
+  float* part = p.part + (int64_t)tile * p.CH * 16;
+  // Software pipeline over the 16-channel chunks: the raw loads of chunk k + 1 are issued before the multiply phase of chunk k and
+  // finished (affine, activation, padding -> LDS) after it.  Row-wise staging: wave w takes channels w, w + 4, ... of the chunk, one
+  // patch row per wave instruction (lanes = columns), so channel, row, bounds and the channel's scale / shift are wave-uniform
+  // (the element-wise form spent ~45 instructions per loaded value); all 76 loads of a chunk are in flight together.
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ix = hx0 + lane;
+  const bool colok = lane < HWG_PC && ix >= 0 && ix < p.HW;
+  const int ixc = min(max(ix, 0), p.HW - 1);
+  float raw[HWG_CK / 4][HWG_PR];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int cc = 0; cc < HWG_CK / 4; ++cc) {
+      const int chc = min(c0 + wv + 4 * cc, p.CH - 1);
+      const float* src = p.hi + n * p.hins + chc * hplane + ixc;
+#pragma unroll
+      for (int r = 0; r < HWG_PR; ++r) raw[cc][r] = src[(int64_t)min(max(hy0 + r, 0), p.HH - 1) * p.HW];
+    }
+  };
+  auto store_chunk = [&](int c0) {
+#pragma unroll
+    for (int cc = 0; cc < HWG_CK / 4; ++cc) {
+      const int c = wv + 4 * cc, ch = c0 + c;
+      const bool chok = ch < p.CH;
+      const int chc = chok ? ch : p.CH - 1;
+      const float sc = p.hisc ? p.hisc[n * p.CH + chc] : 1.f, sh = p.hish ? p.hish[n * p.CH + chc] : 0.f;
+      float* dstp = patch + c * HWG_PLANE + min(lane, HWG_PCP - 1);
+#pragma unroll
+      for (int r = 0; r < HWG_PR; ++r) {
+        const int iy = hy0 + r;
+        const bool ok = chok && colok && iy >= 0 && iy < p.HH;
+        const float t = fmaf(raw[cc][r], sc, sh);
+        if (lane < HWG_PCP) dstp[r * HWG_PCP] = ok ? fmaxf(t, 0.f) + p.hi_slope * fminf(t, 0.f) : 0.f;
+      }
+    }
+  };
+  load_chunk(0);
+  for (int c0 = 0; c0 < p.CH; c0 += HWG_CK) {
+    __syncthreads();                      // the previous chunk's readers are done (first pass: the lo tile is complete)
+    store_chunk(c0);
+    if (c0 + HWG_CK < p.CH) load_chunk(c0 + HWG_CK);
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < HWG_TY / 4; ++j) {
+      const int r = rg + 4 * j;
+      const f32x4* vp = reinterpret_cast<const f32x4*>(patch + chl * HWG_PLANE + (r + ky) * HWG_PCP);
+      const f32x4* dp = reinterpret_cast<const f32x4*>(dyt + r * HWG_PCP);
+      float v[HWG_PCP], d[HWG_TX];
+#pragma unroll
+      for (int i = 0; i < HWG_PCP / 4; ++i) {
+        const f32x4 t = vp[i];
+        v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+      }
+#pragma unroll
+      for (int i = 0; i < HWG_TX / 4; ++i) {
+        const f32x4 t = dp[i];
+        d[4 * i] = t[0]; d[4 * i + 1] = t[1]; d[4 * i + 2] = t[2]; d[4 * i + 3] = t[3];
+      }
+#pragma unroll
+      for (int x = 0; x < HWG_TX; ++x)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) acc[kx] = fmaf(d[x], v[x + kx], acc[kx]);
+    }
+    // the four row groups of a (channel, ky) sit in adjacent lanes: fixed-order combination (0 + 1) + (2 + 3)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const float a = acc[kx] + __shfl_xor(acc[kx], 1);
+      acc[kx] = a + __shfl_xor(a, 2);
+    }
+    if (rg == 0 && c0 + chl < p.CH) *reinterpret_cast<f32x4*>(part + (c0 + chl) * 16 + ky * 4) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+  }
+}
+
 // Fixed-order sum of the PW partials.  64 consecutive elements per workgroup (one coalesced 256-B
 // row per wave-load), 16 waves each summing every 16th partial, combined through LDS in wave order.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t n, int pw, float* __restrict__ dw,
@@ -827,6 +938,7 @@ struct Plan {
   int clt, cht, cl_groups, ch_groups, pw, tiles_y, tiles_x, ntiles, txl;
   int ns;   // 1: N-split kernel (wgrad4x4_ns_kernel), cht = high-res channels per WAVE
   int ty;   // ... its tile rows
+  int head; // 1: single-channel vector-ALU member (wgrad_head_kernel): one partial copy per 16 x 32 tile
   int small;   // 1: small-map kernel (wgrad_small_kernel<clt, cht>): flattened positions of ipb whole images per workgroup step
   int ipb, nblocks, pos, posp, pwf, plane, lds_bytes;
 };
@@ -836,6 +948,7 @@ int ns_tile_rows(int clt, int cht, int LH);
 Plan make_plan(const vts_wgrad_desc* d) {
   Plan pl;
   pl.ty = 0;
+  pl.head = 0;
   const int CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
   pl.ns = 0;
   pl.small = 0;
@@ -866,6 +979,18 @@ Plan make_plan(const vts_wgrad_desc* d) {
         }
       }
     }
+  }
+  static const int use_head = getenv("VTS_WGRAD_HEAD") ? atoi(getenv("VTS_WGRAD_HEAD")) : 1;
+  if (use_head && CL == 1 && !d->lo1.data && !d->hi1.data && d->stride == 1 && d->act_lo == VTS_ACT_NONE && !d->lo0.scale && !d->lo0.shift &&
+      d->LH >= 8 && d->LW >= 16 && d->act_hi != VTS_ACT_TANH) {
+    pl.head = 1;
+    pl.clt = pl.cht = pl.cl_groups = pl.ch_groups = 1;
+    pl.tiles_y = cdiv(d->LH, HWG_TY);
+    pl.tiles_x = cdiv(d->LW, HWG_TX);
+    pl.ntiles = d->N * pl.tiles_y * pl.tiles_x;
+    pl.txl = HWG_TX;
+    pl.pw = pl.ntiles;
+    return pl;
   }
   static const int use_ns = getenv("VTS_WGRAD_NS") ? atoi(getenv("VTS_WGRAD_NS")) : 1;
   static const int ns_min_ch = getenv("VTS_WGRAD_NS_MINCH") ? atoi(getenv("VTS_WGRAD_NS_MINCH")) : 2;   // (5 until round 3: 2 - 4 channel layers on the K-split kernel)
@@ -1085,6 +1210,22 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
 #undef SW_CASE
     VTS_CHECK_ARG(ok, "vts_wgrad4x4: no small-map instance for clt %d chw %d", pl.clt, pl.cht);
     VTS_CHECK_LAUNCH("vts_wgrad4x4 (small maps)");
+    if (d->defer) return VTS_OK;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 64)), dim3(1024), 0, st, ws, nel, pl.pw, d->dw, d->accumulate);
+    VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
+    return VTS_OK;
+  }
+  if (pl.head) {
+    HeadWK q;
+    q.lo = d->lo0.data; q.lons = d->lo0.nstride;
+    q.hi = d->hi0.data; q.hisc = d->hi0.scale; q.hish = d->hi0.shift; q.hins = d->hi0.nstride;
+    q.CH = k.hi.C; q.N = d->N; q.LH = d->LH; q.LW = d->LW; q.HH = d->HH; q.HW = d->HW; q.pad = d->pad; q.padx = d->pad + d->pad_dx;
+    q.hi_slope = vts_slope(d->act_hi);
+    q.tiles_y = pl.tiles_y; q.tiles_x = pl.tiles_x;
+    q.part = ws;
+    hipLaunchKernelGGL(wgrad_head_kernel, dim3(pl.ntiles), dim3(256), 0, st, q);
+    vts_set_kernel("wgrad_head_kernel");
+    VTS_CHECK_LAUNCH("vts_wgrad4x4 (single channel)");
     if (d->defer) return VTS_OK;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel, 64)), dim3(1024), 0, st, ws, nel, pl.pw, d->dw, d->accumulate);
     VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
