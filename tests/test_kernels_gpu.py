@@ -64,6 +64,12 @@ CONV_CASES = [
     (1, 8, 0, 16, 257, 259, 2, 2, 1),
     (1, 3, 0, 2, 301, 277, 2, 1, 2),
     (1, 5, 2, 13, 270, 256, 2, 2, 1),
+    # lane = pixel member (vts_conv_px.hip): stride 2, Cout <= 12, output >= 128 x 128; ragged rows / columns, odd widths, every block count
+    (1, 4, 0, 3, 258, 262, 2, 1, 0),
+    (2, 3, 2, 12, 257, 300, 2, 2, 1),
+    (1, 1, 0, 7, 400, 256, 2, 1, 2),
+    (1, 10, 0, 9, 262, 259, 2, 1, 1),
+    (1, 6, 0, 5, 261, 257, 2, 2, 0),
 ]
 
 
@@ -90,6 +96,38 @@ def test_conv_forward(case):
     ops.conv4x4(Act(x0.to(dev), sc0.to(dev), sh0.to(dev)), w.to(dev), (C0 + C1) * 16, 16, Cout, out, in1=in1, bias=b.to(dev),
                 stride=s, pad=p, act_in=act)
     assert rel(out, ref) < 1e-5
+
+
+def test_thin_stride2_convolutions_take_the_lane_pixel_member():
+    """the dispatch of vts_conv4x4: thin stride-2 layers on full-size maps run on conv_px_s2_kernel (4x4x1 MFMA, lane = pixel), with
+    dual sources, per-channel affine + LeakyReLU on load, derivative mask and accumulation; wide or small ones do not"""
+    from vts import lib as L, ops
+    from vts.ops import Act
+
+    dev = _dev()
+    N, C0, C1, Cout, H, W = 2, 5, 4, 10, 260, 300
+    x0, x1 = detrand.uniform((N, C0, H, W), 7, "x0"), detrand.uniform((N, C1, H, W), 7, "x1")
+    (sc0, sh0), (sc1, sh1) = _affine(N, C0, 7, "a0"), _affine(N, C1, 7, "a1")
+    w = detrand.uniform((Cout, C0 + C1, 4, 4), 7, "w") * 0.2
+    ref = F.conv2d(torch.cat([_apply(x0, sc0, sh0, 1), _apply(x1, sc1, sh1, 1)], 1), w, None, stride=2, padding=1)
+    m = detrand.uniform(ref.shape, 7, "m")
+    base = detrand.uniform(ref.shape, 7, "base")
+    want = base + ref * (m > 0).float()
+    out = base.clone().to(dev)
+    ops.conv4x4(Act(x0.to(dev), sc0.to(dev), sh0.to(dev)), w.to(dev), (C0 + C1) * 16, 16, Cout, out, in1=Act(x1.to(dev), sc1.to(dev), sh1.to(dev)),
+                stride=2, pad=1, act_in=1, dmask=Act(m.to(dev)), dmask_act=L.ACT_RELU, accumulate=True)
+    assert L.load().vts_last_kernel().decode().startswith("conv_px_s2_kernel<3,")
+    assert rel(out, want) < 1e-5
+    # plain operand (no affine, no activation: the gradient case) on an odd input width: the last column pair straddles the row end
+    xo = detrand.uniform((1, 3, 261, 259), 7, "xo")
+    ref = F.conv2d(xo, w[:, :3], None, stride=2, padding=2)
+    out = torch.empty(ref.shape, device=dev)
+    ops.conv4x4(Act(xo.to(dev)), w[:, :3].contiguous().to(dev), 3 * 16, 16, Cout, out, stride=2, pad=2)
+    assert L.load().vts_last_kernel().decode().startswith("conv_px_s2_kernel<3,") and rel(out, ref) < 1e-5
+    for cout, hw in ((40, 260), (10, 64)):     # too wide / too small for it
+        out = torch.empty(1, cout, hw // 2, hw // 2, device=dev)
+        ops.conv4x4(Act(x0[:1, :, :hw, :hw].contiguous().to(dev)), w[:1].repeat(cout, 1, 1, 1)[:, :C0].contiguous().to(dev), C0 * 16, 16, cout, out, stride=2, pad=1)
+        assert not L.load().vts_last_kernel().decode().startswith("conv_px")
 
 
 CONVT_CASES = [
@@ -328,6 +366,10 @@ FUSED_NORM_CASES = [
     (2, 10, 20, 256, 256, 2, 1, False, 0, None, 40.0),     # |mean| >> sigma: the per-wave two-pass partials must stay robust
     (1, 160, 80, 32, 32, 2, 1, True, 0, None, 0.0),        # inner layer: k-split epilogue fusion (InstanceNorm only)
     (3, 32, 64, 20, 20, 1, 2, False, 1, None, 0.0),        # small grid + BatchNorm: must NOT take the InstanceNorm k-split fusion
+    (2, 9, 10, 260, 262, 2, 1, False, 0, None, 0.0),       # lane = pixel member (vts_conv_px.hip): statistics per wave of 2 rows x 62 pixels
+    (3, 4, 8, 259, 257, 2, 2, False, 1, [0, 1], 0.0),      # ... even padding (63 pixels per wave), BatchNorm pass groups, odd sizes
+    (1, 5, 12, 256, 256, 2, 1, False, 0, None, 40.0),      # ... |mean| >> sigma
+    (2, 12, 7, 129, 131, 2, 2, True, 1, None, 0.0),        # transposed lane = pixel member, even padding, odd output width (dword stores)
 ]
 
 
@@ -401,6 +443,8 @@ BWD_SUM_CASES = [
     (1, 20, 10, 96, 136, 2, 1, True, 0, None, True),       # encoder: transposed s2, LeakyReLU mask, accumulated onto the skip contribution
     (4, 32, 16, 66, 65, 2, 2, True, 1, [0, 1, 3], False),  # PatchGAN: transposed s2 pad 2, BatchNorm with pass groups below
     (2, 64, 32, 130, 131, 1, 2, True, 1, None, False),     # PatchGAN stride-1 layer
+    (2, 3, 10, 256, 260, 2, 1, False, 0, None, False),     # outermost up-block (lane = pixel member): 3 -> 10, ReLU mask
+    (1, 7, 12, 262, 300, 2, 1, False, 0, None, True),      # ... 7 -> 12 accumulated onto the skip contribution, ragged tiles
 ]
 
 

@@ -201,8 +201,6 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       const int rc = vts_conv_small_try(d, (hipStream_t)stream);
       if (rc != VTS_ERR_UNSUPPORTED) return rc;
     }
-    const int rc = vts_conv_thin_try(d, (hipStream_t)stream);
-    if (rc != VTS_ERR_UNSUPPORTED) return rc;
   }
   ConvK k;
   k.s0 = d->in0.data; k.sc0 = d->in0.scale; k.sh0 = d->in0.shift; k.ns0 = d->in0.nstride; k.C0 = d->in0.C;
@@ -239,12 +237,24 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   const int N = d->N;
   // statistics of the output in the epilogue (round 3): only the plain "store acc + bias" form through the direct epilogue
   static const int fuse_stats = getenv("VTS_FUSE_STATS") ? atoi(getenv("VTS_FUSE_STATS")) : 1;
-  const bool want_stats = nd && fused && sw.p && fuse_stats && k.direct_epi && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
-                          nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride &&
-                          sw.floats >= vts_conv4x4_norm_ws_floats(d);
+  const bool stats_ok = nd && fused && sw.p && fuse_stats && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
+                        nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride;
+  const bool want_stats = stats_ok && k.direct_epi && sw.floats >= vts_conv4x4_norm_ws_floats(d);
   static const int fuse_bsums = getenv("VTS_FUSE_BSUMS") ? atoi(getenv("VTS_FUSE_BSUMS")) : 1;
-  const bool want_bsums = bsums && fused && sw.p && fuse_bsums && k.direct_epi && d->act_out == VTS_ACT_NONE && d->dmask.data &&
-                          sw.floats >= vts_conv4x4_norm_ws_floats(d);
+  const bool bsums_ok = bsums && fused && sw.p && fuse_bsums && d->act_out == VTS_ACT_NONE && d->dmask.data;
+  const bool want_bsums = bsums_ok && k.direct_epi && sw.floats >= vts_conv4x4_norm_ws_floats(d);
+  {
+    // thin stride-2 convolutions / transposed convolutions on full-size maps: the lane = pixel members (vts_conv_px.hip), with the same
+    // epilogue partials
+    int spl = 0;
+    const int rc = vts_conv_px_try(d, st, stats_ok ? sw.p : nullptr, (!stats_ok && bsums_ok) ? sw.p : nullptr, sw.floats, &spl);
+    if (rc != VTS_ERR_UNSUPPORTED) {
+      if (rc == VTS_OK && spl > 0) *fused = 2 + spl;
+      return rc;
+    }
+    const int rt = vts_conv_thin_try(d, st);   // (what the lane = pixel members do not take: VTS_NO_PXT=1, Cout 13 .. 16)
+    if (rt != VTS_ERR_UNSUPPORTED) return rt;
+  }
   {
     // Small grids (inner U-Net layers: <= 32x32 maps, 80..592 channels) cannot fill 256 CUs with one
     // workgroup per spatial tile: split the output channels over workgroups (no reduction needed) and,

@@ -17,6 +17,8 @@ const float* vts_ident();
 int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st);
 // thin (Cout <= 16) stride-2 transposed layers on full-size maps: direct packed-FMA kernel; VTS_ERR_UNSUPPORTED otherwise
 int vts_conv_thin_try(const vts_conv_desc* d, hipStream_t st);
+// thin (Cout <= 20) stride-2 convolutions on full-size maps: lane = pixel on the 4x4x1 MFMA (vts_conv_px.hip); VTS_ERR_UNSUPPORTED otherwise
+int vts_conv_px_try(const vts_conv_desc* d, hipStream_t st, float* stat_part, float* bsum_part, int64_t part_floats, int* stat_spl);
 // single-output-channel stride-1 layers (PatchGAN prediction heads) on full-size maps: LDS-tiled vector-ALU kernel; VTS_ERR_UNSUPPORTED otherwise
 int vts_conv_head_try(const vts_conv_desc* d, hipStream_t st);
 // PatchNCE on the MFMA path (vts_patchnce.hip): P, D <= 256
