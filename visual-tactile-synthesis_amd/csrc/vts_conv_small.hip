@@ -37,6 +37,8 @@ struct SmallK {
   int GH, GW, PPI, MTP; // phase-grid dims, pixels per image per phase, M-tiles per phase
   int ablate;           // profiling only (env VTS_ABLATE)
   int wbytes;           // extent of the weight view in bytes (buffer descriptor)
+  int fast;             // 1: pipelined flat staging (single source, Cin % 8 == 0, contiguous samples: see the kernel)
+  int inbytes;          // extent of the input tensor in bytes (buffer descriptor of the flat loads)
 };
 
 template <int MODE, int S, int NR, int UMAX, int CK>
@@ -110,6 +112,138 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallK p) {
   const int nlines = p.IPB * CK * p.IH;   // (image, channel, row) lines of the inner region
   __syncthreads();
 
+  // ---- MFMA accumulate of the staged chunk ----
+  auto mfma_phase = [&](int cbase) {
+    const int cvalid = (p.ablate & 2) ? 0 : min(CK, p.Cin - cbase);
+    for (int c = 0; c < cvalid; ++c) {
+      const float* pp = patch + c * p.plane;
+      const float* ww = lds_w + c * 16 * COP + kq * COP + m16;
+      if (MODE == 1 && S == 2) {
+        // every unit slot computes (absent units read offset 0 and are discarded in the epilogue):
+        // a per-unit branch costs more than the spare MFMA
+#pragma unroll
+        for (int k = 0; k < UMAX; ++k) {
+          const float a = pp[abase[k]];
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr)
+            acc[k][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ww[uph[k] * 4 * COP + nr * 16], acc[k][nr], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float b[NR];
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr) b[nr] = ww[g * 4 * COP + nr * 16];
+          const int goff = (MODE == 0) ? g * p.PWi : -g * p.PWi;
+#pragma unroll
+          for (int k = 0; k < UMAX; ++k) {
+            const float a = pp[abase[k] + goff];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) acc[k][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nr], acc[k][nr], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  if (p.fast) {
+    // ---- pipelined flat staging (round 3).  The line-wise staging below spends one wave instruction per 2 map rows -- 5 - 9 useful lanes
+    // of 32 on these maps -- and waits for every chunk's loads before it multiplies: 33 of 65 us on the 32 -> 64 layer of 640 5 x 5 maps
+    // (tools/mb_small.py, VTS_ABLATE).  A chunk of 8 channels of one sample is 8 * IH * IW CONTIGUOUS floats: threads load 16-byte
+    // quads of that run (fully used lanes), the quad -> (channel, y, x) decode is done once (it is the same for every chunk), and the
+    // quads and the weight slice of chunk k + 1 are in flight during the MFMA phase of chunk k.
+    constexpr int NQ = 3;                                   // quads per thread (the host side checks IPB * 2 * IH * IW <= 768)
+    constexpr int NCO = NR * 16;
+    constexpr int NWQ = CK * 4 * NCO / 256;                 // weight quads per thread
+    float* aff_sc = reinterpret_cast<float*>(line_tab + p.IPB * CK * p.IH);   // [IPB][Cin] scale, then shift
+    float* aff_sh = aff_sc + p.IPB * p.Cin;
+    const int HW = p.IH * p.IW, QPI = 2 * HW, nq = p.IPB * QPI;
+    for (int i = tid; i < p.IPB * p.Cin; i += 256) {
+      const int img = i / p.Cin, ci = i - img * p.Cin;
+      const int nn = min(n0 + img, p.N - 1);
+      aff_sc[i] = p.sc0 ? p.sc0[nn * p.C0 + ci] : 1.f;
+      aff_sh[i] = p.sh0 ? p.sh0[nn * p.C0 + ci] : 0.f;
+    }
+    unsigned qoff[NQ];
+    int qpk[NQ][4];                                         // (affine index << 16) | patch offset of the four elements
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = tid + 256 * j;
+      const int img = q / QPI, r = q - img * QPI;
+      const bool ok = q < nq && n0 + img < p.N;
+      qoff[j] = ok ? (unsigned)(((int64_t)(n0 + img) * p.ns0 + 4 * r) * 4) : 0x40000000u;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int e = 4 * r + e4;
+        const int cc = e / HW, pos = e - cc * HW;
+        const int y = pos / p.IW, x = pos - y * p.IW;
+        qpk[j][e4] = ok ? ((img * p.Cin + cc) << 16) | (img * imgstride + cc * p.plane + (y + HALO) * p.PWi + x + HALO) : -1;
+      }
+    }
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.s0, 0, p.inbytes, 0x00020000);
+    unsigned wvo[NWQ];
+    int wdst[NWQ];
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e) {
+      const int u = tid + e * 256;
+      const int co = u % NCO, rest = u / NCO;
+      const int ky = rest & 3, cw = rest >> 2;
+      wvo[e] = co0 + co < p.Cout ? (unsigned)((co0 + co) * p.ws_co + cw * p.ws_ci + ky * 4) * 4u : 0x40000000u;
+      wdst[e] = (cw * 16) * COP + co;                        // + slot * COP per tap
+    }
+    f32x4 qv[NQ], wq[NWQ];
+    auto load_chunk = [&](int cbase) {
+      if (p.ablate & 1) return;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) qv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)qoff[j], cbase * HW * 4, 0));
+#pragma unroll
+      for (int e = 0; e < NWQ; ++e) wq[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)wvo[e], cbase * p.ws_ci * 4, 0));
+    };
+    auto store_chunk = [&](int cbase) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const f32x4 v = qv[j];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int pk = qpk[j][e4];
+          if (pk >= 0) {
+            const int ai = (pk >> 16) + cbase;
+            const float t = fmaf(v[e4], aff_sc[ai], aff_sh[ai]);
+            patch[pk & 0xFFFF] = fmaxf(t, 0.f) + p.slope_in * fminf(t, 0.f);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NWQ; ++e) {
+        const f32x4 v = wq[e];
+        const int u = tid + e * 256;
+        const int ky = (u / NCO) & 3;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          int slot = ky * 4 + kx;
+          if (MODE == 1 && S == 2) slot = ((((ky + p.pad) & 1) * 2 + ((kx + p.pad) & 1)) * 4) + (ky >> 1) * 2 + (kx >> 1);
+          lds_w[wdst[e] + slot * COP] = v[kx];
+        }
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) qv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < NWQ; ++e) wq[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_chunk(0);
+    __syncthreads();          // affine table complete
+    store_chunk(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      if (chunk + 1 < nchunks) load_chunk((chunk + 1) * CK);
+      mfma_phase(chunk * CK);
+      __syncthreads();
+      if (chunk + 1 < nchunks) {
+        store_chunk((chunk + 1) * CK);
+        __syncthreads();
+      }
+    }
+  } else
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int cbase = chunk * CK;
     // ---- stage input lines: unconditional clamped loads first, branch-free finish afterwards ----
@@ -185,37 +319,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallK p) {
       }
     }
     __syncthreads();
-    // ---- MFMA accumulate ----
-    const int cvalid = (p.ablate & 2) ? 0 : min(CK, p.Cin - cbase);
-    for (int c = 0; c < cvalid; ++c) {
-      const float* pp = patch + c * p.plane;
-      const float* ww = lds_w + c * 16 * COP + kq * COP + m16;
-      if (MODE == 1 && S == 2) {
-        // every unit slot computes (absent units read offset 0 and are discarded in the epilogue):
-        // a per-unit branch costs more than the spare MFMA
-#pragma unroll
-        for (int k = 0; k < UMAX; ++k) {
-          const float a = pp[abase[k]];
-#pragma unroll
-          for (int nr = 0; nr < NR; ++nr)
-            acc[k][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ww[uph[k] * 4 * COP + nr * 16], acc[k][nr], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float b[NR];
-#pragma unroll
-          for (int nr = 0; nr < NR; ++nr) b[nr] = ww[g * 4 * COP + nr * 16];
-          const int goff = (MODE == 0) ? g * p.PWi : -g * p.PWi;
-#pragma unroll
-          for (int k = 0; k < UMAX; ++k) {
-            const float a = pp[abase[k] + goff];
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr) acc[k][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nr], acc[k][nr], 0, 0, 0);
-          }
-        }
-      }
-    }
+    mfma_phase(cbase);
     __syncthreads();
   }
 
@@ -257,7 +361,7 @@ template <int MODE, int S, int NR, int UMAX, int CK>
 int launch_small(const SmallK& k, size_t lds_bytes, hipStream_t st) {
   dim3 grid(cdiv(k.N, k.IPB), cdiv(k.Cout, NR * 16));
   hipLaunchKernelGGL((conv_small_kernel<MODE, S, NR, UMAX, CK>), grid, dim3(256), lds_bytes, st, k);
-  vts_set_kernel("conv_small_kernel<%d, %d, %d, %d, %d>", MODE, S, NR, UMAX, CK);
+  vts_set_kernel("conv_small_kernel<%d, %d, %d, %d, %d>%s", MODE, S, NR, UMAX, CK, k.fast ? "+flat" : "");
   VTS_CHECK_LAUNCH("vts_conv4x4 (small maps)");
   return VTS_OK;
 }
@@ -318,7 +422,11 @@ int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st) {
   const int upw = cdiv(k.MTP * P, 4);                            // units per wave
   if (upw > 8) return VTS_ERR_UNSUPPORTED;
   const int U = upw <= 1 ? 1 : (upw <= 2 ? 2 : (upw <= 4 ? 4 : 8));
-  const size_t lds = (size_t)(ipb * CK * k.plane + CK * 16 * COP + k.MTP * 16 + ipb * CK * d->IH) * sizeof(float);
+  static const int fast_on = getenv("VTS_SMALL_FLAT") ? atoi(getenv("VTS_SMALL_FLAT")) : 1;
+  k.inbytes = (int)((int64_t)d->N * d->in0.nstride * 4 < (int64_t)0x40000000 ? (int64_t)d->N * d->in0.nstride * 4 : 0);
+  k.fast = fast_on && !d->in1.data && k.Cin % CK == 0 && d->in0.nstride == (int64_t)k.Cin * d->IH * d->IW && (reinterpret_cast<uintptr_t>(d->in0.data) & 15) == 0 &&
+           ipb * 2 * d->IH * d->IW <= 768 && k.inbytes > 0 && (reinterpret_cast<uintptr_t>(d->w) & 15) == 0 && ((d->ws_co | d->ws_ci) & 3) == 0;
+  const size_t lds = (size_t)(ipb * CK * k.plane + CK * 16 * COP + k.MTP * 16 + ipb * CK * d->IH + (k.fast ? 2 * ipb * k.Cin : 0)) * sizeof(float);
 #define SMALL_U(MODE, S, NRV)                                                  \
   switch (U) {                                                                 \
     case 1: return launch_small<MODE, S, NRV, 1, CK>(k, lds, st);              \

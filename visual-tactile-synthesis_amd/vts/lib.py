@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvts_hip.so")
+LIB_PATH = os.environ.get("VTS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libvts_hip.so")   # (VTS_LIB_PATH: A/B of builds, tools/)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 GAN_MODES = {"nonsaturating": 0, "lsgan": 1, "vanilla": 2, "wgan": 3, "wgangp": 3, "hinge": 4}
