@@ -229,7 +229,11 @@ int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream);
  * values it stores (after mask and accumulation) into `part` (vts_conv4x4_norm_ws_floats(d) floats are enough); *slots = pairs per
  * (n, channel), 0 = not fused (call vts_norm_bwd).  vts_norm_bwd_from_partials then runs ONLY the apply pass of vts_norm_bwd on them
  * (`beta` = the BatchNorm shift that S2' contains, NULL for InstanceNorm): the partial-sum pass -- one read of dy and of x per
- * normalised layer, and its launch -- disappears from the backward chains. */
+ * normalised layer, and its launch -- disappears from the backward chains.
+ * *slots is also an INPUT: -1 tells the convolution that the normalisation is InstanceNorm2d(affine=False) (its scale IS rstd), and where
+ * the convolution takes the small-grid k-split path on a map of <= 4096 pixels its slice-summing epilogue then applies that backward
+ * itself (one launch instead of two); *slots = -1 on return says so: `out` already holds the gradient w.r.t. the RAW tensor, do not call
+ * vts_norm_bwd.  Pass 0 for BatchNorm or to keep the two-call form. */
 int vts_conv4x4_bsums(const vts_conv_desc* d, float* part, int64_t part_floats, int* slots, void* stream);
 int vts_norm_bwd_from_partials(const vts_norm_bwd_desc* d, const float* part, int slots, const float* beta, void* stream);
 

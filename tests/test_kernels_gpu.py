@@ -443,6 +443,8 @@ BWD_SUM_CASES = [
     (1, 20, 10, 96, 136, 2, 1, True, 0, None, True),       # encoder: transposed s2, LeakyReLU mask, accumulated onto the skip contribution
     (4, 32, 16, 66, 65, 2, 2, True, 1, [0, 1, 3], False),  # PatchGAN: transposed s2 pad 2, BatchNorm with pass groups below
     (2, 64, 32, 130, 131, 1, 2, True, 1, None, False),     # PatchGAN stride-1 layer
+    (2, 80, 80, 32, 32, 2, 1, False, 0, None, False),      # inner up-block: small-grid k-split path, InstanceNorm backward applied by its epilogue
+    (3, 80, 80, 8, 8, 2, 1, True, 0, None, True),          # inner down-block: transposed, k-split, accumulated
     (2, 3, 10, 256, 260, 2, 1, False, 0, None, False),     # outermost up-block (lane = pixel member): 3 -> 10, ReLU mask
     (1, 7, 12, 262, 300, 2, 1, False, 0, None, True),      # ... 7 -> 12 accumulated onto the skip contribution, ragged tiles
 ]
@@ -480,7 +482,7 @@ def test_backward_data_conv_emits_the_norm_backward_sums(case):
         try:
             dx = base.clone() if accumulate else torch.empty_like(base)
             ops.conv4x4(ops.Act(g), w, wargs[0], wargs[1], Cx, dx, stride=stride, pad=pad, transposed=transposed, dmask=a, dmask_act=act,
-                        accumulate=accumulate, bwd_sums=True)
+                        accumulate=accumulate, bwd_sums=True if mode else "in")
             had = dx.data_ptr() in ops.BSUMS
             dg, db = torch.zeros(Cx, device=dev), torch.zeros(Cx, device=dev)
             ops.norm_bwd(dx, a, mode, gamma=gamma if mode else None, dgamma=dg if mode else None, dbeta=db if mode else None, groups=groups,

@@ -89,6 +89,52 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_in_kernel(const ConvK
   }
 }
 
+// Split epilogue + InstanceNorm BACKWARD in one launch (round 3): the backward-data convolutions of the inner U-Net layers run k-split and
+// are followed by the normalisation backward of the layer below (norm_bwd_fused_kernel: one workgroup per (n, channel) plane, two block
+// sums, one apply) -- two latency-bound launches on the generator update's critical chain.  One workgroup owns a plane of <= 4096
+// elements: it sums the slices in slice order, applies the derivative mask (t = dmask * scale + shift IS the normalised value xhat of the
+// layer below, scale = rstd) and the accumulation, reduces S1 = sum g, S2 = sum g * xhat and stores
+//     dx = rstd * (g - S1 / HW - xhat * S2 / HW)           (InstanceNorm2d(affine=False) backward; reference models/networks.py:139)
+// -- the gradient w.r.t. the RAW tensor, i.e. what vts_norm_bwd would have left in place.
+__global__ __launch_bounds__(256) void conv_split_epilogue_inbwd_kernel(const ConvK p, int KS) {
+  __shared__ float red[16];
+  const int g = blockIdx.x, n = g / p.Cout, co = g - n * p.Cout;
+  const int HW = p.OH * p.OW;
+  const float bias = p.bias ? p.bias[co] : 0.f;
+  const float dsc = p.dmsc[n * p.dmC + co], dsh = p.dmsh[n * p.dmC + co];
+  const float* dmb = p.dm + n * p.dmns + (int64_t)co * HW;
+  float* ob = p.out + n * p.ons + (int64_t)co * HW;
+  float v[16], tn[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int o = e * 256 + threadIdx.x;
+    float a = 0.f, t = 0.f;
+    if (o < HW) {
+      for (int ks = 0; ks < KS; ++ks) a += p.part[(((int64_t)ks * p.N + n) * p.Cout + co) * HW + o];
+      a += bias;
+      t = dmb[o] * dsc + dsh;
+      a *= vts_act_grad(t, p.dm_act);
+      if (p.accumulate) a += ob[o];
+    }
+    v[e] = a;
+    tn[e] = t;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    s1 += v[e];
+    s2 = fmaf(v[e], tn[e], s2);
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  const float m1 = s1 / (float)HW, m2 = s2 / (float)HW;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int o = e * 256 + threadIdx.x;
+    if (o < HW) ob[o] = dsc * (v[e] - m1 - tn[e] * m2);
+  }
+}
+
 // tile shape (RW, MT) of the full-width variants, as instantiated by VTS_DISPATCH below
 inline void full_tile(int transposed, int stride, int nr, int& rw, int& mt) {
   static const int T[2][2][5][2] = {
@@ -111,7 +157,7 @@ struct StatWs {
   float* p;
   int64_t floats;
 };
-static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw, bool bsums = false);
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw, bool bsums = false, bool in_bwd_ok = false);
 int vts_norm_finalize_partials(const vts_norm_desc* d, const float* part, int spl, hipStream_t st);   // vts_norm.hip
 
 extern "C" int vts_conv4x4(const vts_conv_desc* d, void* stream) { return conv4x4_impl(d, stream, nullptr, nullptr, StatWs{nullptr, 0}); }
@@ -140,10 +186,12 @@ extern "C" int vts_conv4x4_norm(const vts_conv_desc* d, const vts_norm_desc* nd,
 // *slots = 0: plain convolution (the caller runs vts_norm_bwd), else the (S1, S2') pairs per (n, channel) in `part`
 extern "C" int vts_conv4x4_bsums(const vts_conv_desc* d, float* part, int64_t part_floats, int* slots, void* stream) {
   VTS_CHECK_ARG(d && slots && part, "vts_conv4x4_bsums: null pointer");
+  const bool in_bwd_ok = *slots == -1;     // the caller's normalisation is InstanceNorm2d(affine=False): its backward may be applied right here
   *slots = 0;
   int fused = 0;
-  const int rc = conv4x4_impl(d, stream, nullptr, &fused, StatWs{part, part_floats}, true);
+  const int rc = conv4x4_impl(d, stream, nullptr, &fused, StatWs{part, part_floats}, true, in_bwd_ok);
   if (rc == VTS_OK && fused >= 2) *slots = fused - 2;
+  if (rc == VTS_OK && fused == -1) *slots = -1;
   return rc;
 }
 
@@ -153,7 +201,7 @@ extern "C" int vts_norm_stats_from_partials(const vts_norm_desc* nd, const float
 
 static int dispatch_full(const vts_conv_desc* d, const ConvK& k, int nr, int N, hipStream_t st);
 
-static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw, bool bsums) {
+static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_desc* nd, int* fused, StatWs sw, bool bsums, bool in_bwd_ok) {
   VTS_CHECK_ARG(d && d->in0.data && d->w && d->out, "vts_conv4x4: null pointer");
   VTS_CHECK_ARG(d->stride == 1 || d->stride == 2, "vts_conv4x4: stride %d unsupported", d->stride);
   VTS_CHECK_ARG(d->Cout >= 1, "vts_conv4x4: Cout %d", d->Cout);
@@ -294,6 +342,15 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
         VTS_CHECK_LAUNCH("vts_conv4x4 split epilogue + instance norm");
         vts_set_kernel("conv4x4_kernel<%d, %d, 1, 1, 2, 4, false, 0>+ksplit+in", d->transposed ? 1 : 0, d->stride);
         *fused = 1;
+        return VTS_OK;
+      }
+      static const int fuse_inbwd = getenv("VTS_FUSE_SPLIT_INBWD") ? atoi(getenv("VTS_FUSE_SPLIT_INBWD")) : 1;
+      if (bsums && in_bwd_ok && fused && fuse_inbwd && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && d->dmask.data && d->dmask.scale &&
+          d->dmask.shift && d->dmask.C == d->Cout) {
+        hipLaunchKernelGGL(conv_split_epilogue_inbwd_kernel, dim3(N * d->Cout), dim3(256), 0, st, k, KS);
+        VTS_CHECK_LAUNCH("vts_conv4x4 split epilogue + instance norm backward");
+        vts_set_kernel("conv4x4_kernel<%d, %d, 1, 1, 2, 4, false, 0>+ksplit+inbwd", d->transposed ? 1 : 0, d->stride);
+        *fused = -1;
         return VTS_OK;
       }
       hipLaunchKernelGGL(conv_split_epilogue_kernel, dim3((unsigned)cdiv64((int64_t)d->OH * d->OW, 256), d->Cout, N), dim3(256), 0, st, k, KS);

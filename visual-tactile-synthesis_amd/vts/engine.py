@@ -265,7 +265,7 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
         # (the tensor goes straight into the InstanceNorm backward of the block below unless it is the un-normalised innermost feature
         #  or the split point, whose two lane contributions are summed first: there the epilogue also emits that backward's sums)
         ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc,
-                    bwd_sums=(i != nd - 1) and not (lane_mode and i == nls - 1))
+                    bwd_sums="in" if (i != nd - 1) and not (lane_mode and i == nls - 1) else False)
         if skip is not None:
             tgt, acc = add_grad_list(dfeat, i, skip.data.shape, dev)
             wv = blk.weight.view(-1)[c_in0 * outer * 16:]
@@ -334,7 +334,7 @@ def _unet_backward_encoder(G, ctx, dfeat, feats, nd, dev, sq):
             cin = blk.weight.shape[1]
             tgt, acc = add_grad_list(dfeat, i - 1, feats[i - 1].data.shape, dev)
             ops.conv4x4(Act(g), blk.weight, 16, cin * 16, cin, tgt, stride=2, pad=1, transposed=True, dmask=feats[i - 1],
-                        dmask_act=LRELU, accumulate=acc, bwd_sums=i - 1 > 0)     # the last contribution to dfeat[i-1]: its InstanceNorm backward is next
+                        dmask_act=LRELU, accumulate=acc, bwd_sums="in" if i - 1 > 0 else False)     # the last contribution to dfeat[i-1]: its InstanceNorm backward is next
         dfeat[i] = None
     sq.join()
 

@@ -194,9 +194,11 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
         # backward-data convolution in front of a normalisation backward: the epilogue also emits that backward's sums; `out` carries
         # them to norm_bwd (BSUMS: out tensor -> (partials, slots)), which then runs its apply pass only
         part = torch.empty(int(lib.vts_conv4x4_norm_ws_floats(C.byref(d))), dtype=torch.float32, device=x.device)
-        slots = C.c_int(0)
+        slots = C.c_int(-1 if bwd_sums == "in" else 0)     # "in": the normalisation behind `out` is InstanceNorm2d(affine=False)
         _run(label, nbytes, flops, lib.vts_conv4x4_bsums, C.byref(d), part.data_ptr(), part.numel(), C.byref(slots), L.stream())
-        if slots.value:
+        if slots.value == -1:        # the k-split epilogue applied that backward itself: norm_bwd(out, ...) is a no-op
+            BSUMS[out.data_ptr()] = (None, -1, out)
+        elif slots.value:
             BSUMS[out.data_ptr()] = (part, slots.value, out)
         else:
             BSUMS.pop(out.data_ptr(), None)
@@ -953,6 +955,10 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
         global DETAIL
         DETAIL = "%s N%d %dx%dx%d%s" % ("BN" if mode else "IN", n, c, h, w, " groups %s" % list(groups) if groups else "")
     pre = BSUMS.pop(dy.data_ptr(), None)
+    if pre is not None and pre[2] is dy and pre[1] == -1:
+        if mode != 0 or dgamma is not None:
+            raise RuntimeError("conv4x4(bwd_sums='in') applied an InstanceNorm backward, but norm_bwd is asked for mode %d" % mode)
+        return dy
     if pre is not None and pre[2] is dy:
         if TIMER is not None:
             DETAIL += " from %d epilogue slots" % pre[1]
