@@ -521,6 +521,10 @@ int vts_spe_grid(float* out, int64_t out_nstride, int N, int H, int W, int dim, 
 int vts_mask_candidates(const float* M, int N, int H, int W, uint8_t* cand, int* row_count, void* stream);
 int vts_mask_select(const uint8_t* cand, const int* row_prefix, int N, int H, int W, const int64_t* ranks, int K, int* offx,
                     int* offy, void* stream);
+/* ranks[n, 0..K) <- K distinct uniform ranks in [0, row_prefix[n][H-14]) -- random.sample(range(candidates), K) of the same sampler
+ * (models/model_utils.py:217), drawn on the device from (seed, image, draw) so that the host never waits for the candidate count
+ * (Floyd's algorithm: every K-subset equally likely; K <= 1024). */
+int vts_mask_sample_ranks(const int* row_prefix, int N, int H, int K, uint64_t seed, int64_t* ranks, void* stream);
 
 /* Fused Adam over a flat fp32 buffer (torch.optim.Adam defaults; sinskitG_model.py:589-599).
  * step_count: 1-based step index; grad_scale multiplies the gradient first (1/world for DDP mean). */

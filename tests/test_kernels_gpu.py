@@ -740,6 +740,43 @@ def test_mask_candidates_and_select():
     assert ox.cpu().tolist() == exp_x and oy.cpu().tolist() == exp_y
 
 
+def test_device_side_rank_sampler_draws_distinct_uniform_ranks():
+    """vts_mask_sample_ranks = random.sample(range(candidates), K) (models/model_utils.py:217) on the device: K distinct ranks below
+    every image's own candidate count, a function of the seed only, every rank equally likely; fewer candidates than K wrap"""
+    from vts import ops
+
+    dev = _dev()
+    N, H, W, K = 3, 64, 80, 32
+    M = torch.zeros(N, 1, H, W)
+    M[0, 0, 20:40, 10:50] = 1
+    M[1, 0, 5:8, 5:9] = 1
+    M[2, 0, 30, 40] = 1
+    cand, prefix = ops.mask_candidates(M.to(dev))
+    counts = prefix[:, -1].tolist()
+    assert counts == [int(c) for c in cand.view(N, -1).sum(1).tolist()] and min(counts) > K
+    r1 = ops.mask_sample_ranks(prefix, H, K, 1234, torch.empty(N, K, dtype=torch.int64, device=dev)).cpu()
+    r2 = ops.mask_sample_ranks(prefix, H, K, 1234, torch.empty(N, K, dtype=torch.int64, device=dev)).cpu()
+    r3 = ops.mask_sample_ranks(prefix, H, K, 1235, torch.empty(N, K, dtype=torch.int64, device=dev)).cpu()
+    assert torch.equal(r1, r2) and not torch.equal(r1, r3)
+    for n in range(N):
+        assert len(set(r1[n].tolist())) == K and 0 <= int(r1[n].min()) and int(r1[n].max()) < counts[n]
+    # the ranks resolve to candidate positions (the consumer of the ranks)
+    offx, offy = ops.mask_select(cand, prefix, r1.to(dev), H, W)
+    assert bool(cand[torch.arange(N).repeat_interleave(K), offy.long().cpu(), offx.long().cpu()].all())
+    # uniformity: image 2 has 17 x 17 = 289 candidates; over 400 seeds every rank is drawn about 400 * 32 / 289 = 44 times
+    hist = torch.zeros(counts[2])
+    for seed in range(400):
+        r = ops.mask_sample_ranks(prefix, H, K, seed * 7919 + 1, torch.empty(N, K, dtype=torch.int64, device=dev)).cpu()
+        hist += torch.bincount(r[2], minlength=counts[2])
+    assert float(hist.min()) > 15 and float(hist.max()) < 80 and abs(float(hist.mean()) - 400 * K / counts[2]) < 1e-3
+    # fewer candidates than K (the reference raises there): ranks wrap, nothing out of range
+    M1 = torch.zeros(1, 1, H, W)
+    M1[0, 0, 0, 0] = 1
+    c1, p1 = ops.mask_candidates(M1.to(dev))
+    rw = ops.mask_sample_ranks(p1, H, 16, 5, torch.empty(1, 16, dtype=torch.int64, device=dev)).cpu()
+    assert int(p1[0, -1]) < 16 and int(rw.max()) < int(p1[0, -1])
+
+
 @pytest.mark.parametrize("allneg", [False, True])
 def test_patchnce(allneg):
     from vts import ops

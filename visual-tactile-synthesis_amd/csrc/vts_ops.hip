@@ -738,6 +738,48 @@ extern "C" int vts_mask_candidates(const float* M, int N, int H, int W, uint8_t*
   return VTS_OK;
 }
 
+// K DISTINCT uniform ranks in [0, c) per image, c = the image's candidate count (row_prefix[n][Hc]): random.sample(range(c), K) of the
+// reference (models/model_utils.py:217) without the host in the loop -- the count lives on the device, and fetching it made the host wait
+// for the whole upload queue before it could enqueue the step.  Floyd's algorithm (every K-subset equally likely), one wave per image:
+// for j = c - K .. c - 1: t = uniform[0, j]; insert t, or j if t is already in the set (membership test across the lanes).
+// Counter-based generator: splitmix64 of (seed, image, draw); t = mulhi64(hash, j + 1).  c < K (the reference raises): ranks wrap.
+__device__ __forceinline__ unsigned long long vts_splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(64) void mask_sample_ranks_kernel(const int* __restrict__ row_prefix, int Hc, int K, unsigned long long seed,
+                                                               long long* __restrict__ ranks) {
+  __shared__ long long S[1024];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const long long c = row_prefix[(long long)n * (Hc + 1) + Hc];
+  if (c < K) {
+    for (int q = lane; q < K; q += 64) ranks[(long long)n * K + q] = c > 0 ? q % c : 0;
+    return;
+  }
+  for (int i = 0; i < K; ++i) {
+    const long long j = c - K + i;
+    const unsigned long long h = vts_splitmix64(vts_splitmix64(seed ^ ((unsigned long long)n * 0xD1B54A32D192ED03ull)) + (unsigned long long)i);
+    const long long t = (long long)__umul64hi(h, (unsigned long long)(j + 1));
+    bool hit = false;
+    for (int q = lane; q < i; q += 64) hit |= S[q] == t;
+    const bool any = __any(hit);
+    __syncthreads();
+    if (lane == 0) S[i] = any ? j : t;
+    __syncthreads();
+  }
+  for (int q = lane; q < K; q += 64) ranks[(long long)n * K + q] = S[q];
+}
+
+extern "C" int vts_mask_sample_ranks(const int* row_prefix, int N, int H, int K, uint64_t seed, int64_t* ranks, void* stream) {
+  VTS_CHECK_ARG(row_prefix && ranks && N >= 1 && H > 14 && K >= 1 && K <= 1024, "vts_mask_sample_ranks: bad args (K <= 1024)");
+  hipLaunchKernelGGL(mask_sample_ranks_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, row_prefix, H - 14, K, (unsigned long long)seed,
+                     (long long*)ranks);
+  VTS_CHECK_LAUNCH("vts_mask_sample_ranks");
+  return VTS_OK;
+}
+
 extern "C" int vts_mask_select(const uint8_t* cand, const int* row_prefix, int N, int H, int W, const int64_t* ranks, int K, int* offx,
                                int* offy, void* stream) {
   VTS_CHECK_ARG(cand && row_prefix && ranks && offx && offy && K >= 1, "vts_mask_select: bad args");

@@ -445,26 +445,13 @@ class SinSKITGModel(BaseModel):
             # where the host already synchronises for the H2D copies (model_utils.py:212-216)
             self._cand, self._cand_prefix = ops.mask_candidates(
                 self.M, self._buf("cand", (n, h - 14, w - 14), torch.uint8), self._buf("cand_prefix", (n, h - 14 + 1), torch.int32))
-            # the candidate counts go to the host for random.sample: asynchronously into pinned memory; the host waits for them only
-            # when it draws the ranks (_prepare_ranks), so the H2D copies of this batch are already queued behind the previous step
-            pin = self._bufs.get("cand_count_pin")
-            if pin is None or pin.numel() != n:
-                pin = self._bufs["cand_count_pin"] = torch.empty(n, dtype=torch.int32).pin_memory()
-                self._cand_evt = torch.cuda.Event()
-            # the COUNTS the host needs for random.sample come from a second evaluation on the copy stream (0.15 ms), right behind
-            # the mask's upload: queued on the launch stream they would sit behind the previous step's graphs, the host would wait for
-            # that whole step before it could enqueue the next one, and the GPU would idle for the enqueue time in between
-            cs = self._copy_stream
-            with torch.cuda.stream(cs):
-                _, pre2 = ops.mask_candidates(self._bufs["%s_M_stage%d" % (phase, self._stage_parity)],
-                                              self._buf("cand_side", (n, h - 14, w - 14), torch.uint8),
-                                              self._buf("cand_prefix_side", (n, h - 14 + 1), torch.int32))
-                pin.copy_(pre2[:, -1], non_blocking=True)
-                self._cand_evt.record(cs)
-            self._cand_count = None
             k = self.opt.add_fake_T_sample_size
             self._ranks = self._buf("more_ranks", (n, k), torch.int64)
-            self._more_img = self._load("more_img", torch.arange(n, dtype=torch.int32).repeat_interleave(k), torch.int32)
+            mi = self._bufs.get("more_img")          # image index of every extra patch: a constant of (n, k), built on the device once
+            if mi is None or mi.numel() != n * k:
+                mi = self._buf("more_img", (n * k,), torch.int32)
+                mi.copy_(torch.arange(n, dtype=torch.int32, device=self.device).repeat_interleave(k))
+            self._more_img = mi
         done = torch.cuda.Event()
         done.record()        # every reader of this batch's staging buffers has been queued on the launch stream
         self._stage_done[self._stage_parity] = done
@@ -556,17 +543,18 @@ class SinSKITGModel(BaseModel):
         if not (self.opt.use_more_fakeT and "D2" in self.model_names):
             return
         k = self.opt.add_fake_T_sample_size
+        if self._draws is None and os.environ.get("VTS_HOST_RANKS", "0") != "1":
+            # drawn on the device (vts_mask_sample_ranks: Floyd's algorithm over the candidate count the device already holds, seeded from
+            # Python's `random` so that random.seed() still fixes the run).  The host used to fetch that count first -- a second evaluation
+            # of the candidate map on the copy stream, a pinned read-back and a spin on its event, ~5 ms per iteration with a fresh batch
+            # (tools/prof_fresh.py) -- and to upload the ranks it drew.
+            ops.mask_sample_ranks(self._cand_prefix, self.M.shape[2], k, random.getrandbits(64), self._ranks)
+            return
         if self._draws is not None:
             ranks = torch.as_tensor(self._draws["more_idx"]).long()
         else:
-            if self._cand_count is None:
-                if os.environ.get("VTS_EVT_SPIN", "1") == "1":
-                    while not self._cand_evt.query():   # spin: a sleeping event wait was measured to stall ~70 ms every few iterations on this stack
-                        pass
-                else:
-                    self._cand_evt.synchronize()
-                self._cand_count = self._bufs["cand_count_pin"].tolist()
-            ranks = torch.tensor([random.sample(range(c), k) for c in self._cand_count], dtype=torch.int64)
+            counts = self._cand_prefix[:, -1].tolist()       # (VTS_HOST_RANKS=1: the host-side draw of round 2, synchronising)
+            ranks = torch.tensor([random.sample(range(c), k) for c in counts], dtype=torch.int64)
         pin = self._bufs.get("ranks_pin")
         if pin is None or pin.shape != ranks.shape:
             pin = self._bufs["ranks_pin"] = torch.empty(ranks.shape, dtype=torch.int64).pin_memory()

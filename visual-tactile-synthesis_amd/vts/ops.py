@@ -1128,6 +1128,14 @@ def mask_candidates(M, cand=None, prefix=None):
     return cand, prefix
 
 
+def mask_sample_ranks(prefix, h, k, seed, ranks):
+    """ranks [n, k] int64 <- k distinct uniform ranks below every image's candidate count (prefix [n, h - 14 + 1] of mask_candidates)"""
+    lib = L.load()
+    n = prefix.shape[0]
+    L.check(lib.vts_mask_sample_ranks(prefix.data_ptr(), n, h, k, seed & 0xFFFFFFFFFFFFFFFF, ranks.data_ptr(), L.stream()), "vts_mask_sample_ranks")
+    return ranks
+
+
 def mask_select(cand, prefix, ranks, h, w):
     lib = L.load()
     n, k = ranks.shape
