@@ -692,6 +692,16 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   }
 }
 
+// Tile width by map width (round 3): the discriminator maps are 513 / 257 / 129 / 130 / 65 / 66 / 33 / 34 wide, and a 64-column tile
+// covers 129 columns with 192 (a third of every MFMA row group multiplies nothing).  Where three 16-column groups per tile (48 columns)
+// cover the row with >= 7 % fewer columns than the table's width, the dispatch takes the MT = 3 instance (VTS_MT3=0: never).
+inline bool vts_prefer_mt3(const ConvK& k, bool phases4, int mt_default) {
+  static const int on = getenv("VTS_MT3") ? atoi(getenv("VTS_MT3")) : 1;
+  const int GW = phases4 ? (k.OW + 1) / 2 : k.OW;
+  const int c3 = cdiv(GW, 48) * 48, cd = cdiv(GW, 16 * mt_default) * 16 * mt_default;
+  return on && c3 * 100 < cd * 93;
+}
+
 template <int MODE, int S, int NR, int RW, int MT, int CK>
 int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;

@@ -10,7 +10,7 @@ int vts_conv_full_m0s2(const ConvK& k, int nr, int N, hipStream_t st) {
   }
   switch (nr) {
     case 1: return launch<0, 2, 1, 2, 4, 4>(k, N, st);
-    case 2: return launch<0, 2, 2, 1, 4, 4>(k, N, st);
+    case 2: return vts_prefer_mt3(k, false, 4) ? launch<0, 2, 2, 1, 3, 4>(k, N, st) : launch<0, 2, 2, 1, 4, 4>(k, N, st);
     case 3: return launch<0, 2, 3, 1, 4, 4>(k, N, st);
     case 4: return launch<0, 2, 4, 1, 2, 4>(k, N, st);
     default: return launch<0, 2, 5, 1, 2, 4>(k, N, st);

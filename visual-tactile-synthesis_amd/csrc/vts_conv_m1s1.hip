@@ -4,7 +4,7 @@
 int vts_conv_full_m1s1(const ConvK& k, int nr, int N, hipStream_t st) {
   switch (nr) {
     case 1: return launch<1, 1, 1, 2, 4, 4>(k, N, st);
-    case 2: return launch<1, 1, 2, 1, 4, 4>(k, N, st);
+    case 2: return vts_prefer_mt3(k, false, 4) ? launch<1, 1, 2, 1, 3, 4>(k, N, st) : launch<1, 1, 2, 1, 4, 4>(k, N, st);
     case 3: return launch<1, 1, 3, 1, 4, 4>(k, N, st);
     case 4: return launch<1, 1, 4, 1, 2, 4>(k, N, st);
     default: return launch<1, 1, 5, 1, 2, 4>(k, N, st);

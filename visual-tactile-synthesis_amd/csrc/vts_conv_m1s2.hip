@@ -3,7 +3,7 @@
 
 int vts_conv_full_m1s2(const ConvK& k, int nr, int N, hipStream_t st) {
   switch (nr) {
-    case 1: return launch<1, 2, 1, 1, 4, 4>(k, N, st);
+    case 1: return vts_prefer_mt3(k, true, 4) ? launch<1, 2, 1, 1, 3, 4>(k, N, st) : launch<1, 2, 1, 1, 4, 4>(k, N, st);
     case 2: return launch<1, 2, 2, 1, 2, 4>(k, N, st);
     case 3: return launch<1, 2, 3, 1, 2, 4>(k, N, st);
     case 4: return launch<1, 2, 4, 1, 1, 4>(k, N, st);
