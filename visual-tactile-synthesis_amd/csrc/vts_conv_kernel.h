@@ -584,7 +584,9 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     stamp(7);
     return;
   }
-  // the LDS epilogue below serves one tile per workgroup (k-split partials, VTS_DIRECT_EPI=0)
+  // the LDS epilogue below serves one tile per workgroup (k-split partials, VTS_DIRECT_EPI=0).  Only the instance the small-grid path
+  // launches (NR 1, RW 1, MT 2) carries it: the kernel bodies are 47 - 85 KB against a 64 KB instruction cache shared by two CUs
+  if constexpr (!(NR == 1 && RW == 1 && MT == 2)) return;
 
   // ---- epilogue: accumulators -> LDS (channel planes) -> coalesced, vectorised global stores.
   // C/D layout of a 16x16 tile: col (cout) = lane&15, row (pixel) = (lane>>4)*4 + reg.
@@ -726,6 +728,10 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
     if (run < 1) run = 1;
   }
   dim3 grid(cdiv(tiles_x, run), tiles_y, N * CG * KS);
+  if (!(NR == 1 && RW == 1 && MT == 2) && (k.part || !k.direct_epi)) {
+    vts_set_error("vts_conv4x4: this tile instance has no LDS epilogue (VTS_DIRECT_EPI=0 / output beyond 30-bit offsets)");
+    return VTS_ERR_UNSUPPORTED;
+  }
   // VTS_CONV_TRACE=<file>: phase time stamps of every workgroup of the launches whose kernel matches VTS_CONV_TRACE_KERNEL
   // ("MODE,S,NR,RW,MT"), appended as text rows (tools/conv_trace.py draws the occupancy / phase overlap from them)
   static const char* trace_path = getenv("VTS_CONV_TRACE");
