@@ -661,7 +661,7 @@ int px_launch(const PxK& k, int N, int stats, hipStream_t st) {
 // (at most one of them); *stat_spl = slots per (n, channel) written.
 int vts_conv_px_try(const vts_conv_desc* d, hipStream_t st, float* stat_part, float* bsum_part, int64_t part_floats, int* stat_spl) {
   static const int enabled = getenv("VTS_NO_PX") ? 0 : 1;
-  // measured (tools/mb_px.py, profiles/r03e_px_microbench.txt): the 4x4x1 MFMA sustains 11 - 13 cycles per instruction (8 nominal), so
+  // measured (tools/mb_px.py, profiles/r03d_px_microbench.txt): the 4x4x1 MFMA sustains 11 - 13 cycles per instruction (8 nominal), so
   // the mapping pays while the padding of the 16x16x4 tiles costs more than that: up to 12 output channels (9 -> 10 at 1024^2: 71 -> 64 us,
   // 4 -> 8 / 7 -> 8: 73 -> 54 / 59 -> 41 us, 3 -> 10 with mask: 37 -> 32 us); at 16 - 20 channels conv4x4_kernel is 15 - 30 % faster
   static const int max_nb = getenv("VTS_PX_MAX_NB") ? atoi(getenv("VTS_PX_MAX_NB")) : 3;
