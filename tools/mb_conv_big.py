@@ -45,6 +45,22 @@ def case(N, Cin, H, Cout, stride, pad, transposed=False, act=0, dmask=False, acc
 
 if __name__ == "__main__":
     print({k: v for k, v in os.environ.items() if k.startswith("VTS_")})
+    if os.environ.get("VTS_MB_INNER"):
+        case(4, 80, 64, 80, 2, 1, act=1)                        # down4
+        case(4, 80, 32, 80, 2, 1, act=1)                        # down5
+        case(4, 80, 16, 80, 2, 1, act=1)                        # down6
+        case(4, 80, 8, 80, 2, 1, act=1)                         # down7
+        case(4, 592, 4, 80, 2, 1, transposed=True, act=2)       # up7
+        case(4, 160, 8, 80, 2, 1, transposed=True, act=2)       # up6
+        case(4, 160, 16, 80, 2, 1, transposed=True, act=2)      # up5
+        case(4, 160, 32, 80, 2, 1, transposed=True, act=2)      # up4
+        case(4, 80, 8, 80, 2, 1, dmask=True, affine=False)      # backward-data of up6's input half
+        case(4, 80, 16, 80, 2, 1, dmask=True, affine=False)
+        case(4, 80, 32, 80, 2, 1, dmask=True, affine=False)
+        case(4, 80, 4, 80, 2, 1, transposed=True, dmask=True, affine=False)    # backward-data of down7
+        case(4, 80, 8, 80, 2, 1, transposed=True, dmask=True, affine=False)
+        case(4, 80, 16, 80, 2, 1, transposed=True, dmask=True, affine=False)
+        sys.exit(0)
     case(4, 160, 64, 40, 2, 1, transposed=True, act=2)      # up3
     case(4, 80, 128, 20, 2, 1, transposed=True, act=2)      # up2
     case(4, 40, 256, 10, 2, 1, transposed=True, act=2)      # up1
