@@ -587,3 +587,38 @@ def test_frechet_distance_matches_reference(golden_dir):
         assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (i, got, ref, nets.frechet_distance(f1, f2))
     f1, _ = nets.frechet_case(0, seed)
     assert abs(float(ops.frechet_distance(f1.to(dev), f1.to(dev)).cpu())) < 1e-4      # identical sets: 0
+
+
+@pytest.mark.parametrize("size", [256, 512])
+def test_generator_gradients_serial_schedule_equals_lane_schedule(size, monkeypatch):
+    """VTS_PARALLEL_SCALES=0 (one stream: up{i} and up{i}_T accumulate into the split-point gradient by two calls) against the
+    two-lane schedule, at the crop sizes whose inner maps take the k-split path (N < 8, maps <= 32x32): the fused InstanceNorm
+    backward of the k-split epilogue must not run on a partial split-point gradient (round-3 advisor finding)."""
+    from models import create_model
+    from options.train_options import TrainOptions
+    from vts import engine
+
+    opt = TrainOptions(cmd_line=FLAGS % (size, 1)).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    G = model.netG
+    G.load_state_dict(detrand.test_weights(nets.g_param_shapes(), 77))
+    dev = torch.device("cuda:0")
+    x = detrand.uniform((1, 9, size, size), 77, "g_in").to(dev)
+    cot = detrand.uniform((1, 5, size, size), 77, "g_cot").to(dev)
+    grads = {}
+    for par in (True, False):
+        monkeypatch.setattr(engine, "PARALLEL_SCALES", par)
+        for p in G.parameters():
+            p.grad.zero_()
+        y, ctx = engine.unet_forward(G, x)
+        engine.unet_backward(G, ctx, (cot * (1.0 - y * y)).contiguous())
+        torch.cuda.synchronize()
+        grads[par] = {k: p.grad.clone() for k, p in G.named_parameters()}
+    worst = 0.0
+    for k in grads[True]:
+        if null_grad_bias("G", k):
+            continue
+        worst = max(worst, rel(grads[False][k], grads[True][k]))
+    assert worst < 2e-5, worst

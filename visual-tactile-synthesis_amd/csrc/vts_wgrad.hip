@@ -510,6 +510,9 @@ __global__ __launch_bounds__(256) void wgrad4x4_ns_kernel(const WgK p) {
           for (int h = 0; h < CHT; ++h) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[h], acc[t][h], 0, 0, 0);
       }
     }
+    // (round 4, measured and dropped: a two-set register pipeline of the fragment reads -- reads of k-step j + 1 issued before the MFMAs
+    //  of step j, unconditional and clamped, scheduling barriers -- was 3 - 8 % SLOWER on every shape of tools/mb_wgrad.py and + 0.1 ms on
+    //  the step: the co-resident workgroups already cover the LDS latency, the extra registers and scalar bookkeeping only cost.)
     __syncthreads();
   }
 
@@ -1159,10 +1162,18 @@ bool dispatch_ns(const WgK& k, const Plan& pl, hipStream_t st) {
 
 }  // namespace
 
+// round-4 member (vts_wgrad_run.hip): producer / consumer workgroups, <= 256 partial copies
+int vts_wgrad_run_copies(const vts_wgrad_desc* d);
+int vts_wgrad_run_try(const vts_wgrad_desc* d, float* ws, hipStream_t st);
+
 extern "C" int64_t vts_wgrad4x4_ws_floats(const vts_wgrad_desc* d) {
   if (!d) return 0;
-  const Plan pl = make_plan(d);
   const int64_t CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
+  if (d->lo0.data && d->hi0.data && (d->stride == 1 || d->stride == 2)) {
+    const int copies = vts_wgrad_run_copies(d);
+    if (copies > 0) return (int64_t)copies * CL * CH * 16;
+  }
+  const Plan pl = make_plan(d);
   return (int64_t)pl.pw * CL * CH * 16;
 }
 
@@ -1172,6 +1183,21 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   // lo x hi window semantics as in vts_conv4x4: hi is zero outside its HH x HW extent, pad may be negative
   VTS_CHECK_ARG(d->LH <= d->HH + 16 && d->LW <= d->HW + 16 && d->pad >= -8 && d->pad <= 8,
                 "vts_wgrad4x4: lo %dx%d / pad %d implausible for hi %dx%d s%d", d->LH, d->LW, d->pad, d->HH, d->HW, d->stride);
+  {
+    const int copies = vts_wgrad_run_copies(d);
+    if (copies > 0) {
+      const int rc = vts_wgrad_run_try(d, ws, (hipStream_t)stream);
+      if (rc != VTS_ERR_UNSUPPORTED) {
+        if (rc != VTS_OK || d->defer) return rc;
+        const int64_t nel_r = (int64_t)(d->lo0.C + (d->lo1.data ? d->lo1.C : 0)) * (d->hi0.C + (d->hi1.data ? d->hi1.C : 0)) * 16;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel_r, 64)), dim3(1024), 0, (hipStream_t)stream, ws, nel_r, copies, d->dw, d->accumulate);
+        VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
+        return VTS_OK;
+      }
+      vts_set_error("vts_wgrad4x4: the producer / consumer plan has no kernel instance");
+      return VTS_ERR_UNSUPPORTED;
+    }
+  }
   const Plan pl = make_plan(d);
   WgK k;
   fill_src(k.lo, d->lo0, d->lo1, d->act_lo);

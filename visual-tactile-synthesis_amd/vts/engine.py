@@ -263,9 +263,10 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
         else:
             tgt, acc = add_grad(dx, id(inp), inp.data.shape)
         # (the tensor goes straight into the InstanceNorm backward of the block below unless it is the un-normalised innermost feature
-        #  or the split point, whose two lane contributions are summed first: there the epilogue also emits that backward's sums)
+        #  or the split point i == nls - 1, where up{i} and up{i}_T BOTH contribute -- as two lanes or, with VTS_PARALLEL_SCALES=0, as
+        #  two accumulating calls: the fused sums (and the k-split epilogue's fused backward) would see only one part of the gradient)
         ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc,
-                    bwd_sums="in" if (i != nd - 1) and not (lane_mode and i == nls - 1) else False)
+                    bwd_sums="in" if (i != nd - 1) and not (nls > 0 and i == nls - 1) else False)
         if skip is not None:
             tgt, acc = add_grad_list(dfeat, i, skip.data.shape, dev)
             wv = blk.weight.view(-1)[c_in0 * outer * 16:]
