@@ -132,6 +132,9 @@ def kernel_roofline(model, batch_dict, detail_path=None):
             for k, (c, t, nb, fl) in rows:
                 f.write("%4d %8.3f %8.1f %8.2f %8.1f  %s\n" % (c, t * 1e3, t / c * 1e6, fl / t / 1e12, nb / t / 1e9, k))
     total = sum(a[1] for a in agg.values())
+    # Roofline time of the WHOLE step: every launch's algorithmic max(bytes / HBM peak, flops / fp32 MFMA peak), summed (launches without a
+    # work model -- reductions of partials, finalisers -- count as zero: they are overhead, not work).  main() divides it by ms_per_step.
+    step_t_roof = sum(max(nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)) for _, nbytes, flops, _, _, _ in rec)
     # The dominant KERNEL = the kernel template (all of its instances: tile shapes are a dispatch detail) with the largest total time.
     # Labels naming several kernels of one C call ("a_kernel+b_kernel") are not one kernel.  Its launches are HBM-bound on some
     # shapes and MFMA-bound on others (per-launch t_roof = max(bytes / BW, flops / P)); `bound` is the class holding more of the
@@ -216,6 +219,9 @@ def kernel_roofline(model, batch_dict, detail_path=None):
                           "flops_per_launch": round(v[3] / v[0]), "frac": round(v[4] / v[1], 4)} for k, v in inst]
     breakdown = sorted(((k, v[1] * 1e3, v[0]) for k, v in agg.items()), key=lambda x: -x[1])
     roof["breakdown_ms"] = {k: round(ms, 3) for k, ms, _ in breakdown[:8]}
+    roof["step_t_roof_ms"] = step_t_roof * 1e3
+    roof["launches_per_step_all"] = len(rec)
+    roof["serialized_kernel_ms"] = total * 1e3
     return roof
 
 
@@ -253,29 +259,37 @@ def cpu_baseline(size, style_dim, netG="unet256_custom", warmup=3, steps=10, bud
     timed = sorted(times[warmup:]) or sorted(times[-1:])
     t = timed[len(timed) // 2]
     return {"value": 1.0 / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "median of %d oracle train steps after %d warm-up, N=1, %dx%d, same flags" % (len(timed), min(warmup, len(times) - len(timed)), size, size)}
+            "sample": "median of %d oracle train steps after %d warm-up, N=1, %dx%d, same flags; %d of %d host cores: PyTorch-CPU's convolutions "
+                      "with 3..160 channels stop scaling there and their weight gradient drifts 5e-3 from the single-thread result beyond"
+                      % (len(timed), min(warmup, len(times) - len(timed)), size, size, torch.get_num_threads(), os.cpu_count() or 1)}
 
 
-def infer_bench(args):
-    """Generator-only forward (test() of the model): ms per image, inputs resident in HBM."""
+def infer_measure(args, steps=None, warmup=None):
+    """Generator-only forward (test() of the model, BASELINE config 4: 16 images/GPU): seconds per step, images per step, the options"""
     batch_n = 16 if args.batch == 4 else args.batch
+    steps, warmup = steps or args.steps, warmup or args.warmup
     model, opt = build_model(args.size, batch_n, args.model)
     opt.use_hip_graph = not args.no_graph
     opt.skip_D2_visualisation_pass = bool(args.no_viz)
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
     model.eval()
     model.set_input(make_batch(args.size, batch_n, 0, style_dim), phase="test")
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         model.test()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         model.test()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    return (time.perf_counter() - t0) / steps, batch_n, opt
+
+
+def infer_bench(args):
+    """ms per image, inputs resident in HBM."""
+    dt, batch_n, opt = infer_measure(args)
     emit(json.dumps({
-        "metric": "inference_ms_per_image", "value": dt / args.steps / batch_n * 1e3, "unit": "ms/image", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False,
+        "metric": "inference_ms_per_image", "value": dt / batch_n * 1e3, "unit": "ms/image", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s generator forward (test()), %dx%d, %d images/GPU" % (args.model, args.size, args.size, batch_n),
                    "hip_graph": bool(opt.use_hip_graph)},
@@ -442,10 +456,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model != "pix2pixHD" and not args.lpips:
             cpu = cpu_baseline(args.size, style_dim, netG=args.netG)
         ms = dt / args.steps * 1e3
+        infer_ms = None
+        if world == 1 and args.model != "pix2pixHD" and not args.lpips and args.netG == "unet256_custom" and args.batch == 4:
+            del model                       # (the 16-image forward builds its own model: BASELINE config 4)
+            torch.cuda.empty_cache()
+            idt, ib, _ = infer_measure(args, steps=50, warmup=5)
+            infer_ms = idt / ib * 1e3
         out = {
             "metric": "train_images_per_sec", "value": world * args.batch * args.steps / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_spread": {k: round(v, 4) for k, v in spread.items()},
             "ms_per_step_fresh_input": fresh_ms, "images_per_sec_fresh_input": (args.batch * 1e3 / fresh_ms) if fresh_ms else None,
+            "inference_ms_per_image": infer_ms,                                         # generator forward, 16 images (BASELINE config 4)
+            "step_roofline_frac": (roof["step_t_roof_ms"] / ms) if roof else None,      # sum of per-launch roofline times / ms_per_step
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {

@@ -430,6 +430,14 @@ int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, float* dx, i
 /* out [NC][H/2 + 2 pad][W/2 + 2 pad] = zero-padded MaxPool2d(2, 2)(relu(z)), z [NC][H][W]: replaces ReLU + MaxPool2d + the next
  * convolution's padding (torchvision vgg features) */
 int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream);
+/* AlexNet variant of LPIPS (the reference's test-phase eval_LPIPS = lpips.LPIPS(net="alex"), models/sinskitG_model.py:501; pip package
+ * `lpips`, lpips/pretrained_networks.py:alexnet over torchvision alexnet.features):
+ *   vts_maxpool3s2_relu_pad  out[nc][pad + y][pad + x] = max over the 3 x 3 window at (2y, 2x) of relu(z), OH = (H - 3) / 2 + 1, zero border of
+ *                            `pad` pixels (MaxPool2d(3, 2) behind a ReLU + the next convolution's zero padding in one pass)
+ *   vts_s2d4_pad             space-to-depth by 4 of x zero-padded by `pad`: out[n][(c * 4 + i) * 4 + j][Y][X] = xp[n][c][4Y + i][4X + j], Y < OH,
+ *                            X < OW -- the 11 x 11 stride-4 stem becomes a valid 3 x 3 convolution over 16 C channels (vts_conv3x3_wide) */
+int vts_maxpool3s2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream);
+int vts_s2d4_pad(const float* x, int N, int C, int H, int W, int pad, int OH, int OW, float* out, void* stream);
 /* gz [NC][H][W] = adjoint of relu -> MaxPool2d(2, 2) applied to g [NC][H/2][W/2] (first-maximum tie rule of PyTorch) */
 int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int H, int W, float* gz, void* stream);
 /* out [NC][H + 2 pad][W + 2 pad] = zero-padded (g + g2) * (z > 0); g or g2 may be NULL: ReLU backward + the padding of the adjoint conv */

@@ -653,6 +653,38 @@ def golden_sifid(seed=4242):
     print("wrote sifid.npz", out)
 
 
+def lpips_metric_inputs(seed=5151):
+    from oracle import detrand
+    real_I, fake_I = detrand.uniform((2, 3, 72, 88), seed, "rI"), 1.2 * detrand.uniform((2, 3, 72, 88), seed, "fI")
+    real_T, fake_T = 0.3 * detrand.uniform((5, 2, 32, 32), seed, "rT"), 0.6 * detrand.uniform((5, 2, 32, 32), seed, "fT")
+    return real_I, fake_I, real_T, fake_T
+
+
+def golden_lpips_metrics(seed=5151):
+    """I_LPIPS / T_LPIPS through the REFERENCE's compute_evaluation_metric (models/model_utils.py:475-478, 521-527 ->
+    models/tactile_patch_fid.py:compute_touch_lpips_loss) for both backbones the reference evaluates with: `eval_LPIPS` =
+    lpips.LPIPS(net="vgg") while training / validating and lpips.LPIPS(net="alex") in the test phase (models/sinskitG_model.py:497-501).
+    The only stand-in is the network object (pip package `lpips` and its weights are absent): oracle/perceptual.py:LPIPS, the
+    restatement of the package's published algorithm, on seeded stand-in weights.  Also the module's own values on a seeded pair."""
+    from oracle import detrand, perceptual, ref_import
+
+    ref_import.load()
+    from models import model_utils
+
+    real_I, fake_I, real_T, fake_T = lpips_metric_inputs(seed)
+    out = {"seed": seed}
+    for net in ("vgg", "alex"):
+        lp = perceptual.LPIPS(net=net)
+        with torch.no_grad():
+            m = model_utils.compute_evaluation_metric(["G"], real_I, fake_I, real_T_concat=real_T, fake_T_concat=fake_T,
+                                                      eval_metrics=["I_LPIPS", "T_LPIPS"], eval_LPIPS=lp, device=None)
+            a, b = detrand.uniform((2, 3, 80, 96), seed, "lp_a"), detrand.uniform((2, 3, 80, 96), seed, "lp_b")
+            out["%s/module_val" % net] = lp(a, b).flatten().numpy()
+        out["%s/I_LPIPS" % net], out["%s/T_LPIPS" % net] = float(m["metric_I_LPIPS"]), float(m["metric_T_LPIPS"])
+    np.savez_compressed(os.path.join(GOLD, "lpips_metrics.npz"), **out)
+    print("wrote lpips_metrics.npz", {k: v for k, v in out.items()})
+
+
 def golden_io():
     """util.tensor2im / tensor2arr of the reference (util/util.py:58-122) on a ramp tensor"""
     from oracle import ref_import
@@ -889,5 +921,7 @@ if __name__ == "__main__":
         golden_nets_style_modes()
     if "lpips" in which:
         golden_lpips_step()
+    if "lpipsmetrics" in which:
+        golden_lpips_metrics()
     if "p2pvgg" in which:
         golden_p2p_vgg_step()

@@ -3,7 +3,8 @@ bench.py's cpu_baseline leg may import anything under oracle/).
 
 Two third-party pieces, both absent from /root/reference and from this image:
 
-* `lpips.LPIPS(net="vgg")` -- pip package `lpips` (requirements.txt:12, unpinned; current release 0.1.4, model version "0.1").
+* `lpips.LPIPS(net="vgg")` (and net="alex", the reference's test-phase `eval_LPIPS`, models/sinskitG_model.py:501: the same head on
+  torchvision alexnet.features cut after its five ReLUs) -- pip package `lpips` (requirements.txt:12, unpinned; current release 0.1.4, model version "0.1").
   Call sites: models/sinskitG_model.py:495 (construction), :1711 (I term), :1639-1646 (gx / gy terms), models/model_utils.py:477,
   523-527 (I_LPIPS / T_LPIPS metrics).  Its published algorithm (lpips/lpips.py, lpips/pretrained_networks.py of that release):
       x -> (x - shift) / scale,  shift = (-.030, -.088, -.188), scale = (.458, .448, .450)  (a 1-channel input broadcasts to 3)
@@ -98,16 +99,66 @@ class VggFeatures(nn.Module):
         return feats
 
 
-class LPIPS(nn.Module):
-    """lpips.LPIPS(net='vgg', version='0.1', lpips=True, spatial=False) in eval mode"""
+# torchvision alexnet.features as lpips/pretrained_networks.py:alexnet slices it (relu1 .. relu5 are the five taps):
+#   Conv2d(3, 64, 11, stride 4, padding 2) ReLU | MaxPool2d(3, 2) Conv2d(64, 192, 5, padding 2) ReLU | MaxPool2d(3, 2) Conv2d(192, 384, 3,
+#   padding 1) ReLU | Conv2d(384, 256, 3, padding 1) ReLU | Conv2d(256, 256, 3, padding 1) ReLU
+ALEX_CONVS = ((64, 3, 11, 4, 2), (192, 64, 5, 1, 2), (384, 192, 3, 1, 1), (256, 384, 3, 1, 1), (256, 256, 3, 1, 1))   # (cout, cin, k, stride, pad)
+ALEX_POOL_BEFORE = (False, True, True, False, False)        # MaxPool2d(kernel 3, stride 2) in front of the convolution
+ALEX_FEATURE_INDEX = (0, 3, 6, 8, 10)                       # state-dict key `features.<idx>.weight` of torchvision's alexnet
 
-    def __init__(self, net="vgg", seed=20180111, sd=None, **kw):
+
+def standin_state_alex(seed):
+    """seeded stand-in weights of the AlexNet variant (He-scaled convolutions, small biases, non-negative lin weights)"""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, (co, ci, ks, _, _) in enumerate(ALEX_CONVS):
+        sd["conv%d.weight" % k] = torch.randn(co, ci, ks, ks, generator=g) * (2.0 / (ci * ks * ks)) ** 0.5
+        sd["conv%d.bias" % k] = 0.05 * torch.randn(co, generator=g)
+    for i, (co, _, _, _, _) in enumerate(ALEX_CONVS):
+        sd["lin%d.weight" % i] = torch.rand(1, co, 1, 1, generator=g) * (2.0 / co)
+    return sd
+
+
+class AlexFeatures(nn.Module):
+    """ReLU outputs of the five convolutions of torchvision's AlexNet feature stack"""
+
+    def __init__(self, sd):
         super().__init__()
-        if net != "vgg":
-            raise NotImplementedError("only the VGG16 variant is restated (the reference trains and validates with net='vgg')")
-        sd = sd if sd is not None else standin_state(VGG16_CFG, LPIPS_TAPS, seed)
-        self.net = VggFeatures(VGG16_CFG, LPIPS_TAPS, sd)
-        self.lins = nn.ParameterList([nn.Parameter(sd["lin%d.weight" % i].clone(), requires_grad=False) for i in range(len(LPIPS_TAPS))])
+        self.convs = nn.ModuleList([nn.Conv2d(ci, co, ks, stride=st, padding=pd) for co, ci, ks, st, pd in ALEX_CONVS])
+        with torch.no_grad():
+            for k, m in enumerate(self.convs):
+                m.weight.copy_(sd["conv%d.weight" % k])
+                m.bias.copy_(sd["conv%d.bias" % k])
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        feats = []
+        for k, m in enumerate(self.convs):
+            if ALEX_POOL_BEFORE[k]:
+                x = F.max_pool2d(x, 3, 2)
+            x = F.relu(m(x))
+            feats.append(x)
+        return feats
+
+
+class LPIPS(nn.Module):
+    """lpips.LPIPS(net='vgg' | 'alex', version='0.1', lpips=True, spatial=False) in eval mode.  The reference builds the VGG variant for
+    training / validation (models/sinskitG_model.py:495-499) and the AlexNet variant as `eval_LPIPS` of the test phase (:501)."""
+
+    def __init__(self, net="vgg", seed=None, sd=None, **kw):
+        super().__init__()
+        if net == "alex":
+            sd = sd if sd is not None else standin_state_alex(20180112 if seed is None else seed)
+            self.net = AlexFeatures(sd)
+            ntaps = len(ALEX_CONVS)
+        elif net == "vgg":
+            sd = sd if sd is not None else standin_state(VGG16_CFG, LPIPS_TAPS, 20180111 if seed is None else seed)
+            self.net = VggFeatures(VGG16_CFG, LPIPS_TAPS, sd)
+            ntaps = len(LPIPS_TAPS)
+        else:
+            raise NotImplementedError("lpips.LPIPS(net=%r): the reference uses 'vgg' and 'alex' only" % net)
+        self.lins = nn.ParameterList([nn.Parameter(sd["lin%d.weight" % i].clone(), requires_grad=False) for i in range(ntaps)])
         self.register_buffer("shift", torch.tensor(LPIPS_SHIFT)[None, :, None, None])
         self.register_buffer("scale", torch.tensor(LPIPS_SCALE)[None, :, None, None])
         self.eval()

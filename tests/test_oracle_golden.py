@@ -557,3 +557,58 @@ def test_perceptual_standin_weights_agree_between_product_and_checker():
         assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
     assert prod.feature_indices(prod.VGG16_CFG) == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]      # torchvision vgg16.features conv indices
     assert [chk.feature_index(chk.VGG19_CFG, k) for k in chk.VGG19_TAPS] == [0, 5, 10, 19, 28]           # convs in front of relu{1..5}_1 (Vgg19 slices end at 2, 7, 12, 21, 30)
+
+
+def test_lpips_metrics_both_backbones_match_reference_glue(golden_dir):
+    """I_LPIPS / T_LPIPS as the reference's compute_evaluation_metric produced them on the restated lpips.LPIPS modules (VGG16: training /
+    validation phases; AlexNet: the test phase, models/sinskitG_model.py:497-501) == the oracle's own evaluation of the same formulas
+    (tests/golden/lpips_metrics.npz, oracle/make_golden.py lpipsmetrics)"""
+    import torch.nn.functional as F
+
+    from oracle import perceptual
+    from oracle.make_golden import lpips_metric_inputs
+
+    g = np.load(os.path.join(golden_dir, "lpips_metrics.npz"))
+    seed = int(g["seed"])
+    real_I, fake_I, real_T, fake_T = lpips_metric_inputs(seed)
+    for net in ("vgg", "alex"):
+        lp = perceptual.LPIPS(net=net)
+        with torch.no_grad():
+            a, b = detrand.uniform((2, 3, 80, 96), seed, "lp_a"), detrand.uniform((2, 3, 80, 96), seed, "lp_b")
+            np.testing.assert_allclose(lp(a, b).flatten().numpy(), g[net + "/module_val"], rtol=1e-5)
+            vi = float(lp(real_I, fake_I).mean())
+            rT, fT = F.interpolate(real_T, (224, 224)), F.interpolate(fake_T.clamp(0, 1), (224, 224))
+            vt = float(lp(rT[:, 0:1], fT[:, 0:1]).mean() + lp(rT[:, 1:2], fT[:, 1:2]).mean())
+        assert abs(vi - float(g[net + "/I_LPIPS"])) <= 1e-5 * vi and abs(vt - float(g[net + "/T_LPIPS"])) <= 1e-5 * vt
+    assert abs(float(g["alex/I_LPIPS"]) - float(g["vgg/I_LPIPS"])) > 1e-4      # two different metrics under one name
+
+
+def test_ssim_restatement_against_an_independent_float64_evaluation():
+    """I_SSIM (models/model_utils.py:496-499 = torchmetrics.functional.structural_similarity_index_measure(data_range=1); torchmetrics is
+    an unpinned, absent pip dependency): the oracle's restatement (oracle/nets.py:ssim, conv2d on reflect-padded tensors) against a second,
+    independently written evaluation of the documented algorithm -- scipy.ndimage correlate1d with mode='mirror' (= reflect without edge
+    repetition, what F.pad(mode='reflect') does), float64, separable Gaussian 11 taps sigma 1.5, k1 0.01, k2 0.03, border of 5 cropped --
+    and against closed forms (identical images: 1; constant images a, b: (2ab + c1) / (a^2 + b^2 + c1))."""
+    from scipy.ndimage import correlate1d
+
+    def ssim64(t, p):
+        d = np.arange(-5, 6, dtype=np.float64)
+        gk = np.exp(-0.5 * (d / 1.5) ** 2)
+        gk /= gk.sum()
+        blur = lambda x: correlate1d(correlate1d(x, gk, axis=-1, mode="mirror"), gk, axis=-2, mode="mirror")   # noqa: E731
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        mp, mt = blur(p), blur(t)
+        sp, st_, spt = np.maximum(blur(p * p) - mp * mp, 0), np.maximum(blur(t * t) - mt * mt, 0), blur(p * t) - mp * mt
+        full = ((2 * mp * mt + c1) * (2 * spt + c2)) / ((mp * mp + mt * mt + c1) * (sp + st_ + c2))
+        return full[..., 5:-5, 5:-5].reshape(full.shape[0], -1).mean(-1).mean()
+
+    for shape, tag in (((2, 3, 40, 52), "a"), ((1, 3, 64, 64), "b"), ((3, 1, 11, 23), "c")):
+        t = detrand.uniform(shape, 77, "ssim_t" + tag) * 0.5 + 0.5
+        p = (t + 0.2 * detrand.uniform(shape, 77, "ssim_p" + tag)).clamp(0, 1)
+        got = float(nets.ssim(t, p))
+        want = float(ssim64(t.double().numpy(), p.double().numpy()))
+        assert abs(got - want) < 2e-6, (shape, got, want)
+        assert abs(float(nets.ssim(t, t)) - 1.0) < 1e-6
+    for a, b in ((0.2, 0.7), (0.5, 0.5), (0.0, 1.0)):
+        got = float(nets.ssim(torch.full((1, 3, 20, 20), a), torch.full((1, 3, 20, 20), b)))
+        assert abs(got - (2 * a * b + 1e-4) / (a * a + b * b + 1e-4)) < 2e-4      # (fp32 cancellation in E[x^2] - E[x]^2 against c2 = 9e-4)

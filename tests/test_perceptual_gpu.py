@@ -322,3 +322,49 @@ def test_conv3x3_wide_64_channel_tile(case):
     finally:
         del os.environ["VTS_NO_WIDE64"]
     assert torch.equal(out, out2)
+
+
+def test_lpips_alex_network_and_test_phase_metrics_match_reference_fixture(golden_dir):
+    """lpips.LPIPS(net="alex"), the reference's test-phase eval_LPIPS (models/sinskitG_model.py:501), on the HIP kernels (11 x 11 stride-4
+    stem as space-to-depth + GEMM-class 3 x 3, MaxPool2d(3, 2), 5 x 5 on 4 x 4 tap blocks): module values and I_LPIPS / T_LPIPS against
+    tests/golden/lpips_metrics.npz -- the reference's compute_evaluation_metric run on the restated module -- and the VGG backbone's
+    values of the same fixture through the training-phase path."""
+    from models import perceptual as MP
+    from oracle.make_golden import lpips_metric_inputs
+    from vts import ops, perceptual as P
+
+    dev = _dev()
+    g = np.load(golden_dir + "/lpips_metrics.npz")
+    seed = int(g["seed"])
+    alex = MP.build_lpips_alex(None, dev)
+    sd = chk.standin_state_alex(MP.LpipsAlex.SEED)
+    for k in range(5):      # product and checker draw the same stand-in numbers
+        assert torch.equal(alex.convs[k].weight.cpu(), sd["conv%d.weight" % k]) and torch.equal(alex.lins[k].cpu(), sd["lin%d.weight" % k])
+    a, b = detrand.uniform((2, 3, 80, 96), seed, "lp_a").to(dev), detrand.uniform((2, 3, 80, 96), seed, "lp_b").to(dev)
+    per = []
+    for i in range(2):
+        slot = ops.loss_slots(1, dev)
+        P.lpips_alex_value(alex, a[i:i + 1], b[i:i + 1], 1.0, slot)
+        per.append(ops.loss_values(slot)[0])
+    np.testing.assert_allclose(per, g["alex/module_val"], rtol=2e-4)
+    # feature maps against the checker, layer by layer
+    lp = chk.LPIPS(net="alex")
+    x = detrand.uniform((1, 3, 75, 91), seed, "alex_x")
+    with torch.no_grad():
+        ref = lp.net(x)
+    zs = P.alex_forward(alex, x.to(dev))
+    for k in range(5):
+        assert rel(torch.relu(zs[k]), ref[k]) < 2e-5, k
+    # the metric glue of both phases
+    real_I, fake_I, real_T, fake_T = (t.to(dev) for t in lpips_metric_inputs(seed))
+    vgg = MP.build_lpips(None, dev)
+    for name, term in (("alex", lambda x, y, c, s: P.lpips_alex_value(alex, x, y, c, s)), ("vgg", lambda x, y, c, s: P.lpips_term(vgg, x, y, c, s))):
+        buf = ops.loss_slots(2, dev)
+        term(real_I, fake_I, 1.0 / real_I.shape[0], buf[0:1])
+        for c in (0, 1):
+            ra = ops.sifid_input(real_T, c, 1, size=(224, 224))
+            fb = ops.sifid_input(fake_T, c, 1, size=(224, 224), clamp01=True)
+            term(ra, fb, 1.0 / real_T.shape[0], buf[1:2])
+        lv = ops.loss_values(buf)
+        assert abs(lv[0] - float(g[name + "/I_LPIPS"])) <= 3e-4 * lv[0], (name, lv, float(g[name + "/I_LPIPS"]))
+        assert abs(lv[1] - float(g[name + "/T_LPIPS"])) <= 3e-4 * lv[1], (name, lv, float(g[name + "/T_LPIPS"]))

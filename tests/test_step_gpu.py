@@ -622,3 +622,38 @@ def test_generator_gradients_serial_schedule_equals_lane_schedule(size, monkeypa
             continue
         worst = max(worst, rel(grads[False][k], grads[True][k]))
     assert worst < 2e-5, worst
+
+
+def test_test_phase_lpips_metrics_use_the_alexnet_backbone(tmp_path, monkeypatch):
+    """the reference evaluates I_LPIPS / T_LPIPS with lpips.LPIPS(net="alex") in the test phase (models/sinskitG_model.py:501): a model
+    built from TestOptions reports that backbone and the checker's AlexNet restatement reproduces both values (stand-in weights)"""
+    import torch.nn.functional as F
+
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.test_options import TestOptions
+    from oracle import perceptual as chk
+
+    monkeypatch.setenv("VTS_LPIPS_METRICS", "1")
+    size, seed = 256, 37
+    topt = TestOptions(cmd_line="--model sinskitG --gpu_ids 0 --checkpoints_dir %s --name x --crop_size %d" % (tmp_path, size)).parse()
+    tm = create_model(topt)
+    tm.setup(topt)
+    tm.parallelize()
+    tm.netG.load_state_dict(detrand.test_weights(nets.g_param_shapes(), seed))
+    tm.eval()
+    batch = default_collate([make_sample(size, 8, 8, seed)])
+    tm.set_input(batch, phase="test")
+    tm.test()
+    m = tm.compute_metrics()
+    assert tm.metric_lpips_backbone == "alex" and tm.metric_lpips_pretrained is False and tm.metric_ssim_pinned == "restatement"
+    lp = chk.LPIPS(net="alex")
+    with torch.no_grad():
+        ref_I = float(lp(tm.real_I.cpu(), tm.fake_I.cpu()).mean())
+        pset = tm.val_set
+        P = pset["real_T"].shape[0]
+        fake_T = torch.empty(P, 2, 32, 32, device=tm.device)
+        tm._gather(tm.fake_T, pset, fake_T, 0, channels=2)
+        rT, fT = F.interpolate(pset["real_T"].cpu(), (224, 224)), F.interpolate(fake_T.cpu().clamp(0, 1), (224, 224))
+        ref_T = float(lp(rT[:, 0:1], fT[:, 0:1]).mean() + lp(rT[:, 1:2], fT[:, 1:2]).mean())
+    assert abs(m["I_LPIPS"] - ref_I) <= 1e-3 * ref_I and abs(m["T_LPIPS"] - ref_T) <= 1e-3 * ref_T

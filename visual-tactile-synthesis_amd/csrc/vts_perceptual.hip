@@ -34,6 +34,44 @@ __global__ __launch_bounds__(256) void maxpool2_relu_pad_kernel(const float* __r
   }
 }
 
+// AlexNet's MaxPool2d(kernel 3, stride 2) behind a ReLU (torchvision alexnet.features[1:3], [4:6]): out[nc][pad + y][pad + x] = max over the
+// 3 x 3 window at (2y, 2x) of relu(z), OH = (H - 3) / 2 + 1; the `pad`-pixel border is written as zeros (the next convolution's padding).
+__global__ __launch_bounds__(256) void maxpool3s2_relu_pad_kernel(const float* __restrict__ z, int H, int W, int pad, float* __restrict__ out) {
+  const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, PH = OH + 2 * pad, PW = OW + 2 * pad;
+  const int64_t nc = blockIdx.y;
+  const float* zi = z + nc * (int64_t)H * W;
+  float* o = out + nc * (int64_t)PH * PW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < PH * PW; i += gridDim.x * 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int y = py - pad, x = px - pad;
+    float v = 0.f;
+    if (y >= 0 && y < OH && x >= 0 && x < OW) {
+      const float* q = zi + (int64_t)(2 * y) * W + 2 * x;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) v = fmaxf(v, q[a * W + b]);
+    }
+    o[i] = v;
+  }
+}
+
+// Space-to-depth by 4 of the zero-padded input of AlexNet's 11 x 11 stride-4 stem: out[n][(c * 4 + i) * 4 + j][Y][X] = xp[n][c][4Y + i][4X + j],
+// xp = x zero-padded by `pad` (zero beyond, too).  The stem then is a VALID 3 x 3 stride-1 convolution over 16 C channels (weights
+// w'[o][(c, i, j)][a][b] = w[o][c][4a + i][4b + j], zero where 4a + i > 10) and runs on the GEMM-class 3 x 3 kernel.
+__global__ __launch_bounds__(256) void s2d4_pad_kernel(const float* __restrict__ x, int C, int H, int W, int pad, int OH, int OW, float* __restrict__ out) {
+  const int64_t n = blockIdx.y;
+  const int64_t total = (int64_t)C * 16 * OH * OW;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int X = (int)(e % OW);
+    const int64_t r = e / OW;
+    const int Y = (int)(r % OH), ch = (int)(r / OH);
+    const int c = ch >> 4, i = (ch >> 2) & 3, j = ch & 3;
+    const int y = 4 * Y + i - pad, xx = 4 * X + j - pad;
+    out[n * total + e] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[(n * C + c) * (int64_t)H * W + (int64_t)y * W + xx] : 0.f;
+  }
+}
+
 // adjoint of (relu -> MaxPool2d(2, 2)) w.r.t. relu(z): the pooled gradient goes to the FIRST element (row-major scan of the
 // window, PyTorch's tie rule) that holds the window maximum of relu(z).  Windows whose maximum is <= 0 route to their first element
 // in PyTorch and the ReLU mask then removes it: zero here.  Elements outside any window (odd H / W) get zero.
@@ -190,6 +228,25 @@ extern "C" int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int p
                        out + (int64_t)c0 * PH * PW);
   }
   VTS_CHECK_LAUNCH("vts_maxpool2_relu_pad");
+  return VTS_OK;
+}
+
+extern "C" int vts_maxpool3s2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream) {
+  VTS_CHECK_ARG(z && out && NC >= 1 && H >= 3 && W >= 3 && pad >= 0 && pad <= 2, "vts_maxpool3s2_relu_pad: bad args");
+  const int PH = (H - 3) / 2 + 1 + 2 * pad, PW = (W - 3) / 2 + 1 + 2 * pad;
+  for (int c0 = 0; c0 < NC; c0 += 65535) {
+    const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
+    hipLaunchKernelGGL(maxpool3s2_relu_pad_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream, z + (int64_t)c0 * H * W, H, W, pad,
+                       out + (int64_t)c0 * PH * PW);
+  }
+  VTS_CHECK_LAUNCH("vts_maxpool3s2_relu_pad");
+  return VTS_OK;
+}
+
+extern "C" int vts_s2d4_pad(const float* x, int N, int C, int H, int W, int pad, int OH, int OW, float* out, void* stream) {
+  VTS_CHECK_ARG(x && out && N >= 1 && N <= 65535 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && OH >= 1 && OW >= 1, "vts_s2d4_pad: bad args");
+  hipLaunchKernelGGL(s2d4_pad_kernel, dim3(blocks_1d((int64_t)C * 16 * OH * OW), N), dim3(256), 0, (hipStream_t)stream, x, C, H, W, pad, OH, OW, out);
+  VTS_CHECK_LAUNCH("vts_s2d4_pad");
   return VTS_OK;
 }
 

@@ -88,6 +88,9 @@ class SinSKITGModel(BaseModel):
         # separated); the reference gets them from `lpips.LPIPS(net="vgg")`, which downloads (sinskitG_model.py:495).  Without a file the
         # perceptual terms run on seeded stand-in weights and `loss_lpips_pretrained` / `metric_lpips_pretrained` say so.
         parser.add_argument("--lpips_weights", type=str, default="")
+        # ... and of the AlexNet variant the reference evaluates with in the test phase (lpips.LPIPS(net="alex"), sinskitG_model.py:501:
+        # torchvision alexnet features + lpips v0.1 lin layers)
+        parser.add_argument("--lpips_alex_weights", type=str, default="")
         parser.set_defaults(model=cls.MODEL_NAME, dataset_mode=cls.DATASET_MODE, netG="unet256_custom", netD="multiscale",
                             netD2="multiscale", gan_mode="nonsaturating", ngf=10, ndf=8, lr=0.001, beta1=0.0, beta2=0.99,
                             crop_size=1536, no_flip=True, dataroot=cls.DATAROOT, data_len=cls.DATA_LEN)
@@ -235,6 +238,13 @@ class SinSKITGModel(BaseModel):
             raise NotImplementedError(
                 "third-party loss terms need pretrained weights that are not available offline and are not built: %s. "
                 "Disable them explicitly (SURVEY.md §7 'Third-party loss terms')." % "; ".join(bad))
+
+    def _lpips_alex_net(self):
+        """lpips.LPIPS(net="alex"), the reference's eval_LPIPS of the test phase (sinskitG_model.py:501)"""
+        if getattr(self, "netLPIPS_alex", None) is None:
+            from . import perceptual
+            self.netLPIPS_alex = perceptual.build_lpips_alex(self.opt, self.device)
+        return self.netLPIPS_alex
 
     def _lpips_net(self):
         if self.netLPIPS is None:
@@ -890,24 +900,33 @@ class SinSKITGModel(BaseModel):
             vals += [float(engine.sifid_images(net, self.real_I.contiguous(), self.fake_I.contiguous())),
                      float(engine.sifid_tactile(net, pset["real_T"], fake_T_concat))]
             self.metric_sifid_pretrained = bool(net.pretrained)
-        if getattr(self.opt, "lpips_weights", "") or os.environ.get("VTS_LPIPS_METRICS", "0") == "1" or self.netLPIPS is not None:
-            # I_LPIPS / T_LPIPS (model_utils.py:475-478, 521-527).  eval_LPIPS is the VGG network while training (:497-499); the reference
-            # switches to AlexNet at test time (:501) -- not built (11 x 11 stride-4 stem): VGG is used in both phases and
-            # `metric_lpips_backbone` says so.
+        alex_phase = not self.isTrain        # eval_LPIPS: VGG while training / validating (:497-499), AlexNet in the test phase (:501)
+        want_lpips = (getattr(self.opt, "lpips_alex_weights", "") if alex_phase else getattr(self.opt, "lpips_weights", "")) or \
+            os.environ.get("VTS_LPIPS_METRICS", "0") == "1" or (self.netLPIPS is not None and not alex_phase)
+        if want_lpips:
+            # I_LPIPS / T_LPIPS (model_utils.py:475-478, 521-527) with the reference's backbone of the phase
             from vts import perceptual as P_
-            net = self._lpips_net()
             buf = ops.loss_slots(2, self.device)
             n_img = self.real_I.shape[0]
-            P_.lpips_term(net, self.real_I.contiguous(), self.fake_I.contiguous(), 1.0 / n_img, buf[0:1])
+            if alex_phase:
+                net = self._lpips_alex_net()
+                term = lambda a, b, coeff, slot: P_.lpips_alex_value(net, a, b, coeff, slot)      # noqa: E731
+            else:
+                net = self._lpips_net()
+                term = lambda a, b, coeff, slot: P_.lpips_term(net, a, b, coeff, slot)            # noqa: E731
+            term(self.real_I.contiguous(), self.fake_I.contiguous(), 1.0 / n_img, buf[0:1])
             for c in (0, 1):     # nearest resize to 224 x 224, fake clamped to [0, 1], each channel tiled to three; mean over patches, gx + gy
                 a = ops.sifid_input(pset["real_T"], c, 1, size=(224, 224))
                 b = ops.sifid_input(fake_T_concat, c, 1, size=(224, 224), clamp01=True)
                 for i0 in range(0, P, 32):
-                    P_.lpips_term(net, a[i0:i0 + 32], b[i0:i0 + 32], 1.0 / P, buf[1:2])
+                    term(a[i0:i0 + 32], b[i0:i0 + 32], 1.0 / P, buf[1:2])
             lv = ops.loss_values(buf)
             names += ["I_LPIPS", "T_LPIPS"]
             vals += [lv[0], lv[1]]
-            self.metric_lpips_pretrained, self.metric_lpips_backbone = bool(net.pretrained), "vgg"
+            self.metric_lpips_pretrained, self.metric_lpips_backbone = bool(net.pretrained), "alex" if alex_phase else "vgg"
+        # I_SSIM: torchmetrics is an unpinned pip dependency that cannot be run here -- the kernel is pinned to a restatement of its
+        # published algorithm (oracle/nets.py:ssim, cross-checked against an independent float64 evaluation in tests/test_oracle_golden.py)
+        self.metric_ssim_pinned = "restatement"
         for name, v in zip(names, vals):
             setattr(self, "metric_%s%s" % (prefix, name), v)
             if prefix + name not in self.metric_names:

@@ -89,7 +89,7 @@ SYMBOLS = [
     "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract", "vts_tap_embed_at", "vts_tap_extract_at", "vts_w3x3_pack", "vts_conv3x3_wide", "vts_conv3x3_wide_ws_floats", "vts_conv3x3s2_wide", "vts_tconv3x3s2_wide", "vts_wgrad3x3_wide", "vts_wgrad3x3_wide_ws_floats", "vts_upfirdn2d_out_size", "vts_upfirdn2d", "vts_upfirdn2d_bwd", "vts_bias_act", "vts_bias_act_bwd", "vts_modconv_demod", "vts_w4x4_pack", "vts_conv4x4_flat_ok", "vts_conv4x4_wide_ws_floats", "vts_conv4x4_wide", "vts_wgrad4x4_wide_ws_floats", "vts_wgrad4x4_wide",
     "vts_metric_ws_floats", "vts_minmax", "vts_metric_psnr", "vts_metric_tactile", "vts_metric_ssim", "vts_frechet_ws_floats", "vts_frechet_distance", "vts_sifid_input", "vts_modconv_weight", "vts_modconv_weight_bwd", "vts_adain", "vts_adain_bwd", "vts_resample_table",
     "vts_mask_select", "vts_mask_sample_ranks", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
-    "vts_maxpool2_relu_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
+    "vts_maxpool2_relu_pad", "vts_maxpool3s2_relu_pad", "vts_s2d4_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
     "vts_patch_jobs", "vts_g_post_stack", "vts_step_begin", "vts_conv4x4_bsums", "vts_norm_bwd_from_partials",
 ]
 
@@ -202,6 +202,8 @@ def load():
         "vts_conv3x3_wide": [vp, vp, vp, vp, i, i, i, i, i, vp, i64, vp],
         "vts_wgrad3x3_wide": [vp, vp, vp, i, i, i, i, i, i, i, vp, i64, vp],
         "vts_maxpool2_relu_pad": [vp, i, i, i, i, vp, vp],
+        "vts_maxpool3s2_relu_pad": [vp, i, i, i, i, vp, vp],
+        "vts_s2d4_pad": [vp, i, i, i, i, i, i, i, vp, vp],
         "vts_maxpool2_relu_bwd": [vp, vp, i, i, i, vp, vp],
         "vts_relu_mask_pad": [vp, vp, vp, i, i, i, i, vp, vp],
         "vts_lpips_layer": [vp, vp, i, i, i, vp, f, vp, vp, f, vp],

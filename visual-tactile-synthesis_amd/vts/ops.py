@@ -1253,9 +1253,27 @@ def linear_rows(x, weight, bias=None, relu=False):
 # ---- perceptual terms: glue around the frozen VGG stacks (include/vts.h) ----
 def maxpool2_relu_pad(z, pad=1):
     n, c, h, w = z.shape
-    assert z.is_contiguous() and h % 2 == 0 and w % 2 == 0, "VGG feature maps are even-sized"
+    assert z.is_contiguous() and h >= 2 and w >= 2      # (odd sizes: the last row / column belongs to no window, as in MaxPool2d's floor mode)
     out = torch.empty(n, c, h // 2 + 2 * pad, w // 2 + 2 * pad, dtype=torch.float32, device=z.device)
     _run("maxpool2_relu_pad", 4.0 * (z.numel() + out.numel()), 0.0, L.load().vts_maxpool2_relu_pad, z.data_ptr(), n * c, h, w, pad, out.data_ptr(), L.stream())
+    return out
+
+
+def maxpool3s2_relu_pad(z, pad=0):
+    """relu -> MaxPool2d(3, 2) (+ zero border): AlexNet's pooling stages (LPIPS-Alex metric)"""
+    n, c, h, w = z.shape
+    assert z.is_contiguous() and h >= 3 and w >= 3
+    out = torch.empty(n, c, (h - 3) // 2 + 1 + 2 * pad, (w - 3) // 2 + 1 + 2 * pad, dtype=torch.float32, device=z.device)
+    _run("maxpool3s2_relu_pad", 4.0 * (z.numel() + out.numel()), 0.0, L.load().vts_maxpool3s2_relu_pad, z.data_ptr(), n * c, h, w, pad, out.data_ptr(), L.stream())
+    return out
+
+
+def s2d4_pad(x, pad, oh, ow):
+    """space-to-depth by 4 of the zero-padded x: [N, C, H, W] -> [N, 16 C, oh, ow] (AlexNet's stride-4 stem as a 3 x 3 convolution)"""
+    n, c, h, w = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(n, c * 16, oh, ow, dtype=torch.float32, device=x.device)
+    _run("s2d4_pad", 4.0 * (x.numel() + out.numel()), 0.0, L.load().vts_s2d4_pad, x.data_ptr(), n, c, h, w, pad, oh, ow, out.data_ptr(), L.stream())
     return out
 
 

@@ -93,6 +93,48 @@ def vgg_backward(net, zs, tap_grads, x_shape):
     raise RuntimeError("vgg_backward: no tap gradient given")
 
 
+def alex_forward(net, x):
+    """AlexNet feature stack of models/perceptual.py:LpipsAlex on the HIP kernels; x [N, 3, H, W] in the network's input space.
+    Returns {k: raw output z of convolution k} (the taps read relu(z) on load, like the VGG taps).
+      conv0  11 x 11, stride 4, padding 2: space-to-depth by 4 of the padded input (vts_s2d4_pad) + a valid 3 x 3 convolution over the 48
+             phase channels on the GEMM-class kernel (weights rearranged once: LpipsAlex.stem_weight)
+      conv1  5 x 5, padding 2 on relu -> MaxPool2d(3, 2): four 4 x 4 tap blocks on the generator's kernel (ops.convk)
+      conv2-4  3 x 3, padding 1: GEMM-class kernel on the pre-padded relu'd input"""
+    n, _, h, w = x.shape
+    dev = x.device
+    oh, ow = (h + 4 - 11) // 4 + 1, (w + 4 - 11) // 4 + 1
+    zs = {}
+    stem = net._packed.get("stem")
+    if stem is None:
+        net._stem_w = net.stem_weight()
+        stem = net._packed["stem"] = ops.w3x3_pack(net._stem_w, "conv_fwd", tag="alexstem%d" % id(net))
+    p = ops.s2d4_pad(x.contiguous(), 2, oh + 2, ow + 2)
+    z = torch.empty(n, 64, oh, ow, dtype=torch.float32, device=dev)
+    ops.conv3x3_wide(p, stem, net.convs[0].bias, z)
+    zs[0] = z
+    q = ops.maxpool3s2_relu_pad(z, 0)
+    z = torch.empty(n, 192, q.shape[2], q.shape[3], dtype=torch.float32, device=dev)
+    ops.convk(q, net.convs[1].weight, z, bias=net.convs[1].bias, pad=2)
+    zs[1] = z
+    prev = z
+    for k in (2, 3, 4):
+        p = ops.maxpool3s2_relu_pad(prev, 1) if k == 2 else ops.pad_affine(prev, (1, 1, 1, 1), 0, act=RELU)
+        z = torch.empty(n, net.convs[k].weight.shape[0], p.shape[2] - 2, p.shape[3] - 2, dtype=torch.float32, device=dev)
+        ops.conv3x3_wide(p, _packed(net, k, "conv_fwd"), net.convs[k].bias, z)
+        zs[k] = z
+        prev = z
+    return zs
+
+
+def lpips_alex_value(net, a, b, coeff, loss_slot, channels=None):
+    """loss_slot += coeff * sum_n lpips.LPIPS(net="alex")(a_n, b_n) (the metric is symmetric in its arguments; no gradient)"""
+    cx = a.shape[1] if channels is None else channels
+    z1 = alex_forward(net, ops.lpips_input(b, net.shift, net.scale, channels=cx))
+    z0 = alex_forward(net, ops.lpips_input(a, net.shift, net.scale, channels=cx))
+    for i in range(5):
+        ops.lpips_layer(z0[i], z1[i], net.lins[i].view(-1), coeff, loss_slot, dz0=None, grad_coeff=coeff)
+
+
 def lpips_term(net, fake, real, coeff, loss_slot, grad_into=None, grad_accumulate=False, channels=None, nstride_fake=None, nstride_real=None,
                grad_nstride=None):
     """loss_slot += coeff * sum_n LPIPS(fake_n, real_n); grad_into (+)= coeff * d(.)/d fake when given.
