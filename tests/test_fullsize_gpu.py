@@ -11,6 +11,19 @@ from torch.utils.data import default_collate
 
 pytestmark = pytest.mark.gpu
 
+# gradient comparisons against the oracle: every (relative L2 error, network, parameter) is recorded, the worst one is printed at the
+# end of the module (pytest -s) and the bound is ~2x the worst value observed on the MI355X (round 4: see the fixture below)
+GRAD_WORST = []
+GRAD_TOL = 1.5e-3     # observed worst on the MI355X (round 4): 9.6e-4 (D layer2.11.bias, a sum over 4 x 35 x 35 predictions)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _report_worst_gradient():
+    yield
+    if GRAD_WORST:
+        w = max(GRAD_WORST)
+        print("\n[%s] worst gradient rel-L2 vs the oracle over %d comparisons: %.3e (%s %s), bound %.1e" % (__name__, len(GRAD_WORST), w[0], w[1], w[2], GRAD_TOL))
+
 from oracle import detrand, nets, step  # noqa: E402  (checker only)
 
 SIZE = 1024
@@ -139,7 +152,8 @@ def test_full_size_step_matches_oracle_batch1():
             if k.endswith("bias") and ((nm == "G" and not k.startswith(("down0.", "down7.", "up0.", "up0_T."))) or
                                        (nm != "G" and k.split(".")[1] in ("2", "5", "8"))):
                 continue    # bias in front of a normalisation: mathematically zero gradient (rounding noise in autograd)
-            assert rel(p.grad, r) < 2e-3, (nm, k, rel(p.grad, r))
+            GRAD_WORST.append((rel(p.grad, r), nm, k))
+            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
 
 
 def test_headline_config_step_matches_oracle():
@@ -176,7 +190,8 @@ def test_headline_config_step_matches_oracle():
                 continue    # bias in front of a normalisation: mathematically zero gradient
             e = rel(p.grad, ref["grad_" + nm][k])
             worst = max(worst, (e, nm + "." + k))
-            assert e < 2e-3, (nm, k, e)
+            GRAD_WORST.append((e, nm, k))
+            assert e < GRAD_TOL, (nm, k, e)
         for k, b in net.named_buffers():    # the oracle updated its state dicts in place: running statistics after the step
             if k.endswith("running_mean"):
                 scale = float(sd[k.replace("running_mean", "running_var")].max().sqrt())

@@ -16,6 +16,19 @@ from torch.utils.data import default_collate
 
 pytestmark = pytest.mark.gpu
 
+# gradient comparisons against the oracle: every (relative L2 error, network, parameter) is recorded, the worst one is printed at the
+# end of the module (pytest -s) and the bound is ~2x the worst value observed on the MI355X (round 4: see the fixture below)
+GRAD_WORST = []
+GRAD_TOL = 2e-3       # observed worst on the MI355X (round 4): 1.27e-3 (G down5.model.1.weight against the reference's own fp32 CPU run)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _report_worst_gradient():
+    yield
+    if GRAD_WORST:
+        w = max(GRAD_WORST)
+        print("\n[%s] worst gradient rel-L2 vs the oracle over %d comparisons: %.3e (%s %s), bound %.1e" % (__name__, len(GRAD_WORST), w[0], w[1], w[2], GRAD_TOL))
+
 from oracle import detrand, nets, step  # noqa: E402  (checker only)
 
 FLAGS = ("--model sinskitG --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
@@ -142,7 +155,8 @@ def test_second_step_from_synced_state(golden_dir):
         for k, p in net.named_parameters():
             if null_grad_bias(nm, k):
                 continue
-            assert rel(p.grad, ref["grad_" + nm][k]) < 2e-3, (nm, k)
+            GRAD_WORST.append((rel(p.grad, ref["grad_" + nm][k]), nm, k))
+            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
             assert rel(p.data, sd[k]) < 1e-3, (nm, k)
 
 
@@ -171,7 +185,8 @@ def test_step_batch2_matches_oracle():
         for k, p in net.named_parameters():
             if null_grad_bias(nm, k):
                 continue
-            assert rel(p.grad, ref["grad_" + nm][k]) < 2e-3, (nm, k)
+            GRAD_WORST.append((rel(p.grad, ref["grad_" + nm][k]), nm, k))
+            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
             # beta1 = 0: the first Adam update is ~lr*sign(g); elements whose gradient is rounding noise may
             # move by 2*lr either way, so post-step weights are compared at 3e-3 (the gradients above at 2e-3)
             assert rel(p.data, sd[k]) < 3e-3, (nm, k)
@@ -373,7 +388,8 @@ def test_step_on_a_singleskit_dataset_batch_matches_oracle(tmp_path):
         for k, gr in ref["grad_" + nm].items():
             if null_grad_bias(nm, k):
                 continue
-            assert rel(named[k].grad, gr) < 2e-3, (nm, k)
+            GRAD_WORST.append((rel(named[k].grad, gr), nm, k))
+            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
 
 
 def test_eval_metrics_match_oracle():
@@ -657,3 +673,54 @@ def test_test_phase_lpips_metrics_use_the_alexnet_backbone(tmp_path, monkeypatch
         rT, fT = F.interpolate(pset["real_T"].cpu(), (224, 224)), F.interpolate(fake_T.cpu().clamp(0, 1), (224, 224))
         ref_T = float(lp(rT[:, 0:1], fT[:, 0:1]).mean() + lp(rT[:, 1:2], fT[:, 1:2]).mean())
     assert abs(m["I_LPIPS"] - ref_I) <= 1e-3 * ref_I and abs(m["T_LPIPS"] - ref_T) <= 1e-3 * ref_T
+
+
+def test_graph_replayed_step_with_device_draws_matches_oracle():
+    """The execution mode bench.py times -- HIP-graph replay, 'more fake T' ranks drawn on the device (vts_mask_sample_ranks), DiffAugment
+    draws from torch.rand inside the captured graph -- against the oracle, not only against the eager path: steps 1-2 run eager / capture
+    on the model's own draws, then model and oracle are put in the same state (weights, BatchNorm buffers, Adam moments and step counts
+    of an oracle that took two steps), step 3 is a pure replay, and the oracle repeats it with the draws READ BACK from the device."""
+    from data.synthetic_dataset import make_sample
+
+    size, nt, seed = 256, 64, 71
+    model, opt = make_model(size, 1)
+    assert opt.use_hip_graph and model._draws is None
+    sds = load_test_weights(model, seed)
+    batch = default_collate([make_sample(size, nt, nt, seed)])
+    import random
+
+    random.seed(3)
+    torch.manual_seed(3)
+    cnt = int(nets.dilated_mask_positions(batch["M"].float()).shape[0])
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    for s in range(2):      # the oracle's two steps (any draws: only the state they leave matters)
+        d = {"aug": detrand.uniform((4, 1), seed + s, "aug") * 0.5 + 0.5, "more_idx": torch.tensor([random.sample(range(cnt), 32)])}
+        step.train_step(sds[0], sds[1], sds[2], adam, batch, d, record=False)
+    for s in range(2):      # the model's: eager, then capture (+ first replay)
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+    assert model._graphs is not None
+    for nm, net, sd, optim in (("G", model.netG, sds[0], model.optimizer_G), ("D", model.netD, sds[1], model.optimizer_D),
+                               ("D2", model.netD2, sds[2], model.optimizer_D2)):
+        net.load_state_dict({k: v.detach() for k, v in sd.items()})
+        optim.load_named_state(net, adam[nm]["m"], adam[nm]["v"], adam[nm]["step"])
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)          # replay
+    torch.cuda.synchronize()
+    drawn = {"aug": model._aug.detach().cpu().clone(), "more_idx": model._ranks.detach().cpu().clone()}
+    assert drawn["aug"].shape == (4, 1) and float(drawn["aug"].min()) >= 0.0 and float(drawn["aug"].max()) < 1.0
+    assert drawn["more_idx"].shape == (1, 32) and len(set(drawn["more_idx"][0].tolist())) == 32 and int(drawn["more_idx"].max()) < cnt
+    ref = step.train_step(sds[0], sds[1], sds[2], adam, batch, drawn)
+    losses = model.get_current_losses()
+    for k, v in ref["losses"].items():
+        assert abs(losses["l_" + k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses["l_" + k], v)
+    assert rel(model.fake_I, ref["fake_I"]) < 1e-3 and rel(model.fake_T, ref["fake_T"]) < 1e-3
+    worst = 0.0
+    for nm, net, sd in (("G", model.netG, sds[0]), ("D", model.netD, sds[1]), ("D2", model.netD2, sds[2])):
+        for k, p in net.named_parameters():
+            if null_grad_bias(nm, k):
+                continue
+            worst = max(worst, rel(p.grad, ref["grad_" + nm][k]))
+            assert rel(p.data, sd[k]) < 1e-3, (nm, k)
+    print("graph-mode step: worst gradient rel-L2 vs the oracle %.2e" % worst)
+    assert worst < 2e-3, worst
