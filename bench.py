@@ -421,7 +421,8 @@ def main():
         fresh_ms = (time.perf_counter() - tf) / fresh_steps * 1e3
         model.set_input(batch, phase="train")
     comm = None
-    if world > 1:
+    if world > 1 or ddp.active():
+        # (VTS_DDP_FORCE=1 at one rank: the same block -- what the segmented schedule and the collectives' launch cost on one device)
         # exposed communication: the same K steps without the gradient all-reduces (the replicas drift apart: timing only, last)
         ddp.COMM_OFF = True
         for _ in range(2):
@@ -438,7 +439,9 @@ def main():
         ddp.COMM_OFF = False
         comm = {"ms_per_step_without_allreduce": dt_off / args.steps * 1e3,
                 "exposed_allreduce_ms_per_step": (dt - dt_off) / args.steps * 1e3,
-                "buckets": {k: int(b.buf.numel()) * 4 for k, b in model.ddp.buckets.items()} if getattr(model, "ddp", None) else None}
+                "buckets": {k: int(b.buf.numel()) * 4 for k, b in model.ddp.buckets.items()} if getattr(model, "ddp", None) else None,
+                "collective": "reduce-scatter + all-gather (library communicator)" if ddp.DIRECT else "torch.distributed all_reduce (RCCL)",
+                "ranks": world, "graph_segments": len(model._graphs) if getattr(model, "_graphs", None) else None}
 
     if rank == 0:
         roof = kernel_roofline(model, batch, args.detail) if world == 1 else None

@@ -565,6 +565,21 @@ int vts_linear_rows(const float* x, const float* w, const float* bias, int R, in
 /* dst[i] = src[i] for i < nwords (4-byte words) as a kernel on `stream`; src may be pinned host memory. */
 int vts_copy_words(const void* src, void* dst, int64_t nwords, void* stream);
 
+/* ---- optional collective of the data-parallel path (csrc/vts_comm.cpp; off by default, vts/ddp.py: VTS_DDP_DIRECT=1) ----------------
+ * Sum-all-reduce of one flat fp32 gradient bucket as reduce-scatter + all-gather on the library's OWN RCCL communicator and side stream
+ * (each rank reduces 1 / world of the bucket, all xGMI links carry a slice).  Replaces nn.DataParallel's gradient
+ * reduction of the reference (models/base_model.py:104-108).  RCCL is dlopen'ed: single-GPU users never load it.
+ *   vts_comm_unique_id        128-byte ncclUniqueId (rank 0 creates it; the caller distributes it, e.g. with torch.distributed.broadcast)
+ *   vts_comm_init             ncclCommInitRank on the CURRENT device; creates the side stream
+ *   vts_allreduce_flat_async  in place, ordered behind everything enqueued on `producer_stream` so far
+ *   vts_allreduce_flat_wait   `consumer_stream` waits for the last async call of this communicator
+ *   vts_comm_destroy */
+int vts_comm_unique_id(void* id128);
+int vts_comm_init(const void* id128, int rank, int world, void** comm);
+int vts_allreduce_flat_async(void* comm, float* buf, int64_t n, void* producer_stream);
+int vts_allreduce_flat_wait(void* comm, void* consumer_stream);
+int vts_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,17 +69,24 @@ def test_two_devices_real_step_replicas_identical(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671",
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), NCCL_DEBUG="INFO")
         env.pop("VTS_DDP_BACKEND", None)
         procs.append(subprocess.Popen([sys.executable, "-c", script, str(tmp_path)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    logs = []
     for p in procs:
         try:
-            _, err = p.communicate(timeout=900)
+            out, err = p.communicate(timeout=900)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             raise
         assert p.returncode == 0, err.decode()[-4000:]
+        logs.append(out.decode() + err.decode())
+    # RCCL itself saw both ranks: its NCCL_DEBUG=INFO init lines say "nranks 2" (the parse is validated on one rank by
+    # tests/test_rccl_gpu.py::test_rccl_debug_log_reports_the_rank_count)
+    from tests.test_rccl_gpu import nranks_seen
+    for log in logs:
+        assert nranks_seen(log) == [2], log[-2000:]
     r0, r1 = (torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2))
     assert (r0["device"], r1["device"]) == (0, 1)
     for it in range(3):

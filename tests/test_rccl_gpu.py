@@ -15,14 +15,56 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra, env_extra):
+def _bench(extra, env_extra, want_stderr=False):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "3"] + (["--no_cpu_baseline"] if env_extra else []) + extra,
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
-    return json.loads(lines[0])
+    return (json.loads(lines[0]), r.stderr.decode()) if want_stderr else json.loads(lines[0])
+
+
+def nranks_seen(log):
+    """rank counts RCCL reports in its NCCL_DEBUG=INFO lines ("... rank 0 nranks 2 cudaDev 0 ...")"""
+    import re
+    return sorted({int(m) for m in re.findall(r"nranks (\d+)", log)})
+
+
+def test_rccl_debug_log_reports_the_rank_count():
+    """the check tests/test_rccl2_gpu.py applies on two devices ("RCCL saw both ranks"), validated here on the one-rank group: the
+    communicator's INFO lines are found in the bench's stderr and say nranks 1 (and the JSON line stays alone on stdout)"""
+    out, err = _bench(["--size", "256", "--batch", "1"], {"VTS_DDP_FORCE": "1", "MASTER_PORT": "29564", "NCCL_DEBUG": "INFO"}, want_stderr=True)
+    assert out["n_gpus"] == 1 and nranks_seen(err) == [1], err[-2000:]
+
+
+def test_direct_reduce_scatter_all_gather_collective_single_rank(tmp_path):
+    """VTS_DDP_DIRECT=1: the buckets go through the library's own RCCL communicator (reduce-scatter + all-gather + tail all-reduce on a
+    side stream, include/vts.h: vts_allreduce_flat_async / _wait) instead of torch.distributed's all_reduce -- one rank: the sum over
+    ranks is the buffer itself, and the real step still runs (eager, capture, replay) with finite losses"""
+    script = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from vts import ddp
+rank, world = ddp.init_from_env("cuda")
+assert ddp.active() and ddp.DIRECT
+for n in (1, 5, 4096, (1 << 20) + 3):
+    t = torch.randn(n, device="cuda")
+    ref = t.clone()
+    b = ddp.GradBucket(t)
+    b.start()
+    b.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref), n
+print("direct collective ok")
+dist.destroy_process_group()
+""" % os.path.join(ROOT, "visual-tactile-synthesis_amd")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29565", VTS_DDP_FORCE="1", VTS_DDP_DIRECT="1")
+    r = subprocess.run([sys.executable, "-c", script], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and "direct collective ok" in r.stdout.decode(), r.stderr.decode()[-3000:]
+    out = _bench(["--size", "256", "--batch", "2"], {"VTS_DDP_FORCE": "1", "VTS_DDP_DIRECT": "1", "MASTER_PORT": "29566"})
+    assert out["config"]["losses_finite"] and out["value"] > 0
 
 
 @pytest.mark.parametrize("extra", [["--size", "256", "--batch", "2"], ["--size", "256", "--batch", "2", "--no_graph"],

@@ -52,18 +52,58 @@ def init_from_env(device_type="cuda"):
     return rank, world
 
 
+# VTS_DDP_DIRECT=1: the buckets travel as an explicit reduce-scatter + all-gather on the C library's own RCCL communicator and side stream
+# (include/vts.h: vts_allreduce_flat_async / _wait) instead of torch.distributed's all_reduce.  Same GradBucket interface; off by default
+# (never compared on a multi-GPU node).
+DIRECT = os.environ.get("VTS_DDP_DIRECT", "0") == "1"
+_comm = None
+
+
+def direct_comm():
+    """the library's communicator (created once per process; the 128-byte id travels over the default process group)"""
+    global _comm
+    if _comm is None:
+        import ctypes as C
+
+        from . import lib as L
+        lib = L.load()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if dist.get_rank() == 0:
+            raw = (C.c_ubyte * 128)()
+            L.check(lib.vts_comm_unique_id(C.cast(raw, C.c_void_p)), "vts_comm_unique_id")
+            ident = torch.tensor(list(raw), dtype=torch.uint8)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = ident.to(dev) if dist.get_backend() == "nccl" else ident
+        dist.broadcast(t, 0)
+        raw = (C.c_ubyte * 128)(*t.cpu().tolist())
+        handle = C.c_void_p()
+        L.check(lib.vts_comm_init(C.cast(raw, C.c_void_p), dist.get_rank(), dist.get_world_size(), C.byref(handle)), "vts_comm_init")
+        _comm = handle
+    return _comm
+
+
 class GradBucket:
     """Asynchronous all-reduce of one flat gradient buffer."""
 
     def __init__(self, flat_grad):
         self.buf = flat_grad
         self.work = None
+        self.direct = False
 
     def start(self):
         if _active() and not COMM_OFF:
-            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, async_op=True)
+            if DIRECT and self.buf.is_cuda:
+                from . import lib as L
+                L.check(L.load().vts_allreduce_flat_async(direct_comm(), self.buf.data_ptr(), self.buf.numel(), L.stream()), "vts_allreduce_flat_async")
+                self.direct = True
+            else:
+                self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, async_op=True)
 
     def wait(self):
+        if self.direct:
+            from . import lib as L
+            L.check(L.load().vts_allreduce_flat_wait(direct_comm(), L.stream()), "vts_allreduce_flat_wait")
+            self.direct = False
         if self.work is not None:
             self.work.wait()
             self.work = None
