@@ -57,12 +57,12 @@ def build_model(size, batch, model_name, quiet=True, netG="unet256_custom", lpip
     return model, opt
 
 
-def make_batch(size, batch, rank, style_dim):
+def make_batch(size, batch, rank, style_dim, quantize8=False):
     from torch.utils.data import default_collate
 
     from data.synthetic_dataset import make_sample
 
-    return default_collate([make_sample(size, 64, 64, 1234 + 100003 * rank + i, style_dim=style_dim) for i in range(batch)])
+    return default_collate([make_sample(size, 64, 64, 1234 + 100003 * rank + i, style_dim=style_dim, quantize8=quantize8) for i in range(batch)])
 
 
 def make_patch_batch(batch, rank, patch=32):
@@ -407,7 +407,9 @@ def main():
         def pinned(b):   # what the package's DataLoader hands over (data/__init__.py: pin_memory=True)
             return {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
 
-        batches = [pinned(batch), pinned(make_batch(args.size, args.batch, rank + 1, style_dim))]
+        # (as a train.py loop over a material gets them: 8-bit PNG pixels; the dataset front-ends hand the bytes over next to the float
+        #  tensors -- S_u8 / I_u8 / M_u8 -- and set_input uploads those, a quarter of the PCIe traffic, expanded on the device bit for bit)
+        batches = [pinned(make_batch(args.size, args.batch, rank + k, style_dim, quantize8=True)) for k in (0, 1)]
         for i in range(max(2, args.warmup)):
             model.set_input(batches[i % 2], phase="train")
             model.optimize_parameters(epoch=1)

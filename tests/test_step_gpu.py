@@ -724,3 +724,33 @@ def test_graph_replayed_step_with_device_draws_matches_oracle():
             assert rel(p.data, sd[k]) < 1e-3, (nm, k)
     print("graph-mode step: worst gradient rel-L2 vs the oracle %.2e" % worst)
     assert worst < 2e-3, worst
+
+
+def test_uint8_batch_upload_is_bit_identical_to_the_float_batch():
+    """the optional S_u8 / I_u8 / M_u8 batch keys (a quarter of the PCIe bytes): vts_u8_expand reproduces ToTensor [+ Normalize(0.5, 0.5)]
+    bit for bit for all 256 levels, and a training step fed from the bytes leaves exactly the weights of a step fed from the float tensors"""
+    from data.synthetic_dataset import make_sample
+    from vts import ops
+
+    dev = torch.device("cuda:0")
+    lv = torch.arange(256, dtype=torch.uint8)
+    f = lv.to(torch.float32).div(255)
+    assert torch.equal(ops.u8_expand(lv.to(dev), False).cpu(), f) and torch.equal(ops.u8_expand(lv.to(dev), True).cpu(), (f - 0.5) / 0.5)
+    batch = default_collate([make_sample(256, 64, 64, 91 + i, quantize8=True) for i in range(2)])
+    assert batch["S_u8"].dtype == torch.uint8 and torch.equal((batch["S_u8"].float().div(255) - 0.5) / 0.5, batch["S"])
+    plain = {k: v for k, v in batch.items() if not k.endswith("_u8")}
+    flats = []
+    for b in (batch, plain):
+        import random
+        random.seed(7)
+        torch.manual_seed(7)
+        model, opt = make_model(256, 2)
+        load_test_weights(model, 91)
+        for _ in range(2):
+            model.set_input(b, phase="train")
+            model.optimize_parameters(epoch=1)
+        torch.cuda.synchronize()
+        flats.append({n: getattr(model, "flat" + n).flat.cpu().clone() for n in ("G", "D", "D2")})
+        assert torch.equal(model.real_I.cpu(), (batch["I"] * batch["M"]))
+    for n in ("G", "D", "D2"):
+        assert torch.equal(flats[0][n], flats[1][n]), n

@@ -160,6 +160,19 @@ def to_tensor(pic):
     return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t
 
 
+def to_u8(pic):
+    """the uint8 CHW tensor to_tensor() starts from, or None when the picture is not 8-bit (optional S_u8 / I_u8 / M_u8 batch keys: the
+    model uploads those instead of the float tensors and expands them on the device, bit for bit -- a quarter of the PCIe bytes)"""
+    if pic is None:
+        return None
+    a = np.array(pic)
+    if a.dtype != np.uint8:
+        return None
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+
 def normalize_half(t):
     """Normalize(mean 0.5, std 0.5): [0, 1] -> [-1, 1]"""
     return (t - 0.5) / 0.5
@@ -294,6 +307,11 @@ class SingleSkitDataset(torch.utils.data.Dataset):
                 d = {"S": S_tensor, "name": name, "S_paths": self.S_paths[0], "T_images": [], "augmentation_params": aug}
             if M_img is not None:
                 d.update({"M": M_tensor, "M_paths": self.M_paths[0]})
+            if os.environ.get("VTS_U8_BATCH", "1") != "0":      # (not a reference key: see to_u8)
+                for key, pic in (("S", S3), ("I", I3), ("M", M3)):
+                    raw = to_u8(pic) if key in d else None
+                    if raw is not None and tuple(raw.shape) == tuple(d[key].shape):
+                        d[key + "_u8"] = raw
             self.data_dict[index] = d
         print("Finish preprocessing %d data, takes " % len(self), time.time() - t0)
 

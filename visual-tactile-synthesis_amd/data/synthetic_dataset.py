@@ -30,8 +30,10 @@ def _box_blur(a, k):
     return a
 
 
-def make_sample(size, nt, nt_val, seed, patch=32, style_dim=0):
-    """One un-collated sample dict.  Deterministic in (size, nt, nt_val, seed)."""
+def make_sample(size, nt, nt_val, seed, patch=32, style_dim=0, quantize8=False):
+    """One un-collated sample dict.  Deterministic in (size, nt, nt_val, seed).
+    quantize8: sketch / image / mask as a real material delivers them -- 8-bit PNG pixels through ToTensor [+ Normalize(0.5, 0.5)] -- with
+    the optional S_u8 / I_u8 / M_u8 keys of the dataset front-ends next to the float tensors."""
     g = np.random.default_rng(seed)
     H = W = int(size)
     S = np.where(g.random((1, H, W)) > 0.9, -1.0, 1.0)
@@ -61,6 +63,12 @@ def make_sample(size, nt, nt_val, seed, patch=32, style_dim=0):
         masks = np.ones((n, patch, patch), np.float64)
         return T, coords, masks
 
+    if quantize8:
+        u8 = {"S_u8": torch.from_numpy(np.round((S + 1.0) * 127.5).astype(np.uint8)), "I_u8": torch.from_numpy(np.round((I + 1.0) * 127.5).astype(np.uint8)),
+              "M_u8": torch.from_numpy((M * 255).astype(np.uint8))}
+        S = ((u8["S_u8"].to(torch.float32).div(255) - 0.5) / 0.5).numpy()
+        I = ((u8["I_u8"].to(torch.float32).div(255) - 0.5) / 0.5).numpy()
+        M = u8["M_u8"].to(torch.float32).div(255).numpy()
     T, C, K = patches(nt)
     vT, vC, vK = patches(nt_val)
     aug = {
@@ -73,6 +81,8 @@ def make_sample(size, nt, nt_val, seed, patch=32, style_dim=0):
     if style_dim:
         sc = np.random.default_rng(seed + 7919).normal(0.0, 1.0, style_dim)
         extra["style_code"] = torch.from_numpy((sc / np.linalg.norm(sc)).astype(np.float32))
+    if quantize8:
+        extra.update(u8)
     return {
         **extra,
         "S": torch.from_numpy(S), "I": torch.from_numpy(I), "M": torch.from_numpy(M),

@@ -384,7 +384,21 @@ class SinSKITGModel(BaseModel):
         if not hasattr(self, "_copy_stream"):
             self._copy_stream, self._stage_parity, self._stage_done = torch.cuda.Stream(), 0, [None, None]
         self._stage_parity ^= 1
-        S = self._load(phase + "_S", input["S"], staged=True)
+        # 8-bit sources (optional keys S_u8 / I_u8 / M_u8 next to the float tensors: the dataset front-ends attach them where the float
+        # tensor IS ToTensor [+ Normalize] of those bytes): a quarter of the PCIe traffic, expanded on the device bit for bit (vts_u8_expand)
+        u8 = os.environ.get("VTS_U8_BATCH", "1") != "0"
+
+        def image(key, normalize):
+            if u8 and (key + "_u8") in input:
+                raw = self._load("%s_%s_u8" % (phase, key), input[key + "_u8"], dtype=torch.uint8, staged=True)
+                par = self._stage_parity
+                f = self._bufs.get("%s_%s_f%d" % (phase, key, par))
+                if f is None or tuple(f.shape) != tuple(raw.shape):
+                    f = self._bufs["%s_%s_f%d" % (phase, key, par)] = torch.empty(tuple(raw.shape), dtype=torch.float32, device=self.device)
+                return ops.u8_expand(raw, normalize, out=f)
+            return self._load("%s_%s" % (phase, key), input[key], staged=True)
+
+        S = image("S", True)
         n, _, h, w = S.shape
         # The D1 update runs the discriminator on [fake | real] in ONE batched launch per layer (engine.msd_multi, `groups`):
         # sketch and image live in persistent [2n, C, H, W] buffers -- rows [0, n) are the fake pass (S, fake_I written by the
@@ -394,7 +408,7 @@ class SinSKITGModel(BaseModel):
         self.real_S = S2[:n]
         if self.opt.use_bg_mask:
             self.M = self._buf(phase + "_M", tuple(torch.as_tensor(input["M"]).shape))      # read by the captured graphs: persistent; filled from the staging copy
-            self.M.copy_(self._load(phase + "_M", input["M"], staged=True))
+            self.M.copy_(image("M", False))
             ops.mask_mul(S, self.M, out=self.real_S)
             self.M_T = self.M  # nearest resize at multiplier 1 is the identity
         else:
@@ -403,7 +417,7 @@ class SinSKITGModel(BaseModel):
             S2[n:].copy_(self.real_S)
         self._S2 = S2
         if "I" in input:
-            I = self._load(phase + "_I", input["I"], staged=True)
+            I = image("I", True)
             I2 = self._buf(phase + "_I2", (2 * n if self._pair else n, 3, h, w))
             self.real_I = I2[n:] if self._pair else I2
             if self.opt.use_bg_mask:

@@ -1099,6 +1099,15 @@ def g_out_grad(d_fake_I, d_fake_T, M, g_out, d_raw):
     return d_raw
 
 
+def u8_expand(src, normalize, out=None):
+    """uint8 image data -> float32 as ToTensor (/ 255) [+ Normalize(0.5, 0.5)] would make it, bit for bit"""
+    assert src.dtype == torch.uint8 and src.is_contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    L.check(L.load().vts_u8_expand(src.data_ptr(), src.numel(), int(bool(normalize)), out.data_ptr(), L.stream()), "vts_u8_expand")
+    return out
+
+
 def mask_mul(x, M, out=None):
     lib = L.load()
     n, c, h, w = x.shape
