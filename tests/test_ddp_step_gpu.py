@@ -35,13 +35,13 @@ mode, out_dir = sys.argv[1], sys.argv[2]
 # generator's gradient is taken through differ between two implementations by +- lr wherever g is rounding noise (that is what the
 # 6e-3 bound of round 2 absorbed); with a vanishing step the generator gradient is a like-for-like comparison at the 2e-3 of the
 # single-rank tests.  The replica-identity checks run with the real rates in "graph" mode.
-model, opt = build(" --lr 1e-12 --lr_G2 1e-12" if mode == "oracle" else "")
+model, opt = build(" --lr 1e-12 --lr_G2 1e-12" if mode == "oracle" else "")      # ("oracle_lr": the same comparison at the REAL rates)
 load_test_weights(model, SEED if rank == 0 else SEED + 10)     # rank 1 starts from OTHER weights: parallelize() must replace them
 model.parallelize()
 assert ddp.active() and set(model.ddp.buckets) == {"D", "D2", "G_dec", "G_enc"}, model.ddp.buckets.keys()
 batch, draws = sample_and_draws(rank)
 steps = 1
-if mode == "oracle":
+if mode in ("oracle", "oracle_lr"):
     model._draws = draws          # fixed augmentation / sampler draws: eager step, comparable with the oracle
 else:
     torch.manual_seed(100 + rank)
@@ -155,3 +155,49 @@ def test_two_ranks_graph_replay_keeps_replicas_identical(tmp_path):
     for n in ("G", "D", "D2"):
         assert torch.equal(r0["flat"][n], r1["flat"][n]) and torch.isfinite(r0["flat"][n]).all()
     assert r0["losses"] != r1["losses"]        # different samples
+
+
+def test_two_ranks_real_step_at_real_learning_rates_follows_the_oracle(tmp_path):
+    """the vanishing-rate run above cannot see an ordering error between the discriminators' updates and the generator's backward (nothing
+    moves at lr 1e-12): the same two-rank step at the REAL rates -- the discriminators' post-step weights against the oracle's (Adam's first
+    update is lr * sign(g): elements whose gradient is rounding noise may differ by 2 lr, hence 3e-3 as in the single-rank tests) and the
+    generator's gradient, taken through the UPDATED discriminators, at the 6e-3 that absorbs those sign flips (round-3 advisor finding)"""
+    from oracle import detrand, nets, step
+    from tests.test_step_gpu import null_grad_bias, rel
+
+    r0, r1 = _run_ranks("oracle_lr", tmp_path, 29645)
+    for n in ("G", "D", "D2"):
+        assert torch.equal(r0["flat"][n], r1["flat"][n])
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+
+    def oracle_rank(rank, exchange=None):
+        sds = (detrand.test_weights(nets.g_param_shapes(), SEED), detrand.test_weights(nets.d_param_shapes(4), SEED + 1),
+               detrand.test_weights(nets.d_param_shapes(7), SEED + 2))
+        batch, draws = sample_and_draws(rank)
+        adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+        return step.train_step(sds[0], sds[1], sds[2], adam, batch, draws, exchange=exchange), sds
+
+    first = [oracle_rank(r)[0] for r in range(2)]
+    mean = {n: {k: 0.5 * (first[0]["grad_" + n][k] + first[1]["grad_" + n][k]) for k in first[0]["grad_" + n]} for n in ("D", "D2")}
+    second = [oracle_rank(r, exchange=lambda n, g: mean[n] if n in mean else g) for r in range(2)]
+    refs = [o for o, _ in second]
+    sds0 = second[0][1]        # the oracle's post-step state of rank 0 (D / D2 identical on both ranks after the exchange)
+    import re
+    from models import networks  # noqa: F401  (state-dict key order of the flat buffers is the module's)
+    worst_g = 0.0
+    for k, g in r0["grad"]["G"].items():
+        if null_grad_bias("G", k):
+            continue
+        g0, g1 = refs[0]["grad_G"][k].double(), refs[1]["grad_G"][k].double()
+        err = (g.double() * r0["scale"] - 0.5 * (g0 + g1)).norm().item()
+        worst_g = max(worst_g, err / (0.5 * (g0.norm().item() + g1.norm().item())))
+    assert worst_g <= 6e-3, worst_g
+    # post-step discriminator weights: rebuild named tensors from rank 0's flat buffers through a fresh model's parameter layout
+    model, _ = build()
+    for nm, sd in (("D", sds0[1]), ("D2", sds0[2])):
+        flat = getattr(model, "flat" + nm)
+        flat.flat.copy_(r0["flat"][nm])
+        for k, p in getattr(model, "net" + nm).named_parameters():
+            if null_grad_bias(nm, k):
+                continue
+            assert rel(p.data, sd[k]) < 3e-3, (nm, k, rel(p.data, sd[k]))

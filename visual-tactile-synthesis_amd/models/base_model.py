@@ -130,7 +130,7 @@ class BaseModel(ABC):
                 print("cannot find model path", load_path, "skip")  # reference: warn and continue (:264-267)
                 continue
             net = getattr(self, "net" + name)
-            state_dict = torch.load(load_path, map_location="cpu")
+            state_dict = torch.load(load_path, map_location="cpu", weights_only=True)
             clean = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in state_dict.items())
             own = net.state_dict()
             extra = [k for k in clean if k not in own]

@@ -43,7 +43,7 @@ class InceptionBlock0(nn.Module):
 
     def load_weights(self, path):
         """state dict of the reference's InceptionV3 wrapper, of torchvision's inception_v3, or of pytorch-fid's FID network"""
-        sd = torch.load(path, map_location="cpu")
+        sd = torch.load(path, map_location="cpu", weights_only=True)
         sd = sd.get("state_dict", sd)
         own = self.state_dict()
         got = {}

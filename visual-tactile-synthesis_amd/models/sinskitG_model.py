@@ -223,6 +223,8 @@ class SinSKITGModel(BaseModel):
         self._graphs = None     # the captured segments of the step, or None
         self._infer_graph, self._infer_eager_done = None, False   # captured inference forward (test())
         self._eager_steps_done = 0
+        if os.environ.get("VTS_KO_LANES") and os.environ.get("VTS_KO_LANES_ACK", "") != "timing-only":
+            raise RuntimeError("VTS_KO_LANES skips discriminator lanes (wrong losses and gradients): set VTS_KO_LANES_ACK=timing-only to run the timing experiment")
         self._draws = None      # tests / parity runs inject {"aug": [4,N], "more_idx": [N,K]}
         self.ddp = None
         self.style_code = None
@@ -251,6 +253,12 @@ class SinSKITGModel(BaseModel):
             from . import perceptual
             self.netLPIPS = perceptual.build_lpips(self.opt, self.device)
             self.loss_lpips_pretrained = self.metric_lpips_pretrained = bool(self.netLPIPS.pretrained)
+            if not self.netLPIPS.pretrained and self.isTrain and (self.opt.lambda_G1_lpips > 0 or self.opt.lambda_G2_lpips > 0):
+                import sys
+                print("WARNING: the LPIPS loss terms (lambda_G1_lpips %g, lambda_G2_lpips %g) run on SEEDED STAND-IN VGG16 weights: no --lpips_weights "
+                      "file was given and the pretrained ones cannot be downloaded here.  Training with them does not reproduce the reference; "
+                      "pass --lpips_weights <torchvision vgg16 + lpips v0.1 state dicts> or set both lambdas to 0."
+                      % (self.opt.lambda_G1_lpips, self.opt.lambda_G2_lpips), file=sys.stderr, flush=True)
         return self.netLPIPS
 
     # ------------------------------------------------------------------ input
@@ -470,6 +478,18 @@ class SinSKITGModel(BaseModel):
             self._cand, self._cand_prefix = ops.mask_candidates(
                 self.M, self._buf("cand", (n, h - 14, w - 14), torch.uint8), self._buf("cand_prefix", (n, h - 14 + 1), torch.int32))
             k = self.opt.add_fake_T_sample_size
+            # The reference draws random.sample(range(count), k) (model_utils.py:217) and RAISES when an image has fewer than k candidate
+            # positions; the device-side draw wraps instead.  Reading the counts here would stall the host behind the step in flight, so
+            # they travel to pinned memory asynchronously and are checked one set_input later (or at the next loss read), by which time
+            # the copy has long finished: a too-small mask fails loudly, one step late, at no cost.
+            self._check_candidate_counts()
+            pin = self._bufs.get("cand_count_pin")
+            if pin is None or pin.numel() != n:
+                pin = self._bufs["cand_count_pin"] = torch.empty(n, dtype=torch.int32).pin_memory()
+            pin.copy_(self._cand_prefix[:, -1], non_blocking=True)
+            evt = torch.cuda.Event()
+            evt.record()
+            self._cand_check = (pin, evt, k, self.name)
             self._ranks = self._buf("more_ranks", (n, k), torch.int64)
             mi = self._bufs.get("more_img")          # image index of every extra patch: a constant of (n, k), built on the device once
             if mi is None or mi.numel() != n * k:
@@ -479,6 +499,22 @@ class SinSKITGModel(BaseModel):
         done = torch.cuda.Event()
         done.record()        # every reader of this batch's staging buffers has been queued on the launch stream
         self._stage_done[self._stage_parity] = done
+
+    def _check_candidate_counts(self, wait=False):
+        """raises like random.sample would have (reference models/model_utils.py:217) when the previous batch's mask had fewer candidate
+        positions than add_fake_T_sample_size; never blocks unless `wait`"""
+        chk = getattr(self, "_cand_check", None)
+        if chk is None:
+            return
+        pin, evt, k, name = chk
+        if not wait and not evt.query():
+            return
+        evt.synchronize()
+        self._cand_check = None
+        counts = pin.tolist()
+        if min(counts) < k:
+            raise ValueError("Sample larger than population: the background mask of %s leaves %s candidate positions for the %d 'more fake T' "
+                             "patches (reference: random.sample in get_patch_in_input, models/model_utils.py:217)" % (name, counts, k))
 
     # ------------------------------------------------------------------ forward
     def _g_input(self):
@@ -950,6 +986,7 @@ class SinSKITGModel(BaseModel):
     # ------------------------------------------------------------------ logging
     def get_current_losses(self):
         vals = ops.loss_values(self._loss_buf)   # the only device->host sync of the loss path
+        self._check_candidate_counts(wait=True)
         for i, name in enumerate(LOSS_SLOTS):
             setattr(self, "loss_" + name, vals[i])
         return BaseModel.get_current_losses(self)

@@ -12,6 +12,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libvts_hip.so")   # (VTS_LIB_PATH: A/B of builds, tools/)
+if os.environ.get("VTS_LIB_PATH"):
+    import sys
+    print("NOTE: VTS_LIB_PATH overrides the in-tree library: loading %s" % LIB_PATH, file=sys.stderr, flush=True)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 GAN_MODES = {"nonsaturating": 0, "lsgan": 1, "vanilla": 2, "wgan": 3, "wgangp": 3, "hinge": 4}
