@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two builds of libvts_hip.so on the same GPU box: tools/ab_bench.sh gpurun_ab/libvts_hip_base.so gpurun_ab/libvts_hip_new.so [rounds]
+# A/B of two builds of libvts_hip.so on the same GPU box: tools/probes/ab_bench.sh gpurun_ab/libvts_hip_base.so gpurun_ab/libvts_hip_new.so [rounds]
 A=$1; B=$2; R=${3:-3}
 L=visual-tactile-synthesis_amd/libvts_hip.so
 cp $L /tmp/keep.so

@@ -1,9 +1,9 @@
 """Forward / forward+backward time of pix2pixHD's GlobalGenerator (ngf 64, 4 downsamplings, 9 blocks: 1024 channels)
-on the HIP path, with HIP events.  python tools/bench_global.py [H W [N]]"""
+on the HIP path, with HIP events.  python tools/probes/bench_global.py [H W [N]]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "visual-tactile-synthesis_amd"))
 import torch  # noqa: E402
 

@@ -1,11 +1,11 @@
 """Random-shape check of the lane = pixel members (vts_conv_px.hip) against PyTorch on the GPU box: stride-2 convolutions / transposed
 convolutions with few output channels on maps >= 128 x 128, dual sources, per-channel affine + activation on load, bias, derivative
-mask, accumulation, tanh (transposed), odd / even sizes and paddings.   python tools/fuzz_px.py [cases] [seed]"""
+mask, accumulation, tanh (transposed), odd / even sizes and paddings.   python tools/probes/fuzz_px.py [cases] [seed]"""
 import os
 import random
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "visual-tactile-synthesis_amd"))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

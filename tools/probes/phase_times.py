@@ -1,8 +1,8 @@
-"""Time the captured segments of the skitG step (HIP events around the graph replays).  python tools/phase_times.py"""
+"""Time the captured segments of the skitG step (HIP events around the graph replays).  python tools/probes/phase_times.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "visual-tactile-synthesis_amd"))
 import torch  # noqa: E402

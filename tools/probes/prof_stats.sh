@@ -1,4 +1,4 @@
-# rocprofv3 kernel stats of the headline bench:  bash tools/prof_stats.sh <tag>   -> gpurun_out/stats_<tag>.csv
+# rocprofv3 kernel stats of the headline bench:  bash tools/probes/prof_stats.sh <tag>   -> gpurun_out/stats_<tag>.csv
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=${1:-x}; O=gpurun_out/stats_$T; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o run -- python bench.py --steps 10 --warmup 3 --no_cpu_baseline > $O/log.txt 2>&1

@@ -1,11 +1,11 @@
 """Run a few training steps of the HIP path over a matrix of sizes / batch sizes / option toggles and report finiteness.
-python tools/robustness_matrix.py"""
+python tools/probes/robustness_matrix.py"""
 import contextlib
 import io
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "visual-tactile-synthesis_amd"))
 import torch  # noqa: E402

@@ -1,6 +1,6 @@
 """Timeline analysis of one training step from a rocprofv3 --kernel-trace CSV (graph replay, concurrent lanes).
 
-    python tools/trace_timeline.py <run_kernel_trace.csv> [--step K] [--dump out.txt]
+    python tools/probes/trace_timeline.py <run_kernel_trace.csv> [--step K] [--dump out.txt]
 
 Steps are delimited by the generator's Adam launch (the last kernel of a step).  Prints the span of the step, the time during
 which 0 / 1 / 2 / ... kernels run, and which kernels account for the time at concurrency 1 (the critical path candidates)."""

@@ -1028,7 +1028,7 @@ def _sg2d_passes(D, passes, criterion):
 
 
 KO_LANES = tuple(int(k) for k in os.environ.get("VTS_KO_LANES", "").split(",") if k)
-if KO_LANES:      # timing experiment (tools/r02_ko.sh): the named discriminator lanes are skipped, losses and gradients are WRONG
+if KO_LANES:      # timing experiment (tools/probes/r02_ko.sh): the named discriminator lanes are skipped, losses and gradients are WRONG
     import sys
     print("WARNING: VTS_KO_LANES=%s -- discriminator lanes are knocked out, this run's results are wrong (timing experiment only)"
           % os.environ["VTS_KO_LANES"], file=sys.stderr, flush=True)
