@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int LDS_FLOATS = (PATCH_FLOATS + W_FLOATS) > OUT_FLOATS ? (PATCH_FLOATS + W_FLOATS) : OUT_FLOATS;
 
   __shared__ float lds[LDS_FLOATS];
+  // round 4: the statistics / backward-sum partials of the four waves of a tile are combined here, ONE slot per workgroup and tile (they
+  // were one per wave: the mergers -- norm_finalize_wide_kernel, norm_bwd_apply_sums_kernel -- read a quarter of the records now)
+  __shared__ float lds_stat[STATS ? 4 * NR * 16 * 3 : 1];
   float* lds_patch = lds;
   float* lds_w = lds + PATCH_FLOATS;
 
@@ -352,10 +355,9 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
       // One pass over the accumulators: sum and sum of squares of the values BEFORE the bias (the variance does not see a constant,
       // so a large bias costs no precision; what is left of |mean| / sigma inside a wave's 64 .. 512 values is what a convolution of
       // zero-mean-ish weights produces), M2 = q - s * mean.  The Chan merge of the second stage handles the spread BETWEEN partials.
-      const int slot = (by * p.tiles_x + tx0 / TX) * 4 + wave;
+      const int slot = by * p.tiles_x + tx0 / TX;
 #pragma unroll
       for (int nr = 0; nr < NR; ++nr) {
-        const int co = co0 + nr * 16 + m16;
         float sum = 0.f, sq = 0.f, cnt = 0.f;
 #pragma unroll
         for (int r = 0; r < RW; ++r)
@@ -381,14 +383,38 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         sum += __shfl_xor(sum, 32, 64);
         sq += __shfl_xor(sq, 32, 64);
         cnt += __shfl_xor(cnt, 32, 64);
-        if (kq == 0 && co < p.Cout) {
+        if (kq == 0) {      // this wave's (mean, M2, count), as before
           const float mean = sum / fmaxf(cnt, 1.f);
-          float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
-          o[0] = mean + (p.bias ? p.bias[co] : 0.f);
-          o[1] = fmaxf(sq - sum * mean, 0.f);
-          o[2] = cnt;
+          float* q = lds_stat + (wave * NR * 16 + nr * 16 + m16) * 3;
+          q[0] = mean;
+          q[1] = fmaxf(sq - sum * mean, 0.f);
+          q[2] = cnt;
         }
       }
+      __syncthreads();
+      if (tid < NR * 16 && co0 + tid < p.Cout) {      // Chan merge of waves 0 .. 3 in order: deterministic, robust between the waves
+        float cnt = 0.f, wm = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float* q = lds_stat + (w * NR * 16 + tid) * 3;
+          cnt += q[2];
+          wm = fmaf(q[2], q[0], wm);
+        }
+        const float mean = wm / fmaxf(cnt, 1.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float* q = lds_stat + (w * NR * 16 + tid) * 3;
+          const float d = q[0] - mean;
+          m2 += q[1] + q[2] * d * d;
+        }
+        const int co = co0 + tid;
+        float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
+        o[0] = mean + (p.bias ? p.bias[co] : 0.f);
+        o[1] = m2;
+        o[2] = cnt;
+      }
+      __syncthreads();      // (lds_stat is free for the next tile of a run)
     }
     float bs1 = 0.f, bs2 = 0.f;     // STATS == 2: this lane's share of S1 / S2' of the channel it is emitting
     auto emit = [&](int co, int y, int x, float bias, float dsc, float dsh, f32x4 v) {
@@ -470,15 +496,31 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
         bs2 += __shfl_xor(bs2, 16, 64);
         bs1 += __shfl_xor(bs1, 32, 64);
         bs2 += __shfl_xor(bs2, 32, 64);
-        if (kq == 0 && co < p.Cout) {
-          const int slot = (by * p.tiles_x + tx0 / TX) * 4 + wave;
-          float* o = p.bsum_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 2;
-          o[0] = bs1;
-          o[1] = bs2;
+        if (kq == 0) {
+          float* q = lds_stat + (wave * NR * 16 + nr * 16 + m16) * 3;
+          q[0] = bs1;
+          q[1] = bs2;
         }
         bs1 = 0.f;
         bs2 = 0.f;
       }
+    }
+    if (STATS == 2) {
+      __syncthreads();
+      if (tid < NR * 16 && co0 + tid < p.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float* q = lds_stat + (w * NR * 16 + tid) * 3;
+          s1 += q[0];
+          s2 += q[1];
+        }
+        const int slot = by * p.tiles_x + tx0 / TX;
+        float* o = p.bsum_part + (((int64_t)n * p.Cout + co0 + tid) * p.stat_spl + slot) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+      __syncthreads();
     }
   };
 
@@ -711,7 +753,7 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   const int GH = P == 4 ? (k.OH + 1) / 2 : k.OH, GW = P == 4 ? (k.OW + 1) / 2 : k.OW;
   const int tiles_x = cdiv(GW, 16 * MT), tiles_y = cdiv(GH, 4 * RW);
   k.tiles_x = tiles_x;
-  k.stat_spl = tiles_x * tiles_y * 4;
+  k.stat_spl = tiles_x * tiles_y;      // one statistics / backward-sum slot per workgroup tile (round 4; one per wave before)
   t_stat_spl = k.stat_spl;
   // Tile runs: only where the per-tile chunk pipeline is too short to overlap anything (<= run_max_chunks chunks per tile) and
   // the grid stays several workgroups per CU deep after the cut.  VTS_TILE_RUN=<n> forces a run length (1 = one tile per workgroup).

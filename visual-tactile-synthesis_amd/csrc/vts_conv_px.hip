@@ -97,11 +97,54 @@ __device__ __forceinline__ float from_prev(float v) {
 //   padding odd  (2m + 1):  pixel xo = g + m   tap  kx 0 = P_{g-1}.y      kx 1,2 = P_g    kx 3 = P_{g+1}.x   62 pixels per wave (lanes 1..62)
 // Pairs never straddle the left edge; an odd input width makes the last pair straddle the right edge (its second dword is masked).
 // 84 - 110 registers: 4 - 5 waves per SIMD hide the load latency without any software pipelining beyond one channel of prefetch.
+// Merge of the four waves' epilogue records of one tile (round 4): Chan's formula for the statistics (mean, M2, count), plain sums for the
+// normalisation-backward pairs, waves 0 .. 3 in order (deterministic); ONE slot per workgroup -- the mergers behind read a quarter of the
+// records they read with one slot per wave.  Every thread of the workgroup must call it (barrier).
+template <int NB, int STATS>
+__device__ __forceinline__ void px_merge_stats(const float* px_stat, const PxK& p, int n, int slot) {
+  __syncthreads();
+  const int co = threadIdx.x;
+  if (co >= NB * 4 || co >= p.Cout) return;
+  if (STATS == 1) {
+    float cnt = 0.f, wm = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* q = px_stat + (w * NB * 4 + co) * 3;
+      cnt += q[2];
+      wm = fmaf(q[2], q[0], wm);
+    }
+    const float mean = wm / fmaxf(cnt, 1.f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* q = px_stat + (w * NB * 4 + co) * 3;
+      const float d = q[0] - mean;
+      m2 += q[1] + q[2] * d * d;
+    }
+    float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
+    o[0] = mean + (p.bias ? p.bias[co] : 0.f);
+    o[1] = m2;
+    o[2] = cnt;
+  } else {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* q = px_stat + (w * NB * 4 + co) * 3;
+      s1 += q[0];
+      s2 += q[1];
+    }
+    float* o = p.bsum_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 2;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
 template <int NB, int T, int PP, int STATS>
 __global__ __launch_bounds__(256) void conv_px_s2_kernel(const PxK p) {
   constexpr int R = 2 * T + 2;   // input rows under T output rows
   constexpr int VL = PP ? 62 : 63, L0 = PP ? 1 : 0;
   extern __shared__ float wl[];  // [ci][blk][64]: A-operand images
+  __shared__ float px_stat[STATS ? 4 * NB * 4 * 3 : 1];   // per-wave statistics / backward-sum records of the tile, merged at the end
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int iplane = p.IH * p.IW;
@@ -268,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_px_s2_kernel(const PxK p) {
     const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? p.dmC * oplane * 4 : 0, 0x00020000);
     const bool xok = lane >= L0 && lane < L0 + VL && xo < p.OW;
     const unsigned vox = xok ? (unsigned)xo * 4u : OOB_OFF;
-    const int slot = (by * p.tiles_x + bx) * 4 + wave;
+    const int slot = by * p.tiles_x + bx;
     const int nvy = min(max(p.OH - y0, 0), T);
     const float cnt = (float)(nvy * min(max(p.OW - x0, 0), VL));
     const float* biasp = p.bias ? p.bias : p.ident + 1;
@@ -331,23 +374,23 @@ __global__ __launch_bounds__(256) void conv_px_s2_kernel(const PxK p) {
           s1 = wave_sum(s1);
           s2 = wave_sum(s2);
           const int co = b * 4 + i;
-          if (lane == 0 && co < p.Cout) {
+          if (lane == 0) {      // this wave's record; the four waves of the tile are merged below (one slot per workgroup: round 4)
+            float* q = px_stat + (wave * NB * 4 + co) * 3;
             if (STATS == 1) {
               const float mean = s1 / fmaxf(cnt, 1.f);
-              float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
-              o[0] = mean + bias[i];
-              o[1] = fmaxf(s2 - s1 * mean, 0.f);
-              o[2] = cnt;
+              q[0] = mean;
+              q[1] = fmaxf(s2 - s1 * mean, 0.f);
+              q[2] = cnt;
             } else {
-              float* o = p.bsum_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 2;
-              o[0] = s1;
-              o[1] = s2;
+              q[0] = s1;
+              q[1] = s2;
             }
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // one block at a time
     }
+    if (STATS != 0) px_merge_stats<NB, STATS>(px_stat, p, n, slot);
   }
 }
 
@@ -370,6 +413,7 @@ __global__ __launch_bounds__(256) void convt_px_s2_kernel(const PxK p) {
   constexpr int R = T + ND - 1;   // input rows under T low-resolution rows
   constexpr int VL = PP ? 62 : 63, L0 = PP ? 1 : 0;
   extern __shared__ float wl[];  // [ci][blk][64]: A-operand images
+  __shared__ float px_stat[STATS ? 4 * NB * 4 * 3 : 1];   // per-wave statistics / backward-sum records of the tile, merged at the end
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int iplane = p.IH * p.IW;
@@ -525,7 +569,7 @@ __global__ __launch_bounds__(256) void convt_px_s2_kernel(const PxK p) {
   const bool ok0 = lok && 2 * qx < p.OW, ok1 = lok && 2 * qx + 1 < p.OW;
   const bool pairs = (p.OW & 1) == 0;   // uniform
   const unsigned vx0 = ok0 ? (unsigned)qx * 8u : OOB_OFF, vx1 = ok1 ? (unsigned)qx * 8u + 4u : OOB_OFF;
-  const int slot = (by * p.tiles_x + bx) * 4 + wave;
+  const int slot = by * p.tiles_x + bx;
   const int nvy = min(max(p.OH - 2 * qy0, 0), 2 * T);
   const float cnt = (float)(nvy * min(max(p.OW - 2 * x0, 0), 2 * VL));
   const float* biasp = p.bias ? p.bias : p.ident + 1;
@@ -604,23 +648,23 @@ __global__ __launch_bounds__(256) void convt_px_s2_kernel(const PxK p) {
       if (STATS != 0) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
-        if (lane == 0 && co < p.Cout) {
+        if (lane == 0) {
+          float* q = px_stat + (wave * NB * 4 + co) * 3;
           if (STATS == 1) {
             const float mean = s1 / fmaxf(cnt, 1.f);
-            float* o = p.stat_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 3;
-            o[0] = mean + bias;
-            o[1] = fmaxf(s2 - s1 * mean, 0.f);
-            o[2] = cnt;
+            q[0] = mean;
+            q[1] = fmaxf(s2 - s1 * mean, 0.f);
+            q[2] = cnt;
           } else {
-            float* o = p.bsum_part + (((int64_t)n * p.Cout + co) * p.stat_spl + slot) * 2;
-            o[0] = s1;
-            o[1] = s2;
+            q[0] = s1;
+            q[1] = s2;
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // one channel at a time
     }
   }
+  if (STATS != 0) px_merge_stats<NB, STATS>(px_stat, p, n, slot);
 }
 
 template <int NB, int T, int PP>
@@ -709,7 +753,7 @@ int vts_conv_px_try(const vts_conv_desc* d, hipStream_t st, float* stat_part, fl
     k.tiles_x = cdiv(d->OW, (k.padx & 1) ? 62 : 63);
     k.tiles_y = cdiv(d->OH, 4 * T);
   }
-  k.stat_spl = k.tiles_x * k.tiles_y * 4;
+  k.stat_spl = k.tiles_x * k.tiles_y;      // one slot per workgroup tile (round 4; one per wave before)
   int stats = 0;
   k.stat_part = nullptr; k.bsum_part = nullptr;
   if (stat_part || bsum_part) {
