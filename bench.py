@@ -65,12 +65,12 @@ def make_batch(size, batch, rank, style_dim, quantize8=False):
     return default_collate([make_sample(size, 64, 64, 1234 + 100003 * rank + i, style_dim=style_dim, quantize8=quantize8) for i in range(batch)])
 
 
-def make_patch_batch(batch, rank, patch=32):
+def make_patch_batch(batch, rank, patch=32, height=None, width=None):
     from torch.utils.data import default_collate
 
     from data.synthetic_dataset import make_patch_sample
 
-    return default_collate([make_patch_sample(1234 + 100003 * rank + i, patch=patch) for i in range(batch)])
+    return default_collate([make_patch_sample(1234 + 100003 * rank + i, patch=patch, height=height, width=width) for i in range(batch)])
 
 
 def csrc_sha16():
@@ -340,6 +340,8 @@ def main():
     ap.add_argument("--netG", type=str, default="unet256_custom",
                     help="generator: unet256_custom (headline config) | resnet_{4,6,9}blocks (alternate; needs --model sinskitG)")
     ap.add_argument("--p2p_size", type=int, default=32, help="pix2pixHD only: side of the (square) training images / patches")
+    ap.add_argument("--p2p_h", type=int, default=0, help="pix2pixHD only: image height (with --p2p_w: BASELINE config 3 is --p2p_h 1024 --p2p_w 2048 --batch 1)")
+    ap.add_argument("--p2p_w", type=int, default=0, help="pix2pixHD only: image width")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--lpips", action="store_true",
                     help="SECONDARY workload: the same step with the reference's default LPIPS-VGG16 terms on (lambda_G1_lpips 1, lambda_G2_lpips 10; "
@@ -372,7 +374,8 @@ def main():
     opt.skip_D2_visualisation_pass = bool(args.no_viz)
     style_dim = opt.style_code_dim if getattr(opt, "use_style_code", False) else 0
     # pix2pixHD: the reference trains it on 32x32 patches (default); --p2p_size S feeds S x S images instead (BASELINE config 3)
-    batch = (make_patch_batch(args.batch, rank, args.p2p_size) if args.model == "pix2pixHD"
+    p2p_h, p2p_w = args.p2p_h or args.p2p_size, args.p2p_w or args.p2p_size
+    batch = (make_patch_batch(args.batch, rank, args.p2p_size, p2p_h, p2p_w) if args.model == "pix2pixHD"
              else make_batch(args.size, args.batch, rank, style_dim))
     model.set_input(batch, phase="train")       # H2D once: inputs are resident in HBM before the timed region
 
@@ -477,7 +480,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": ("pix2pixHD G+D+D2 train step (GlobalGenerator ngf 64, ndf 64), %d %dx%d images/GPU, VGG term off "
-                             "(no weights offline)" % (args.batch, args.p2p_size, args.p2p_size)) if args.model == "pix2pixHD" else
+                             "(no weights offline)" % (args.batch, p2p_w, p2p_h)) if args.model == "pix2pixHD" else
                             "%s%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
                             "%s" % (args.model, "" if args.netG == "unet256_custom" else " (netG %s)" % args.netG,
                                     args.size, args.size, args.batch,

@@ -93,18 +93,19 @@ def make_sample(size, nt, nt_val, seed, patch=32, style_dim=0, quantize8=False):
     }
 
 
-def make_patch_sample(seed, patch=32):
+def make_patch_sample(seed, patch=32, height=None, width=None):
     """One un-collated patch sample with the patchskit contract used by pix2pixHD's patch-wise training
     (/root/reference/data/patchskit_dataset.py:277-333, `return_patch=True`): aligned 32x32 sketch / mask /
-    image / tactile patches."""
+    image / tactile patches (height / width: a rectangular whole image instead, BASELINE config 3's 2048 x 1024)."""
     g = np.random.default_rng(seed)
-    S = _box_blur(np.where(g.random((1, patch, patch)) > 0.9, -1.0, 1.0), 3).astype(np.float32)
-    I = _box_blur(g.uniform(-1.0, 1.0, (3, patch, patch)), 5).astype(np.float32)
-    yy, xx = np.mgrid[0:patch, 0:patch]
-    M = (((yy - patch / 2) / (0.45 * patch)) ** 2 + ((xx - patch / 2) / (0.4 * patch)) ** 2 <= 1.0).astype(np.float32)[None]
-    T = np.clip(g.normal(0.0, 0.05, (2, patch, patch)), -0.3, 0.3).astype(np.float32)
+    ph, pw = int(height or patch), int(width or patch)
+    S = _box_blur(np.where(g.random((1, ph, pw)) > 0.9, -1.0, 1.0), 3).astype(np.float32)
+    I = _box_blur(g.uniform(-1.0, 1.0, (3, ph, pw)), 5).astype(np.float32)
+    yy, xx = np.mgrid[0:ph, 0:pw]
+    M = (((yy - ph / 2) / (0.45 * ph)) ** 2 + ((xx - pw / 2) / (0.4 * pw)) ** 2 <= 1.0).astype(np.float32)[None]
+    T = np.clip(g.normal(0.0, 0.05, (2, ph, pw)), -0.3, 0.3).astype(np.float32)
     return {"S_images": torch.from_numpy(S), "M_images": torch.from_numpy(M), "I_images": torch.from_numpy(I),
-            "T_images": torch.from_numpy(T), "I_masks": np.ones((patch, patch), np.float64), "name": "synthetic_%d" % seed,
+            "T_images": torch.from_numpy(T), "I_masks": np.ones((ph, pw), np.float64), "name": "synthetic_%d" % seed,
             "S_paths": "synthetic/%d.png" % seed, "augmentation_params": {"patch_crop_size": patch}}
 
 
