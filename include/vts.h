@@ -311,6 +311,18 @@ int vts_tap_extract_at(const float* dw4, int64_t rows, int K, int oy, int ox, fl
 int vts_w3x3_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* wt, void* stream);
 int vts_conv3x3_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
                      float* ws, int64_t ws_floats, void* stream);
+/* The same convolution with the frozen VGG stacks' padded layout as its OUTPUT (perceptual terms, reference models/sinskitG_model.py:1711,
+ * models/networks.py:2021-2067): out is [N][Cout][H + 2][W + 2], the next 3x3 convolution's pre-padded operand; the kernel stores the
+ * interior and the zero one-pixel border:
+ *   vts_conv3x3_wide_relu_pad   max(conv + bias, 0): no ReLU + padding pass between two convolutions
+ *   vts_conv3x3_wide_mask_pad   (conv + add) where mask > 0, else 0; `mask` (the padded ReLU'd activation of the layer in front) and `add`
+ *                               (optional: that layer's tap gradient) have out's layout: no ReLU-mask + padding pass between two input adjoints
+ * VTS_ERR_UNSUPPORTED for shapes that do not take a tiled direct launch (small maps): the caller keeps the dense form there.
+ * vts_zero_border: buf [NC][H + 2 pad][W + 2 pad], the border of `pad` pixels <- 0 (interior untouched). */
+int vts_conv3x3_wide_relu_pad(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W, void* stream);
+int vts_conv3x3_wide_mask_pad(const float* in, const float* wt, float* out, int N, int Cin, int Cout, int H, int W, const float* add,
+                              const float* mask, void* stream);
+int vts_zero_border(float* buf, int64_t NC, int H, int W, int pad, void* stream);
 int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
 int vts_conv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int OH, int OW,
                        float* ws, int64_t ws_floats, void* stream);
@@ -429,7 +441,9 @@ int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, float* dx, i
  * 2021-2067.  Activations are RAW convolution outputs z; every consumer applies relu on load. ---- */
 /* out [NC][H/2 + 2 pad][W/2 + 2 pad] = zero-padded MaxPool2d(2, 2)(relu(z)), z [NC][H][W]: replaces ReLU + MaxPool2d + the next
  * convolution's padding (torchvision vgg features) */
-int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream);
+/* (zpad, here and in the three entries below: z is itself a padded tensor [NC][H + 2 zpad][W + 2 zpad] read at its interior -- the ReLU'd,
+ * pre-padded output of vts_conv3x3_wide_relu_pad; 0: dense [NC][H][W]) */
+int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, int zpad, void* stream);
 /* AlexNet variant of LPIPS (the reference's test-phase eval_LPIPS = lpips.LPIPS(net="alex"), models/sinskitG_model.py:501; pip package
  * `lpips`, lpips/pretrained_networks.py:alexnet over torchvision alexnet.features):
  *   vts_maxpool3s2_relu_pad  out[nc][pad + y][pad + x] = max over the 3 x 3 window at (2y, 2x) of relu(z), OH = (H - 3) / 2 + 1, zero border of
@@ -438,14 +452,17 @@ int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* 
  *                            X < OW -- the 11 x 11 stride-4 stem becomes a valid 3 x 3 convolution over 16 C channels (vts_conv3x3_wide) */
 int vts_maxpool3s2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream);
 int vts_s2d4_pad(const float* x, int N, int C, int H, int W, int pad, int OH, int OW, float* out, void* stream);
-/* gz [NC][H][W] = adjoint of relu -> MaxPool2d(2, 2) applied to g [NC][H/2][W/2] (first-maximum tie rule of PyTorch) */
-int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int H, int W, float* gz, void* stream);
-/* out [NC][H + 2 pad][W + 2 pad] = zero-padded (g + g2) * (z > 0); g or g2 may be NULL: ReLU backward + the padding of the adjoint conv */
-int vts_relu_mask_pad(const float* g, const float* g2, const float* z, int NC, int H, int W, int pad, float* out, void* stream);
+/* gz [NC][H + 2 pad][W + 2 pad] = zero-padded (adjoint of relu -> MaxPool2d(2, 2) applied to g [NC][H/2][W/2] (first-maximum tie rule of
+ * PyTorch) + g2 where z > 0); g2 (optional, this layer's tap gradient) has z's layout */
+int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int H, int W, float* gz, int zpad, const float* g2, int pad, void* stream);
+/* out [NC][H + 2 pad][W + 2 pad] = zero-padded (g + g2) * (z > 0); g (dense [NC][H][W]) or g2 (z's layout) may be NULL: ReLU backward + the
+ * padding of the adjoint conv */
+int vts_relu_mask_pad(const float* g, const float* g2, const float* z, int NC, int H, int W, int pad, float* out, int zpad, void* stream);
 /* one LPIPS tap: loss_slot += coeff * sum_n mean_pixels sum_c w[c] (f0n - f1n)^2 with f = relu(z), fn = f / (|f|_channels + 1e-10);
- * dz0 (optional) = grad_coeff * d(that sum)/d relu(z0)  (lpips.LPIPS.forward: normalize_tensor, lin layers, spatial_average) */
+ * dz0 (optional, z0's layout; with zpad its border is the caller's) = grad_coeff * d(that sum)/d z0, i.e. the gradient w.r.t. relu(z0) where
+ * z0 > 0 and 0 elsewhere  (lpips.LPIPS.forward: normalize_tensor, lin layers, spatial_average) */
 int vts_lpips_layer(const float* z0, const float* z1, int N, int C, int HW, const float* w, float coeff, int64_t* loss_slot, float* dz0,
-                    float grad_coeff, void* stream);
+                    float grad_coeff, int W, int zpad, void* stream);   /* W: map width (needed when zpad > 0) */
 /* loss_slot += coeff * sum |relu(za) - relu(zb)|;  grad (optional) = coeff * sign(.)  (VGGLoss: nn.L1Loss on ReLU features) */
 int vts_l1_relu(const float* za, const float* zb, int64_t n, float coeff, int64_t* loss_slot, float* grad, void* stream);
 /* LPIPS ScalingLayer: y [N][3][HW] = (x - shift_c) / scale_c; Cx = 1 broadcasts the single channel (tactile gx / gy); shift3 / scale3

@@ -87,7 +87,86 @@ def test_lpips_layer_value_and_gradient(shape):
     dz = torch.empty(shape, device=dev)
     ops.lpips_layer(z0.detach().to(dev), z1.to(dev), wl.to(dev), 0.3, slot, dz0=dz, grad_coeff=0.3)
     assert abs(ops.loss_values(slot)[0] - float(val)) <= 1e-5 * max(1e-3, abs(float(val)))
-    assert rel(dz, f0.grad) < 1e-5
+    assert rel(dz, z0.grad) < 1e-5                 # (the gradient w.r.t. z0 itself: the ReLU mask is applied by the kernel)
+    # the padded layout of the VGG stacks (relu(z) inside a zero border, as ops.conv3x3_wide_relu_pad leaves it): same value, and the
+    # gradient in the same layout
+    p0, p1 = F.pad(F.relu(z0.detach()), (1,) * 4).to(dev), F.pad(F.relu(z1), (1,) * 4).to(dev)
+    slot2 = ops.loss_slots(1, dev)
+    dzp = ops.zero_border(torch.full(p0.shape, 7.0, device=dev))
+    ops.lpips_layer(p0, p1, wl.to(dev), 0.3, slot2, dz0=dzp, grad_coeff=0.3, zpad=1)
+    assert ops.loss_values(slot2)[0] == ops.loss_values(slot)[0]
+    assert torch.equal(dzp, F.pad(dz, (1,) * 4))
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 40, 72), (4, 64, 65, 97), (4, 136, 64, 128)])
+def test_padded_layout_convolution_epilogues(shape):
+    """ops.conv3x3_wide_relu_pad / conv3x3_wide_mask_pad against the dense convolution followed by the separate pass they replace
+    (bit-identical: same kernel, same accumulation order), and the readers of the padded layout against their dense forms"""
+    from vts import ops
+
+    dev = _dev()
+    n, ci, h, w = shape
+    co = 64 if ci != 64 else 128
+    x = detrand.uniform(shape, 21, "x").to(dev)
+    wt = (detrand.uniform((co, ci, 3, 3), 21, "w") * 0.2).to(dev)
+    bias = detrand.uniform((co,), 21, "b").to(dev)
+    p = ops.pad_affine(x, (1, 1, 1, 1), 0)
+    packed = ops.w3x3_pack(wt, "conv_fwd", tag="t_epi%d" % ci)
+    z = torch.empty(n, co, h, w, device=dev)
+    ops.conv3x3_wide(p, packed, bias, z)
+    out = torch.full((n, co, h + 2, w + 2), 3.0, device=dev)
+    assert ops.conv3x3_wide_relu_pad(p, packed, bias, out)
+    assert torch.equal(out, F.pad(F.relu(z), (1,) * 4))
+    ref = F.conv2d(x.cpu().double(), wt.cpu().double(), bias.cpu().double(), padding=1)
+    assert rel(z.cpu().double(), ref) < 1e-5
+    # adjoint epilogue: (conv + add) where mask > 0
+    mask = F.pad(F.relu(detrand.uniform((n, co, h, w), 22, "m")), (1,) * 4).to(dev)
+    add = ops.zero_border(detrand.uniform((n, co, h + 2, w + 2), 22, "a").to(dev))
+    z0 = torch.empty(n, co, h, w, device=dev)
+    ops.conv3x3_wide(p, packed, None, z0)
+    for a in (add, None):
+        out = torch.full((n, co, h + 2, w + 2), 3.0, device=dev)
+        assert ops.conv3x3_wide_mask_pad(p, packed, out, mask, add=a)
+        want = z0 + a[:, :, 1:-1, 1:-1] if a is not None else z0
+        assert torch.equal(out, F.pad(want * (mask[:, :, 1:-1, 1:-1] > 0), (1,) * 4))
+    # readers: pooling, its adjoint (+ tap gradient, padded output), the ReLU mask
+    zr = F.pad(F.relu(z), (1,) * 4)
+    assert torch.equal(ops.maxpool2_relu_pad(zr, 1, zpad=1), ops.maxpool2_relu_pad(z, 1))
+    g = detrand.uniform((n, co, h // 2, w // 2), 23, "g").to(dev)
+    tap = detrand.uniform((n, co, h, w), 23, "t").to(dev)
+    dense = ops.relu_mask_pad(ops.maxpool2_relu_bwd(g, z), tap, z, pad=1)
+    assert torch.equal(ops.maxpool2_relu_bwd(g, zr, zpad=1, g2=F.pad(tap, (1,) * 4), pad=1), dense)
+    gd = detrand.uniform((n, co, h, w), 24, "gd").to(dev)
+    assert torch.equal(ops.relu_mask_pad(gd, F.pad(tap, (1,) * 4), zr, pad=1, zpad=1), ops.relu_mask_pad(gd, tap, z, pad=1))
+
+
+def test_small_maps_decline_the_padded_epilogue():
+    from vts import ops
+
+    dev = _dev()
+    p = torch.zeros(256, 256, 10, 10, device=dev)
+    packed = ops.w3x3_pack(torch.zeros(256, 256, 3, 3, device=dev), "conv_fwd", tag="t_small")
+    assert not ops.conv3x3_wide_relu_pad(p, packed, None, torch.empty(256, 256, 10, 10, device=dev))
+
+
+def test_padded_and_dense_vgg_schedules_agree_bit_for_bit(monkeypatch):
+    """VTS_VGG_PADDED=0 (round 3: dense raw outputs + separate ReLU / padding passes) and the padded-layout schedule run the same
+    arithmetic in the same order"""
+    from vts import ops, perceptual as P
+
+    dev = _dev()
+    net, _ = _lpips_pair()
+    a = detrand.uniform((2, 3, 64, 96), 31, "a").to(dev)
+    b = detrand.uniform((2, 3, 64, 96), 31, "b").to(dev)
+    res = {}
+    for padded in (True, False):
+        monkeypatch.setattr(P, "PADDED", padded)
+        slot = ops.loss_slots(1, dev)
+        grad = torch.empty_like(a)
+        P.lpips_term(net, a, b, 1.0, slot, grad_into=grad)
+        res[padded] = (ops.loss_values(slot)[0], grad)
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1])
 
 
 def _lpips_pair():
@@ -291,7 +370,7 @@ def test_lpips_on_a_full_patch_set_equals_its_halves():
         P.lpips_term(net, a[h], b[h], 1.0, s_half, grad_into=g_half[h])
     va, vh = ops.loss_values(s_all)[0], ops.loss_values(s_half)[0]
     assert va > 0 and abs(va - vh) <= 1e-5 * va
-    assert rel(g_all, g_half) < 1e-4      # other k-split plans at the two batch sizes
+    assert rel(g_all, g_half) < 3e-4      # other k-split plans at the two batch sizes (fp32 summation order through 13 layers + ReLU masks)
 
 
 @pytest.mark.parametrize("case", [(4, 64, 64, 128, 128), (8, 72, 64, 100, 90), (8, 128, 48, 96, 96)])

@@ -41,6 +41,13 @@ struct WideK {
   signed char dy[16], dx[16], wt_tap[16];   // (the 3x3 kernels use <= 9; the 4x4 flat entry up to 16)
   int KS, cps;   // k-split for small grids: blockIdx.z = n + N * slice, cps input-channel chunks per slice
   float* part;   // [KS][N][Cout][OH][OW] raw partial sums (KS > 1), reduced in slice order by wide_reduce_kernel
+  // epilogue of the frozen VGG stacks (tiled direct kernels only).  1: store max(acc + bias, 0) -- the ReLU'd output straight into the next
+  // layer's padded input (vts_conv3x3_wide_relu_pad).  2: store (acc + ep_add) where ep_mask > 0, else 0 -- the input adjoint's output with
+  // the tap gradient added and the ReLU mask of the layer in front applied, straight into the next adjoint's padded input
+  // (vts_conv3x3_wide_mask_pad); ep_add (optional) and ep_mask have the output's layout
+  int ep_mode;
+  const float* ep_add;
+  const float* ep_mask;
 };
 
 // K: kernel extent (3 | 4: taps of the packed weight = K * K), CKT: input channels per chunk, LIVE: most taps one launch uses
@@ -167,8 +174,32 @@ __device__ __forceinline__ void wide_body(const WideK& p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wco * 64 + i * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
-        if (co < p.Cout && y < p.H && x < p.W)
-          ob[co * oplane + (int64_t)(p.oy0 + p.os * y) * p.OW + p.ox0 + p.os * x] = acc[i][j][r] + (add_bias ? p.bias[co] : 0.f);
+        if (co < p.Cout && y < p.H && x < p.W) {
+          float v = acc[i][j][r] + (add_bias ? p.bias[co] : 0.f);
+          const int64_t o = co * oplane + (int64_t)(p.oy0 + p.os * y) * p.OW + p.ox0 + p.os * x;
+          if (p.ep_mode == 1) v = fmaxf(v, 0.f);
+          if (p.ep_mode == 2) {
+            const int64_t e = (int64_t)n * p.Cout * oplane + o;
+            v = p.ep_mask[e] > 0.f ? v + (p.ep_add ? p.ep_add[e] : 0.f) : 0.f;
+          }
+          ob[o] = v;
+          if (p.ep_mode) {      // padded output: the tiles on the rim of the map also store the zero border next to them
+            float* q = ob + o;
+            const bool xl = x == 0, xr = x == p.W - 1;
+            if (xl) q[-1] = 0.f;
+            if (xr) q[1] = 0.f;
+            if (y == 0) {
+              q[-p.OW] = 0.f;
+              if (xl) q[-p.OW - 1] = 0.f;
+              if (xr) q[-p.OW + 1] = 0.f;
+            }
+            if (y == p.H - 1) {
+              q[p.OW] = 0.f;
+              if (xl) q[p.OW - 1] = 0.f;
+              if (xr) q[p.OW + 1] = 0.f;
+            }
+          }
+        }
       }
     }
 }
@@ -693,6 +724,67 @@ extern "C" int vts_conv3x3_wide(const float* in, const float* wt, const float* b
   k.IPH = H + 2; k.IPW = W + 2; k.OH = H; k.OW = W; k.os = 1; k.oy0 = 0; k.ox0 = 0;
   full_taps(k);
   return wide_launch(k, 1, ws, ws_floats, (hipStream_t)stream);
+}
+
+// The frozen VGG stacks of the perceptual terms (round 4): activations and their gradients live in the NEXT convolution's pre-padded layout
+// [N, C, H + 2, W + 2] with a zero one-pixel border (stored by the tiles on the rim of the map, together with their outputs).
+//   vts_conv3x3_wide_relu_pad   forward: out interior = max(conv + bias, 0).  The separate ReLU + padding pass between two convolutions
+//                               (vts_pad_affine: a read and a write of every feature map) disappears; taps, pooling and the ReLU mask of
+//                               the backward read the padded tensor (relu(z) > 0 <=> z > 0)
+//   vts_conv3x3_wide_mask_pad   input adjoint: out interior = (conv + add) where mask > 0, else 0 -- `mask` the padded ReLU'd activation
+//                               of the layer in front, `add` (optional, same layout) that layer's tap gradient: the ReLU-mask + padding
+//                               pass between two adjoints (vts_relu_mask_pad) disappears
+// Tiled direct launches only: VTS_ERR_UNSUPPORTED for shapes that take the flattened / k-split paths (the caller keeps the dense form there).
+__global__ __launch_bounds__(256) void zero_border_kernel(float* __restrict__ buf, int PH, int PW, int pad) {
+  float* o = buf + (int64_t)blockIdx.y * PH * PW;
+  const int rows = 2 * pad * PW, side = 2 * pad * (PH - 2 * pad);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows + side; i += gridDim.x * 256) {
+    int y, x;
+    if (i < rows) {
+      const int r = i / PW;
+      y = r < pad ? r : PH - 2 * pad + r; x = i - r * PW;
+    } else {
+      const int j = i - rows, r = j / (2 * pad), c = j - r * 2 * pad;
+      y = pad + r; x = c < pad ? c : PW - 2 * pad + c;
+    }
+    o[(int64_t)y * PW + x] = 0.f;
+  }
+}
+
+extern "C" int vts_zero_border(float* buf, int64_t NC, int H, int W, int pad, void* stream) {
+  VTS_CHECK_ARG(buf && NC >= 1 && NC <= 0x7fffffff && H >= 1 && W >= 1 && pad >= 1 && pad <= 8, "vts_zero_border: bad args");
+  const int PH = H + 2 * pad, PW = W + 2 * pad, per = 2 * pad * (PW + H);
+  for (int64_t c0 = 0; c0 < NC; c0 += 65535) {
+    const int nc = (int)std::min<int64_t>(65535, NC - c0);
+    hipLaunchKernelGGL(zero_border_kernel, dim3(std::min(cdiv(per, 256), 64), nc), dim3(256), 0, (hipStream_t)stream, buf + c0 * PH * PW, PH, PW, pad);
+  }
+  VTS_CHECK_LAUNCH("vts_zero_border");
+  return VTS_OK;
+}
+
+static int wide_pad_launch(WideK& k, int N, int Cin, int Cout, int H, int W, hipStream_t st) {
+  k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
+  k.IPH = H + 2; k.IPW = W + 2; k.OH = H + 2; k.OW = W + 2; k.os = 1; k.oy0 = 1; k.ox0 = 1;
+  full_taps(k);
+  int cps;
+  if (flat_ok(H, W, k.IPH * k.IPW, CK) || wide_plan(N, Cin, Cout, H, W, &cps) > 1 || (Cout & 3)) return VTS_ERR_UNSUPPORTED;
+  return wide_launch(k, 1, nullptr, 0, st);
+}
+
+extern "C" int vts_conv3x3_wide_relu_pad(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int H, int W,
+                                         void* stream) {
+  VTS_CHECK_ARG(in && wt && out && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "vts_conv3x3_wide_relu_pad: bad args");
+  WideK k{};
+  k.in = in; k.wt = wt; k.bias = bias; k.out = out; k.ep_mode = 1;
+  return wide_pad_launch(k, N, Cin, Cout, H, W, (hipStream_t)stream);
+}
+
+extern "C" int vts_conv3x3_wide_mask_pad(const float* in, const float* wt, float* out, int N, int Cin, int Cout, int H, int W, const float* add,
+                                         const float* mask, void* stream) {
+  VTS_CHECK_ARG(in && wt && out && mask && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "vts_conv3x3_wide_mask_pad: bad args");
+  WideK k{};
+  k.in = in; k.wt = wt; k.bias = nullptr; k.out = out; k.ep_mode = 2; k.ep_add = add; k.ep_mask = mask;
+  return wide_pad_launch(k, N, Cin, Cout, H, W, (hipStream_t)stream);
 }
 
 extern "C" int vts_conv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int OH, int OW,

@@ -17,18 +17,19 @@ __device__ __forceinline__ void loss_add64(long long* slot, double v) {
 
 // out[nc][1 + y][1 + x] = max over the 2x2 window of relu(z); the one-pixel border (pad = 1) is written as zeros: the next
 // convolution's pre-padded input in one pass.  pad = 0: plain pooled map.
-__global__ __launch_bounds__(256) void maxpool2_relu_pad_kernel(const float* __restrict__ z, int H, int W, int pad, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void maxpool2_relu_pad_kernel(const float* __restrict__ z, int H, int W, int pad, float* __restrict__ out, int zpad) {
   const int OH = H >> 1, OW = W >> 1, PH = OH + 2 * pad, PW = OW + 2 * pad;
   const int64_t nc = blockIdx.y;
-  const float* zi = z + nc * (int64_t)H * W;
+  const int ZW = W + 2 * zpad;                    // (zpad: z itself is a padded tensor [H + 2 zpad][W + 2 zpad], read at its interior)
+  const float* zi = z + nc * (int64_t)(H + 2 * zpad) * ZW + (int64_t)zpad * ZW + zpad;
   float* o = out + nc * (int64_t)PH * PW;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < PH * PW; i += gridDim.x * 256) {
     const int py = i / PW, px = i - py * PW;
     const int y = py - pad, x = px - pad;
     float v = 0.f;
     if (y >= 0 && y < OH && x >= 0 && x < OW) {
-      const float* q = zi + (int64_t)(2 * y) * W + 2 * x;
-      v = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[W], q[W + 1])), 0.f);
+      const float* q = zi + (int64_t)(2 * y) * ZW + 2 * x;
+      v = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[ZW], q[ZW + 1])), 0.f);
     }
     o[i] = v;
   }
@@ -75,45 +76,59 @@ __global__ __launch_bounds__(256) void s2d4_pad_kernel(const float* __restrict__
 // adjoint of (relu -> MaxPool2d(2, 2)) w.r.t. relu(z): the pooled gradient goes to the FIRST element (row-major scan of the
 // window, PyTorch's tie rule) that holds the window maximum of relu(z).  Windows whose maximum is <= 0 route to their first element
 // in PyTorch and the ReLU mask then removes it: zero here.  Elements outside any window (odd H / W) get zero.
+// g2 (optional): the tap gradient of this layer, in z's layout, added where z > 0.  pad: the result is written into the interior of a
+// [H + 2 pad][W + 2 pad] map with a zero border (the next input adjoint's pre-padded operand), i.e. the routed gradient is the gradient
+// w.r.t. z itself (routing only reaches elements with z > 0).
 __global__ __launch_bounds__(256) void maxpool2_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z, int H, int W,
-                                                                float* __restrict__ gz) {
-  const int OH = H >> 1, OW = W >> 1;
+                                                                float* __restrict__ gz, int zpad, const float* __restrict__ g2, int pad) {
+  const int OH = H >> 1, OW = W >> 1, PH = H + 2 * pad, PW = W + 2 * pad;
   const int64_t nc = blockIdx.y;
-  const float* zi = z + nc * (int64_t)H * W;
+  const int ZW = W + 2 * zpad;
+  const int64_t zo = nc * (int64_t)(H + 2 * zpad) * ZW + (int64_t)zpad * ZW + zpad;
+  const float* zi = z + zo;
+  const float* ti = g2 ? g2 + zo : nullptr;
   const float* gi = g + nc * (int64_t)OH * OW;
-  float* o = gz + nc * (int64_t)H * W;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
-    const int y = i / W, x = i - y * W;
-    const int wy = y >> 1, wx = x >> 1;
+  float* o = gz + nc * (int64_t)PH * PW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < PH * PW; i += gridDim.x * 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int y = py - pad, x = px - pad;
     float v = 0.f;
-    if (wy < OH && wx < OW) {
-      const float* q = zi + (int64_t)(2 * wy) * W + 2 * wx;
-      const float e[4] = {q[0], q[1], q[W], q[W + 1]};
-      const float m = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
-      const int k = (y & 1) * 2 + (x & 1);
-      bool first = e[k] == m && m > 0.f;
-      for (int j = 0; j < k; ++j) first = first && e[j] != m;
-      if (first) v = gi[(int64_t)wy * OW + wx];
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const int wy = y >> 1, wx = x >> 1;
+      if (wy < OH && wx < OW) {
+        const float* q = zi + (int64_t)(2 * wy) * ZW + 2 * wx;
+        const float e[4] = {q[0], q[1], q[ZW], q[ZW + 1]};
+        const float m = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+        const int k = (y & 1) * 2 + (x & 1);
+        bool first = e[k] == m && m > 0.f;
+        for (int j = 0; j < k; ++j) first = first && e[j] != m;
+        if (first) v = gi[(int64_t)wy * OW + wx];
+      }
+      if (ti && zi[(int64_t)y * ZW + x] > 0.f) v += ti[(int64_t)y * ZW + x];
     }
     o[i] = v;
   }
 }
 
-// out[nc][pad + y][pad + x] = (g + g2) * (z > 0), zero border: ReLU backward fused with the zero padding the adjoint convolution wants
+// out[nc][pad + y][pad + x] = (g + g2) * (z > 0), zero border: ReLU backward fused with the zero padding the adjoint convolution wants.
+// g (optional) is dense [H][W]; g2 (optional, a tap gradient) has z's layout.
 __global__ __launch_bounds__(256) void relu_mask_pad_kernel(const float* __restrict__ g, const float* __restrict__ g2, const float* __restrict__ z,
-                                                            int H, int W, int pad, float* __restrict__ out) {
+                                                            int H, int W, int pad, float* __restrict__ out, int zpad) {
   const int PH = H + 2 * pad, PW = W + 2 * pad;
   const int64_t nc = blockIdx.y;
   const int64_t off = nc * (int64_t)H * W;
+  const int ZW = W + 2 * zpad;
+  const int64_t zo = nc * (int64_t)(H + 2 * zpad) * ZW + (int64_t)zpad * ZW + zpad;
+  const float* zi = z + zo;
+  const float* ti = g2 ? g2 + zo : nullptr;
   float* o = out + nc * (int64_t)PH * PW;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < PH * PW; i += gridDim.x * 256) {
     const int py = i / PW, px = i - py * PW;
     const int y = py - pad, x = px - pad;
     float v = 0.f;
     if (y >= 0 && y < H && x >= 0 && x < W) {
-      const int64_t j = off + (int64_t)y * W + x;
-      const float t = (g ? g[j] : 0.f) + (g2 ? g2[j] : 0.f);
-      v = z[j] > 0.f ? t : 0.f;
+      const float t = (g ? g[off + (int64_t)y * W + x] : 0.f) + (ti ? ti[(int64_t)y * ZW + x] : 0.f);
+      v = zi[(int64_t)y * ZW + x] > 0.f ? t : 0.f;
     }
     o[i] = v;
   }
@@ -121,21 +136,26 @@ __global__ __launch_bounds__(256) void relu_mask_pad_kernel(const float* __restr
 
 // LPIPS head of one tap.  Thread = pixel, loop over channels (coalesced across the wave: channel stride HW).
 //   a = f0 / (|f0| + eps), b = f1 / (|f1| + eps), d = sum_c w_c (a_c - b_c)^2, value = coeff * sum_{n, pixels} d / HW
-//   dz0 (gradient w.r.t. relu(z0), optional) = grad_coeff / HW * d(d)/d(f0)
+//   dz0 (optional) = grad_coeff / HW * d(d)/d(f0) where z0 > 0, else 0: the gradient w.r.t. z0 itself (ReLU mask applied), in z0's layout
 __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ z0, const float* __restrict__ z1, int C, int HW,
                                                           const float* __restrict__ w, float coeff, long long* __restrict__ loss,
-                                                          float* __restrict__ dz0, float grad_coeff) {
+                                                          float* __restrict__ dz0, float grad_coeff, int W, int zpad) {
   __shared__ float red[16];
   const int n = blockIdx.y;
-  const float* p0 = z0 + (int64_t)n * C * HW;
-  const float* p1 = z1 + (int64_t)n * C * HW;
-  float* pg = dz0 ? dz0 + (int64_t)n * C * HW : nullptr;
+  // zpad: both feature tensors are padded [C][H + 2 zpad][W + 2 zpad] (the ReLU'd, pre-padded outputs of vts_conv3x3_wide_relu_pad), read
+  // at their interior; the gradient dz0 has the same layout (its border is the caller's: vts_zero_border)
+  const int ZW = W + 2 * zpad;
+  const int64_t ZP = zpad ? (int64_t)(HW / W + 2 * zpad) * ZW : HW;
+  const float* p0 = z0 + (int64_t)n * C * ZP;
+  const float* p1 = z1 + (int64_t)n * C * ZP;
+  float* pg = dz0 ? dz0 + (int64_t)n * C * ZP : nullptr;
   const float eps = 1e-10f;
   float acc = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const int64_t zi = zpad ? (int64_t)(i / W + zpad) * ZW + (i % W) + zpad : i;
     float s0 = 0.f, s1 = 0.f;
     for (int c = 0; c < C; ++c) {
-      const float f0 = fmaxf(p0[(int64_t)c * HW + i], 0.f), f1 = fmaxf(p1[(int64_t)c * HW + i], 0.f);
+      const float f0 = fmaxf(p0[(int64_t)c * ZP + zi], 0.f), f1 = fmaxf(p1[(int64_t)c * ZP + zi], 0.f);
       s0 = fmaf(f0, f0, s0);
       s1 = fmaf(f1, f1, s1);
     }
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     const float i0 = 1.f / (r0 + eps), i1 = 1.f / (r1 + eps);
     float d = 0.f, S = 0.f;
     for (int c = 0; c < C; ++c) {
-      const float f0 = fmaxf(p0[(int64_t)c * HW + i], 0.f), f1 = fmaxf(p1[(int64_t)c * HW + i], 0.f);
+      const float f0 = fmaxf(p0[(int64_t)c * ZP + zi], 0.f), f1 = fmaxf(p1[(int64_t)c * ZP + zi], 0.f);
       const float t = f0 * i0 - f1 * i1;
       const float wt = w[c] * t;
       d = fmaf(wt, t, d);
@@ -155,13 +175,83 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
       const float k1 = 2.f * grad_coeff / (float)HW * i0;
       const float k2 = r0 > 0.f ? 2.f * grad_coeff / (float)HW * S * i0 * i0 / r0 : 0.f;
       for (int c = 0; c < C; ++c) {
-        const float f0 = fmaxf(p0[(int64_t)c * HW + i], 0.f), f1 = fmaxf(p1[(int64_t)c * HW + i], 0.f);
+        const float f0 = fmaxf(p0[(int64_t)c * ZP + zi], 0.f), f1 = fmaxf(p1[(int64_t)c * ZP + zi], 0.f);
         const float t = f0 * i0 - f1 * i1;
-        pg[(int64_t)c * HW + i] = k1 * w[c] * t - k2 * f0;
+        pg[(int64_t)c * ZP + zi] = f0 > 0.f ? k1 * w[c] * t - k2 * f0 : 0.f;
       }
     }
   }
   acc = block_sum(acc, red);
+  if (threadIdx.x == 0 && loss) loss_add64(loss, (double)acc * (double)coeff / (double)HW);
+}
+
+// The same head for the VGG channel counts (64 | 128 | 256 | 512), ONE pass over the features (round 4): a workgroup takes 64 pixels
+// (one per lane), its NW waves split the channels (CPW each) and keep their slice of f0 / f1 in registers; the two channel reductions
+// (|f|^2, then d and S) cross the waves through LDS in a fixed order.  The generic kernel above reads every feature three times.
+template <int CPW, int NW>
+__global__ __launch_bounds__(64 * NW) void lpips_layer_regs_kernel(const float* __restrict__ z0, const float* __restrict__ z1, int HW,
+                                                                    const float* __restrict__ w, float coeff, long long* __restrict__ loss,
+                                                                    float* __restrict__ dz0, float grad_coeff, int W, int zpad) {
+  constexpr int C = CPW * NW;
+  __shared__ float part[4][NW][64];
+  __shared__ float red[16];
+  const int n = blockIdx.y, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ZW = W + 2 * zpad;
+  const int64_t ZP = zpad ? (int64_t)(HW / W + 2 * zpad) * ZW : HW;
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < HW;
+  const int ic = live ? i : HW - 1;
+  const int64_t zi = zpad ? (int64_t)(ic / W + zpad) * ZW + (ic % W) + zpad : ic;
+  const int64_t base = ((int64_t)n * C + wv * CPW) * ZP + zi;
+  const float* p0 = z0 + base;
+  const float* p1 = z1 + base;
+  const float eps = 1e-10f;
+  float f0[CPW], f1[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    f0[c] = fmaxf(p0[(int64_t)c * ZP], 0.f);
+    f1[c] = fmaxf(p1[(int64_t)c * ZP], 0.f);
+  }
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    s0 = fmaf(f0[c], f0[c], s0);
+    s1 = fmaf(f1[c], f1[c], s1);
+  }
+  part[0][wv][lane] = s0;
+  part[1][wv][lane] = s1;
+  __syncthreads();
+  s0 = 0.f; s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) { s0 += part[0][k][lane]; s1 += part[1][k][lane]; }
+  const float r0 = sqrtf(s0), r1 = sqrtf(s1);
+  const float i0 = 1.f / (r0 + eps), i1 = 1.f / (r1 + eps);
+  float d = 0.f, S = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const float t = f0[c] * i0 - f1[c] * i1;
+    const float wt = w[wv * CPW + c] * t;
+    d = fmaf(wt, t, d);
+    S = fmaf(wt, f0[c], S);
+  }
+  part[2][wv][lane] = d;
+  part[3][wv][lane] = S;
+  __syncthreads();
+  d = 0.f; S = 0.f;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) { d += part[2][k][lane]; S += part[3][k][lane]; }
+  if (dz0 && live) {
+    float* pg = dz0 + base;
+    const float k1 = 2.f * grad_coeff / (float)HW * i0;
+    const float k2 = r0 > 0.f ? 2.f * grad_coeff / (float)HW * S * i0 * i0 / r0 : 0.f;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      const float t = f0[c] * i0 - f1[c] * i1;
+      pg[(int64_t)c * ZP] = f0[c] > 0.f ? k1 * w[wv * CPW + c] * t - k2 * f0[c] : 0.f;
+    }
+  }
+  const float acc = block_sum(live && wv == 0 ? d : 0.f, red);
   if (threadIdx.x == 0 && loss) loss_add64(loss, (double)acc * (double)coeff / (double)HW);
 }
 
@@ -219,13 +309,13 @@ inline unsigned blocks_1d(int64_t n) {
 
 }  // namespace
 
-extern "C" int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, void* stream) {
-  VTS_CHECK_ARG(z && out && NC >= 1 && H >= 2 && W >= 2 && (pad == 0 || pad == 1) && NC <= 65535 * 16, "vts_maxpool2_relu_pad: bad args");
+extern "C" int vts_maxpool2_relu_pad(const float* z, int NC, int H, int W, int pad, float* out, int zpad, void* stream) {
+  VTS_CHECK_ARG(z && out && NC >= 1 && H >= 2 && W >= 2 && (pad == 0 || pad == 1) && NC <= 65535 * 16 && zpad >= 0 && zpad <= 2, "vts_maxpool2_relu_pad: bad args");
   const int PH = H / 2 + 2 * pad, PW = W / 2 + 2 * pad;
   for (int c0 = 0; c0 < NC; c0 += 65535) {
     const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
-    hipLaunchKernelGGL(maxpool2_relu_pad_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream, z + (int64_t)c0 * H * W, H, W, pad,
-                       out + (int64_t)c0 * PH * PW);
+    hipLaunchKernelGGL(maxpool2_relu_pad_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream, z + (int64_t)c0 * (H + 2 * zpad) * (W + 2 * zpad), H, W, pad,
+                       out + (int64_t)c0 * PH * PW, zpad);
   }
   VTS_CHECK_LAUNCH("vts_maxpool2_relu_pad");
   return VTS_OK;
@@ -250,35 +340,48 @@ extern "C" int vts_s2d4_pad(const float* x, int N, int C, int H, int W, int pad,
   return VTS_OK;
 }
 
-extern "C" int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int H, int W, float* gz, void* stream) {
-  VTS_CHECK_ARG(g && z && gz && NC >= 1 && H >= 2 && W >= 2, "vts_maxpool2_relu_bwd: bad args");
+extern "C" int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int H, int W, float* gz, int zpad, const float* g2, int pad,
+                                     void* stream) {
+  VTS_CHECK_ARG(g && z && gz && NC >= 1 && H >= 2 && W >= 2 && zpad >= 0 && zpad <= 2 && pad >= 0 && pad <= 2, "vts_maxpool2_relu_bwd: bad args");
+  const int PH = H + 2 * pad, PW = W + 2 * pad;
   for (int c0 = 0; c0 < NC; c0 += 65535) {
     const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
-    hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3(blocks_1d((int64_t)H * W), nc), dim3(256), 0, (hipStream_t)stream,
-                       g + (int64_t)c0 * (H / 2) * (W / 2), z + (int64_t)c0 * H * W, H, W, gz + (int64_t)c0 * H * W);
+    const int64_t zo = (int64_t)c0 * (H + 2 * zpad) * (W + 2 * zpad);
+    hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream,
+                       g + (int64_t)c0 * (H / 2) * (W / 2), z + zo, H, W, gz + (int64_t)c0 * PH * PW, zpad, g2 ? g2 + zo : nullptr, pad);
   }
   VTS_CHECK_LAUNCH("vts_maxpool2_relu_bwd");
   return VTS_OK;
 }
 
-extern "C" int vts_relu_mask_pad(const float* g, const float* g2, const float* z, int NC, int H, int W, int pad, float* out, void* stream) {
-  VTS_CHECK_ARG((g || g2) && z && out && NC >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad <= 2, "vts_relu_mask_pad: bad args");
+extern "C" int vts_relu_mask_pad(const float* g, const float* g2, const float* z, int NC, int H, int W, int pad, float* out, int zpad, void* stream) {
+  VTS_CHECK_ARG((g || g2) && z && out && NC >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad <= 2 && zpad >= 0 && zpad <= 2, "vts_relu_mask_pad: bad args");
   const int PH = H + 2 * pad, PW = W + 2 * pad;
   for (int c0 = 0; c0 < NC; c0 += 65535) {
     const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
-    const int64_t o = (int64_t)c0 * H * W;
+    const int64_t o = (int64_t)c0 * H * W, zo = (int64_t)c0 * (H + 2 * zpad) * (W + 2 * zpad);
     hipLaunchKernelGGL(relu_mask_pad_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream, g ? g + o : nullptr,
-                       g2 ? g2 + o : nullptr, z + o, H, W, pad, out + (int64_t)c0 * PH * PW);
+                       g2 ? g2 + zo : nullptr, z + zo, H, W, pad, out + (int64_t)c0 * PH * PW, zpad);
   }
   VTS_CHECK_LAUNCH("vts_relu_mask_pad");
   return VTS_OK;
 }
 
 extern "C" int vts_lpips_layer(const float* z0, const float* z1, int N, int C, int HW, const float* w, float coeff, int64_t* loss_slot,
-                               float* dz0, float grad_coeff, void* stream) {
-  VTS_CHECK_ARG(z0 && z1 && w && N >= 1 && N <= 65535 && C >= 1 && HW >= 1, "vts_lpips_layer: bad args");
-  hipLaunchKernelGGL(lpips_layer_kernel, dim3(blocks_1d(HW), N), dim3(256), 0, (hipStream_t)stream, z0, z1, C, HW, w, coeff,
-                     reinterpret_cast<long long*>(loss_slot), dz0, grad_coeff);
+                               float* dz0, float grad_coeff, int W, int zpad, void* stream) {
+  VTS_CHECK_ARG(z0 && z1 && w && N >= 1 && N <= 65535 && C >= 1 && HW >= 1 && zpad >= 0 && zpad <= 2 && (zpad == 0 || (W >= 1 && HW % W == 0)),
+                "vts_lpips_layer: bad args");
+  static const int generic = getenv("VTS_LPIPS_GENERIC") ? 1 : 0;
+  const int Wm = W > 0 ? W : HW;
+  auto* slot = reinterpret_cast<long long*>(loss_slot);
+  const dim3 grid((HW + 63) / 64, N);
+  hipStream_t st = (hipStream_t)stream;
+  if (!generic && C == 64) hipLaunchKernelGGL((lpips_layer_regs_kernel<16, 4>), grid, dim3(256), 0, st, z0, z1, HW, w, coeff, slot, dz0, grad_coeff, Wm, zpad);
+  else if (!generic && C == 128) hipLaunchKernelGGL((lpips_layer_regs_kernel<32, 4>), grid, dim3(256), 0, st, z0, z1, HW, w, coeff, slot, dz0, grad_coeff, Wm, zpad);
+  else if (!generic && C == 256) hipLaunchKernelGGL((lpips_layer_regs_kernel<64, 4>), grid, dim3(256), 0, st, z0, z1, HW, w, coeff, slot, dz0, grad_coeff, Wm, zpad);
+  else if (!generic && C == 512) hipLaunchKernelGGL((lpips_layer_regs_kernel<64, 8>), grid, dim3(512), 0, st, z0, z1, HW, w, coeff, slot, dz0, grad_coeff, Wm, zpad);
+  else
+    hipLaunchKernelGGL(lpips_layer_kernel, dim3(blocks_1d(HW), N), dim3(256), 0, st, z0, z1, C, HW, w, coeff, slot, dz0, grad_coeff, Wm, zpad);
   VTS_CHECK_LAUNCH("vts_lpips_layer");
   return VTS_OK;
 }

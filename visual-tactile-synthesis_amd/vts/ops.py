@@ -1260,12 +1260,62 @@ def linear_rows(x, weight, bias=None, relu=False):
 
 
 # ---- perceptual terms: glue around the frozen VGG stacks (include/vts.h) ----
-def maxpool2_relu_pad(z, pad=1):
-    n, c, h, w = z.shape
+def maxpool2_relu_pad(z, pad=1, zpad=0):
+    """zpad: z is a padded tensor [N, C, H + 2 zpad, W + 2 zpad] read at its interior (the *_relu_pad convolution's output)"""
+    n, c = z.shape[:2]
+    h, w = z.shape[2] - 2 * zpad, z.shape[3] - 2 * zpad
     assert z.is_contiguous() and h >= 2 and w >= 2      # (odd sizes: the last row / column belongs to no window, as in MaxPool2d's floor mode)
     out = torch.empty(n, c, h // 2 + 2 * pad, w // 2 + 2 * pad, dtype=torch.float32, device=z.device)
-    _run("maxpool2_relu_pad", 4.0 * (z.numel() + out.numel()), 0.0, L.load().vts_maxpool2_relu_pad, z.data_ptr(), n * c, h, w, pad, out.data_ptr(), L.stream())
+    _run("maxpool2_relu_pad", 4.0 * (z.numel() + out.numel()), 0.0, L.load().vts_maxpool2_relu_pad, z.data_ptr(), n * c, h, w, pad, out.data_ptr(), zpad, L.stream())
     return out
+
+
+def conv3x3_wide_relu_pad(p, wt, bias, out):
+    """out [N, Co, H + 2, W + 2] (zero border, kept by the caller) <- interior = relu(valid 3x3 conv of the pre-padded p [N, Ci, H + 2, W + 2]);
+    returns False when the shape does not take a tiled direct launch (the caller then uses conv3x3_wide + a padding pass)"""
+    n, ci, ph, pw = p.shape
+    co, h, w = out.shape[1], ph - 2, pw - 2
+    assert out.shape == (n, co, ph, pw) and p.is_contiguous() and out.is_contiguous()
+    lib = L.load()
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d relu+pad" % (n, ci, h, w, co, h, w)
+    rc = [0]
+
+    def call(*a):
+        rc[0] = lib.vts_conv3x3_wide_relu_pad(*a)
+        return 0 if rc[0] == L.ERR_UNSUPPORTED else rc[0]
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() + wt.numel()), 2.0 * n * h * w * co * ci * 9, call,
+         p.data_ptr(), wt.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, L.stream())
+    return rc[0] == 0
+
+
+def conv3x3_wide_mask_pad(p, wt, out, mask, add=None):
+    """out [N, Co, H + 2, W + 2] (zero border) <- interior = (valid 3x3 conv of the pre-padded p + add) where mask > 0, else 0; mask / add
+    have out's layout.  The input adjoint of a frozen VGG layer with the ReLU mask of the layer in front (and that layer's tap gradient)
+    in its epilogue.  False: shape not taken (see conv3x3_wide_relu_pad)."""
+    n, ci, ph, pw = p.shape
+    co, h, w = out.shape[1], ph - 2, pw - 2
+    assert out.shape == (n, co, ph, pw) and mask.shape == out.shape and (add is None or add.shape == out.shape)
+    assert p.is_contiguous() and out.is_contiguous() and mask.is_contiguous() and (add is None or add.is_contiguous())
+    lib = L.load()
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d mask+pad" % (n, ci, h, w, co, h, w)
+    rc = [0]
+
+    def call(*a):
+        rc[0] = lib.vts_conv3x3_wide_mask_pad(*a)
+        return 0 if rc[0] == L.ERR_UNSUPPORTED else rc[0]
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() * (2 + (add is not None)) + wt.numel()), 2.0 * n * h * w * co * ci * 9, call,
+         p.data_ptr(), wt.data_ptr(), out.data_ptr(), n, ci, co, h, w, L.ptr(add), mask.data_ptr(), L.stream())
+    return rc[0] == 0
+
+
+def zero_border(buf, pad=1):
+    n, c, ph, pw = buf.shape
+    _run("zero_border", 0.0, 0.0, L.load().vts_zero_border, buf.data_ptr(), n * c, ph - 2 * pad, pw - 2 * pad, pad, L.stream())
+    return buf
 
 
 def maxpool3s2_relu_pad(z, pad=0):
@@ -1286,29 +1336,38 @@ def s2d4_pad(x, pad, oh, ow):
     return out
 
 
-def maxpool2_relu_bwd(g, z):
-    n, c, h, w = z.shape
-    assert g.shape == (n, c, h // 2, w // 2) and g.is_contiguous() and z.is_contiguous()
-    gz = torch.empty_like(z)
-    _run("maxpool2_relu_bwd", 4.0 * (2 * z.numel() + g.numel()), 0.0, L.load().vts_maxpool2_relu_bwd, g.data_ptr(), z.data_ptr(), n * c, h, w, gz.data_ptr(), L.stream())
+def maxpool2_relu_bwd(g, z, zpad=0, g2=None, pad=0):
+    """g2 (this layer's tap gradient, z's layout) is added where z > 0; pad: zero-bordered output (the next adjoint's operand)"""
+    n, c = z.shape[:2]
+    h, w = z.shape[2] - 2 * zpad, z.shape[3] - 2 * zpad
+    assert g.shape == (n, c, h // 2, w // 2) and g.is_contiguous() and z.is_contiguous() and (g2 is None or (g2.shape == z.shape and g2.is_contiguous()))
+    gz = torch.empty(n, c, h + 2 * pad, w + 2 * pad, dtype=torch.float32, device=z.device)
+    _run("maxpool2_relu_bwd", 4.0 * ((2 + (g2 is not None)) * gz.numel() + g.numel()), 0.0, L.load().vts_maxpool2_relu_bwd, g.data_ptr(), z.data_ptr(), n * c, h, w,
+         gz.data_ptr(), zpad, L.ptr(g2), pad, L.stream())
     return gz
 
 
-def relu_mask_pad(g, g2, z, pad=1):
-    n, c, h, w = z.shape
-    for t in (g, g2):
-        assert t is None or (t.shape == z.shape and t.is_contiguous())
+def relu_mask_pad(g, g2, z, pad=1, zpad=0):
+    """g: dense [N, C, H, W]; g2 (a tap gradient): z's layout"""
+    n, c = z.shape[:2]
+    h, w = z.shape[2] - 2 * zpad, z.shape[3] - 2 * zpad
+    assert g is None or (g.shape == (n, c, h, w) and g.is_contiguous())
+    assert g2 is None or (g2.shape == z.shape and g2.is_contiguous())
     out = torch.empty(n, c, h + 2 * pad, w + 2 * pad, dtype=torch.float32, device=z.device)
-    _run("relu_mask_pad", 4.0 * (z.numel() * (2 + (g is not None and g2 is not None)) + out.numel()), 0.0, L.load().vts_relu_mask_pad, L.ptr(g), L.ptr(g2),
-         z.data_ptr(), n * c, h, w, pad, out.data_ptr(), L.stream())
+    _run("relu_mask_pad", 4.0 * (n * c * h * w * (2 + (g is not None and g2 is not None)) + out.numel()), 0.0, L.load().vts_relu_mask_pad, L.ptr(g), L.ptr(g2),
+         z.data_ptr(), n * c, h, w, pad, out.data_ptr(), zpad, L.stream())
     return out
 
 
-def lpips_layer(z0, z1, w, coeff, loss_slot, dz0=None, grad_coeff=0.0):
-    n, c, h, wd = z0.shape
+def lpips_layer(z0, z1, w, coeff, loss_slot, dz0=None, grad_coeff=0.0, zpad=0):
+    """zpad: z0 / z1 are padded [N, C, H + 2 zpad, W + 2 zpad] tensors read at their interior; dz0 (the gradient w.r.t. z0, ReLU mask
+    applied) has z0's layout -- its border is the caller's"""
+    n, c = z0.shape[:2]
+    h, wd = z0.shape[2] - 2 * zpad, z0.shape[3] - 2 * zpad
     assert z1.shape == z0.shape and z0.is_contiguous() and z1.is_contiguous() and w.numel() == c
-    _run("lpips_layer", 4.0 * z0.numel() * (4 + 3 * (dz0 is not None)), 6.0 * z0.numel(), L.load().vts_lpips_layer, z0.data_ptr(), z1.data_ptr(), n, c, h * wd,
-         w.data_ptr(), coeff, L.ptr(loss_slot), L.ptr(dz0), grad_coeff, L.stream())
+    assert dz0 is None or dz0.shape == z0.shape
+    _run("lpips_layer", 4.0 * n * c * h * wd * (4 + 3 * (dz0 is not None)), 6.0 * n * c * h * wd, L.load().vts_lpips_layer, z0.data_ptr(), z1.data_ptr(), n, c, h * wd,
+         w.data_ptr(), coeff, L.ptr(loss_slot), L.ptr(dz0), grad_coeff, wd, zpad, L.stream())
 
 
 def l1_relu(za, zb, coeff, loss_slot, grad=None):

@@ -4,19 +4,25 @@
                   samples; :1648-1657: per-image sum over the NT patches), value into a fixed-point loss slot, gradient w.r.t. `fake`
   vgg_feature_l1  VGGLoss (models/networks.py:2021-2033): sum_i w_i L1(relu_i(x), relu_i(y)), gradient w.r.t. x
 
-Network layout: torchvision VGG features = 3x3 convolutions (padding 1) + ReLU, MaxPool2d(2, 2) between blocks.  Here every
-convolution's RAW output z is kept and relu is applied by the reader: the next convolution's pre-padded input is one fused pass
-(pad_affine with ReLU, or vts_maxpool2_relu_pad behind a block), the taps read z with relu on load.  The 3 -> 64 first layer runs as
-4x4 tap blocks on the generator's kernel (ops.convk), everything else on the GEMM-class MFMA kernels (ops.conv3x3_wide) with weights
-packed ONCE (the stacks are frozen).  The backward is the input adjoint only (no weight gradients): ReLU mask + padding in one pass
-(vts_relu_mask_pad), the same GEMM kernel on flipped / transposed packing, vts_maxpool2_relu_bwd behind a block.
+Network layout: torchvision VGG features = 3x3 convolutions (padding 1) + ReLU, MaxPool2d(2, 2) between blocks.  Round 4: a
+convolution stores relu(z) straight into the next convolution's pre-padded operand (zero one-pixel border), so between two convolutions
+of a block there is NO pass at all, and behind a block only the pooling pass; taps, pooling and the backward's ReLU mask read that padded
+tensor (relu(z) > 0 <=> z > 0).  The backward mirrors it: an input adjoint's epilogue applies the ReLU mask of the layer in front and
+adds that layer's tap gradient.  Layers whose maps are too small for a tiled launch keep the round-3 form: the RAW output
+z, relu applied by the reader, padding as one fused pass (pad_affine with ReLU / vts_relu_mask_pad).  Every convolution runs on the
+GEMM-class MFMA kernels (ops.conv3x3_wide; the 3 -> 64 stem as one 8-channel chunk) with weights packed ONCE (the stacks are frozen).
+The backward is the input adjoint only (no weight gradients): the same GEMM kernel on flipped / transposed packing,
+vts_maxpool2_relu_bwd behind a block, and the stem's 64 -> 3 adjoint as 4x4 tap blocks on the generator's kernel (ops.convk_bwd_data).
 """
+import os
+
 import torch
 
 from . import lib as L
 from . import ops
 
 RELU = L.ACT_RELU
+PADDED = os.environ.get("VTS_VGG_PADDED", "1") != "0"    # 0: every activation as a dense raw output + separate ReLU / padding passes (round 3)
 
 
 def _packed(net, k, mode):
@@ -43,8 +49,11 @@ def _layout(net):
 
 
 def vgg_forward(net, x, keep_all=True, last_tap_only_needed=True):
-    """x [N, 3, H, W] (already in the network's input space).  Returns {conv index: raw output z}: every convolution when keep_all
-    (a backward follows), else the tapped ones only.  Stops after the deepest tap."""
+    """x [N, 3, H, W] (already in the network's input space).  Returns {conv index: (activation, zpad)}: every convolution when keep_all
+    (a backward follows), else the tapped ones only.  Stops after the deepest tap.
+      zpad 1  relu(z) in the interior of a zero-bordered [N, C, H + 2, W + 2] tensor -- written by the convolution itself
+              (ops.conv3x3_wide_relu_pad) and read as it is by the next convolution: no pass in between
+      zpad 0  the raw output z, dense (maps too small for a tiled launch; VTS_VGG_PADDED=0)"""
     n, _, h, w = x.shape
     dev = x.device
     zs = {}
@@ -56,41 +65,77 @@ def vgg_forward(net, x, keep_all=True, last_tap_only_needed=True):
         conv = net.convs[k]
         co, ci = conv.weight.shape[:2]
         if k == 0:
-            z = torch.empty(n, co, h, w, dtype=torch.float32, device=dev)
-            ops.convk(x, conv.weight, z, bias=conv.bias, pad=1)
+            p = ops.pad_affine(x, (1, 1, 1, 1), 0)      # (3 channels: the stem runs on the GEMM-class kernel too, one 8-channel chunk)
         else:
-            p = ops.maxpool2_relu_pad(prev, 1) if pooled else ops.pad_affine(prev, (1, 1, 1, 1), 0, act=RELU)
-            z = torch.empty(n, co, p.shape[2] - 2, p.shape[3] - 2, dtype=torch.float32, device=dev)
+            pt, pz = prev
+            if pooled:
+                p = ops.maxpool2_relu_pad(pt, 1, zpad=pz)
+            else:
+                p = pt if pz else ops.pad_affine(pt, (1, 1, 1, 1), 0, act=RELU)
+        hh, ww = p.shape[2] - 2, p.shape[3] - 2
+        cur = None
+        if PADDED:
+            out = torch.empty(n, co, hh + 2, ww + 2, dtype=torch.float32, device=dev)
+            if ops.conv3x3_wide_relu_pad(p, _packed(net, k, "conv_fwd"), conv.bias, out):
+                cur = (out, 1)
+            del out
+        if cur is None:
+            z = torch.empty(n, co, hh, ww, dtype=torch.float32, device=dev)
             ops.conv3x3_wide(p, _packed(net, k, "conv_fwd"), conv.bias, z)
+            cur = (z, 0)
         if keep_all or k in net.taps:
-            zs[k] = z
-        prev = z
+            zs[k] = cur
+        prev = cur
     return zs
 
 
-def vgg_backward(net, zs, tap_grads, x_shape):
-    """gradient w.r.t. the network input given {tap conv index: gradient w.r.t. relu(z_tap)}; zs from vgg_forward(keep_all=True)"""
+def tap_gradient_buffer(feat):
+    """an uninitialised tap gradient in the activation's layout (zero border where it has one)"""
+    t, zp = feat
+    g = torch.empty_like(t)
+    if zp:
+        ops.zero_border(g, zp)
+    return g
+
+
+def vgg_backward(net, zs, tap_grads, x_shape, masked_taps=False):
+    """gradient w.r.t. the network input given {tap conv index: gradient w.r.t. relu(z_tap), in that activation's layout}; zs from
+    vgg_forward(keep_all=True).  masked_taps: the tap gradients already carry the ReLU mask (ops.lpips_layer writes them so).
+    G is the gradient w.r.t. z_k in the input adjoint's pre-padded layout; where the layer in front is kept padded its ReLU mask and tap
+    gradient ride in the adjoint's epilogue (ops.conv3x3_wide_mask_pad) or in the pooling adjoint (ops.maxpool2_relu_bwd)."""
     lay = [e for e in _layout(net) if e[0] <= max(net.taps)]
-    g = None            # gradient w.r.t. relu(z_k) arriving from the layers behind, at z_k's resolution
     n = x_shape[0]
-    for idx in range(len(lay) - 1, -1, -1):
+    top = max(k for k in tap_grads)
+    G = None
+    for idx in range(len(lay) - 1, 0, -1):
         k, pooled = lay[idx]
-        z = zs[k]
-        gt = tap_grads.get(k)
-        if g is None and gt is None:
+        if k > top:
             continue
+        if k == top:
+            zt, zp = zs[k]
+            G = tap_grads[k] if (masked_taps and zp == 1) else ops.relu_mask_pad(None, tap_grads[k], zt, pad=1, zpad=zp)
         conv = net.convs[k]
-        co, ci = conv.weight.shape[:2]
-        if k == 0:
-            gm = ops.relu_mask_pad(g, gt, z, pad=0)
-            dx = torch.empty(x_shape, dtype=torch.float32, device=z.device)
-            ops.convk_bwd_data(gm, conv.weight, dx, pad=1)
-            return dx
-        gp = ops.relu_mask_pad(g, gt, z, pad=1)
-        gin = torch.empty(n, ci, z.shape[2], z.shape[3], dtype=torch.float32, device=z.device)
-        ops.conv3x3_wide(gp, _packed(net, k, "conv_adj"), None, gin)
-        g = ops.maxpool2_relu_bwd(gin, zs[lay[idx - 1][0]]) if pooled else gin
-    raise RuntimeError("vgg_backward: no tap gradient given")
+        ci = conv.weight.shape[1]
+        kf = lay[idx - 1][0]
+        ft, fp = zs[kf]
+        T = tap_grads.get(kf)
+        hh, ww = G.shape[2] - 2, G.shape[3] - 2
+        if PADDED and not pooled and fp == 1:
+            out = torch.empty_like(ft)
+            if ops.conv3x3_wide_mask_pad(G, _packed(net, k, "conv_adj"), out, ft, add=T):
+                G = out
+                continue
+            del out
+        gin = torch.empty(n, ci, hh, ww, dtype=torch.float32, device=G.device)
+        ops.conv3x3_wide(G, _packed(net, k, "conv_adj"), None, gin)
+        G = ops.maxpool2_relu_bwd(gin, ft, zpad=fp, g2=T, pad=1) if pooled else ops.relu_mask_pad(gin, T, ft, pad=1, zpad=fp)
+    if G is None:
+        raise RuntimeError("vgg_backward: no tap gradient given")
+    # the stem's input adjoint (64 -> 3) on the generator's kernel: G carries a zero border, so the padding-1 adjoint of the dense
+    # gradient is the padding-2 adjoint of G (din[y] = sum_k G[y + 2 - k] w[k])
+    dx = torch.empty(x_shape, dtype=torch.float32, device=G.device)
+    ops.convk_bwd_data(G, net.convs[0].weight, dx, pad=2)
+    return dx
 
 
 def alex_forward(net, x):
@@ -149,13 +194,15 @@ def lpips_term(net, fake, real, coeff, loss_slot, grad_into=None, grad_accumulat
     z0 = vgg_forward(net, y0, keep_all=want)
     tap_grads = {}
     for i, k in enumerate(net.taps):
-        dz = torch.empty_like(z0[k]) if want else None
-        ops.lpips_layer(z0[k], z1[k], net.lins[i].view(-1), coeff, loss_slot, dz0=dz, grad_coeff=coeff)
+        assert z0[k][1] == z1[k][1]
+        dz = tap_gradient_buffer(z0[k]) if want else None
+        ops.lpips_layer(z0[k][0], z1[k][0], net.lins[i].view(-1), coeff, loss_slot, dz0=dz, grad_coeff=coeff, zpad=z0[k][1])
         if want:
             tap_grads[k] = dz
     if not want:
         return None
-    gy = vgg_backward(net, z0, tap_grads, tuple(y0.shape))
+    del z1
+    gy = vgg_backward(net, z0, tap_grads, tuple(y0.shape), masked_taps=True)
     return ops.lpips_input_bwd(gy, net.scale, grad_into, cx, accumulate=grad_accumulate, nstride=grad_nstride)
 
 
@@ -165,8 +212,13 @@ def vgg_feature_l1(net, x, y, coeff, loss_slot, want_grad=True):
     zx = vgg_forward(net, x, keep_all=want_grad)
     tap_grads = {}
     for wi, k in zip(net.weights, net.taps):
-        g = torch.empty_like(zx[k]) if want_grad else None
-        ops.l1_relu(zx[k], zy[k], coeff * wi / zx[k].numel(), loss_slot, grad=g)
+        (tx, zp), (ty, zq) = zx[k], zy[k]
+        assert zp == zq
+        # (padded activations: the two zero borders agree, so the flat pass over the whole buffers adds nothing there and leaves a zero
+        # border in the gradient; the mean is over the interior)
+        count = tx.shape[0] * tx.shape[1] * (tx.shape[2] - 2 * zp) * (tx.shape[3] - 2 * zp)
+        g = torch.empty_like(tx) if want_grad else None
+        ops.l1_relu(tx, ty, coeff * wi / count, loss_slot, grad=g)
         if want_grad:
             tap_grads[k] = g
     if not want_grad:
