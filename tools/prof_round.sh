@@ -15,6 +15,8 @@ python tools/pmc_mfma.py $O/pmc_mfma $O/mfma_util.json "$T"
 cp $O/traffic_pmc.json profiles/${T}_traffic_pmc.json; cp $O/mfma_util.json profiles/${T}_mfma_util.json
 # SQ counters per kernel instance (two passes of 8 counters: instructions, issue / LDS waits, MFMA busy, LDS bank conflicts)
 bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmcsq/sq.json $O/sq_counters.json; rm -rf gpurun_out/pmcsq
+python tools/sq_table.py $O/sq_counters.json $O/mfma_util.json > $O/sq_table.md
+[ -x tools/probes/bin/lastwg_sc1 ] && timeout 120 tools/probes/bin/lastwg_sc1 > $O/lastwg_probe.txt 2>&1
 python bench.py --detail $O/kernel_shape_table.txt > $O/bench.json 2>$O/bench.err
 VTS_DDP_FORCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29590 python bench.py --no_cpu_baseline > $O/bench_ddp_forced_1rank.json 2>/dev/null
 python bench.py --batch 1 --no_cpu_baseline > $O/bench_batch1.json 2>/dev/null
