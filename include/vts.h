@@ -584,7 +584,7 @@ int vts_copy_words(const void* src, void* dst, int64_t nwords, void* stream);
 
 /* set_input (models/sinskitG_model.py:702-793) with 8-bit sources: out[i] = src[i] / 255 (normalize 0: ToTensor) or (src[i] / 255 - 0.5) / 0.5
  * (normalize 1: + Normalize(0.5, 0.5)), evaluated in fp32 in the transform's own order -- bit-identical to the float tensor the reference's
- * dataset caches from the same PNG pixels (data/singleskit_dataset.py:269-276), so a batch may travel as uint8 (a quarter of the bytes). */
+ * dataset caches from the same PNG pixels (data/singleskit_dataset.py:317-329), so a batch may travel as uint8 (a quarter of the bytes). */
 int vts_u8_expand(const uint8_t* src, int64_t n, int normalize, float* out, void* stream);
 
 /* ---- optional collective of the data-parallel path (csrc/vts_comm.cpp; off by default, vts/ddp.py: VTS_DDP_DIRECT=1) ----------------
