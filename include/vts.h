@@ -587,6 +587,45 @@ int vts_copy_words(const void* src, void* dst, int64_t nwords, void* stream);
  * dataset caches from the same PNG pixels (data/singleskit_dataset.py:317-329), so a batch may travel as uint8 (a quarter of the bytes). */
 int vts_u8_expand(const uint8_t* src, int64_t n, int normalize, float* out, void* stream);
 
+/* ---- network-level entry (csrc/vts_unet.cpp; SURVEY.md 8b: `vts_unet_fwd`) ------------------------------------------------------------
+ * The inference forward of the reference's generator as ONE call, for hosts that are not Python: CustomUnetGenerator.forward
+ * (models/networks.py:1430-1645) over Down / Up (thirdparty/unet/unet_parts_custom.py:9-79) -- num_downs x [LeakyReLU(0.2) -> Conv2d(4, 2, 1)
+ * -> InstanceNorm2d] (down0: convolution only; the innermost block: no norm), num_downs x [ReLU -> ConvTranspose2d(4, 2, 1) on cat(x, skip)
+ * -> InstanceNorm2d] with the layers num_layer_separate-1 .. 0 duplicated for the tactile branch (`_T`), Tanh on both outermost blocks.
+ * This is what test.py's loop spends its time in (test.py:62-74 -> SinSKITGModel.forward, models/sinskitG_model.py:1309-1319); the
+ * Python product runs the same operators from vts/engine.py:unet_forward (bit-identical output: tests/test_network_abi_gpu.py).
+ *   in0 / in1      the network input as a channel concatenation of two sources (sketch ++ positional grid, sinskitG_model.py:1309-1313);
+ *                  in1.C = 0: one source.  Plain tensors: scale = shift = NULL
+ *   channels[i]    output channels of down_i; down_w[i] [channels[i]][Cin_i][4][4], down_b[i] [channels[i]] (NULL: no bias)
+ *   up_w[i]        nn.ConvTranspose2d layout [Cin_i][up_cout[i]][4][4] of up_i (Cin_i = channels of cat(x, skip_i), + style.C at the
+ *                  innermost block), up_b[i] [up_cout[i]]; upT_* the same for up_i_T, i < num_layer_separate
+ *   style          optional: the tiled style code [N][style.C][H >> num_downs][W >> num_downs] concatenated to the innermost block's
+ *                  input (skitG, style_code_mode concat + mapping tile: models/networks.py:1600-1630); style.C = 0: none
+ *   out            [N][up_cout[0] + upT_cout[0]][H][W]: visual channels first, then the tactile ones (the reference's torch.cat)
+ * H and W must be divisible by 2^num_downs.  No allocation, no host synchronisation: every launch goes to `stream` (and side_stream),
+ * scratch is vts_unet_forward_ws_floats(d) floats (-1 on a bad descriptor). */
+#define VTS_UNET_MAX_DOWNS 10
+typedef struct vts_unet_desc {
+  int N, H, W;
+  int num_downs, num_layer_separate;
+  vts_operand in0, in1;
+  int channels[VTS_UNET_MAX_DOWNS];
+  const float* down_w[VTS_UNET_MAX_DOWNS];
+  const float* down_b[VTS_UNET_MAX_DOWNS];
+  const float* up_w[VTS_UNET_MAX_DOWNS];
+  const float* up_b[VTS_UNET_MAX_DOWNS];
+  int up_cout[VTS_UNET_MAX_DOWNS];
+  const float* upT_w[VTS_UNET_MAX_DOWNS];
+  const float* upT_b[VTS_UNET_MAX_DOWNS];
+  int upT_cout[VTS_UNET_MAX_DOWNS];
+  vts_operand style;
+  float* out;
+  void* side_stream; /* optional second hipStream_t: the tactile branch (up_i_T, i < num_layer_separate) runs on it beside the visual
+                        branch, forked from and joined back into `stream` by events (capturable); NULL: everything on `stream` */
+} vts_unet_desc;
+int64_t vts_unet_forward_ws_floats(const vts_unet_desc* d);
+int vts_unet_forward(const vts_unet_desc* d, float* ws, int64_t ws_floats, void* stream);
+
 /* ---- optional collective of the data-parallel path (csrc/vts_comm.cpp; off by default, vts/ddp.py: VTS_DDP_DIRECT=1) ----------------
  * Sum-all-reduce of one flat fp32 gradient bucket as reduce-scatter + all-gather on the library's OWN RCCL communicator and side stream
  * (each rank reduces 1 / world of the bucket, all xGMI links carry a slice).  Replaces nn.DataParallel's gradient

@@ -1,0 +1,155 @@
+"""The network-level C entry vts_unet_forward (include/vts.h; SURVEY 8b's `vts_unet_fwd`): the generator's inference forward as ONE call.
+
+  * against the Python schedule of the product (vts/engine.py:unet_forward), bit for bit, at the sizes whose inner layers take the
+    k-split path and at the headline size; with the tiled style code of the skitG generator
+  * against the REFERENCE module's output (tests/golden/nets_256.npz: CustomUnetGenerator run on CPU), within the north_star tolerance
+  * from a host that is not Python: examples/unet_infer_host.cpp (built by __graft_entry__.build) reads the weights and the input from
+    a file, runs the forward with hipMalloc'ed buffers on its own stream and writes the output -- equal to the product's, bit for bit
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, nets  # noqa: E402  (checker only)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "visual-tactile-synthesis_amd", "bin", "unet_infer_host")
+FLAGS = ("--model %s --gpu_ids 0 --lambda_G1_lpips 0 --lambda_G2_lpips 0 --use_vision_aided_loss False "
+         "--lambda_G2_GAN_feat 0 --checkpoints_dir /tmp/vts_test_ckpt --name t --crop_size %d --batch_size %d")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def generator(size, n, model_name="sinskitG", seed=77):
+    from models import create_model
+    from options.train_options import TrainOptions
+
+    opt = TrainOptions(cmd_line=FLAGS % (model_name, size, n)).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    G = model.netG
+    if model_name == "sinskitG":
+        G.load_state_dict(detrand.test_weights(nets.g_param_shapes(), seed))
+    else:
+        G.load_state_dict(detrand.test_weights(nets.g_param_shapes(style_nc=opt.style_code_dim, num_layer_style_code=opt.num_layer_style_code), seed))
+    return G, opt
+
+
+@pytest.mark.parametrize("size,n", [(256, 1), (512, 2), (1024, 4)])
+def test_c_forward_equals_the_python_schedule_bit_for_bit(size, n):
+    from vts import engine
+
+    G, _ = generator(size, n)
+    dev = torch.device("cuda:0")
+    s = detrand.uniform((n, 1, size, size), 5, "sketch").to(dev)
+    grid = detrand.uniform((n, 8, size, size), 5, "grid").to(dev)
+    y_py, _ = engine.unet_forward(G, (s, grid), keep=False)
+    y_c = engine.unet_forward_c(G, (s, grid))
+    torch.cuda.synchronize()
+    assert torch.equal(y_c, y_py)
+    # one source instead of a concatenated pair
+    x = torch.cat([s, grid], 1)
+    assert torch.equal(engine.unet_forward_c(G, x), y_py)
+    # the tactile branch on a second stream (forked from / joined into the launch stream by events)
+    y_l = engine.unet_forward_c(G, (s, grid), side_stream=torch.cuda.Stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y_l, y_py)
+
+
+def test_c_forward_matches_the_reference_module(golden_dir):
+    """tests/golden/nets_256.npz holds the output of the reference's CustomUnetGenerator (run on CPU) for seeded weights and input"""
+    from vts import engine
+
+    g = np.load(os.path.join(golden_dir, "nets_256.npz"))
+    size, seed = int(g["size"]), int(g["seed"])
+    G, _ = generator(size, 1, seed=seed)
+    G.load_state_dict(detrand.test_weights(nets.g_param_shapes(), seed))
+    x = detrand.uniform((1, 9, size, size), seed, "g_in").to("cuda:0")
+    y = engine.unet_forward_c(G, x)
+    assert rel(y[:, :, ::4, ::4], g["G_out_sub"]) < 1e-4          # north_star: outputs within 1e-3 rel-L2; observed ~1e-6
+
+
+def test_c_forward_with_the_tiled_style_code():
+    """skitG: the unit-norm style code tiled over the innermost map and concatenated there (style_code_mode concat, mapping tile)"""
+    from vts import engine
+
+    G, opt = generator(256, 2, model_name="skitG")
+    dev = torch.device("cuda:0")
+    x = detrand.uniform((2, 9, 256, 256), 9, "g_in").to(dev)
+    sc = detrand.uniform((2, opt.style_code_dim), 9, "style")
+    sc = (sc / sc.norm(dim=1, keepdim=True)).to(dev)
+    y_py, _ = engine.unet_forward(G, x, style_code=sc, keep=False)
+    tile = sc[:, :, None, None].expand(-1, -1, 256 >> G.num_downs, 256 >> G.num_downs).contiguous()
+    assert torch.equal(engine.unet_forward_c(G, x, style_tile=tile), y_py)
+
+
+def test_bad_descriptors_are_refused_through_the_abi():
+    import ctypes as C
+
+    from vts import engine, lib as L
+
+    G, _ = generator(256, 1)
+    x = torch.zeros(1, 9, 256, 256, device="cuda:0")
+    out = torch.empty(1, 5, 256, 256, device="cuda:0")
+    lib = L.load()
+    d = engine.unet_desc(G, x, out)
+    d.H = 250                                    # not divisible by 2^num_downs (the reference's U-Net fails in torch.cat there)
+    assert lib.vts_unet_forward_ws_floats(C.byref(d)) == -1 and b"divisible" in lib.vts_last_error()
+    d = engine.unet_desc(G, x, out)
+    need = lib.vts_unet_forward_ws_floats(C.byref(d))
+    ws = torch.empty(16, device="cuda:0")
+    assert need > 16 and lib.vts_unet_forward(C.byref(d), ws.data_ptr(), 16, None) != 0 and b"workspace" in lib.vts_last_error()
+    d.up_cout[3] = 7                             # decoder / encoder channel mismatch
+    assert lib.vts_unet_forward_ws_floats(C.byref(d)) == -1 and b"up3" in lib.vts_last_error()
+
+
+def write_host_input(path, G, s, grid):
+    nd, nls = G.num_downs, G.num_layer_separate
+    n, _, h, w = s.shape
+    sd = {k: v.detach().float().cpu().numpy() for k, v in G.state_dict().items()}
+    with open(path, "wb") as f:
+        f.write(struct.pack("<9i", 0x55535456, n, h, w, nd, nls, s.shape[1], grid.shape[1], 0))
+        chans = [sd["down%d.model.%d.weight" % (i, 0 if i == 0 else 1)].shape[0] for i in range(nd)]
+        upc = [sd["up%d.model.1.weight" % i].shape[1] for i in range(nd)]
+        uptc = [sd["up%d_T.model.1.weight" % i].shape[1] if i < nls else 0 for i in range(nd)]
+        for lst in (chans, upc, uptc):
+            f.write(struct.pack("<%di" % nd, *lst))
+        f.write(s.cpu().numpy().astype("<f4").tobytes())
+        f.write(grid.cpu().numpy().astype("<f4").tobytes())
+        for i in range(nd):
+            k = "down%d.model.%d." % (i, 0 if i == 0 else 1)
+            names = [k + "weight", k + "bias", "up%d.model.1.weight" % i, "up%d.model.1.bias" % i]
+            if i < nls:
+                names += ["up%d_T.model.1.weight" % i, "up%d_T.model.1.bias" % i]
+            for name in names:
+                f.write(np.ascontiguousarray(sd[name]).astype("<f4").tobytes())
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="examples/unet_infer_host.cpp not built (python -c 'import __graft_entry__ as g; g.build()')")
+def test_a_cpp_host_runs_the_generator_without_python(tmp_path):
+    from vts import engine
+
+    size, n = 512, 2
+    G, _ = generator(size, n)
+    dev = torch.device("cuda:0")
+    s = detrand.uniform((n, 1, size, size), 3, "sketch").to(dev)
+    grid = detrand.uniform((n, 8, size, size), 3, "grid").to(dev)
+    y_py, _ = engine.unet_forward(G, (s, grid), keep=False)
+    torch.cuda.synchronize()
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_host_input(fin, G, s, grid)
+    r = subprocess.run([HOST, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "ms per image" in r.stdout
+    y = torch.from_numpy(np.fromfile(fout, dtype="<f4").reshape(n, 5, size, size))
+    assert torch.equal(y, y_py.cpu())

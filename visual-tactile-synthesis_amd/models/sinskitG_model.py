@@ -528,6 +528,10 @@ class SinSKITGModel(BaseModel):
             if self._style() is not None:
                 raise NotImplementedError("style codes are only built for netG=unet256_custom")
             g_out, self._g_ctx = engine.resnet_forward(self.netG, self._g_input(), keep=keep)
+        elif not keep:
+            # inference: one call of the network-level C entry (include/vts.h: vts_unet_forward) where it covers the configuration
+            g_out, self._g_ctx = engine.unet_forward_infer(self.netG, self._g_input(), style_code=self._style(),
+                                                           style_tiles=getattr(self, "_style_tiles", None)), None
         else:
             g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep,
                                                      style_tiles=getattr(self, "_style_tiles", None))

@@ -136,6 +136,92 @@ def unet_forward(G, x, style_code=None, keep=True, style_tiles=None):
     return g_out, ctx
 
 
+def unet_desc(G, x, g_out, style_tile=None, side_stream=None):
+    """vts_unet_desc of generator G on the input x (a tensor / Act or a pair that is concatenated on load) writing g_out [N, 5, H, W]:
+    the network-level C entry vts_unet_forward (include/vts.h) runs the inference forward from it.  style_tile: [N, style_dim, h, w]
+    tiled style code of the innermost block (style_code_mode concat + mapping tile), or None."""
+    import ctypes as C
+
+    if isinstance(x, (tuple, list)):
+        x0, x1 = _as_act(x[0]), _as_act(x[1])
+    else:
+        x0, x1 = _as_act(x), None
+    n, _, h, w = x0.data.shape
+    nd = G.num_downs
+    if nd > L.UNET_MAX_DOWNS:
+        raise ValueError("vts_unet_forward takes at most %d down blocks" % L.UNET_MAX_DOWNS)
+    d = L.UnetDesc()
+    d.N, d.H, d.W, d.num_downs, d.num_layer_separate = n, h, w, nd, G.num_layer_separate
+    d.in0 = x0.operand()
+    d.in1 = x1.operand() if x1 is not None else L.Operand(None, None, None, 0, 0)
+    for i in range(nd):
+        dn, up = getattr(G, "down%d" % i).conv, getattr(G, "up%d" % i).conv
+        d.channels[i] = dn.weight.shape[0]
+        d.down_w[i], d.down_b[i] = dn.weight.data_ptr(), L.ptr(dn.bias)
+        d.up_w[i], d.up_b[i], d.up_cout[i] = up.weight.data_ptr(), L.ptr(up.bias), up.weight.shape[1]
+        if i < G.num_layer_separate:
+            ut = getattr(G, "up%d_T" % i).conv
+            d.upT_w[i], d.upT_b[i], d.upT_cout[i] = ut.weight.data_ptr(), L.ptr(ut.bias), ut.weight.shape[1]
+    d.style = L.operand(style_tile) if style_tile is not None else L.Operand(None, None, None, 0, 0)
+    d.out = g_out.data_ptr()
+    d.side_stream = side_stream.cuda_stream if side_stream is not None else None     # the tactile branch's lane
+    return d
+
+
+UNET_C = os.environ.get("VTS_UNET_C", "1") != "0"     # inference forward through the network-level C entry (0: the Python schedule)
+
+
+def unet_c_ok(G, style_code):
+    """can vts_unet_forward run this generator's inference forward?  (plain U-Net, or the style code tiled into the innermost block)"""
+    if not UNET_C or G.num_downs > L.UNET_MAX_DOWNS:
+        return False
+    if style_code is None:
+        return True
+    return bool(G.use_style) and G.style_mapping == "tile" and G.style_mode == "concat" and G.num_layer_style_code == 1
+
+
+def unet_forward_infer(G, x, style_code=None, style_tiles=None):
+    """inference forward (nothing kept for a backward) -> g_out: ONE call of the network-level C entry where it covers the configuration
+    (the tactile decoder branch on the first side lane, as unet_forward runs it), else the Python schedule"""
+    if not unet_c_ok(G, style_code):
+        return unet_forward(G, x, style_code=style_code, keep=False, style_tiles=style_tiles)[0]
+    tile = None
+    if style_code is not None:
+        i = G.num_downs - 1
+        tile = style_tiles.get(i) if style_tiles else None
+        if tile is None:
+            x0 = _as_act(x[0] if isinstance(x, (tuple, list)) else x).data
+            hh, ww = x0.shape[2] >> G.num_downs, x0.shape[3] >> G.num_downs
+            tile = style_code.to(torch.float32)[:, :, None, None].expand(-1, -1, hh, ww).contiguous()
+    side = None
+    if PARALLEL_SCALES and G.num_layer_separate > 0:
+        pool = _SIDE_STREAMS.setdefault(torch.cuda.current_device(), [])
+        if not pool:
+            pool.append(torch.cuda.Stream())
+        side = pool[0]
+    return unet_forward_c(G, x, style_tile=tile, side_stream=side)
+
+
+def unet_forward_c(G, x, style_tile=None, g_out=None, side_stream=None):
+    """the generator's inference forward through ONE C call (vts_unet_forward); bit-identical to unet_forward(keep=False)"""
+    import ctypes as C
+
+    lib = L.load()
+    x0 = _as_act(x[0] if isinstance(x, (tuple, list)) else x)
+    n, _, h, w = x0.data.shape
+    if g_out is None:
+        nls = G.num_layer_separate
+        oc = G.up0.conv.weight.shape[1] + (G.up0_T.conv.weight.shape[1] if nls > 0 else 0)
+        g_out = _empty(n, oc, h, w, x0.data.device)
+    d = unet_desc(G, x, g_out, style_tile, side_stream)
+    need = lib.vts_unet_forward_ws_floats(C.byref(d))
+    if need < 0:
+        raise RuntimeError("vts_unet_forward: %s" % lib.vts_last_error().decode())
+    ws = torch.empty(int(need), dtype=torch.float32, device=x0.data.device)
+    L.check(lib.vts_unet_forward(C.byref(d), ws.data_ptr(), ws.numel(), L.stream()), "vts_unet_forward")
+    return g_out
+
+
 def _style_map_forward(G, j, style, hh, ww):
     """style_code_mapping<j> (networks.py:1459-1465, 1611-1615): Linear(style_dim, P, bias=False) -> BatchNorm1d (batch_size > 1) |
     InstanceNorm1d -> ReLU, reshaped to [N, P / (h w), h, w].  The Linear is a 1 x 1 convolution on a 1 x 1 map; BatchNorm1d over

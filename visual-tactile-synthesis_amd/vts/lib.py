@@ -67,6 +67,21 @@ class NormDesc(C.Structure):
     ]
 
 
+UNET_MAX_DOWNS = 10
+
+
+class UnetDesc(C.Structure):
+    """vts_unet_desc (include/vts.h): the generator's inference forward as one C call"""
+    _fields_ = [
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("num_downs", C.c_int), ("num_layer_separate", C.c_int),
+        ("in0", Operand), ("in1", Operand), ("channels", C.c_int * UNET_MAX_DOWNS),
+        ("down_w", C.c_void_p * UNET_MAX_DOWNS), ("down_b", C.c_void_p * UNET_MAX_DOWNS),
+        ("up_w", C.c_void_p * UNET_MAX_DOWNS), ("up_b", C.c_void_p * UNET_MAX_DOWNS), ("up_cout", C.c_int * UNET_MAX_DOWNS),
+        ("upT_w", C.c_void_p * UNET_MAX_DOWNS), ("upT_b", C.c_void_p * UNET_MAX_DOWNS), ("upT_cout", C.c_int * UNET_MAX_DOWNS),
+        ("style", Operand), ("out", C.c_void_p), ("side_stream", C.c_void_p),
+    ]
+
+
 class PatchJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_nstride", C.c_int64), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("img", C.c_void_p), ("offx", C.c_void_p), ("offy", C.c_void_p), ("P", C.c_int), ("dst", C.c_void_p),
@@ -95,7 +110,7 @@ SYMBOLS = [
     "vts_mask_select", "vts_mask_sample_ranks", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
     "vts_maxpool2_relu_pad", "vts_maxpool3s2_relu_pad", "vts_s2d4_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
     "vts_patch_jobs", "vts_g_post_stack", "vts_step_begin", "vts_conv4x4_bsums", "vts_norm_bwd_from_partials",
-    "vts_u8_expand", "vts_comm_unique_id", "vts_comm_init", "vts_allreduce_flat_async", "vts_allreduce_flat_wait", "vts_comm_destroy",
+    "vts_u8_expand", "vts_unet_forward", "vts_unet_forward_ws_floats", "vts_comm_unique_id", "vts_comm_init", "vts_allreduce_flat_async", "vts_allreduce_flat_wait", "vts_comm_destroy",
 ]
 
 
@@ -129,6 +144,8 @@ def load():
                  "vts_wgrad3x3_wide_ws_floats"):
         getattr(lib, name).restype = C.c_int64
     lib.vts_conv4x4_ws_floats.argtypes = [C.POINTER(ConvDesc)]
+    lib.vts_unet_forward_ws_floats.argtypes = [C.POINTER(UnetDesc)]
+    lib.vts_unet_forward_ws_floats.restype = C.c_int64
     lib.vts_conv4x4_norm_ws_floats.argtypes = [C.POINTER(ConvDesc)]
     lib.vts_conv4x4_norm_ws_floats.restype = C.c_int64
     lib.vts_norm_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -211,7 +228,7 @@ def load():
         "vts_conv3x3_wide_mask_pad": [vp, vp, vp, i, i, i, i, i, vp, vp, vp],
         "vts_zero_border": [vp, i64, i, i, i, vp],
         "vts_maxpool3s2_relu_pad": [vp, i, i, i, i, vp, vp],
-        "vts_u8_expand": [vp, i64, i, vp, vp], "vts_comm_unique_id": [vp], "vts_comm_init": [vp, i, i, vp], "vts_allreduce_flat_async": [vp, vp, i64, vp],
+        "vts_u8_expand": [vp, i64, i, vp, vp], "vts_unet_forward": [C.POINTER(UnetDesc), vp, i64, vp], "vts_comm_unique_id": [vp], "vts_comm_init": [vp, i, i, vp], "vts_allreduce_flat_async": [vp, vp, i64, vp],
         "vts_allreduce_flat_wait": [vp, vp], "vts_comm_destroy": [vp],
         "vts_s2d4_pad": [vp, i, i, i, i, i, i, i, vp, vp],
         "vts_maxpool2_relu_bwd": [vp, vp, i, i, i, vp, i, vp, i, vp],
