@@ -30,6 +30,10 @@ from vts.optim import FlatAdam, FlatParams
 from . import networks
 from .base_model import BaseModel
 
+# 1 (default): on one GPU the generator's discriminator-free loss terms run as one more lane beside the discriminator updates; 0: serially
+# behind them (A/B timing; results are identical: the lanes only read the forward's outputs and add into their own fixed-point loss slots)
+G_PRE_LANE = os.environ.get("VTS_G_PRE_LANE", "1") != "0"
+
 B = str2bool
 
 # (flag, type, default[, choices])  -- reference: sinskitG_model.py:52-296
@@ -722,7 +726,17 @@ class SinSKITGModel(BaseModel):
                 passes.append(dict(in0=self._real_stack, real=True, coeff=lam2, slot=slot["D_real_T_concat"], grad_coeff=0.5 * lam2,
                                    accumulate=True))
             jobs.append((self.netD2, passes))
-        engine.msd_multi(jobs, self.criterionGAN)
+        # single GPU: the generator's discriminator-free terms (_seg_g_pre: L1 / perceptual terms, patch scatter) run as one more lane
+        # beside the discriminator updates instead of serially behind them (data parallel: they are their own segment, the one the
+        # D / D2 all-reduces travel under)
+        self._g_pre_done = False
+        extra = None
+        if G_PRE_LANE and not self._ddp_segments():
+            def extra():
+                self._seg_g_pre()
+                self._g_pre_done = True
+        heavy = opt.lambda_G1_lpips > 0.0 or opt.lambda_G2_lpips > 0.0      # the perceptual terms: ~90 ms of VGG convolutions
+        engine.msd_multi(jobs, self.criterionGAN, extra=extra, extra_cost=90.0 if heavy else 0.1)
         if p_fake_I is not None:
             self.pred_fake_I = p_fake_I["preds"][-1][:n]
         if p_full is not None:
@@ -811,7 +825,9 @@ class SinSKITGModel(BaseModel):
         self._g_backward(part)
 
     def _seg_g_update(self):
-        self._seg_g_pre()
+        if not getattr(self, "_g_pre_done", False):
+            self._seg_g_pre()
+        self._g_pre_done = False
         self._seg_g_main()
 
     def _seg_g_enc(self):
@@ -832,6 +848,10 @@ class SinSKITGModel(BaseModel):
     def _seg_adam_g(self):
         self.optimizer_G.step(self._gscale, bump=False)
 
+    def _ddp_segments(self):
+        from vts import ddp as _ddp
+        return bool(_ddp.active() and (self.ddp.buckets if self.ddp is not None else {}))
+
     def _segments(self):
         """(segment, buckets to wait for before it, buckets to start after it).  Single GPU: three segments.  Data parallel: the
         step is cut where a gradient bucket becomes complete, and every all-reduce gets compute to travel under --
@@ -839,10 +859,9 @@ class SinSKITGModel(BaseModel):
           G_dec (decoder gradients, complete halfway through the backward) under the encoder's backward (_seg_g_enc),
           G_enc is the exposed one (waited for right before Adam(G)).
         The reference has no counterpart (nn.DataParallel, base_model.py:104-108, reduces inside autograd)."""
-        buckets = self.ddp.buckets if self.ddp is not None else {}
-        from vts import ddp as _ddp
-        if not (_ddp.active() and buckets):
+        if not self._ddp_segments():
             return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_update, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
+        buckets = self.ddp.buckets
         if "G_dec" in buckets:
             return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_pre, (), ()),
                     (lambda: self._seg_g_main("decoder"), ("D", "D2"), ("G_dec",)), (self._seg_g_enc, (), ("G_enc",)),

@@ -375,6 +375,8 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
             fn()
 
         def chain(lane):
+            # (weight gradients inline.  Round 4 re-measured them on a queue of their own per lane -- four streams, both queues forked
+            # from the launch stream in front of the lanes: + 0.22 ms on the step, as with one shared queue in round 3)
             for i in range(nls):
                 up_bwd(i, "up%d%s" % (i, "_T" if lane else ""), lane_dx[lane], lane_df[lane], inline, lane_mode=True)
 
@@ -799,11 +801,12 @@ class SideQueue:
     LANE = 7
 
     def __init__(self):
+        self.lane = SideQueue.LANE      # scratch / partial-arena index of this queue
         self.main = torch.cuda.current_stream()
         side = _SIDE_STREAMS.setdefault(torch.cuda.current_device(), [])
-        while len(side) < SideQueue.LANE:
+        while len(side) < self.lane:
             side.append(torch.cuda.Stream())
-        self.stream = side[SideQueue.LANE - 1]
+        self.stream = side[self.lane - 1]
         self.keep = []
         self.on = PARALLEL_SCALES
 
@@ -811,7 +814,7 @@ class SideQueue:
         if not self.on:
             return fn()
         self.stream.wait_stream(self.main)
-        lane, ops.WS_LANE = ops.WS_LANE, SideQueue.LANE
+        lane, ops.WS_LANE = ops.WS_LANE, self.lane
         try:
             with torch.cuda.stream(self.stream):
                 fn()
@@ -825,9 +828,9 @@ class SideQueue:
 
     def join(self):
         if self.on:
-            lane, ops.WS_LANE = ops.WS_LANE, SideQueue.LANE
+            lane, ops.WS_LANE = ops.WS_LANE, self.lane
             with torch.cuda.stream(self.stream):
-                ops.wgrad_flush(SideQueue.LANE)     # this lane's deferred weight-gradient reduction, on its own stream
+                ops.wgrad_flush(self.lane)     # this lane's deferred weight-gradient reduction, on its own stream
             ops.WS_LANE = lane
             self.main.wait_stream(self.stream)
         self.keep = []
@@ -1061,8 +1064,10 @@ def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=
     return None
 
 
-def msd_multi(jobs, criterion):
+def msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
     """Several discriminators' passes of one training phase, all scales of all of them side by side.
+    extra: a callable that runs as ONE MORE lane beside them (work of the phase that needs no discriminator: the generator's L1 /
+    perceptual terms, which only read the forward's outputs); extra_cost: its rough time in ms (for the packing of lanes into streams).
 
     jobs: [(D, [pass, ...]), ...]; the passes of one D run in order (BatchNorm running statistics and gradient
     accumulation are order dependent), different D's and different scales are independent lanes.
@@ -1080,7 +1085,9 @@ def msd_multi(jobs, criterion):
     sg_jobs = [j for j in jobs if getattr(j[0], "is_stylegan2_d", False)]
     jobs = [j for j in jobs if not getattr(j[0], "is_stylegan2_d", False)]
     if jobs:
-        _msd_multi(jobs, criterion)
+        _msd_multi(jobs, criterion, extra, extra_cost)
+    elif extra is not None:
+        extra()
     for D, passes in sg_jobs:
         _sg2d_passes(D, passes, criterion)
 
@@ -1120,7 +1127,52 @@ if KO_LANES:      # timing experiment (tools/probes/r02_ko.sh): the named discri
           % os.environ["VTS_KO_LANES"], file=sys.stderr, flush=True)
 
 
-def _msd_multi(jobs, criterion):
+LANE_STREAMS = int(os.environ.get("VTS_LANE_STREAMS", "4"))
+
+
+def _lane_groups(costs, env="VTS_LANE_GROUPS"):
+    """Which lanes share a stream.  The part runs at most FOUR hardware queues side by side (GPU_MAX_HW_QUEUES, default 4; with 5 - 8 the
+    step takes 10 - 11 ms instead of 5.9: the queues beyond four are time-sliced), and a replayed graph maps its parallel branches onto
+    them round-robin in capture order -- with one stream per lane (six or seven) WHICH lanes end up sharing a queue was an accident of
+    the enqueue order (measured 5.87 .. 6.26 ms over permutations of the same lanes; round 4).  So the lanes are packed into
+    VTS_LANE_STREAMS (4) streams here, longest-processing-time first on `costs` (ms estimates), the heavier lane of a stream first.
+    VTS_LANE_GROUPS="0|1,5|3|2,4" (discriminator updates) / VTS_LANE_GROUPS_G (the generator step's passes) override the packing
+    (measurement); VTS_LANE_STREAMS=0: one stream per lane."""
+    n = len(costs)
+    spec = os.environ.get(env, "")
+    if spec:
+        groups = [[int(t) for t in g.split(",") if t.strip() != "" and int(t) < n] for g in spec.split("|")]
+        groups = [g for g in groups if g]
+        seen = sorted(i for g in groups for i in g)
+        if len(seen) != len(set(seen)):
+            raise ValueError("VTS_LANE_GROUPS names a lane twice: %s" % spec)
+        return groups + [[i] for i in range(n) if i not in seen]      # lanes the spec does not mention keep their own stream
+    if LANE_STREAMS <= 0 or n <= LANE_STREAMS:
+        return [[i] for i in range(n)]
+    order = sorted(range(1, n), key=lambda i: -costs[i])
+    bins, load = [[0]], [costs[0]]            # lane 0 (the caller puts its heaviest lane first) stays on the launch stream
+    for i in order:
+        if len(bins) < LANE_STREAMS:
+            bins.append([i])
+            load.append(costs[i])
+            continue
+        k = min(range(len(bins)), key=lambda b: load[b])
+        bins[k].append(i)
+        load[k] += costs[i]
+    return bins
+
+
+def _lane_cost(passes, s):
+    """rough time of one discriminator scale over its passes, ms: a latency floor (its ~25 dependent launches) + a term per input pixel"""
+    px = 0
+    for p in passes:
+        a0 = p["_pyr"][s][0]
+        t = a0.data if isinstance(a0, Act) else a0
+        px += t.shape[0] * t.shape[2] * t.shape[3]
+    return 0.35 + 1e-7 * px
+
+
+def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
     lanes = []
     for D, passes in jobs:
         for p in passes:
@@ -1129,9 +1181,16 @@ def _msd_multi(jobs, criterion):
             p["_din"] = [None] * D.num_D
         for s in range(D.num_D):
             lanes.append((D, s, passes))
+    costs = [_lane_cost(passes, s) for _, s, passes in lanes]
+    if extra is not None:
+        lanes.append((None, -1, extra))
+        costs.append(float(extra_cost))
 
     def lane(i):
         D, s, passes = lanes[i]
+        if D is None:
+            passes()
+            return
         cache = {}      # packed weights of this scale: shared by its passes (they run in order in this lane)
         for p in passes:
             prep = p.get("prep")
@@ -1174,8 +1233,10 @@ def _msd_multi(jobs, criterion):
                 p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
                                                    p.get("input_grad") is not None, cache, into=into)
 
+    nograd = all(not p.get("param_grads", True) for _, passes in jobs for p in passes)     # the generator step's passes
+    groups = _lane_groups(costs, "VTS_LANE_GROUPS_G" if nograd else "VTS_LANE_GROUPS")
     with ops.deferred_wgrad():    # one reduction launch for the weight-gradient partials of all lanes, after they have joined
-        _run_lanes(len(lanes), lane)
+        _run_lanes(len(groups), lambda gi: [lane(i) for i in groups[gi]])
     for D, passes in jobs:
         for p in passes:
             if p.get("input_grad") is not None:
