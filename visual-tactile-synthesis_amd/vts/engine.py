@@ -1136,8 +1136,12 @@ def _lane_groups(costs, env="VTS_LANE_GROUPS"):
     them round-robin in capture order -- with one stream per lane (six or seven) WHICH lanes end up sharing a queue was an accident of
     the enqueue order (measured 5.87 .. 6.26 ms over permutations of the same lanes; round 4).  So the lanes are packed into
     VTS_LANE_STREAMS (4) streams here, longest-processing-time first on `costs` (ms estimates), the heavier lane of a stream first.
-    VTS_LANE_GROUPS="0|1,5|3|2,4" (discriminator updates) / VTS_LANE_GROUPS_G (the generator step's passes) override the packing
-    (measurement); VTS_LANE_STREAMS=0: one stream per lane."""
+    VTS_LANE_GROUPS="0|1,5|3|2,4" (discriminator updates) / VTS_LANE_GROUPS_G (the generator step's passes, insensitive: 5.67 - 5.72 ms
+    over eleven groupings) override the packing (measurement); VTS_LANE_STREAMS=0: one stream per lane.
+    Measured and dropped on top of the packing (round 4): the launch-stream lane's weight gradients appended to the lightest other
+    stream (5.95 vs 5.67 ms); side-queue items issued one item late, so that the launch chain's own edge leaves a fork node of the
+    captured graph first (5.87 vs 5.67 ms); 2 / 3 / 5 / all side-queue items of the generator backward behind ONE wait on the launch
+    stream (5.63 - 5.70 ms: no effect); the decoder lanes' weight gradients on queues of their own (+ 0.22 ms)."""
     n = len(costs)
     spec = os.environ.get(env, "")
     if spec:
