@@ -7,7 +7,6 @@ VTS_G_PRE_LANE=0 run "packed, L1 terms serial"
 VTS_LANE_STREAMS=3 run "three streams"
 VTS_LANE_STREAMS=5 run "five streams"
 VTS_LANE_GROUPS="0|1,2,3,4,5" run "two streams"
-GPU_MAX_HW_QUEUES=3 run "GPU_MAX_HW_QUEUES=3"
 GPU_MAX_HW_QUEUES=5 run "GPU_MAX_HW_QUEUES=5"
 GPU_MAX_HW_QUEUES=8 run "GPU_MAX_HW_QUEUES=8"
 done

@@ -793,46 +793,60 @@ PARALLEL_SCALES = os.environ.get("VTS_PARALLEL_SCALES", "1") != "0"
 _SIDE_STREAMS = {}
 
 
+SIDE_QUEUES = int(os.environ.get("VTS_SIDE_QUEUES", "2"))     # round 4: 5.65 -> 5.59 ms (three: 5.61)
+
+
 class SideQueue:
     """Work that nothing on the launch stream waits for until the end of a phase -- the weight / bias gradients of a
     backward pass (28 % of the step's kernel time, all of it off the critical path of the backward-data chain) --
-    is enqueued on one side stream: `run` forks at the current point of the launch stream (the operands are ready
-    there) and keeps the operand tensors alive; `join` makes the launch stream wait once, at the end."""
+    is enqueued on side streams: `run` forks at the current point of the launch stream (the operands are ready
+    there) and keeps the operand tensors alive; `join` makes the launch stream wait once, at the end.  Round 4: the items alternate
+    between TWO streams (the generator backward's trunk / encoder phase has the launch chain and nothing else on the other queues, and
+    its weight gradients take longer than its backward-data chain: the join used to wait for them)."""
     LANE = 7
 
     def __init__(self):
-        self.lane = SideQueue.LANE      # scratch / partial-arena index of this queue
         self.main = torch.cuda.current_stream()
         side = _SIDE_STREAMS.setdefault(torch.cuda.current_device(), [])
-        while len(side) < self.lane:
+        while len(side) < SideQueue.LANE:
             side.append(torch.cuda.Stream())
-        self.stream = side[self.lane - 1]
+        # VTS_SIDE_QUEUES=2: items alternate between two streams (scratch / partial-arena index = the stream's lane number)
+        self.lanes = [SideQueue.LANE - k for k in range(max(1, SIDE_QUEUES))]
+        self.streams = [side[ln - 1] for ln in self.lanes]
+        self.turn = 0
         self.keep = []
         self.on = PARALLEL_SCALES
 
     def run(self, fn, *tensors):
         if not self.on:
             return fn()
-        self.stream.wait_stream(self.main)
-        lane, ops.WS_LANE = ops.WS_LANE, self.lane
+        k = self.turn % len(self.lanes)
+        self.turn += 1
+        stream, ln = self.streams[k], self.lanes[k]
+        stream.wait_stream(self.main)
+        lane, ops.WS_LANE = ops.WS_LANE, ln
         try:
-            with torch.cuda.stream(self.stream):
+            with torch.cuda.stream(stream):
                 fn()
         except BaseException:
             ops.WS_LANE = lane
             ops.wgrad_discard()
-            self.main.wait_stream(self.stream)
+            for st in self.streams:
+                self.main.wait_stream(st)
             raise
         ops.WS_LANE = lane
         self.keep.extend(tensors)
 
     def join(self):
         if self.on:
-            lane, ops.WS_LANE = ops.WS_LANE, self.lane
-            with torch.cuda.stream(self.stream):
-                ops.wgrad_flush(self.lane)     # this lane's deferred weight-gradient reduction, on its own stream
+            lane = ops.WS_LANE
+            for stream, ln in zip(self.streams, self.lanes):
+                ops.WS_LANE = ln
+                with torch.cuda.stream(stream):
+                    ops.wgrad_flush(ln)     # this queue's deferred weight-gradient reduction, on its own stream
             ops.WS_LANE = lane
-            self.main.wait_stream(self.stream)
+            for stream in self.streams:
+                self.main.wait_stream(stream)
         self.keep = []
 
 
