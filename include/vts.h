@@ -323,6 +323,19 @@ int vts_conv3x3_wide_relu_pad(const float* in, const float* wt, const float* bia
 int vts_conv3x3_wide_mask_pad(const float* in, const float* wt, float* out, int N, int Cin, int Cout, int H, int W, const float* add,
                               const float* mask, void* stream);
 int vts_zero_border(float* buf, int64_t NC, int H, int W, int pad, void* stream);
+/* Winograd F(2x2, 3x3) form of the same stride-1 convolution (csrc/vts_conv3x3_wino.hip; round 4) for the frozen VGG stacks: 16 instead
+ * of 36 multiplications per 2 x 2 outputs and channel pair, fp32 throughout (the result differs from the direct form by rounding only).
+ *   vts_w3x3_wino_pack   U[(a * 16 + p) * B + b] = (G g G^T)[p] of the taps g[t] = w[a * sa + b * sb + (flip ? 8 - t : t)] -- arguments as
+ *                        vts_w3x3_pack; a runs to A rounded up to 8 (zero rows); vts_w3x3_wino_floats(A, B) floats
+ *   vts_conv3x3_wino     out <- conv of the pre-padded in [N][Cin][H + 2][W + 2]; out_pad 1: out is [N][Cout][H + 2][W + 2] and the kernel stores
+ *                        the interior and the zero border (the padded layout of vts_conv3x3_wide_relu_pad / _mask_pad: ep_mode 1 / 2 with
+ *                        ep_add / ep_mask as there; ep_mode 0: plain); VTS_ERR_UNSUPPORTED unless vts_conv3x3_wino_ok (Cout a multiple of
+ *                        64, Cin >= 32, >= 256 workgroups of 16 x 16 pixels x 64 channels) */
+int64_t vts_w3x3_wino_floats(int A, int B);
+int vts_w3x3_wino_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* U, void* stream);
+int vts_conv3x3_wino_ok(int N, int Cin, int Cout, int H, int W);
+int vts_conv3x3_wino(const float* in, const float* U, const float* bias, float* out, int N, int Cin, int Cout, int H, int W, int out_pad,
+                     int ep_mode, const float* ep_add, const float* ep_mask, void* stream);
 int64_t vts_conv3x3_wide_ws_floats(int N, int Cin, int Cout, int H, int W);
 int vts_conv3x3s2_wide(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int Cout, int OH, int OW,
                        float* ws, int64_t ws_floats, void* stream);

@@ -140,6 +140,62 @@ def test_padded_layout_convolution_epilogues(shape):
     assert torch.equal(ops.relu_mask_pad(gd, F.pad(tap, (1,) * 4), zr, pad=1, zpad=1), ops.relu_mask_pad(gd, tap, z, pad=1))
 
 
+@pytest.mark.parametrize("case", [(16, 64, 64, 64, 64), (9, 36, 128, 70, 90), (4, 128, 64, 130, 126)])
+def test_winograd_convolution_against_float64_and_the_direct_kernel(case):
+    """ops.conv3x3_wino (F(2x2, 3x3), fp32): against F.conv2d in float64 -- as close as the direct GEMM-class kernel --, odd map sizes and a
+    channel count that is not a multiple of the 8-channel chunk; the padded-layout epilogues (ReLU / mask + tap gradient, zero border
+    stored by the kernel) against the plain result; the input adjoint through the flipped / transposed transform"""
+    from vts import ops
+
+    dev = _dev()
+    n, ci, co, h, w = case
+    assert ops.conv3x3_wino_ok(n, ci, co, h, w)
+    x = detrand.uniform((n, ci, h, w), 41, "x")
+    wt = detrand.uniform((co, ci, 3, 3), 41, "w") * (1.0 / (ci * 9) ** 0.5)
+    b = 0.1 * detrand.uniform((co,), 41, "b")
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    xd, wd, bd = x.to(dev), wt.to(dev), b.to(dev)
+    p = ops.pad_affine(xd, (1, 1, 1, 1), 0)
+    U = ops.w3x3_wino_pack(wd, "conv_fwd", tag="t_wino%d" % ci)
+    y = torch.full((n, co, h, w), 7.0, device=dev)
+    ops.conv3x3_wino(p, U, bd, y)
+    z = torch.empty_like(y)
+    ops.conv3x3_wide(p, ops.w3x3_pack(wd, "conv_fwd", tag="t_wino%d" % ci), bd, z)
+    e_w, e_d = rel(y.cpu().double(), ref), rel(z.cpu().double(), ref)
+    assert e_w < 2e-6 and e_w < 4 * e_d + 1e-7, (e_w, e_d)        # observed 3e-7 .. 1e-6 for both forms
+    # padded layout: ReLU, and mask + tap gradient (no bias: the adjoint's form)
+    yp = torch.full((n, co, h + 2, w + 2), 3.0, device=dev)
+    ops.conv3x3_wino(p, U, bd, yp, ep_mode=1)
+    assert torch.equal(yp, F.pad(torch.relu(y), (1,) * 4))
+    y0 = torch.empty_like(y)
+    ops.conv3x3_wino(p, U, None, y0)
+    mask = F.pad(torch.relu(detrand.uniform((n, co, h, w), 42, "m")), (1,) * 4).to(dev)
+    add = ops.zero_border(detrand.uniform((n, co, h + 2, w + 2), 42, "a").to(dev))
+    for a in (add, None):
+        out = torch.full((n, co, h + 2, w + 2), 3.0, device=dev)
+        ops.conv3x3_wino(p, U, None, out, ep_mode=2, add=a, mask=mask)
+        want = y0 + a[:, :, 1:-1, 1:-1] if a is not None else y0
+        assert torch.equal(out, F.pad(want * (mask[:, :, 1:-1, 1:-1] > 0), (1,) * 4))
+    # input adjoint: gradient of sum(conv(x) * g) w.r.t. x = conv of the padded g with the flipped, transposed weight
+    if ops.conv3x3_wino_ok(n, co, ci, h, w):
+        g = detrand.uniform((n, co, h, w), 43, "g")
+        gref = F.conv_transpose2d(g.double(), wt.double(), padding=1)
+        gin = torch.empty(n, ci, h, w, device=dev)
+        ops.conv3x3_wino(ops.pad_affine(g.to(dev), (1, 1, 1, 1), 0), ops.w3x3_wino_pack(wd, "conv_adj", tag="t_wino%d" % ci), None, gin)
+        assert rel(gin.cpu().double(), gref) < 2e-6
+
+
+def test_winograd_declines_what_it_does_not_take():
+    from vts import ops
+
+    assert not ops.conv3x3_wino_ok(4, 3, 64, 1024, 1024)      # the 3-channel stem
+    assert not ops.conv3x3_wino_ok(4, 64, 3, 1024, 1024)      # its adjoint (output channels not a multiple of 64)
+    assert not ops.conv3x3_wino_ok(1, 64, 64, 32, 32)         # too few workgroups for the chip
+    p = torch.zeros(1, 64, 34, 34, device=_dev())
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_wino(p, torch.zeros(64 * 16 * 64, device=_dev()), None, torch.empty(1, 64, 32, 32, device=_dev()))
+
+
 def test_small_maps_decline_the_padded_epilogue():
     from vts import ops
 

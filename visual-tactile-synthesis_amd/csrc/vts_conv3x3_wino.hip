@@ -1,0 +1,254 @@
+// Winograd F(2 x 2, 3 x 3) form of the GEMM-class 3 x 3 convolution (round 4), for the frozen VGG stacks of the perceptual terms
+// (lpips.LPIPS(net="vgg") as the reference calls it, models/sinskitG_model.py:495, 1639-1646, 1711; VGGLoss, models/networks.py:2021-2067):
+// those stacks are 75 of the 94 ms of the reference-default step and already run at 0.76 of the fp32 MFMA peak as direct convolutions, so
+// the multiplications themselves have to go: 16 instead of 36 per 2 x 2 outputs and channel pair (Lavin & Gray 2016; cuDNN / MIOpen offer
+// the same algorithm for fp32 3 x 3 layers).  Arithmetic stays fp32; the result differs from the direct form by rounding only (observed
+// ~1e-6 relative), inside the tolerance the parity tests state.
+//
+//   Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A       d: 4 x 4 input patch, g: 3 x 3 taps, Y: 2 x 2 outputs, '.' elementwise
+//
+// Weights are transformed once (the stacks are frozen): U[ci][p][co], p = 4 i + j the position in the 4 x 4 transform domain.
+// Kernel: a workgroup (4 waves, ONE per SIMD: the 16 accumulator tiles of a wave fill the 256 accumulation registers) owns 64 output
+// channels x 64 tiles (8 x 8 tiles = 16 x 16 output pixels) of one image.  Per chunk of 8 input channels it transforms the 512
+// (channel, tile) patches to V[p][ci][tile] in LDS (two per thread, straight from global memory: rows of four floats at even columns),
+// stages U[p][ci][co] beside it, and runs 16 positions x 4 k-steps of v_mfma_f32_32x32x2_f32 (64 per wave and chunk: a 64 x 64 x 8 GEMM per
+// position).  The next chunk's global loads are issued into registers before the MFMA phase.  The output transform runs on the
+// accumulators in registers (every position of one (channel, tile) pair lives in the same lane), with the epilogues of the direct kernel:
+// bias, ReLU into the padded layout, mask + tap gradient (vts_conv3x3_wide_relu_pad / _mask_pad).
+#include "vts_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int RSRC_FLAGS = 0x00020000;     // raw buffer, dword range check (as vts_conv3x3_wide.hip)
+
+struct WinoK {
+  const float* in;    // pre-padded [N][Cin][IPH][IPW]
+  const float* U;     // [Cin8][16][Cout]  (Cin8 = Cin rounded up to 8, zero rows beyond Cin)
+  const float* bias;
+  float* out;         // [N][Cout][OH][OW], the H x W result at (oy0, ox0)
+  int N, Cin, Cout, H, W, IPH, IPW, OH, OW, oy0, ox0;
+  int ep_mode;        // 0 plain, 1 relu (+ zero border of the padded layout), 2 (acc + ep_add) where ep_mask > 0 (+ zero border)
+  const float* ep_add;
+  const float* ep_mask;
+};
+
+constexpr int CKW = 8, TCO = 64, TT = 64;     // channels per chunk, output channels and tiles per workgroup
+
+__device__ __forceinline__ f32x4 ld4(const rsrc_t& rs, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoK p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 16 * CKW * 64];
+  float* lds_u = lds;                       // [p][ci][64 co]
+  float* lds_v = lds + 16 * CKW * 64;       // [p][ci][64 tiles]
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mi = wave & 1, ni = wave >> 1;
+  const int bx_n = (p.W + 15) >> 4;
+  const int bx = blockIdx.x % bx_n, by = blockIdx.x / bx_n;
+  const int x0 = bx * 16, y0 = by * 16, co0 = blockIdx.y * TCO, n = blockIdx.z;
+  const int plane = p.IPH * p.IPW;
+  const int nchunks = (p.Cin + CKW - 1) / CKW;
+
+  // buffer resources: the whole input from this image on (a patch row beyond the map reads the next plane -- finite garbage that only
+  // reaches outputs beyond the map, which are not stored; beyond the tensor: zeros), the transformed weights
+  const int64_t in_floats = (int64_t)(p.N - n) * p.Cin * plane;
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0,
+                                                       (int)(in_floats * 4 > 0x7fffffff ? 0x7fffffff : in_floats * 4), RSRC_FLAGS);
+  const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, nchunks * CKW * 16 * p.Cout * 4, RSRC_FLAGS);
+
+  // this thread's two (channel, tile) patches of a chunk and its eight weight quads
+  int doff[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int j = tid + e * 256, ci = j >> 6, t = j & 63, ty = t >> 3, tx = t & 7;
+    doff[e] = (ci * plane + (y0 + 2 * ty) * p.IPW + x0 + 2 * tx) * 4;
+  }
+  int uoff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = tid + e * 256, row = idx >> 4, q = idx & 15;     // row = ci * 16 + p of the chunk, 16 quads of output channels
+    uoff[e] = (row * p.Cout + co0 + 4 * q) * 4;
+  }
+  f32x4 dreg[2][4], ureg[8];
+  auto load_chunk = [&](int c) {
+    const int cb = c * CKW * plane * 4, ub = c * CKW * 16 * p.Cout * 4;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dreg[e][r] = ld4(rs_in, cb + doff[e] + r * p.IPW * 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ureg[e] = ld4(rs_u, ub + uoff[e]);
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = tid + e * 256, row = idx >> 4, q = idx & 15, ci = row >> 4, pp = row & 15;
+      *reinterpret_cast<f32x4*>(lds_u + (pp * CKW + ci) * 64 + 4 * q) = ureg[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = tid + e * 256, ci = j >> 6, t = j & 63;
+      // V = B^T d B
+      float tt[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d0 = dreg[e][0][c], d1 = dreg[e][1][c], d2 = dreg[e][2][c], d3 = dreg[e][3][c];
+        tt[0][c] = d0 - d2; tt[1][c] = d1 + d2; tt[2][c] = d2 - d1; tt[3][c] = d1 - d3;
+      }
+      float* v = lds_v + ci * 64 + t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[((4 * i + 0) * CKW) * 64] = tt[i][0] - tt[i][2];
+        v[((4 * i + 1) * CKW) * 64] = tt[i][1] + tt[i][2];
+        v[((4 * i + 2) * CKW) * 64] = tt[i][2] - tt[i][1];
+        v[((4 * i + 3) * CKW) * 64] = tt[i][1] - tt[i][3];
+      }
+    }
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    store_chunk();
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* ua = lds_u + kh * 64 + mi * 32 + l32;
+    const float* vb = lds_v + kh * 64 + ni * 32 + l32;
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp)
+#pragma unroll
+      for (int ks = 0; ks < CKW / 2; ++ks) {
+        const float a = ua[(pp * CKW + 2 * ks) * 64], b = vb[(pp * CKW + 2 * ks) * 64];
+        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[pp], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+  // output transform Y = A^T M A per (channel, tile); C layout of a 32 x 32 tile: column (tile) = lane % 32, row (channel) =
+  // (r / 4) * 8 + (lane / 32) * 4 + r % 4
+  const int t = ni * 32 + l32, ty = t >> 3, tx = t & 7;
+  const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
+  const int64_t oplane = (int64_t)p.OH * p.OW;
+  float* ob = p.out + (int64_t)n * p.Cout * oplane;
+  if (oy < p.H && ox < p.W) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mi * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+      float s[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[0][j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+        s[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+      }
+      const float bsv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float y[2] = {s[a][0] + s[a][1] + s[a][2] + bsv, s[a][1] - s[a][2] - s[a][3] + bsv};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int yy = oy + a, xx = ox + b;
+          if (yy < p.H && xx < p.W) {
+            const int64_t o = co * oplane + (int64_t)(p.oy0 + yy) * p.OW + p.ox0 + xx;
+            float v = y[b];
+            if (p.ep_mode == 1) v = fmaxf(v, 0.f);
+            if (p.ep_mode == 2) {
+              const int64_t e = (int64_t)n * p.Cout * oplane + o;
+              v = p.ep_mask[e] > 0.f ? v + (p.ep_add ? p.ep_add[e] : 0.f) : 0.f;
+            }
+            ob[o] = v;
+            if (p.ep_mode) {      // padded output: the pixels on the rim of the map also store the zero border next to them
+              float* q = ob + o;
+              const bool xl = xx == 0, xr = xx == p.W - 1;
+              if (xl) q[-1] = 0.f;
+              if (xr) q[1] = 0.f;
+              if (yy == 0) {
+                q[-p.OW] = 0.f;
+                if (xl) q[-p.OW - 1] = 0.f;
+                if (xr) q[-p.OW + 1] = 0.f;
+              }
+              if (yy == p.H - 1) {
+                q[p.OW] = 0.f;
+                if (xl) q[p.OW - 1] = 0.f;
+                if (xr) q[p.OW + 1] = 0.f;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// U[(a * 16 + p) * B + b] = (G g G^T)[p] of the taps g[t] = w[a * sa + b * sb + (flip ? 8 - t : t)], a < A8 (zero rows for a >= A)
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int A, int A8, int B, int64_t sa, int64_t sb, int flip,
+                                                          float* __restrict__ U) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)A8 * B) return;
+  const int a = (int)(i / B), b = (int)(i % B);
+  float g[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = a < A ? w[a * sa + b * sb + (flip ? 8 - t : t)] : 0.f;
+  float tg[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    tg[0][c] = g[0][c];
+    tg[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+    tg[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+    tg[3][c] = g[2][c];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u0 = tg[r][0], u1 = 0.5f * (tg[r][0] + tg[r][1] + tg[r][2]), u2 = 0.5f * (tg[r][0] - tg[r][1] + tg[r][2]), u3 = tg[r][2];
+    float* o = U + ((int64_t)a * 16 + 4 * r) * B + b;
+    o[0] = u0; o[B] = u1; o[2 * (int64_t)B] = u2; o[3 * (int64_t)B] = u3;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vts_w3x3_wino_floats(int A, int B) { return (int64_t)((A + 7) / 8 * 8) * 16 * B; }
+
+extern "C" int vts_w3x3_wino_pack(const float* w, int A, int B, int64_t sa, int64_t sb, int flip, float* U, void* stream) {
+  VTS_CHECK_ARG(w && U && A >= 1 && B >= 1, "vts_w3x3_wino_pack: bad args");
+  const int A8 = (A + 7) / 8 * 8;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)cdiv64((int64_t)A8 * B, 256)), dim3(256), 0, (hipStream_t)stream, w, A, A8, B, sa, sb, flip, U);
+  VTS_CHECK_LAUNCH("vts_w3x3_wino_pack");
+  return VTS_OK;
+}
+
+// shapes the kernel takes: 64-channel output groups, maps that give the chip enough 16 x 16 blocks, operands inside 31-bit byte offsets
+extern "C" int vts_conv3x3_wino_ok(int N, int Cin, int Cout, int H, int W) {
+  if (Cout % TCO || Cin < 32 || H < 8 || W < 8) return 0;
+  if ((int64_t)((Cin + 7) / 8 * 8) * 16 * Cout * 4 > 0x7fffffff) return 0;
+  if ((int64_t)((Cin + 7) / 8 * 8) * (H + 2) * (W + 2) * 4 > 0x7fffffff) return 0;         // byte offsets inside one image
+  const int64_t wgs = (int64_t)cdiv(W, 16) * cdiv(H, 16) * (Cout / TCO) * N;
+  return wgs >= 256;
+}
+
+extern "C" int vts_conv3x3_wino(const float* in, const float* U, const float* bias, float* out, int N, int Cin, int Cout, int H, int W, int out_pad,
+                                int ep_mode, const float* ep_add, const float* ep_mask, void* stream) {
+  VTS_CHECK_ARG(in && U && out && N >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && (out_pad == 0 || out_pad == 1), "vts_conv3x3_wino: bad args");
+  VTS_CHECK_ARG(ep_mode >= 0 && ep_mode <= 2 && (ep_mode == 0 || out_pad == 1) && (ep_mode != 2 || ep_mask), "vts_conv3x3_wino: epilogue mode %d", ep_mode);
+  if (!vts_conv3x3_wino_ok(N, Cin, Cout, H, W)) return VTS_ERR_UNSUPPORTED;
+  VTS_CHECK_ARG((int64_t)Cin * (H + 2) * (W + 2) * 4 <= 0x7fffffff && N <= 65535, "vts_conv3x3_wino: operand exceeds the 2 GiB buffer range");
+  WinoK k{};
+  k.in = in; k.U = U; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
+  k.IPH = H + 2; k.IPW = W + 2; k.OH = H + 2 * out_pad; k.OW = W + 2 * out_pad; k.oy0 = out_pad; k.ox0 = out_pad;
+  k.ep_mode = ep_mode; k.ep_add = ep_add; k.ep_mask = ep_mask;
+  const dim3 grid(cdiv(W, 16) * cdiv(H, 16), Cout / TCO, N);
+  hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+  vts_set_kernel("conv3x3_wino_kernel");
+  VTS_CHECK_LAUNCH("vts_conv3x3_wino");
+  return VTS_OK;
+}

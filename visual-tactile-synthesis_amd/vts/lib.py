@@ -105,7 +105,7 @@ SYMBOLS = [
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_g_out_grad", "vts_mask_mul", "vts_spe_grid", "vts_mask_candidates",
-    "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract", "vts_tap_embed_at", "vts_tap_extract_at", "vts_w3x3_pack", "vts_conv3x3_wide", "vts_conv3x3_wide_relu_pad", "vts_conv3x3_wide_mask_pad", "vts_zero_border", "vts_conv3x3_wide_ws_floats", "vts_conv3x3s2_wide", "vts_tconv3x3s2_wide", "vts_wgrad3x3_wide", "vts_wgrad3x3_wide_ws_floats", "vts_upfirdn2d_out_size", "vts_upfirdn2d", "vts_upfirdn2d_bwd", "vts_bias_act", "vts_bias_act_bwd", "vts_modconv_demod", "vts_w4x4_pack", "vts_conv4x4_flat_ok", "vts_conv4x4_wide_ws_floats", "vts_conv4x4_wide", "vts_wgrad4x4_wide_ws_floats", "vts_wgrad4x4_wide",
+    "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract", "vts_tap_embed_at", "vts_tap_extract_at", "vts_w3x3_pack", "vts_conv3x3_wide", "vts_w3x3_wino_floats", "vts_w3x3_wino_pack", "vts_conv3x3_wino_ok", "vts_conv3x3_wino", "vts_conv3x3_wide_relu_pad", "vts_conv3x3_wide_mask_pad", "vts_zero_border", "vts_conv3x3_wide_ws_floats", "vts_conv3x3s2_wide", "vts_tconv3x3s2_wide", "vts_wgrad3x3_wide", "vts_wgrad3x3_wide_ws_floats", "vts_upfirdn2d_out_size", "vts_upfirdn2d", "vts_upfirdn2d_bwd", "vts_bias_act", "vts_bias_act_bwd", "vts_modconv_demod", "vts_w4x4_pack", "vts_conv4x4_flat_ok", "vts_conv4x4_wide_ws_floats", "vts_conv4x4_wide", "vts_wgrad4x4_wide_ws_floats", "vts_wgrad4x4_wide",
     "vts_metric_ws_floats", "vts_minmax", "vts_metric_psnr", "vts_metric_tactile", "vts_metric_ssim", "vts_frechet_ws_floats", "vts_frechet_distance", "vts_sifid_input", "vts_modconv_weight", "vts_modconv_weight_bwd", "vts_adain", "vts_adain_bwd", "vts_resample_table",
     "vts_mask_select", "vts_mask_sample_ranks", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
     "vts_maxpool2_relu_pad", "vts_maxpool3s2_relu_pad", "vts_s2d4_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
@@ -145,6 +145,8 @@ def load():
         getattr(lib, name).restype = C.c_int64
     lib.vts_conv4x4_ws_floats.argtypes = [C.POINTER(ConvDesc)]
     lib.vts_unet_forward_ws_floats.argtypes = [C.POINTER(UnetDesc)]
+    lib.vts_w3x3_wino_floats.argtypes = [C.c_int, C.c_int]
+    lib.vts_w3x3_wino_floats.restype = C.c_int64
     lib.vts_unet_forward_ws_floats.restype = C.c_int64
     lib.vts_conv4x4_norm_ws_floats.argtypes = [C.POINTER(ConvDesc)]
     lib.vts_conv4x4_norm_ws_floats.restype = C.c_int64
@@ -226,6 +228,8 @@ def load():
         "vts_maxpool2_relu_pad": [vp, i, i, i, i, vp, i, vp],
         "vts_conv3x3_wide_relu_pad": [vp, vp, vp, vp, i, i, i, i, i, vp],
         "vts_conv3x3_wide_mask_pad": [vp, vp, vp, i, i, i, i, i, vp, vp, vp],
+        "vts_w3x3_wino_pack": [vp, i, i, i64, i64, i, vp, vp], "vts_conv3x3_wino_ok": [i, i, i, i, i],
+        "vts_conv3x3_wino": [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp],
         "vts_zero_border": [vp, i64, i, i, i, vp],
         "vts_maxpool3s2_relu_pad": [vp, i, i, i, i, vp, vp],
         "vts_u8_expand": [vp, i64, i, vp, vp], "vts_unet_forward": [C.POINTER(UnetDesc), vp, i64, vp], "vts_comm_unique_id": [vp], "vts_comm_init": [vp, i, i, vp], "vts_allreduce_flat_async": [vp, vp, i64, vp],

@@ -684,6 +684,46 @@ def w3x3_pack(w, mode, tag=None):
     return buf
 
 
+WINO = os.environ.get("VTS_WINO", "1") != "0"     # Winograd F(2x2, 3x3) for the frozen VGG stacks' 3x3 layers (0: direct GEMM-class kernel)
+
+
+def w3x3_wino_pack(w, mode, tag=None):
+    """transform-domain weights U of a 3x3 nn.Conv2d weight [Co,Ci,3,3] for conv3x3_wino, in a persistent buffer; mode conv_fwd | conv_adj"""
+    d0, d1 = w.shape[0], w.shape[1]
+    A, B, sa, sb, flip = {"conv_fwd": (d1, d0, 9, 9 * d1, 0), "conv_adj": (d0, d1, 9 * d1, 9, 1)}[mode]
+    lib = L.load()
+    key = ("wino", w.data_ptr(), tuple(w.shape), mode, tag)
+    buf = _ws.get(key)
+    if buf is None:
+        buf = _ws[key] = torch.empty(int(lib.vts_w3x3_wino_floats(A, B)), dtype=torch.float32, device=w.device)
+    _run("w3x3_wino_pack", 4.0 * (w.numel() + buf.numel()), 0.0, lib.vts_w3x3_wino_pack, w.data_ptr(), A, B, sa, sb, flip, buf.data_ptr(), L.stream())
+    return buf
+
+
+def conv3x3_wino_ok(n, ci, co, h, w):
+    return WINO and bool(L.load().vts_conv3x3_wino_ok(n, ci, co, h, w))
+
+
+def conv3x3_wino(p, U, bias, out, ep_mode=0, add=None, mask=None):
+    """out <- 3x3 convolution of the pre-padded p [N,Ci,H+2,W+2] in Winograd F(2x2,3x3) form.  out [N,Co,H,W] (ep_mode 0), or the padded
+    layout [N,Co,H+2,W+2] with ep_mode 0 (plain) | 1 (ReLU) | 2 ((conv + add) where mask > 0); add / mask have out's layout.
+    The caller checks conv3x3_wino_ok first."""
+    n, ci, ph, pw = p.shape
+    co, h, w = out.shape[1], ph - 2, pw - 2
+    out_pad = 1 if out.shape[2] == ph else 0
+    assert out.shape == (n, co, h + 2 * out_pad, w + 2 * out_pad) and p.is_contiguous() and out.is_contiguous()
+    assert ep_mode == 0 or out_pad == 1
+    for t in (add, mask):
+        assert t is None or (t.shape == out.shape and t.is_contiguous())
+    if TIMER is not None:
+        global DETAIL
+        DETAIL = "N%d %dx%dx%d -> %dx%dx%d winograd%s" % (n, ci, h, w, co, h, w, ("", " relu+pad", " mask+pad")[ep_mode])
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() * (1 + (add is not None) + (mask is not None)) + U.numel()), 2.0 * n * h * w * co * ci * 9,
+         L.load().vts_conv3x3_wino, p.data_ptr(), U.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, out_pad, ep_mode, L.ptr(add), L.ptr(mask),
+         L.stream())
+    return out
+
+
 def conv3x3_wide(p, wt, bias, out):
     """out [N,Co,H,W] <- valid 3x3 conv of the pre-padded p [N,Ci,H+2,W+2] with packed weights wt (GEMM-class kernel)"""
     n, ci, ph, pw = p.shape

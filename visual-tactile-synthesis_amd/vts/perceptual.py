@@ -35,6 +35,15 @@ def _packed(net, k, mode):
     return buf
 
 
+def _wino(net, k, mode):
+    """transform-domain weights of convolution k for the Winograd kernel (frozen stack: transformed once)"""
+    key = (k, mode, "wino")
+    buf = net._packed.get(key)
+    if buf is None:
+        buf = net._packed[key] = ops.w3x3_wino_pack(net.convs[k].weight, mode, tag="frozen%d" % id(net))
+    return buf
+
+
 def _layout(net):
     """[(conv index, pooled_before?)] in forward order"""
     out, k, pool = [], 0, False
@@ -74,7 +83,12 @@ def vgg_forward(net, x, keep_all=True, last_tap_only_needed=True):
                 p = pt if pz else ops.pad_affine(pt, (1, 1, 1, 1), 0, act=RELU)
         hh, ww = p.shape[2] - 2, p.shape[3] - 2
         cur = None
-        if PADDED:
+        if ops.conv3x3_wino_ok(n, ci, co, hh, ww):       # Winograd F(2x2, 3x3): the layers with >= 32 input channels on maps that fill the chip
+            out = torch.empty(n, co, hh + 2 * PADDED, ww + 2 * PADDED, dtype=torch.float32, device=dev)
+            ops.conv3x3_wino(p, _wino(net, k, "conv_fwd"), conv.bias, out, ep_mode=1 if PADDED else 0)
+            cur = (out, 1 if PADDED else 0)
+            del out
+        elif PADDED:
             out = torch.empty(n, co, hh + 2, ww + 2, dtype=torch.float32, device=dev)
             if ops.conv3x3_wide_relu_pad(p, _packed(net, k, "conv_fwd"), conv.bias, out):
                 cur = (out, 1)
@@ -120,14 +134,23 @@ def vgg_backward(net, zs, tap_grads, x_shape, masked_taps=False):
         ft, fp = zs[kf]
         T = tap_grads.get(kf)
         hh, ww = G.shape[2] - 2, G.shape[3] - 2
+        co = conv.weight.shape[0]
+        wino = ops.conv3x3_wino_ok(n, co, ci, hh, ww)        # the input adjoint: a convolution from the layer's output to its input channels
         if PADDED and not pooled and fp == 1:
             out = torch.empty_like(ft)
+            if wino:
+                ops.conv3x3_wino(G, _wino(net, k, "conv_adj"), None, out, ep_mode=2, add=T, mask=ft)
+                G = out
+                continue
             if ops.conv3x3_wide_mask_pad(G, _packed(net, k, "conv_adj"), out, ft, add=T):
                 G = out
                 continue
             del out
         gin = torch.empty(n, ci, hh, ww, dtype=torch.float32, device=G.device)
-        ops.conv3x3_wide(G, _packed(net, k, "conv_adj"), None, gin)
+        if wino:
+            ops.conv3x3_wino(G, _wino(net, k, "conv_adj"), None, gin)
+        else:
+            ops.conv3x3_wide(G, _packed(net, k, "conv_adj"), None, gin)
         G = ops.maxpool2_relu_bwd(gin, ft, zpad=fp, g2=T, pad=1) if pooled else ops.relu_mask_pad(gin, T, ft, pad=1, zpad=fp)
     if G is None:
         raise RuntimeError("vgg_backward: no tap gradient given")
