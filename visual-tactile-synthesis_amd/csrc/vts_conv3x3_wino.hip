@@ -21,6 +21,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));     // an 8-byte access at dword alignment
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int RSRC_FLAGS = 0x00020000;     // raw buffer, dword range check (as vts_conv3x3_wide.hip)
@@ -190,6 +191,154 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoK p) {
   }
 }
 
+// The same tile on EIGHT waves (two per SIMD, round 4).  With one wave per SIMD the phases of a chunk run one after the other -- ablation:
+// issuing the chunk's sixteen 16-byte loads stalls the wave ~1300 cycles in the memory pipeline, the transform + LDS writes take ~750, the
+// 64 MFMAs 4096 -- because an in-order wave has nothing to overlap them with, and every attempt to interleave them inside one wave lost to
+// conservative waits.  Here the sixteen transform positions are split between two waves (rows 0-1 / rows 2-3 of the 4 x 4 transform
+// domain: 128 accumulation registers each), so that each SIMD holds two instruction streams and issues one wave's loads / transform
+// between the other's MFMAs.  The price is the output transform: Y = A^T M A needs all four rows, so the two waves exchange their
+// partial row sums through LDS once per workgroup (each then finishes one of the two output rows of every tile).
+__global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // two buffers of (U [p][ci][64 co], V [p][ci][64 tiles]): 2 x 64 KB
+  constexpr int BUF = 2 * 16 * CKW * 64;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = wave & 3, half = wave >> 2, mi = sub & 1, ni = sub >> 1;
+  const int bx_n = (p.W + 15) >> 4;
+  const int bx = blockIdx.x % bx_n, by = blockIdx.x / bx_n;
+  const int x0 = bx * 16, y0 = by * 16, co0 = blockIdx.y * TCO, n = blockIdx.z;
+  const int plane = p.IPH * p.IPW;
+  const int nchunks = (p.Cin + CKW - 1) / CKW;
+  const int64_t in_floats = (int64_t)(p.N - n) * p.Cin * plane;
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0,
+                                                       (int)(in_floats * 4 > 0x7fffffff ? 0x7fffffff : in_floats * 4), RSRC_FLAGS);
+  const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, nchunks * CKW * 16 * p.Cout * 4, RSRC_FLAGS);
+
+  // this thread's (channel, tile) patch of a chunk and its four weight quads
+  const int pci = tid >> 6, pt = tid & 63;
+  const int doff = (pci * plane + (y0 + 2 * (pt >> 3)) * p.IPW + x0 + 2 * (pt & 7)) * 4;
+  int uoff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + e * 512, row = idx >> 4, q = idx & 15;
+    uoff[e] = (row * p.Cout + co0 + 4 * q) * 4;
+  }
+  f32x4 dreg[4], ureg[4];
+  auto load_chunk = [&](int c) {
+    const int cb = c * CKW * plane * 4, ub = c * CKW * 16 * p.Cout * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dreg[r] = ld4(rs_in, cb + doff + r * p.IPW * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ureg[e] = ld4(rs_u, ub + uoff[e]);
+  };
+  auto store_chunk = [&](float* buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 512, row = idx >> 4, q = idx & 15, ci = row >> 4, pp = row & 15;
+      *reinterpret_cast<f32x4*>(buf + (pp * CKW + ci) * 64 + 4 * q) = ureg[e];
+    }
+    float tt[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d0 = dreg[0][c], d1 = dreg[1][c], d2 = dreg[2][c], d3 = dreg[3][c];
+      tt[0][c] = d0 - d2; tt[1][c] = d1 + d2; tt[2][c] = d2 - d1; tt[3][c] = d1 - d3;
+    }
+    float* v = buf + 16 * CKW * 64 + pci * 64 + pt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[((4 * i + 0) * CKW) * 64] = tt[i][0] - tt[i][2];
+      v[((4 * i + 1) * CKW) * 64] = tt[i][1] + tt[i][2];
+      v[((4 * i + 2) * CKW) * 64] = tt[i][2] - tt[i][1];
+      v[((4 * i + 3) * CKW) * 64] = tt[i][1] - tt[i][3];
+    }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(lds);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    float* cur = lds + (c & 1) * BUF;
+    float* nxt = lds + ((c + 1) & 1) * BUF;
+    const bool more = c + 1 < nchunks;
+    if (more) load_chunk(c + 1);
+    const float* ua = cur + (half * 8 * CKW + kh) * 64 + mi * 32 + l32;
+    const float* vb = cur + 16 * CKW * 64 + (half * 8 * CKW + kh) * 64 + ni * 32 + l32;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+      for (int ks = 0; ks < CKW / 2; ++ks) {
+        const float a = ua[(pp * CKW + 2 * ks) * 64], b = vb[(pp * CKW + 2 * ks) * 64];
+        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[pp], 0, 0, 0);
+      }
+    if (more) store_chunk(nxt);
+    __syncthreads();
+  }
+
+  // Output transform.  Rows of M this wave holds: half 0: M0, M1; half 1: M2, M3 (acc[4 * i' + j]).  s0 = M0 + M1 + M2, s1 = M1 - M2 - M3:
+  // half 0 finishes output row 0 of every tile (it needs M2 from its partner), half 1 row 1 (it needs M1).  Exchange through LDS:
+  // x[r][j][thread of the partner pair], 4 floats per accumulator register.
+  float* xch = lds + half * (16 * 4 * 256) ;      // 64 KB per half: [r][j][256 threads of this half]
+  const int th = tid & 255;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xch[(r * 4 + j) * 256 + th] = half ? acc[j][r] : acc[4 + j][r];      // half 1 sends M2, half 0 sends M1
+  __syncthreads();
+  const float* got = lds + (half ^ 1) * (16 * 4 * 256);
+  const int t = ni * 32 + l32, ty = t >> 3, tx = t & 7;
+  const int oy = y0 + 2 * ty + half, ox = x0 + 2 * tx;       // this wave's output row of the tile
+  const int64_t oplane = (int64_t)p.OH * p.OW;
+  float* ob = p.out + (int64_t)n * p.Cout * oplane;
+  if (oy < p.H && ox < p.W) {
+    const bool pair = ox + 1 < p.W;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mi * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+      float sj[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float o = got[(r * 4 + j) * 256 + th];
+        sj[j] = half ? o - acc[j][r] - acc[4 + j][r] : acc[j][r] + acc[4 + j][r] + o;      // s1 = M1 - M2 - M3 | s0 = M0 + M1 + M2
+      }
+      const float bsv = p.bias ? p.bias[co] : 0.f;
+      float v0 = sj[0] + sj[1] + sj[2] + bsv, v1 = sj[1] - sj[2] - sj[3] + bsv;
+      const int64_t o = co * oplane + (int64_t)(p.oy0 + oy) * p.OW + p.ox0 + ox;
+      if (p.ep_mode == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      if (p.ep_mode == 2) {
+        const int64_t e = (int64_t)n * p.Cout * oplane + o;
+        const float m0 = p.ep_mask[e], m1 = pair ? p.ep_mask[e + 1] : 0.f;
+        const float a0 = p.ep_add ? p.ep_add[e] : 0.f, a1 = (p.ep_add && pair) ? p.ep_add[e + 1] : 0.f;
+        v0 = m0 > 0.f ? v0 + a0 : 0.f;
+        v1 = m1 > 0.f ? v1 + a1 : 0.f;
+      }
+      if (pair) {
+        const f32x2u v = {v0, v1};
+        *reinterpret_cast<f32x2u*>(ob + o) = v;
+      } else {
+        ob[o] = v0;
+      }
+      if (p.ep_mode) {      // padded output: the rows on the rim of the map also store the zero border next to them
+        float* q = ob + o;
+        const int xlast = pair ? 1 : 0;                        // offset of this tile's last column inside the map
+        const bool left = ox == 0, right = ox + xlast == p.W - 1;
+        if (left) q[-1] = 0.f;
+        if (right) q[xlast + 1] = 0.f;
+        const int xa = left ? -1 : 0, xb = right ? xlast + 1 : xlast;
+        if (oy == 0)
+          for (int xx = xa; xx <= xb; ++xx) q[-p.OW + xx] = 0.f;
+        if (oy == p.H - 1)
+          for (int xx = xa; xx <= xb; ++xx) q[p.OW + xx] = 0.f;
+      }
+    }
+  }
+}
+
 // U[(a * 16 + p) * B + b] = (G g G^T)[p] of the taps g[t] = w[a * sa + b * sb + (flip ? 8 - t : t)], a < A8 (zero rows for a >= A)
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int A, int A8, int B, int64_t sa, int64_t sb, int flip,
                                                           float* __restrict__ U) {
@@ -247,8 +396,20 @@ extern "C" int vts_conv3x3_wino(const float* in, const float* U, const float* bi
   k.IPH = H + 2; k.IPW = W + 2; k.OH = H + 2 * out_pad; k.OW = W + 2 * out_pad; k.oy0 = out_pad; k.ox0 = out_pad;
   k.ep_mode = ep_mode; k.ep_add = ep_add; k.ep_mask = ep_mask;
   const dim3 grid(cdiv(W, 16) * cdiv(H, 16), Cout / TCO, N);
-  hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
-  vts_set_kernel("conv3x3_wino_kernel");
+  static const int v1 = getenv("VTS_WINO_V1") ? 1 : 0;      // the one-wave-per-SIMD kernel (A/B timing)
+  if (v1) {
+    hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+    vts_set_kernel("conv3x3_wino_kernel");
+  } else {
+    constexpr int LDS_BYTES = 2 * 2 * 16 * CKW * 64 * 4;       // 128 KB: two buffers of the weight and the patch tile
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) {
+      vts_set_error("vts_conv3x3_wino: %d bytes of LDS per workgroup refused: %s", LDS_BYTES, hipGetErrorString(attr));
+      return VTS_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(conv3x3_wino8_kernel, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, k);
+    vts_set_kernel("conv3x3_wino8_kernel");
+  }
   VTS_CHECK_LAUNCH("vts_conv3x3_wino");
   return VTS_OK;
 }
