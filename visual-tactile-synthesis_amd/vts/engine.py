@@ -466,6 +466,9 @@ def _is_wide(conv):
 def _conv_valid3(p, conv, out):
     """valid 3x3 conv of a pre-padded identity tensor"""
     if _is_wide(conv):
+        n, ci, ph, pw = p.shape
+        if ops.conv3x3_wino_ok(n, ci, out.shape[1], ph - 2, pw - 2):      # Winograd F(2x2, 3x3): 1.5 - 1.9x the direct kernel (round 4)
+            return ops.conv3x3_wino(p, ops.w3x3_wino_pack(conv.weight, "conv_fwd"), conv.bias, out)
         return ops.conv3x3_wide(p, ops.w3x3_pack(conv.weight, "conv_fwd"), conv.bias, out)
     return ops.convk(p, conv.weight, out, bias=conv.bias, pad=0)
 
@@ -474,6 +477,9 @@ def _conv_valid3_bwd_data(g, conv, dp):
     """dp (padded size) <- adjoint of _conv_valid3 w.r.t. its input"""
     if _is_wide(conv):
         q = ops.pad_affine(g, (2, 2, 2, 2), 0)
+        n, co, qh, qw = q.shape
+        if ops.conv3x3_wino_ok(n, co, dp.shape[1], qh - 2, qw - 2):
+            return ops.conv3x3_wino(q, ops.w3x3_wino_pack(conv.weight, "conv_adj"), None, dp)
         return ops.conv3x3_wide(q, ops.w3x3_pack(conv.weight, "conv_adj"), None, dp)
     return ops.convk_bwd_data(g, conv.weight, dp, pad=0)
 

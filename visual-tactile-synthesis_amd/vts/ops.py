@@ -718,8 +718,10 @@ def conv3x3_wino(p, U, bias, out, ep_mode=0, add=None, mask=None):
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d winograd%s" % (n, ci, h, w, co, h, w, ("", " relu+pad", " mask+pad")[ep_mode])
-    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() * (1 + (add is not None) + (mask is not None)) + U.numel()), 2.0 * n * h * w * co * ci * 9,
-         L.load().vts_conv3x3_wino, p.data_ptr(), U.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, out_pad, ep_mode, L.ptr(add), L.ptr(mask),
+    # (flops: the multiplications the transform-domain GEMMs execute -- 16 per 2 x 2 outputs and channel pair, 4 / 9 of the direct form's --
+    #  so that a roofline fraction computed from them stays a utilisation of the matrix pipe; the direct-equivalent rate is 2.25x that)
+    _run("conv3x3_wide", 4.0 * (p.numel() + out.numel() * (1 + (add is not None) + (mask is not None)) + U.numel()),
+         2.0 * n * ((h + 1) // 2) * ((w + 1) // 2) * 16 * co * ci, L.load().vts_conv3x3_wino, p.data_ptr(), U.data_ptr(), L.ptr(bias), out.data_ptr(), n, ci, co, h, w, out_pad, ep_mode, L.ptr(add), L.ptr(mask),
          L.stream())
     return out
 
