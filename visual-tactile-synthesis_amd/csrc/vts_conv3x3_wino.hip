@@ -381,6 +381,9 @@ extern "C" int vts_conv3x3_wino_ok(int N, int Cin, int Cout, int H, int W) {
   if (Cout % TCO || Cin < 32 || H < 8 || W < 8) return 0;
   if ((int64_t)((Cin + 7) / 8 * 8) * 16 * Cout * 4 > 0x7fffffff) return 0;
   if ((int64_t)((Cin + 7) / 8 * 8) * (H + 2) * (W + 2) * 4 > 0x7fffffff) return 0;         // byte offsets inside one image
+  // a workgroup multiplies a full 16 x 16 block whatever part of it lies inside the map: maps that leave more than ~40 % of their blocks
+  // empty (8 x 8 and smaller) are faster on the flattened direct kernel
+  if ((int64_t)H * W * 10 < (int64_t)cdiv(W, 16) * 16 * cdiv(H, 16) * 16 * 6) return 0;
   const int64_t wgs = (int64_t)cdiv(W, 16) * cdiv(H, 16) * (Cout / TCO) * N;
   return wgs >= 256;
 }
