@@ -795,9 +795,17 @@ class SinSKITGModel(BaseModel):
             have = d_patch is not None
             if not have:
                 d_patch = torch.empty(P, 2, 32, 32, device=dev)
-            for c in (0, 1):
-                P_.lpips_term(self.netLPIPS, self.fake_T_concat[:, c:c + 1], ts["real_T"][:, c:c + 1], opt.lambda_G2_lpips / n, slot["G2_lpips"],
-                              grad_into=d_patch[:, c:c + 1], grad_accumulate=have)
+            # (the two channels of the P patches as ONE batch of 2 P single-channel images -- [P, 2, 32, 32] is [2 P, 1, 32, 32] in memory --:
+            #  the term is a sum over patches and channels, so one call with twice the batch replaces two; the small maps of the deep
+            #  VGG layers get twice the workgroups.  VTS_LPIPS_T_SPLIT=1: one call per channel, as in round 3)
+            f, r = self.fake_T_concat, ts["real_T"]
+            if os.environ.get("VTS_LPIPS_T_SPLIT", "0") != "1" and f.is_contiguous() and r.is_contiguous() and d_patch.is_contiguous():
+                P_.lpips_term(self.netLPIPS, f.view(2 * P, 1, 32, 32), r.view(2 * P, 1, 32, 32), opt.lambda_G2_lpips / n, slot["G2_lpips"],
+                              grad_into=d_patch.view(2 * P, 1, 32, 32), grad_accumulate=have)
+            else:
+                for c in (0, 1):
+                    P_.lpips_term(self.netLPIPS, f[:, c:c + 1], r[:, c:c + 1], opt.lambda_G2_lpips / n, slot["G2_lpips"],
+                                  grad_into=d_patch[:, c:c + 1], grad_accumulate=have)
         if d_patch is not None:
             d_fake_T = torch.empty(n, 2, h, w, device=dev)
             ops.patch_scatter_bwd(d_patch, 0, 2, ts["offx"], ts["offy"], nt, 32, d_fake_T)
