@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoK p) {
 // domain: 128 accumulation registers each), so that each SIMD holds two instruction streams and issues one wave's loads / transform
 // between the other's MFMAs.  The price is the output transform: Y = A^T M A needs all four rows, so the two waves exchange their
 // partial row sums through LDS once per workgroup (each then finishes one of the two output rows of every tile).
+// ABL: profiling instances (env VTS_WINO_ABLATE; compile-time -- a run-time test inside the unrolled loops wrecks the code): 1 no global loads after
+// the first chunk, 8 no transform / LDS staging after the first chunk (results are wrong, timing only)
+template <int ABL>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];      // two buffers of (U [p][ci][64 co], V [p][ci][64 tiles]): 2 x 64 KB
   constexpr int BUF = 2 * 16 * CKW * 64;
@@ -259,16 +262,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // The two waves of a SIMD run the chunk's phases in OPPOSITE order, so that one's transform / LDS writes issue under the other's MFMAs
+  // (with the same order both stage at the same time, in front of the barrier: ablation -- 11 % of the kernel in the staging, 11 % in the
+  // load issue):   half 0:  load(c + 1)   -> MFMA(c) -> stage(c + 1) -> barrier
+  //                half 1:  stage(c + 1)  -> load(c + 2) -> MFMA(c)  -> barrier      (its registers run one chunk further ahead)
   load_chunk(0);
   store_chunk(lds);
+  if (half && nchunks > 1 && !(ABL & 1)) load_chunk(1);
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     float* cur = lds + (c & 1) * BUF;
     float* nxt = lds + ((c + 1) & 1) * BUF;
     const bool more = c + 1 < nchunks;
-    if (more) load_chunk(c + 1);
     const float* ua = cur + (half * 8 * CKW + kh) * 64 + mi * 32 + l32;
     const float* vb = cur + 16 * CKW * 64 + (half * 8 * CKW + kh) * 64 + ni * 32 + l32;
+    if (half == 1 && more && !(ABL & 8)) store_chunk(nxt);
+    const int lc = c + 1 + half;
+    if (lc < nchunks && !(ABL & 1)) load_chunk(lc);
+    // (ONE copy of the MFMA block: with a copy in each branch of `half` the accumulators spilled -- 400 bytes of scratch, 5x slower)
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp)
 #pragma unroll
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
         const float a = ua[(pp * CKW + 2 * ks) * 64], b = vb[(pp * CKW + 2 * ks) * 64];
         acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[pp], 0, 0, 0);
       }
-    if (more) store_chunk(nxt);
+    if (half == 0 && more && !(ABL & 8)) store_chunk(nxt);
     __syncthreads();
   }
 
@@ -405,12 +416,14 @@ extern "C" int vts_conv3x3_wino(const float* in, const float* U, const float* bi
     vts_set_kernel("conv3x3_wino_kernel");
   } else {
     constexpr int LDS_BYTES = 2 * 2 * 16 * CKW * 64 * 4;       // 128 KB: two buffers of the weight and the patch tile
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const int ablate = getenv("VTS_WINO_ABLATE") ? atoi(getenv("VTS_WINO_ABLATE")) : 0;
+    void (*kern)(const WinoK) = ablate == 1 ? conv3x3_wino8_kernel<1> : ablate == 8 ? conv3x3_wino8_kernel<8> : ablate == 9 ? conv3x3_wino8_kernel<9> : conv3x3_wino8_kernel<0>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) {
       vts_set_error("vts_conv3x3_wino: %d bytes of LDS per workgroup refused: %s", LDS_BYTES, hipGetErrorString(attr));
       return VTS_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(conv3x3_wino8_kernel, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, k);
     vts_set_kernel("conv3x3_wino8_kernel");
   }
   VTS_CHECK_LAUNCH("vts_conv3x3_wino");
