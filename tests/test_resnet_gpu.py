@@ -441,7 +441,7 @@ def test_conv3x3_wide_ksplit_small_map():
 
 
 @pytest.mark.parametrize("shape", [(1, 64, 128, 16, 32), (2, 70, 132, 9, 37), (1, 256, 64, 8, 64), (3, 8, 4, 5, 5), (32, 64, 128, 2, 2),
-                                   (5, 70, 132, 4, 4), (9, 136, 72, 3, 5), (2, 64, 64, 8, 8), (33, 130, 64, 1, 1), (32, 1024, 512, 2, 2)])
+                                   (5, 70, 132, 4, 4), (9, 136, 72, 3, 5), (2, 64, 64, 8, 8), (33, 130, 64, 1, 1), (32, 1024, 512, 2, 2), (2, 128, 192, 40, 56), (3, 72, 64, 33, 17)])
 def test_wgrad3x3_wide(shape):
     """GEMM-class weight gradient vs autograd; accumulate; run-to-run determinism"""
     from vts import ops

@@ -1230,8 +1230,17 @@ extern "C" int vts_wgrad3x3_wide(const float* dout, const float* in, float* dw, 
   k.tiles_x = cdiv(W, stride == 1 ? 32 : 16);
   k.tiles_per_img = k.tiles_x * cdiv(H, GTY);
   k.ntiles = N * k.tiles_per_img;
-  const int KS = wg_wide_plan(N, Cin, Cout, H, W, stride, &k.tps);
+  int KS = wg_wide_plan(N, Cin, Cout, H, W, stride, &k.tps);
   VTS_CHECK_ARG(ws_floats >= KS * nel, "vts_wgrad3x3_wide: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)(KS * nel));
+  if (stride == 1) {      // Winograd F(3x3, 2x2) form (vts_conv3x3_wino.hip) where it takes the shape: the same partial layout, fewer slices
+    const int wks = vts_wgrad3x3_wino_try(dout, in, ws, N, Cin, Cout, H, W, KS, (hipStream_t)stream);
+    if (wks > 0) {
+      VTS_CHECK_LAUNCH("vts_wgrad3x3_wide (winograd)");
+      hipLaunchKernelGGL(wg_wide_reduce_kernel, dim3((unsigned)cdiv64(nel, 256)), dim3(256), 0, (hipStream_t)stream, ws, wks, nel, dw, accumulate);
+      VTS_CHECK_LAUNCH("vts_wgrad3x3_wide reduce");
+      return VTS_OK;
+    }
+  }
   const dim3 grid(cdiv(Cout, GCO), cdiv(Cin, GCI), KS);
   if (stride == 1) hipLaunchKernelGGL(wgrad3x3_wide_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
   else hipLaunchKernelGGL(wgrad3x3_wide_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, k);

@@ -350,6 +350,160 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
   }
 }
 
+// Weight gradient of the same convolution in Winograd F(3 x 3, 2 x 2) form (round 4): per 2 x 2 tile of the output gradient dY and its
+// 4 x 4 input patch X,   dW = sum_tiles A'^T [ (G' dY G'^T) . (B^T X B) ] A',   G' = [[1,0],[.5,.5],[.5,-.5],[0,1]],
+// A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]], B^T as in the forward form -- 16 instead of 36 multiplications per tile and channel pair.
+// The kernel is the forward kernel with the roles turned: a workgroup owns 64 output x 64 input channels, the GEMM's K dimension is
+// the TILE index (8 tiles per chunk), both operands are transformed on the fly (every thread one (output channel, tile) and one (input
+// channel, tile) pair per chunk) into Z[p][tile][co] / V[p][tile][ci] in LDS (row pitch 72: the eight tiles of a wave's store land on
+// distinct banks), the 16 positions are split between two waves per SIMD running the chunk's phases in opposite order, and the wave
+// pairs exchange two rows of the 4 x 4 accumulator block through LDS before the 3 x 3 inverse transform.  Partials [ks][co][ci][9] like
+// wgrad3x3_wide_kernel's (reduced by the same wg_wide_reduce_kernel).
+struct WinoWgK {
+  const float* dout;    // [N][Cout][H][W]
+  const float* in;      // pre-padded [N][Cin][H + 2][W + 2]
+  float* part;          // [KS][Cout][Cin][9]
+  int N, Cin, Cout, H, W, IPW, iplane, oplane;
+  int tiles_x, tpi, ntiles, cps, nchunks;   // 2 x 2 tiles per row / image / in all; chunks (of 8 tiles) per K slice / in all
+};
+
+constexpr int WG_PITCH = 72;
+
+__global__ __launch_bounds__(512, 2) void wgrad3x3_wino_kernel(const WinoWgK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // two buffers of (Z [16][8][72], V [16][8][72]); the exchange reuses them
+  constexpr int HALF = 16 * 8 * WG_PITCH, BUF = 2 * HALF;
+  const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = wave & 3, half = wave >> 2, mi = sub & 1, ni = sub >> 1;
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64, ks = blockIdx.z;
+  const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dout), 0, (int)((int64_t)p.N * p.Cout * p.oplane * 4), RSRC_FLAGS);
+  const auto rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((int64_t)p.N * p.Cin * p.iplane * 4), RSRC_FLAGS);
+
+  // this thread's (channel, tile-of-the-chunk) pair on both sides: eight consecutive channels x eight tiles per wave
+  const int ch = wave * 8 + (lane & 7), tl = lane >> 3;
+  const bool co_ok = co0 + ch < p.Cout, ci_ok = ci0 + ch < p.Cin;
+  float dy[2][2];
+  f32x4 xr[4];
+  auto load_chunk = [&](int c) {
+    const int t = c * 8 + tl;
+    const int n = t / p.tpi, r = t - n * p.tpi, ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
+    const bool tok = t < p.ntiles;
+    const int dbase = ((n * p.Cout + co0 + ch) * p.oplane + 2 * ty * p.W + 2 * tx) * 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool ok = tok && co_ok && 2 * ty + a < p.H && 2 * tx + b < p.W;
+        dy[a][b] = ok ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, dbase + (a * p.W + b) * 4, 0, 0)) : 0.f;
+      }
+    const int xbase = (tok && ci_ok) ? ((n * p.Cin + ci0 + ch) * p.iplane + 2 * ty * p.IPW + 2 * tx) * 4 : 0x7ffffff0;   // (beyond the buffer: zeros)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) xr[rr] = ld4(rs_i, xbase + rr * p.IPW * 4);
+  };
+  auto store_chunk = [&](float* buf) {
+    // Z = G' dY G'^T
+    float t0[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      t0[0][b] = dy[0][b]; t0[1][b] = 0.5f * (dy[0][b] + dy[1][b]); t0[2][b] = 0.5f * (dy[0][b] - dy[1][b]); t0[3][b] = dy[1][b];
+    }
+    float* z = buf + tl * WG_PITCH + ch;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z[((4 * i + 0) * 8) * WG_PITCH] = t0[i][0];
+      z[((4 * i + 1) * 8) * WG_PITCH] = 0.5f * (t0[i][0] + t0[i][1]);
+      z[((4 * i + 2) * 8) * WG_PITCH] = 0.5f * (t0[i][0] - t0[i][1]);
+      z[((4 * i + 3) * 8) * WG_PITCH] = t0[i][1];
+    }
+    // V = B^T X B
+    float tt[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d0 = xr[0][c], d1 = xr[1][c], d2 = xr[2][c], d3 = xr[3][c];
+      tt[0][c] = d0 - d2; tt[1][c] = d1 + d2; tt[2][c] = d2 - d1; tt[3][c] = d1 - d3;
+    }
+    float* v = buf + HALF + tl * WG_PITCH + ch;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[((4 * i + 0) * 8) * WG_PITCH] = tt[i][0] - tt[i][2];
+      v[((4 * i + 1) * 8) * WG_PITCH] = tt[i][1] + tt[i][2];
+      v[((4 * i + 2) * 8) * WG_PITCH] = tt[i][2] - tt[i][1];
+      v[((4 * i + 3) * 8) * WG_PITCH] = tt[i][1] - tt[i][3];
+    }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int c_beg = ks * p.cps, c_end = min(p.nchunks, c_beg + p.cps);
+  if (c_beg < c_end) {
+    load_chunk(c_beg);
+    store_chunk(lds);
+    if (half && c_beg + 1 < c_end) load_chunk(c_beg + 1);
+  }
+  __syncthreads();
+  for (int c = c_beg; c < c_end; ++c) {
+    float* cur = lds + ((c - c_beg) & 1) * BUF;
+    float* nxt = lds + ((c - c_beg + 1) & 1) * BUF;
+    const bool more = c + 1 < c_end;
+    const float* za = cur + (half * 64 + kh) * WG_PITCH + mi * 32 + l32;             // A[i = co][k = tile]
+    const float* vb = cur + HALF + (half * 64 + kh) * WG_PITCH + ni * 32 + l32;      // B[k = tile][j = ci]
+    if (half == 1 && more) store_chunk(nxt);
+    const int lc = c + 1 + half;
+    if (lc < c_end) load_chunk(lc);
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float a = za[(pp * 8 + 2 * kk) * WG_PITCH], b = vb[(pp * 8 + 2 * kk) * WG_PITCH];
+        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[pp], 0, 0, 0);
+      }
+    if (half == 0 && more) store_chunk(nxt);
+    __syncthreads();
+  }
+
+  // Inverse transform dW = A'^T Q A'.  Rows of Q this wave holds: half 0: Q0, Q1; half 1: Q2, Q3.  s0 = Q0 + Q1 + Q2 (half 0 finishes it: tap
+  // row 0), s1 = Q1 - Q2, s2 = Q1 + Q2 - Q3 (half 1: tap rows 1, 2): half 0 sends Q1, half 1 sends Q2.
+  float* xch = lds + half * (16 * 4 * 256);
+  const int th = tid & 255;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xch[(r * 4 + j) * 256 + th] = half ? acc[j][r] : acc[4 + j][r];
+  __syncthreads();
+  const float* got = lds + (half ^ 1) * (16 * 4 * 256);
+  const int ci = ci0 + ni * 32 + l32;
+  float* ob = p.part + (int64_t)ks * p.Cout * p.Cin * 9;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + mi * 32 + (r >> 2) * 8 + kh * 4 + (r & 3);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = got[(r * 4 + j) * 256 + th];
+    if (co < p.Cout && ci < p.Cin) {
+      float* w = ob + ((int64_t)co * p.Cin + ci) * 9;
+      if (half == 0) {
+        float s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = acc[j][r] + acc[4 + j][r] + o[j];
+        w[0] = s[0] + s[1] + s[2]; w[1] = s[1] - s[2]; w[2] = s[1] + s[2] - s[3];
+      } else {
+        float s1[4], s2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s1[j] = o[j] - acc[j][r];
+          s2[j] = o[j] + acc[j][r] - acc[4 + j][r];
+        }
+        w[3] = s1[0] + s1[1] + s1[2]; w[4] = s1[1] - s1[2]; w[5] = s1[1] + s1[2] - s1[3];
+        w[6] = s2[0] + s2[1] + s2[2]; w[7] = s2[1] - s2[2]; w[8] = s2[1] + s2[2] - s2[3];
+      }
+    }
+  }
+}
+
 // U[(a * 16 + p) * B + b] = (G g G^T)[p] of the taps g[t] = w[a * sa + b * sb + (flip ? 8 - t : t)], a < A8 (zero rows for a >= A)
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int A, int A8, int B, int64_t sa, int64_t sb, int flip,
                                                           float* __restrict__ U) {
@@ -429,3 +583,29 @@ extern "C" int vts_conv3x3_wino(const float* in, const float* U, const float* bi
   VTS_CHECK_LAUNCH("vts_conv3x3_wino");
   return VTS_OK;
 }
+
+// Internal (vts_conv3x3_wide.hip: vts_wgrad3x3_wide): partials of the stride-1 weight gradient in Winograd form into part [KS][Cout][Cin][9]
+// with KS <= max_ks slices; returns the number of slices written, 0 if the shape is not taken.
+int vts_wgrad3x3_wino_try(const float* dout, const float* in, float* part, int N, int Cin, int Cout, int H, int W, int max_ks, hipStream_t st) {
+  static const int off = getenv("VTS_WINO") && atoi(getenv("VTS_WINO")) == 0 ? 1 : (getenv("VTS_WINO_WGRAD") && atoi(getenv("VTS_WINO_WGRAD")) == 0 ? 1 : 0);
+  if (off || Cin < 64 || Cout < 64 || H < 8 || W < 8 || max_ks < 1) return 0;
+  if ((int64_t)N * Cin * (H + 2) * (W + 2) * 4 > 0x7fffffe0ll || (int64_t)N * Cout * H * W * 4 > 0x7fffffe0ll) return 0;
+  WinoWgK k{};
+  k.dout = dout; k.in = in; k.part = part; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
+  k.IPW = W + 2; k.iplane = (H + 2) * (W + 2); k.oplane = H * W;
+  k.tiles_x = cdiv(W, 2); k.tpi = k.tiles_x * cdiv(H, 2); k.ntiles = N * k.tpi; k.nchunks = cdiv(k.ntiles, 8);
+  const int groups = cdiv(Cout, 64) * cdiv(Cin, 64);
+  int KS = cdiv(256, groups);                  // one workgroup per CU (128 KB of LDS each)
+  if (KS > max_ks) KS = max_ks;
+  if (KS > k.nchunks / 8) KS = k.nchunks / 8;  // >= 8 chunks per slice
+  if (KS < 1) KS = 1;
+  k.cps = cdiv(k.nchunks, KS);
+  KS = cdiv(k.nchunks, k.cps);
+  constexpr int LDS_BYTES = 2 * 2 * 16 * 8 * WG_PITCH * 4;      // 147 KB
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return 0;
+  hipLaunchKernelGGL(wgrad3x3_wino_kernel, dim3(cdiv(Cout, 64), cdiv(Cin, 64), KS), dim3(512), LDS_BYTES, st, k);
+  vts_set_kernel("wgrad3x3_wino_kernel");
+  return KS;
+}
+

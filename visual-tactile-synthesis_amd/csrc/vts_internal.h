@@ -21,6 +21,8 @@ int vts_conv_thin_try(const vts_conv_desc* d, hipStream_t st);
 int vts_conv_px_try(const vts_conv_desc* d, hipStream_t st, float* stat_part, float* bsum_part, int64_t part_floats, int* stat_spl);
 // single-output-channel stride-1 layers (PatchGAN prediction heads) on full-size maps: LDS-tiled vector-ALU kernel; VTS_ERR_UNSUPPORTED otherwise
 int vts_conv_head_try(const vts_conv_desc* d, hipStream_t st);
+// stride-1 3x3 weight gradient in Winograd F(3x3, 2x2) form (vts_conv3x3_wino.hip): partials [KS][Cout][Cin][9] with KS <= max_ks; returns KS, 0 = shape not taken
+int vts_wgrad3x3_wino_try(const float* dout, const float* in, float* part, int N, int Cin, int Cout, int H, int W, int max_ks, hipStream_t st);
 // PatchNCE on the MFMA path (vts_patchnce.hip): P, D <= 256
 bool vts_patchnce_mfma_ok(int P, int D);
 int vts_patchnce_mfma(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq, hipStream_t st);
