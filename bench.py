@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s
 MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_16x16x4_f32)
 
 
-def build_model(size, batch, model_name, quiet=True, netG="unet256_custom", lpips=False):
+def build_model(size, batch, model_name, quiet=True, netG="unet256_custom", lpips=False, p2p_vgg=False):
     import contextlib
     import io
 
@@ -44,8 +44,8 @@ def build_model(size, batch, model_name, quiet=True, netG="unet256_custom", lpip
              "--checkpoints_dir /tmp/vts_bench --name bench --crop_size %d --batch_size %d --netG %s"
              % (model_name, "" if lpips else "--lambda_G1_lpips 0 --lambda_G2_lpips 0 ", size, batch, netG))
     if model_name == "pix2pixHD":   # reference defaults (ngf 64, 4 downsamplings, 9 blocks), VGG term off (no weights offline)
-        flags = ("--model pix2pixHD --gpu_ids 0 --no_vgg_loss True --checkpoints_dir /tmp/vts_bench --name bench --batch_size %d "
-                 "--dataset_mode patchskit" % batch)
+        flags = ("--model pix2pixHD --gpu_ids 0 --no_vgg_loss %s --checkpoints_dir /tmp/vts_bench --name bench --batch_size %d "
+                 "--dataset_mode patchskit" % ("False" if p2p_vgg else "True", batch))
     ctx = contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()
     with ctx:
         opt = TrainOptions(cmd_line=flags).parse()
@@ -342,6 +342,7 @@ def main():
     ap.add_argument("--p2p_size", type=int, default=32, help="pix2pixHD only: side of the (square) training images / patches")
     ap.add_argument("--p2p_h", type=int, default=0, help="pix2pixHD only: image height (with --p2p_w: BASELINE config 3 is --p2p_h 1024 --p2p_w 2048 --batch 1)")
     ap.add_argument("--p2p_w", type=int, default=0, help="pix2pixHD only: image width")
+    ap.add_argument("--p2p_vgg", action="store_true", help="pix2pixHD only: keep the reference's default VGG19 feature loss on (seeded stand-in weights)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--lpips", action="store_true",
                     help="SECONDARY workload: the same step with the reference's default LPIPS-VGG16 terms on (lambda_G1_lpips 1, lambda_G2_lpips 10; "
@@ -367,7 +368,7 @@ def main():
     torch.manual_seed(1234 + rank)      # per-rank DiffAugment draws (the default generator is seeded identically on every rank)
     if args.infer:
         return infer_bench(args)
-    model, opt = build_model(args.size, args.batch, args.model, netG=args.netG, lpips=args.lpips)
+    model, opt = build_model(args.size, args.batch, args.model, netG=args.netG, lpips=args.lpips, p2p_vgg=args.p2p_vgg)
     if args.lpips and args.steps == 250:
         args.steps, args.warmup = 30, 4      # ~70 ms per step
     opt.use_hip_graph = not args.no_graph
@@ -479,8 +480,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": ("pix2pixHD G+D+D2 train step (GlobalGenerator ngf 64, ndf 64), %d %dx%d images/GPU, VGG term off "
-                             "(no weights offline)" % (args.batch, p2p_w, p2p_h)) if args.model == "pix2pixHD" else
+                "workload": ("pix2pixHD G+D+D2 train step (GlobalGenerator ngf 64, ndf 64), %d %dx%d images/GPU, %s"
+                             % (args.batch, p2p_w, p2p_h, "VGG19 feature loss ON (the reference's default; seeded stand-in VGG weights)" if args.p2p_vgg
+                                else "VGG term off (no weights offline)")) if args.model == "pix2pixHD" else
                             "%s%s G+D1+D2 train step, %dx%d sketch->(RGB,tactile), %d images/GPU, 64 tactile patches/image, "
                             "%s" % (args.model, "" if args.netG == "unet256_custom" else " (netG %s)" % args.netG,
                                     args.size, args.size, args.batch,

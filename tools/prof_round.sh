@@ -28,9 +28,10 @@ VTS_MB=top python tools/microbench_conv.py > $O/conv_microbench.txt 2>&1
 python bench.py --model pix2pixHD --batch 32 --no_cpu_baseline > $O/pix2pixHD_patch_bench.json 2>/dev/null
 python bench.py --model pix2pixHD --p2p_size 1024 --batch 2 --steps 5 --warmup 3 --no_cpu_baseline > $O/pix2pixHD_2x1024_bench.json 2>/dev/null
 python bench.py --model pix2pixHD --p2p_h 1024 --p2p_w 2048 --batch 1 --steps 5 --warmup 3 --no_cpu_baseline > $O/pix2pixHD_2048x1024_bench.json 2>/dev/null
+python bench.py --model pix2pixHD --p2p_h 1024 --p2p_w 2048 --batch 1 --steps 5 --warmup 3 --no_cpu_baseline --p2p_vgg > $O/pix2pixHD_2048x1024_vgg_bench.json 2>/dev/null
 python bench.py --model sinskitG --netG resnet_9blocks --no_cpu_baseline > $O/resnet9_bench.json 2>/dev/null
 python bench.py --lpips --detail $O/lpips_kernel_shape_table.txt > $O/bench_lpips.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lpips -o run -- python bench.py --lpips --steps 6 --warmup 3 > $O/stats_lpips.log 2>&1
 cp $O/stats_lpips/run_kernel_stats.csv $O/lpips_kernel_stats.csv; rm -rf $O/stats_lpips
 rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
-head -c 1500 $O/bench.json; echo; for f in bench_batch1 bench_no_viz infer_bench pix2pixHD_patch_bench pix2pixHD_2x1024_bench pix2pixHD_2048x1024_bench resnet9_bench bench_lpips bench_ddp_forced_1rank; do python -c "import json,sys; d=json.load(open('$O/$f.json')); print('$f', d['metric'], round(d['value'],2), d['unit'], round(d['ms_per_step'],3), 'ms')"; done
+head -c 1500 $O/bench.json; echo; for f in bench_batch1 bench_no_viz infer_bench pix2pixHD_patch_bench pix2pixHD_2x1024_bench pix2pixHD_2048x1024_bench pix2pixHD_2048x1024_vgg_bench resnet9_bench bench_lpips bench_ddp_forced_1rank; do python -c "import json,sys; d=json.load(open('$O/$f.json')); print('$f', d['metric'], round(d['value'],2), d['unit'], round(d['ms_per_step'],3), 'ms')"; done
