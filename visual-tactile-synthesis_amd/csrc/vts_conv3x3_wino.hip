@@ -323,8 +323,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
       if (p.ep_mode == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       if (p.ep_mode == 2) {
         const int64_t e = (int64_t)n * p.Cout * oplane + o;
-        const float m0 = p.ep_mask[e], m1 = pair ? p.ep_mask[e + 1] : 0.f;
-        const float a0 = p.ep_add ? p.ep_add[e] : 0.f, a1 = (p.ep_add && pair) ? p.ep_add[e + 1] : 0.f;
+        float m0, m1 = 0.f, a0 = 0.f, a1 = 0.f;
+        if (pair) {       // one 8-byte load per operand and row (dword-aligned is enough)
+          const f32x2u m = *reinterpret_cast<const f32x2u*>(p.ep_mask + e);
+          m0 = m[0]; m1 = m[1];
+          if (p.ep_add) {
+            const f32x2u ad = *reinterpret_cast<const f32x2u*>(p.ep_add + e);
+            a0 = ad[0]; a1 = ad[1];
+          }
+        } else {
+          m0 = p.ep_mask[e];
+          if (p.ep_add) a0 = p.ep_add[e];
+        }
         v0 = m0 > 0.f ? v0 + a0 : 0.f;
         v1 = m1 > 0.f ? v1 + a1 : 0.f;
       }
