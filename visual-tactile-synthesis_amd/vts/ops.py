@@ -1422,10 +1422,12 @@ def _triple(v):
     return (C.c_float * 3)(*[float(t) for t in v])
 
 
-def lpips_input(x, shift, scale, nstride=None, channels=None):
-    """LPIPS ScalingLayer output [N, 3, H, W] of x [N, 3 | 1, H, W] (a 1-channel VIEW of a wider tensor: pass its batch stride)"""
+def lpips_input(x, shift, scale, nstride=None, channels=None, out=None):
+    """LPIPS ScalingLayer output [N, 3, H, W] of x [N, 3 | 1, H, W] (a 1-channel VIEW of a wider tensor: pass its batch stride);
+    out: a contiguous [N, 3, H, W] destination (a batch slice of a larger tensor)"""
     n, cx, h, w = x.shape if channels is None else (x.shape[0], channels, x.shape[2], x.shape[3])
-    y = torch.empty(n, 3, h, w, dtype=torch.float32, device=x.device)
+    y = torch.empty(n, 3, h, w, dtype=torch.float32, device=x.device) if out is None else out
+    assert y.shape == (n, 3, h, w) and y.is_contiguous()
     L.check(L.load().vts_lpips_input(x.data_ptr(), x.stride(0) if nstride is None else nstride, n, cx, h * w, _triple(shift), _triple(scale), y.data_ptr(), L.stream()),
             "vts_lpips_input")
     return y

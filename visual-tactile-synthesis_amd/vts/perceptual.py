@@ -22,6 +22,7 @@ from . import lib as L
 from . import ops
 
 RELU = L.ACT_RELU
+BATCH_PAIR = os.environ.get("VTS_LPIPS_BATCH_PAIR", "1") != "0"     # fake | real images as one batch through the VGG stack (0: two forwards, round 3)
 PADDED = os.environ.get("VTS_VGG_PADDED", "1") != "0"    # 0: every activation as a dense raw output + separate ReLU / padding passes (round 3)
 
 
@@ -209,12 +210,25 @@ def lpips_term(net, fake, real, coeff, loss_slot, grad_into=None, grad_accumulat
     fake / real: [N, 3, H, W], or 1-channel VIEWS (channels=1, nstride_* = batch stride of the tensor they are a channel of):
     the ScalingLayer broadcasts the single channel to three, as lpips does for the tactile gx / gy images."""
     cx = fake.shape[1] if channels is None else channels
-    y1 = ops.lpips_input(real, net.shift, net.scale, nstride=nstride_real, channels=cx)
-    z1 = vgg_forward(net, y1, keep_all=False)
-    del y1
-    y0 = ops.lpips_input(fake, net.shift, net.scale, nstride=nstride_fake, channels=cx)
     want = grad_into is not None
-    z0 = vgg_forward(net, y0, keep_all=want)
+    n = fake.shape[0]
+    if BATCH_PAIR and want:
+        # fake and real images through the stack as ONE batch of 2 N (rows [0, N) fake, [N, 2 N) real): half the launches, twice the
+        # workgroups per launch on the deep layers' small maps; the backward runs on the fake rows (contiguous batch slices)
+        y = torch.empty(2 * n, 3, fake.shape[2], fake.shape[3], dtype=torch.float32, device=fake.device)
+        y0 = ops.lpips_input(fake, net.shift, net.scale, nstride=nstride_fake, channels=cx, out=y[:n])
+        ops.lpips_input(real, net.shift, net.scale, nstride=nstride_real, channels=cx, out=y[n:])
+        zz = vgg_forward(net, y, keep_all=True)
+        del y
+        z0 = {k: (t[:n], zp) for k, (t, zp) in zz.items()}
+        z1 = {k: (zz[k][0][n:], zz[k][1]) for k in net.taps}
+        del zz
+    else:
+        y1 = ops.lpips_input(real, net.shift, net.scale, nstride=nstride_real, channels=cx)
+        z1 = vgg_forward(net, y1, keep_all=False)
+        del y1
+        y0 = ops.lpips_input(fake, net.shift, net.scale, nstride=nstride_fake, channels=cx)
+        z0 = vgg_forward(net, y0, keep_all=want)
     tap_grads = {}
     for i, k in enumerate(net.taps):
         assert z0[k][1] == z1[k][1]
@@ -231,8 +245,15 @@ def lpips_term(net, fake, real, coeff, loss_slot, grad_into=None, grad_accumulat
 
 def vgg_feature_l1(net, x, y, coeff, loss_slot, want_grad=True):
     """VGGLoss: loss_slot += coeff * sum_i w_i mean|relu_i(x) - relu_i(y)|; returns d(.)/dx (or None).  x, y [N, 3, H, W]."""
-    zy = vgg_forward(net, y, keep_all=False)
-    zx = vgg_forward(net, x, keep_all=want_grad)
+    n = x.shape[0]
+    if BATCH_PAIR and want_grad and x.shape == y.shape:
+        zz = vgg_forward(net, torch.cat([x, y], 0), keep_all=True)        # rows [0, N): x (the backward's side), [N, 2 N): y
+        zx = {k: (t[:n], zp) for k, (t, zp) in zz.items()}
+        zy = {k: (zz[k][0][n:], zz[k][1]) for k in net.taps}
+        del zz
+    else:
+        zy = vgg_forward(net, y, keep_all=False)
+        zx = vgg_forward(net, x, keep_all=want_grad)
     tap_grads = {}
     for wi, k in zip(net.weights, net.taps):
         (tx, zp), (ty, zq) = zx[k], zy[k]
