@@ -140,7 +140,8 @@ def test_padded_layout_convolution_epilogues(shape):
     assert torch.equal(ops.relu_mask_pad(gd, F.pad(tap, (1,) * 4), zr, pad=1, zpad=1), ops.relu_mask_pad(gd, tap, z, pad=1))
 
 
-@pytest.mark.parametrize("case", [(16, 64, 64, 64, 64), (9, 36, 128, 70, 90), (4, 128, 64, 130, 126)])
+@pytest.mark.parametrize("case", [(16, 64, 64, 64, 64), (9, 36, 128, 70, 90), (4, 128, 64, 130, 126), (256, 64, 128, 8, 8), (600, 64, 128, 6, 10),
+                                  (1024, 64, 512, 2, 2), (1000, 40, 128, 5, 3)])
 def test_winograd_convolution_against_float64_and_the_direct_kernel(case):
     """ops.conv3x3_wino (F(2x2, 3x3), fp32): against F.conv2d in float64 -- as close as the direct GEMM-class kernel --, odd map sizes and a
     channel count that is not a multiple of the 8-channel chunk; the padded-layout epilogues (ReLU / mask + tap gradient, zero border

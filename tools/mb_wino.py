@@ -33,7 +33,8 @@ def timed(fn, reps=20):
 
 cases = [(1, 32, 64, 24, 40, True), (2, 64, 64, 72, 88, True), (4, 64, 64, 1024, 1024, False), (4, 64, 128, 512, 512, False), (4, 128, 128, 512, 512, False),
          (4, 128, 256, 256, 256, False), (4, 256, 256, 256, 256, False), (4, 256, 512, 128, 128, False), (4, 512, 512, 128, 128, False), (4, 512, 512, 64, 64, False),
-         (256, 64, 64, 32, 32, False), (256, 128, 128, 16, 16, False)]
+         (256, 64, 64, 32, 32, False), (256, 128, 128, 16, 16, False), (1024, 256, 256, 8, 8, False), (1024, 128, 256, 8, 8, False),
+         (1024, 512, 512, 4, 4, False), (1024, 512, 512, 2, 2, False)]
 for n, ci, co, h, w, check64 in cases:
     gen = torch.Generator().manual_seed(ci * 7 + co)
     x = (torch.rand(n, ci, h, w, generator=gen) * 2 - 1).to(dev)

@@ -35,6 +35,9 @@ struct WinoK {
   int ep_mode;        // 0 plain, 1 relu (+ zero border of the padded layout), 2 (acc + ep_add) where ep_mask > 0 (+ zero border)
   const float* ep_add;
   const float* ep_mask;
+  // flat-tile mode (maps smaller than a 16 x 16 block, large batches: the tactile patches' deep layers): a workgroup takes 64 consecutive
+  // 2 x 2 tiles of the FLATTENED (image, tile row, tile column) index instead of an 8 x 8 block of tiles of one image
+  int flat, tiles_x, tpi, ntiles;
 };
 
 constexpr int CKW = 8, TCO = 64, TT = 64;     // channels per chunk, output channels and tiles per workgroup
@@ -207,19 +210,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
   const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sub = wave & 3, half = wave >> 2, mi = sub & 1, ni = sub >> 1;
-  const int bx_n = (p.W + 15) >> 4;
-  const int bx = blockIdx.x % bx_n, by = blockIdx.x / bx_n;
-  const int x0 = bx * 16, y0 = by * 16, co0 = blockIdx.y * TCO, n = blockIdx.z;
+  const int co0 = blockIdx.y * TCO;
   const int plane = p.IPH * p.IPW;
   const int nchunks = (p.Cin + CKW - 1) / CKW;
-  const int64_t in_floats = (int64_t)(p.N - n) * p.Cin * plane;
-  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n * p.Cin * plane, 0,
+  // tile t (0 .. 63) of this workgroup -> (image, top-left output pixel): an 8 x 8 block of tiles of image blockIdx.z, or 64 consecutive
+  // tiles of the flattened (image, tile row, tile column) index
+  auto tile_of = [&](int t, int& img, int& py, int& px) {
+    if (p.flat) {
+      const int T = blockIdx.x * 64 + t;
+      img = T / p.tpi;
+      const int r = T - img * p.tpi, ty = r / p.tiles_x;
+      py = 2 * ty; px = 2 * (r - ty * p.tiles_x);
+      if (T >= p.ntiles) { img = p.N; py = 0; px = 0; }      // beyond the batch: loads return zeros, nothing is stored
+    } else {
+      const int bx_n = (p.W + 15) >> 4;
+      img = blockIdx.z;
+      py = (blockIdx.x / bx_n) * 16 + 2 * (t >> 3);
+      px = (blockIdx.x % bx_n) * 16 + 2 * (t & 7);
+    }
+  };
+  const int n0 = p.flat ? 0 : blockIdx.z;                      // first image the input descriptor covers
+  const int64_t in_floats = (int64_t)(p.N - n0) * p.Cin * plane;
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (int64_t)n0 * p.Cin * plane, 0,
                                                        (int)(in_floats * 4 > 0x7fffffff ? 0x7fffffff : in_floats * 4), RSRC_FLAGS);
   const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, nchunks * CKW * 16 * p.Cout * 4, RSRC_FLAGS);
 
   // this thread's (channel, tile) patch of a chunk and its four weight quads
   const int pci = tid >> 6, pt = tid & 63;
-  const int doff = (pci * plane + (y0 + 2 * (pt >> 3)) * p.IPW + x0 + 2 * (pt & 7)) * 4;
+  int l_img, l_py, l_px;
+  tile_of(pt, l_img, l_py, l_px);
+  const int doff = (((l_img - n0) * p.Cin + pci) * plane + l_py * p.IPW + l_px) * 4;
   int uoff[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -302,11 +322,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const WinoK p) {
     for (int j = 0; j < 4; ++j) xch[(r * 4 + j) * 256 + th] = half ? acc[j][r] : acc[4 + j][r];      // half 1 sends M2, half 0 sends M1
   __syncthreads();
   const float* got = lds + (half ^ 1) * (16 * 4 * 256);
-  const int t = ni * 32 + l32, ty = t >> 3, tx = t & 7;
-  const int oy = y0 + 2 * ty + half, ox = x0 + 2 * tx;       // this wave's output row of the tile
+  int n, oy, ox;
+  tile_of(ni * 32 + l32, n, oy, ox);
+  oy += half;                                                  // this wave's output row of the tile
   const int64_t oplane = (int64_t)p.OH * p.OW;
   float* ob = p.out + (int64_t)n * p.Cout * oplane;
-  if (oy < p.H && ox < p.W) {
+  if (n < p.N && oy < p.H && ox < p.W) {
     const bool pair = ox + 1 < p.W;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -552,9 +573,21 @@ extern "C" int vts_w3x3_wino_pack(const float* w, int A, int B, int64_t sa, int6
 }
 
 // shapes the kernel takes: 64-channel output groups, maps that give the chip enough 16 x 16 blocks, operands inside 31-bit byte offsets
+// flat-tile mode: maps of at most 16 x 16 pixels whose batch gives the chip >= 128 workgroups of 64 tiles x 64 channels, the whole input
+// inside 31-bit byte offsets (VTS_WINO_FLAT=0: off)
+static bool wino_flat(int N, int Cin, int Cout, int H, int W) {
+  static const int off = getenv("VTS_WINO_FLAT") && atoi(getenv("VTS_WINO_FLAT")) == 0;
+  if (off || H > 16 || W > 16 || (H == 16 && W == 16)) return false;
+  if ((int64_t)N * ((Cin + 7) / 8 * 8) * (H + 2) * (W + 2) * 4 > 0x7fffffffll) return false;
+  const int64_t tiles = (int64_t)N * cdiv(H, 2) * cdiv(W, 2);
+  return cdiv64(tiles, 64) * (Cout / TCO) >= 128;
+}
+
 extern "C" int vts_conv3x3_wino_ok(int N, int Cin, int Cout, int H, int W) {
-  if (Cout % TCO || Cin < 32 || H < 8 || W < 8) return 0;
+  if (Cout % TCO || Cin < 32) return 0;
   if ((int64_t)((Cin + 7) / 8 * 8) * 16 * Cout * 4 > 0x7fffffff) return 0;
+  if (wino_flat(N, Cin, Cout, H, W)) return 1;
+  if (H < 8 || W < 8) return 0;
   if ((int64_t)((Cin + 7) / 8 * 8) * (H + 2) * (W + 2) * 4 > 0x7fffffff) return 0;         // byte offsets inside one image
   // a workgroup multiplies a full 16 x 16 block whatever part of it lies inside the map: maps that leave more than ~40 % of their blocks
   // empty (8 x 8 and smaller) are faster on the flattened direct kernel
@@ -573,9 +606,11 @@ extern "C" int vts_conv3x3_wino(const float* in, const float* U, const float* bi
   k.in = in; k.U = U; k.bias = bias; k.out = out; k.N = N; k.Cin = Cin; k.Cout = Cout; k.H = H; k.W = W;
   k.IPH = H + 2; k.IPW = W + 2; k.OH = H + 2 * out_pad; k.OW = W + 2 * out_pad; k.oy0 = out_pad; k.ox0 = out_pad;
   k.ep_mode = ep_mode; k.ep_add = ep_add; k.ep_mask = ep_mask;
-  const dim3 grid(cdiv(W, 16) * cdiv(H, 16), Cout / TCO, N);
+  k.flat = wino_flat(N, Cin, Cout, H, W) ? 1 : 0;
+  k.tiles_x = cdiv(W, 2); k.tpi = k.tiles_x * cdiv(H, 2); k.ntiles = N * k.tpi;
+  const dim3 grid = k.flat ? dim3(cdiv(k.ntiles, 64), Cout / TCO, 1) : dim3(cdiv(W, 16) * cdiv(H, 16), Cout / TCO, N);
   static const int v1 = getenv("VTS_WINO_V1") ? 1 : 0;      // the one-wave-per-SIMD kernel (A/B timing)
-  if (v1) {
+  if (v1 && !k.flat) {
     hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
     vts_set_kernel("conv3x3_wino_kernel");
   } else {
