@@ -33,6 +33,7 @@ from .base_model import BaseModel
 # 1 (default): on one GPU the generator's discriminator-free loss terms run as one more lane beside the discriminator updates; 0: serially
 # behind them (A/B timing; results are identical: the lanes only read the forward's outputs and add into their own fixed-point loss slots)
 G_PRE_LANE = os.environ.get("VTS_G_PRE_LANE", "1") != "0"
+D1_REAL_EARLY = os.environ.get("VTS_D1_REAL_EARLY", "1") != "0"     # D1's pass on the real images beside the generator forward (see _seg_d_updates)
 
 B = str2bool
 
@@ -644,10 +645,11 @@ class SinSKITGModel(BaseModel):
     # The step is cut into segments at the points where a data-parallel run exchanges gradients.
     # Each segment is pure device work on persistent buffers, so it can run eagerly or be replayed
     # from a captured HIP graph (optimize_parameters below).
-    def _forward_and_stacks(self):
+    def _forward_and_stacks(self, begin=True):
         opt, dev, ts, slot = self.opt, self.device, self.train_set, self._slot
         P = ts["real_T"].shape[0]
-        ops.step_begin(self._loss_buf, self._step_counters)      # loss slots <- 0, optimiser step counters += 1
+        if begin:
+            ops.step_begin(self._loss_buf, self._step_counters)      # loss slots <- 0, optimiser step counters += 1
         self.forward(keep=True)
         # patches (compute_additional_output :1268-1291)
         # the patch stacks of the D2 update in ONE buffer, [fake | more fake | real] along the batch (batched passes)
@@ -678,14 +680,35 @@ class SinSKITGModel(BaseModel):
     def _seg_d_updates(self):
         """forward, then the D1 (full resolution) and D2 (32x32 patches) updates: all scales of both discriminators run
         side by side (engine.msd_multi); within one discriminator the passes keep the reference's order."""
-        self._forward_and_stacks()
         opt, dev, slot = self.opt, self.device, self._slot
+        n = self.real_S.shape[0]
+        # D1 on the REAL images does not depend on the generator: its three scales (forward, backward, weight gradients) run on side streams
+        # BESIDE the generator forward, which is one chain that leaves most of the chip idle.  The pass only records its BatchNorm
+        # statistics; the fake pass below splices the running-statistics update in behind its own (the reference's order: fake, then
+        # real, sinskitG_model.py:1361-1374) and accumulates its gradients onto these.  VTS_D1_REAL_EARLY=0: one batched [fake | real] pass.
+        p_real_early = None
+        if (D1_REAL_EARLY and "D" in self.model_names and self._pair and not getattr(self.netD, "is_stylegan2_d", False)
+                and getattr(self, "_I2_pyr", None) is not None and engine.PARALLEL_SCALES):
+            lam = opt.lambda_G1_GAN
+            pyr = [(Act(S[n:2 * n]), Act(I[n:2 * n])) for S, I in zip(self._S2_pyr, self._I2_pyr)]
+            p_real_early = dict(in0=self._S2[n:], in1=self._I2[n:], pyr=pyr, real=True, coeff=lam, slot=slot["D_real_I"], grad_coeff=0.5 * lam,
+                                stat_only=True, keep_stats=True)
+            ops.step_begin(self._loss_buf, self._step_counters)      # (in front of the fork: the real pass adds into its loss slot)
+            engine.msd_multi([(self.netD, [p_real_early])], self.criterionGAN, extra=lambda: self._forward_and_stacks(begin=False), extra_cost=1.0,
+                             extra_main=True, streams=3)
+        else:
+            self._forward_and_stacks()
         jobs = []
         p_fake_I = p_full = None
-        n = self.real_S.shape[0]
         if "D" in self.model_names:      # compute_D1_loss
             lam = opt.lambda_G1_GAN
-            if getattr(self.netD, "is_stylegan2_d", False) or not self._pair:
+            if p_real_early is not None:
+                pyr = self._d1_pyramid(n, pool_fake=True)
+                p_fake_I = dict(in0=self._S2[:n], in1=self._I2[:n], pyr=pyr, prep=self._d1_pool_prep() if pyr is not None else None,
+                                groups=[dict(n0=0, n1=n, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)],
+                                accumulate=True, ext_from=p_real_early, ext_after=0)
+                jobs.append((self.netD, [p_fake_I]))
+            elif getattr(self.netD, "is_stylegan2_d", False) or not self._pair:
                 p_fake_I = dict(in0=self.real_S, in1=self.fake_I, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)
                 jobs.append((self.netD, [p_fake_I, dict(in0=self.real_S, in1=self.real_I, real=True, coeff=lam, slot=slot["D_real_I"],
                                                         grad_coeff=0.5 * lam, accumulate=True)]))

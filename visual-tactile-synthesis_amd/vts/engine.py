@@ -866,29 +866,43 @@ def _run_lanes(n_lanes, body):
         for lane in range(n_lanes):
             body(lane)
         return
+    # A call made from the launch-stream lane of an enclosing call (the generator forward's two decoder lanes inside the lane set of
+    # _msd_multi(extra_main=True)) takes the side streams / scratch indices BEHIND the enclosing call's: `_LANE_BASE`.  (From a SIDE lane
+    # a fork is still forbidden: hipStreamEndCapture does not survive it.)
+    global _LANE_BASE
+    base = _LANE_BASE
     main = torch.cuda.current_stream()
     dev = torch.cuda.current_device()
     side = _SIDE_STREAMS.setdefault(dev, [])
-    while len(side) < n_lanes - 1:
+    while len(side) < base + n_lanes - 1:
         side.append(torch.cuda.Stream())
-    for st in side[:n_lanes - 1]:
+    mine = side[base:base + n_lanes - 1]
+    for st in mine:
         st.wait_stream(main)
+    ws0 = ops.WS_LANE
     try:
         for lane in range(1, n_lanes):
-            ops.WS_LANE = lane
-            with torch.cuda.stream(side[lane - 1]):
+            ops.WS_LANE = base + lane
+            with torch.cuda.stream(mine[lane - 1]):
                 body(lane)
-                ops.wgrad_flush(lane)       # deferred weight-gradient reductions of this lane, on its own stream
-        ops.WS_LANE = 0
-        body(0)
-        ops.wgrad_flush(0)
+                ops.wgrad_flush(base + lane)       # deferred weight-gradient reductions of this lane, on its own stream
+        ops.WS_LANE = ws0
+        _LANE_BASE = base + n_lanes - 1
+        try:
+            body(0)
+        finally:
+            _LANE_BASE = base
+        ops.wgrad_flush(ws0)
     except BaseException:
-        ops.WS_LANE = 0
+        ops.WS_LANE = ws0
         ops.wgrad_discard()                 # a lane body raised: no stale partial jobs for the next backward
         raise
     finally:
-        for st in side[:n_lanes - 1]:       # the side streams are joined back in every case (a capture must not end with a dangling fork)
+        for st in mine:                     # the side streams are joined back in every case (a capture must not end with a dangling fork)
             main.wait_stream(st)
+
+
+_LANE_BASE = 0
 
 
 def _pyramid(D, in0, in1):
@@ -1084,7 +1098,7 @@ def msd_backward(D, ctx, dpreds, param_grads=True, accumulate=False, input_grad=
     return None
 
 
-def msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
+def msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, streams=None):
     """Several discriminators' passes of one training phase, all scales of all of them side by side.
     extra: a callable that runs as ONE MORE lane beside them (work of the phase that needs no discriminator: the generator's L1 /
     perceptual terms, which only read the forward's outputs); extra_cost: its rough time in ms (for the packing of lanes into streams).
@@ -1105,7 +1119,7 @@ def msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
     sg_jobs = [j for j in jobs if getattr(j[0], "is_stylegan2_d", False)]
     jobs = [j for j in jobs if not getattr(j[0], "is_stylegan2_d", False)]
     if jobs:
-        _msd_multi(jobs, criterion, extra, extra_cost)
+        _msd_multi(jobs, criterion, extra, extra_cost, extra_main, streams)
     elif extra is not None:
         extra()
     for D, passes in sg_jobs:
@@ -1150,7 +1164,7 @@ if KO_LANES:      # timing experiment (tools/probes/r02_ko.sh): the named discri
 LANE_STREAMS = int(os.environ.get("VTS_LANE_STREAMS", "4"))
 
 
-def _lane_groups(costs, env="VTS_LANE_GROUPS"):
+def _lane_groups(costs, env="VTS_LANE_GROUPS", streams=None):
     """Which lanes share a stream.  The part runs at most FOUR hardware queues side by side (GPU_MAX_HW_QUEUES, default 4; with 5 - 8 the
     step takes 10 - 11 ms instead of 5.9: the queues beyond four are time-sliced), and a replayed graph maps its parallel branches onto
     them round-robin in capture order -- with one stream per lane (six or seven) WHICH lanes end up sharing a queue was an accident of
@@ -1171,12 +1185,13 @@ def _lane_groups(costs, env="VTS_LANE_GROUPS"):
         if len(seen) != len(set(seen)):
             raise ValueError("VTS_LANE_GROUPS names a lane twice: %s" % spec)
         return groups + [[i] for i in range(n) if i not in seen]      # lanes the spec does not mention keep their own stream
-    if LANE_STREAMS <= 0 or n <= LANE_STREAMS:
+    limit = LANE_STREAMS if streams is None else min(LANE_STREAMS, streams) if LANE_STREAMS > 0 else 0
+    if limit <= 0 or n <= limit:
         return [[i] for i in range(n)]
     order = sorted(range(1, n), key=lambda i: -costs[i])
     bins, load = [[0]], [costs[0]]            # lane 0 (the caller puts its heaviest lane first) stays on the launch stream
     for i in order:
-        if len(bins) < LANE_STREAMS:
+        if len(bins) < limit:
             bins.append([i])
             load.append(costs[i])
             continue
@@ -1196,7 +1211,7 @@ def _lane_cost(passes, s):
     return 0.35 + 1e-7 * px
 
 
-def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
+def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, streams=None):
     lanes = []
     for D, passes in jobs:
         for p in passes:
@@ -1206,7 +1221,10 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
         for s in range(D.num_D):
             lanes.append((D, s, passes))
     costs = [_lane_cost(passes, s) for _, s, passes in lanes]
-    if extra is not None:
+    if extra is not None and extra_main:      # the extra work IS the launch-stream lane (it may fork lanes of its own: the generator forward)
+        lanes.insert(0, (None, -1, extra))
+        costs.insert(0, float(extra_cost))
+    elif extra is not None:
         lanes.append((None, -1, extra))
         costs.append(float(extra_cost))
 
@@ -1258,7 +1276,7 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
                                                    p.get("input_grad") is not None, cache, into=into)
 
     nograd = all(not p.get("param_grads", True) for _, passes in jobs for p in passes)     # the generator step's passes
-    groups = _lane_groups(costs, "VTS_LANE_GROUPS_G" if nograd else "VTS_LANE_GROUPS")
+    groups = _lane_groups(costs, "VTS_LANE_GROUPS_G" if nograd else "VTS_LANE_GROUPS", streams)
     with ops.deferred_wgrad():    # one reduction launch for the weight-gradient partials of all lanes, after they have joined
         _run_lanes(len(groups), lambda gi: [lane(i) for i in groups[gi]])
     for D, passes in jobs:
@@ -1266,7 +1284,8 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1):
             if p.get("input_grad") is not None:
                 _merge_input_grads(p["_din"], p["input_grad"])
             p.pop("_pyr"), p.pop("_din")
-            p.pop("_stats", None)
+            if not p.get("keep_stats"):
+                p.pop("_stats", None)
 
 
 # ======================================================================================================================
