@@ -491,7 +491,8 @@ int vts_step_begin(int64_t* loss_slots, int nslots, int* step_counters, int ncou
 #define VTS_LOSS_SCALE 1099511627776.0 /* 2^40 */
 
 /* GANLoss on one scale (models/networks.py:497-521), forward value and gradient in one pass.
- *   mode: 0 nonsaturating, 1 lsgan, 2 vanilla(BCE logits), 3 wgan, 4 hinge
+ *   mode: 0 nonsaturating, 1 lsgan, 2 vanilla(BCE logits), 3 wgan, 4 hinge, 5 vanilla on sigmoid(pred) (the Sigmoid the reference's
+ *         MultiscaleDiscriminator appends for gan_mode 'vanilla', networks.py:1659, 1731-1732, still followed by BCEWithLogits :507-509)
  *   loss_out[0] += coeff * mean_over_batch( per-sample loss )   (lsgan/vanilla/wgan: global mean)
  *   dpred (if non-NULL) = grad_coeff * d(mean_over_batch(per-sample loss)) / dpred   */
 int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
@@ -542,6 +543,20 @@ int vts_g_post(const float* g_out, const float* M, int N, int H, int W, float sc
 int vts_g_post_stack(const float* g_out, const float* M, int N, int H, int W, float scale_nz, const float* rb, const float* rs,
                      float* fake_I, float* fake_T, int64_t fake_T_nstride, float* fake_N, float* aug_fake_I, int64_t aug_nstride,
                      const float* S, float* stack_S, float* stack_M, int64_t stack_nstride, void* stream);
+
+/* One DiffAugment operation on x [N, C, H, W] (sample stride x_ns floats) -> out (sample stride out_ns; out != x), times the mask M
+ * [N, 1, H, W] when M is given: any policy string over the reference's letters runs as a chain of these
+ * (thirdparty/DiffAugment.py:25-80, AUGMENT_FNS :89-96; the default 'bs' has the fused entry below).  The random numbers are the
+ * caller's (DiffAugment draws them from torch's generator), one set per sample:
+ *   op 'b'  out = x + (pf - 0.5)                                  pf = the uniform draw
+ *      's'  out = (x - mean_c x) * 2 pf + mean_c x
+ *      'c'  out = (x - mean_chw x) * (pf + 0.5) + mean_chw x       ws: vts_diffaug_op_ws_floats(N) floats; x contiguous per sample
+ *      't'  out[i, j] = x[i + pi0, j + pi1], zero outside          pi0 / pi1 = row / column translation (randint(-s, s + 1), s = int(extent / 8 + 0.5))
+ *      'o'  rows clamp(pi0 - ch / 2 + [0, ch)), columns clamp(pi1 - cw / 2 + [0, cw)) zeroed, ch = int(H / 2 + 0.5), cw likewise
+ *      'n'  out = x + pf * noise                                   pf = sigma (rand * 0.1, zeroed where the gate draw >= 0.5), noise [N, C, H, W] */
+int vts_diffaug_op_ws_floats(int N);
+int vts_diffaug_op(const float* x, int64_t x_ns, float* out, int64_t out_ns, int N, int C, int H, int W, int op, const float* pf,
+                   const int* pi0, const int* pi1, const float* noise, const float* M, float* ws, void* stream);
 
 /* aug = DiffAugment_bs(x; rb, rs) * M for a 3-channel image. */
 int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, const float* rb, const float* rs, float* aug,

@@ -824,6 +824,115 @@ def golden_sg2g(seed=909, input_nc=4, n=2):
     print("wrote stylegan2_g_32.npz (%d entries)" % len(out))
 
 
+def golden_diffaug():
+    """DiffAugment beyond 'bs' (thirdparty/DiffAugment.py:25-96): every letter on its own and three multi-letter policies, on odd and
+    even extents.  Inputs regenerate from detrand; the draws regenerate from torch's global generator (nets.diffaug_draws after
+    torch.manual_seed); the fixture keeps the reference's outputs sub-sampled + probed and the small draws as a cross-check."""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from thirdparty.DiffAugment import DiffAugment
+
+    out = {"policies": np.array(["b", "s", "c", "t", "o", "n", "bsctno", "onctsb", "ttcc"]), "shapes": np.array([[2, 3, 20, 28], [3, 3, 33, 17], [1, 3, 64, 64]])}
+    for pol in out["policies"]:
+        pol = str(pol)
+        for si, shape in enumerate(out["shapes"]):
+            shape = tuple(int(v) for v in shape)
+            x = detrand.uniform(shape, 11 + si, "diffaug_" + pol)
+            torch.manual_seed(50 + si)
+            ref = DiffAugment(x, policy=pol)
+            torch.manual_seed(50 + si)
+            d = nets.diffaug_draws(pol, shape)
+            assert float((nets.diffaug(x, pol, d) - ref).abs().max()) <= 2e-7      # (exact but for the summation order of the contrast mean)
+            tag = "%s/%d" % (pol, si)
+            if si == 0:
+                out[tag + "/out"] = ref.numpy()
+            else:
+                out[tag + "/out_sub"] = ref[:, :, ::3, ::3].numpy()
+                out[tag + "/out_probe"] = detrand.probe(ref, "out")
+            for k, dd in enumerate(d):
+                for nm, v in dd.items():
+                    if nm != "noise":
+                        out["%s/draw%d_%s" % (tag, k, nm)] = v.numpy()
+                    else:
+                        out["%s/draw%d_noise_probe" % (tag, k)] = detrand.probe(v, "noise")
+    np.savez_compressed(os.path.join(GOLD, "diffaug.npz"), **out)
+    print("wrote diffaug.npz (%d entries)" % len(out))
+
+
+VARIANTS = {
+    # PatchGAN depth per discriminator off its default (row a7).  (gan_mode lsgan / vanilla / wgan cannot run the reference's sinskitG
+    # step at all: compute_G2_loss takes len() of the scalar those modes return, sinskitG_model.py:1783 -- so the variants use the two
+    # per-sample modes.)
+    "depth_2_4": ["--n_layers_D", "2", "--n_layers_D2", "4"],
+    "hinge_depth_4_2": ["--gan_mode", "hinge", "--n_layers_D", "4", "--n_layers_D2", "2"],
+    # DiffAugment policy with every letter (row a15)
+    "diffaug_all": ["--diffaugment", "bsctno"],
+}
+
+
+def golden_step_variants(size=256, seed=232, nt=64):
+    """One SinSKITGModel.optimize_parameters of the REFERENCE per entry of VARIANTS."""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from models.sinskitG_model import SinSKITGModel
+
+    out = {"size": size, "seed": seed, "nt": nt, "variants": np.array(list(VARIANTS))}
+    for vi, (name, extra) in enumerate(VARIANTS.items()):
+        flags = ["--lambda_G1_lpips", "0", "--lambda_G2_lpips", "0", "--use_vision_aided_loss", "False", "--lambda_G2_GAN_feat", "0",
+                 "--checkpoints_dir", "/tmp/vts_golden_ckpt", "--name", "golden_var"] + extra
+        opt = _ref_opt("sinskitG", True, flags)
+        model = SinSKITGModel(opt)
+        model.setup(opt)
+        shapesG = nets.g_param_shapes()
+        shapesD = nets.d_param_shapes(4, n_layers=opt.n_layers_D)
+        shapesD2 = nets.d_param_shapes(7, n_layers=opt.n_layers_D2)
+        for net, sh in ((model.netD, shapesD), (model.netD2, shapesD2)):
+            assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in sh.items()}, name
+        model.netG.load_state_dict(detrand.test_weights(shapesG, seed + 10 * vi))
+        model.netD.load_state_dict(detrand.test_weights(shapesD, seed + 10 * vi + 1))
+        model.netD2.load_state_dict(detrand.test_weights(shapesD2, seed + 10 * vi + 2))
+        model.train()
+        batch = _synthetic_batch(size, nt, seed + 10 * vi)
+        model.set_input(batch, phase="train")
+        k = int(nets.dilated_mask_positions(model.M).shape[0])
+        torch.manual_seed(seed + vi)
+        if opt.diffaugment == "bs":
+            aug = torch.stack([torch.rand(1, 1, 1, 1).flatten() for _ in range(4)])
+        else:
+            aug = None
+        random.seed(seed + vi)
+        more = np.array(random.sample(range(k), opt.add_fake_T_sample_size), dtype=np.int64)[None]
+        torch.manual_seed(seed + vi)
+        random.seed(seed + vi)
+        model.optimize_parameters(epoch=1)
+        tag = name
+        out[tag + "/flags"] = json.dumps(extra)
+        if aug is not None:
+            out[tag + "/aug"] = aug.numpy()
+        out[tag + "/more_idx"] = more
+        losses = model.get_current_losses()
+        out[tag + "/loss_names"] = np.array(list(losses.keys()))
+        out[tag + "/loss_values"] = np.array(list(losses.values()), dtype=np.float64)
+        for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+            for kk, p in net.named_parameters():
+                out["%s/grad_%s/%s" % (tag, nm, kk)] = detrand.probe(p.grad, kk)
+                out["%s/param_%s/%s" % (tag, nm, kk)] = detrand.probe(p, kk)
+            for kk, b in net.named_buffers():
+                out["%s/buf_%s/%s" % (tag, nm, kk)] = b.detach().double().numpy()
+        out[tag + "/fake_I_probe"] = detrand.probe(model.fake_I, "fake_I")
+        out[tag + "/fake_T_probe"] = detrand.probe(model.fake_T, "fake_T")
+        out[tag + "/aug_fake_I_probe"] = detrand.probe(model.aug_fake_I, "aug_fake_I")
+        out[tag + "/aug_real_I_probe"] = detrand.probe(model.aug_real_I, "aug_real_I")
+        out[tag + "/aug_fake_I_sub"] = model.aug_fake_I.detach()[:, :, ::8, ::8].numpy()
+        out[tag + "/pred_fake_T_full_probe"] = detrand.probe(model.pred_fake_T_full, "pftf")
+        out[tag + "/pred_fake_I_probe"] = detrand.probe(model.pred_fake_I, "pfi")
+        print(name, {k: round(float(v), 5) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(GOLD, "sinskitG_variants_step_%d.npz" % size), **out)
+    print("wrote sinskitG_variants_step_%d.npz (%d entries)" % (size, len(out)))
+
+
 def golden_step(size=256, seed=202, steps=2, nt=64):
     """Full SinSKITGModel.optimize_parameters x `steps` on one synthetic sample (BASELINE config 0)."""
     from oracle import detrand, nets, ref_import
@@ -925,3 +1034,7 @@ if __name__ == "__main__":
         golden_lpips_metrics()
     if "p2pvgg" in which:
         golden_p2p_vgg_step()
+    if "diffaug" in which:
+        golden_diffaug()
+    if "variants" in which:
+        golden_step_variants()

@@ -53,6 +53,77 @@ def diffaug_bs(x, r_b, r_s):
     return ((x - m) * (r_s.view(-1, 1, 1, 1) * 2) + m).contiguous()
 
 
+def diffaug_draws(policy, shape, dtype=torch.float32):
+    """The random numbers DiffAugment(x, policy) consumes for x of `shape` [N, C, H, W], drawn from torch's global generator with the
+    reference's own calls in the reference's order (thirdparty/DiffAugment.py:25-80, AUGMENT_FNS :89-96), so that after
+    torch.manual_seed(s) this returns exactly what the reference draws after the same seed.  One dict per policy letter:
+      b / s / c : r  [N] uniform            t : tx, ty [N] int64 row / column translation
+      o : ox, oy [N] int64 cutout centre     n : sigma [N] (gate already applied), noise [N, C, H, W]"""
+    n, c, h, w = shape
+    out = []
+    for letter in policy:
+        if letter in "bsc":
+            out.append({"r": torch.rand(n, 1, 1, 1, dtype=dtype).flatten()})
+        elif letter == "t":
+            sx, sy = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
+            tx = torch.randint(-sx, sx + 1, size=[n, 1, 1])
+            ty = torch.randint(-sy, sy + 1, size=[n, 1, 1])
+            out.append({"tx": tx.flatten(), "ty": ty.flatten()})
+        elif letter == "o":
+            cs = int(h * 0.5 + 0.5), int(w * 0.5 + 0.5)
+            ox = torch.randint(0, h + (1 - cs[0] % 2), size=[n, 1, 1])
+            oy = torch.randint(0, w + (1 - cs[1] % 2), size=[n, 1, 1])
+            out.append({"ox": ox.flatten(), "oy": oy.flatten()})
+        elif letter == "n":
+            sigma = torch.rand(n, 1, 1, 1, dtype=dtype).abs() * 0.1
+            sigma = torch.where(torch.rand(n, 1, 1, 1, dtype=dtype) < 0.5, sigma, torch.zeros_like(sigma))
+            out.append({"sigma": sigma.flatten(), "noise": torch.randn(n, c, h, w, dtype=dtype)})
+        else:
+            raise KeyError(letter)
+    return out
+
+
+def diffaug(x, policy, draws):
+    """DiffAugment(x, policy) (thirdparty/DiffAugment.py:9-80) with the drawn numbers passed in (diffaug_draws); letters apply in order.
+      b  x + (r - 0.5)                                   s  (x - mean_c x) * 2 r + mean_c x
+      c  (x - mean_chw x) * (r + 0.5) + mean_chw x       t  out[i, j] = x[i + tx, j + ty], zero outside (zero pad 1 + clamped gather)
+      o  rows / columns clamp(o - size // 2 + [0, size)) zeroed, size = int(0.5 * extent + 0.5)
+      n  x + sigma * noise"""
+    n, c, h, w = x.shape
+    v = lambda t: t.to(x.dtype).view(-1, 1, 1, 1)
+    for letter, d in zip(policy, draws):
+        if letter == "b":
+            x = x + (v(d["r"]) - 0.5)
+        elif letter == "s":
+            m = x.mean(dim=1, keepdim=True)
+            x = (x - m) * (v(d["r"]) * 2) + m
+        elif letter == "c":
+            m = x.mean(dim=[1, 2, 3], keepdim=True)
+            x = (x - m) * (v(d["r"]) + 0.5) + m
+        elif letter == "t":
+            rows = torch.arange(h).view(1, h, 1) + d["tx"].view(-1, 1, 1)
+            cols = torch.arange(w).view(1, 1, w) + d["ty"].view(-1, 1, 1)
+            ok = ((rows >= 0) & (rows < h) & (cols >= 0) & (cols < w)).unsqueeze(1)
+            b = torch.arange(n).view(-1, 1, 1)
+            g = x.permute(0, 2, 3, 1)[b, rows.clamp(0, h - 1).expand(n, h, w), cols.clamp(0, w - 1).expand(n, h, w)].permute(0, 3, 1, 2)
+            x = g * ok.to(x.dtype)
+        elif letter == "o":
+            ch, cw = int(h * 0.5 + 0.5), int(w * 0.5 + 0.5)
+            mask = torch.ones(n, 1, h, w, dtype=x.dtype)
+            for i in range(n):
+                r0, r1 = int(d["ox"][i]) - ch // 2, int(d["ox"][i]) - ch // 2 + ch - 1
+                c0, c1 = int(d["oy"][i]) - cw // 2, int(d["oy"][i]) - cw // 2 + cw - 1
+                r0, r1 = min(max(r0, 0), h - 1), min(max(r1, 0), h - 1)
+                c0, c1 = min(max(c0, 0), w - 1), min(max(c1, 0), w - 1)
+                mask[i, 0, r0:r1 + 1, c0:c1 + 1] = 0
+            x = x * mask
+        elif letter == "n":
+            x = x + v(d["sigma"]) * d["noise"]
+        else:
+            raise KeyError(letter)
+    return x.contiguous()
+
+
 def compute_normal(t, scale_nz):
     """models/model_utils.py:408-428."""
     gx, gy = t[:, 0:1], t[:, 1:2]
@@ -479,13 +550,33 @@ D_BN_IDX = {2: 3, 5: 6, 8: 9}
 D_STRIDE = {0: 2, 2: 2, 5: 2, 8: 1, 11: 1}
 
 
-def nlayer_forward(sd, prefix, x, training=True, update_stats=True, momentum=0.1, feats=None):
-    """One NLayerDiscriminator (n_layers=3, BatchNorm2d affine + running stats)."""
-    for ci in D_CONV_IDX:
+def d_layout(n_layers=3):
+    """Sequential indices of one NLayerDiscriminator (networks.py:1696-1737): conv 0 (stride 2) + LeakyReLU; n_layers - 1 blocks
+    [conv stride 2, norm, LeakyReLU]; one block [conv stride 1, norm, LeakyReLU]; conv stride 1 -> 1 channel.
+    Returns (conv indices, {conv: norm index}, {conv: stride}); n_layers = 3 gives D_CONV_IDX / D_BN_IDX / D_STRIDE."""
+    conv = [0] + [2 + 3 * k for k in range(n_layers)] + [2 + 3 * n_layers]
+    bn = {c: c + 1 for c in conv[1:-1]}
+    stride = {c: (2 if j < n_layers else 1) for j, c in enumerate(conv)}
+    return tuple(conv), bn, stride
+
+
+def d_channels(input_nc, ndf, n_layers=3):
+    """channel counts along one PatchGAN: nf doubles per block, capped at 512 (networks.py:1712-1727)"""
+    ch = [input_nc, ndf]
+    for _ in range(n_layers):
+        ch.append(min(ch[-1] * 2, 512))
+    return ch + [1]
+
+
+def nlayer_forward(sd, prefix, x, training=True, update_stats=True, momentum=0.1, feats=None, n_layers=3, use_sigmoid=False):
+    """One NLayerDiscriminator (BatchNorm2d affine + running stats); use_sigmoid: the trailing nn.Sigmoid the reference appends for
+    gan_mode 'vanilla' (networks.py:1659, 1731-1732)."""
+    conv_idx, bn_idx, stride = d_layout(n_layers)
+    for ci in conv_idx:
         k = "%s.%d" % (prefix, ci)
-        x = F.conv2d(x, sd[k + ".weight"], sd[k + ".bias"], stride=D_STRIDE[ci], padding=2)
-        if ci in D_BN_IDX:
-            b = "%s.%d" % (prefix, D_BN_IDX[ci])
+        x = F.conv2d(x, sd[k + ".weight"], sd[k + ".bias"], stride=stride[ci], padding=2)
+        if ci in bn_idx:
+            b = "%s.%d" % (prefix, bn_idx[ci])
             if training and update_stats:
                 x = F.batch_norm(x, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"],
                                  sd[b + ".bias"], True, momentum, 1e-5)
@@ -497,17 +588,17 @@ def nlayer_forward(sd, prefix, x, training=True, update_stats=True, momentum=0.1
                                  sd[b + ".bias"], False, momentum, 1e-5)
         if feats is not None:
             feats.append(x)
-        if ci != 11:
+        if ci != conv_idx[-1]:
             x = F.leaky_relu(x, 0.2)
-    return x
+    return torch.sigmoid(x) if use_sigmoid else x
 
 
-def msd_forward(sd, x, num_D=3, training=True, update_stats=True):
+def msd_forward(sd, x, num_D=3, training=True, update_stats=True, n_layers=3, use_sigmoid=False):
     """MultiscaleDiscriminator.forward: layer{num_D-1} sees full resolution first;
     pyramid by AvgPool2d(3, 2, padding 1, count_include_pad=False).  Returns [[pred_s0],...]."""
     res = []
     for i in range(num_D):
-        res.append([nlayer_forward(sd, "layer%d" % (num_D - 1 - i), x, training, update_stats)])
+        res.append([nlayer_forward(sd, "layer%d" % (num_D - 1 - i), x, training, update_stats, n_layers=n_layers, use_sigmoid=use_sigmoid)])
         if i != num_D - 1:
             x = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
     return res
@@ -670,16 +761,17 @@ def d_if_to_plain(sd):
     return out
 
 
-def d_param_shapes(input_nc, ndf=8, num_D=3):
-    """Ordered {key: shape} of MultiscaleDiscriminator (n_layers=3, BatchNorm2d), incl. buffers."""
-    chans = [input_nc, ndf, ndf * 2, ndf * 4, ndf * 8, 1]
+def d_param_shapes(input_nc, ndf=8, num_D=3, n_layers=3):
+    """Ordered {key: shape} of MultiscaleDiscriminator (BatchNorm2d), incl. buffers."""
+    chans = d_channels(input_nc, ndf, n_layers)
+    conv_idx, bn_idx, _ = d_layout(n_layers)
     shapes = {}
     for d in range(num_D):
-        for j, ci in enumerate(D_CONV_IDX):
+        for j, ci in enumerate(conv_idx):
             shapes["layer%d.%d.weight" % (d, ci)] = (chans[j + 1], chans[j], 4, 4)
             shapes["layer%d.%d.bias" % (d, ci)] = (chans[j + 1],)
-            if ci in D_BN_IDX:
-                b = "layer%d.%d" % (d, D_BN_IDX[ci])
+            if ci in bn_idx:
+                b = "layer%d.%d" % (d, bn_idx[ci])
                 c = chans[j + 1]
                 shapes[b + ".weight"] = (c,)
                 shapes[b + ".bias"] = (c,)

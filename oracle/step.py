@@ -32,6 +32,7 @@ DEFAULT_HP = dict(
     batch_size_G2=64, add_fake_T_sample_size=32, scale_nz=0.25, num_D=3,
     use_more_fakeT=True, use_diffaug=True, lr_scale=1.0, netG="unet256_custom",
     lambda_G1_lpips=0.0, lambda_G2_lpips=0.0,
+    n_layers_D=3, n_layers_D2=3, smooth_GAN_label=True, diffaugment="bs",
 )
 
 
@@ -111,7 +112,12 @@ def _d1(sdD, x, opt):
     if getattr(opt, "netD", "multiscale") == "stylegan2":
         from oracle import stylegan2
         return [[stylegan2.discriminator_forward(sdD, x, x.shape[-1])]]
-    return nets.msd_forward(sdD, x, opt.num_D)
+    return nets.msd_forward(sdD, x, opt.num_D, n_layers=getattr(opt, "n_layers_D", 3), use_sigmoid=opt.gan_mode == "vanilla")
+
+
+def _d2(sdD2, x, opt):
+    """netD2: MultiscaleDiscriminator(n_layers_D2), with the trailing Sigmoid the reference adds for gan_mode 'vanilla' (networks.py:1659)"""
+    return nets.msd_forward(sdD2, x, opt.num_D, n_layers=getattr(opt, "n_layers_D2", 3), use_sigmoid=opt.gan_mode == "vanilla")
 
 
 def _exchange(sd, name, exchange):
@@ -138,14 +144,21 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     inp = prepare_input(batch)
     N, NT = inp.N, inp.NT
     lamD1, lamD2 = opt.lambda_G1_GAN, opt.lambda_G2_GAN
-    gl = lambda p, real: nets.gan_loss(p, real, opt.gan_mode)
+    # label smoothing: GANLoss(gan_mode, target_real_label=0.8) (sinskitG_model.py:485-488); only lsgan / vanilla read the labels
+    real_label = 0.8 if getattr(opt, "smooth_GAN_label", True) else 1.0
+    gl = lambda p, real: nets.gan_loss(p, real, opt.gan_mode, real_label=real_label)
 
     # ---- forward (G requires grad for the later G step) ----
     _req(sdG, True)
     _req(sdD, False)
     _req(sdD2, False)
     g_out, fake_I, fake_T = generator_forward(sdG, inp, opt, style_code)
-    if opt.use_diffaug:
+    if opt.use_diffaug and "aug_policy" in draws:
+        # any policy over b / s / c / t / o / n: draws["aug_policy"] = (nets.diffaug_draws for real_I, then for fake_I) (:1330-1333)
+        pol = getattr(opt, "diffaugment", "bs")
+        aug_real_I = nets.diffaug(inp.real_I, pol, draws["aug_policy"][0]) * inp.M
+        aug_fake_I = nets.diffaug(fake_I, pol, draws["aug_policy"][1]) * inp.M
+    elif opt.use_diffaug:
         aug = draws["aug"].float()
         aug_real_I = nets.diffaug_bs(inp.real_I, aug[0], aug[1]) * inp.M
         aug_fake_I = nets.diffaug_bs(fake_I, aug[2], aug[3]) * inp.M
@@ -177,10 +190,10 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     # ---- D2 step ----
     _req(sdD2, True)
     fake_stack = torch.cat((fake_T_concat.detach(), S_concat, fake_I_concat), 1)
-    pred_fake_T = nets.msd_forward(sdD2, fake_stack, opt.num_D)
+    pred_fake_T = _d2(sdD2, fake_stack, opt)
     loss_D_fake_T = gl(pred_fake_T, False).mean() * lamD2
     full_stack = torch.cat((fake_T.detach(), inp.real_S, fake_I_full), 1)
-    pred_full = nets.msd_forward(sdD2, full_stack, opt.num_D)  # visualisation only; still updates BN stats
+    pred_full = _d2(sdD2, full_stack, opt)  # visualisation only; still updates BN stats
     loss_D_more = torch.zeros(())
     if opt.use_more_fakeT:
         stacks = []
@@ -193,10 +206,10 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
             i = nets.gather_patches(fake_I[n:n + 1].detach(), ox, oy, 32)
             stacks.append(torch.cat((t, s, i, torch.ones_like(s)), 1))
         more_stack = torch.cat(stacks, 0)
-        pred_more = nets.msd_forward(sdD2, more_stack, opt.num_D)
+        pred_more = _d2(sdD2, more_stack, opt)
         loss_D_more = gl(pred_more, False).mean() * lamD2
     real_stack = torch.cat((inp.real_T, S_concat, real_I_concat), 1)
-    pred_real_T = nets.msd_forward(sdD2, real_stack, opt.num_D)
+    pred_real_T = _d2(sdD2, real_stack, opt)
     loss_D_real_T = gl(pred_real_T, True).mean() * lamD2
     loss_D2 = (loss_D_fake_T + loss_D_more + loss_D_real_T) * 0.5
     loss_D2.backward()
@@ -212,7 +225,7 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     loss_G_GAN = gl(pred_g, True).mean() * lamD1
     loss_G_L1 = F.l1_loss(fake_I, inp.real_I) * opt.lambda_G1_L1
     g2_stack = torch.cat((fake_T_concat.clone().detach(), S_concat, fake_I_concat), 1)
-    pred_g2 = nets.msd_forward(sdD2, g2_stack, opt.num_D)
+    pred_g2 = _d2(sdD2, g2_stack, opt)
     loss_G2_GAN = (gl(pred_g2, True) * lamD2).view(-1, NT).mean(dim=0).sum()  # logged only: no gradient path
     l1 = (fake_T_concat - inp.real_T).abs() * opt.lambda_G2_L1
     loss_G2_L1 = l1.view(-1, NT, 2, 32, 32).sum(dim=1).mean()

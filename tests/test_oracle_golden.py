@@ -323,6 +323,80 @@ def test_train_step_matches_reference(golden_dir):
                     _close(v.double().numpy(), g["%s/buf_%s/%s" % (tag, nm, k)], rtol=1e-4, atol=1e-6)
 
 
+def _variant_opt(extra):
+    """oracle hyper-parameters for a flag list of oracle/make_golden.py:VARIANTS"""
+    kw = {}
+    for k, v in zip(extra[::2], extra[1::2]):
+        k = k.lstrip("-")
+        kw[k] = int(v) if k.startswith("n_layers") else v
+    return step.hp(**kw)
+
+
+def _variant_draws(g, name, opt, seed, vi, size):
+    draws = {"more_idx": torch.from_numpy(g[name + "/more_idx"])}
+    if opt.diffaugment == "bs":
+        draws["aug"] = torch.from_numpy(g[name + "/aug"])
+    else:       # the reference seeds torch's generator with seed + vi in front of the step: DiffAugment(real_I), then DiffAugment(fake_I)
+        torch.manual_seed(seed + vi)
+        draws["aug_policy"] = (nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)), nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)))
+    return draws
+
+
+def test_train_step_variants_match_reference(golden_dir):
+    """PatchGAN depths 2 / 4 (n_layers_D, n_layers_D2), hinge, and the six-letter DiffAugment policy: one reference step each"""
+    g = _load(golden_dir, "sinskitG_variants_step_256.npz")
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    for vi, name in enumerate(str(v) for v in g["variants"]):
+        opt = _variant_opt(json.loads(str(g[name + "/flags"])))
+        sdG = detrand.test_weights(nets.g_param_shapes(), seed + 10 * vi)
+        sdD = detrand.test_weights(nets.d_param_shapes(4, n_layers=opt.n_layers_D), seed + 10 * vi + 1)
+        sdD2 = detrand.test_weights(nets.d_param_shapes(7, n_layers=opt.n_layers_D2), seed + 10 * vi + 2)
+        adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+        out = step.train_step(sdG, sdD, sdD2, adam, _batch(size, nt, seed + 10 * vi), _variant_draws(g, name, opt, seed, vi, size), opt=opt)
+        ref = dict(zip([str(s) for s in g[name + "/loss_names"]], g[name + "/loss_values"]))
+        for k, v in out["losses"].items():
+            assert abs(v - ref["l_" + k]) <= 2e-4 * max(1.0, abs(ref["l_" + k])), (name, k, v, ref["l_" + k])
+        _close(out["aug_fake_I"][:, :, ::8, ::8].numpy(), g[name + "/aug_fake_I_sub"], rtol=1e-4, atol=2e-5)
+        for nm in ("aug_fake_I", "aug_real_I"):
+            _probe_close(out[nm], g["%s/%s_probe" % (name, nm)], nm)
+        _probe_close(out["pred_fake_T_full"], g[name + "/pred_fake_T_full_probe"], "pftf")
+        _probe_close(out["pred_fake_I"][-1], g[name + "/pred_fake_I_probe"], "pfi")
+        for nm, sd in (("G", sdG), ("D", sdD), ("D2", sdD2)):
+            for k, gr in out["grad_" + nm].items():
+                _probe_close(gr, g["%s/grad_%s/%s" % (name, nm, k)], k, rtol=5e-4)
+            for k, v in sd.items():
+                key = "%s/param_%s/%s" % (name, nm, k)
+                if key in g:
+                    _probe_close(v, g[key], k, rtol=1e-4)
+                else:
+                    _close(v.double().numpy(), g["%s/buf_%s/%s" % (name, nm, k)], rtol=1e-4, atol=1e-6)
+
+
+def test_diffaugment_policies_match_reference(golden_dir):
+    """every DiffAugment letter (b s c t o n) and multi-letter policies against the reference's outputs; the draws regenerate from
+    torch's generator in the reference's order and are cross-checked against the recorded ones"""
+    g = _load(golden_dir, "diffaug.npz")
+    for pol in (str(v) for v in g["policies"]):
+        for si, shape in enumerate(g["shapes"]):
+            shape = tuple(int(v) for v in shape)
+            x = detrand.uniform(shape, 11 + si, "diffaug_" + pol)
+            torch.manual_seed(50 + si)
+            d = nets.diffaug_draws(pol, shape)
+            tag = "%s/%d" % (pol, si)
+            for k, dd in enumerate(d):
+                for nm, v in dd.items():
+                    if nm == "noise":
+                        _probe_close(v, g["%s/draw%d_noise_probe" % (tag, k)], "noise")
+                    else:
+                        assert np.array_equal(v.numpy(), g["%s/draw%d_%s" % (tag, k, nm)]), (tag, k, nm)
+            y = nets.diffaug(x, pol, d)
+            if si == 0:
+                _close(y.numpy(), g[tag + "/out"], rtol=0, atol=2e-7)
+            else:
+                _close(y[:, :, ::3, ::3].numpy(), g[tag + "/out_sub"], rtol=0, atol=2e-7)
+                _probe_close(y, g[tag + "/out_probe"], "out")
+
+
 def test_option_fixture_is_reference_dump(golden_dir):
     d = json.load(open(os.path.join(golden_dir, "ref_option_defaults.json")))
     assert d["sinskitG_train"]["ngf"]["default"] == 10 and d["sinskitG_train"]["netD2"]["default"] == "multiscale"

@@ -7,6 +7,7 @@ at 2e-3 on their l2 norm / fixed random projection.  Biases of convolutions that
 Instance/BatchNorm have a mathematically-zero gradient (pure rounding noise in the reference
 as well), so they are excluded from gradient and parameter comparisons.
 """
+import json
 import os
 
 import numpy as np
@@ -117,6 +118,62 @@ def test_step_matches_reference_golden(golden_dir):
                     assert rel(b, refb) < tol, k
                 else:
                     assert int(b) == int(refb), k
+
+
+def test_step_variants_match_reference_golden(golden_dir):
+    """One reference step per variant of oracle/make_golden.py:VARIANTS: PatchGAN depths 2 / 4 (--n_layers_D, --n_layers_D2), hinge,
+    and the six-letter DiffAugment policy 'bsctno' (its draws regenerate from torch's CPU generator in the reference's order)."""
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+
+    g = np.load(os.path.join(golden_dir, "sinskitG_variants_step_256.npz"))
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    tol = 1e-3
+    for vi, name in enumerate(str(v) for v in g["variants"]):
+        extra = json.loads(str(g[name + "/flags"]))
+        opt = TrainOptions(cmd_line=(FLAGS % (size, 1)) + " " + " ".join(extra)).parse()
+        model = create_model(opt)
+        model.setup(opt)
+        model.parallelize()
+        model.train()
+        sds = (detrand.test_weights(nets.g_param_shapes(), seed + 10 * vi),
+               detrand.test_weights(nets.d_param_shapes(4, n_layers=opt.n_layers_D), seed + 10 * vi + 1),
+               detrand.test_weights(nets.d_param_shapes(7, n_layers=opt.n_layers_D2), seed + 10 * vi + 2))
+        for net, sd in zip((model.netG, model.netD, model.netD2), sds):
+            assert list(net.state_dict().keys()) == list(sd.keys()), name
+            net.load_state_dict(sd)
+        model._draws = {"more_idx": torch.from_numpy(g[name + "/more_idx"])}
+        if opt.diffaugment == "bs":
+            model._draws["aug"] = torch.from_numpy(g[name + "/aug"])
+        else:
+            torch.manual_seed(seed + vi)
+            model._draws["aug_policy"] = (nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)), nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)))
+        model.set_input(default_collate([make_sample(size, nt, nt, seed + 10 * vi)]), phase="train")
+        model.optimize_parameters(epoch=1)
+        ref = dict(zip([str(s) for s in g[name + "/loss_names"]], g[name + "/loss_values"]))
+        for k, v in model.get_current_losses().items():
+            assert abs(v - ref[k]) <= tol * max(1.0, abs(ref[k])), (name, k, v, ref[k])
+        assert rel(model.aug_fake_I[:, :, ::8, ::8], torch.from_numpy(g[name + "/aug_fake_I_sub"])) < tol, name
+        for nm in ("fake_I", "fake_T", "aug_fake_I", "aug_real_I", "pred_fake_T_full", "pred_fake_I"):
+            key = {"pred_fake_T_full": "pftf", "pred_fake_I": "pfi"}.get(nm, nm)
+            probe_close(getattr(model, nm).contiguous(), g["%s/%s_probe" % (name, nm)], key, 2 * tol)
+        for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+            bn_convs = () if nm == "G" else tuple(str(c) for c in net.BN_IDX)
+            for k, p in net.named_parameters():
+                if (nm == "G" and null_grad_bias(nm, k)) or (nm != "G" and k.endswith("bias") and k.split(".")[1] in bn_convs):
+                    continue
+                probe_close(p.grad, g["%s/grad_%s/%s" % (name, nm, k)], k, 2 * tol)
+                probe_close(p.data, g["%s/param_%s/%s" % (name, nm, k)], k, tol)
+            for k, b in net.named_buffers():
+                refb = torch.from_numpy(g["%s/buf_%s/%s" % (name, nm, k)])
+                if k.endswith("running_mean"):
+                    scale = float(np.sqrt(g["%s/buf_%s/%s" % (name, nm, k.replace("running_mean", "running_var"))].max()))
+                    assert (b.double().cpu() - refb).abs().max().item() < tol * scale, (name, k)
+                elif b.dtype.is_floating_point:
+                    assert rel(b, refb) < tol, (name, k)
+                else:
+                    assert int(b) == int(refb), (name, k)
 
 
 def test_second_step_from_synced_state(golden_dir):

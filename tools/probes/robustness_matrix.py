@@ -30,6 +30,11 @@ CASES = [
     ("sinskitG separate0", "--model sinskitG --crop_size 256 --batch_size 1 --num_layer_separate 0", 256, 1),
     ("sinskitG resnet6", "--model sinskitG --crop_size 256 --batch_size 2 --netG resnet_6blocks", 256, 2),
     ("sinskitG netD stylegan2", "--model sinskitG --crop_size 256 --load_size 256 --batch_size 2 --netD stylegan2", 256, 2),
+    ("sinskitG D depth 2 / D2 depth 4", "--model sinskitG --crop_size 256 --batch_size 2 --n_layers_D 2 --n_layers_D2 4", 256, 2),
+    ("skitG 1024 b4 D depth 4", "--model skitG --crop_size 1024 --batch_size 4 --n_layers_D 4", 1024, 4),
+    ("sinskitG vanilla D depth 5", "--model sinskitG --crop_size 512 --batch_size 1 --gan_mode vanilla --n_layers_D 5", 512, 1),
+    ("sinskitG diffaugment bsctno", "--model sinskitG --crop_size 256 --batch_size 2 --diffaugment bsctno", 256, 2),
+    ("skitG 1024 b4 diffaugment cto", "--model skitG --crop_size 1024 --batch_size 4 --diffaugment cto", 1024, 4),
     ("sinskitG 200 steps + lr decay", "--model sinskitG --crop_size 256 --batch_size 1", 256, 1),
 ]
 

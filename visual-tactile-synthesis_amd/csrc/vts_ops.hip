@@ -119,6 +119,12 @@ __global__ __launch_bounds__(256) void ganloss_kernel(const float* __restrict__ 
       case 1: l = (p - label) * (p - label); g = 2.f * (p - label); break;
       case 2: l = fmaxf(p, 0.f) - p * label + log1pf(expf(-fabsf(p))); g = sigmoid_f(p) - label; break;
       case 3: l = real ? -p : p; g = real ? -1.f : 1.f; break;
+      case 5: {   // 'vanilla' behind the PatchGAN's trailing Sigmoid (reference networks.py:1659, 1731-1732): BCE-with-logits OF sigmoid(p)
+        const float q = sigmoid_f(p);
+        l = q - q * label + log1pf(expf(-q));      // q > 0
+        g = (sigmoid_f(q) - label) * q * (1.f - q);
+        break;
+      }
       default: {
         const float t = real ? 1.f - p : 1.f + p;
         l = fmaxf(t, 0.f);
@@ -327,6 +333,79 @@ __global__ __launch_bounds__(256) void diffaug_kernel(const float* __restrict__ 
   o[0] = ((r1 - mean) * k + mean) * m;
   o[HW] = ((g1 - mean) * k + mean) * m;
   o[2 * HW] = ((b1 - mean) * k + mean) * m;
+}
+
+// One DiffAugment operation beyond the fused 'bs' pair (thirdparty/DiffAugment.py:36-80): contrast, translation, cutout, noise -- and b / s
+// on their own, so that any policy string runs as a chain of these.  One thread per pixel, all channels; grid (HW / 256, N).
+//   'c' reads the sample's mean from `part` (DIFFAUG_PARTS partial sums per sample, summed here in a fixed order)
+constexpr int DIFFAUG_PARTS = 256;
+
+__global__ __launch_bounds__(256) void diffaug_mean_part_kernel(const float* __restrict__ x, int64_t xns, int64_t CHW, float* __restrict__ part) {
+  __shared__ float red[16];
+  const int n = blockIdx.y;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < CHW; i += (int64_t)DIFFAUG_PARTS * 256) acc += x[n * xns + i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[n * DIFFAUG_PARTS + blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void diffaug_op_kernel(const float* __restrict__ x, int64_t xns, float* __restrict__ out, int64_t ons, int C, int H,
+                                                         int W, int op, const float* __restrict__ pf, const int* __restrict__ pi0,
+                                                         const int* __restrict__ pi1, const float* __restrict__ noise,
+                                                         const float* __restrict__ part, const float* __restrict__ M) {
+  __shared__ float red[16];
+  const int n = blockIdx.y;
+  const int64_t HW = (int64_t)H * W;
+  float mean_all = 0.f;
+  if (op == 'c') {      // every block re-derives the sample mean from the partials (block-uniform, so the barrier inside is safe)
+    mean_all = block_sum(part[n * DIFFAUG_PARTS + threadIdx.x], red) / (float)(C * HW);
+  }
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  const int y = (int)(i / W), xx = (int)(i % W);
+  const float m = M ? M[n * HW + i] : 1.f;
+  const float* p = x + n * xns + i;
+  float* o = out + n * ons + i;
+  switch (op) {
+    case 'b': {
+      const float d = pf[n] - 0.5f;
+      for (int c = 0; c < C; ++c) o[c * HW] = (p[c * HW] + d) * m;
+      break;
+    }
+    case 's': {
+      float mean = 0.f;
+      for (int c = 0; c < C; ++c) mean += p[c * HW];
+      mean /= (float)C;
+      const float k = pf[n] * 2.f;
+      for (int c = 0; c < C; ++c) o[c * HW] = ((p[c * HW] - mean) * k + mean) * m;
+      break;
+    }
+    case 'c': {
+      const float k = pf[n] + 0.5f;
+      for (int c = 0; c < C; ++c) o[c * HW] = ((p[c * HW] - mean_all) * k + mean_all) * m;
+      break;
+    }
+    case 't': {     // out[y, x] = in[y + tx, x + ty], zero outside (the reference pads by one zero row / column and clamps into it)
+      const int sy = y + pi0[n], sx = xx + pi1[n];
+      const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+      const float* q = x + n * xns + (int64_t)(ok ? sy : 0) * W + (ok ? sx : 0);
+      for (int c = 0; c < C; ++c) o[c * HW] = ok ? q[c * HW] * m : 0.f;
+      break;
+    }
+    case 'o': {     // rows / columns clamp(offset - size / 2 + [0, size)) are zeroed, size = int(0.5 * extent + 0.5)
+      const int ch = (int)(H * 0.5 + 0.5), cw = (int)(W * 0.5 + 0.5);
+      const int r0 = min(max(pi0[n] - ch / 2, 0), H - 1), r1 = min(max(pi0[n] - ch / 2 + ch - 1, 0), H - 1);
+      const int c0 = min(max(pi1[n] - cw / 2, 0), W - 1), c1 = min(max(pi1[n] - cw / 2 + cw - 1, 0), W - 1);
+      const bool cut = y >= r0 && y <= r1 && xx >= c0 && xx <= c1;
+      for (int c = 0; c < C; ++c) o[c * HW] = cut ? 0.f : p[c * HW] * m;
+      break;
+    }
+    default: {      // 'n': x + sigma * noise
+      const float sg = pf[n];
+      const float* z = noise + (int64_t)n * C * HW + i;
+      for (int c = 0; c < C; ++c) o[c * HW] = (p[c * HW] + sg * z[c * HW]) * m;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void g_out_grad_kernel(const float* __restrict__ dI, const float* __restrict__ dT,
@@ -612,7 +691,7 @@ extern "C" int vts_avgpool3s2_bwd(const float* dy, int N, int C, int H, int W, f
 
 extern "C" int vts_ganloss(const float* pred, int N, int M, int mode, int target_is_real, float target_label, float coeff,
                            float grad_coeff, int64_t* loss_out, float* dpred, void* stream) {
-  VTS_CHECK_ARG(pred && N >= 1 && M >= 1 && mode >= 0 && mode <= 4, "vts_ganloss: bad args");
+  VTS_CHECK_ARG(pred && N >= 1 && M >= 1 && mode >= 0 && mode <= 5, "vts_ganloss: bad args");
   const int64_t total = (int64_t)N * M;
   hipLaunchKernelGGL(ganloss_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, total, mode, target_is_real,
                      target_label, 1.f / (float)total, coeff, grad_coeff, reinterpret_cast<long long*>(loss_out), dpred);
@@ -724,6 +803,28 @@ extern "C" int vts_g_out_grad(const float* d_fake_I, const float* d_fake_T, cons
   hipLaunchKernelGGL(g_out_grad_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, d_fake_I, d_fake_T, M,
                      g_out, HW, d_raw);
   VTS_CHECK_LAUNCH("vts_g_out_grad");
+  return VTS_OK;
+}
+
+extern "C" int vts_diffaug_op_ws_floats(int N) { return N * DIFFAUG_PARTS; }
+
+extern "C" int vts_diffaug_op(const float* x, int64_t x_ns, float* out, int64_t out_ns, int N, int C, int H, int W, int op, const float* pf,
+                              const int* pi0, const int* pi1, const float* noise, const float* M, float* ws, void* stream) {
+  VTS_CHECK_ARG(x && out && x != out && N >= 1 && C >= 1 && H >= 1 && W >= 1, "vts_diffaug_op: bad args");
+  const bool f = op == 'b' || op == 's' || op == 'c' || op == 'n', g = op == 't' || op == 'o';
+  VTS_CHECK_ARG(f || g, "vts_diffaug_op: op must be one of b s c t o n");
+  VTS_CHECK_ARG(!f || pf, "vts_diffaug_op: b / s / c / n need the per-sample float draw");
+  VTS_CHECK_ARG(!g || (pi0 && pi1), "vts_diffaug_op: t / o need the two per-sample integer draws");
+  VTS_CHECK_ARG(op != 'n' || noise, "vts_diffaug_op: n needs the noise tensor");
+  VTS_CHECK_ARG(op != 'c' || ws, "vts_diffaug_op: c needs vts_diffaug_op_ws_floats(N) floats of workspace");
+  const int64_t HW = (int64_t)H * W;
+  if (op == 'c') {
+    VTS_CHECK_ARG(x_ns == (int64_t)C * HW, "vts_diffaug_op: c needs a contiguous sample");
+    hipLaunchKernelGGL(diffaug_mean_part_kernel, dim3(DIFFAUG_PARTS, N), dim3(256), 0, (hipStream_t)stream, x, x_ns, (int64_t)C * HW, ws);
+  }
+  hipLaunchKernelGGL(diffaug_op_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, x, x_ns, out, out_ns, C, H, W, op,
+                     pf, pi0, pi1, noise, ws, M);
+  VTS_CHECK_LAUNCH("vts_diffaug_op");
   return VTS_OK;
 }
 

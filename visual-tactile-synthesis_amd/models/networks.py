@@ -324,20 +324,36 @@ class GlobalGenerator(ResnetGenerator):
                          down="stride", up="convT", conv_bias=True, opt=opt)
 
 
-class MultiscaleDiscriminator(nn.Module):
-    """num_D PatchGANs over an average-pooled pyramid (reference: networks.py:1649-1750).
-    BatchNorm2d(affine, running stats) as in the hot-path default (normD=batch)."""
+def _patchgan_layout(n_layers):
+    """Sequential indices of one NLayerDiscriminator (reference networks.py:1696-1737): conv 0 (stride 2); n_layers - 1 blocks
+    [conv stride 2, norm, LeakyReLU]; one block [conv stride 1, norm, LeakyReLU]; conv stride 1 -> 1 channel."""
+    conv = [0] + [2 + 3 * k for k in range(n_layers)] + [2 + 3 * n_layers]
+    return tuple(conv), {c: c + 1 for c in conv[1:-1]}, {c: (2 if j < n_layers else 1) for j, c in enumerate(conv)}
 
-    CONV_IDX = (0, 2, 5, 8, 11)
-    BN_IDX = {2: 3, 5: 6, 8: 9}
-    STRIDE = {0: 2, 2: 2, 5: 2, 8: 1, 11: 1}
+
+def _patchgan_channels(input_nc, ndf, n_layers):
+    ch = [input_nc, ndf]
+    for _ in range(n_layers):
+        ch.append(min(ch[-1] * 2, 512))
+    return ch + [1]
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """num_D PatchGANs of depth n_layers over an average-pooled pyramid (reference: networks.py:1649-1750).
+    BatchNorm2d(affine, running stats) as in the hot-path default (normD=batch).  With gan_mode 'vanilla' the reference appends a
+    Sigmoid to every PatchGAN (`use_sigmoid`, :1659, 1731-1732) and still feeds BCEWithLogits (:507-509): `use_sigmoid` is kept as an
+    attribute, forward() returns the squashed maps and the loss kernel takes the same detour (GANLoss.accumulate(pre_sigmoid=True))."""
+
+    CONV_IDX, BN_IDX, STRIDE = _patchgan_layout(3)      # (0, 2, 5, 8, 11) / {2: 3, 5: 6, 8: 9} / strides 2 2 2 1 1
 
     def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, opt=None):
         super().__init__()
-        if n_layers != 3:
-            raise NotImplementedError("MultiscaleDiscriminator: only n_layers=3 is built")
-        self.input_nc, self.ndf, self.num_D = input_nc, ndf, num_D
-        chans = [input_nc, ndf, min(ndf * 2, 512), min(ndf * 4, 512), min(ndf * 8, 512), 1]
+        if n_layers < 1:
+            raise ValueError("MultiscaleDiscriminator: n_layers must be >= 1")
+        self.input_nc, self.ndf, self.num_D, self.n_layers = input_nc, ndf, num_D, n_layers
+        self.use_sigmoid = getattr(opt, "gan_mode", None) == "vanilla"
+        self.CONV_IDX, self.BN_IDX, self.STRIDE = _patchgan_layout(n_layers)
+        chans = _patchgan_channels(input_nc, ndf, n_layers)
         self.chans = chans
         for d in range(num_D):
             children = {}
@@ -350,7 +366,7 @@ class MultiscaleDiscriminator(nn.Module):
     def forward(self, x):
         """Returns [[pred_scale0], [pred_scale1], ...] like the reference."""
         preds, _ = engine.msd_forward(self, x, None, keep=False)
-        return [[p] for p in preds]
+        return [[torch.sigmoid(p) if self.use_sigmoid else p] for p in preds]
 
 
 class _LayerView:
@@ -361,10 +377,10 @@ class _LayerView:
 
     def __getattr__(self, name):
         ci = int(name)
-        conv_idx = MultiscaleDiscriminator.CONV_IDX
+        conv_idx = self._owner.CONV_IDX
         if ci in conv_idx:
             return getattr(getattr(self._owner, "scale%d_layer%d" % (self._d, conv_idx.index(ci))), "0")
-        j = {v: conv_idx.index(k) for k, v in MultiscaleDiscriminator.BN_IDX.items()}[ci]
+        j = {v: conv_idx.index(k) for k, v in self._owner.BN_IDX.items()}[ci]
         return getattr(getattr(self._owner, "scale%d_layer%d" % (self._d, j)), "1")
 
 
@@ -375,15 +391,17 @@ class MultiscaleDiscriminatorIF(MultiscaleDiscriminator):
 
     def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, opt=None):
         nn.Module.__init__(self)
-        if n_layers != 3:
-            raise NotImplementedError("MultiscaleDiscriminator: only n_layers=3 is built")
-        self.input_nc, self.ndf, self.num_D = input_nc, ndf, num_D
-        chans = [input_nc, ndf, min(ndf * 2, 512), min(ndf * 4, 512), min(ndf * 8, 512), 1]
+        if n_layers < 1:
+            raise ValueError("MultiscaleDiscriminator: n_layers must be >= 1")
+        self.input_nc, self.ndf, self.num_D, self.n_layers = input_nc, ndf, num_D, n_layers
+        self.use_sigmoid = getattr(opt, "gan_mode", None) == "vanilla"
+        self.CONV_IDX, self.BN_IDX, self.STRIDE = _patchgan_layout(n_layers)
+        chans = _patchgan_channels(input_nc, ndf, n_layers)
         self.chans = chans
         for d in range(num_D):
-            for j in range(5):
+            for j in range(n_layers + 2):
                 kids = {0: _ConvParams((chans[j + 1], chans[j], 4, 4), chans[j + 1])}
-                if 1 <= j <= 3:
+                if 1 <= j <= n_layers:
                     kids[1] = _BNParams(chans[j + 1])
                 setattr(self, "scale%d_layer%d" % (d, j), _Holder(kids))
 
@@ -399,7 +417,7 @@ class MultiscaleDiscriminatorIF(MultiscaleDiscriminator):
         res = []
         for (_, _, acts) in ctx.scales:
             feats = [_ops.pad_affine(a, (0, 0, 0, 0), 0, act=engine.LRELU) for a in acts[:-1]]
-            res.append(feats + [acts[-1].data])
+            res.append(feats + [torch.sigmoid(acts[-1].data) if self.use_sigmoid else acts[-1].data])
         return res
 
 
@@ -516,24 +534,30 @@ class GANLoss:
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
         from vts import lib as L
 
-        if gan_mode not in L.GAN_MODES:
+        if gan_mode not in L.GAN_MODES or gan_mode == "vanilla_sigmoid":
             raise NotImplementedError("gan mode %s not implemented" % gan_mode)
         self.gan_mode, self.real_label, self.fake_label = gan_mode, target_real_label, target_fake_label
 
     def to(self, device):
         return self
 
-    def accumulate(self, preds, target_is_real, coeff, slot, grad_coeff=None, want_grad=True, out_grads=None):
+    def accumulate(self, preds, target_is_real, coeff, slot, grad_coeff=None, want_grad=True, out_grads=None, pre_sigmoid=False):
         """slot += coeff * sum_scales mean_batch(loss); returns [dpred per scale] scaled by grad_coeff (written into out_grads
-        -- e.g. batch slices of one gradient buffer -- when given)."""
+        -- e.g. batch slices of one gradient buffer -- when given).  `preds` are the discriminator's RAW maps; pre_sigmoid: the
+        discriminator ends in a Sigmoid (MultiscaleDiscriminator.use_sigmoid, gan_mode 'vanilla'), applied inside the loss kernel."""
         from vts import ops
 
         grads = []
         label = self.real_label if target_is_real else self.fake_label
+        mode = self.gan_mode
+        if pre_sigmoid:
+            if mode != "vanilla":
+                raise NotImplementedError("a discriminator ending in a Sigmoid is only known with gan_mode 'vanilla'")
+            mode = "vanilla_sigmoid"
         for i, p in enumerate(preds):
             p = p[-1] if isinstance(p, (list, tuple)) else p
             g = (out_grads[i] if out_grads is not None else torch.empty_like(p)) if want_grad else None
-            ops.ganloss(p, self.gan_mode, target_is_real, coeff, slot, g, label=label, grad_coeff=grad_coeff)
+            ops.ganloss(p, mode, target_is_real, coeff, slot, g, label=label, grad_coeff=grad_coeff)
             grads.append(g)
         return grads
 

@@ -549,9 +549,19 @@ class SinSKITGModel(BaseModel):
         self.fake_T = self._full_stack[:, 0:2]
         aug_fake = self._full_stack[:, 3:6] if has_real else None
         rb = rs = None
-        if has_real and opt.use_diffaug:
-            if opt.diffaugment != "bs":
-                raise NotImplementedError("DiffAugment policy '%s' is not built (only 'bs')" % opt.diffaugment)
+        policy = None
+        if has_real and opt.use_diffaug and opt.diffaugment and opt.diffaugment != "bs":
+            # any other policy over the reference's letters b s c t o n (thirdparty/DiffAugment.py:89-96): a chain of single-operation
+            # launches instead of the fused 'bs' pass; the generator's post-processing then leaves aug_fake_I to that chain
+            policy = opt.diffaugment
+            if self._draws is not None and "aug_policy" in self._draws:
+                pdraws = self._draws["aug_policy"]
+            else:       # the reference's order: DiffAugment(real_I) draws first, then DiffAugment(fake_I) (:1330-1333)
+                pdraws = (ops.diffaug_draws(policy, (n, 3, h, w), dev), ops.diffaug_draws(policy, (n, 3, h, w), dev))
+            self.aug_real_I = ops.diffaug_policy(self.real_I, policy, pdraws[0], self.M, torch.empty_like(self.real_I))
+        if policy is not None:
+            pass
+        elif has_real and opt.use_diffaug and opt.diffaugment:
             draws = self._draws["aug"].to(dev).float() if self._draws is not None else torch.rand(4, n, device=dev)
             self._aug = draws
             rb, rs = draws[2].contiguous(), draws[3].contiguous()
@@ -564,8 +574,10 @@ class SinSKITGModel(BaseModel):
             self.aug_real_I = self.real_I
         # (training: the same pass writes the sketch and the mask into their channels of the full-resolution D2 stack)
         ops.g_post(g_out, self.M, opt.scale_nz, rb, rs, fake_I=self.fake_I, fake_T=self.fake_T, fake_N=self.fake_N,
-                   aug_fake_I=aug_fake, S=self.real_S if keep else None, stack_S=self._full_stack[:, 2:3] if keep else None,
-                   stack_M=self._full_stack[:, 6:7] if keep else None)
+                   aug_fake_I=aug_fake if policy is None else None, S=self.real_S if keep else None,
+                   stack_S=self._full_stack[:, 2:3] if keep else None, stack_M=self._full_stack[:, 6:7] if keep else None)
+        if policy is not None:
+            ops.diffaug_policy(self.fake_I.contiguous(), policy, pdraws[1], self.M, aug_fake)
         self.aug_fake_I = aug_fake
         self.fake_gx = self.fake_T[:, 0:1]
         self.fake_gy = self.fake_T[:, 1:2]
@@ -637,7 +649,8 @@ class SinSKITGModel(BaseModel):
     def _d_pass(self, net, in0, in1, target_real, coeff, slot, accumulate, backward=True):
         """One discriminator forward (+ backward into its parameter grads).  Returns preds."""
         preds, ctx = engine.msd_forward(net, in0, in1, keep=backward)
-        dp = self.criterionGAN.accumulate(preds, target_real, coeff, slot, grad_coeff=0.5 * coeff, want_grad=backward)
+        dp = self.criterionGAN.accumulate(preds, target_real, coeff, slot, grad_coeff=0.5 * coeff, want_grad=backward,
+                                          pre_sigmoid=getattr(net, "use_sigmoid", False))
         if backward:
             engine.msd_backward(net, ctx, dp, param_grads=True, accumulate=accumulate)
         return preds
@@ -760,10 +773,15 @@ class SinSKITGModel(BaseModel):
                 self._g_pre_done = True
         heavy = opt.lambda_G1_lpips > 0.0 or opt.lambda_G2_lpips > 0.0      # the perceptual terms: ~90 ms of VGG convolutions
         engine.msd_multi(jobs, self.criterionGAN, extra=extra, extra_cost=90.0 if heavy else 0.1)
+        # (visuals: the maps as the discriminator returns them -- behind its Sigmoid where gan_mode 'vanilla' gives it one)
         if p_fake_I is not None:
             self.pred_fake_I = p_fake_I["preds"][-1][:n]
+            if getattr(self.netD, "use_sigmoid", False):
+                self.pred_fake_I = torch.sigmoid(self.pred_fake_I)
         if p_full is not None:
             self.pred_fake_T_full = p_full["preds"][-1]
+            if getattr(self.netD2, "use_sigmoid", False):
+                self.pred_fake_T_full = torch.sigmoid(self.pred_fake_T_full)
 
     def _d1_pyramid(self, rows, pool_fake):
         """input pyramid of D1 over the first `rows` samples of the pair buffers, or None (engine pools itself).  pool_fake: pool the

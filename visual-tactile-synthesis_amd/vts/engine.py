@@ -1262,7 +1262,8 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, st
                     if want and gc is None:
                         g[gr["n0"]:gr["n1"]].zero_()
                     criterion.accumulate([pred[gr["n0"]:gr["n1"]]], gr["real"], gr["coeff"], gr["slot"], grad_coeff=gc,
-                                         want_grad=gc is not None, out_grads=[g[gr["n0"]:gr["n1"]]] if gc is not None else None)
+                                         want_grad=gc is not None, out_grads=[g[gr["n0"]:gr["n1"]]] if gc is not None else None,
+                                         pre_sigmoid=getattr(D, "use_sigmoid", False))
                 if want:
                     p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
                                                        p.get("input_grad") is not None, cache, gstarts, into=into)
@@ -1270,7 +1271,8 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, st
             if not p.get("loss", True):
                 continue
             gc = p.get("grad_coeff")
-            g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None)[0]
+            g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None,
+                                     pre_sigmoid=getattr(D, "use_sigmoid", False))[0]
             if gc is not None:
                 p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
                                                    p.get("input_grad") is not None, cache, into=into)

@@ -1133,6 +1133,62 @@ def diffaug_bs_mask(x, M, rb, rs, out):
     return out
 
 
+def diffaug_draws(policy, shape, device):
+    """the random numbers DiffAugment(x, policy) consumes (thirdparty/DiffAugment.py:25-80), drawn on the device: one dict per letter
+    (b / s / c: r; t: tx, ty; o: ox, oy; n: sigma, noise) -- the layout of oracle/nets.py:diffaug_draws, which tests pass in instead"""
+    n, c, h, w = shape
+    out = []
+    for letter in policy:
+        if letter in "bsc":
+            out.append({"r": torch.rand(n, device=device)})
+        elif letter == "t":
+            sx, sy = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
+            out.append({"tx": torch.randint(-sx, sx + 1, (n,), device=device), "ty": torch.randint(-sy, sy + 1, (n,), device=device)})
+        elif letter == "o":
+            ch, cw = int(h * 0.5 + 0.5), int(w * 0.5 + 0.5)
+            out.append({"ox": torch.randint(0, h + (1 - ch % 2), (n,), device=device), "oy": torch.randint(0, w + (1 - cw % 2), (n,), device=device)})
+        elif letter == "n":
+            sigma = torch.rand(n, device=device) * 0.1
+            sigma = torch.where(torch.rand(n, device=device) < 0.5, sigma, torch.zeros_like(sigma))
+            out.append({"sigma": sigma, "noise": torch.randn(n, c, h, w, device=device)})
+        else:
+            raise KeyError("DiffAugment policy letter '%s' (the reference knows b s c t o n)" % letter)
+    return out
+
+
+def diffaug_policy(x, policy, draws, M, out):
+    """out <- DiffAugment(x, policy) * M as a chain of vts_diffaug_op launches, one per letter (the mask rides on the last one).
+    x: contiguous [N, C, H, W]; out: [N, C, H, W] with any sample stride (e.g. a channel slice of a stack); draws: diffaug_draws layout"""
+    lib = L.load()
+    n, c, h, w = x.shape
+    dev = x.device
+    assert x.is_contiguous() and out.stride(1) == h * w and out.stride(3) == 1 and len(draws) == len(policy)
+    assert policy, "empty policy: the caller skips the augmentation"
+    cur = x
+    for k, (letter, d) in enumerate(zip(policy, draws)):
+        last = k == len(policy) - 1
+        dst = out if last else torch.empty_like(x)
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+        pf = pi0 = pi1 = noise = ws = None
+        if letter in "bsc":
+            pf = f32(d["r"])
+        elif letter == "t":
+            pi0, pi1 = i32(d["tx"]), i32(d["ty"])
+        elif letter == "o":
+            pi0, pi1 = i32(d["ox"]), i32(d["oy"])
+        elif letter == "n":
+            pf, noise = f32(d["sigma"]), f32(d["noise"])
+        else:
+            raise KeyError("DiffAugment policy letter '%s' (the reference knows b s c t o n)" % letter)
+        if letter == "c":
+            ws = torch.empty(int(lib.vts_diffaug_op_ws_floats(n)), dtype=torch.float32, device=dev)
+        L.check(lib.vts_diffaug_op(cur.data_ptr(), cur.stride(0), dst.data_ptr(), dst.stride(0), n, c, h, w, ord(letter), L.ptr(pf), L.ptr(pi0),
+                                   L.ptr(pi1), L.ptr(noise), L.ptr(M) if last else None, L.ptr(ws), L.stream()), "vts_diffaug_op")
+        cur = dst
+    return out
+
+
 def g_out_grad(d_fake_I, d_fake_T, M, g_out, d_raw):
     lib = L.load()
     n, _, h, w = g_out.shape
