@@ -615,6 +615,13 @@ int vts_copy_words(const void* src, void* dst, int64_t nwords, void* stream);
  * dataset caches from the same PNG pixels (data/singleskit_dataset.py:317-329), so a batch may travel as uint8 (a quarter of the bytes). */
 int vts_u8_expand(const uint8_t* src, int64_t n, int normalize, float* out, void* stream);
 
+/* set_input's image part (reference models/sinskitG_model.py:702-760: real_S = S * M, real_I = I * M on the dataset's tensors) in one pass
+ * over 8-bit sources: S [N,1,HW], I [N,3,HW] (or NULL), M [N,1,HW] (or NULL: no mask) bytes ->
+ *   M_out [N,1,HW] = M / 255 (or NULL), S_out = Normalize(ToTensor(S)) * M, S_out2 = the same again (or NULL; the real rows of the
+ *   discriminator's pair buffer), I_out [N,3,HW] likewise.  Bit-identical to vts_u8_expand followed by vts_mask_mul. */
+int vts_input_images_u8(const uint8_t* S, const uint8_t* I, const uint8_t* M, int N, int64_t HW, float* M_out, float* S_out, float* S_out2,
+                        float* I_out, void* stream);
+
 /* ---- network-level entry (csrc/vts_unet.cpp; SURVEY.md 8b: `vts_unet_fwd`) ------------------------------------------------------------
  * The inference forward of the reference's generator as ONE call, for hosts that are not Python: CustomUnetGenerator.forward
  * (models/networks.py:1430-1645) over Down / Up (thirdparty/unet/unet_parts_custom.py:9-79) -- num_downs x [LeakyReLU(0.2) -> Conv2d(4, 2, 1)

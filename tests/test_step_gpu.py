@@ -811,3 +811,35 @@ def test_uint8_batch_upload_is_bit_identical_to_the_float_batch():
         assert torch.equal(model.real_I.cpu(), (batch["I"] * batch["M"]))
     for n in ("G", "D", "D2"):
         assert torch.equal(flats[0][n], flats[1][n]), n
+
+
+def test_fresh_batch_staging_paths_agree_bit_for_bit(monkeypatch):
+    """set_input's fast paths -- the one-launch image preparation (vts_input_images_u8) and the patch sets travelling on the copy stream
+    into double-buffered staging blocks -- against the plain sequence (u8_expand + mask_mul launches, patch block read on the launch
+    stream): six replayed steps over alternating batches leave identical weights and losses (a staging race would show here)"""
+    from data.synthetic_dataset import make_sample
+
+    batches = [default_collate([make_sample(256, 64, 64, 191 + 2 * k + i, quantize8=True) for i in range(2)]) for k in range(3)]
+    batches = [{k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+    results = []
+    for fused, cs in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("VTS_FUSED_INPUT", fused)
+        monkeypatch.setenv("VTS_PATCH_COPY_STREAM", cs)
+        import random
+        random.seed(7)
+        torch.manual_seed(7)
+        model, opt = make_model(256, 2)
+        load_test_weights(model, 91)
+        for it in range(6):
+            model.set_input(batches[it % 3], phase="train")
+            model.optimize_parameters(epoch=1)
+        torch.cuda.synchronize()
+        results.append(({n: getattr(model, "flat" + n).flat.cpu().clone() for n in ("G", "D", "D2")}, model.get_current_losses(),
+                        model.real_I.cpu().clone(), model.train_set["real_T"].cpu().clone()))
+        b = batches[5 % 3]
+        assert torch.equal(results[-1][2], b["I"] * b["M"])
+    for r in results[1:]:
+        for n in ("G", "D", "D2"):
+            assert torch.equal(results[0][0][n], r[0][n]), n
+        assert results[0][1] == r[1]
+        assert torch.equal(results[0][3], r[3])

@@ -369,6 +369,14 @@ class SinSKITGModel(BaseModel):
                  ("img", torch.from_numpy(np.repeat(np.arange(n, dtype=np.int32), nt)), torch.int32)]
         words = sum((t.numel() + 63) // 64 * 64 for _, t, _ in parts)       # all fields are 4-byte types; 256-byte aligned slots
         dev = self._buf(tag + "_block", (words,), torch.int32)
+        # the pinned block travels on the COPY stream into one of two device staging blocks (the launch stream would otherwise read it over
+        # PCIe, ~ 57 us per patch set, between two steps); the launch stream then copies device -> device into the block the graphs read
+        par = getattr(self, "_stage_parity", 0)
+        stage = self._bufs.get("%s_stage%d" % (tag, par))
+        cs = getattr(self, "_copy_stream", None) if os.environ.get("VTS_PATCH_COPY_STREAM", "1") != "0" else None
+        if cs is not None and (stage is None or stage.numel() != words):
+            stage = self._bufs["%s_stage%d" % (tag, par)] = torch.empty(words, dtype=torch.int32, device=self.device)
+            cs.wait_stream(torch.cuda.current_stream())
         pin = self._pins.get(tag)
         if pin is None or pin.numel() != words:
             pin = self._pins[tag] = torch.empty(words, dtype=torch.int32).pin_memory()
@@ -383,8 +391,22 @@ class SinSKITGModel(BaseModel):
             views[name] = dev[o:o + k].view(dt).view(t.shape)
             o += (k + 63) // 64 * 64
         from vts import lib as L
-        L.check(L.load().vts_copy_words(pin.data_ptr(), dev.data_ptr(), words, L.stream()), "vts_copy_words")   # kernel reads the pinned block
-        self._pin_evt[tag].record()
+        if cs is None:
+            L.check(L.load().vts_copy_words(pin.data_ptr(), dev.data_ptr(), words, L.stream()), "vts_copy_words")   # kernel reads the pinned block
+            self._pin_evt[tag].record()
+        else:
+            if self._stage_done[par] is not None:
+                cs.wait_event(self._stage_done[par])      # the device -> device copy that read this staging block two batches ago
+            with torch.cuda.stream(cs):
+                if os.environ.get("VTS_PATCH_COPY_KERNEL", "0") == "1":
+                    L.check(L.load().vts_copy_words(pin.data_ptr(), stage.data_ptr(), words, L.stream()), "vts_copy_words")
+                else:   # a DMA copy: a kernel on a fifth stream waits for one of the four hardware queues the step's lanes occupy
+                    stage.copy_(pin, non_blocking=True)
+                self._pin_evt[tag].record(cs)
+                evt = torch.cuda.Event()
+                evt.record(cs)
+            torch.cuda.current_stream().wait_event(evt)
+            dev.copy_(stage, non_blocking=True)
         real_T = ops.mask_mul(views["raw"], views["masks"], out=self._buf(tag + "_real_T", views["raw"].shape))
         return dict(real_T=real_T, masks=views["masks"], NT=nt, offx=views["offx"], offy=views["offy"], img=views["img"],
                     coords=np.asarray(T_coords))
@@ -411,7 +433,15 @@ class SinSKITGModel(BaseModel):
                 return ops.u8_expand(raw, normalize, out=f)
             return self._load("%s_%s" % (phase, key), input[key], staged=True)
 
-        S = image("S", True)
+        # the usual training batch (8-bit S / I / M, background mask, [fake | real] pair buffers): ONE launch writes M, both copies of the
+        # masked sketch and the masked real image from the three staged byte tensors (vts_input_images_u8; seven launches otherwise)
+        fused = (u8 and os.environ.get("VTS_FUSED_INPUT", "1") != "0" and self.opt.use_bg_mask and self.isTrain and phase == "train"
+                 and "I" in input and all((k + "_u8") in input for k in ("S", "I", "M")))
+        if fused:
+            rawS, rawI, rawM = (self._load("%s_%s_u8" % (phase, k), input[k + "_u8"], dtype=torch.uint8, staged=True) for k in ("S", "I", "M"))
+            S = rawS
+        else:
+            S = image("S", True)
         n, _, h, w = S.shape
         # The D1 update runs the discriminator on [fake | real] in ONE batched launch per layer (engine.msd_multi, `groups`):
         # sketch and image live in persistent [2n, C, H, W] buffers -- rows [0, n) are the fake pass (S, fake_I written by the
@@ -419,24 +449,32 @@ class SinSKITGModel(BaseModel):
         self._pair = bool(self.isTrain and phase == "train" and "I" in input)
         S2 = self._buf(phase + "_S2", (2 * n if self._pair else n, 1, h, w))
         self.real_S = S2[:n]
-        if self.opt.use_bg_mask:
+        if fused:
+            self.M = self._buf(phase + "_M", tuple(torch.as_tensor(input["M"]).shape))
+            self.M_T = self.M
+            I2 = self._buf(phase + "_I2", (2 * n, 3, h, w))
+            ops.input_images_u8(rawS, rawI, rawM, self.M, S2[:n], S2[n:], I2[n:])
+        elif self.opt.use_bg_mask:
             self.M = self._buf(phase + "_M", tuple(torch.as_tensor(input["M"]).shape))      # read by the captured graphs: persistent; filled from the staging copy
             self.M.copy_(image("M", False))
             ops.mask_mul(S, self.M, out=self.real_S)
             self.M_T = self.M  # nearest resize at multiplier 1 is the identity
         else:
             self.real_S.copy_(S)
-        if self._pair:
+        if self._pair and not fused:
             S2[n:].copy_(self.real_S)
         self._S2 = S2
         if "I" in input:
-            I = image("I", True)
-            I2 = self._buf(phase + "_I2", (2 * n if self._pair else n, 3, h, w))
-            self.real_I = I2[n:] if self._pair else I2
-            if self.opt.use_bg_mask:
-                ops.mask_mul(I, self.M, out=self.real_I)
+            if fused:
+                self.real_I = I2[n:]
             else:
-                self.real_I.copy_(I)
+                I = image("I", True)
+                I2 = self._buf(phase + "_I2", (2 * n if self._pair else n, 3, h, w))
+                self.real_I = I2[n:] if self._pair else I2
+                if self.opt.use_bg_mask:
+                    ops.mask_mul(I, self.M, out=self.real_I)
+                else:
+                    self.real_I.copy_(I)
             self._I2 = I2
             self.full_T_coords = input.get("full_T_coords")
             # Input pyramid of the multiscale D1 (AvgPool2d(3, 2, 1) per level, networks.py:1670,1692): the sketch and real-image levels
@@ -474,12 +512,20 @@ class SinSKITGModel(BaseModel):
             self.train_real_T_concat = self.train_set["real_T"]
             self.train_I_masks = self.train_set["masks"]
             if "val_T_images" in input and len(input["val_T_images"]) > 0:
-                self.val_set = self._patch_set(phase + "_va", input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
+                # only compute_metrics reads the validation patches: in the training phase they are uploaded on first use (the `val_set`
+                # property) instead of with every batch -- a host staging copy, a DMA and two launches per step saved
+                if phase == "train" and os.environ.get("VTS_LAZY_VAL_SET", "1") != "0":
+                    self._val_pending = (phase + "_va", input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
+                else:
+                    self.val_set = self._patch_set(phase + "_va", input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
             elif phase == "test":
                 self.val_set = self.train_set
         if self.isTrain and self.opt.use_more_fakeT and phase == "train":
             # candidate positions of the "more fake T" sampler depend on the mask only: build them here,
             # where the host already synchronises for the H2D copies (model_utils.py:212-216)
+            prev = getattr(self, "_cand_check", None)
+            if prev is not None:
+                torch.cuda.current_stream().wait_event(prev[1])     # (the previous batch's counts have left the buffer this call rewrites)
             self._cand, self._cand_prefix = ops.mask_candidates(
                 self.M, self._buf("cand", (n, h - 14, w - 14), torch.uint8), self._buf("cand_prefix", (n, h - 14 + 1), torch.int32))
             k = self.opt.add_fake_T_sample_size
@@ -491,9 +537,20 @@ class SinSKITGModel(BaseModel):
             pin = self._bufs.get("cand_count_pin")
             if pin is None or pin.numel() != n:
                 pin = self._bufs["cand_count_pin"] = torch.empty(n, dtype=torch.int32).pin_memory()
-            pin.copy_(self._cand_prefix[:, -1], non_blocking=True)
-            evt = torch.cuda.Event()
-            evt.record()
+            if getattr(self, "_copy_stream", None) is not None and os.environ.get("VTS_CAND_COPY_STREAM", "1") != "0":
+                # off the launch stream: a device -> host copy between set_input's kernels and the step's graphs costs the launch stream two
+                # engine switches (~ 0.1 ms of idle device); nothing on the launch stream reads it
+                ready = torch.cuda.Event()
+                ready.record()
+                self._copy_stream.wait_event(ready)
+                with torch.cuda.stream(self._copy_stream):
+                    pin.copy_(self._cand_prefix[:, -1], non_blocking=True)
+                    evt = torch.cuda.Event()
+                    evt.record(self._copy_stream)
+            else:
+                pin.copy_(self._cand_prefix[:, -1], non_blocking=True)
+                evt = torch.cuda.Event()
+                evt.record()
             self._cand_check = (pin, evt, k, self.name)
             self._ranks = self._buf("more_ranks", (n, k), torch.int64)
             mi = self._bufs.get("more_img")          # image index of every extra patch: a constant of (n, k), built on the device once
@@ -504,6 +561,19 @@ class SinSKITGModel(BaseModel):
         done = torch.cuda.Event()
         done.record()        # every reader of this batch's staging buffers has been queued on the launch stream
         self._stage_done[self._stage_parity] = done
+
+    @property
+    def val_set(self):
+        pend = getattr(self, "_val_pending", None)
+        if pend is not None:
+            self._val_pending = None
+            self._val_set = self._patch_set(*pend)
+        return getattr(self, "_val_set", None)
+
+    @val_set.setter
+    def val_set(self, v):
+        self._val_pending = None
+        self._val_set = v
 
     def _check_candidate_counts(self, wait=False):
         """raises like random.sample would have (reference models/model_utils.py:217) when the previous batch's mask had fewer candidate

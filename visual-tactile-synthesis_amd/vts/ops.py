@@ -1206,6 +1206,17 @@ def u8_expand(src, normalize, out=None):
     return out
 
 
+def input_images_u8(S, I, M, M_out, S_out, S_out2, I_out):
+    """set_input's image part in one launch: bytes -> M / 255, Normalize(ToTensor(S)) * M (twice), Normalize(ToTensor(I)) * M; bit-identical
+    to u8_expand + mask_mul"""
+    n, hw = S.shape[0], S.shape[2] * S.shape[3]
+    for t in (S, I, M, M_out, S_out, S_out2, I_out):
+        assert t is None or t.is_contiguous()
+    assert S.dtype == torch.uint8 and (I is None or (I.dtype == torch.uint8 and I.shape[1] == 3)) and S.shape[1] == 1
+    L.check(L.load().vts_input_images_u8(S.data_ptr(), L.ptr(I), L.ptr(M), n, hw, L.ptr(M_out), S_out.data_ptr(), L.ptr(S_out2), L.ptr(I_out),
+                                         L.stream()), "vts_input_images_u8")
+
+
 def mask_mul(x, M, out=None):
     lib = L.load()
     n, c, h, w = x.shape
