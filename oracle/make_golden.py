@@ -448,19 +448,19 @@ def p2p_batch(n, size, seed):
 P2P_FLAGS = ["--model", "pix2pixHD", "--no_vgg_loss", "True", "--ngf", "8", "--ndf", "8", "--n_downsample_global", "3", "--n_blocks_global", "2", "--batch_size", "4"]
 
 
-def golden_p2p_step(size=32, seed=505, n=4, steps=2):
+def golden_p2p_step(size=32, seed=505, n=4, steps=2, extra=(), fname="pix2pixHD_step_%d.npz", n_layers=3):
     """Pix2PixHDModel.optimize_parameters x `steps` on one synthetic patch batch (small G / D so the fixture stays small)."""
     from oracle import detrand, nets, ref_import
 
     ref_import.load()
     import models
-    opt = _ref_opt("pix2pixHD", True, P2P_FLAGS)
+    opt = _ref_opt("pix2pixHD", True, P2P_FLAGS + list(extra))
     opt.checkpoints_dir, opt.name = "/tmp/vts_golden_ckpt", "p2p"
     os.makedirs(os.path.join(opt.checkpoints_dir, opt.name), exist_ok=True)
     model = models.create_model(opt)
     model.setup(opt)
     shG = nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True)
-    shD, shD2 = nets.d_if_param_shapes(4, 8, 2), nets.d_if_param_shapes(3, 8, 2)
+    shD, shD2 = nets.d_if_param_shapes(4, 8, 2, n_layers), nets.d_if_param_shapes(3, 8, 2, n_layers)
     for net, sh in ((model.netG, shG), (model.netD, shD), (model.netD2, shD2)):
         ref = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         assert ref == {k: tuple(v) for k, v in sh.items()}, (sorted(set(ref) ^ set(sh))[:6])
@@ -469,7 +469,7 @@ def golden_p2p_step(size=32, seed=505, n=4, steps=2):
     model.netD2.load_state_dict(detrand.test_weights(shD2, seed + 2))
     model.train()
     batch = p2p_batch(n, size, seed)
-    out = {"size": size, "seed": seed, "n": n, "steps": steps, "flags": np.array(P2P_FLAGS),
+    out = {"size": size, "seed": seed, "n": n, "steps": steps, "flags": np.array(P2P_FLAGS + list(extra)), "n_layers_D": n_layers,
            "lr": opt.lr, "beta1": opt.beta1, "gan_mode": np.array(opt.gan_mode)}
     for it in range(steps):
         model.set_input(batch, phase="train")
@@ -486,8 +486,8 @@ def golden_p2p_step(size=32, seed=505, n=4, steps=2):
                 out["%s/buf_%s/%s" % (tag, nm, kk)] = b.detach().double().numpy()
         out[tag + "/fake_I"] = model.fake_I.detach().numpy()
         out[tag + "/fake_T"] = model.fake_T.detach().numpy()
-    np.savez_compressed(os.path.join(GOLD, "pix2pixHD_step_%d.npz" % size), **out)
-    print("wrote pix2pixHD_step_%d.npz (%d entries)" % (size, len(out)))
+    np.savez_compressed(os.path.join(GOLD, fname % size), **out)
+    print("wrote " + fname % size + " (%d entries)" % len(out))
     print({k: float(v) for k, v in losses.items()})
 
 
@@ -1034,6 +1034,9 @@ if __name__ == "__main__":
         golden_lpips_metrics()
     if "p2pvgg" in which:
         golden_p2p_vgg_step()
+    if "p2pvanilla" in which:
+        # gan_mode 'vanilla' (the discriminators end in a Sigmoid and BCEWithLogits follows, networks.py:1659, 507-509) at PatchGAN depth 2
+        golden_p2p_step(seed=525, steps=1, extra=("--gan_mode", "vanilla", "--n_layers_D", "2"), fname="pix2pixHD_vanilla_step_%d.npz", n_layers=2)
     if "diffaug" in which:
         golden_diffaug()
     if "variants" in which:

@@ -733,31 +733,31 @@ def g_param_shapes(input_nc=9, ngf=10, num_downs=8, num_layer_separate=4, style_
     return shapes
 
 
-def d_if_param_shapes(input_nc, ndf=64, num_D=2):
+def d_if_param_shapes(input_nc, ndf=64, num_D=2, n_layers=3):
     """MultiscaleDiscriminator with getIntermFeat=True (pix2pixHD default `getIntermFeat_D`, networks.py:1661-1667):
     the same layers as d_param_shapes under the keys scale{i}_layer{j}.{0 conv | 1 norm}.*"""
-    ch = [input_nc, ndf, min(2 * ndf, 512), min(4 * ndf, 512), min(8 * ndf, 512), 1]
+    ch = d_channels(input_nc, ndf, n_layers)
     sh = {}
     for i in range(num_D):
-        for j in range(5):
+        for j in range(n_layers + 2):
             k = "scale%d_layer%d." % (i, j)
             sh[k + "0.weight"] = (ch[j + 1], ch[j], 4, 4)
             sh[k + "0.bias"] = (ch[j + 1],)
-            if 1 <= j <= 3:
+            if 1 <= j <= n_layers:
                 for nm, shape in (("weight", (ch[j + 1],)), ("bias", (ch[j + 1],)), ("running_mean", (ch[j + 1],)),
                                   ("running_var", (ch[j + 1],)), ("num_batches_tracked", ())):
                     sh[k + "1." + nm] = shape
     return sh
 
 
-def d_if_to_plain(sd):
+def d_if_to_plain(sd, n_layers=3):
     """scale{i}_layer{j}.{0|1}.x  ->  layer{i}.{conv / norm index of the fused Sequential}.x  (same network)"""
-    conv_idx, bn_idx = (0, 2, 5, 8, 11), {1: 3, 2: 6, 3: 9}
+    conv_idx, bn_of_conv, _ = d_layout(n_layers)
     out = {}
     for k, v in sd.items():
         head, sub, name = k.split(".", 2)
         i, j = int(head[5:head.index("_")]), int(head[head.index("layer") + 5:])
-        out["layer%d.%d.%s" % (i, conv_idx[j] if sub == "0" else bn_idx[j], name)] = v
+        out["layer%d.%d.%s" % (i, conv_idx[j] if sub == "0" else bn_of_conv[conv_idx[j]], name)] = v
     return out
 
 

@@ -284,7 +284,7 @@ def inference(sdG, batch, opt=None, style_code=None):
 # need pretrained weights (off: --no_vgg_loss True).
 # ----------------------------------------------------------------------------
 P2P_HP = dict(lr=2e-4, beta1=0.5, beta2=0.999, gan_mode="lsgan", n_blocks_global=9, n_downsample_global=4, num_D_D1=2, num_D_D2=2,
-              scale_nz=0.25)
+              scale_nz=0.25, n_layers_D=3)
 
 
 def p2p_hp(**kw):
@@ -313,17 +313,22 @@ def p2p_train_step(sdG, sdD, sdD2, adam, batch, opt=None, record=True, vgg_loss=
     channels), None = --no_vgg_loss True."""
     opt = opt or p2p_hp()
     inp = p2p_prepare(batch)
-    pD, pD2 = nets.d_if_to_plain(sdD), nets.d_if_to_plain(sdD2)     # views onto the same tensors
+    nl = getattr(opt, "n_layers_D", 3)
+    pD, pD2 = nets.d_if_to_plain(sdD, nl), nets.d_if_to_plain(sdD2, nl)     # views onto the same tensors
     gl = lambda p, real: nets.gan_loss(p, real, opt.gan_mode)
+    # both discriminators: depth n_layers_D.  No Sigmoid even for gan_mode 'vanilla': with getIntermFeat (this model's key style) the
+    # reference registers only the first n_layers + 2 blocks of NLayerDiscriminator's sequence (networks.py:1664-1666) -- the trailing
+    # [Sigmoid] block is dropped, unlike in the fused `layer<i>` form (:1668) the sinskitG discriminators use
+    dkw = dict(n_layers=nl, use_sigmoid=False)
     _req(sdG, True)
     g_out, fake_I, fake_T = p2p_generator(sdG, inp, opt)
     # ---- D, D2 (one backward for both) ----
     _req(sdD, True)
     _req(sdD2, True)
-    loss_D_fake = gl(nets.msd_forward(pD, torch.cat((inp.real_S, fake_I.detach()), 1), opt.num_D_D1), False)
-    loss_D_real = gl(nets.msd_forward(pD, torch.cat((inp.real_S, inp.real_I), 1), opt.num_D_D1), True)
-    loss_D2_fake = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, fake_T.detach()), 1), opt.num_D_D2), False)
-    loss_D2_real = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, inp.real_T), 1), opt.num_D_D2), True)
+    loss_D_fake = gl(nets.msd_forward(pD, torch.cat((inp.real_S, fake_I.detach()), 1), opt.num_D_D1, **dkw), False)
+    loss_D_real = gl(nets.msd_forward(pD, torch.cat((inp.real_S, inp.real_I), 1), opt.num_D_D1, **dkw), True)
+    loss_D2_fake = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, fake_T.detach()), 1), opt.num_D_D2, **dkw), False)
+    loss_D2_real = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, inp.real_T), 1), opt.num_D_D2, **dkw), True)
     ((loss_D_fake + loss_D_real) * 0.5 + (loss_D2_fake + loss_D2_real) * 0.5).backward()
     out = {}
     if record:
@@ -333,8 +338,8 @@ def p2p_train_step(sdG, sdD, sdD2, adam, batch, opt=None, record=True, vgg_loss=
     _req(sdD, False)
     _req(sdD2, False)
     # ---- G ----
-    loss_G_I = gl(nets.msd_forward(pD, torch.cat((inp.real_S, fake_I), 1), opt.num_D_D1), True)
-    loss_G_T = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, fake_T), 1), opt.num_D_D2), True)
+    loss_G_I = gl(nets.msd_forward(pD, torch.cat((inp.real_S, fake_I), 1), opt.num_D_D1, **dkw), True)
+    loss_G_T = gl(nets.msd_forward(pD2, torch.cat((inp.real_S, fake_T), 1), opt.num_D_D2, **dkw), True)
     loss_vgg_I = loss_vgg_T = torch.zeros(())
     if vgg_loss is not None:
         loss_vgg_I = vgg_loss(fake_I, inp.real_I) * lambda_vgg

@@ -930,3 +930,30 @@ def test_single_channel_weight_gradient(shape):
     ops.wgrad4x4(Act(lo.to(dev)), hi_op, dw, act_hi=act, stride=1, pad=pad, defer=False)
     assert L.load().vts_last_kernel().decode() == "wgrad_head_kernel"
     assert rel(dw, ref) < 3e-6
+
+
+@pytest.mark.parametrize("n,h,w,with_I,with_M", [(2, 64, 64, True, True), (3, 33, 47, True, True), (1, 17, 19, False, True), (2, 40, 24, True, False)])
+def test_input_images_from_bytes_equals_expand_then_mask(n, h, w, with_I, with_M):
+    """vts_input_images_u8 (set_input's image part in one launch, dword-load and generic instances) is bit-identical to
+    vts_u8_expand + vts_mask_mul, i.e. to Normalize(ToTensor(bytes)) * (mask bytes / 255)"""
+    from vts import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    S = torch.randint(0, 256, (n, 1, h, w), generator=g, dtype=torch.uint8)
+    I = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8) if with_I else None
+    M = (torch.randint(0, 2, (n, 1, h, w), generator=g, dtype=torch.uint8) * 255) if with_M else None
+    if with_M:
+        M[0, 0, 0, :5] = torch.tensor([0, 1, 127, 200, 255], dtype=torch.uint8)      # (non-binary mask bytes take the same path)
+    Mo = torch.empty(n, 1, h, w, device=dev) if with_M else None
+    S2 = torch.full((2 * n, 1, h, w), 9.0, device=dev)
+    I2 = torch.full((2 * n, 3, h, w), 9.0, device=dev) if with_I else None
+    ops.input_images_u8(S.to(dev), I.to(dev) if with_I else None, M.to(dev) if with_M else None, Mo, S2[:n], S2[n:], I2[n:] if with_I else None)
+    m = M.float().div(255) if with_M else torch.ones(n, 1, h, w)
+    s_ref = (S.float().div(255) - 0.5) / 0.5 * m
+    assert torch.equal(S2[:n].cpu(), s_ref) and torch.equal(S2[n:].cpu(), s_ref)
+    if with_M:
+        assert torch.equal(Mo.cpu(), m)
+        assert torch.equal(ops.mask_mul(ops.u8_expand(S.to(dev), True), Mo).cpu(), s_ref)
+    if with_I:
+        assert torch.equal(I2[n:].cpu(), (I.float().div(255) - 0.5) / 0.5 * m) and bool((I2[:n] == 9).all())

@@ -183,14 +183,17 @@ def p2p_batch(n, size, seed):
             "augmentation_params": {}}
 
 
-def test_pix2pixHD_step_matches_reference(golden_dir):
-    """oracle.step.p2p_train_step vs two optimize_parameters() of the reference Pix2PixHDModel"""
-    g = _load(golden_dir, "pix2pixHD_step_32.npz")
+@pytest.mark.parametrize("fixture", ["pix2pixHD_step_32.npz", "pix2pixHD_vanilla_step_32.npz"])
+def test_pix2pixHD_step_matches_reference(golden_dir, fixture):
+    """oracle.step.p2p_train_step vs optimize_parameters() of the reference Pix2PixHDModel: the default lsgan / depth-3 discriminators (two
+    steps), and gan_mode 'vanilla' -- the discriminators then end in a Sigmoid that BCEWithLogits is applied to -- at depth 2 (one step)"""
+    g = _load(golden_dir, fixture)
     size, seed, n, steps = int(g["size"]), int(g["seed"]), int(g["n"]), int(g["steps"])
+    nl = int(g["n_layers_D"]) if "n_layers_D" in g.files else 3
     sdG = detrand.test_weights(nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True), seed)
-    sdD, sdD2 = detrand.test_weights(nets.d_if_param_shapes(4, 8, 2), seed + 1), detrand.test_weights(nets.d_if_param_shapes(3, 8, 2), seed + 2)
+    sdD, sdD2 = detrand.test_weights(nets.d_if_param_shapes(4, 8, 2, nl), seed + 1), detrand.test_weights(nets.d_if_param_shapes(3, 8, 2, nl), seed + 2)
     adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
-    opt = step.p2p_hp(n_blocks_global=2, n_downsample_global=3, lr=float(g["lr"]), beta1=float(g["beta1"]))
+    opt = step.p2p_hp(n_blocks_global=2, n_downsample_global=3, lr=float(g["lr"]), beta1=float(g["beta1"]), gan_mode=str(g["gan_mode"]), n_layers_D=nl)
     batch = p2p_batch(n, size, seed)
     for it in range(steps):
         tag = "s%d" % it

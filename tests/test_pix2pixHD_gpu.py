@@ -40,20 +40,23 @@ def make_model(extra=""):
     return model, opt
 
 
-def load_weights(model, seed):
+def load_weights(model, seed, nl=3):
     sds = (detrand.test_weights(nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True), seed),
-           detrand.test_weights(nets.d_if_param_shapes(4, 8, 2), seed + 1), detrand.test_weights(nets.d_if_param_shapes(3, 8, 2), seed + 2))
+           detrand.test_weights(nets.d_if_param_shapes(4, 8, 2, nl), seed + 1), detrand.test_weights(nets.d_if_param_shapes(3, 8, 2, nl), seed + 2))
     for net, sd in zip((model.netG, model.netD, model.netD2), sds):
         assert sorted(net.state_dict().keys()) == sorted(sd.keys())
         net.load_state_dict(sd)
     return sds
 
 
-def test_step_matches_reference_golden(golden_dir):
-    g = np.load(os.path.join(golden_dir, "pix2pixHD_step_32.npz"))
+@pytest.mark.parametrize("fixture,extra", [("pix2pixHD_step_32.npz", ""), ("pix2pixHD_vanilla_step_32.npz", " --gan_mode vanilla --n_layers_D 2")])
+def test_step_matches_reference_golden(golden_dir, fixture, extra):
+    """the reference's own step: default flags, and gan_mode 'vanilla' at PatchGAN depth 2 (no Sigmoid in the getIntermFeat form of the
+    discriminators, whatever gan_mode: MultiscaleDiscriminatorIF)"""
+    g = np.load(os.path.join(golden_dir, fixture))
     size, seed, n = int(g["size"]), int(g["seed"]), int(g["n"])
-    model, opt = make_model(" --use_hip_graph False")
-    sdG, sdD, sdD2 = load_weights(model, seed)
+    model, opt = make_model(" --use_hip_graph False" + extra)
+    sdG, sdD, sdD2 = load_weights(model, seed, int(g["n_layers_D"]) if "n_layers_D" in g.files else 3)
     batch = p2p_batch(n, size, seed)
     model.set_input(batch, phase="train")
     model.optimize_parameters(epoch=1)

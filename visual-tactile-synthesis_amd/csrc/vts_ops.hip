@@ -451,30 +451,56 @@ __global__ __launch_bounds__(256) void u8_expand_kernel(const uint8_t* __restric
 // set_input's image part in one pass over 8-bit sources: M = bytes / 255, S = Normalize(ToTensor(bytes)) * M (written twice: the fake and
 // the real rows of the discriminator's pair buffer), I likewise (real rows).  The same operations in the same order as u8_expand_kernel +
 // mask_mul_kernel (bit-identical), 5 bytes read and 24 written per pixel instead of seven launches.
+template <bool VEC>
 __global__ __launch_bounds__(256) void input_images_u8_kernel(const uint8_t* __restrict__ S, const uint8_t* __restrict__ I, const uint8_t* __restrict__ Mb,
                                                               int64_t HW, float* __restrict__ Mo, float* __restrict__ So, float* __restrict__ So2,
                                                               float* __restrict__ Io) {
   const int n = blockIdx.y;
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= HW) return;
-  const int cnt = (int)min((int64_t)4, HW - i);
-  float m[4];
+  const int cnt = VEC ? 4 : (int)min((int64_t)4, HW - i);
+  auto bytes = [&](const uint8_t* p, uint8_t (&b)[4]) {      // VEC: HW % 4 == 0 and 4-byte aligned planes -> one dword load
+    if (VEC) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+      b[0] = w & 255u; b[1] = (w >> 8) & 255u; b[2] = (w >> 16) & 255u; b[3] = w >> 24;
+    } else {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j < cnt) {
-      m[j] = Mb ? __fdiv_rn((float)Mb[n * HW + i + j], 255.f) : 1.f;
-      if (Mo) Mo[n * HW + i + j] = m[j];
-      const float s = __fdiv_rn(__fsub_rn(__fdiv_rn((float)S[n * HW + i + j], 255.f), 0.5f), 0.5f) * m[j];
-      So[n * HW + i + j] = s;
-      if (So2) So2[n * HW + i + j] = s;
+      for (int j = 0; j < 4; ++j) b[j] = j < cnt ? p[j] : 0;
     }
-  }
-  if (I) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
+  };
+  auto store = [&](float* p, const float (&v)[4]) {
+    if (VEC) {
+      *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (j < cnt) Io[(n * 3 + c) * HW + i + j] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)I[(n * 3 + c) * HW + i + j], 255.f), 0.5f), 0.5f) * m[j];
+        if (j < cnt) p[j] = v[j];
+    }
+  };
+  uint8_t b[4];
+  float m[4], v[4];
+  if (Mb) {
+    bytes(Mb + n * HW + i, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = __fdiv_rn((float)b[j], 255.f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = 1.f;
+  }
+  if (Mo) store(Mo + n * HW + i, m);
+  bytes(S + n * HW + i, b);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)b[j], 255.f), 0.5f), 0.5f) * m[j];
+  store(So + n * HW + i, v);
+  if (So2) store(So2 + n * HW + i, v);
+  if (I) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      bytes(I + (n * 3 + c) * HW + i, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)b[j], 255.f), 0.5f), 0.5f) * m[j];
+      store(Io + (n * 3 + c) * HW + i, v);
+    }
   }
 }
 
@@ -875,8 +901,15 @@ extern "C" int vts_u8_expand(const uint8_t* src, int64_t n, int normalize, float
 extern "C" int vts_input_images_u8(const uint8_t* S, const uint8_t* I, const uint8_t* M, int N, int64_t HW, float* M_out, float* S_out,
                                    float* S_out2, float* I_out, void* stream) {
   VTS_CHECK_ARG(S && S_out && N >= 1 && HW >= 1 && (!I || I_out) && (!M_out || M), "vts_input_images_u8: bad args");
-  hipLaunchKernelGGL(input_images_u8_kernel, dim3((unsigned)cdiv64(HW, 1024), N), dim3(256), 0, (hipStream_t)stream, S, I, M, HW, M_out, S_out,
-                     S_out2, I_out);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(I) | reinterpret_cast<uintptr_t>(M);
+  const uintptr_t al16 = reinterpret_cast<uintptr_t>(M_out) | reinterpret_cast<uintptr_t>(S_out) | reinterpret_cast<uintptr_t>(S_out2) |
+                         reinterpret_cast<uintptr_t>(I_out);
+  if (HW % 4 == 0 && (al & 3) == 0 && (al16 & 15) == 0)
+    hipLaunchKernelGGL(input_images_u8_kernel<true>, dim3((unsigned)cdiv64(HW, 1024), N), dim3(256), 0, (hipStream_t)stream, S, I, M, HW, M_out,
+                       S_out, S_out2, I_out);
+  else
+    hipLaunchKernelGGL(input_images_u8_kernel<false>, dim3((unsigned)cdiv64(HW, 1024), N), dim3(256), 0, (hipStream_t)stream, S, I, M, HW, M_out,
+                       S_out, S_out2, I_out);
   VTS_CHECK_LAUNCH("vts_input_images_u8");
   return VTS_OK;
 }

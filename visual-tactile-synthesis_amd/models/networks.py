@@ -394,7 +394,9 @@ class MultiscaleDiscriminatorIF(MultiscaleDiscriminator):
         if n_layers < 1:
             raise ValueError("MultiscaleDiscriminator: n_layers must be >= 1")
         self.input_nc, self.ndf, self.num_D, self.n_layers = input_nc, ndf, num_D, n_layers
-        self.use_sigmoid = getattr(opt, "gan_mode", None) == "vanilla"
+        # no Sigmoid in this form, whatever gan_mode: the reference registers only the first n_layers + 2 blocks of the PatchGAN's
+        # sequence as scale<d>_layer<j> (networks.py:1664-1666), which leaves the trailing [Sigmoid] block of 'vanilla' mode out
+        self.use_sigmoid = False
         self.CONV_IDX, self.BN_IDX, self.STRIDE = _patchgan_layout(n_layers)
         chans = _patchgan_channels(input_nc, ndf, n_layers)
         self.chans = chans
