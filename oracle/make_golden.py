@@ -146,6 +146,31 @@ def golden_patchsample():
     print("wrote patchsample.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def golden_patchsample_whole():
+    """PatchSampleF with num_patches = 0 (the whole map; its Normalize then runs over the positions): with and without the MLP"""
+    from oracle import detrand, ref_import
+
+    ref_import.load()
+    from models import networks
+
+    out = {}
+    feats = [detrand.uniform((2, 6, 5, 7), 51, "f0"), detrand.uniform((3, 10, 4, 4), 51, "f1")]
+    fo, ids = networks.PatchSampleF(use_mlp=False, gpu_ids=[])(feats, 0, None)
+    assert ids == [[], []]
+    out["plain0"], out["plain1"] = fo[0].numpy(), fo[1].numpy()
+    torch.manual_seed(19)
+    mlp = networks.PatchSampleF(use_mlp=True, init_type="normal", init_gain=0.02, nc=12, gpu_ids=[])
+    with torch.no_grad():
+        fm, _ = mlp(feats, 0, None)
+    for i in range(2):
+        m = getattr(mlp, "mlp_%d" % i)
+        out["mlp%d_w0" % i], out["mlp%d_b0" % i] = m[0].weight.detach().numpy(), m[0].bias.detach().numpy()
+        out["mlp%d_w2" % i], out["mlp%d_b2" % i] = m[2].weight.detach().numpy(), m[2].bias.detach().numpy()
+    out["mlp0"], out["mlp1"] = fm[0].numpy(), fm[1].numpy()
+    np.savez_compressed(os.path.join(GOLD, "patchsample_whole.npz"), **out)
+    print("wrote patchsample_whole.npz", {k: v.shape for k, v in out.items()})
+
+
 def golden_ops():
     """Operator-level vectors: SPE, DiffAugment, GANLoss (all modes), PatchNCE, patch gather, normals."""
     from oracle import detrand, ref_import
@@ -868,6 +893,8 @@ VARIANTS = {
     "hinge_depth_4_2": ["--gan_mode", "hinge", "--n_layers_D", "4", "--n_layers_D2", "2"],
     # DiffAugment policy with every letter (row a15)
     "diffaug_all": ["--diffaugment", "bsctno"],
+    # Dropout(0.5) in the intermediate Up blocks of the generator (row a4; the draws replay: nets.dropout_draws, then DiffAugment's)
+    "dropout": ["--no_dropout", "False"],
 }
 
 
@@ -898,6 +925,8 @@ def golden_step_variants(size=256, seed=232, nt=64):
         model.set_input(batch, phase="train")
         k = int(nets.dilated_mask_positions(model.M).shape[0])
         torch.manual_seed(seed + vi)
+        if not opt.no_dropout:
+            nets.dropout_draws((1, size, size))      # the generator forward consumes its dropout masks first
         if opt.diffaugment == "bs":
             aug = torch.stack([torch.rand(1, 1, 1, 1).flatten() for _ in range(4)])
         else:
@@ -996,6 +1025,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step", "style", "io"]
     if "patchsample" in which:
         golden_patchsample()
+    if "patchsamplewhole" in which:
+        golden_patchsample_whole()
     if "ops" in which:
         golden_ops()
     if "nets" in which:

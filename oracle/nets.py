@@ -270,9 +270,21 @@ def adain(content, style, eps=1e-5):
     return (content - cm) / cs * ss + sm
 
 
+def dropout_draws(shape_n_h_w, ngf=10, num_downs=8):
+    """keep masks of the Up-block dropouts (--no_dropout False: Dropout(0.5) behind the InstanceNorm of up<num_downs-2> .. up<num_downs//2>,
+    networks.py:1508-1519, unet_parts_custom.py:66-67) drawn from torch's global generator as F.dropout draws them on the CPU
+    (`empty_like(x).bernoulli_(1 - p)`), in forward order: {layer: [N, 8 ngf, h, w] of 0 / 1}"""
+    n, h, w = shape_n_h_w
+    out = {}
+    for i in range(num_downs - 2, num_downs // 2 - 1, -1):
+        out[i] = torch.empty(n, ngf * 8, h >> i, w >> i).bernoulli_(0.5)
+    return out
+
+
 def unet_forward(sd, x, num_downs=8, num_layer_separate=4, style_code=None, num_layer_style_code=1,
-                 return_feats=False, style_mode="concat", style_mapping="tile"):
-    """CustomUnetGenerator.forward (networks.py:1576-1645), instance norm; style code concat / adain x tile / project (:1600-1632)"""
+                 return_feats=False, style_mode="concat", style_mapping="tile", dropout_masks=None):
+    """CustomUnetGenerator.forward (networks.py:1576-1645), instance norm; style code concat / adain x tile / project (:1600-1632);
+    dropout_masks: {layer: keep mask} of the train-mode Dropout(0.5) behind the norm of the intermediate Up blocks (dropout_draws)"""
     feats = []
     for i in range(num_downs):
         key = "down%d.model.%d" % (i, 0 if i == 0 else 1)
@@ -307,7 +319,12 @@ def unet_forward(sd, x, num_downs=8, num_layer_separate=4, style_code=None, num_
                 z = torch.cat([inp, skip], 1)
             z = F.relu(z)
             z = F.conv_transpose2d(z, sd[name + ".model.1.weight"], sd[name + ".model.1.bias"], stride=2, padding=1)
-            return torch.tanh(z) if i == 0 else _inorm(z)
+            if i == 0:
+                return torch.tanh(z)
+            z = _inorm(z)
+            if dropout_masks is not None and i in dropout_masks and not name.endswith("_T"):
+                z = z * dropout_masks[i] / 0.5
+            return z
 
         if num_layer_separate >= i + 1:
             if x_t is None:
@@ -663,9 +680,20 @@ def patchnce_loss(feat_q, feat_k, batch_size, nce_T=0.07, all_negatives_from_min
 
 def patch_sample_f(feats, patch_ids, mlps=None):
     """PatchSampleF.forward with given ids (networks.py:687-719): feats list of [B, C, H, W]; mlps: None or a list of
-    (w0 [nc, C], b0, w2 [nc, nc], b2) per feature map.  Returns the list of L2-normalised [B * P, C | nc] rows."""
+    (w0 [nc, C], b0, w2 [nc, nc], b2) per feature map.  Returns the list of L2-normalised [B * P, C | nc] rows.
+    patch_ids None = num_patches 0: the whole map stays [B, HW, C] through the MLP, Normalize(2) then divides by the norm over dim 1
+    -- the positions -- and the result is reshaped to [B, C | nc, H, W] (:704-706, 713-717)."""
     outs = []
     for i, feat in enumerate(feats):
+        if patch_ids is None:
+            b, _, h, w = feat.shape
+            x = feat.permute(0, 2, 3, 1).flatten(1, 2)
+            if mlps is not None:
+                w0, b0, w2, b2 = mlps[i]
+                x = F.linear(F.relu(F.linear(x, w0, b0)), w2, b2)
+            x = l2_normalize(x)
+            outs.append(x.permute(0, 2, 1).reshape(b, x.shape[-1], h, w))
+            continue
         x = feat.permute(0, 2, 3, 1).flatten(1, 2)[:, torch.as_tensor(patch_ids[i], dtype=torch.long), :].flatten(0, 1)
         if mlps is not None:
             w0, b0, w2, b2 = mlps[i]

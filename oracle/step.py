@@ -69,12 +69,12 @@ def _gather_all(img, coords):
     return torch.cat(outs, 0)
 
 
-def generator_forward(sdG, inp, opt, style_code=None):
+def generator_forward(sdG, inp, opt, style_code=None, dropout_masks=None):
     netG = getattr(opt, "netG", "unet256_custom")
     if netG.startswith("resnet_"):   # --netG resnet_{4,6,9}blocks (sinskitG_model.py:509-520 -> networks.define_G)
         out = nets.resnet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), n_blocks=int(netG[len("resnet_")]))
     else:
-        out = nets.unet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), style_code=style_code)
+        out = nets.unet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), style_code=style_code, dropout_masks=dropout_masks)
     fake_I = out[:, 0:3] * inp.M
     fake_T = out[:, -2:] * inp.M
     return out, fake_I, fake_T
@@ -152,7 +152,7 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     _req(sdG, True)
     _req(sdD, False)
     _req(sdD2, False)
-    g_out, fake_I, fake_T = generator_forward(sdG, inp, opt, style_code)
+    g_out, fake_I, fake_T = generator_forward(sdG, inp, opt, style_code, dropout_masks=draws.get("dropout"))
     if opt.use_diffaug and "aug_policy" in draws:
         # any policy over b / s / c / t / o / n: draws["aug_policy"] = (nets.diffaug_draws for real_I, then for fake_I) (:1330-1333)
         pol = getattr(opt, "diffaugment", "bs")

@@ -957,3 +957,27 @@ def test_input_images_from_bytes_equals_expand_then_mask(n, h, w, with_I, with_M
         assert torch.equal(ops.mask_mul(ops.u8_expand(S.to(dev), True), Mo).cpu(), s_ref)
     if with_I:
         assert torch.equal(I2[n:].cpu(), (I.float().div(255) - 0.5) / 0.5 * m) and bool((I2[:n] == 9).all())
+
+
+def test_patchsample_whole_map_matches_reference(golden_dir):
+    """PatchSampleF(num_patches=0) on the HIP path against the reference module's outputs (tests/golden/patchsample_whole.npz): every
+    position gathered, the MLP on the rows, the norm over the positions of each (image, channel), NCHW result, empty id lists"""
+    import os
+
+    from models.networks import PatchSampleF
+
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "patchsample_whole.npz"))
+    fd = [detrand.uniform((2, 6, 5, 7), 51, "f0").to(dev), detrand.uniform((3, 10, 4, 4), 51, "f1").to(dev)]
+    plain, ids = PatchSampleF(use_mlp=False)(fd, 0, None)
+    assert ids == [[], []] and plain[0].shape == (2, 6, 5, 7) and plain[1].shape == (3, 10, 4, 4)
+    assert rel(plain[0], torch.from_numpy(g["plain0"])) < 1e-6 and rel(plain[1], torch.from_numpy(g["plain1"])) < 1e-6
+    f = PatchSampleF(use_mlp=True, nc=12)
+    f.create_mlp(fd)
+    for i in range(2):
+        m = getattr(f, "mlp_%d" % i)
+        for idx, (kw, kb) in ((0, ("w0", "b0")), (2, ("w2", "b2"))):
+            m[idx].weight.data.copy_(torch.from_numpy(g["mlp%d_%s" % (i, kw)]))
+            m[idx].bias.data.copy_(torch.from_numpy(g["mlp%d_%s" % (i, kb)]))
+    fm, _ = f(fd, 0, None)
+    assert fm[0].shape == (2, 12, 5, 7) and rel(fm[0], torch.from_numpy(g["mlp0"])) < 1e-5 and rel(fm[1], torch.from_numpy(g["mlp1"])) < 1e-5

@@ -331,16 +331,18 @@ def _variant_opt(extra):
     kw = {}
     for k, v in zip(extra[::2], extra[1::2]):
         k = k.lstrip("-")
-        kw[k] = int(v) if k.startswith("n_layers") else v
+        kw[k] = int(v) if k.startswith("n_layers") else (v == "True") if v in ("True", "False") else v
     return step.hp(**kw)
 
 
 def _variant_draws(g, name, opt, seed, vi, size):
     draws = {"more_idx": torch.from_numpy(g[name + "/more_idx"])}
+    torch.manual_seed(seed + vi)     # the reference seeds torch's generator with seed + vi in front of the step
+    if not getattr(opt, "no_dropout", True):
+        draws["dropout"] = nets.dropout_draws((1, size, size))       # the generator forward draws first
     if opt.diffaugment == "bs":
         draws["aug"] = torch.from_numpy(g[name + "/aug"])
-    else:       # the reference seeds torch's generator with seed + vi in front of the step: DiffAugment(real_I), then DiffAugment(fake_I)
-        torch.manual_seed(seed + vi)
+    else:       # DiffAugment(real_I), then DiffAugment(fake_I)
         draws["aug_policy"] = (nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)), nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)))
     return draws
 
@@ -398,6 +400,19 @@ def test_diffaugment_policies_match_reference(golden_dir):
             else:
                 _close(y[:, :, ::3, ::3].numpy(), g[tag + "/out_sub"], rtol=0, atol=2e-7)
                 _probe_close(y, g[tag + "/out_probe"], "out")
+
+
+def test_patchsample_whole_map_matches_reference(golden_dir):
+    """PatchSampleF with num_patches = 0: the whole map, normalised over the positions (the reference's 3-D Normalize quirk)"""
+    g = _load(golden_dir, "patchsample_whole.npz")
+    feats = [detrand.uniform((2, 6, 5, 7), 51, "f0"), detrand.uniform((3, 10, 4, 4), 51, "f1")]
+    plain = nets.patch_sample_f(feats, None)
+    _close(plain[0].numpy(), g["plain0"], rtol=1e-6, atol=1e-7)
+    _close(plain[1].numpy(), g["plain1"], rtol=1e-6, atol=1e-7)
+    mlps = [tuple(torch.from_numpy(g["mlp%d_%s" % (i, k)]) for k in ("w0", "b0", "w2", "b2")) for i in range(2)]
+    fm = nets.patch_sample_f(feats, None, mlps)
+    _close(fm[0].numpy(), g["mlp0"], rtol=1e-5, atol=1e-7)
+    _close(fm[1].numpy(), g["mlp1"], rtol=1e-5, atol=1e-7)
 
 
 def test_option_fixture_is_reference_dump(golden_dir):

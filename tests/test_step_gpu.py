@@ -144,10 +144,12 @@ def test_step_variants_match_reference_golden(golden_dir):
             assert list(net.state_dict().keys()) == list(sd.keys()), name
             net.load_state_dict(sd)
         model._draws = {"more_idx": torch.from_numpy(g[name + "/more_idx"])}
+        torch.manual_seed(seed + vi)
+        if not opt.no_dropout:
+            model._draws["dropout"] = nets.dropout_draws((1, size, size))
         if opt.diffaugment == "bs":
             model._draws["aug"] = torch.from_numpy(g[name + "/aug"])
         else:
-            torch.manual_seed(seed + vi)
             model._draws["aug_policy"] = (nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)), nets.diffaug_draws(opt.diffaugment, (1, 3, size, size)))
         model.set_input(default_collate([make_sample(size, nt, nt, seed + 10 * vi)]), phase="train")
         model.optimize_parameters(epoch=1)

@@ -35,6 +35,8 @@ CASES = [
     ("sinskitG vanilla D depth 5", "--model sinskitG --crop_size 512 --batch_size 1 --gan_mode vanilla --n_layers_D 5", 512, 1),
     ("sinskitG diffaugment bsctno", "--model sinskitG --crop_size 256 --batch_size 2 --diffaugment bsctno", 256, 2),
     ("skitG 1024 b4 diffaugment cto", "--model skitG --crop_size 1024 --batch_size 4 --diffaugment cto", 1024, 4),
+    ("sinskitG Up-block dropout", "--model sinskitG --crop_size 256 --batch_size 2 --no_dropout False", 256, 2),
+    ("skitG 1024 b4 Up-block dropout", "--model skitG --crop_size 1024 --batch_size 4 --no_dropout False", 1024, 4),
     ("sinskitG 200 steps + lr decay", "--model sinskitG --crop_size 256 --batch_size 1", 256, 1),
 ]
 

@@ -76,11 +76,17 @@ class CustomUnetGenerator(nn.Module):
     """U-Net with dual visual / tactile decoders (reference: networks.py:1430-1645,
     thirdparty/unet/unet_parts_custom.py:9-79).  InstanceNorm only (the hot-path default)."""
 
-    def __init__(self, input_nc, output_nc, num_downs=8, ngf=64, num_layer_separate=0, opt=None):
+    def __init__(self, input_nc, output_nc, num_downs=8, ngf=64, num_layer_separate=0, opt=None, use_dropout=False):
         super().__init__()
         assert output_nc == 5, "current architecture is designed specifically for 5 output channels, 3 - RGB, 2 - touch"
         assert 0 <= num_layer_separate <= num_downs
         self.input_nc, self.num_downs, self.ngf, self.num_layer_separate = input_nc, num_downs, ngf, num_layer_separate
+        # Dropout(0.5) behind the InstanceNorm of the intermediate Up blocks up<num_downs // 2> .. up<num_downs - 2> (reference
+        # networks.py:1508-1519 -> unet_parts_custom.py:66-67), active in train() mode only.  Built for the shared trunk (the blocks
+        # that have no `_T` twin: num_layer_separate <= num_downs // 2, the reference's default 4 of 8).
+        self.use_dropout = bool(use_dropout)
+        if self.use_dropout and num_layer_separate > num_downs // 2:
+            raise NotImplementedError("Up-block dropout with num_layer_separate > num_downs // 2 (dropout inside the separate decoders)")
         self.opt = opt
         use_style = bool(opt is not None and getattr(opt, "use_style_code", False))
         self.use_style = use_style
@@ -489,10 +495,9 @@ def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, in
                               down="stride" if no_antialias else "blur", up="convT" if no_antialias_up else "blur", opt=opt)
     elif norm != "instance":
         raise NotImplementedError("unet256_custom is built for normG=instance only")
-    elif use_dropout:
-        raise NotImplementedError("unet256_custom: Dropout(0.5) in the Up blocks (--no_dropout False) is not built; pass --no_dropout True")
     else:
-        net = CustomUnetGenerator(input_nc, output_nc, num_downs=8, ngf=ngf, num_layer_separate=num_layer_separate, opt=opt)
+        net = CustomUnetGenerator(input_nc, output_nc, num_downs=8, ngf=ngf, num_layer_separate=num_layer_separate, opt=opt,
+                                  use_dropout=use_dropout)
     return init_net(net, init_type, init_gain, gpu_ids)
 
 
@@ -578,7 +583,7 @@ class PatchSampleF(nn.Module):
     [B * P, C] (vts_patch_sample), optionally run the 2-layer MLP Linear(C, nc) - ReLU - Linear(nc, nc) (vts_linear_rows; created on
     first use and initialised like the reference: init_net normal / 0.02, bias 0), L2-normalise the rows (vts_l2norm_rows).
     state_dict keys match the reference's (mlp_<i>.0.weight, mlp_<i>.0.bias, mlp_<i>.2.weight, mlp_<i>.2.bias).
-    num_patches == 0 (whole map, reshaped back to NCHW) is not built."""
+    num_patches == 0: the whole map, normalised over the positions of each (image, channel) and reshaped back to NCHW like the reference."""
 
     def __init__(self, use_mlp=False, init_type="normal", init_gain=0.02, nc=256, gpu_ids=()):
         super().__init__()
@@ -605,14 +610,17 @@ class PatchSampleF(nn.Module):
 
         from vts import ops
 
-        if num_patches <= 0:
-            raise NotImplementedError("PatchSampleF with num_patches = 0 (whole feature map) is not built")
+        if num_patches < 0:
+            raise ValueError("PatchSampleF: num_patches must be >= 0")
         if self.use_mlp and not self.mlp_init:
             self.create_mlp(feats)
         return_ids, return_feats = [], []
         for feat_id, feat in enumerate(feats):
-            hw = feat.shape[2] * feat.shape[3]
-            if patch_ids is not None:
+            b, _, fh, fw = feat.shape
+            hw = fh * fw
+            if num_patches == 0:        # the whole map (networks.py:704-706): every position, no ids returned
+                patch_id = torch.arange(hw, dtype=torch.long, device=feat.device)
+            elif patch_ids is not None:
                 patch_id = patch_ids[feat_id]
             else:
                 patch_id = np.random.permutation(hw)
@@ -623,6 +631,14 @@ class PatchSampleF(nn.Module):
                 mlp = getattr(self, "mlp_%d" % feat_id)
                 x = ops.linear_rows(x, mlp[0].weight, mlp[0].bias, relu=True)
                 x = ops.linear_rows(x, mlp[2].weight, mlp[2].bias)
+            if num_patches == 0:
+                # the reference keeps the rows 3-D here ([B, HW, C]), so its Normalize(2) sums over dim 1 = the POSITIONS of each
+                # (image, channel), and then reshapes back to [B, C, H, W] (networks.py:713-717): rows = (image, channel) over HW
+                c = x.shape[1]
+                rows = x.view(b, hw, c).permute(0, 2, 1).contiguous().view(b * c, hw)
+                return_ids.append([])
+                return_feats.append(ops.l2norm_rows(rows).view(b, c, fh, fw))
+                continue
             return_ids.append(patch_id)
             return_feats.append(ops.l2norm_rows(x))
         return return_feats, return_ids

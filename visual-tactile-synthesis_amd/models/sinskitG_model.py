@@ -609,7 +609,8 @@ class SinSKITGModel(BaseModel):
                                                            style_tiles=getattr(self, "_style_tiles", None)), None
         else:
             g_out, self._g_ctx = engine.unet_forward(self.netG, self._g_input(), style_code=self._style(), keep=keep,
-                                                     style_tiles=getattr(self, "_style_tiles", None))
+                                                     style_tiles=getattr(self, "_style_tiles", None),
+                                                     dropout_masks=self._draws.get("dropout") if self._draws is not None else None)
         self.g_out = g_out
         has_real = hasattr(self, "real_I") and not self.test_edit_S
         self.fake_I = self._I2[:n] if (has_real and getattr(self, "_pair", False)) else torch.empty(n, 3, h, w, device=dev)

@@ -40,11 +40,21 @@ class UnetCtx:
     __slots__ = ("x", "feats", "ups", "g_out", "style", "style_ctx", "adain_in", "dstyle")
 
 
-def unet_forward(G, x, style_code=None, keep=True, style_tiles=None):
+def dropout_layers(G):
+    """the Up blocks that end in Dropout(0.5) when the generator was built with use_dropout (reference networks.py:1508-1519), in the
+    order the forward visits them"""
+    if not getattr(G, "use_dropout", False):
+        return []
+    return list(range(G.num_downs - 2, G.num_downs // 2 - 1, -1))
+
+
+def unet_forward(G, x, style_code=None, keep=True, style_tiles=None, dropout_masks=None):
     """x: [N, input_nc, H, W] tensor / Act, or a pair (x0, x1) that is concatenated on load
     (sketch ++ positional grid).  Returns (g_out [N,5,H,W] post-tanh, ctx).
     style_tiles: {layer index: [N, style_dim, h, w]} the tiled style code when the caller holds it (it depends on the batch only: the
-    model tiles it once per set_input instead of once per step)"""
+    model tiles it once per set_input instead of once per step)
+    dropout_masks: {layer index: keep mask [N, C, h, w] of 0 / 1} for the Up blocks of dropout_layers(G) in train() mode (drawn here with
+    torch.bernoulli when absent; tests pass the reference's draws)"""
     if isinstance(x, (tuple, list)):
         x, x_extra = _as_act(x[0]), _as_act(x[1])
     else:
@@ -92,6 +102,8 @@ def unet_forward(G, x, style_code=None, keep=True, style_tiles=None):
                 else:
                     style_ctx[i] += (smap,)
 
+    drop_layers = dropout_layers(G) if G.training else []
+
     def up(i, name, inp):
         hh, ww = h >> (i + 1), w >> (i + 1)
         skip = None if i in (0, nd - 1) else feats[i]
@@ -106,7 +118,20 @@ def unet_forward(G, x, style_code=None, keep=True, style_tiles=None):
         r = ops.conv4x4(inp, blk.weight, 16, outer * 16, outer, out, in1=skip if skip is not None else extra, bias=blk.bias,
                         stride=2, pad=1, transposed=True, act_in=RELU, act_out=TANH if i == 0 else 0, instance_norm=i != 0)
         res = Act(out) if i == 0 else r
-        ups[name] = (inp, res, extra)
+        drop = None
+        if i in drop_layers:
+            # Dropout(0.5) behind the InstanceNorm: the normalised map is materialised, multiplied by keep * 2 (tiny maps: 80 channels at
+            # <= 1/16 of the resolution), and the next block reads it as a plain tensor; the backward multiplies by the same map
+            keep2 = dropout_masks.get(i) if dropout_masks is not None else None
+            if keep2 is None:
+                keep2 = torch.bernoulli(torch.full(out.shape, 0.5, device=dev))
+            keep2 = (keep2.to(device=dev, dtype=torch.float32) * 2.0).contiguous()
+            y = ops.pad_affine(r, (0, 0, 0, 0), 0)
+            yd = torch.empty_like(y)
+            ops.mask_mul(y.view(-1, 1, y.shape[2], y.shape[3]), keep2.view(-1, 1, y.shape[2], y.shape[3]), out=yd.view(-1, 1, y.shape[2], y.shape[3]))
+            drop = (r, keep2)
+            res = Act(yd)
+        ups[name] = (inp, res, extra, drop)
         return res
 
     nls = G.num_layer_separate
@@ -174,6 +199,8 @@ UNET_C = os.environ.get("VTS_UNET_C", "1") != "0"     # inference forward throug
 def unet_c_ok(G, style_code):
     """can vts_unet_forward run this generator's inference forward?  (plain U-Net, or the style code tiled into the innermost block)"""
     if not UNET_C or G.num_downs > L.UNET_MAX_DOWNS:
+        return False
+    if G.training and dropout_layers(G):     # a forward outside eval() keeps the Dropout of the Up blocks active
         return False
     if style_code is None:
         return True
@@ -321,19 +348,31 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
         store[key] = t
         return t, False
 
+    dropped = {id(v[1]) for v in ctx.ups.values() if v[3] is not None}
+
+    def dropped_input(inp):
+        """the block's primary input is a Dropout output: its gradient is not yet the gradient of a normalised map (no fused sums)"""
+        return id(inp) in dropped
+
     def up_bwd(i, name, dx, dfeat, wq, lane_mode=False):
         """backward of one up block: weight gradient (through wq: side queue, or inline inside a lane), gradient w.r.t.
         the block input into dx / dfeat[nd-1], gradient w.r.t. the skip feature into dfeat[i]"""
         skip = None if i in (0, nd - 1) else feats[i]
         blk = getattr(G, name).conv
-        inp, outp, extra = ctx.ups[name]
+        inp, outp, extra, drop = ctx.ups[name]
         outer = blk.weight.shape[1]
         if i == 0:
             c0 = 0 if name == "up0" else 3
             g = d_raw[:, c0:c0 + outer]  # channel-slice view: batch stride stays 5*H*W
         else:
             g = dx.pop(id(outp))
-            ops.norm_bwd(g, outp, 0)
+            if drop is not None:     # Dropout backward: the same keep * 2 map, then the InstanceNorm backward on the block's own statistics
+                gd = torch.empty_like(g)
+                ops.mask_mul(g.view(-1, 1, g.shape[2], g.shape[3]), drop[1].view(-1, 1, g.shape[2], g.shape[3]), out=gd.view(-1, 1, g.shape[2], g.shape[3]))
+                g = gd
+                ops.norm_bwd(g, drop[0], 0)
+            else:
+                ops.norm_bwd(g, outp, 0)
         gop = Act(g)
         second = skip if skip is not None else extra
         wq(lambda: ops.wgrad4x4(inp, gop, blk.weight.grad, lo1=second, act_lo=RELU, stride=2, pad=1), g)
@@ -352,7 +391,7 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
         #  or the split point i == nls - 1, where up{i} and up{i}_T BOTH contribute -- as two lanes or, with VTS_PARALLEL_SCALES=0, as
         #  two accumulating calls: the fused sums (and the k-split epilogue's fused backward) would see only one part of the gradient)
         ops.conv4x4(gop, blk.weight, outer * 16, 16, c_in0, tgt, stride=2, pad=1, dmask=inp, dmask_act=RELU, accumulate=acc,
-                    bwd_sums="in" if (i != nd - 1) and not (nls > 0 and i == nls - 1) else False)
+                    bwd_sums="in" if (i != nd - 1) and not (nls > 0 and i == nls - 1) and not dropped_input(inp) else False)
         if skip is not None:
             tgt, acc = add_grad_list(dfeat, i, skip.data.shape, dev)
             wv = blk.weight.view(-1)[c_in0 * outer * 16:]
