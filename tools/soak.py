@@ -13,10 +13,12 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     model, opt = bench.build_model(1024, 4, "skitG")
     opt.use_hip_graph = True
-    batch = bench.make_batch(1024, 4, 0, opt.style_code_dim)
+    # alternating 8-bit batches in pinned memory: the fresh-batch path of a train.py loop (one-launch image preparation, staged uploads)
+    batches = [bench.make_batch(1024, 4, k, opt.style_code_dim, quantize8=True) for k in (0, 1, 2)]
+    batches = [{k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
     mem = []
     for it in range(steps):
-        model.set_input(batch, phase="train")
+        model.set_input(batches[it % 3], phase="train")
         model.optimize_parameters(epoch=1)
         if it % 100 == 99 or it == 4:
             torch.cuda.synchronize()
