@@ -131,6 +131,32 @@ def main():
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "arrays")
 
+    # the multi-material form of the skitG model (data/skit_dataset.py): two materials at the reference's fixed relative place
+    # ./datasets/singleskit_<material>_padded_<padded_size>_x<multiplier>/; opt.load_contact_mask is an attribute no parser of the
+    # reference defines (its published class raises AttributeError without it): set to the parent's default, True
+    from data.skit_dataset import SkitDataset     # the REFERENCE's
+    out = {"meta": np.array("reference SkitDataset on two synthetic materials (write_material seeds 31 / 32 train, 33 / 34 test); seeds 9 / 10; "
+                            "load_contact_mask True injected; w_resampling False; torch %s" % torch.__version__)}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for phase, mseeds, seed, pre in (("train", (31, 32), 9, "zoom_crop"), ("test", (33, 34), 10, "none")):
+                for m, ms in zip(("matA", "matB"), mseeds):
+                    sm.write_material(os.path.join(tmp, "datasets", "singleskit_%s_padded_400_x1" % m), seed=ms, phase=phase)
+                random.seed(seed)
+                np.random.seed(seed)
+                # (a mild zoom: the reference indexes its valid-rectangle lists by FILE index and raises IndexError as soon as one GelSight
+                #  rectangle leaves the crop, singleskit_dataset.py:742-754)
+                ds = SkitDataset(dataset_opt("unused_root", phase, material_list=["matA", "matB"], padded_size=400, load_contact_mask=True,
+                                             data_len=3, preprocess=pre, random_scale_max=1.04, crop_size=320))
+                out[phase + "/len"] = np.array(len(ds))
+                dump(ds, phase, out)
+        finally:
+            os.chdir(cwd)
+    path = os.path.join(ROOT, "tests", "golden", "skit_dataset.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "arrays")
+
 
 if __name__ == "__main__":
     main()

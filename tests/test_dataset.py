@@ -123,6 +123,48 @@ def test_patchskit_dataset_matches_reference_cache(phase, mseed, seed, tmp_path,
         assert ds[0]["S"].shape == (1, 256, 256) and ds[0]["T_images"].ndim == 4 and ds[0]["I_masks"].shape[1:] == (32, 1, 32)      # sic: the reference unsqueezes axis -2 (patchskit_dataset.py:313, its own TODO)
 
 
+@pytest.mark.parametrize("phase,mseeds,seed,pre", [("train", (31, 32), 9, "zoom_crop"), ("test", (33, 34), 10, "none")])
+def test_skit_dataset_matches_reference_cache(phase, mseeds, seed, pre, tmp_path, golden_dir, monkeypatch):
+    """data/skit_dataset.py (the multi-material front-end of skitG) against what the REFERENCE's SkitDataset cached for two seeded
+    materials at its fixed relative place ./datasets/singleskit_<material>_padded_<size>_x<multiplier>/: entry i belongs to material
+    i % 2 and takes zoom level i; `S_paths` is always the first material's, `name` the entry's own"""
+    from data.skit_dataset import SkitDataset
+
+    g = np.load(os.path.join(golden_dir, "skit_dataset.npz"))
+    for m, ms in zip(("matA", "matB"), mseeds):
+        write_material(str(tmp_path / "datasets" / ("singleskit_%s_padded_400_x1" % m)), seed=ms, phase=phase)
+    monkeypatch.chdir(tmp_path)
+    random.seed(seed)
+    np.random.seed(seed)
+    ds = SkitDataset(dataset_opt("unused_root", phase, material_list=["matA", "matB"], padded_size=400, data_len=3, preprocess=pre,
+                                 random_scale_max=1.04, crop_size=320))
+    assert len(ds) == int(g[phase + "/len"]) == 3
+    _compare_with_reference_cache(ds, g, phase)
+    assert "style_code" not in ds[0]
+    if phase == "train":        # the package's addition: a precomputed style code per material becomes the batch key the skitG model reads
+        np.save(str(tmp_path / "datasets" / "singleskit_matB_padded_400_x1" / "style_code.npy"), np.arange(512, dtype=np.float64))
+        random.seed(seed)
+        np.random.seed(seed)
+        ds2 = SkitDataset(dataset_opt("unused_root", phase, material_list=["matA", "matB"], padded_size=400, data_len=3, preprocess=pre,
+                                      random_scale_max=1.04, crop_size=320))
+        assert "style_code" not in ds2[0] and ds2[1]["style_code"].dtype == torch.float32 and ds2[1]["style_code"].shape == (512,)
+        assert torch.equal(ds2[1]["S"], ds[1]["S"])
+    assert ds[0]["name"] == ds[2]["name"] and ds[0]["S_paths"] == ds[1]["S_paths"] and ds[0]["M_paths"] != ds[1]["M_paths"]
+    if phase == "train":
+        assert not torch.equal(ds[0]["S"], ds[2]["S"])       # same material, another zoom level / crop position
+
+
+def test_skit_is_a_creatable_dataset_mode():
+    from data import find_dataset_using_name
+    from data.skit_dataset import SkitDataset
+
+    assert find_dataset_using_name("skit") is SkitDataset
+    with pytest.raises(NotImplementedError):
+        SkitDataset(dataset_opt("x", "test", material_list=["a"], padded_size=1, use_external_test_input=True))
+    with pytest.raises(ValueError):
+        SkitDataset(dataset_opt("x", "test", material_list=[], padded_size=1))
+
+
 def test_patchskit_is_a_creatable_dataset_mode(tmp_path):
     """--dataset_mode patchskit resolves through the factory (it used to raise 'not built')"""
     from data import find_dataset_using_name

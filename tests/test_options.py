@@ -76,8 +76,12 @@ def test_unbuilt_dataset_modes_raise_instead_of_aliasing():
     from data import create_dataset
     from options.train_options import TrainOptions
 
+    opt = parse(TrainOptions, "--model skitG --gpu_ids -1 --dataset_mode aligned --checkpoints_dir /tmp/vts_opt")
+    with pytest.raises(NotImplementedError, match="dataset_mode aligned"):
+        create_dataset(opt)
+    # `skit` is built since round 4 (data/skit_dataset.py): it resolves through the command line, and says what it needs
     opt = parse(TrainOptions, "--model skitG --gpu_ids -1 --dataset_mode skit --checkpoints_dir /tmp/vts_opt")
-    with pytest.raises(NotImplementedError, match="dataset_mode skit"):
+    with pytest.raises(ValueError, match="material_list"):
         create_dataset(opt)
 
 

@@ -11,24 +11,14 @@ import torch.utils.data
 
 # reference dataset modes whose CPU front-end is not built here: their option setter resolves (the reference parser asks for it
 # while gathering options, options/base_options.py:238-240) but create_dataset refuses them
-_UNBUILT = ("skit", "aligned")
+_UNBUILT = ("aligned",)
 
 
 def find_dataset_using_name(dataset_name):
-    if dataset_name == "skit":
-        # reference data/skit_dataset.py: (i) its preprocess_data reads opt.load_contact_mask (:423), an option no parser defines --
-        # the published class raises AttributeError for any material that has tactile data; (ii) what it adds over singleskit is the
-        # style IMAGE (style_I / style_M, :497-498), which only the CLIP ViT-B/32 encoder turns into the 512-d style code the skitG
-        # generator consumes (skitG_model.py:484-489) -- CLIP's weights cannot exist offline, so the style code is an input here
-        # (batch key "style_code").
-        raise NotImplementedError(
-            "--dataset_mode skit: not built -- the reference class fails as published (opt.load_contact_mask is undefined, data/skit_dataset.py:423) "
-            "and its extra outputs (style_I / style_M) need the CLIP encoder. Feed skitG with singleskit material folders plus a "
-            "`style_code` entry, or use --dataset_mode synthetic.")
     if dataset_name in _UNBUILT:
         raise NotImplementedError(
             "--dataset_mode %s: this dataset front-end is not built in the MI355X package (SURVEY.md 8f-3). Use --dataset_mode "
-            "singleskit / patchskit for TouchClothing material folders or --dataset_mode synthetic for the seeded generator." % dataset_name)
+            "singleskit / skit / patchskit for TouchClothing material folders or --dataset_mode synthetic for the seeded generator." % dataset_name)
     try:
         lib = importlib.import_module("data." + dataset_name + "_dataset")
     except ImportError as e:
