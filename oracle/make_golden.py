@@ -895,7 +895,23 @@ VARIANTS = {
     "diffaug_all": ["--diffaugment", "bsctno"],
     # Dropout(0.5) in the intermediate Up blocks of the generator (row a4; the draws replay: nets.dropout_draws, then DiffAugment's)
     "dropout": ["--no_dropout", "False"],
+    # the same flag with the ResNet generator (row a19): Dropout(0.5) inside every block
+    "resnet_dropout": ["--netG", "resnet_6blocks", "--no_dropout", "False"],
 }
+
+
+def variant_g_shapes(opt):
+    from oracle import nets
+    if opt.netG.startswith("resnet_"):
+        return nets.resnet_param_shapes(n_blocks=int(opt.netG[len("resnet_")]), use_dropout=not opt.no_dropout)
+    return nets.g_param_shapes()
+
+
+def variant_dropout_draws(opt, size):
+    from oracle import nets
+    if opt.netG.startswith("resnet_"):
+        return nets.resnet_dropout_draws((1, size, size), n_blocks=int(opt.netG[len("resnet_")]))
+    return nets.dropout_draws((1, size, size))
 
 
 def golden_step_variants(size=256, seed=232, nt=64):
@@ -912,12 +928,12 @@ def golden_step_variants(size=256, seed=232, nt=64):
         opt = _ref_opt("sinskitG", True, flags)
         model = SinSKITGModel(opt)
         model.setup(opt)
-        shapesG = nets.g_param_shapes()
+        shapesG = variant_g_shapes(opt)
         shapesD = nets.d_param_shapes(4, n_layers=opt.n_layers_D)
         shapesD2 = nets.d_param_shapes(7, n_layers=opt.n_layers_D2)
         for net, sh in ((model.netD, shapesD), (model.netD2, shapesD2)):
             assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in sh.items()}, name
-        model.netG.load_state_dict(detrand.test_weights(shapesG, seed + 10 * vi))
+        model.netG.load_state_dict(detrand.test_weights(shapesG, seed + 10 * vi), strict=not opt.netG.startswith("resnet_"))   # (blur `filt` buffers)
         model.netD.load_state_dict(detrand.test_weights(shapesD, seed + 10 * vi + 1))
         model.netD2.load_state_dict(detrand.test_weights(shapesD2, seed + 10 * vi + 2))
         model.train()
@@ -926,7 +942,7 @@ def golden_step_variants(size=256, seed=232, nt=64):
         k = int(nets.dilated_mask_positions(model.M).shape[0])
         torch.manual_seed(seed + vi)
         if not opt.no_dropout:
-            nets.dropout_draws((1, size, size))      # the generator forward consumes its dropout masks first
+            variant_dropout_draws(opt, size)      # the generator forward consumes its dropout masks first
         if opt.diffaugment == "bs":
             aug = torch.stack([torch.rand(1, 1, 1, 1).flatten() for _ in range(4)])
         else:

@@ -393,9 +393,20 @@ def _gnorm(sd, key, x, norm, training):
     return y
 
 
-def resnet_forward(sd, x, n_blocks=9, n_down=2, norm="instance", down="blur", up="blur", training=True):
+def resnet_dropout_draws(shape_n_h_w, ngf=10, n_blocks=9, n_down=2):
+    """keep masks of the blocks' Dropout(0.5) (--no_dropout False; ResnetBlock.build_conv_block, networks.py:1305-1306) drawn from torch's
+    global generator as F.dropout draws them on the CPU, in block order: a list of [N, ngf * 2^n_down, h / 2^n_down, w / 2^n_down] of 0 / 1"""
+    n, h, w = shape_n_h_w
+    return [torch.empty(n, ngf * 2 ** n_down, h >> n_down, w >> n_down).bernoulli_(0.5) for _ in range(n_blocks)]
+
+
+def resnet_forward(sd, x, n_blocks=9, n_down=2, norm="instance", down="blur", up="blur", training=True, dropout_masks=None):
     """ResnetGenerator.forward (reference defaults: instance / blur / blur) and, with norm='batch', down='stride',
-    up='convT', pix2pixHD's GlobalGenerator.forward.  Missing biases (`use_bias=False` with BatchNorm) are None."""
+    up='convT', pix2pixHD's GlobalGenerator.forward.  Missing biases (`use_bias=False` with BatchNorm) are None.
+    dropout_masks (resnet_dropout_draws): the generator was built with use_dropout -- Dropout(0.5) behind the first ReLU of every block,
+    which also moves the block's second conv / norm from conv_block.5 / .6 to .6 / .7 in the state dict."""
+    masks = list(dropout_masks) if dropout_masks is not None else None
+    kb = 6 if masks is not None else 5
     def wb(i):
         return sd["model.%d.weight" % i], sd.get("model.%d.bias" % i)
 
@@ -412,8 +423,10 @@ def resnet_forward(sd, x, n_blocks=9, n_down=2, norm="instance", down="blur", up
             k = "model.%d.conv_block." % i
             y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[k + "1.weight"], sd.get(k + "1.bias"))
             y = F.relu(_gnorm(sd, k + "2", y, norm, training))
-            y = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[k + "5.weight"], sd.get(k + "5.bias"))
-            x = x + _gnorm(sd, k + "6", y, norm, training)
+            if masks is not None and training:
+                y = y * masks.pop(0) / 0.5
+            y = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), sd[k + "%d.weight" % kb], sd.get(k + "%d.bias" % kb))
+            x = x + _gnorm(sd, k + "%d" % (kb + 1), y, norm, training)
         elif kind == "up_conv3":
             if up == "blur":
                 w, b = wb(i + 1)
@@ -510,7 +523,8 @@ def local_enhancer_param_shapes(input_nc=1, output_nc=5, ngf=32, n_down=3, n_blo
     return sh
 
 
-def resnet_param_shapes(input_nc=9, output_nc=5, ngf=10, n_blocks=9, n_down=2, norm="instance", down="blur", up="blur", conv_bias=None):
+def resnet_param_shapes(input_nc=9, output_nc=5, ngf=10, n_blocks=9, n_down=2, norm="instance", down="blur", up="blur", conv_bias=None,
+                        use_dropout=False):
     """state_dict entries of ResnetGenerator / GlobalGenerator (the `filt` buffers of the blur modules are constants
     and not listed).  conv_bias None: the reference's rule use_bias = (norm == instance)."""
     if conv_bias is None:
@@ -540,7 +554,7 @@ def resnet_param_shapes(input_nc=9, output_nc=5, ngf=10, n_blocks=9, n_down=2, n
             nrm("model.%d" % (i + 1), 2 * c)
             c *= 2
         elif kind == "block":
-            for j in (1, 5):
+            for j in (1, 6 if use_dropout else 5):      # (a Dropout module behind the first ReLU shifts the second conv / norm)
                 conv("model.%d.conv_block.%d" % (i, j), (c, c, 3, 3))
                 nrm("model.%d.conv_block.%d" % (i, j + 1), c)
         elif kind == "up_conv3":

@@ -72,7 +72,7 @@ def _gather_all(img, coords):
 def generator_forward(sdG, inp, opt, style_code=None, dropout_masks=None):
     netG = getattr(opt, "netG", "unet256_custom")
     if netG.startswith("resnet_"):   # --netG resnet_{4,6,9}blocks (sinskitG_model.py:509-520 -> networks.define_G)
-        out = nets.resnet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), n_blocks=int(netG[len("resnet_")]))
+        out = nets.resnet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), n_blocks=int(netG[len("resnet_")]), dropout_masks=dropout_masks)
     else:
         out = nets.unet_forward(sdG, torch.cat((inp.real_S, inp.S_pe), 1), style_code=style_code, dropout_masks=dropout_masks)
     fake_I = out[:, 0:3] * inp.M

@@ -338,8 +338,9 @@ def _variant_opt(extra):
 def _variant_draws(g, name, opt, seed, vi, size):
     draws = {"more_idx": torch.from_numpy(g[name + "/more_idx"])}
     torch.manual_seed(seed + vi)     # the reference seeds torch's generator with seed + vi in front of the step
-    if not getattr(opt, "no_dropout", True):
-        draws["dropout"] = nets.dropout_draws((1, size, size))       # the generator forward draws first
+    if not getattr(opt, "no_dropout", True):       # the generator forward draws first
+        draws["dropout"] = (nets.resnet_dropout_draws((1, size, size), n_blocks=int(opt.netG[len("resnet_")])) if opt.netG.startswith("resnet_")
+                            else nets.dropout_draws((1, size, size)))
     if opt.diffaugment == "bs":
         draws["aug"] = torch.from_numpy(g[name + "/aug"])
     else:       # DiffAugment(real_I), then DiffAugment(fake_I)
@@ -353,7 +354,9 @@ def test_train_step_variants_match_reference(golden_dir):
     size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
     for vi, name in enumerate(str(v) for v in g["variants"]):
         opt = _variant_opt(json.loads(str(g[name + "/flags"])))
-        sdG = detrand.test_weights(nets.g_param_shapes(), seed + 10 * vi)
+        gshapes = (nets.resnet_param_shapes(n_blocks=int(opt.netG[len("resnet_")]), use_dropout=not getattr(opt, "no_dropout", True)) if opt.netG.startswith("resnet_")
+                   else nets.g_param_shapes())
+        sdG = detrand.test_weights(gshapes, seed + 10 * vi)
         sdD = detrand.test_weights(nets.d_param_shapes(4, n_layers=opt.n_layers_D), seed + 10 * vi + 1)
         sdD2 = detrand.test_weights(nets.d_param_shapes(7, n_layers=opt.n_layers_D2), seed + 10 * vi + 2)
         adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}

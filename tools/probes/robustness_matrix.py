@@ -37,6 +37,7 @@ CASES = [
     ("skitG 1024 b4 diffaugment cto", "--model skitG --crop_size 1024 --batch_size 4 --diffaugment cto", 1024, 4),
     ("sinskitG Up-block dropout", "--model sinskitG --crop_size 256 --batch_size 2 --no_dropout False", 256, 2),
     ("skitG 1024 b4 Up-block dropout", "--model skitG --crop_size 1024 --batch_size 4 --no_dropout False", 1024, 4),
+    ("sinskitG resnet9 block dropout", "--model sinskitG --crop_size 256 --batch_size 2 --netG resnet_9blocks --no_dropout False", 256, 2),
     ("sinskitG 200 steps + lr decay", "--model sinskitG --crop_size 256 --batch_size 1", 256, 1),
 ]
 

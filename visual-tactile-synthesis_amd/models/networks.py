@@ -161,14 +161,19 @@ class ResnetGenerator(nn.Module):
       up    'blur' (Upsample + conv3) | 'convT' (ConvTranspose2d 3x3 s2 p1 op1)
 
     `self.layout` lists the reference's nn.Sequential so that the state_dict keys are `model.<idx>...`;
-    reflect padding, no dropout."""
+    reflect padding; optional dropout in the blocks."""
 
     def __init__(self, input_nc, output_nc, ngf=64, n_blocks=6, n_downsampling=2, norm="instance", down="blur", up="blur",
-                 conv_bias=None, opt=None):
+                 conv_bias=None, opt=None, use_dropout=False):
         super().__init__()
         assert norm in ("instance", "batch") and down in ("blur", "stride") and up in ("blur", "convT")
         self.input_nc, self.output_nc, self.ngf, self.n_blocks, self.n_down = input_nc, output_nc, ngf, n_blocks, n_downsampling
         self.norm = norm
+        # use_dropout: Dropout(0.5) behind the first conv / norm / ReLU of every block (ResnetBlock.build_conv_block, networks.py:1305-1306;
+        # train() mode only) -- it also shifts the second conv / norm of the block from conv_block.5 / .6 to .6 / .7 in the state dict
+        self.use_dropout = bool(use_dropout)
+        kb = 6 if self.use_dropout else 5
+        self._block_keys = ("1", "2", str(kb), str(kb + 1))
         if conv_bias is None:          # ResnetGenerator: use_bias = (norm_layer == InstanceNorm2d)  (networks.py:1069-1073)
             conv_bias = norm == "instance"
         mods, layout = {}, []
@@ -185,9 +190,9 @@ class ResnetGenerator(nn.Module):
             add("norm", _BNParams(c) if norm == "batch" else None)
 
         def block(c):
-            kids = {1: _ConvParams((c, c, 3, 3), c if conv_bias else 0), 5: _ConvParams((c, c, 3, 3), c if conv_bias else 0)}
+            kids = {1: _ConvParams((c, c, 3, 3), c if conv_bias else 0), kb: _ConvParams((c, c, 3, 3), c if conv_bias else 0)}
             if norm == "batch":
-                kids[2], kids[6] = _BNParams(c), _BNParams(c)
+                kids[2], kids[kb + 1] = _BNParams(c), _BNParams(c)
             return _Holder({"conv_block": _Holder(kids)})
 
         add("pad")
@@ -221,7 +226,7 @@ class ResnetGenerator(nn.Module):
 
     def block_mods(self, idx):
         cb = getattr(self.model, str(idx)).conv_block
-        return [getattr(cb, k, None) for k in ("1", "2", "5", "6")]   # conv a, norm a, conv b, norm b
+        return [getattr(cb, k, None) for k in self._block_keys]   # conv a, norm a, conv b, norm b
 
     def forward(self, x, style_code=None, verbose=False):
         """Inference forward on the HIP path; returns [N,output_nc,H,W]."""
@@ -489,10 +494,11 @@ def define_G(input_nc, output_nc, ngf, netG, norm="batch", use_dropout=False, in
     if netG in resnet_blocks:
         if norm not in ("batch", "instance"):
             raise NotImplementedError("resnet generator: norm %s is not built" % norm)
-        if use_dropout or generate_T_imgs:
-            raise NotImplementedError("resnet generator: dropout / generate_T_imgs are not built")
+        if generate_T_imgs:
+            raise NotImplementedError("resnet generator: generate_T_imgs is not built")
         net = ResnetGenerator(input_nc, output_nc, ngf=ngf, n_blocks=resnet_blocks[netG], norm=norm,
-                              down="stride" if no_antialias else "blur", up="convT" if no_antialias_up else "blur", opt=opt)
+                              down="stride" if no_antialias else "blur", up="convT" if no_antialias_up else "blur", opt=opt,
+                              use_dropout=use_dropout)
     elif norm != "instance":
         raise NotImplementedError("unet256_custom is built for normG=instance only")
     else:

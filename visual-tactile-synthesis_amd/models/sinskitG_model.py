@@ -602,7 +602,8 @@ class SinSKITGModel(BaseModel):
         if isinstance(self.netG, networks.ResnetGenerator):
             if self._style() is not None:
                 raise NotImplementedError("style codes are only built for netG=unet256_custom")
-            g_out, self._g_ctx = engine.resnet_forward(self.netG, self._g_input(), keep=keep)
+            g_out, self._g_ctx = engine.resnet_forward(self.netG, self._g_input(), keep=keep,
+                                                       dropout_masks=self._draws.get("dropout") if self._draws is not None else None)
         elif not keep:
             # inference: one call of the network-level C entry (include/vts.h: vts_unet_forward) where it covers the configuration
             g_out, self._g_ctx = engine.unet_forward_infer(self.netG, self._g_input(), style_code=self._style(),

@@ -538,7 +538,7 @@ def _conv3(x, conv, out, stride, act_in):
     return ops.conv4x4(x, w4, ci * 16, 16, co, out, bias=conv.bias, stride=2, pad=1, act_in=act_in)
 
 
-def _seq_forward(G, seq, srcs, cur, pending):
+def _seq_forward(G, seq, srcs, cur, pending, dropout_masks=None):
     """Run one nn.Sequential-like segment (`seq.layout` over `seq.mod` / `seq.block_mods`).  srcs: the network input(s)
     (Acts, concatenated on store into the first padded tensor) when the segment starts at the input (cur None);
     otherwise cur is the incoming activation (Act with `pending` activation, or an identity tensor).
@@ -637,19 +637,31 @@ def _seq_forward(G, seq, srcs, cur, pending):
             r1 = _empty(n, ca.weight.shape[0], xb.shape[2], xb.shape[3], dev)
             _conv_valid3(p1, ca, r1)
             a1 = _g_norm(G, r1, na)
-            p2 = ops.pad_affine(a1, (1, 1, 1, 1), 1, act=RELU)
+            keep2 = None
+            if getattr(G, "use_dropout", False) and G.training:
+                # Dropout(0.5) between the ReLU and the second reflection pad (networks.py:1305-1306): relu(norm(r1)) is materialised,
+                # multiplied by keep * 2, and padded as a plain tensor; the backward multiplies by the same map
+                k = dropout_masks.pop(0) if dropout_masks else torch.bernoulli(torch.full(r1.shape, 0.5, device=dev))
+                keep2 = (k.to(device=dev, dtype=torch.float32) * 2.0).contiguous()
+                y1 = ops.pad_affine(a1, (0, 0, 0, 0), 0, act=RELU)
+                y1d = torch.empty_like(y1)
+                v = lambda t: t.view(-1, 1, t.shape[2], t.shape[3])
+                ops.mask_mul(v(y1), v(keep2), out=v(y1d))
+                p2 = ops.pad_affine(y1d, (1, 1, 1, 1), 1)
+            else:
+                p2 = ops.pad_affine(a1, (1, 1, 1, 1), 1, act=RELU)
             r2 = _empty(n, cb.weight.shape[0], xb.shape[2], xb.shape[3], dev)
             _conv_valid3(p2, cb, r2)
             a2 = _g_norm(G, r2, nb)
             cur, pending = ops.pad_affine(a2, (0, 0, 0, 0), 0, res=xb), 0
-            steps.append(("block", ca, cb, p1, a1, p2, a2, na, nb, blk_src))
+            steps.append(("block", ca, cb, p1, a1, p2, a2, na, nb, blk_src, keep2))
             i += 1
         else:
             raise RuntimeError("unexpected layout entry %r" % (e,))
     return cur, pending, steps
 
 
-def resnet_forward(G, x, keep=True):
+def resnet_forward(G, x, keep=True, dropout_masks=None):
     """x: tensor / Act, or a pair (x0, x1) concatenated on store into the first padded tensor.
     Returns (g_out [N,output_nc,H,W] post-tanh, ctx).  Every 3x3 / 7x7 conv runs as 4x4 tap blocks
     (ops.convk) or, for wide layers, on the GEMM-class kernels; normalisation is a statistics pass only and is
@@ -657,7 +669,7 @@ def resnet_forward(G, x, keep=True):
     if getattr(G, "is_local_enhancer", False):
         return local_enhancer_forward(G, x, keep)
     srcs = [_as_act(t) for t in (x if isinstance(x, (tuple, list)) else (x,))]
-    cur, _, steps = _seq_forward(G, G, srcs, None, 0)
+    cur, _, steps = _seq_forward(G, G, srcs, None, 0, dropout_masks=list(dropout_masks) if dropout_masks else None)
     ctx = None
     if keep:
         ctx = ResnetCtx()
@@ -774,7 +786,7 @@ def _seq_backward(steps, g, sq, bn_of):
             ops.blur_up_bwd(g, da)
             g = through_norm_relu(da, inp, producer_bn(inp)) if inp_act == RELU else da
         elif kind == "block":
-            _, ca, cb, p1, a1, p2, a2, na, nb, blk_src = st
+            _, ca, cb, p1, a1, p2, a2, na, nb, blk_src, keep2 = st
             dy = g
             g2 = dy.clone()
             _g_norm_bwd(g2, a2, nb)
@@ -783,6 +795,11 @@ def _seq_backward(steps, g, sq, bn_of):
             _conv_valid3_bwd_data(g2, cb, dp2)
             da1 = torch.empty_like(a1.data)
             ops.pad_bwd(dp2, (1, 1, 1, 1), 1, da1)
+            if keep2 is not None:      # Dropout backward
+                dd = torch.empty_like(da1)
+                v = lambda t: t.view(-1, 1, t.shape[2], t.shape[3])
+                ops.mask_mul(v(da1), v(keep2), out=v(dd))
+                da1 = dd
             g1 = through_norm_relu(da1, a1, na)
             sq.run(lambda: _wgrad_valid3(g1, p1, ca), g1)
             dp1 = torch.empty_like(p1)
