@@ -99,4 +99,39 @@ def test_friction_map_matches_reference(golden_dir):
             assert v.dtype == np.uint8 and np.array_equal(v, g["%s/%s" % (tag, k)]), (tag, k)
     import pytest
     with pytest.raises(NotImplementedError):
-        postprocess_gz(img, m, gx, gy, method="equalize", use_raw_arr=True)
+        postprocess_gz(img, m, gx, gy, method="dilation", use_raw_arr=True)      # (upstream: NameError)
+    # the reference's default mapping: CLAHE (restated, parity-unpinned) -> a 2-D map, full range after the min-max
+    res = postprocess_gz(img.copy(), m, gx.copy(), gy.copy(), Tanvas_width=48, Tanvas_height=32, method="equalize", use_raw_arr=True)
+    assert res[2].ndim == 2 and res[2].dtype == np.uint8 and res[2].min() == 0 and res[2].max() == 255 and res[5].shape == (32, 48)
+
+
+def test_clahe_restatement_properties():
+    """util.image_io.clahe_u8 (OpenCV's CLAHE restated; parity unpinned: cv2 is absent): properties the published algorithm has"""
+    from util.image_io import clahe_u8
+
+    rng = np.random.RandomState(3)
+    img = (rng.rand(64, 96) ** 2 * 255).astype(np.uint8)
+    # one tile, no effective clipping = global histogram equalisation: LUT = round(cdf * 255 / area)
+    out = clahe_u8(img, clip_limit=1e9, tiles=(1, 1))
+    cdf = np.cumsum(np.bincount(img.ravel(), minlength=256))
+    assert np.array_equal(out, np.rint(cdf.astype(np.float32) * (np.float32(255.0) / np.float32(img.size))).astype(np.uint8)[img])
+    # one tile: the mapping is a LUT, monotone in the input value, whatever the clip limit
+    for clip in (1.0, 4.0, 40.0):
+        o = clahe_u8(img, clip, (1, 1)).astype(int)
+        order = np.argsort(img.ravel(), kind="stable")
+        assert (np.diff(o.ravel()[order]) >= 0).all()
+    # the tightest clip limit flattens the histogram: the LUT is the identity ramp (+- rounding) -> the image is (almost) unchanged
+    flat = clahe_u8(img, 1e-9, (1, 1)).astype(int)        # clip limit max(.., 1): every bin clipped to 1 ... redistribution makes it uniform
+    assert np.abs(flat - img.astype(int)).max() <= 1
+    # a constant image stays constant; sizes that the tile grid does not divide keep their shape (reflect-101 extension)
+    assert len(np.unique(clahe_u8(np.full((40, 40), 77, np.uint8)))) == 1
+    odd = (rng.rand(37, 53) * 255).astype(np.uint8)
+    o = clahe_u8(odd, 4.0, (4, 4))
+    assert o.shape == odd.shape and o.dtype == np.uint8
+    # 4 x 4 tiles: an image made of 16 identical tiles gets the SAME lookup table everywhere -> equals the one-tile result of one tile
+    tile = (rng.rand(16, 24) * 255).astype(np.uint8)
+    big = np.tile(tile, (4, 4))
+    assert np.array_equal(clahe_u8(big, 4.0, (4, 4)), np.tile(clahe_u8(tile, 4.0, (1, 1)), (4, 4)))
+    # contrast limiting: a low-contrast tile is stretched less with a small clip limit than with none
+    low = (120 + rng.rand(64, 64) * 16).astype(np.uint8)
+    assert np.ptp(clahe_u8(low, 2.0, (1, 1)).astype(int)) < np.ptp(clahe_u8(low, 1e9, (1, 1)).astype(int))

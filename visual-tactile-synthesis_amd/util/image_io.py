@@ -171,12 +171,61 @@ def read_exr(path):
     return np.stack([planes["R"], planes["G"], planes["B"]], axis=2)
 
 
+def clahe_u8(img, clip_limit=4.0, tiles=(4, 4)):
+    """Contrast-limited adaptive histogram equalisation of a uint8 image [H, W], restated from the published algorithm of OpenCV's
+    CLAHE (`cv2.createCLAHE(clipLimit, tileGridSize).apply`, modules/imgproc/src/clahe.cpp, 4.x) -- the reference's default friction-map
+    mapping runs it through myutils.equalize_this (myutils.py:103-118).  PARITY UNPINNED: OpenCV is not in this image (requirements.txt
+    of the reference does not pin it either), so the restatement is checked against the algorithm's properties only (tests/test_image_io.py).
+      * the image is extended to a multiple of the tile grid (BORDER_REFLECT_101 on the bottom / right);
+      * per tile: 256-bin histogram; bins clipped at max(1, int(clip_limit * tile_area / 256)); the clipped mass is redistributed
+        uniformly (integer batch to every bin, the residual to every (256 / residual)-th bin from bin 0); LUT = round(cdf * 255 / tile_area);
+      * per pixel: bilinear interpolation between the LUTs of the four nearest tile CENTRES (float32), rounded half to even."""
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    assert a.ndim == 2
+    h, w = a.shape
+    ty, tx = int(tiles[1]), int(tiles[0])
+    ext = a
+    if w % tx or h % ty:
+        ext = np.pad(a, ((0, ty - h % ty if h % ty else 0), (0, tx - w % tx if w % tx else 0)), mode="reflect")
+    th, tw = ext.shape[0] // ty, ext.shape[1] // tx
+    area = th * tw
+    scale = np.float32(255.0) / np.float32(area)
+    clip = max(int(clip_limit * area / 256), 1) if clip_limit > 0 else 0
+    luts = np.empty((ty, tx, 256), np.float32)
+    for j in range(ty):
+        for i in range(tx):
+            hist = np.bincount(ext[j * th:(j + 1) * th, i * tw:(i + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if clip > 0:
+                clipped = int(np.maximum(hist - clip, 0).sum())
+                hist = np.minimum(hist, clip)
+                batch, residual = clipped // 256, clipped % 256
+                hist += batch
+                if residual:
+                    step = max(256 // residual, 1)
+                    idx = np.arange(0, 256, step)[:residual]
+                    hist[idx] += 1
+            cdf = np.cumsum(hist).astype(np.float32)
+            luts[j, i] = np.clip(np.rint(cdf * scale), 0, 255)
+    yf = np.arange(h, dtype=np.float32) * np.float32(1.0 / th) - np.float32(0.5)
+    xf = np.arange(w, dtype=np.float32) * np.float32(1.0 / tw) - np.float32(0.5)
+    y1, x1 = np.floor(yf).astype(np.int64), np.floor(xf).astype(np.int64)
+    ya, xa = (yf - y1).astype(np.float32), (xf - x1).astype(np.float32)
+    y2, x2 = np.minimum(y1 + 1, ty - 1), np.minimum(x1 + 1, tx - 1)
+    y1, x1 = np.maximum(y1, 0), np.maximum(x1, 0)
+    v = a.astype(np.int64)
+    l11, l12 = luts[y1[:, None], x1[None, :], v], luts[y1[:, None], x2[None, :], v]
+    l21, l22 = luts[y2[:, None], x1[None, :], v], luts[y2[:, None], x2[None, :], v]
+    xa_, ya_ = xa[None, :], ya[:, None]
+    res = (l11 * (1 - xa_) + l12 * xa_) * (1 - ya_) + (l21 * (1 - xa_) + l22 * xa_) * ya_
+    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+
+
 def postprocess_gz(fake_I, M, gx, gy, Tanvas_width=1280, Tanvas_height=800, use_raw_arr=False, thresholding=False, threshold_quantile=0.9,
                    method="log10", compute_gz=True, gz=None, change_bg_color=False, bg_color=(255, 255, 255)):
     """Friction map for haptic rendering from the tactile output (Step2_Postprocessing_for_Rendering.py:18-140): gz = gx^2 + gy^2,
-    optional quantile clipping, min-max normalisation, a non-linear mapping ('log10' / 'exp2'), uint8 images and their resized copies
-    for the TanvasTouch screen.  The reference's 'equalize' (OpenCV CLAHE through myutils.equalize_this) and 'dilation' (skimage Sobel +
-    OpenCV morphology) mappings depend on libraries this image does not have and are not built.
+    optional quantile clipping, min-max normalisation, a non-linear mapping ('equalize': CLAHE, restated from OpenCV's algorithm and
+    parity-unpinned, see clahe_u8; 'log10' / 'exp2': pinned to the reference), uint8 images and their resized copies for the TanvasTouch
+    screen.  'dilation' (skimage Sobel + OpenCV morphology) is not built: upstream it raises NameError (it reads gz_equalize unassigned).
     Returns (gz_im, fake_I_im, gz_postprocess_im, gz_im_Tanvas, fake_I_im_Tanvas, gz_postprocess_im_Tanvas) like the reference."""
     from PIL import Image
     if compute_gz:
@@ -195,12 +244,18 @@ def postprocess_gz(fake_I, M, gx, gy, Tanvas_width=1280, Tanvas_height=800, use_
     gz = (gz - np.min(gz)) / (np.max(gz) - np.min(gz))
     if gz.ndim == 2:
         gz = np.tile(gz[:, :, None], (1, 1, 3))
-    if method == "log10":
+    if method == "equalize":
+        # the reference's default (Step2_Postprocessing_for_Rendering.py:88-92): the three identical channels -> bytes -> gray (the same
+        # byte: OpenCV's RGB2GRAY weights sum to one) -> CLAHE(clipLimit 4, 4 x 4 tiles) -> min-max; a 2-D map from here on
+        eq = clahe_u8((gz[:, :, 0] * 255 if np.max(gz) <= 1 else gz[:, :, 0]).astype(np.uint8), 4.0, (4, 4)).astype(np.float64)
+        post = (eq - np.min(eq)) / (np.max(eq) - np.min(eq))
+    elif method == "log10":
         post = np.log10(gz * 9.0 + 1.0)      # [0, 1] -> [1, 10] -> log in [0, 1]
     elif method == "exp2":
         post = np.exp2(gz * 3.0 - 3.0)       # [0, 1] -> [-3, 0]
     else:
-        raise NotImplementedError("friction-map mapping '%s' is not built (needs OpenCV / skimage); use 'log10' or 'exp2'" % method)
+        # ('dilation' cannot run upstream either: it reads gz_equalize before any assignment, Step2_Postprocessing_for_Rendering.py:95)
+        raise NotImplementedError("friction-map mapping '%s' is not built; use 'equalize', 'log10' or 'exp2'" % method)
     post = (post - post.min()) / (np.max(post) - post.min())
     gz_im = np.uint8(gz * 255)
     fake_I_im = np.uint8(fake_I)
