@@ -46,6 +46,34 @@ def test_maxpool_relu_pad_and_adjoint(shape):
     assert torch.equal(masked.cpu(), z.grad)
 
 
+@pytest.mark.parametrize("shape,pad,zpad,tap", [((2, 5, 8, 12), 1, 1, True), ((1, 3, 2, 2), 2, 0, True), ((2, 4, 2, 10), 1, 2, False),
+                                                ((2, 4, 10, 2), 2, 1, True), ((1, 64, 32, 32), 1, 1, True), ((3, 2, 6, 6), 0, 0, True),
+                                                ((1, 2, 5, 7), 1, 0, True)])
+def test_maxpool_adjoint_window_kernel_against_autograd(shape, pad, zpad, tap):
+    """vts_maxpool2_relu_bwd (one thread per 2 x 2 window for even sizes, per element otherwise): routed gradient + tap gradient where
+    z > 0, written into a zero-bordered map -- against autograd of max_pool2d(relu(z)) + <tap, relu(z)>; border zeros on a poisoned buffer"""
+    from vts import lib as L
+    from vts import ops
+
+    n, c, h, w = shape
+    dev = _dev()
+    z = detrand.uniform(shape, 31, "z").requires_grad_(True)
+    z.data[0, 0, 0:2, 0:2] = 0.41
+    z.data[0, 1, 0:2, 0:2] = -0.3
+    y = F.max_pool2d(F.relu(z), 2, 2)
+    cot = detrand.uniform(tuple(y.shape), 31, "cot")
+    t = detrand.uniform(shape, 31, "tap") if tap else None
+    loss = (y * cot).sum() + ((F.relu(z) * t).sum() if tap else 0)
+    loss.backward()
+    zp = F.pad(z.detach(), (zpad,) * 4).to(dev)
+    tp = F.pad(t, (zpad,) * 4).to(dev) if tap else None
+    out = torch.full((n, c, h + 2 * pad, w + 2 * pad), 9.0, device=dev)
+    lib = L.load()
+    L.check(lib.vts_maxpool2_relu_bwd(cot.to(dev).data_ptr(), zp.data_ptr(), n * c, h, w, out.data_ptr(), zpad, L.ptr(tp), pad, L.stream()), "bwd")
+    # (the kernel leaves the ReLU mask of the ROUTED part to the routing rule itself: a maximum is only routed where it is positive)
+    assert torch.equal(out.cpu(), F.pad(z.grad, (pad,) * 4)), (out.cpu() - F.pad(z.grad, (pad,) * 4)).abs().max()
+
+
 def test_relu_mask_pad_and_l1_relu():
     from vts import ops
 

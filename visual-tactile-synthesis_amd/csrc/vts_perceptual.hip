@@ -110,6 +110,66 @@ __global__ __launch_bounds__(256) void maxpool2_relu_bwd_kernel(const float* __r
   }
 }
 
+// The same for even H, W, one thread per 2 x 2 WINDOW (round 4, late): the window's four z values, its pooled gradient and its four tap
+// gradients are read once (8-byte accesses; the per-element form reads every window four times and divides per element), the four routed
+// gradients go out as two 8-byte stores; the zero border of the padded result is written by the threads of the first / last window of a row
+// and by the first / last window rows.  Same routing rule (the FIRST maximum in row-major order, only where it is positive).
+__global__ __launch_bounds__(256) void maxpool2_relu_bwd_win_kernel(const float* __restrict__ g, const float* __restrict__ z, int H, int W,
+                                                                    float* __restrict__ gz, int zpad, const float* __restrict__ g2, int pad) {
+  typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+  const int OH = H >> 1, OW = W >> 1, PW = W + 2 * pad;
+  const int64_t nc = blockIdx.y;
+  const int ZW = W + 2 * zpad;
+  const int64_t zo = nc * (int64_t)(H + 2 * zpad) * ZW + (int64_t)zpad * ZW + zpad;
+  const float* zi = z + zo;
+  const float* ti = g2 ? g2 + zo : nullptr;
+  const float* gi = g + nc * (int64_t)OH * OW;
+  float* o = gz + nc * (int64_t)(H + 2 * pad) * PW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < OH * OW; i += gridDim.x * 256) {
+    const int wy = i / OW, wx = i - wy * OW;
+    const float* q = zi + (int64_t)(2 * wy) * ZW + 2 * wx;
+    const f2u r0 = *reinterpret_cast<const f2u*>(q), r1 = *reinterpret_cast<const f2u*>(q + ZW);
+    const float e[4] = {r0.x, r0.y, r1.x, r1.y};
+    const float m = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+    const float gv = gi[i];
+    int k = 4;                                   // index of the first maximum, if it is positive
+    if (m > 0.f) k = e[0] == m ? 0 : e[1] == m ? 1 : e[2] == m ? 2 : 3;
+    float v[4] = {k == 0 ? gv : 0.f, k == 1 ? gv : 0.f, k == 2 ? gv : 0.f, k == 3 ? gv : 0.f};
+    if (ti) {
+      const float* t = ti + (int64_t)(2 * wy) * ZW + 2 * wx;
+      const f2u t0 = *reinterpret_cast<const f2u*>(t), t1 = *reinterpret_cast<const f2u*>(t + ZW);
+      v[0] += e[0] > 0.f ? t0.x : 0.f;
+      v[1] += e[1] > 0.f ? t0.y : 0.f;
+      v[2] += e[2] > 0.f ? t1.x : 0.f;
+      v[3] += e[3] > 0.f ? t1.y : 0.f;
+    }
+    float* d = o + (int64_t)(2 * wy + pad) * PW + 2 * wx + pad;
+    *reinterpret_cast<f2u*>(d) = f2u{v[0], v[1]};
+    *reinterpret_cast<f2u*>(d + PW) = f2u{v[2], v[3]};
+    if (pad) {
+      if (wx == 0)
+        for (int r = 0; r < 2; ++r)
+          for (int c = 0; c < pad; ++c) d[r * PW - pad + c] = 0.f;
+      if (wx == OW - 1)
+        for (int r = 0; r < 2; ++r)
+          for (int c = 0; c < pad; ++c) d[r * PW + 2 + c] = 0.f;
+      if (wy == 0 || wy == OH - 1) {             // the border rows above / below this window's two columns (+ the corners at the row ends)
+        const int c_lo = wx == 0 ? -pad : 0, c_hi = wx == OW - 1 ? 2 + pad : 2;
+        for (int r = 1; r <= pad; ++r) {
+          float* b = wy == 0 ? d - (int64_t)r * PW : d + (int64_t)(1 + r) * PW;
+          for (int c = c_lo; c < c_hi; ++c) b[c] = 0.f;
+        }
+        if (OH == 1) {                           // one window row: both the top and the bottom border belong to it
+          for (int r = 1; r <= pad; ++r) {
+            float* b = d + (int64_t)(1 + r) * PW;
+            for (int c = c_lo; c < c_hi; ++c) b[c] = 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
 // out[nc][pad + y][pad + x] = (g + g2) * (z > 0), zero border: ReLU backward fused with the zero padding the adjoint convolution wants.
 // g (optional) is dense [H][W]; g2 (optional, a tap gradient) has z's layout.
 __global__ __launch_bounds__(256) void relu_mask_pad_kernel(const float* __restrict__ g, const float* __restrict__ g2, const float* __restrict__ z,
@@ -347,8 +407,13 @@ extern "C" int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int
   for (int c0 = 0; c0 < NC; c0 += 65535) {
     const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
     const int64_t zo = (int64_t)c0 * (H + 2 * zpad) * (W + 2 * zpad);
-    hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream,
-                       g + (int64_t)c0 * (H / 2) * (W / 2), z + zo, H, W, gz + (int64_t)c0 * PH * PW, zpad, g2 ? g2 + zo : nullptr, pad);
+    static const int per_element = getenv("VTS_MAXPOOL_BWD_ELEM") ? 1 : 0;
+    if (!per_element && H % 2 == 0 && W % 2 == 0)
+      hipLaunchKernelGGL(maxpool2_relu_bwd_win_kernel, dim3(blocks_1d((int64_t)(H / 2) * (W / 2)), nc), dim3(256), 0, (hipStream_t)stream,
+                         g + (int64_t)c0 * (H / 2) * (W / 2), z + zo, H, W, gz + (int64_t)c0 * PH * PW, zpad, g2 ? g2 + zo : nullptr, pad);
+    else
+      hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3(blocks_1d((int64_t)PH * PW), nc), dim3(256), 0, (hipStream_t)stream,
+                         g + (int64_t)c0 * (H / 2) * (W / 2), z + zo, H, W, gz + (int64_t)c0 * PH * PW, zpad, g2 ? g2 + zo : nullptr, pad);
   }
   VTS_CHECK_LAUNCH("vts_maxpool2_relu_bwd");
   return VTS_OK;
