@@ -183,6 +183,7 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     # from profiles/ -- but ONLY from a summary measured on exactly these kernel sources (csrc_sha16); otherwise null.
     roof["traffic"] = None
     src, prof = newest_profile("*_traffic_pmc.json")
+    traffic_prof = prof
     if prof is not None:
         num = den = 0.0
         for lbl, i in f["inst"].items():
@@ -215,8 +216,14 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     roof["algorithmic_bytes_per_launch_family"] = f["bytes"] / f["n"]
     roof["share_of_timed_kernels"] = f["t"] / total
     inst = sorted(f["inst"].items(), key=lambda kv: -kv[1][1])[:6]
+    def pmc_ratio(k, v):   # measured HBM bytes per launch of this instance (train-step launches only) / its algorithmic bytes per launch
+        ent = traffic_prof["kernels"].get(k.split("+")[0]) if traffic_prof else None
+        return round(ent["hbm_bytes_per_launch"] / (v[2] / v[0]), 3) if ent and v[2] > 0 else None
+
     roof["instances"] = [{"kernel": k, "launches": v[0], "avg_us": round(v[1] / v[0] * 1e6, 2), "bytes_per_launch": round(v[2] / v[0]),
-                          "flops_per_launch": round(v[3] / v[0]), "frac": round(v[4] / v[1], 4)} for k, v in inst]
+                          "flops_per_launch": round(v[3] / v[0]), "frac": round(v[4] / v[1], 4), "traffic_ratio": pmc_ratio(k, v)} for k, v in inst]
+    if roof["traffic"] is not None:
+        roof["traffic_ratio"] = roof["traffic"] / roof["algorithmic_bytes_per_launch_family"]
     breakdown = sorted(((k, v[1] * 1e3, v[0]) for k, v in agg.items()), key=lambda x: -x[1])
     roof["breakdown_ms"] = {k: round(ms, 3) for k, ms, _ in breakdown[:8]}
     roof["step_t_roof_ms"] = step_t_roof * 1e3
@@ -354,6 +361,10 @@ def main():
     ap.add_argument("--infer", action="store_true",
                     help="measure the inference forward instead (BASELINE config 4: generator only, 16 images/GPU): ms per image")
     ap.add_argument("--detail", type=str, default=None, help="write a per-(kernel, shape) timing table to this path")
+    ap.add_argument("--train_only", action="store_true",
+                    help="profiling form: warm-up + timed train steps on the resident batch and NOTHING else in the process (no fresh-input loop, "
+                         "no per-launch event step, no host-enqueue probes, no CPU baseline, no inference leg), so that every kernel row of a "
+                         "rocprofv3 / PMC pass over this command is launches-per-step x (warmup + steps) train-step launches")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -407,7 +418,7 @@ def main():
     # the same K steps with a FRESH host batch per step: set_input (H2D of S / I / M / patches, masking, candidate map) inside the timed
     # region, as a train.py loop pays it (`value` keeps the contract: inputs resident in HBM)
     fresh_ms = None
-    if world == 1 and args.model != "pix2pixHD" and not args.lpips:
+    if world == 1 and args.model != "pix2pixHD" and not args.lpips and not args.train_only:
         def pinned(b):   # what the package's DataLoader hands over (data/__init__.py: pin_memory=True)
             return {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
 
@@ -450,7 +461,7 @@ def main():
                 "ranks": world, "graph_segments": len(model._graphs) if getattr(model, "_graphs", None) else None}
 
     if rank == 0:
-        roof = kernel_roofline(model, batch, args.detail) if world == 1 else None
+        roof = kernel_roofline(model, batch, args.detail) if world == 1 and not args.train_only else None
         if roof is not None:
             # host enqueue time of one step (no sync): tells whether the step is launch-bound
             for key, flag in (("host_enqueue_ms_eager", False), ("host_enqueue_ms", model.opt.use_hip_graph)):
@@ -462,11 +473,11 @@ def main():
                 torch.cuda.synchronize()
                 model.opt.use_hip_graph = keep
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and args.model != "pix2pixHD" and not args.lpips:
+        if world == 1 and not args.no_cpu_baseline and args.model != "pix2pixHD" and not args.lpips and not args.train_only:
             cpu = cpu_baseline(args.size, style_dim, netG=args.netG)
         ms = dt / args.steps * 1e3
         infer_ms = None
-        if world == 1 and args.model != "pix2pixHD" and not args.lpips and args.netG == "unet256_custom" and args.batch == 4:
+        if world == 1 and args.model != "pix2pixHD" and not args.lpips and args.netG == "unet256_custom" and args.batch == 4 and not args.train_only:
             del model                       # (the 16-image forward builds its own model: BASELINE config 4)
             torch.cuda.empty_cache()
             idt, ib, _ = infer_measure(args, steps=50, warmup=5)
@@ -490,6 +501,7 @@ def main():
                                     else "LPIPS/CLIP terms off (no weights offline)"),
                 "global_batch": world * args.batch, "parallelism": "dp%d" % world, "losses_finite": finite,
                 "hip_graph": bool(opt.use_hip_graph), "d2_visualisation_pass": not args.no_viz,
+                "train_only": bool(args.train_only),
             },
             "roofline": roof, "cpu_baseline": cpu,
         }

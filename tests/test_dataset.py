@@ -143,11 +143,18 @@ def test_skit_dataset_matches_reference_cache(phase, mseeds, seed, pre, tmp_path
     assert "style_code" not in ds[0]
     if phase == "train":        # the package's addition: a precomputed style code per material becomes the batch key the skitG model reads
         np.save(str(tmp_path / "datasets" / "singleskit_matB_padded_400_x1" / "style_code.npy"), np.arange(512, dtype=np.float64))
+        kw = dict(material_list=["matA", "matB"], padded_size=400, data_len=3, preprocess=pre, random_scale_max=1.04, crop_size=320)
+        with pytest.raises(FileNotFoundError, match="matA"):      # a code for one material only: refused at construction, the missing one named
+            SkitDataset(dataset_opt("unused_root", phase, **kw))
+        np.save(str(tmp_path / "datasets" / "singleskit_matA_padded_400_x1" / "style_code.npy"), np.ones(7, dtype=np.float64))
+        with pytest.raises(ValueError, match="style_code_dim"):   # wrong length
+            SkitDataset(dataset_opt("unused_root", phase, style_code_dim=512, **kw))
+        np.save(str(tmp_path / "datasets" / "singleskit_matA_padded_400_x1" / "style_code.npy"), -np.arange(512, dtype=np.float64))
         random.seed(seed)
         np.random.seed(seed)
-        ds2 = SkitDataset(dataset_opt("unused_root", phase, material_list=["matA", "matB"], padded_size=400, data_len=3, preprocess=pre,
-                                      random_scale_max=1.04, crop_size=320))
-        assert "style_code" not in ds2[0] and ds2[1]["style_code"].dtype == torch.float32 and ds2[1]["style_code"].shape == (512,)
+        ds2 = SkitDataset(dataset_opt("unused_root", phase, style_code_dim=512, **kw))
+        assert ds2[1]["style_code"].dtype == torch.float32 and ds2[1]["style_code"].shape == (512,) and ds2[1]["style_code"][3] == 3
+        assert ds2[0]["style_code"][3] == -3 and ds2[2]["style_code"][3] == -3
         assert torch.equal(ds2[1]["S"], ds[1]["S"])
     assert ds[0]["name"] == ds[2]["name"] and ds[0]["S_paths"] == ds[1]["S_paths"] and ds[0]["M_paths"] != ds[1]["M_paths"]
     if phase == "train":

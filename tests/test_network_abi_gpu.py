@@ -93,6 +93,26 @@ def test_c_forward_with_the_tiled_style_code():
     assert torch.equal(engine.unet_forward_c(G, x, style_tile=tile), y_py)
 
 
+def test_inference_with_every_decoder_layer_separate_takes_the_python_schedule():
+    """num_layer_separate == num_downs (the reference asserts 0 <= nls <= nd, models/networks.py:1430-1645, and builds up{nd-1}_T): the C
+    entry refuses a generator without a shared decoder trunk, so the inference forward must fall back to the Python schedule, not raise"""
+    from models.networks import CustomUnetGenerator
+    from vts import engine
+
+    dev = torch.device("cuda:0")
+    G = CustomUnetGenerator(9, 5, num_downs=8, ngf=10, num_layer_separate=8).to(dev)
+    sd = detrand.test_weights(nets.g_param_shapes(num_layer_separate=8), 91)
+    G.load_state_dict(sd)
+    G.eval()
+    assert not engine.unet_c_ok(G, None)
+    x = detrand.uniform((1, 9, 256, 256), 6, "x")
+    y = engine.unet_forward_infer(G, x.to(dev))
+    ref = nets.unet_forward(sd, x, num_layer_separate=8)
+    ref = ref[0] if isinstance(ref, (tuple, list)) else ref
+    torch.cuda.synchronize()
+    assert rel(y, ref) < 1e-3       # north_star tolerance (rel-L2, fp32)
+
+
 def test_bad_descriptors_are_refused_through_the_abi():
     import ctypes as C
 

@@ -4,7 +4,7 @@ O=gpurun_out/pmcsq; rm -rf $O; mkdir -p $O
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
 i=$((i+1))
-rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o run -- python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_graph > $O/p$i.log 2>&1
+rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o run -- python bench.py --steps 2 --warmup 1 --train_only --no_graph > $O/p$i.log 2>&1
 done
 python - <<'PY'
 import csv,glob,collections,re,json

@@ -21,14 +21,18 @@ def kernel_key(name):
     return m.group(1) if m else name
 
 
-def collect(d, counter):
+def collect(d, counter, by_grid=False):
+    """{instance: [launches, sum]}; by_grid: {(instance, "grid x wg"): [launches, sum]} -- one instance serves several shapes of a step"""
     acc = {}
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
                 if row["Counter_Name"] != counter:
                     continue
-                a = acc.setdefault(kernel_key(row["Kernel_Name"]), [0, 0.0])
+                k = kernel_key(row["Kernel_Name"])
+                if by_grid:
+                    k = (k, "%s/%s" % (row.get("Grid_Size", "?"), row.get("Workgroup_Size", "?")))
+                a = acc.setdefault(k, [0, 0.0])
                 a[0] += 1
                 a[1] += float(row["Counter_Value"])
     return acc
@@ -50,9 +54,15 @@ def main(fetch_dir, write_dir, dst, note=""):
         w_kb = wv / wc if wc else 0.0
         kernels[k] = {"launches_sampled": max(fc, wc), "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
                       "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0}
+    feg, wrg = collect(fetch_dir, "FETCH_SIZE", True), collect(write_dir, "WRITE_SIZE", True)
+    for (k, g) in sorted(set(feg) | set(wrg)):
+        fc, fv = feg.get((k, g), [0, 0.0])
+        wc, wv = wrg.get((k, g), [0, 0.0])
+        kernels[k].setdefault("by_grid", {})[g] = {"launches_sampled": max(fc, wc),
+                                                   "hbm_bytes_per_launch": (2.0 * (fv / fc if fc else 0.0) + (wv / wc if wc else 0.0)) * 1024.0}
     out = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) over "
-                  "`python bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_graph`; mean per launch of each kernel "
-                  "instance; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)",
+                  "`python bench.py --steps 2 --warmup 1 --train_only --no_graph`; mean per launch of each kernel "
+                  "instance (train steps only: launches_sampled = launches per step x 3; by_grid splits an instance by its grid size / workgroup size); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)",
            "note": note, "csrc_sha16": csrc_sha16(), "kernels": kernels}
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)

@@ -93,13 +93,23 @@ extern "C" int vts_comm_init(const void* id128, int rank, int world, void** comm
   Rccl* R = rccl();
   VTS_CHECK_ARG(R, "vts_comm_init: librccl.so could not be loaded (set VTS_RCCL_LIB)");
   Comm* c = (Comm*)calloc(1, sizeof(Comm));
+  VTS_CHECK_ARG(c, "vts_comm_init: out of host memory");
   ncclUniqueId_ id;
   memcpy(&id, id128, sizeof id);
-  RCCL_CHECK(R->CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+  if (R->CommInitRank(&c->comm, world, id, rank) != 0) {
+    free(c);
+    vts_set_error("vts_comm_init: ncclCommInitRank failed (rank %d of %d)", rank, world);
+    return VTS_ERR_LAUNCH;
+  }
   c->rank = rank;
   c->world = world;
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+    if (c->done) (void)hipEventDestroy(c->done);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    (void)R->CommDestroy(c->comm);
+    free(c);
     vts_set_error("vts_comm_init: could not create the side stream / events");
     return VTS_ERR_LAUNCH;
   }

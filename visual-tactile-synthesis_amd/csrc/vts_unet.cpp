@@ -206,6 +206,15 @@ extern "C" int vts_unet_forward(const vts_unet_desc* d, float* ws, int64_t ws_fl
     if (rc != VTS_OK) return rc;
   }
   bool forked = false;
+  // an error after the fork still joins the side stream (inside a graph capture a dangling fork invalidates the capture; outside, the
+  // side stream would be left unordered with the caller's stream)
+  auto finish = [&](int rc) {
+    if (forked && (hipEventRecord(join, (hipStream_t)d->side_stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, join, 0) != hipSuccess) && rc == VTS_OK) {
+      vts_set_error("vts_unet_forward: joining the side stream failed");
+      return (int)VTS_ERR_LAUNCH;
+    }
+    return rc;
+  };
   for (int k = 0; k < n; ++k) {
     vts_conv_desc& c = L[k].c;
     // the visual branch's own layers follow the trunk on `stream`; the tactile branch (all at the end of the list) runs on the side
@@ -213,15 +222,19 @@ extern "C" int vts_unet_forward(const vts_unet_desc* d, float* ws, int64_t ws_fl
     const bool own0 = lanes && !forked && k >= d->num_downs + (d->num_downs - d->num_layer_separate);
     if (own0) {
       VTS_CHECK_HIP(hipEventRecord(fork, (hipStream_t)stream));
-      VTS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)d->side_stream, fork, 0));
       forked = true;
+      if (hipStreamWaitEvent((hipStream_t)d->side_stream, fork, 0) != hipSuccess) {
+        forked = false;
+        vts_set_error("vts_unet_forward: forking the side stream failed");
+        return VTS_ERR_LAUNCH;
+      }
     }
     const int lane = lanes ? L[k].lane : 0;
     void* st = lane ? d->side_stream : stream;
     if ((int64_t)c.OH * c.OW <= 64 * 64) { c.ws = ws + P.conv_ws[lane]; c.ws_floats = P.conv_ws_floats; }
     if (!L[k].normed) {
       const int rc = vts_conv4x4(&c, st);
-      if (rc != VTS_OK) return rc;
+      if (rc != VTS_OK) return finish(rc);
       continue;
     }
     vts_norm_desc nd{};
@@ -232,14 +245,10 @@ extern "C" int vts_unet_forward(const vts_unet_desc* d, float* ws, int64_t ws_fl
     nd.scale = stt; nd.shift = stt + NC; nd.mean_out = stt + 2 * NC; nd.rstd_out = stt + 3 * NC;
     int fused = 0;
     int rc = vts_conv4x4_norm(&c, &nd, ws + P.stat_ws[lane], P.stat_ws_floats, &fused, st);
-    if (rc != VTS_OK) return rc;
+    if (rc != VTS_OK) return finish(rc);
     if (fused >= 2) rc = vts_norm_stats_from_partials(&nd, ws + P.stat_ws[lane], fused - 2, st);
     else if (fused == 0) rc = vts_norm_stats(&nd, ws + P.conv_ws[lane], st);
-    if (rc != VTS_OK) return rc;
+    if (rc != VTS_OK) return finish(rc);
   }
-  if (forked) {
-    VTS_CHECK_HIP(hipEventRecord(join, (hipStream_t)d->side_stream));
-    VTS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, join, 0));
-  }
-  return VTS_OK;
+  return finish(VTS_OK);
 }

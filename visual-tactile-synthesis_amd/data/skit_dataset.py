@@ -69,6 +69,15 @@ class SkitDataset(SingleSkitDataset):
             #  <material folder>/style_code.npy [style_code_dim], becomes the batch key `style_code` the skitG model of this package reads)
             sc = os.path.join(dataroot, "style_code.npy")
             self.style_codes.append(np.load(sc).astype(np.float32).reshape(-1) if os.path.exists(sc) else None)
+        # all or none: a batch collated from several materials needs the same keys in every entry, and skitG reads `style_code` of each
+        have = [c is not None for c in self.style_codes]
+        if any(have) and not all(have):
+            raise FileNotFoundError("style_code.npy is present for some materials but missing for: %s (expected <dataset folder>/style_code.npy "
+                                    "for every material of --material_list, or for none)" % [m for m, h in zip(materials, have) if not h])
+        dim = getattr(opt, "style_code_dim", None)
+        for m, c in zip(materials, self.style_codes):
+            if c is not None and dim is not None and c.shape[0] != int(dim):
+                raise ValueError("style_code.npy of material %s holds %d values, --style_code_dim is %d" % (m, c.shape[0], int(dim)))
         if opt.sketch_nc == 1:
             self.S_imgs = [ImageOps.grayscale(Image.open(p)) for p in self.S_paths]
         else:

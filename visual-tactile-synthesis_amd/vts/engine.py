@@ -200,6 +200,8 @@ def unet_c_ok(G, style_code):
     """can vts_unet_forward run this generator's inference forward?  (plain U-Net, or the style code tiled into the innermost block)"""
     if not UNET_C or G.num_downs > L.UNET_MAX_DOWNS:
         return False
+    if G.num_layer_separate >= G.num_downs:     # no shared decoder trunk (every up block duplicated): the C entry's check() refuses it
+        return False
     if G.training and dropout_layers(G):     # a forward outside eval() keeps the Dropout of the Up blocks active
         return False
     if style_code is None:
