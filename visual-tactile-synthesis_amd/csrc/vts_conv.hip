@@ -262,11 +262,12 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   k.dm = d->dmask.data; k.dmsc = d->dmask.scale; k.dmsh = d->dmask.shift; k.dmns = d->dmask.nstride;
   k.dm_act = d->dmask_act; k.dmC = d->dmask.C;
   k.accumulate = d->accumulate;
-  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.trace = nullptr; k.stat_part = nullptr; k.stat_spl = 0; k.bsum_part = nullptr;
+  k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.stat_part = nullptr; k.stat_spl = 0; k.bsum_part = nullptr;
+#ifdef VTS_PROFILING
   static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
   k.ablate = ablate;
-  static const int stagger = getenv("VTS_STAGGER") ? atoi(getenv("VTS_STAGGER")) : 0;
-  k.stagger = stagger;
+  k.trace = nullptr;
+#endif
   static const int xcd_swizzle = getenv("VTS_XCD_SWIZZLE") ? atoi(getenv("VTS_XCD_SWIZZLE")) : 1;
   k.xcd_swizzle = xcd_swizzle;
   static const int direct_epi = getenv("VTS_DIRECT_EPI") ? atoi(getenv("VTS_DIRECT_EPI")) : 1;

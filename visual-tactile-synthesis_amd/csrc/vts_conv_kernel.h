@@ -29,12 +29,9 @@ struct ConvK {
   const float* ident;  // {1, 0}
   float slope_in;      // input activation as t > 0 ? t : slope * t
   int identity_in;     // no affine on either source and no input activation
-  int ablate;       // profiling only (env VTS_ABLATE): 1 skip global loads, 2 skip MFMA, 4 skip epilogue
   int wbytes;       // extent of the weight tensor view in bytes (buffer descriptor of the weight loads)
   int xcd_swizzle;  // 1: XCD-aware workgroup order (default); VTS_XCD_SWIZZLE=0 keeps the hardware order
   int direct_epi;   // 1: stores straight from the accumulator registers (default); 0: through LDS (VTS_DIRECT_EPI=0)
-  int stagger;      // start-up stagger in units of ~3.4 us (s_sleep 127): workgroup w of a co-resident set waits (w % 3) * stagger units
-  unsigned long long* trace;   // profiling only (env VTS_CONV_TRACE): per workgroup 8 x 64-bit: hw id, then s_memrealtime (100 MHz) at the phase boundaries
   int tiles_x;      // tiles per row band; a workgroup walks the run [bx * tiles_x / gridDim.x, (bx + 1) * tiles_x / gridDim.x) of them
   // round 3: statistics of the output fused into the direct epilogue.  Every WAVE writes (mean, M2, count) of its rows of the tile per
   // output channel -- the partial format of stats_partial_kernel (vts_norm.hip), slot = (tile row * tiles_x + tile) * 4 + wave of
@@ -48,7 +45,17 @@ struct ConvK {
   // (S1, S2') pair per wave and tile in the layout of norm_bwd_partial_kernel: the stand-alone partial pass (a read of dy AND x)
   // and its launch disappear.
   float* bsum_part;
+#ifdef VTS_PROFILING   // (make PROFILING=1: the production kernels carry none of this -- their bodies are 40 - 60 KB against a 64 KB instruction cache)
+  int ablate;                  // env VTS_ABLATE: 1 skip global loads, 2 skip MFMA, 4 skip epilogue
+  unsigned long long* trace;   // env VTS_CONV_TRACE: per workgroup 8 x 64-bit: hw id, then s_memrealtime (100 MHz) at the phase boundaries
+#endif
 };
+
+#ifdef VTS_PROFILING
+#define VTS_ABL(p, bit) ((p).ablate & (bit))
+#else
+#define VTS_ABL(p, bit) 0
+#endif
 
 
 extern thread_local int t_stat_spl;   // statistics slots per (n, channel) of the last launch (defined in vts_conv.hip)
@@ -75,8 +82,23 @@ __device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
 
 // Output staging region of one epilogue pass: 16 output channels x ER rows x EC columns, plane pitch odd
 // so that the 16 channel planes land on distinct LDS banks.
+// Minimum waves per SIMD the register allocation must leave room for (second argument of __launch_bounds__).  Without it hipcc budgets a
+// 256-thread kernel for 512 registers per lane and splits them into architectural + accumulation halves: the 64-accumulator instances of
+// the transposed stride-2 operator came out at 152 - 160 registers (3 waves per SIMD) although they fit 118 - 125 (4 waves) without a
+// spill -- and with 3 workgroups per CU the 1024-workgroup launches of the decoder (40 -> 10 at 512^2) ran a second, one-third-full round.
+// Measured per instance on the shapes of the step (tools/mb_conv_ab.py, profiles/r05b_conv_ab_launch_bounds.txt): 40 -> 10 transposed
+// 62.8 -> 57.2 us, its adjoint-of-down1 twin 39.5 -> 33.1; the small-tile members 1 - 4 % faster; but the forward-convolution instances with
+// >= 3 output-channel groups or 64-column tiles got SLOWER under the tighter budget (20 -> 80 at 256^2: 36.1 -> 46.2 us, 10 -> 40 at 512^2:
+// 52.3 -> 59.0, 10 -> 20: 35.2 -> 37.0) and keep the unconstrained allocation, as do the tile-run instances (their in-loop epilogue spills).
+constexpr int conv_min_waves(int mode, int s, int nr, int rw, int mt, bool run) {
+  if (run) return 1;
+  if (mode == 0 && (nr >= 3 || mt >= 4)) return 1;
+  const int acc_regs = rw * mt * ((mode == 1 && s == 2) ? 4 : 1) * nr * 4;
+  return acc_regs <= 64 ? 4 : (acc_regs <= 96 ? 3 : 2);
+}
+
 template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN, int STATS>
-__global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void conv4x4_kernel(const ConvK p) {
   constexpr int P = (MODE == 1 && S == 2) ? 4 : 1;
   constexpr int TY = 4 * RW, TX = 16 * MT;
   constexpr int PR = MODE == 0 ? (TY - 1) * S + 4 : (S == 2 ? TY + 2 : TY + 3);
@@ -96,7 +118,8 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   constexpr int NWV = CK * NR;                         // ... weights (CK*16*NR*16 / 256)
   constexpr int EC = (P == 4) ? 2 * TX : TX;           // epilogue pass: TY rows x EC columns x 16 channels
   constexpr int EPL = TY * EC + 1;
-  constexpr int PATCH_FLOATS = CK * PR * PCP, W_FLOATS = CK * 16 * COP, OUT_FLOATS = 16 * EPL;
+  constexpr int PATCH_FLOATS = CK * PR * PCP, W_FLOATS = CK * 16 * COP;
+  constexpr int OUT_FLOATS = (NR == 1 && RW == 1 && MT == 2) ? 16 * EPL : 0;  // staging of the LDS epilogue (only the small-grid instance carries it)
   constexpr int LDS_FLOATS = (PATCH_FLOATS + W_FLOATS) > OUT_FLOATS ? (PATCH_FLOATS + W_FLOATS) : OUT_FLOATS;
 
   __shared__ float lds[LDS_FLOATS];
@@ -106,17 +129,15 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   float* lds_patch = lds;
   float* lds_w = lds + PATCH_FLOATS;
 
-  if (p.stagger > 0) {
-    // co-resident workgroups start in lock-step and would load / multiply / store in phase; shift every third one
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int units = ((lin >> 8) % 3) * p.stagger;
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef VTS_PROFILING
   const int trace_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   auto stamp = [&](int i) {
     if (p.trace && tid == 0) p.trace[(int64_t)trace_wg * 8 + i] = i == 0 ? (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) : __builtin_amdgcn_s_memrealtime();
   };
+#else
+  auto stamp = [](int) {};
+#endif
   stamp(0);
   stamp(1);
   // provably wave-uniform wave index: all per-row staging state (bounds, row pointers, normalisation
@@ -531,7 +552,7 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   stamp(2);
   if (units > 0) {
     set_tile(tile_begin);
-    if (!(p.ablate & 1)) load_chunk(chunk_begin, true);
+    if (!VTS_ABL(p, 1)) load_chunk(chunk_begin, true);
     stamp(3);
     store_chunk(true);
   }
@@ -547,14 +568,14 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
     }
     if (more) {
       if (RUN && tile_n != tile) set_tile(tile_n);
-      if (!(p.ablate & 1)) load_chunk(chunk_n, reload_w);
+      if (!VTS_ABL(p, 1)) load_chunk(chunk_n, reload_w);
     }
     // ---- MFMA accumulate ----
     // One group = the four taps (K = 4) of one (channel, ky) or (channel, phase): NR weight fragments + RW x MT patch fragments,
     // then RW x MT x NR MFMAs.  The fragments of the NEXT group are read (two register sets, ping-pong) before the MFMAs of the
     // current one are issued, so LDS latency hides behind 32-cycle MFMAs even with one wave on the SIMD; the scheduling barriers
     // keep the compiler from sinking the reads back to their first use (it did: read -> wait -> 2 MFMA, 70 % issue rate).
-    const int cvalid = (p.ablate & 2) ? 0 : min(CK, p.Cin - chunk * CK);   // channels beyond Cin are zero: skip them
+    const int cvalid = VTS_ABL(p, 2) ? 0 : min(CK, p.Cin - chunk * CK);   // channels beyond Cin are zero: skip them
     {
       constexpr int NA = RW * MT;
       auto rd = [&](int c, int g, float (&av)[NA], float (&bv)[NR]) {
@@ -580,30 +601,65 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
             for (int nr = 0; nr < NR; ++nr)
               acc[r][mt][P == 4 ? g : 0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r * MT + mt], bv[nr], acc[r][mt][P == 4 ? g : 0][nr], 0, 0, 0);
       };
-      float ax[NA], bx[NR], ay[NA], by_[NR];
-      if (cvalid > 0) rd(0, 0, ax, bx);
-      for (int c = 0; c < cvalid; ++c) {
-        rd(c, 1, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(0, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(c, 2, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(1, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(c, 3, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(2, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < cvalid) rd(c + 1, 0, ax, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(3, ay, by_);
-        __builtin_amdgcn_sched_barrier(0);
+#ifndef VTS_DEEP_MAX
+#define VTS_DEEP_MAX 4
+#endif
+      if constexpr (NA * NR <= VTS_DEEP_MAX) {
+        // Short groups (<= 4 MFMAs = 128 cycles of the matrix pipe): the fragments are read THREE groups ahead (four register sets, set = tap
+        // group).  One group ahead (the form below) gives a read 64 - 128 cycles before its s_waitcnt; a wave that has its SIMD to itself
+        // -- the k-split / cout-split launches of the inner layers run 1 - 2 workgroups per CU -- then waits out the rest of the LDS latency
+        // in every group (ISA: read, read, s_waitcnt lgkmcnt(2), 2 MFMAs; measured 65 - 120 cycles per MFMA on those launches).
+        float av[4][NA], bv[4][NR];
+        if (cvalid > 0) {
+          rd(0, 0, av[0], bv[0]);
+          rd(0, 1, av[1], bv[1]);
+          rd(0, 2, av[2], bv[2]);
+        }
+        for (int c = 0; c < cvalid; ++c) {
+          const int cn = min(c + 1, CK - 1);     // (past the last channel: in-bounds reads nobody uses)
+          rd(c, 3, av[3], bv[3]);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(0, av[0], bv[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(cn, 0, av[0], bv[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(1, av[1], bv[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(cn, 1, av[1], bv[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(2, av[2], bv[2]);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(cn, 2, av[2], bv[2]);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(3, av[3], bv[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        float ax[NA], bx[NR], ay[NA], by_[NR];
+        if (cvalid > 0) rd(0, 0, ax, bx);
+        for (int c = 0; c < cvalid; ++c) {
+          rd(c, 1, ay, by_);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(0, ax, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(c, 2, ax, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(1, ay, by_);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(c, 3, ay, by_);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(2, ax, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c + 1 < cvalid) rd(c + 1, 0, ax, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(3, ay, by_);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     if (u == 0) stamp(5);
     if (RUN && direct && tile_n != tile) {   // tile complete: its accumulators go out while the next tile's loads are in flight
-      if (p.ablate & 4) {
+      if (VTS_ABL(p, 4)) {
         if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
       } else {
         epilogue_direct(tile * TX);
@@ -621,7 +677,7 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   if (RUN) return;   // (the host launches RUN instances only with the direct epilogue)
   const int tx0 = tile_begin * TX;
   if (direct) {
-    if (!(p.ablate & 4)) epilogue_direct(tx0);
+    if (!VTS_ABL(p, 4)) epilogue_direct(tx0);
     else if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
     stamp(7);
     return;
@@ -634,7 +690,7 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const ConvK p) {
   // C/D layout of a 16x16 tile: col (cout) = lane&15, row (pixel) = (lane>>4)*4 + reg.
   // One pass handles 16 output channels and, for transposed s2, one output row parity (both column
   // parities interleaved, so rows are contiguous in x).
-  if (p.ablate & 4) {
+  if (VTS_ABL(p, 4)) {
     if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
     return;
   }
@@ -774,6 +830,7 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
     vts_set_error("vts_conv4x4: this tile instance has no LDS epilogue (VTS_DIRECT_EPI=0 / output beyond 30-bit offsets)");
     return VTS_ERR_UNSUPPORTED;
   }
+#ifdef VTS_PROFILING
   // VTS_CONV_TRACE=<file>: phase time stamps of every workgroup of the launches whose kernel matches VTS_CONV_TRACE_KERNEL
   // ("MODE,S,NR,RW,MT"), appended as text rows (tools/conv_trace.py draws the occupancy / phase overlap from them)
   static const char* trace_path = getenv("VTS_CONV_TRACE");
@@ -789,6 +846,7 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
     }
   }
   k.trace = trace_dev;
+#endif
   // (the statistics epilogue is its own instantiation: inside the shared one it raised the register count of EVERY launch of the
   //  template -- e.g. 110 -> 199 VGPRs and occupancy 2 -> 1 on the 40 -> 10 transposed layer -- whether statistics were asked for or not)
   if (k.stat_part) {
@@ -804,6 +862,7 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d, %s, %s>%s", MODE, S, NR, RW, MT, CK, (run > 1 && NR <= 2) ? "true" : "false",   // as rocprofv3 names the instance
                  k.stat_part ? "1" : (k.bsum_part ? "2" : "0"), KS > 1 ? "+ksplit" : (CG > 1 ? "+coutsplit" : ""));
   VTS_CHECK_LAUNCH("vts_conv4x4");
+#ifdef VTS_PROFILING
   if (trace_dev) {
     (void)hipStreamSynchronize(st);
     unsigned long long* h = (unsigned long long*)malloc(trace_wgs * 64);
@@ -821,6 +880,7 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
     free(h);
     (void)hipFree(trace_dev);
   }
+#endif
   return VTS_OK;
 }
 
