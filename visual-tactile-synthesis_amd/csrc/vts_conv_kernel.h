@@ -65,10 +65,10 @@ int vts_conv_full_m0s1(const ConvK& k, int nr, int N, hipStream_t st);
 int vts_conv_full_m0s2(const ConvK& k, int nr, int N, hipStream_t st);
 int vts_conv_full_m1s1(const ConvK& k, int nr, int N, hipStream_t st);
 int vts_conv_full_m1s2(const ConvK& k, int nr, int N, hipStream_t st);
-int vts_conv_split_m0s1(const ConvK& k, int N, hipStream_t st, int CG, int KS);
-int vts_conv_split_m0s2(const ConvK& k, int N, hipStream_t st, int CG, int KS);
-int vts_conv_split_m1s1(const ConvK& k, int N, hipStream_t st, int CG, int KS);
-int vts_conv_split_m1s2(const ConvK& k, int N, hipStream_t st, int CG, int KS);
+int vts_conv_split_m0s1(const ConvK& k, int N, hipStream_t st, int CG, int KS, int ck);
+int vts_conv_split_m0s2(const ConvK& k, int N, hipStream_t st, int CG, int KS, int ck);
+int vts_conv_split_m1s1(const ConvK& k, int N, hipStream_t st, int CG, int KS, int ck);
+int vts_conv_split_m1s2(const ConvK& k, int N, hipStream_t st, int CG, int KS, int ck);
 
 namespace {
 
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
   constexpr int PC = MODE == 0 ? (TX - 1) * S + 4 : (S == 2 ? TX + 2 : TX + 3);
   constexpr int PCP = PC + 1;
   constexpr int COP = (NR % 2 == 1) ? NR * 16 : NR * 16 + 16;
-  static_assert(CK == 4, "staging maps wave w to input channel w of the chunk");
+  static_assert(CK % 4 == 0 && CK >= 4 && CK <= 16, "staging maps wave w to the input channels w, w + 4, ... of the chunk");
+  constexpr int CKW = CK / 4;                          // channels of a chunk one wave stages
   // Row-wise staging: wave w stages the PR rows of channel w of the chunk, 64 columns per load.  A short
   // remainder (<= 16 columns) is staged element-wise instead of by a mostly idle 64-lane piece.
   constexpr int REM = PC % 64;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
   constexpr int NROWS = CK * PR;
   constexpr int NPV = PR * NCM > 0 ? PR * NCM : 1;      // prefetch registers: row-wise part of the patch
   constexpr int NTV = (NROWS * TW + 255) / 256 > 0 ? (NROWS * TW + 255) / 256 : 1;  // ... tail columns
-  constexpr int NWV = CK * NR;                         // ... weights (CK*16*NR*16 / 256)
+  constexpr int NWV = CKW * NR;                        // ... weights (CK*16*NR*16 floats / 256 threads / 4 per load)
   constexpr int EC = (P == 4) ? 2 * TX : TX;           // epilogue pass: TY rows x EC columns x 16 channels
   constexpr int EPL = TY * EC + 1;
   constexpr int PATCH_FLOATS = CK * PR * PCP, W_FLOATS = CK * 16 * COP;
@@ -222,12 +223,16 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
   //    in cout, so the LDS stores ([tap][cout], cout fastest) are bank-conflict-free (the old tap-fastest mapping was 16-way).
   constexpr int TPR = TW > 0 ? 64 / TW : 1;            // patch rows per tail load
   static_assert(TW == 0 || PR <= TPR, "one tail load covers all patch rows");
-  float pv[NPV], tv = 0.f;
-  f32x4 wv[NR];
+  float pv[CKW][NPV], tv[CKW];
+  f32x4 wv[NWV];
 #pragma unroll
-  for (int i = 0; i < NPV; ++i) pv[i] = 0.f;
+  for (int h = 0; h < CKW; ++h) {
+    tv[h] = 0.f;
 #pragma unroll
-  for (int i = 0; i < NR; ++i) wv[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    for (int i = 0; i < NPV; ++i) pv[h][i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) wv[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
 
   const int iplane = p.IH * p.IW;
   const float* sb0 = p.s0 + n * p.ns0;
@@ -261,15 +266,21 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
       vo_t = (r_t < PR && ix >= 0 && ix < p.IW) ? (unsigned)(r_t * p.IW + ix) * 4u : OOB_OFF;
     }
   };
-  float wsc = 1.f, wsh = 0.f;
-  unsigned cur_nrec = 0;
+  float wsc[CKW], wsh[CKW];
+  unsigned cur_nrec[CKW];
+#pragma unroll
+  for (int h = 0; h < CKW; ++h) {
+    wsc[h] = 1.f;
+    wsh[h] = 0.f;
+    cur_nrec[h] = 0;
+  }
 
   // weights: chunk-invariant part of the per-thread unit decode (unit = the 4 kx taps of one (cout, chunk channel, ky))
   constexpr int NCO = NR * 16;
-  unsigned wvo[NR];
-  int wc[NR], wld[NR][4];
+  unsigned wvo[NWV];
+  int wc[NWV], wld[NWV][4];
 #pragma unroll
-  for (int e = 0; e < NR; ++e) {
+  for (int e = 0; e < NWV; ++e) {
     const int u = tid + e * 256;
     const int co = u % NCO, rest = u / NCO;
     const int ky = rest & 3, c = rest >> 2;
@@ -292,33 +303,36 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
 
   auto load_chunk = [&](int chunk, bool with_w) {
     const int cbase = chunk * CK;
-    const int cic = cbase + wave + opaque_zero();
-    {
-      const int ccl = min(cic, p.Cin - 1);
-      const bool first = ccl < p.C0;
-      const int cl = first ? ccl : ccl - p.C0;
-      const float* scp = first ? p.sc0 : p.sc1;
-      const float* shp = first ? p.sh0 : p.sh1;
-      const int aidx = n * (first ? p.C0 : p.C1) + cl;
-      const bool hsc = scp != nullptr, hsh = shp != nullptr;
-      wsc = (hsc ? scp : p.ident)[hsc ? aidx : 0];
-      wsh = (hsh ? shp : p.ident)[hsh ? aidx : 1];
+#pragma unroll
+    for (int h = 0; h < CKW; ++h) {
+      const int cic = cbase + wave + 4 * h + opaque_zero();
+      {
+        const int ccl = min(cic, p.Cin - 1);
+        const bool first = ccl < p.C0;
+        const int cl = first ? ccl : ccl - p.C0;
+        const float* scp = first ? p.sc0 : p.sc1;
+        const float* shp = first ? p.sh0 : p.sh1;
+        const int aidx = n * (first ? p.C0 : p.C1) + cl;
+        const bool hsc = scp != nullptr, hsh = shp != nullptr;
+        wsc[h] = (hsc ? scp : p.ident)[hsc ? aidx : 0];
+        wsh[h] = (hsh ? shp : p.ident)[hsh ? aidx : 1];
+      }
+      const bool cok = cic < p.Cin;
+      const int cc = cok ? cic : 0;
+      const bool first = cc < p.C0;
+      const float* base = (first ? sb0 : sb1) + (int64_t)(first ? cc : cc - p.C0) * iplane;
+      cur_nrec[h] = cok ? (unsigned)iplane * 4u : 0u;
+      const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)cur_nrec[h], 0x00020000);
+#pragma unroll
+      for (int r = 0; r < PR; ++r)
+#pragma unroll
+        for (int cm = 0; cm < NCM; ++cm) pv[h][r * NCM + cm] = ld_buf(rs, vo_m[cm] + row0 + r * rstep);
+      if (TW > 0) tv[h] = ld_buf(rs, vo_t + row0);
     }
-    const bool cok = cic < p.Cin;
-    const int cc = cok ? cic : 0;
-    const bool first = cc < p.C0;
-    const float* base = (first ? sb0 : sb1) + (int64_t)(first ? cc : cc - p.C0) * iplane;
-    cur_nrec = cok ? (unsigned)iplane * 4u : 0u;
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)cur_nrec, 0x00020000);
-#pragma unroll
-    for (int r = 0; r < PR; ++r)
-#pragma unroll
-      for (int cm = 0; cm < NCM; ++cm) pv[r * NCM + cm] = ld_buf(rs, vo_m[cm] + row0 + r * rstep);
-    if (TW > 0) tv = ld_buf(rs, vo_t + row0);
     if (with_w) {
       const int wsoff = cbase * p.ws_ci * 4;
 #pragma unroll
-      for (int e = 0; e < NR; ++e)
+      for (int e = 0; e < NWV; ++e)
         wv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(cbase + wc[e] < p.Cin ? wvo[e] : OOB_OFF), wsoff, 0));
     }
   };
@@ -332,19 +346,22 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
 
   auto store_patch = [&](auto plain_tag) {
     constexpr bool PLAIN = decltype(plain_tag)::value;
-    float* dst = lds_patch + wave * PR * PCP;
 #pragma unroll
-    for (int r = 0; r < PR; ++r)
+    for (int h = 0; h < CKW; ++h) {
+      float* dst = lds_patch + (wave + 4 * h) * PR * PCP;
 #pragma unroll
-      for (int cm = 0; cm < NCM; ++cm) {
-        float v = pv[r * NCM + cm];
-        if (!PLAIN) v = finish(v, wsc, wsh, vo_m[cm] + row0 + r * rstep < cur_nrec);
-        dst[r * PCP + colw[cm]] = v;
+      for (int r = 0; r < PR; ++r)
+#pragma unroll
+        for (int cm = 0; cm < NCM; ++cm) {
+          float v = pv[h][r * NCM + cm];
+          if (!PLAIN) v = finish(v, wsc[h], wsh[h], vo_m[cm] + row0 + r * rstep < cur_nrec[h]);
+          dst[r * PCP + colw[cm]] = v;
+        }
+      if (TW > 0) {
+        float v = tv[h];
+        if (!PLAIN) v = finish(v, wsc[h], wsh[h], vo_t + row0 < cur_nrec[h]);
+        dst[dst_t] = v;
       }
-    if (TW > 0) {
-      float v = tv;
-      if (!PLAIN) v = finish(v, wsc, wsh, vo_t + row0 < cur_nrec);
-      dst[dst_t] = v;
     }
   };
 
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
     else store_patch(TagF());
     if (with_w) {
 #pragma unroll
-      for (int e = 0; e < NR; ++e)
+      for (int e = 0; e < NWV; ++e)
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) lds_w[wld[e][kx]] = wv[e][kx];
     }
@@ -825,6 +842,7 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
     if (run > tiles_x) run = tiles_x;
     if (run < 1) run = 1;
   }
+  if (CK != 4) run = 1;
   dim3 grid(cdiv(tiles_x, run), tiles_y, N * CG * KS);
   if (!(NR == 1 && RW == 1 && MT == 2) && (k.part || !k.direct_epi)) {
     vts_set_error("vts_conv4x4: this tile instance has no LDS epilogue (VTS_DIRECT_EPI=0 / output beyond 30-bit offsets)");
@@ -849,14 +867,17 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
 #endif
   // (the statistics epilogue is its own instantiation: inside the shared one it raised the register count of EVERY launch of the
   //  template -- e.g. 110 -> 199 VGPRs and occupancy 2 -> 1 on the 40 -> 10 transposed layer -- whether statistics were asked for or not)
+  // (tile runs only exist in 4-channel steps: they serve the layers of <= 4 chunks)
+  constexpr bool RUNI = (NR <= 2) && CK == 4;
+  if (CK != 4) run = 1;
   if (k.stat_part) {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 1>), grid, dim3(256), 0, st, k);
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, RUNI, 1>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 1>), grid, dim3(256), 0, st, k);
   } else if (k.bsum_part) {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 2>), grid, dim3(256), 0, st, k);
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, RUNI, 2>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 2>), grid, dim3(256), 0, st, k);
   } else {
-    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, (NR <= 2), 0>), grid, dim3(256), 0, st, k);
+    if (run > 1) hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, RUNI, 0>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((conv4x4_kernel<MODE, S, NR, RW, MT, CK, false, 0>), grid, dim3(256), 0, st, k);
   }
   vts_set_kernel("conv4x4_kernel<%d, %d, %d, %d, %d, %d, %s, %s>%s", MODE, S, NR, RW, MT, CK, (run > 1 && NR <= 2) ? "true" : "false",   // as rocprofv3 names the instance
@@ -883,5 +904,9 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
 #endif
   return VTS_OK;
 }
+
+
+// (8-channel steps on the full-width instances measured SLOWER -- 80 -> 20 transposed 61.7 -> 87.0 us, 40 -> 10 57.3 -> 74.0, 32 -> 64 at
+//  130^2 58.5 -> 59.6: the doubled staging registers cost the occupancy the launch bounds had just won; only the split instance takes them)
 
 }  // namespace

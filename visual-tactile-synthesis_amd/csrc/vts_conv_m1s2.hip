@@ -12,4 +12,6 @@ int vts_conv_full_m1s2(const ConvK& k, int nr, int N, hipStream_t st) {
 }
 
 // small grids: one 16-channel output group per workgroup (CG groups) and, if asked, KS slices of the input-channel loop
-int vts_conv_split_m1s2(const ConvK& k, int N, hipStream_t st, int CG, int KS) { return launch<1, 2, 1, 1, 2, 4>(k, N, st, CG, KS); }
+int vts_conv_split_m1s2(const ConvK& k, int N, hipStream_t st, int CG, int KS, int ck) {
+  return ck == 8 ? launch<1, 2, 1, 1, 2, 8>(k, N, st, CG, KS) : launch<1, 2, 1, 1, 2, 4>(k, N, st, CG, KS);
+}
