@@ -1162,17 +1162,13 @@ bool dispatch_ns(const WgK& k, const Plan& pl, hipStream_t st) {
 
 }  // namespace
 
-// round-4 member (vts_wgrad_run.hip): producer / consumer workgroups, <= 256 partial copies
-int vts_wgrad_run_copies(const vts_wgrad_desc* d);
-int vts_wgrad_run_try(const vts_wgrad_desc* d, float* ws, hipStream_t st);
+// (round 4 built a producer / consumer member -- persistent workgroups of 4 MFMA + 2..8 loader waves, one read per operand; faster alone on
+//  the thin full-size layers, 0.16 ms SLOWER in the step because its 512 / 768-thread workgroups stop sharing CUs with the other lanes.  It was
+//  never the default; round 5 removed it from the library: tools/probes/wgrad_run_r04.hip.txt, numbers in profiles/r04b_wgrad_microbench_*.txt)
 
 extern "C" int64_t vts_wgrad4x4_ws_floats(const vts_wgrad_desc* d) {
   if (!d) return 0;
   const int64_t CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
-  if (d->lo0.data && d->hi0.data && (d->stride == 1 || d->stride == 2)) {
-    const int copies = vts_wgrad_run_copies(d);
-    if (copies > 0) return (int64_t)copies * CL * CH * 16;
-  }
   const Plan pl = make_plan(d);
   return (int64_t)pl.pw * CL * CH * 16;
 }
@@ -1183,21 +1179,6 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   // lo x hi window semantics as in vts_conv4x4: hi is zero outside its HH x HW extent, pad may be negative
   VTS_CHECK_ARG(d->LH <= d->HH + 16 && d->LW <= d->HW + 16 && d->pad >= -8 && d->pad <= 8,
                 "vts_wgrad4x4: lo %dx%d / pad %d implausible for hi %dx%d s%d", d->LH, d->LW, d->pad, d->HH, d->HW, d->stride);
-  {
-    const int copies = vts_wgrad_run_copies(d);
-    if (copies > 0) {
-      const int rc = vts_wgrad_run_try(d, ws, (hipStream_t)stream);
-      if (rc != VTS_ERR_UNSUPPORTED) {
-        if (rc != VTS_OK || d->defer) return rc;
-        const int64_t nel_r = (int64_t)(d->lo0.C + (d->lo1.data ? d->lo1.C : 0)) * (d->hi0.C + (d->hi1.data ? d->hi1.C : 0)) * 16;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(nel_r, 64)), dim3(1024), 0, (hipStream_t)stream, ws, nel_r, copies, d->dw, d->accumulate);
-        VTS_CHECK_LAUNCH("vts_wgrad4x4 reduce");
-        return VTS_OK;
-      }
-      vts_set_error("vts_wgrad4x4: the producer / consumer plan has no kernel instance");
-      return VTS_ERR_UNSUPPORTED;
-    }
-  }
   const Plan pl = make_plan(d);
   WgK k;
   fill_src(k.lo, d->lo0, d->lo1, d->act_lo);
