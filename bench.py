@@ -26,6 +26,12 @@ for p in (os.path.join(ROOT, "visual-tactile-synthesis_amd"), ROOT):
 # parallel region; that starved the HIP runtime's completion thread and stalled graph-replayed steps by 70..170 ms
 # (tools/probes/stall_bisect2.py).  Passive waiting must be chosen before libgomp starts, i.e. before `import torch`.
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+# RCCL's own account of the communicator: rank 0 parses "nranks N" out of its init lines into comm.nranks_seen.  RCCL caches its debug
+# settings when the library initialises, so they are chosen here, before torch loads it.
+RCCL_LOG = None
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("VTS_DDP_FORCE", "0") == "1") and "NCCL_DEBUG_FILE" not in os.environ:
+    RCCL_LOG = "/tmp/vts_rccl_%d.log" % os.getpid()
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=RCCL_LOG)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -271,6 +277,62 @@ def cpu_baseline(size, style_dim, netG="unet256_custom", warmup=3, steps=10, bud
                       % (len(timed), min(warmup, len(times) - len(timed)), size, size, torch.get_num_threads(), os.cpu_count() or 1)}
 
 
+def collective_ab(model, world, dev, barrier, steps=10):
+    """Warm-up A/B of the two bucket collectives at world > 1: torch.distributed's all_reduce (RCCL's choice of algorithm) against the
+    library's explicit reduce-scatter + all-gather on its own communicator (VTS_DDP_DIRECT).  The direct path is first
+    CHECKED against all_reduce on a buffer whose length is not a multiple of the world size (it had never run on more than one device);
+    any failure keeps the torch path.  The faster one is left switched on for the timed region; both times go into the `comm` block."""
+    from vts import ddp
+
+    def timed():
+        for _ in range(2):
+            model.optimize_parameters(epoch=1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.optimize_parameters(epoch=1)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps * 1e3
+
+    res = {"torch_all_reduce_ms_per_step": timed(), "direct_ms_per_step": None, "direct_checked": False, "chosen": "torch"}
+    try:
+        n = 1000003
+        x = (torch.arange(n, device=dev, dtype=torch.float32) % 97.0) * float(dist.get_rank() + 1)
+        ref = x.clone()
+        dist.all_reduce(ref)
+        ddp.DIRECT = True
+        b = ddp.GradBucket(x)
+        b.start()
+        b.wait()
+        torch.cuda.synchronize()
+        ok = torch.tensor([1.0 if torch.equal(x, ref) else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        res["direct_checked"] = bool(ok.item() == 1.0)
+        if res["direct_checked"]:
+            res["direct_ms_per_step"] = timed()
+    except Exception as e:      # noqa: BLE001
+        res["direct_error"] = repr(e)[:300]
+    use_direct = bool(res["direct_checked"] and res["direct_ms_per_step"] is not None and res["direct_ms_per_step"] < res["torch_all_reduce_ms_per_step"])
+    flag = torch.tensor([1.0 if use_direct else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # one decision for all ranks
+    ddp.DIRECT = bool(flag.item() == 1.0)
+    res["chosen"] = "direct" if ddp.DIRECT else "torch"
+    barrier()
+    return res
+
+
+def rccl_nranks(path):
+    """largest `nranks N` in RCCL's own init log of this process (NCCL_DEBUG=INFO, NCCL_DEBUG_FILE), or None"""
+    import re
+
+    if not path or not os.path.exists(path):
+        return None
+    found = [int(m) for m in re.findall(r"nranks (\d+)", open(path, errors="replace").read())]
+    return max(found) if found else None
+
+
 def infer_measure(args, steps=None, warmup=None):
     """Generator-only forward (test() of the model, BASELINE config 4: 16 images/GPU): seconds per step, images per step, the options"""
     batch_n = 16 if args.batch == 4 else args.batch
@@ -372,6 +434,7 @@ def main():
 
     from vts import ddp
 
+    rccl_log = RCCL_LOG
     rank, world = ddp.init_from_env("cuda")
     if world != args.gpus and not (world == 1 and ddp.FORCE):
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
@@ -399,6 +462,9 @@ def main():
     for _ in range(args.warmup):
         model.optimize_parameters(epoch=1)
     barrier()
+    ab = None
+    if world > 1 and os.environ.get("VTS_DDP_AB", "1") != "0" and "VTS_DDP_DIRECT" not in os.environ:
+        ab = collective_ab(model, world, dev, barrier)      # torch.distributed all_reduce vs the library's reduce-scatter + all-gather
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step on the launch stream: spread, no sync
     t0 = time.perf_counter()
     marks[0].record()
@@ -409,6 +475,16 @@ def main():
     dt = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     spread = {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1], "p90": per_step[int(0.9 * (len(per_step) - 1))]}
+    per_rank = None
+    if world > 1 or ddp.active():
+        # every rank's own clock and device identity, gathered over the collective backend itself: a SCALE record then shows by itself
+        # that N ranks on N different devices took part
+        props = torch.cuda.get_device_properties(dev)
+        bus = float(getattr(props, "pci_bus_id", -1)) + 256.0 * float(getattr(props, "pci_domain_id", 0))
+        mine = torch.tensor([float(rank), float(torch.cuda.current_device()), bus, dt / args.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(max(world, 1))]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in r.tolist()] for r in allr]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -458,7 +534,10 @@ def main():
                 "exposed_allreduce_ms_per_step": (dt - dt_off) / args.steps * 1e3,
                 "buckets": {k: int(b.buf.numel()) * 4 for k, b in model.ddp.buckets.items()} if getattr(model, "ddp", None) else None,
                 "collective": "reduce-scatter + all-gather (library communicator)" if ddp.DIRECT else "torch.distributed all_reduce (RCCL)",
-                "ranks": world, "graph_segments": len(model._graphs) if getattr(model, "_graphs", None) else None}
+                "ranks": world, "graph_segments": len(model._graphs) if getattr(model, "_graphs", None) else None,
+                "ms_per_step_per_rank": {"min": min(r[3] for r in per_rank), "max": max(r[3] for r in per_rank)} if per_rank else None,
+                "devices_seen": sorted({(int(r[1]), int(r[2])) for r in per_rank}) if per_rank else None,      # (local device index, PCI bus) per rank
+                "ranks_gathered": len(per_rank) if per_rank else None, "nranks_seen": rccl_nranks(rccl_log), "collective_ab": ab}
 
     if rank == 0:
         roof = kernel_roofline(model, batch, args.detail) if world == 1 and not args.train_only else None

@@ -57,3 +57,82 @@ def test_two_rank_bucket_allreduce_and_broadcast():
     assert torch.equal(a["grad"], b["grad"]) and float(a["grad"][0]) == 3.0   # 1 + 2 summed
     assert a["scale"] == 0.5                                  # mean = sum * 1/world, applied in the Adam kernel
     assert not torch.equal(a["s"], b["s"])                    # ranks draw different samples
+
+
+def test_flat_params_chunk_cuts_at_convolution_weights():
+    """FlatParams.chunk (vts/optim.py): bucket boundaries are starts of 4-d parameters, in order, the buckets tile the gradient"""
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.nn as nn
+
+    from vts.optim import FlatParams
+
+    layers = []
+    for i in range(12):
+        layers += [nn.Conv2d(8, 8, 3), nn.BatchNorm2d(8)]
+    net = nn.Sequential(*layers)
+    flat = FlatParams(net)
+    cut_params = flat.chunk(8, min_floats=1)
+    assert 4 <= len(flat.cuts) + 1 <= 8 and flat.cuts == sorted(set(flat.cuts))
+    starts, o = {}, 0
+    for p in flat.params:
+        starts[o] = p
+        o += p.numel()
+    assert all(starts[c].dim() == 4 and starts[c] is q for c, q in zip(flat.cuts, cut_params))
+    b = flat.buckets("G")
+    assert list(b) == ["G_%d" % k for k in range(len(flat.cuts) + 1)] and sum(v.numel() for v in b.values()) == flat.numel
+    assert b["G_0"].data_ptr() == flat.grad.data_ptr()
+    sizes = [v.numel() for v in b.values()]
+    assert max(sizes) <= 2 * min(sizes) + 8 * 8 * 9          # roughly equal
+    # too small to be worth several collectives: one bucket
+    flat2 = FlatParams(nn.Sequential(nn.Conv2d(2, 2, 3), nn.Conv2d(2, 2, 3)))
+    assert flat2.chunk(8) == [] and list(flat2.buckets("G")) == ["G"]
+
+
+def _chunk_worker(rank, world, port, out):
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import torch.nn as nn
+
+    from vts import ddp
+    from vts.optim import FlatParams
+
+    ddp.init_from_env("cpu")
+
+    class M:
+        model_names = ["G"]
+
+    res = {}
+    for tag, k in (("one", 1), ("many", 8)):
+        torch.manual_seed(5)
+        m = M()
+        m.netG = nn.Sequential(*[nn.Conv2d(4, 4, 3) for _ in range(10)])
+        m.flatG = FlatParams(m.netG)
+        m.flatG.chunk(k, min_floats=1)
+        state = ddp.attach(m)
+        g = torch.Generator().manual_seed(100 + rank)
+        m.flatG.grad.copy_(torch.randn(m.flatG.numel, generator=g))
+        names = sorted(state.buckets, key=lambda s: -int(s.split("_")[1]) if "_" in s else 0)     # backward order: last bucket first
+        for nme in names:
+            state.buckets[nme].start()
+        for nme in names:
+            state.buckets[nme].wait()
+        res[tag] = (m.flatG.grad.clone(), len(names))
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_chunked_buckets_equal_the_monolithic_allreduce():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_chunk_worker, args=(world, 29621, out), nprocs=world, join=True)
+    for r in (0, 1):
+        assert out[r]["many"][1] >= 4 and out[r]["one"][1] == 1
+        assert torch.equal(out[r]["many"][0], out[r]["one"][0])
+    assert torch.equal(out[0]["many"][0], out[1]["many"][0])

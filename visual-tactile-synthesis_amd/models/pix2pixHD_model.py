@@ -14,6 +14,8 @@ The GAN feature-matching term of the reference compares every discriminator feat
 networks.py:2021-2067) runs on the GEMM-class kernels (vts/perceptual.py); its pretrained weights cannot exist offline:
 `--vgg_weights` loads them, otherwise seeded stand-ins are used and `loss_vgg_pretrained` is False.
 """
+import os
+
 import torch
 
 from vts.misc import str2bool
@@ -92,6 +94,9 @@ class Pix2PixHDModel(BaseModel):
         self.netG = networks.define_G(opt.sketch_nc, opt.image_nc + opt.touch_nc, opt.ngf, opt.netG, opt.norm, gpu_ids=self.gpu_ids,
                                       opt=opt)
         self.flatG = FlatParams(self.netG)
+        # data parallel: the generator's gradient travels as up to 8 buckets cut at layer boundaries, each started as soon as the backward
+        # has written it (_segments); VTS_G_BUCKETS=1: one bucket behind the whole backward; VTS_G_BUCKET_MIN_MB: smallest bucket worth a collective
+        self.flatG.chunk(int(os.environ.get("VTS_G_BUCKETS", "8")), min_floats=int(float(os.environ.get("VTS_G_BUCKET_MIN_MB", "16")) * (1 << 18)))
         if self.isTrain:
             self.netD = networks.define_D(opt.image_nc + opt.sketch_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm, num_D=opt.num_D_D1,
                                           gpu_ids=self.gpu_ids, opt=opt)
@@ -219,14 +224,41 @@ class Pix2PixHDModel(BaseModel):
             slot["G_VGG"].copy_(slot["G_VGG_I"] + slot["G_VGG_T"])
         d_raw = torch.empty(n, 5, h, w, device=dev)
         ops.g_out_grad(d_fake_I, d_fake_T, self.M, self.g_out, d_raw)
-        engine.resnet_backward(self.netG, self._g_ctx, d_raw)
+        if self._g_stages():
+            # data parallel, chunked generator bucket: only the LAST stage of the backward here (the layers of the last bucket)
+            b = engine.resnet_stage_bounds(self._g_ctx, self.flatG.cut_params)
+            self._g_bounds = b
+            self._g_flow = engine.resnet_backward_stage(self.netG, self._g_ctx, d_raw, b[-2], b[-1])
+        else:
+            engine.resnet_backward(self.netG, self._g_ctx, d_raw)
+
+    def _seg_g_stage(self, j):
+        """stage j of the generator's backward (the layers of gradient bucket G_j), j = K-2 .. 0"""
+        b = self._g_bounds
+        self._g_flow = engine.resnet_backward_stage(self.netG, self._g_ctx, self._g_flow, b[j], b[j + 1])
 
     def _seg_adam_g(self):
         self.optimizer_G.step(self._gscale)
 
+    def _g_stages(self):
+        """number of stages of the generator's backward = chunks of its gradient bucket when the step runs data parallel, else 0"""
+        from vts import ddp as _ddp
+        if self.ddp is None or not _ddp.active() or not getattr(self.flatG, "cuts", None):
+            return 0
+        return len(self.flatG.cuts) + 1
+
     def _segments(self):
-        """(segment, buckets to wait for before it, buckets to start after it)"""
-        return [(self._seg_forward_d, (), ("D", "D2")), (self._seg_adam_d_g, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
+        """(segment, buckets to wait for before it, buckets to start after it).  Data parallel: the generator's gradient (730 MB at the
+        reference's ngf 64) travels as K buckets cut at layer boundaries; the backward runs as K stages from the output layer down, and
+        the all-reduce of bucket j starts as soon as stage j has written it, under the stages below."""
+        K = self._g_stages()
+        if not K:
+            return [(self._seg_forward_d, (), ("D", "D2")), (self._seg_adam_d_g, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
+        segs = [(self._seg_forward_d, (), ("D", "D2")), (self._seg_adam_d_g, ("D", "D2"), ("G_%d" % (K - 1),))]
+        for j in range(K - 2, -1, -1):
+            segs.append((lambda j=j: self._seg_g_stage(j), (), ("G_%d" % j,)))
+        segs.append((self._seg_adam_g, tuple("G_%d" % j for j in range(K - 1, -1, -1)), ()))
+        return segs
 
     def _comm(self, name, start):
         if self.ddp is None or name not in self.ddp.buckets:

@@ -714,17 +714,18 @@ def _bn_map(*step_lists):
     return bn_of
 
 
-def _seq_backward(steps, g, sq, bn_of):
+def _seq_backward(steps, g, sq, bn_of, lo=0, hi=None):
     """backward of one segment: g = gradient w.r.t. its output (the pre-tanh output for a final conv7, else w.r.t. the
     raw output of its last conv / the identity output of its last block).  Writes the parameters' .grad (overwrite;
-    through the side queue sq) and returns the gradient w.r.t. the segment's input (None for a network input)."""
+    through the side queue sq) and returns the gradient w.r.t. the segment's input (None for a network input).
+    lo / hi: only steps[lo:hi] (the stages of resnet_backward_stage)."""
     dev = g.device
     through_norm_relu = _through_norm_relu
 
     def producer_bn(a):
         return bn_of.get(id(a))
 
-    for st in reversed(steps):
+    for st in reversed(steps[lo:hi]):
         kind = st[0]
         if kind == "conv7_out":
             _, conv, p, src_act, _, _ = st
@@ -829,6 +830,47 @@ def resnet_backward(G, ctx, d_raw):
     else:
         _seq_backward(ctx.steps, d_raw, sq, _bn_map(ctx.steps))
     sq.join()
+
+
+def _step_weights(st):
+    """the convolution weights a step of a ResNet-family generator owns"""
+    if st[0] in ("conv7_out", "conv7", "conv3", "convT3"):
+        return [st[1].weight]
+    if st[0] == "block":
+        return [st[1].weight, st[2].weight]
+    return []
+
+
+def resnet_stage_bounds(ctx, cut_params):
+    """Step indices at which a backward pass is cut so that, once stage j (steps[b[j]:b[j+1]], run from the last stage to the first) has
+    finished, every parameter of gradient bucket j has its final gradient (vts/optim.py:FlatParams.chunk: every bucket but the first
+    starts at a convolution weight).  A bucket that starts inside a two-convolution block is complete after the stage that holds the
+    block (the block's first convolution then belongs to the next bucket down and is simply early).  Returns [0, s_1, .., s_K-1, len(steps)]."""
+    steps = ctx.steps
+    where = {}
+    for i, st in enumerate(steps):
+        for w in _step_weights(st):
+            where[w.data_ptr()] = i
+    bounds = [0]
+    for p in cut_params:
+        i = where.get(p.data_ptr())
+        if i is None:
+            raise RuntimeError("a gradient bucket does not start at a layer of this generator's backward")
+        bounds.append(max(i, bounds[-1]))
+    bounds.append(len(steps))
+    return bounds
+
+
+def resnet_backward_stage(G, ctx, g, lo, hi):
+    """steps[lo:hi] of resnet_backward (single generator), weight gradients joined: on return every parameter of these steps has its
+    final .grad, and the returned tensor is the gradient flowing into steps[:lo].  Chaining the stages from the last to the first equals
+    resnet_backward; a data-parallel step starts the all-reduce of a stage's gradient bucket behind it (models/pix2pixHD_model.py)."""
+    if getattr(G, "is_local_enhancer", False):
+        raise NotImplementedError("staged backward of the local enhancer")
+    sq = SideQueue()
+    g = _seq_backward(ctx.steps, g, sq, _bn_map(ctx.steps), lo, hi)
+    sq.join()
+    return g
 
 
 def add_grad_list(lst, idx, shape, dev):

@@ -41,9 +41,34 @@ class FlatParams:
 
     def buckets(self, name):
         """gradient buckets of this network for the data-parallel all-reduce: {bucket name: contiguous view of the flat gradient}"""
+        if getattr(self, "cuts", None):
+            edges = [0] + list(self.cuts) + [self.numel]
+            return {"%s_%d" % (name, k): self.grad[edges[k]:edges[k + 1]] for k in range(len(edges) - 1)}
         if self.split is None or self.split in (0, self.numel):
             return {name: self.grad}
         return {name + "_dec": self.grad[:self.split], name + "_enc": self.grad[self.split:]}
+
+    def chunk(self, k, min_floats=1 << 22):
+        """Cut the flat gradient into <= k contiguous buckets of roughly equal size whose boundaries are STARTS OF CONVOLUTION WEIGHTS
+        (4-d parameters): a backward pass completes the gradients from the end of the buffer towards its start, layer by layer, so
+        bucket j is complete as soon as the backward has passed the layer its first weight belongs to, and its all-reduce can travel
+        under the rest of the backward (the pix2pixHD generator's 730 MB gradient in >= 8 pieces).  Buckets smaller than
+        min_floats are not worth a collective of their own.  Returns the cut parameters (the tensors whose start opens buckets 1 ..)."""
+        starts, o = [], 0
+        for p in self.params:
+            if p.dim() == 4 and o > 0:
+                starts.append((o, p))
+            o += p.numel()
+        k = max(1, min(int(k), self.numel // max(1, int(min_floats))))
+        cuts, cut_params = [], []
+        for j in range(1, k):
+            target = self.numel * j // k
+            cand = min(starts, key=lambda s: abs(s[0] - target)) if starts else None
+            if cand is not None and cand[0] not in cuts and (not cuts or cand[0] > cuts[-1]):
+                cuts.append(cand[0])
+                cut_params.append(cand[1])
+        self.cuts, self.cut_params = cuts, cut_params
+        return cut_params
 
 
 class FlatAdam(torch.optim.Optimizer):
