@@ -14,15 +14,25 @@ pytestmark = pytest.mark.gpu
 # gradient comparisons against the oracle: every (relative L2 error, network, parameter) is recorded, the worst one is printed at the
 # end of the module (pytest -s) and the bound is ~2x the worst value observed on the MI355X (round 4: see the fixture below)
 GRAD_WORST = []
-GRAD_TOL = 1.5e-3     # observed worst on the MI355X (round 4): 9.6e-4 (D layer2.11.bias, a sum over 4 x 35 x 35 predictions)
+# north_star's bar: 1e-3 relative L2.  It holds for every parameter TENSOR.  The one-element gradients -- the biases of the three prediction
+# heads, each a plain sum over N x H x W signed values -- get 1.5e-3: their "relative L2" is the relative error of ONE cancelling sum, and
+# the fp32 CPU oracle's own value of it moves by several 1e-4 with its thread count (bench.py / __graft_entry__.smoke pin it to <= 16
+# threads for that reason); observed worst on the MI355X 9.6e-4 (D layer2.11.bias, 4 x 35 x 35 terms), worst multi-element tensor 6e-4.
+GRAD_TOL = 1.0e-3
+GRAD_TOL_SCALAR = 1.5e-3
+
+
+def grad_tol(t):
+    return GRAD_TOL_SCALAR if t.numel() == 1 else GRAD_TOL
 
 
 @pytest.fixture(scope="module", autouse=True)
 def _report_worst_gradient():
     yield
     if GRAD_WORST:
-        w = max(GRAD_WORST)
-        print("\n[%s] worst gradient rel-L2 vs the oracle over %d comparisons: %.3e (%s %s), bound %.1e" % (__name__, len(GRAD_WORST), w[0], w[1], w[2], GRAD_TOL))
+        top = sorted(GRAD_WORST, reverse=True)[:6]
+        print("\n[%s] gradient rel-L2 vs the oracle over %d comparisons, bound %.1e (one-element tensors %.1e); worst: %s"
+              % (__name__, len(GRAD_WORST), GRAD_TOL, GRAD_TOL_SCALAR, ", ".join("%.2e %s %s" % w for w in top)))
 
 from oracle import detrand, nets, step  # noqa: E402  (checker only)
 
@@ -153,7 +163,7 @@ def test_full_size_step_matches_oracle_batch1():
                                        (nm != "G" and k.split(".")[1] in ("2", "5", "8"))):
                 continue    # bias in front of a normalisation: mathematically zero gradient (rounding noise in autograd)
             GRAD_WORST.append((rel(p.grad, r), nm, k))
-            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
+            assert GRAD_WORST[-1][0] < grad_tol(r), GRAD_WORST[-1]
 
 
 def test_headline_config_step_matches_oracle():
@@ -191,7 +201,7 @@ def test_headline_config_step_matches_oracle():
             e = rel(p.grad, ref["grad_" + nm][k])
             worst = max(worst, (e, nm + "." + k))
             GRAD_WORST.append((e, nm, k))
-            assert e < GRAD_TOL, (nm, k, e)
+            assert e < grad_tol(p.grad), (nm, k, e)
         for k, b in net.named_buffers():    # the oracle updated its state dicts in place: running statistics after the step
             if k.endswith("running_mean"):
                 scale = float(sd[k.replace("running_mean", "running_var")].max().sqrt())

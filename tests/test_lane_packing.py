@@ -45,6 +45,9 @@ def test_a_heavy_extra_lane_gets_a_stream_of_its_own(engine):
 
 def test_overrides(engine, monkeypatch):
     monkeypatch.setenv("VTS_LANE_GROUPS", "0|1,5|3|2,4")
+    assert engine._lane_groups(HEADLINE) == engine._lane_groups(HEADLINE, "VTS_LANE_GROUPS_G")      # ignored without VTS_TUNING=1 (vts/tune.py)
+    monkeypatch.setenv("VTS_TUNING", "1")
+    monkeypatch.setenv("VTS_LANE_GROUPS", "0|1,5|3|2,4")
     assert engine._lane_groups(HEADLINE) == [[0], [1, 5], [3], [2, 4], [6]]       # a lane the spec does not name keeps its own stream
     assert engine._lane_groups(HEADLINE, "VTS_LANE_GROUPS_G") != [[0], [1, 5], [3], [2, 4], [6]]     # the generator step has its own variable
     monkeypatch.setenv("VTS_LANE_GROUPS", "0,1|1,2")

@@ -478,14 +478,16 @@ def test_conv3x3_wide_64_channel_tile(case):
     ops.conv3x3_wide(p, packed, b.to(dev), out)
     assert L.load().vts_last_kernel().decode() == "conv3x3_wide64_kernel"
     assert rel(out, ref) < 1e-5
-    os.environ["VTS_NO_WIDE64"] = "1"
-    try:
-        out2 = torch.empty_like(out)
-        ops.conv3x3_wide(p, packed, b.to(dev), out2)
-        assert L.load().vts_last_kernel().decode().startswith("conv3x3_wide_kernel")
-    finally:
-        del os.environ["VTS_NO_WIDE64"]
-    assert torch.equal(out, out2)
+    # the same layer on the generic wide kernel: a dispatch switch, i.e. only in the instrumented library (make PROFILING=1, csrc/vts_internal.h:vts_tune)
+    if os.environ.get("VTS_LIB_PATH", "").endswith("_prof.so"):
+        os.environ["VTS_NO_WIDE64"] = "1"
+        try:
+            out2 = torch.empty_like(out)
+            ops.conv3x3_wide(p, packed, b.to(dev), out2)
+            assert L.load().vts_last_kernel().decode().startswith("conv3x3_wide_kernel")
+        finally:
+            del os.environ["VTS_NO_WIDE64"]
+        assert torch.equal(out, out2)
 
 
 def test_lpips_alex_network_and_test_phase_metrics_match_reference_fixture(golden_dir):

@@ -107,6 +107,12 @@ def test_bench_spawns_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["losses_finite"]
     assert "comm" in out and "exposed_allreduce_ms_per_step" in out["comm"] and set(out["comm"]["buckets"]) == {"D", "D2", "G_dec", "G_enc"}
+    c = out["comm"]      # the record proves its rank count by itself: RCCL's own init log, one clock and one device per rank
+    assert c["nranks_seen"] == 2 and c["ranks_gathered"] == 2 and len(c["devices_seen"]) == 2
+    assert 0 < c["ms_per_step_per_rank"]["min"] <= c["ms_per_step_per_rank"]["max"]
+    ab = c["collective_ab"]    # warm-up A/B of all_reduce vs the library's reduce-scatter + all-gather, the latter checked first
+    assert ab is not None and ab["torch_all_reduce_ms_per_step"] > 0 and ab["chosen"] in ("torch", "direct")
+    assert ab["direct_checked"] or "direct_error" in ab or ab["direct_ms_per_step"] is None
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():

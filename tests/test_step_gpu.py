@@ -860,6 +860,7 @@ def test_fresh_batch_staging_paths_agree_bit_for_bit(monkeypatch):
     batches = [{k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
     results = []
     for fused, cs in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("VTS_TUNING", "1")        # experiment switches are honoured only under it (vts/tune.py)
         monkeypatch.setenv("VTS_FUSED_INPUT", fused)
         monkeypatch.setenv("VTS_PATCH_COPY_STREAM", cs)
         import random

@@ -244,7 +244,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   {
     const int rh0 = vts_conv_head_try(d, (hipStream_t)stream);      // Cout = 1 prediction heads: full-size and small-map members
     if (rh0 != VTS_ERR_UNSUPPORTED) return rh0;
-    static const int use_small = getenv("VTS_NO_SMALL") ? 0 : 1;
+    static const int use_small = vts_tune_set("VTS_NO_SMALL") ? 0 : 1;
     if (use_small) {
       const int rc = vts_conv_small_try(d, (hipStream_t)stream);
       if (rc != VTS_ERR_UNSUPPORTED) return rc;
@@ -264,13 +264,13 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   k.accumulate = d->accumulate;
   k.N = d->N; k.CG = 1; k.cps = 1 << 30; k.part = nullptr; k.tiles_x = 0; k.stat_part = nullptr; k.stat_spl = 0; k.bsum_part = nullptr;
 #ifdef VTS_PROFILING
-  static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
+  static const int ablate = vts_tune("VTS_ABLATE", 0);
   k.ablate = ablate;
   k.trace = nullptr;
 #endif
-  static const int xcd_swizzle = getenv("VTS_XCD_SWIZZLE") ? atoi(getenv("VTS_XCD_SWIZZLE")) : 1;
+  static const int xcd_swizzle = vts_tune("VTS_XCD_SWIZZLE", 1);
   k.xcd_swizzle = xcd_swizzle;
-  static const int direct_epi = getenv("VTS_DIRECT_EPI") ? atoi(getenv("VTS_DIRECT_EPI")) : 1;
+  static const int direct_epi = vts_tune("VTS_DIRECT_EPI", 1);
   k.direct_epi = direct_epi && (int64_t)d->Cout * d->OH * d->OW * 4 < (int64_t)OOB_OFF && (!d->dmask.data || (int64_t)d->dmask.C * d->OH * d->OW * 4 < (int64_t)OOB_OFF);
   k.ident = vts_ident();
   VTS_CHECK_ARG(k.ident, "vts_conv4x4: could not allocate the identity constants");
@@ -285,11 +285,11 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
   const int nr = (d->Cout + 15) / 16;
   const int N = d->N;
   // statistics of the output in the epilogue (round 3): only the plain "store acc + bias" form through the direct epilogue
-  static const int fuse_stats = getenv("VTS_FUSE_STATS") ? atoi(getenv("VTS_FUSE_STATS")) : 1;
+  static const int fuse_stats = vts_tune("VTS_FUSE_STATS", 1);
   const bool stats_ok = nd && fused && sw.p && fuse_stats && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
                         nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride;
   const bool want_stats = stats_ok && k.direct_epi && sw.floats >= vts_conv4x4_norm_ws_floats(d);
-  static const int fuse_bsums = getenv("VTS_FUSE_BSUMS") ? atoi(getenv("VTS_FUSE_BSUMS")) : 1;
+  static const int fuse_bsums = vts_tune("VTS_FUSE_BSUMS", 1);
   const bool bsums_ok = bsums && fused && sw.p && fuse_bsums && d->act_out == VTS_ACT_NONE && d->dmask.data;
   const bool want_bsums = bsums_ok && k.direct_epi && sw.floats >= vts_conv4x4_norm_ws_floats(d);
   {
@@ -315,11 +315,11 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
     const int full_wgs = cdiv(GW, 16 * mt) * cdiv(GH, 4 * rw) * N;
     // input channels per pipeline step of the split instance: 8 where the slice is long enough (the per-chunk cost -- two barriers, the
     // staging stores, the descriptor arithmetic: 0.25 - 0.5 us measured -- is paid half as often); VTS_SPLIT_CK=4: always 4
-    static const int split_ck = getenv("VTS_SPLIT_CK") ? atoi(getenv("VTS_SPLIT_CK")) : 8;
+    static const int split_ck = vts_tune("VTS_SPLIT_CK", 8);
     int ck = 4;
     const int nchunks = (k.Cin + 3) / 4;
-    static const int small_thr = getenv("VTS_SMALL_WGS") ? atoi(getenv("VTS_SMALL_WGS")) : 300;   // < ~1.2 workgroups per CU: split (measured: 128 -> 300 = step 7.88 -> 7.51 ms)
-    static const int target_wgs = getenv("VTS_TARGET_WGS") ? atoi(getenv("VTS_TARGET_WGS")) : 320;
+    static const int small_thr = vts_tune("VTS_SMALL_WGS", 300);   // < ~1.2 workgroups per CU: split (measured: 128 -> 300 = step 7.88 -> 7.51 ms)
+    static const int target_wgs = vts_tune("VTS_TARGET_WGS", 320);
     if (full_wgs < small_thr && (nr > 1 || nchunks >= 8)) {
       const int base = cdiv(GW, 32) * cdiv(GH, 4) * N * nr;
       int KS = target_wgs / base;
@@ -342,7 +342,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
       else rc = d->stride == 2 ? vts_conv_split_m1s2(k, N, st, nr, KS, ck) : vts_conv_split_m1s1(k, N, st, nr, KS, ck);
       if (rc == VTS_OK && (cg_stats || cg_bsums)) *fused = 2 + t_stat_spl;    // partials written: the caller merges them
       if (rc != VTS_OK || KS == 1) return rc;
-      static const int fuse_in = getenv("VTS_FUSE_SPLIT_IN") ? atoi(getenv("VTS_FUSE_SPLIT_IN")) : 1;
+      static const int fuse_in = vts_tune("VTS_FUSE_SPLIT_IN", 1);
       if (nd && nd->mode == 0 && fuse_in && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && !d->dmask.data && !d->accumulate &&
           nd->x == d->out && nd->N == N && nd->C == d->Cout && nd->HW == d->OH * d->OW && nd->nstride == d->out_nstride) {
         const InStatsOut q{nd->scale, nd->shift, nd->mean_out, nd->rstd_out, nd->eps};
@@ -352,7 +352,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
         *fused = 1;
         return VTS_OK;
       }
-      static const int fuse_inbwd = getenv("VTS_FUSE_SPLIT_INBWD") ? atoi(getenv("VTS_FUSE_SPLIT_INBWD")) : 1;
+      static const int fuse_inbwd = vts_tune("VTS_FUSE_SPLIT_INBWD", 1);
       if (bsums && in_bwd_ok && fused && fuse_inbwd && (int64_t)d->OH * d->OW <= 4096 && d->act_out == VTS_ACT_NONE && d->dmask.data && d->dmask.scale &&
           d->dmask.shift && d->dmask.C == d->Cout) {
         hipLaunchKernelGGL(conv_split_epilogue_inbwd_kernel, dim3(N * d->Cout), dim3(256), 0, st, k, KS);

@@ -591,7 +591,7 @@ static int wide_plan(int N, int Cin, int Cout, int H, int W, int* cps, int ck = 
     if (KS > nchunks / 4) KS = nchunks / 4;
     if (KS < 1) KS = 1;
   }
-  static const int force = getenv("VTS_WIDE_KS") ? atoi(getenv("VTS_WIDE_KS")) : 0;   // measurement override
+  static const int force = vts_tune("VTS_WIDE_KS", 0);   // measurement override
   if (force > 0) KS = force < nchunks ? force : nchunks;
   *cps = cdiv(nchunks, KS);
   return cdiv(nchunks, *cps);
@@ -675,7 +675,7 @@ static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_
   k.KS = KS; k.cps = cps; k.part = KS > 1 ? ws : nullptr;
   dim3 grid(cdiv(k.W, TX) * cdiv(k.H, TY), cdiv(k.Cout, TCO), k.N * KS);
   // maps whose 4 x 32 tiling wastes >= 10 %% more than runs of 128 flattened pixels (and whose rows fit the patch): the row-run kernel
-  static const int no_rowrun = getenv("VTS_NO_ROWRUN") ? 1 : 0;
+  static const int no_rowrun = vts_tune_set("VTS_NO_ROWRUN") ? 1 : 0;
   const double eff_tile = (double)k.W * k.H / ((double)cdiv(k.W, TX) * TX * cdiv(k.H, TY) * TY);
   const double eff_run = (double)k.W * k.H / (128.0 * cdiv(k.W * k.H, 128));
   if (!no_rowrun && S == 1 && k.os == 1 && k.ntaps == TW && k.W >= 64 && ck * rr_rows(k.W, K) * ((k.IPW + 3) & ~3) <= RR_PATCH_FLOATS &&
@@ -693,7 +693,7 @@ static int wide_launch(WideK& k, int S, float* ws, int64_t ws_floats, hipStream_
     if (S == 1) hipLaunchKernelGGL(conv4x4_wide_kernel<1>, grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL(conv4x4_wide_kernel<2>, grid, dim3(256), 0, st, k);
     vts_set_kernel(KS > 1 ? "conv4x4_wide_kernel<%d>+ksplit" : "conv4x4_wide_kernel<%d>", S);
-  } else if (S == 1 && KS == 1 && k.os == 1 && k.Cout <= 64 && cdiv(k.W, TX) * cdiv(k.H, 8) * k.N >= 256 && !getenv("VTS_NO_WIDE64")) {
+  } else if (S == 1 && KS == 1 && k.os == 1 && k.Cout <= 64 && cdiv(k.W, TX) * cdiv(k.H, 8) * k.N >= 256 && !vts_tune_set("VTS_NO_WIDE64")) {
     grid = dim3(cdiv(k.W, TX) * cdiv(k.H, 8), 1, k.N);
     hipLaunchKernelGGL(conv3x3_wide64_kernel, grid, dim3(256), 0, st, k);
     vts_set_kernel("conv3x3_wide64_kernel");

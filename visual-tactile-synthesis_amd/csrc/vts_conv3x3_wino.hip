@@ -576,7 +576,7 @@ extern "C" int vts_w3x3_wino_pack(const float* w, int A, int B, int64_t sa, int6
 // flat-tile mode: maps of at most 16 x 16 pixels whose batch gives the chip >= 128 workgroups of 64 tiles x 64 channels, the whole input
 // inside 31-bit byte offsets (VTS_WINO_FLAT=0: off)
 static bool wino_flat(int N, int Cin, int Cout, int H, int W) {
-  static const int off = getenv("VTS_WINO_FLAT") && atoi(getenv("VTS_WINO_FLAT")) == 0;
+  static const int off = vts_tune("VTS_WINO_FLAT", 1) == 0;
   if (off || H > 16 || W > 16 || (H == 16 && W == 16)) return false;
   if ((int64_t)N * ((Cin + 7) / 8 * 8) * (H + 2) * (W + 2) * 4 > 0x7fffffffll) return false;
   const int64_t tiles = (int64_t)N * cdiv(H, 2) * cdiv(W, 2);
@@ -609,13 +609,13 @@ extern "C" int vts_conv3x3_wino(const float* in, const float* U, const float* bi
   k.flat = wino_flat(N, Cin, Cout, H, W) ? 1 : 0;
   k.tiles_x = cdiv(W, 2); k.tpi = k.tiles_x * cdiv(H, 2); k.ntiles = N * k.tpi;
   const dim3 grid = k.flat ? dim3(cdiv(k.ntiles, 64), Cout / TCO, 1) : dim3(cdiv(W, 16) * cdiv(H, 16), Cout / TCO, N);
-  static const int v1 = getenv("VTS_WINO_V1") ? 1 : 0;      // the one-wave-per-SIMD kernel (A/B timing)
+  static const int v1 = vts_tune_set("VTS_WINO_V1") ? 1 : 0;      // the one-wave-per-SIMD kernel (A/B timing)
   if (v1 && !k.flat) {
     hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
     vts_set_kernel("conv3x3_wino_kernel");
   } else {
     constexpr int LDS_BYTES = 2 * 2 * 16 * CKW * 64 * 4;       // 128 KB: two buffers of the weight and the patch tile
-    static const int ablate = getenv("VTS_WINO_ABLATE") ? atoi(getenv("VTS_WINO_ABLATE")) : 0;
+    static const int ablate = vts_tune("VTS_WINO_ABLATE", 0);
     void (*kern)(const WinoK) = ablate == 1 ? conv3x3_wino8_kernel<1> : ablate == 8 ? conv3x3_wino8_kernel<8> : ablate == 9 ? conv3x3_wino8_kernel<9> : conv3x3_wino8_kernel<0>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) {
@@ -632,7 +632,7 @@ extern "C" int vts_conv3x3_wino(const float* in, const float* U, const float* bi
 // Internal (vts_conv3x3_wide.hip: vts_wgrad3x3_wide): partials of the stride-1 weight gradient in Winograd form into part [KS][Cout][Cin][9]
 // with KS <= max_ks slices; returns the number of slices written, 0 if the shape is not taken.
 int vts_wgrad3x3_wino_try(const float* dout, const float* in, float* part, int N, int Cin, int Cout, int H, int W, int max_ks, hipStream_t st) {
-  static const int off = getenv("VTS_WINO") && atoi(getenv("VTS_WINO")) == 0 ? 1 : (getenv("VTS_WINO_WGRAD") && atoi(getenv("VTS_WINO_WGRAD")) == 0 ? 1 : 0);
+  static const int off = vts_tune("VTS_WINO", 1) == 0 ? 1 : (vts_tune("VTS_WINO_WGRAD", 1) == 0 ? 1 : 0);
   if (off || Cin < 64 || Cout < 64 || H < 8 || W < 8 || max_ks < 1) return 0;
   if ((int64_t)N * Cin * (H + 2) * (W + 2) * 4 > 0x7fffffe0ll || (int64_t)N * Cout * H * W * 4 > 0x7fffffe0ll) return 0;
   WinoWgK k{};

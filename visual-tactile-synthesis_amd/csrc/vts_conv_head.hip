@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_head_small_kernel(const HeadSK p) {
 }  // namespace
 
 int vts_conv_head_try(const vts_conv_desc* d, hipStream_t st) {
-  static const int off = getenv("VTS_NO_HEAD") ? 1 : 0;
+  static const int off = vts_tune_set("VTS_NO_HEAD") ? 1 : 0;
   if (off || d->transposed || d->stride != 1 || d->Cout != 1 || d->in1.data || d->dmask.data || d->accumulate || d->act_out != VTS_ACT_NONE)
     return VTS_ERR_UNSUPPORTED;
   if (d->in0.C > HK_MAXC || d->in0.C < 8 || (int64_t)d->IH * d->IW * d->in0.C >= (1ll << 31)) return VTS_ERR_UNSUPPORTED;

@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
 // covers 129 columns with 192 (a third of every MFMA row group multiplies nothing).  Where three 16-column groups per tile (48 columns)
 // cover the row with >= 7 % fewer columns than the table's width, the dispatch takes the MT = 3 instance (VTS_MT3=0: never).
 inline bool vts_prefer_mt3(const ConvK& k, bool phases4, int mt_default) {
-  static const int on = getenv("VTS_MT3") ? atoi(getenv("VTS_MT3")) : 1;
+  static const int on = vts_tune("VTS_MT3", 1);
   const int GW = phases4 ? (k.OW + 1) / 2 : k.OW;
   const int c3 = cdiv(GW, 48) * 48, cd = cdiv(GW, 16 * mt_default) * 16 * mt_default;
   return on && c3 * 100 < cd * 93;
@@ -830,9 +830,9 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   t_stat_spl = k.stat_spl;
   // Tile runs: only where the per-tile chunk pipeline is too short to overlap anything (<= run_max_chunks chunks per tile) and
   // the grid stays several workgroups per CU deep after the cut.  VTS_TILE_RUN=<n> forces a run length (1 = one tile per workgroup).
-  static const int run_force = getenv("VTS_TILE_RUN") ? atoi(getenv("VTS_TILE_RUN")) : 0;
-  static const int run_wgs = getenv("VTS_TILE_RUN_WGS") ? atoi(getenv("VTS_TILE_RUN_WGS")) : 2048;
-  static const int run_max_chunks = getenv("VTS_TILE_RUN_CHUNKS") ? atoi(getenv("VTS_TILE_RUN_CHUNKS")) : 4;
+  static const int run_force = vts_tune("VTS_TILE_RUN", 0);
+  static const int run_wgs = vts_tune("VTS_TILE_RUN_WGS", 2048);
+  static const int run_max_chunks = vts_tune("VTS_TILE_RUN_CHUNKS", 4);
   int run = 1;
   if (NR <= 2 && !k.part && k.direct_epi && KS == 1) {
     const int64_t total = (int64_t)tiles_x * tiles_y * N * CG;

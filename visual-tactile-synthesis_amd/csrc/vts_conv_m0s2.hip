@@ -3,7 +3,7 @@
 
 int vts_conv_full_m0s2(const ConvK& k, int nr, int N, hipStream_t st) {
   if (nr == 1) {   // tile of the thin forward layers: 8x32 outputs (measured best of 8x64 / 4x64 / 4x32 / 8x32); VTS_TILE01=rw*10+mt
-    static const int tile01 = getenv("VTS_TILE01") ? atoi(getenv("VTS_TILE01")) : 22;
+    static const int tile01 = vts_tune("VTS_TILE01", 22);
     if (tile01 == 14) return launch<0, 2, 1, 1, 4, 4>(k, N, st);
     if (tile01 == 12) return launch<0, 2, 1, 1, 2, 4>(k, N, st);
     if (tile01 == 22) return launch<0, 2, 1, 2, 2, 4>(k, N, st);

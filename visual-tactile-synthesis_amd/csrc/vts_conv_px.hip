@@ -704,16 +704,16 @@ int px_launch(const PxK& k, int N, int stats, hipStream_t st) {
 // VTS_ERR_UNSUPPORTED: not a thin full-size stride-2 convolution, use the other members.  stat_part / bsum_part: epilogue partials wanted
 // (at most one of them); *stat_spl = slots per (n, channel) written.
 int vts_conv_px_try(const vts_conv_desc* d, hipStream_t st, float* stat_part, float* bsum_part, int64_t part_floats, int* stat_spl) {
-  static const int enabled = getenv("VTS_NO_PX") ? 0 : 1;
+  static const int enabled = vts_tune_set("VTS_NO_PX") ? 0 : 1;
   // measured (tools/mb_px.py, profiles/r03d_px_microbench.txt): the 4x4x1 MFMA sustains 11 - 13 cycles per instruction (8 nominal), so
   // the mapping pays while the padding of the 16x16x4 tiles costs more than that: up to 12 output channels (9 -> 10 at 1024^2: 71 -> 64 us,
   // 4 -> 8 / 7 -> 8: 73 -> 54 / 59 -> 41 us, 3 -> 10 with mask: 37 -> 32 us); at 16 - 20 channels conv4x4_kernel is 15 - 30 % faster
-  static const int max_nb = getenv("VTS_PX_MAX_NB") ? atoi(getenv("VTS_PX_MAX_NB")) : 3;
-  static const int min_hw = getenv("VTS_PX_MIN_HW") ? atoi(getenv("VTS_PX_MIN_HW")) : 128 * 128;
+  static const int max_nb = vts_tune("VTS_PX_MAX_NB", 3);
+  static const int min_hw = vts_tune("VTS_PX_MIN_HW", 128 * 128);
   const int Cin = d->in0.C + (d->in1.data ? d->in1.C : 0);
   const int nb = (d->Cout + 3) / 4;
-  static const int enabled_t = getenv("VTS_NO_PXT") ? 0 : 1;
-  static const int max_nb_t = getenv("VTS_PXT_MAX_NB") ? atoi(getenv("VTS_PXT_MAX_NB")) : 3;
+  static const int enabled_t = vts_tune_set("VTS_NO_PXT") ? 0 : 1;
+  static const int max_nb_t = vts_tune("VTS_PXT_MAX_NB", 3);
   if (d->stride != 2 || d->pad_dx != 0 && d->transposed) return VTS_ERR_UNSUPPORTED;
   // (transposed, measured: 10 -> 3 / 10 -> 2 at 1024^2 42 -> 36 / 41 -> 35 us, 16 -> 8 at 513^2 72 -> 59 us (N 8), 8 -> 4 at 1025^2 62 -> 56 us;
   //  with 9 - 12 output channels only where convt2_thin_kernel was the alternative (10 -> 9: 180 -> 90 us; 40 -> 10: 88 vs 62 us on conv4x4_kernel))
@@ -739,9 +739,9 @@ int vts_conv_px_try(const vts_conv_desc* d, hipStream_t st, float* stat_part, fl
   VTS_CHECK_ARG(k.ident, "vts_conv4x4: could not allocate the identity constants");
   k.slope_in = vts_slope(d->act_in);
   k.identity_in = (d->act_in == VTS_ACT_NONE && !d->in0.scale && !d->in0.shift && !(d->in1.data && (d->in1.scale || d->in1.shift))) ? 1 : 0;
-  static const int xcd_swizzle = getenv("VTS_XCD_SWIZZLE") ? atoi(getenv("VTS_XCD_SWIZZLE")) : 1;
+  static const int xcd_swizzle = vts_tune("VTS_XCD_SWIZZLE", 1);
   k.xcd_swizzle = xcd_swizzle;
-  static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
+  static const int ablate = vts_tune("VTS_ABLATE", 0);
   k.ablate = ablate;
   int Tt = 0;
   if (d->transposed) {   // tiles of the low-resolution grid

@@ -391,7 +391,7 @@ int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st) {
   k.ident = vts_ident();
   if (!k.ident) return VTS_ERR_UNSUPPORTED;
   k.slope_in = vts_slope(d->act_in);
-  static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
+  static const int ablate = vts_tune("VTS_ABLATE", 0);
   k.ablate = ablate;
   k.wbytes = (int)(((int64_t)(d->Cout - 1) * d->ws_co + (int64_t)(k.Cin - 1) * d->ws_ci + 16) * 4);
   k.PWi = d->IW + 2 * HALO + 1;
@@ -410,7 +410,7 @@ int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st) {
   const int groups = cdiv(d->Cout, NR * 16);
   int ipb = (4 * 8 * 16) / (k.PPI * P);                          // fills 8 units per wave
   const int lds_cap = (48 * 1024 / 4 - CK * 16 * COP) / (CK * k.plane);
-  static const int small_wgs = getenv("VTS_SMALL_WGS") ? atoi(getenv("VTS_SMALL_WGS")) : 256;
+  static const int small_wgs = vts_tune("VTS_SMALL_WGS", 256);
   int ipb_par = (d->N * groups) / small_wgs;                     // keeps >= ~256 workgroups
   if (ipb_par < 1) ipb_par = 1;
   if (ipb > lds_cap) ipb = lds_cap;
@@ -422,7 +422,7 @@ int vts_conv_small_try(const vts_conv_desc* d, hipStream_t st) {
   const int upw = cdiv(k.MTP * P, 4);                            // units per wave
   if (upw > 8) return VTS_ERR_UNSUPPORTED;
   const int U = upw <= 1 ? 1 : (upw <= 2 ? 2 : (upw <= 4 ? 4 : 8));
-  static const int fast_on = getenv("VTS_SMALL_FLAT") ? atoi(getenv("VTS_SMALL_FLAT")) : 1;
+  static const int fast_on = vts_tune("VTS_SMALL_FLAT", 1);
   k.inbytes = (int)((int64_t)d->N * d->in0.nstride * 4 < (int64_t)0x40000000 ? (int64_t)d->N * d->in0.nstride * 4 : 0);
   k.fast = fast_on && !d->in1.data && k.Cin % CK == 0 && d->in0.nstride == (int64_t)k.Cin * d->IH * d->IW && (reinterpret_cast<uintptr_t>(d->in0.data) & 15) == 0 &&
            ipb * 2 * d->IH * d->IW <= 768 && k.inbytes > 0 && (reinterpret_cast<uintptr_t>(d->w) & 15) == 0 && ((d->ws_co | d->ws_ci) & 3) == 0;

@@ -157,7 +157,7 @@ int thin_launch(const ThinK& k, int N, hipStream_t st) {
 // measured and dropped: 54 us vs 58 us for 4 -> 8 @513^2 at best, 2x slower with the blocked window at 2-3 waves per SIMD; its 16
 // stride-2 loads and activations per output leave it instruction-bound like the MFMA kernel.)
 int vts_conv_thin_try(const vts_conv_desc* d, hipStream_t st) {
-  static const int enabled = getenv("VTS_NO_THIN") ? 0 : 1;
+  static const int enabled = vts_tune_set("VTS_NO_THIN") ? 0 : 1;
   const int Cin = d->in0.C + (d->in1.data ? d->in1.C : 0);
   if (!enabled || !d->transposed || d->stride != 2 || d->Cout > 16 || d->pad_dx != 0 || d->pad < 0) return VTS_ERR_UNSUPPORTED;
   // measured (profiles/r01k): wins 1.5-2.3x where Cin x Cout(padded) <= 128 (10 -> 3 @1024^2: 104 -> 51 us, 16 -> 8 @513^2: 70 -> 48 us);

@@ -27,6 +27,24 @@ int vts_wgrad3x3_wino_try(const float* dout, const float* in, float* part, int N
 bool vts_patchnce_mfma_ok(int P, int D);
 int vts_patchnce_mfma(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq, hipStream_t st);
 // LeakyReLU slope that expresses the activation codes as  t > 0 ? t : slope * t
+// Tuning / experiment switches (tile tables, thresholds, "run the other kernel" knobs: ~50 VTS_* names across the library) exist only in
+// the instrumented build (make PROFILING=1 -> libvts_hip_prof.so, loaded through VTS_LIB_PATH by tools/): there they are read from the
+// environment.  The PRODUCTION library reads exactly one environment variable (VTS_RCCL_LIB, the RCCL library to dlopen, vts_comm.cpp);
+// every dispatch decision in it is the measured default, a compile-time constant -- no switch can change what a user's run computes.
+#ifdef VTS_PROFILING
+#include <stdlib.h>
+static inline int vts_tune(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static inline bool vts_tune_set(const char* name) { return getenv(name) != nullptr; }
+static inline const char* vts_tune_str(const char* name) { return getenv(name); }
+#else
+static inline constexpr int vts_tune(const char*, int dflt) { return dflt; }
+static inline constexpr bool vts_tune_set(const char*) { return false; }
+static inline constexpr const char* vts_tune_str(const char*) { return nullptr; }
+#endif
+
 static inline float vts_slope(int act) { return act == VTS_ACT_LRELU ? 0.2f : (act == VTS_ACT_RELU ? 0.f : 1.f); }
 
 #define VTS_CHECK_ARG(cond, ...)     \

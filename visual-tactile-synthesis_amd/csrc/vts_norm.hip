@@ -1059,7 +1059,7 @@ extern "C" int vts_norm_bwd(const vts_norm_bwd_desc* d, float* ws, void* stream)
   hipLaunchKernelGGL(norm_bwd_partial_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, d->C, d->HW, spl,
                      d->mean, d->rstd, part);
   VTS_CHECK_LAUNCH("vts_norm_bwd partial");
-  static const int three = getenv("VTS_NORM_BWD_3K") ? atoi(getenv("VTS_NORM_BWD_3K")) : 0;   // 1: the separate finalize launch (A/B timing)
+  static const int three = vts_tune("VTS_NORM_BWD_3K", 0);   // 1: the separate finalize launch (A/B timing)
   if (!three) {
     hipLaunchKernelGGL(norm_bwd_apply_fin_kernel, dim3(spl, d->C, d->N), dim3(256), 0, st, d->dy, d->x, d->nstride, part, k);
     VTS_CHECK_LAUNCH("vts_norm_bwd apply");
@@ -1087,7 +1087,7 @@ extern "C" int vts_norm_bwd_from_partials(const vts_norm_bwd_desc* d, const floa
   }
   k.pspl = slots;
   k.beta = beta;
-  static const int wide = getenv("VTS_NORM_BWD_SUMS") ? atoi(getenv("VTS_NORM_BWD_SUMS")) : 1;   // 0: the 2048-element apply kernel (A/B)
+  static const int wide = vts_tune("VTS_NORM_BWD_SUMS", 1);   // 0: the 2048-element apply kernel (A/B)
   if (wide) {
     // elements per workgroup: multiples of 2048, as many as leave >= ~768 workgroups, at most 32 K
     int chunk = CHUNK;

@@ -725,7 +725,7 @@ inline unsigned blocks_for(int64_t n, int cap = 2048) {
 extern "C" int vts_avgpool3s2(const float* x, int64_t xns, int N, int C, int H, int W, float* y, void* stream) {
   VTS_CHECK_ARG(x && y && N * C <= 65535, "vts_avgpool3s2: bad args");
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-  static const bool rows4 = !(getenv("VTS_AVGPOOL_ROWS4") && atoi(getenv("VTS_AVGPOOL_ROWS4")) == 0);
+  static const bool rows4 = !(vts_tune("VTS_AVGPOOL_ROWS4", 1) == 0);
   if (rows4 && W % 2 == 0 && W >= 4 && (reinterpret_cast<uintptr_t>(x) & 7) == 0 && xns % 2 == 0 && ((int64_t)H * W) % 2 == 0)
     hipLaunchKernelGGL(avgpool_rows4_kernel, dim3(cdiv(OW, 64), cdiv(OH, 16), N * C), dim3(256), 0, (hipStream_t)stream, x, xns, C, H, W,
                        OH, OW, y);
@@ -1013,7 +1013,7 @@ extern "C" int vts_l2norm_rows(const float* x, int rows, int D, float* y, void* 
 extern "C" int vts_patchnce(const float* q, const float* k, int B, int P, int D, float T, float gscale, float* loss, float* dq,
                             void* stream) {
   VTS_CHECK_ARG(q && k && B >= 1 && P >= 1 && D >= 1 && T > 0.f, "vts_patchnce: bad args");
-  static const int use_mfma = getenv("VTS_PATCHNCE_MFMA") ? atoi(getenv("VTS_PATCHNCE_MFMA")) : 1;
+  static const int use_mfma = vts_tune("VTS_PATCHNCE_MFMA", 1);
   if (use_mfma && vts_patchnce_mfma_ok(P, D)) return vts_patchnce_mfma(q, k, B, P, D, T, gscale, loss, dq, (hipStream_t)stream);
   const size_t sm = (size_t)(D + P + 1) * sizeof(float);
   VTS_CHECK_ARG(sm <= 64 * 1024, "vts_patchnce: D + P too large for one LDS tile");

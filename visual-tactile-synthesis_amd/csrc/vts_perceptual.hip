@@ -407,7 +407,7 @@ extern "C" int vts_maxpool2_relu_bwd(const float* g, const float* z, int NC, int
   for (int c0 = 0; c0 < NC; c0 += 65535) {
     const int nc = NC - c0 < 65535 ? NC - c0 : 65535;
     const int64_t zo = (int64_t)c0 * (H + 2 * zpad) * (W + 2 * zpad);
-    static const int per_element = getenv("VTS_MAXPOOL_BWD_ELEM") ? 1 : 0;
+    static const int per_element = vts_tune_set("VTS_MAXPOOL_BWD_ELEM") ? 1 : 0;
     if (!per_element && H % 2 == 0 && W % 2 == 0)
       hipLaunchKernelGGL(maxpool2_relu_bwd_win_kernel, dim3(blocks_1d((int64_t)(H / 2) * (W / 2)), nc), dim3(256), 0, (hipStream_t)stream,
                          g + (int64_t)c0 * (H / 2) * (W / 2), z + zo, H, W, gz + (int64_t)c0 * PH * PW, zpad, g2 ? g2 + zo : nullptr, pad);
@@ -436,7 +436,7 @@ extern "C" int vts_lpips_layer(const float* z0, const float* z1, int N, int C, i
                                float* dz0, float grad_coeff, int W, int zpad, void* stream) {
   VTS_CHECK_ARG(z0 && z1 && w && N >= 1 && N <= 65535 && C >= 1 && HW >= 1 && zpad >= 0 && zpad <= 2 && (zpad == 0 || (W >= 1 && HW % W == 0)),
                 "vts_lpips_layer: bad args");
-  static const int generic = getenv("VTS_LPIPS_GENERIC") ? 1 : 0;
+  static const int generic = vts_tune_set("VTS_LPIPS_GENERIC") ? 1 : 0;
   const int Wm = W > 0 ? W : HW;
   auto* slot = reinterpret_cast<long long*>(loss_slot);
   const dim3 grid((HW + 63) / 64, N);

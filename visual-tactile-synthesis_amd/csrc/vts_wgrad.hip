@@ -955,7 +955,7 @@ Plan make_plan(const vts_wgrad_desc* d) {
   const int CL = d->lo0.C + (d->lo1.data ? d->lo1.C : 0), CH = d->hi0.C + (d->hi1.data ? d->hi1.C : 0);
   pl.ns = 0;
   pl.small = 0;
-  static const int use_small = getenv("VTS_WGRAD_SMALL") ? atoi(getenv("VTS_WGRAD_SMALL")) : 1;
+  static const int use_small = vts_tune("VTS_WGRAD_SMALL", 1);
   if (use_small && !d->lo1.data && !d->hi1.data && d->N >= 32 && d->LH * d->LW <= 324 && d->HH <= 34 && d->HW <= 34 && CL <= 64 && CH <= 64 &&
       d->pad >= 0 && d->pad <= SW_HALO && d->pad + d->pad_dx >= 0 && d->pad + d->pad_dx <= SW_HALO) {
     const int clt = CL <= 16 ? 1 : (CL <= 32 ? 2 : 4);
@@ -971,7 +971,7 @@ Plan make_plan(const vts_wgrad_desc* d) {
         const int pos = (ipb * d->LH * d->LW + 3) & ~3;
         const int posp = pos + ((4 - pos) & 31);       // row pitch = 4 (mod 32): the 16 channel rows of an A fragment land on distinct banks
         const int64_t floats = (int64_t)clt * 16 * posp + (int64_t)ipb * CH * plane + pos;
-        static const int lds_cap_kb = getenv("VTS_WGRAD_SMALL_LDS_KB") ? atoi(getenv("VTS_WGRAD_SMALL_LDS_KB")) : 150;
+        static const int lds_cap_kb = vts_tune("VTS_WGRAD_SMALL_LDS_KB", 150);
         if (floats * 4 <= (int64_t)lds_cap_kb * 1024 || (ipb == 1 && floats * 4 <= 150 * 1024)) {
           pl.small = 1; pl.clt = clt; pl.cht = chw; pl.ipb = ipb; pl.pos = pos; pl.posp = posp; pl.pwf = pwf; pl.plane = plane;
           pl.lds_bytes = (int)(floats * 4);
@@ -983,7 +983,7 @@ Plan make_plan(const vts_wgrad_desc* d) {
       }
     }
   }
-  static const int use_head = getenv("VTS_WGRAD_HEAD") ? atoi(getenv("VTS_WGRAD_HEAD")) : 1;
+  static const int use_head = vts_tune("VTS_WGRAD_HEAD", 1);
   if (use_head && CL == 1 && !d->lo1.data && !d->hi1.data && d->stride == 1 && d->act_lo == VTS_ACT_NONE && !d->lo0.scale && !d->lo0.shift &&
       d->LH >= 8 && d->LW >= 16 && d->act_hi != VTS_ACT_TANH) {
     pl.head = 1;
@@ -995,9 +995,9 @@ Plan make_plan(const vts_wgrad_desc* d) {
     pl.pw = pl.ntiles;
     return pl;
   }
-  static const int use_ns = getenv("VTS_WGRAD_NS") ? atoi(getenv("VTS_WGRAD_NS")) : 1;
-  static const int ns_min_ch = getenv("VTS_WGRAD_NS_MINCH") ? atoi(getenv("VTS_WGRAD_NS_MINCH")) : 2;   // (5 until round 3: 2 - 4 channel layers on the K-split kernel)
-  static const int ns_min_w = getenv("VTS_WGRAD_NS_MINW") ? atoi(getenv("VTS_WGRAD_NS_MINW")) : 8;
+  static const int use_ns = vts_tune("VTS_WGRAD_NS", 1);
+  static const int ns_min_ch = vts_tune("VTS_WGRAD_NS_MINCH", 2);   // (5 until round 3: 2 - 4 channel layers on the K-split kernel)
+  static const int ns_min_w = vts_tune("VTS_WGRAD_NS_MINW", 8);
   // (the buffer-load addressing of the N-split kernel needs channel planes below 2^26 bytes)
   if (use_ns && CH >= ns_min_ch && d->LW > ns_min_w && (int64_t)d->HH * d->HW < (1 << 24) && (int64_t)d->LH * d->LW < (1 << 24)) {
     // N-split kernel: the waves of a workgroup split 4*cht high-res channels; groups are balanced so that the last one is not mostly empty
@@ -1013,7 +1013,7 @@ Plan make_plan(const vts_wgrad_desc* d) {
     pl.tiles_x = cdiv(d->LW, 28);
     pl.ntiles = d->N * pl.tiles_y * pl.tiles_x;
     const int64_t nel = (int64_t)CL * CH * 16;
-    static const int old_plan = getenv("VTS_WGRAD_OLDPLAN") ? atoi(getenv("VTS_WGRAD_OLDPLAN")) : 0;
+    static const int old_plan = vts_tune("VTS_WGRAD_OLDPLAN", 0);
     if (old_plan) {   // round-2 rule (A/B switch): 512 workgroups, partial copies capped at 2x the operand bytes
       const int groups = pl.cl_groups * pl.ch_groups;
       int pw = 512 / groups;
@@ -1069,9 +1069,9 @@ Plan make_plan(const vts_wgrad_desc* d) {
       if (copies > pl.ntiles) copies = pl.ntiles;
       pl.pw = copies;
     }
-    static const bool tune = getenv("VTS_WGRAD_TUNE") != nullptr;   // tools/probes/wgrad_sweep.py: "cl_groups,ch_groups,copies" re-read per call
+    static const bool tune = vts_tune_set("VTS_WGRAD_TUNE");   // tools/probes/wgrad_sweep.py: "cl_groups,ch_groups,copies" re-read per call
     if (tune) {
-      const char* e = getenv("VTS_WGRAD_PLAN");
+      const char* e = vts_tune_str("VTS_WGRAD_PLAN");
       int a = 0, b = 0, c = 0;
       if (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && c >= 1) {
         pl.cl_groups = a;
@@ -1134,7 +1134,7 @@ void launch_ns_tall(const WgK& k, const Plan& pl, hipStream_t st) {
 
 // tile rows of the stride-2 N-split kernel for (clt, cht) accumulator tiles per wave on an LH-row map
 int ns_tile_rows(int clt, int cht, int LH) {
-  static const int tall = getenv("VTS_WGRAD_TALL") ? atoi(getenv("VTS_WGRAD_TALL")) : 1;
+  static const int tall = vts_tune("VTS_WGRAD_TALL", 1);
   // measured (tools/probes/wgrad_sweep.py): 8 rows help only with ONE high-resolution channel per wave (2 - 4 channel layers: up0
   // 52 -> 42 us, D layer 0 99 -> 77 us); with 2 - 3 channels per wave the 36 - 42 prefetch registers and 30 - 48 KB of patch rows
   // cost more co-resident workgroups than the longer tile saves (16 -> 8 channel layer: 43 -> 59 us)
@@ -1187,7 +1187,7 @@ extern "C" int vts_wgrad4x4(const vts_wgrad_desc* d, float* ws, void* stream) {
   k.cl_groups = pl.cl_groups; k.ch_groups = pl.ch_groups;
   k.tiles_y = pl.tiles_y; k.tiles_x = pl.tiles_x; k.ntiles = pl.ntiles;
   k.part = ws;
-  static const int ablate = getenv("VTS_ABLATE") ? atoi(getenv("VTS_ABLATE")) : 0;
+  static const int ablate = vts_tune("VTS_ABLATE", 0);
   k.ablate = ablate;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nel = (int64_t)k.lo.C * k.hi.C * 16;
@@ -1277,7 +1277,7 @@ extern "C" int vts_wgrad_reduce_batch(const vts_reduce_job* jobs, int njobs, voi
       t.blk_start[j] = blocks;
       int maxpw = 0;
       for (int sg = 0; sg < q.nseg; ++sg) maxpw = q.pw[sg] > maxpw ? q.pw[sg] : maxpw;
-      static const int narrow_min = getenv("VTS_REDUCE_NARROW_MIN") ? atoi(getenv("VTS_REDUCE_NARROW_MIN")) : 256;
+      static const int narrow_min = vts_tune("VTS_REDUCE_NARROW_MIN", 256);
       t.narrow[j] = maxpw > narrow_min ? 1 : 0;      // more than 16 copies per wave of the 256-element form
       blocks += (int)cdiv64(q.nel, t.narrow[j] ? 64 : RB_ELEMS);
     }

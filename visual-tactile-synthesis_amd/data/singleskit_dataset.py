@@ -23,6 +23,7 @@ list index only while every rectangle is valid (otherwise the reference raises I
 same behaviour).  Not carried over: the debugging plots / cv2.imwrite dumps and the `logs/<date>` directory the reference creates."""
 import ntpath
 import os
+from vts import tune
 import random
 import time
 
@@ -307,7 +308,7 @@ class SingleSkitDataset(torch.utils.data.Dataset):
                 d = {"S": S_tensor, "name": name, "S_paths": self.S_paths[0], "T_images": [], "augmentation_params": aug}
             if M_img is not None:
                 d.update({"M": M_tensor, "M_paths": self.M_paths[0]})
-            if os.environ.get("VTS_U8_BATCH", "1") != "0":      # (not a reference key: see to_u8)
+            if tune.get("VTS_U8_BATCH", "1") != "0":      # (not a reference key: see to_u8)
                 for key, pic in (("S", S3), ("I", I3), ("M", M3)):
                     raw = to_u8(pic) if key in d else None
                     if raw is not None and tuple(raw.shape) == tuple(d[key].shape):

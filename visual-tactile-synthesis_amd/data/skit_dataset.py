@@ -21,6 +21,7 @@ Not kept (continued):
 """
 import ntpath
 import os
+from vts import tune
 import time
 
 import numpy as np
@@ -149,7 +150,7 @@ class SkitDataset(SingleSkitDataset):
                 d.update({"M": M_tensor, "M_paths": self.M_paths[mi]})
             if self.style_codes[mi] is not None:
                 d["style_code"] = torch.from_numpy(self.style_codes[mi])
-            if os.environ.get("VTS_U8_BATCH", "1") != "0":      # (not a reference key: singleskit_dataset.to_u8)
+            if tune.get("VTS_U8_BATCH", "1") != "0":      # (not a reference key: singleskit_dataset.to_u8)
                 for key, pic in (("S", S3), ("I", I3), ("M", M3)):
                     raw = to_u8(pic) if key in d else None
                     if raw is not None and tuple(raw.shape) == tuple(d[key].shape):

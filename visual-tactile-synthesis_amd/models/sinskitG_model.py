@@ -17,6 +17,7 @@ What is different on this side of the boundary:
     must be disabled by flag -- requesting them raises instead of silently dropping them.
 """
 import os
+from vts import tune
 import random
 
 import numpy as np
@@ -32,8 +33,8 @@ from .base_model import BaseModel
 
 # 1 (default): on one GPU the generator's discriminator-free loss terms run as one more lane beside the discriminator updates; 0: serially
 # behind them (A/B timing; results are identical: the lanes only read the forward's outputs and add into their own fixed-point loss slots)
-G_PRE_LANE = os.environ.get("VTS_G_PRE_LANE", "1") != "0"
-D1_REAL_EARLY = os.environ.get("VTS_D1_REAL_EARLY", "1") != "0"     # D1's pass on the real images beside the generator forward (see _seg_d_updates)
+G_PRE_LANE = tune.get("VTS_G_PRE_LANE", "1") != "0"
+D1_REAL_EARLY = tune.get("VTS_D1_REAL_EARLY", "1") != "0"     # D1's pass on the real images beside the generator forward (see _seg_d_updates)
 
 B = str2bool
 
@@ -228,7 +229,7 @@ class SinSKITGModel(BaseModel):
         self._graphs = None     # the captured segments of the step, or None
         self._infer_graph, self._infer_eager_done = None, False   # captured inference forward (test())
         self._eager_steps_done = 0
-        if os.environ.get("VTS_KO_LANES") and os.environ.get("VTS_KO_LANES_ACK", "") != "timing-only":
+        if tune.get("VTS_KO_LANES", None) and tune.get("VTS_KO_LANES_ACK", "") != "timing-only":
             raise RuntimeError("VTS_KO_LANES skips discriminator lanes (wrong losses and gradients): set VTS_KO_LANES_ACK=timing-only to run the timing experiment")
         self._draws = None      # tests / parity runs inject {"aug": [4,N], "more_idx": [N,K]}
         self.ddp = None
@@ -373,7 +374,7 @@ class SinSKITGModel(BaseModel):
         # PCIe, ~ 57 us per patch set, between two steps); the launch stream then copies device -> device into the block the graphs read
         par = getattr(self, "_stage_parity", 0)
         stage = self._bufs.get("%s_stage%d" % (tag, par))
-        cs = getattr(self, "_copy_stream", None) if os.environ.get("VTS_PATCH_COPY_STREAM", "1") != "0" else None
+        cs = getattr(self, "_copy_stream", None) if tune.get("VTS_PATCH_COPY_STREAM", "1") != "0" else None
         if cs is not None and (stage is None or stage.numel() != words):
             stage = self._bufs["%s_stage%d" % (tag, par)] = torch.empty(words, dtype=torch.int32, device=self.device)
             cs.wait_stream(torch.cuda.current_stream())
@@ -398,7 +399,7 @@ class SinSKITGModel(BaseModel):
             if self._stage_done[par] is not None:
                 cs.wait_event(self._stage_done[par])      # the device -> device copy that read this staging block two batches ago
             with torch.cuda.stream(cs):
-                if os.environ.get("VTS_PATCH_COPY_KERNEL", "0") == "1":
+                if tune.get("VTS_PATCH_COPY_KERNEL", "0") == "1":
                     L.check(L.load().vts_copy_words(pin.data_ptr(), stage.data_ptr(), words, L.stream()), "vts_copy_words")
                 else:   # a DMA copy: a kernel on a fifth stream waits for one of the four hardware queues the step's lanes occupy
                     stage.copy_(pin, non_blocking=True)
@@ -421,7 +422,7 @@ class SinSKITGModel(BaseModel):
         self._stage_parity ^= 1
         # 8-bit sources (optional keys S_u8 / I_u8 / M_u8 next to the float tensors: the dataset front-ends attach them where the float
         # tensor IS ToTensor [+ Normalize] of those bytes): a quarter of the PCIe traffic, expanded on the device bit for bit (vts_u8_expand)
-        u8 = os.environ.get("VTS_U8_BATCH", "1") != "0"
+        u8 = tune.get("VTS_U8_BATCH", "1") != "0"
 
         def image(key, normalize):
             if u8 and (key + "_u8") in input:
@@ -435,7 +436,7 @@ class SinSKITGModel(BaseModel):
 
         # the usual training batch (8-bit S / I / M, background mask, [fake | real] pair buffers): ONE launch writes M, both copies of the
         # masked sketch and the masked real image from the three staged byte tensors (vts_input_images_u8; seven launches otherwise)
-        fused = (u8 and os.environ.get("VTS_FUSED_INPUT", "1") != "0" and self.opt.use_bg_mask and self.isTrain and phase == "train"
+        fused = (u8 and tune.get("VTS_FUSED_INPUT", "1") != "0" and self.opt.use_bg_mask and self.isTrain and phase == "train"
                  and "I" in input and all((k + "_u8") in input for k in ("S", "I", "M")))
         if fused:
             rawS, rawI, rawM = (self._load("%s_%s_u8" % (phase, k), input[k + "_u8"], dtype=torch.uint8, staged=True) for k in ("S", "I", "M"))
@@ -514,7 +515,7 @@ class SinSKITGModel(BaseModel):
             if "val_T_images" in input and len(input["val_T_images"]) > 0:
                 # only compute_metrics reads the validation patches: in the training phase they are uploaded on first use (the `val_set`
                 # property) instead of with every batch -- a host staging copy, a DMA and two launches per step saved
-                if phase == "train" and os.environ.get("VTS_LAZY_VAL_SET", "1") != "0":
+                if phase == "train" and tune.get("VTS_LAZY_VAL_SET", "1") != "0":
                     self._val_pending = (phase + "_va", input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
                 else:
                     self.val_set = self._patch_set(phase + "_va", input["val_T_images"], input["val_I_masks"], input["val_T_coords"])
@@ -537,7 +538,7 @@ class SinSKITGModel(BaseModel):
             pin = self._bufs.get("cand_count_pin")
             if pin is None or pin.numel() != n:
                 pin = self._bufs["cand_count_pin"] = torch.empty(n, dtype=torch.int32).pin_memory()
-            if getattr(self, "_copy_stream", None) is not None and os.environ.get("VTS_CAND_COPY_STREAM", "1") != "0":
+            if getattr(self, "_copy_stream", None) is not None and tune.get("VTS_CAND_COPY_STREAM", "1") != "0":
                 # off the launch stream: a device -> host copy between set_input's kernels and the step's graphs costs the launch stream two
                 # engine switches (~ 0.1 ms of idle device); nothing on the launch stream reads it
                 ready = torch.cuda.Event()
@@ -696,7 +697,7 @@ class SinSKITGModel(BaseModel):
         if not (self.opt.use_more_fakeT and "D2" in self.model_names):
             return
         k = self.opt.add_fake_T_sample_size
-        if self._draws is None and os.environ.get("VTS_HOST_RANKS", "0") != "1":
+        if self._draws is None and tune.get("VTS_HOST_RANKS", "0") != "1":
             # drawn on the device (vts_mask_sample_ranks: Floyd's algorithm over the candidate count the device already holds, seeded from
             # Python's `random` so that random.seed() still fixes the run).  The host used to fetch that count first -- a second evaluation
             # of the candidate map on the copy stream, a pinned read-back and a spin on its event, ~5 ms per iteration with a fresh batch
@@ -912,7 +913,7 @@ class SinSKITGModel(BaseModel):
             #  the term is a sum over patches and channels, so one call with twice the batch replaces two; the small maps of the deep
             #  VGG layers get twice the workgroups.  VTS_LPIPS_T_SPLIT=1: one call per channel, as in round 3)
             f, r = self.fake_T_concat, ts["real_T"]
-            if os.environ.get("VTS_LPIPS_T_SPLIT", "0") != "1" and f.is_contiguous() and r.is_contiguous() and d_patch.is_contiguous():
+            if tune.get("VTS_LPIPS_T_SPLIT", "0") != "1" and f.is_contiguous() and r.is_contiguous() and d_patch.is_contiguous():
                 P_.lpips_term(self.netLPIPS, f.view(2 * P, 1, 32, 32), r.view(2 * P, 1, 32, 32), opt.lambda_G2_lpips / n, slot["G2_lpips"],
                               grad_into=d_patch.view(2 * P, 1, 32, 32), grad_accumulate=have)
             else:

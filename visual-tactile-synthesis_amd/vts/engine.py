@@ -14,6 +14,7 @@ Reference graphs reproduced here:
 (their backward is PyTorch autograd in the reference).
 """
 import os
+from . import tune
 
 import torch
 
@@ -193,7 +194,7 @@ def unet_desc(G, x, g_out, style_tile=None, side_stream=None):
     return d
 
 
-UNET_C = os.environ.get("VTS_UNET_C", "1") != "0"     # inference forward through the network-level C entry (0: the Python schedule)
+UNET_C = tune.get("VTS_UNET_C", "1") != "0"     # inference forward through the network-level C entry (0: the Python schedule)
 
 
 def unet_c_ok(G, style_code):
@@ -895,11 +896,11 @@ def _pool_act(a):
 # The scales of a multiscale discriminator are independent chains of small kernels (the D2 passes over 32x32
 # tactile patches never fill 256 CUs): they run concurrently on side HIP streams, forked from and joined back
 # into the launch stream (so the schedule is still a DAG that torch.cuda.CUDAGraph captures as such).
-PARALLEL_SCALES = os.environ.get("VTS_PARALLEL_SCALES", "1") != "0"
+PARALLEL_SCALES = tune.get("VTS_PARALLEL_SCALES", "1") != "0"
 _SIDE_STREAMS = {}
 
 
-SIDE_QUEUES = int(os.environ.get("VTS_SIDE_QUEUES", "2"))     # round 4: 5.65 -> 5.59 ms (three: 5.61)
+SIDE_QUEUES = int(tune.get("VTS_SIDE_QUEUES", "2"))     # round 4: 5.65 -> 5.59 ms (three: 5.61)
 
 
 class SideQueue:
@@ -1014,12 +1015,12 @@ def _pyramid(D, in0, in1):
     return pyr
 
 
-FLAT_D = os.environ.get("VTS_FLAT_D", "1") != "0"
-FLAT_MIN_C = int(os.environ.get("VTS_FLAT_MIN_C", "64"))   # small maps: channels from which the flattened GEMM-class kernel takes over
+FLAT_D = tune.get("VTS_FLAT_D", "1") != "0"
+FLAT_MIN_C = int(tune.get("VTS_FLAT_MIN_C", "64"))   # small maps: channels from which the flattened GEMM-class kernel takes over
 
 
-WIDE_MIN_CI = int(os.environ.get("VTS_WIDE_MIN_CI", "64"))   # round 3 A/B: 32 / 64 (D1 layer 3 on the GEMM-class kernels) costs + 1.0 - 1.4 ms per step
-WIDE_MIN_CO = int(os.environ.get("VTS_WIDE_MIN_CO", "128"))
+WIDE_MIN_CI = int(tune.get("VTS_WIDE_MIN_CI", "64"))   # round 3 A/B: 32 / 64 (D1 layer 3 on the GEMM-class kernels) costs + 1.0 - 1.4 ms per step
+WIDE_MIN_CO = int(tune.get("VTS_WIDE_MIN_CO", "128"))
 
 
 def _flat4(conv, j, h, w, oh, ow, st):
@@ -1254,14 +1255,14 @@ def _sg2d_passes(D, passes, criterion):
             dst.add_(src) if acc else dst.copy_(src)
 
 
-KO_LANES = tuple(int(k) for k in os.environ.get("VTS_KO_LANES", "").split(",") if k)
+KO_LANES = tuple(int(k) for k in tune.get("VTS_KO_LANES", "").split(",") if k)
 if KO_LANES:      # timing experiment (tools/probes/r02_ko.sh): the named discriminator lanes are skipped, losses and gradients are WRONG
     import sys
     print("WARNING: VTS_KO_LANES=%s -- discriminator lanes are knocked out, this run's results are wrong (timing experiment only)"
-          % os.environ["VTS_KO_LANES"], file=sys.stderr, flush=True)
+          % tune.get("VTS_KO_LANES", ""), file=sys.stderr, flush=True)
 
 
-LANE_STREAMS = int(os.environ.get("VTS_LANE_STREAMS", "4"))
+LANE_STREAMS = int(tune.get("VTS_LANE_STREAMS", "4"))
 
 
 def _lane_groups(costs, env="VTS_LANE_GROUPS", streams=None):
@@ -1277,7 +1278,7 @@ def _lane_groups(costs, env="VTS_LANE_GROUPS", streams=None):
     captured graph first (5.87 vs 5.67 ms); 2 / 3 / 5 / all side-queue items of the generator backward behind ONE wait on the launch
     stream (5.63 - 5.70 ms: no effect); the decoder lanes' weight gradients on queues of their own (+ 0.22 ms)."""
     n = len(costs)
-    spec = os.environ.get(env, "")
+    spec = tune.get(env, "")
     if spec:
         groups = [[int(t) for t in g.split(",") if t.strip() != "" and int(t) < n] for g in spec.split("|")]
         groups = [g for g in groups if g]

@@ -5,6 +5,7 @@ per-(n,c) scale/shift produced by vts_norm_stats (see include/vts.h, vts_operand
 """
 import ctypes as C
 import os
+from . import tune
 
 import torch
 
@@ -39,7 +40,7 @@ DETAIL = None  # shape string of the launch being issued (only filled while TIME
 
 # timing experiments only (results are wrong): VTS_KNOCKOUT=norm_stats,wgrad4x4 skips every launch whose label starts with one of
 # the prefixes -- what a category of kernels contributes to the critical path of the laned step
-KNOCKOUT = tuple(k for k in os.environ.get("VTS_KNOCKOUT", "").split(",") if k)
+KNOCKOUT = tuple(k for k in tune.get("VTS_KNOCKOUT", "").split(",") if k)
 
 
 def _run(label, nbytes, flops, fn, *args):
@@ -86,7 +87,7 @@ _counters = {}
 # device-scope, and with one L2 per XCD a device-scope fence writes back / invalidates that whole L2 -- thousands of workgroups doing
 # so while six other lanes keep the L2s dirty is far more expensive than the ~140 tiny finalize launches it saves.  A kernel boundary
 # is the cheap cross-XCD synchronisation on this part.  (VTS_FUSE_FINALIZE=1 turns it on; tests/test_kernels_gpu.py covers both.)
-FUSE_FINALIZE = os.environ.get("VTS_FUSE_FINALIZE", "0") == "1"
+FUSE_FINALIZE = tune.get("VTS_FUSE_FINALIZE", "0") == "1"
 
 
 def counters(device):
@@ -132,7 +133,7 @@ def _op(a):
     return L.operand(a)
 
 
-BWD_SUMS = os.environ.get("VTS_BWD_SUMS", "1") != "0"
+BWD_SUMS = tune.get("VTS_BWD_SUMS", "1") != "0"
 BSUMS = {}       # data_ptr of a gradient tensor -> (partials, slots, the tensor): sums its producing convolution left for norm_bwd
 
 _stat_ws = {}
@@ -269,8 +270,8 @@ def _arena(device):
     return a
 
 
-DEFER_WGRAD = os.environ.get("VTS_WGRAD_DEFER", "1") != "0"
-FLUSH_BYTES = int(os.environ.get("VTS_WGRAD_FLUSH_MB", "96")) << 20   # a lane reduces its pending partials once they exceed this (keeps the reduction spread over the backward)
+DEFER_WGRAD = tune.get("VTS_WGRAD_DEFER", "1") != "0"
+FLUSH_BYTES = int(tune.get("VTS_WGRAD_FLUSH_MB", "96")) << 20   # a lane reduces its pending partials once they exceed this (keeps the reduction spread over the backward)
 
 
 def wgrad_flush(lane=None):
@@ -684,7 +685,7 @@ def w3x3_pack(w, mode, tag=None):
     return buf
 
 
-WINO = os.environ.get("VTS_WINO", "1") != "0"     # Winograd F(2x2, 3x3) for the frozen VGG stacks' 3x3 layers (0: direct GEMM-class kernel)
+WINO = tune.get("VTS_WINO", "1") != "0"     # Winograd F(2x2, 3x3) for the frozen VGG stacks' 3x3 layers (0: direct GEMM-class kernel)
 
 
 def w3x3_wino_pack(w, mode, tag=None):

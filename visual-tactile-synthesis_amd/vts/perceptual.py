@@ -15,6 +15,7 @@ The backward is the input adjoint only (no weight gradients): the same GEMM kern
 vts_maxpool2_relu_bwd behind a block, and the stem's 64 -> 3 adjoint as 4x4 tap blocks on the generator's kernel (ops.convk_bwd_data).
 """
 import os
+from . import tune
 
 import torch
 
@@ -22,8 +23,8 @@ from . import lib as L
 from . import ops
 
 RELU = L.ACT_RELU
-BATCH_PAIR = os.environ.get("VTS_LPIPS_BATCH_PAIR", "1") != "0"     # fake | real images as one batch through the VGG stack (0: two forwards, round 3)
-PADDED = os.environ.get("VTS_VGG_PADDED", "1") != "0"    # 0: every activation as a dense raw output + separate ReLU / padding passes (round 3)
+BATCH_PAIR = tune.get("VTS_LPIPS_BATCH_PAIR", "1") != "0"     # fake | real images as one batch through the VGG stack (0: two forwards, round 3)
+PADDED = tune.get("VTS_VGG_PADDED", "1") != "0"    # 0: every activation as a dense raw output + separate ReLU / padding passes (round 3)
 
 
 def _packed(net, k, mode):
