@@ -900,6 +900,78 @@ VARIANTS = {
 }
 
 
+# conditioning ablations the reference CAN run (probed round 5: --use_cGAN_G2 False dies in define_D -- networks.py:1658 dereferences an opt
+# that sinskitG_model.py:575 does not pass -- and --use_bg_mask False in optimize_parameters -- sinskitG_model.py:638 reads a self.M that
+# set_input only creates under use_bg_mask, :721)
+COND_VARIANTS = {
+    "no_cGAN": ["--use_cGAN", "False"],                                         # D1 on the image alone (3 channels)
+    "G2_no_S": ["--use_cGAN_G2_S", "False"],                                    # D2 stacks [T, I, mask] (6 channels)
+    "G2_no_I": ["--use_cGAN_G2_I", "False"],                                    # D2 stacks [T, S] (3 channels)
+    "no_cGAN_G2_T_only": ["--use_cGAN", "False", "--use_cGAN_G2_S", "False", "--use_cGAN_G2_I", "False"],     # D2 on the tactile patches alone
+}
+
+
+def cond_channels(extra):
+    kw = dict(zip((k.lstrip("-") for k in extra[::2]), (v == "True" for v in extra[1::2])))
+    c1 = 3 + (1 if kw.get("use_cGAN", True) else 0)
+    c2 = 2 + (1 if kw.get("use_cGAN_G2_S", True) else 0) + (4 if kw.get("use_cGAN_G2_I", True) else 0)
+    return c1, c2
+
+
+def golden_step_conditioning(size=256, seed=515, nt=64):
+    """One SinSKITGModel.optimize_parameters of the REFERENCE per entry of COND_VARIANTS -> tests/golden/sinskitG_cond_step_256.npz"""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from models.sinskitG_model import SinSKITGModel
+
+    out = {"size": size, "seed": seed, "nt": nt, "variants": np.array(list(COND_VARIANTS))}
+    for vi, (name, extra) in enumerate(COND_VARIANTS.items()):
+        flags = ["--lambda_G1_lpips", "0", "--lambda_G2_lpips", "0", "--use_vision_aided_loss", "False", "--lambda_G2_GAN_feat", "0",
+                 "--checkpoints_dir", "/tmp/vts_golden_ckpt", "--name", "golden_cond"] + extra
+        opt = _ref_opt("sinskitG", True, flags)
+        model = SinSKITGModel(opt)
+        model.setup(opt)
+        c1, c2 = cond_channels(extra)
+        shapesG, shapesD, shapesD2 = nets.g_param_shapes(), nets.d_param_shapes(c1), nets.d_param_shapes(c2)
+        for net, sh in ((model.netD, shapesD), (model.netD2, shapesD2)):
+            assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in sh.items()}, name
+        model.netG.load_state_dict(detrand.test_weights(shapesG, seed + 10 * vi))
+        model.netD.load_state_dict(detrand.test_weights(shapesD, seed + 10 * vi + 1))
+        model.netD2.load_state_dict(detrand.test_weights(shapesD2, seed + 10 * vi + 2))
+        model.train()
+        batch = _synthetic_batch(size, nt, seed + 10 * vi)
+        model.set_input(batch, phase="train")
+        k = int(nets.dilated_mask_positions(model.M).shape[0])
+        torch.manual_seed(seed + vi)
+        aug = torch.stack([torch.rand(1, 1, 1, 1).flatten() for _ in range(4)])
+        random.seed(seed + vi)
+        more = np.array(random.sample(range(k), opt.add_fake_T_sample_size), dtype=np.int64)[None]
+        torch.manual_seed(seed + vi)
+        random.seed(seed + vi)
+        model.optimize_parameters(epoch=1)
+        tag = name
+        out[tag + "/flags"] = json.dumps(extra)
+        out[tag + "/aug"] = aug.numpy()
+        out[tag + "/more_idx"] = more
+        losses = model.get_current_losses()
+        out[tag + "/loss_names"] = np.array(list(losses.keys()))
+        out[tag + "/loss_values"] = np.array(list(losses.values()), dtype=np.float64)
+        for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+            for kk, p in net.named_parameters():
+                out["%s/grad_%s/%s" % (tag, nm, kk)] = detrand.probe(p.grad, kk)
+                out["%s/param_%s/%s" % (tag, nm, kk)] = detrand.probe(p, kk)
+            for kk, b in net.named_buffers():
+                out["%s/buf_%s/%s" % (tag, nm, kk)] = b.detach().double().numpy()
+        out[tag + "/fake_I_probe"] = detrand.probe(model.fake_I, "fake_I")
+        out[tag + "/fake_T_probe"] = detrand.probe(model.fake_T, "fake_T")
+        out[tag + "/pred_fake_T_full_probe"] = detrand.probe(model.pred_fake_T_full, "pftf")
+        out[tag + "/pred_fake_I_probe"] = detrand.probe(model.pred_fake_I, "pfi")
+        print(name, c1, c2, {k: round(float(v), 5) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(GOLD, "sinskitG_cond_step_%d.npz" % size), **out)
+    print("wrote sinskitG_cond_step_%d.npz (%d entries)" % (size, len(out)))
+
+
 def variant_g_shapes(opt):
     from oracle import nets
     if opt.netG.startswith("resnet_"):
@@ -1039,6 +1111,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["ops", "nets", "step", "resnet", "global", "local", "p2p", "metrics", "sg2", "sg2step", "style", "io"]
+    if "cond" in which:
+        golden_step_conditioning()
     if "patchsample" in which:
         golden_patchsample()
     if "patchsamplewhole" in which:

@@ -33,6 +33,10 @@ DEFAULT_HP = dict(
     use_more_fakeT=True, use_diffaug=True, lr_scale=1.0, netG="unet256_custom",
     lambda_G1_lpips=0.0, lambda_G2_lpips=0.0,
     n_layers_D=3, n_layers_D2=3, smooth_GAN_label=True, diffaugment="bs",
+    # conditioning of the discriminators (sinskitG_model.py:525-559, 1359, 1372, 1481-1486, 1521-1560, 1578-1582, 1671, 1775-1779): D1 sees
+    # cat(S, I) or I alone; the D2 stacks are [T] + [S] + [I, mask].  (use_cGAN_G2 False and use_bg_mask False cannot run upstream:
+    # define_D is called without opt (networks.py:1658) / set_input never sets self.M (:638) -- probed, not restated.)
+    use_cGAN=True, use_cGAN_G2_S=True, use_cGAN_G2_I=True,
 )
 
 
@@ -172,11 +176,15 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     fake_I_concat = torch.cat([_gather_all(aug_fake_I, inp.coords).detach(), inp.masks], 1)
     fake_I_full = torch.cat([aug_fake_I.detach(), inp.M], 1)
 
+    cS, cI = bool(getattr(opt, "use_cGAN_G2_S", True)), bool(getattr(opt, "use_cGAN_G2_I", True))
+    d1_in = (lambda img: torch.cat((inp.real_S, img), 1)) if getattr(opt, "use_cGAN", True) else (lambda img: img)
+    stack = lambda t, s_, i_: torch.cat([t] + ([s_] if cS else []) + ([i_] if cI else []), 1)      # noqa: E731
+
     # ---- D1 step ----
     _req(sdD, True)
-    pred_fake = _d1(sdD, torch.cat((inp.real_S, fake_I.detach()), 1), opt)
+    pred_fake = _d1(sdD, d1_in(fake_I.detach()), opt)
     loss_D_fake_I = gl(pred_fake, False).mean() * lamD1
-    pred_real = _d1(sdD, torch.cat((inp.real_S, inp.real_I), 1), opt)
+    pred_real = _d1(sdD, d1_in(inp.real_I), opt)
     loss_D_real_I = gl(pred_real, True).mean() * lamD1
     loss_D1 = (loss_D_fake_I + loss_D_real_I) * 0.5
     loss_D1.backward()
@@ -189,10 +197,10 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
 
     # ---- D2 step ----
     _req(sdD2, True)
-    fake_stack = torch.cat((fake_T_concat.detach(), S_concat, fake_I_concat), 1)
+    fake_stack = stack(fake_T_concat.detach(), S_concat, fake_I_concat)
     pred_fake_T = _d2(sdD2, fake_stack, opt)
     loss_D_fake_T = gl(pred_fake_T, False).mean() * lamD2
-    full_stack = torch.cat((fake_T.detach(), inp.real_S, fake_I_full), 1)
+    full_stack = stack(fake_T.detach(), inp.real_S, fake_I_full)
     pred_full = _d2(sdD2, full_stack, opt)  # visualisation only; still updates BN stats
     loss_D_more = torch.zeros(())
     if opt.use_more_fakeT:
@@ -204,11 +212,11 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
             t = nets.gather_patches(fake_T[n:n + 1].detach(), ox, oy, 32)
             s = nets.gather_patches(inp.real_S[n:n + 1], ox, oy, 32)
             i = nets.gather_patches(fake_I[n:n + 1].detach(), ox, oy, 32)
-            stacks.append(torch.cat((t, s, i, torch.ones_like(s)), 1))
+            stacks.append(stack(t, s, torch.cat((i, torch.ones_like(s)), 1)))
         more_stack = torch.cat(stacks, 0)
         pred_more = _d2(sdD2, more_stack, opt)
         loss_D_more = gl(pred_more, False).mean() * lamD2
-    real_stack = torch.cat((inp.real_T, S_concat, real_I_concat), 1)
+    real_stack = stack(inp.real_T, S_concat, real_I_concat)
     pred_real_T = _d2(sdD2, real_stack, opt)
     loss_D_real_T = gl(pred_real_T, True).mean() * lamD2
     loss_D2 = (loss_D_fake_T + loss_D_more + loss_D_real_T) * 0.5
@@ -221,10 +229,10 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
     _req(sdD2, False)
 
     # ---- G step ----
-    pred_g = _d1(sdD, torch.cat((inp.real_S, fake_I), 1), opt)
+    pred_g = _d1(sdD, d1_in(fake_I), opt)
     loss_G_GAN = gl(pred_g, True).mean() * lamD1
     loss_G_L1 = F.l1_loss(fake_I, inp.real_I) * opt.lambda_G1_L1
-    g2_stack = torch.cat((fake_T_concat.clone().detach(), S_concat, fake_I_concat), 1)
+    g2_stack = stack(fake_T_concat.clone().detach(), S_concat, fake_I_concat)
     pred_g2 = _d2(sdD2, g2_stack, opt)
     loss_G2_GAN = (gl(pred_g2, True) * lamD2).view(-1, NT).mean(dim=0).sum()  # logged only: no gradient path
     l1 = (fake_T_concat - inp.real_T).abs() * opt.lambda_G2_L1

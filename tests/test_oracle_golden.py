@@ -380,6 +380,51 @@ def test_train_step_variants_match_reference(golden_dir):
                     _close(v.double().numpy(), g["%s/buf_%s/%s" % (name, nm, k)], rtol=1e-4, atol=1e-6)
 
 
+def test_train_step_conditioning_ablations_match_reference(golden_dir):
+    """--use_cGAN False (D1 on the image alone), --use_cGAN_G2_S / _I False (D2 stacks without the sketch / without image + mask) and all
+    three together: one reference step each (oracle/make_golden.py:COND_VARIANTS; the two conditioning flags the reference itself cannot
+    run -- use_cGAN_G2, use_bg_mask -- are not restated)"""
+    from oracle.make_golden import cond_channels
+    g = _load(golden_dir, "sinskitG_cond_step_256.npz")
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    for vi, name in enumerate(str(v) for v in g["variants"]):
+        extra = json.loads(str(g[name + "/flags"]))
+        opt = _variant_opt(extra)
+        c1, c2 = cond_channels(extra)
+        sdG = detrand.test_weights(nets.g_param_shapes(), seed + 10 * vi)
+        sdD = detrand.test_weights(nets.d_param_shapes(c1), seed + 10 * vi + 1)
+        sdD2 = detrand.test_weights(nets.d_param_shapes(c2), seed + 10 * vi + 2)
+        adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+        draws = {"more_idx": torch.from_numpy(g[name + "/more_idx"]), "aug": torch.from_numpy(g[name + "/aug"])}
+        out = step.train_step(sdG, sdD, sdD2, adam, _batch(size, nt, seed + 10 * vi), draws, opt=opt)
+        ref = dict(zip([str(s) for s in g[name + "/loss_names"]], g[name + "/loss_values"]))
+        for k, v in out["losses"].items():
+            assert abs(v - ref["l_" + k]) <= 2e-4 * max(1.0, abs(ref["l_" + k])), (name, k, v, ref["l_" + k])
+        _probe_close(out["pred_fake_T_full"], g[name + "/pred_fake_T_full_probe"], "pftf")
+        _probe_close(out["pred_fake_I"][-1], g[name + "/pred_fake_I_probe"], "pfi")
+        for nm, sd in (("G", sdG), ("D", sdD), ("D2", sdD2)):
+            for k, gr in out["grad_" + nm].items():
+                null = k.endswith("bias") and ((nm != "G" and k.split(".")[1] in ("2", "5", "8")) or
+                                                (nm == "G" and k.split(".")[0] not in ("down0", "down7", "up0", "up0_T")))
+                if null:
+                    continue       # a bias in front of a normalisation: analytically zero gradient, rounding noise on both sides (and Adam's
+                                   # first step turns that noise into +- lr: the parameter is not comparable either)
+                _probe_close(gr, g["%s/grad_%s/%s" % (name, nm, k)], k, rtol=5e-4)
+                _probe_close(sd[k], g["%s/param_%s/%s" % (name, nm, k)], k, rtol=1e-4)
+            for k, v in sd.items():
+                key = "%s/buf_%s/%s" % (name, nm, k)
+                if key not in g:
+                    continue
+                if k.endswith("running_mean"):
+                    # the conv bias in front of a BatchNorm has a zero gradient, Adam's first step moves it by +- lr along the SIGN of the
+                    # rounding noise, and the generator step's pass (after that update) folds the shift into the running mean at momentum
+                    # 0.1: +- 1e-4 per element between any two implementations (the variance is untouched and is compared at 1e-4)
+                    scale = float(np.sqrt(g[key.replace("running_mean", "running_var")].max()))
+                    assert np.abs(v.double().numpy() - g[key]).max() < 2.5e-4 * scale, (name, nm, k)
+                else:
+                    _close(v.double().numpy(), g[key], rtol=1e-4, atol=1e-6)
+
+
 def test_diffaugment_policies_match_reference(golden_dir):
     """every DiffAugment letter (b s c t o n) and multi-letter policies against the reference's outputs; the draws regenerate from
     torch's generator in the reference's order and are cross-checked against the recorded ones"""

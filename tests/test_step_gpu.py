@@ -120,6 +120,64 @@ def test_step_matches_reference_golden(golden_dir):
                     assert int(b) == int(refb), k
 
 
+def test_step_conditioning_ablations_match_reference_golden(golden_dir):
+    """--use_cGAN False (D1 on the image alone: its input gradient is then the gradient w.r.t. the ONLY concat source), --use_cGAN_G2_S False
+    and --use_cGAN_G2_I False (D2 stacks of 6 / 3 channels) and all three (D2 on the tactile patches alone): one REFERENCE step each
+    (tests/golden/sinskitG_cond_step_256.npz, oracle/make_golden.py:COND_VARIANTS).  The two conditioning flags the reference cannot run
+    itself (--use_cGAN_G2 False, --use_bg_mask False: probed) raise with that finding."""
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+    from oracle.make_golden import cond_channels
+
+    for bad in ("--use_cGAN_G2 False", "--use_bg_mask False"):
+        with pytest.raises(NotImplementedError, match="reference"):
+            create_model(TrainOptions(cmd_line=(FLAGS % (256, 1)) + " " + bad).parse())
+    g = np.load(os.path.join(golden_dir, "sinskitG_cond_step_256.npz"))
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    tol = 1e-3
+    for vi, name in enumerate(str(v) for v in g["variants"]):
+        extra = json.loads(str(g[name + "/flags"]))
+        opt = TrainOptions(cmd_line=(FLAGS % (size, 1)) + " " + " ".join(extra)).parse()
+        model = create_model(opt)
+        model.setup(opt)
+        model.parallelize()
+        model.train()
+        c1, c2 = cond_channels(extra)
+        sds = (detrand.test_weights(nets.g_param_shapes(), seed + 10 * vi), detrand.test_weights(nets.d_param_shapes(c1), seed + 10 * vi + 1),
+               detrand.test_weights(nets.d_param_shapes(c2), seed + 10 * vi + 2))
+        for net, sd in zip((model.netG, model.netD, model.netD2), sds):
+            assert sorted(net.state_dict().keys()) == sorted(sd.keys()), name
+            net.load_state_dict(sd)
+        model._draws = {"more_idx": torch.from_numpy(g[name + "/more_idx"]), "aug": torch.from_numpy(g[name + "/aug"])}
+        model.set_input(default_collate([make_sample(size, nt, nt, seed + 10 * vi)]), phase="train")
+        model.optimize_parameters(epoch=1)
+        ref = dict(zip([str(s) for s in g[name + "/loss_names"]], g[name + "/loss_values"]))
+        for k, v in model.get_current_losses().items():
+            assert abs(v - ref[k]) <= tol * max(1.0, abs(ref[k])), (name, k, v, ref[k])
+        for nm in ("fake_I", "fake_T", "pred_fake_T_full", "pred_fake_I"):
+            key = {"pred_fake_T_full": "pftf", "pred_fake_I": "pfi"}.get(nm, nm)
+            probe_close(getattr(model, nm).contiguous(), g["%s/%s_probe" % (name, nm)], key, 2 * tol)
+        for nm, net in (("G", model.netG), ("D", model.netD), ("D2", model.netD2)):
+            bn_convs = () if nm == "G" else tuple(str(c) for c in net.BN_IDX)
+            for k, p in net.named_parameters():
+                if (nm == "G" and null_grad_bias(nm, k)) or (nm != "G" and k.endswith("bias") and k.split(".")[1] in bn_convs):
+                    continue
+                probe_close(p.grad, g["%s/grad_%s/%s" % (name, nm, k)], k, 2 * tol)
+                probe_close(p.data, g["%s/param_%s/%s" % (name, nm, k)], k, tol)
+            for k, b in net.named_buffers():
+                refb = torch.from_numpy(g["%s/buf_%s/%s" % (name, nm, k)])
+                if k.endswith("running_mean"):
+                    scale = float(np.sqrt(g["%s/buf_%s/%s" % (name, nm, k.replace("running_mean", "running_var"))].max()))
+                    assert (b.double().cpu() - refb).abs().max().item() < tol * scale, (name, k)
+                elif b.dtype.is_floating_point:
+                    assert rel(b, refb) < tol, (name, k)
+                else:
+                    assert int(b) == int(refb), (name, k)
+        # the same step captured and replayed (default graph path): losses stay finite and the replicas of the step's outputs keep their shapes
+        assert model._full_stack.shape[1] == c2 and model._stack_all.shape[1] == c2
+
+
 def test_step_variants_match_reference_golden(golden_dir):
     """One reference step per variant of oracle/make_golden.py:VARIANTS: PatchGAN depths 2 / 4 (--n_layers_D, --n_layers_D2), hinge,
     and the six-letter DiffAugment policy 'bsctno' (its draws regenerate from torch's CPU generator in the reference's order)."""

@@ -181,10 +181,22 @@ class SinSKITGModel(BaseModel):
         self.flatG = FlatParams(self.netG, first=(lambda k: k.startswith("up")) if isinstance(self.netG, networks.CustomUnetGenerator) else None)
         self.use_cGAN_G2_S = bool(opt.use_cGAN_G2_S)
         self.use_cGAN_G2_I = bool(opt.use_cGAN_G2_I)
+        # Conditioning of the discriminators (sinskitG_model.py:525-559): D1 sees cat(S, I) or, with --use_cGAN False, the image alone; the D2
+        # stacks are [T(2)] + [S(1)] (use_cGAN_G2_S) + [I(3), mask(1)] (use_cGAN_G2_I).  Channel offsets of the stacks:
+        self.use_cGAN = bool(opt.use_cGAN)
+        self._cS = 2 if self.use_cGAN_G2_S else None                     # sketch channel
+        self._cI = (2 + (1 if self.use_cGAN_G2_S else 0)) if self.use_cGAN_G2_I else None      # image channels (3), then the mask
+        self._c2 = 2 + (1 if self.use_cGAN_G2_S else 0) + (4 if self.use_cGAN_G2_I else 0)
         if self.isTrain:
-            if not (opt.use_cGAN and opt.use_cGAN_G2 and self.use_cGAN_G2_S and self.use_cGAN_G2_I and opt.use_bg_mask):
-                raise NotImplementedError("the HIP step is built for the default conditioning "
-                                          "(use_cGAN, use_cGAN_G2{,_S,_I}, use_bg_mask all True)")
+            if not opt.use_cGAN_G2:
+                # probed on the reference (round 5, CPU): SinSKITGModel.__init__ dies -- define_D(...) for netD2 is called without `opt`
+                # (sinskitG_model.py:575) and MultiscaleDiscriminator reads opt.gan_mode (networks.py:1658)
+                raise NotImplementedError("--use_cGAN_G2 False: the reference itself cannot construct this model (define_D without opt, "
+                                          "networks.py:1658); use --use_cGAN_G2_S False --use_cGAN_G2_I False for D2 on the tactile patches alone")
+            if not opt.use_bg_mask:
+                # probed on the reference: optimize_parameters dies at sinskitG_model.py:638 (self.M is only set under use_bg_mask, :721)
+                raise NotImplementedError("--use_bg_mask False: the reference's training step cannot run without the mask (sinskitG_model.py:638 "
+                                          "reads self.M, which set_input creates only under use_bg_mask, :721)")
             if opt.T_resolution_multiplier != 1:
                 # Probed on the reference itself (round 3, CPU, 256 x 256, --T_resolution_multiplier 2, netG unet256_custom and
                 # resnet_9blocks): its own optimize_parameters fails with "Sizes of tensors must match except in dimension 1. Expected
@@ -197,12 +209,12 @@ class SinSKITGModel(BaseModel):
                                           "(patch sizes 32 vs %d collide in compute_D2_loss, sinskitG_model.py:1477-1484)"
                                           % (opt.T_resolution_multiplier, 32 * opt.T_resolution_multiplier))
             if "D" in self.model_names:
-                self.netD = networks.define_D(opt.image_nc + opt.sketch_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.normD,
+                self.netD = networks.define_D(opt.image_nc + (opt.sketch_nc if self.use_cGAN else 0), opt.ndf, opt.netD, opt.n_layers_D, opt.normD,
                                               opt.init_type, opt.init_gain, opt.no_antialias, num_D=opt.num_D_D1,
                                               gpu_ids=self.gpu_ids, opt=opt)
                 self.flatD = FlatParams(self.netD)
             if "D2" in self.model_names:
-                self.netD2 = networks.define_D(opt.touch_nc + opt.sketch_nc + opt.image_nc + 1, opt.ndf, opt.netD2,
+                self.netD2 = networks.define_D(self._c2, opt.ndf, opt.netD2,
                                                opt.n_layers_D2, opt.normD, opt.init_type, opt.init_gain, opt.no_antialias,
                                                num_D=opt.num_D_D2, gpu_ids=self.gpu_ids, opt=opt)
                 self.flatD2 = FlatParams(self.netD2)
@@ -617,10 +629,11 @@ class SinSKITGModel(BaseModel):
         has_real = hasattr(self, "real_I") and not self.test_edit_S
         self.fake_I = self._I2[:n] if (has_real and getattr(self, "_pair", False)) else torch.empty(n, 3, h, w, device=dev)
         self.fake_N = torch.empty(n, 3, h, w, device=dev)
-        # the D2 full-resolution stack [fake_T(2), S(1), aug_fake_I(3), M(1)] is filled in place
-        self._full_stack = torch.empty(n, 7, h, w, device=dev)
+        # the D2 full-resolution stack [fake_T(2), S(1), aug_fake_I(3), M(1)] (default conditioning; see _cS / _cI) is filled in place
+        cS, cI = self._cS, self._cI
+        self._full_stack = torch.empty(n, self._c2, h, w, device=dev)
         self.fake_T = self._full_stack[:, 0:2]
-        aug_fake = self._full_stack[:, 3:6] if has_real else None
+        aug_fake = (self._full_stack[:, cI:cI + 3] if cI is not None else torch.empty(n, 3, h, w, device=dev)) if has_real else None
         rb = rs = None
         policy = None
         if has_real and opt.use_diffaug and opt.diffaugment and opt.diffaugment != "bs":
@@ -648,7 +661,8 @@ class SinSKITGModel(BaseModel):
         # (training: the same pass writes the sketch and the mask into their channels of the full-resolution D2 stack)
         ops.g_post(g_out, self.M, opt.scale_nz, rb, rs, fake_I=self.fake_I, fake_T=self.fake_T, fake_N=self.fake_N,
                    aug_fake_I=aug_fake if policy is None else None, S=self.real_S if keep else None,
-                   stack_S=self._full_stack[:, 2:3] if keep else None, stack_M=self._full_stack[:, 6:7] if keep else None)
+                   stack_S=self._full_stack[:, cS:cS + 1] if (keep and cS is not None) else None,
+                   stack_M=self._full_stack[:, cI + 3:cI + 4] if (keep and cI is not None) else None)
         if policy is not None:
             ops.diffaug_policy(self.fake_I.contiguous(), policy, pdraws[1], self.M, aug_fake)
         self.aug_fake_I = aug_fake
@@ -740,26 +754,32 @@ class SinSKITGModel(BaseModel):
         # patches (compute_additional_output :1268-1291)
         # the patch stacks of the D2 update in ONE buffer, [fake | more fake | real] along the batch (batched passes)
         K = self.real_S.shape[0] * opt.add_fake_T_sample_size if (opt.use_more_fakeT and "D2" in self.model_names) else 0
-        self._stack_all = torch.empty(2 * P + K, 7, 32, 32, device=dev)
+        cS, cI = self._cS, self._cI
+        self._stack_all = torch.empty(2 * P + K, self._c2, 32, 32, device=dev)
         fake_stack = self._stack_all[:P]                      # [fake_T, S, aug_fake_I, mask]
         real_stack = self._stack_all[P + K:]                  # [real_T, S, aug_real_I, mask]
         self._more_stack = self._stack_all[P:P + K]
         self.fake_T_concat = torch.empty(P, 2, 32, 32, device=dev)
         g = dict(img=ts["img"], offx=ts["offx"], offy=ts["offy"])
         # every channel run of the three stacks in ONE launch (ops.patch_jobs; it was nine gathers and five copies)
-        jobs = [dict(dst=fake_stack, c0=0, src=self.fake_T, channels=2, **g), dict(dst=fake_stack, c0=2, src=self.real_S, **g),
-                dict(dst=fake_stack, c0=3, src=self.aug_fake_I, channels=3, **g), dict(dst=fake_stack, c0=6, src=ts["masks"]),
-                dict(dst=real_stack, c0=0, src=ts["real_T"]), dict(dst=real_stack, c0=2, src=self.real_S, **g),
-                dict(dst=real_stack, c0=3, src=self.aug_real_I, **g), dict(dst=real_stack, c0=6, src=ts["masks"]),
+        jobs = [dict(dst=fake_stack, c0=0, src=self.fake_T, channels=2, **g), dict(dst=real_stack, c0=0, src=ts["real_T"]),
                 dict(dst=self.fake_T_concat, c0=0, src=self.fake_T, channels=2, **g)]
+        if cS is not None:
+            jobs += [dict(dst=fake_stack, c0=cS, src=self.real_S, **g), dict(dst=real_stack, c0=cS, src=self.real_S, **g)]
+        if cI is not None:
+            jobs += [dict(dst=fake_stack, c0=cI, src=self.aug_fake_I, channels=3, **g), dict(dst=fake_stack, c0=cI + 3, src=ts["masks"]),
+                     dict(dst=real_stack, c0=cI, src=self.aug_real_I, **g), dict(dst=real_stack, c0=cI + 3, src=ts["masks"])]
         if K:
             # the "more fake T" squares at random positions of the dilated mask (model_utils.py:212-222): [fake_T, S, fake_I, 1]
             h, w = self.real_S.shape[2:]
             mox, moy = ops.mask_select(self._cand, self._cand_prefix, self._ranks, h, w)
             self.fake_sample_offset_x, self.fake_sample_offset_y = mox, moy
             m = dict(img=self._more_img, offx=mox, offy=moy)
-            jobs += [dict(dst=self._more_stack, c0=0, src=self.fake_T, channels=2, **m), dict(dst=self._more_stack, c0=2, src=self.real_S, **m),
-                     dict(dst=self._more_stack, c0=3, src=self.fake_I, **m), dict(dst=self._more_stack, c0=6, channels=1, fill=1.0)]
+            jobs += [dict(dst=self._more_stack, c0=0, src=self.fake_T, channels=2, **m)]
+            if cS is not None:
+                jobs += [dict(dst=self._more_stack, c0=cS, src=self.real_S, **m)]
+            if cI is not None:
+                jobs += [dict(dst=self._more_stack, c0=cI, src=self.fake_I, **m), dict(dst=self._more_stack, c0=cI + 3, channels=1, fill=1.0)]
         ops.patch_jobs(jobs)
         self._fake_stack, self._real_stack = fake_stack, real_stack
 
@@ -776,8 +796,9 @@ class SinSKITGModel(BaseModel):
         if (D1_REAL_EARLY and "D" in self.model_names and self._pair and not getattr(self.netD, "is_stylegan2_d", False)
                 and getattr(self, "_I2_pyr", None) is not None and engine.PARALLEL_SCALES):
             lam = opt.lambda_G1_GAN
-            pyr = [(Act(S[n:2 * n]), Act(I[n:2 * n])) for S, I in zip(self._S2_pyr, self._I2_pyr)]
-            p_real_early = dict(in0=self._S2[n:], in1=self._I2[n:], pyr=pyr, real=True, coeff=lam, slot=slot["D_real_I"], grad_coeff=0.5 * lam,
+            pyr = [self._d1_pair(Act(S[n:2 * n]), Act(I[n:2 * n])) for S, I in zip(self._S2_pyr, self._I2_pyr)]
+            in0, in1 = self._d1_pair(self._S2[n:], self._I2[n:])
+            p_real_early = dict(in0=in0, in1=in1, pyr=pyr, real=True, coeff=lam, slot=slot["D_real_I"], grad_coeff=0.5 * lam,
                                 stat_only=True, keep_stats=True)
             ops.step_begin(self._loss_buf, self._step_counters)      # (in front of the fork: the real pass adds into its loss slot)
             engine.msd_multi([(self.netD, [p_real_early])], self.criterionGAN, extra=lambda: self._forward_and_stacks(begin=False), extra_cost=1.0,
@@ -790,17 +811,21 @@ class SinSKITGModel(BaseModel):
             lam = opt.lambda_G1_GAN
             if p_real_early is not None:
                 pyr = self._d1_pyramid(n, pool_fake=True)
-                p_fake_I = dict(in0=self._S2[:n], in1=self._I2[:n], pyr=pyr, prep=self._d1_pool_prep() if pyr is not None else None,
+                in0, in1 = self._d1_pair(self._S2[:n], self._I2[:n])
+                p_fake_I = dict(in0=in0, in1=in1, pyr=pyr, prep=self._d1_pool_prep() if pyr is not None else None,
                                 groups=[dict(n0=0, n1=n, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)],
                                 accumulate=True, ext_from=p_real_early, ext_after=0)
                 jobs.append((self.netD, [p_fake_I]))
             elif getattr(self.netD, "is_stylegan2_d", False) or not self._pair:
-                p_fake_I = dict(in0=self.real_S, in1=self.fake_I, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)
-                jobs.append((self.netD, [p_fake_I, dict(in0=self.real_S, in1=self.real_I, real=True, coeff=lam, slot=slot["D_real_I"],
+                in0, in1 = self._d1_pair(self.real_S, self.fake_I)
+                p_fake_I = dict(in0=in0, in1=in1, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam)
+                in0, in1 = self._d1_pair(self.real_S, self.real_I)
+                jobs.append((self.netD, [p_fake_I, dict(in0=in0, in1=in1, real=True, coeff=lam, slot=slot["D_real_I"],
                                                         grad_coeff=0.5 * lam, accumulate=True)]))
             else:   # fake | real batched: rows [0, n) / [n, 2n) of the persistent pair buffers
                 pyr = self._d1_pyramid(2 * n, pool_fake=True)
-                p_fake_I = dict(in0=self._S2, in1=self._I2, pyr=pyr, prep=self._d1_pool_prep() if pyr is not None else None, groups=[
+                in0, in1 = self._d1_pair(self._S2, self._I2)
+                p_fake_I = dict(in0=in0, in1=in1, pyr=pyr, prep=self._d1_pool_prep() if pyr is not None else None, groups=[
                     dict(n0=0, n1=n, real=False, coeff=lam, slot=slot["D_fake_I"], grad_coeff=0.5 * lam),
                     dict(n0=n, n1=2 * n, real=True, coeff=lam, slot=slot["D_real_I"], grad_coeff=0.5 * lam)])
                 jobs.append((self.netD, [p_fake_I]))
@@ -861,7 +886,12 @@ class SinSKITGModel(BaseModel):
         fake-image rows now (the D update, right after the forward); the generator step reuses those levels."""
         if getattr(self, "_I2_pyr", None) is None or not self._pair or self.fake_I.data_ptr() != self._I2.data_ptr():
             return None
-        return [(Act(S[:rows]), Act(I[:rows])) for S, I in zip(self._S2_pyr, self._I2_pyr)]
+        return [self._d1_pair(Act(S[:rows]), Act(I[:rows])) for S, I in zip(self._S2_pyr, self._I2_pyr)]
+
+    def _d1_pair(self, S, I):
+        """the two concat sources of D1's first layer: (S, I) -- torch.cat((real_S, image), 1), sinskitG_model.py:1359-1372, 1671 -- or, with
+        --use_cGAN False, the image alone"""
+        return (S, I) if self.use_cGAN else (I, None)
 
     def _d1_pool_prep(self):
         """{scale: callable} pooling the fake-image rows of the D1 input pyramid INSIDE each scale's lane (engine.msd_multi `prep`):
@@ -934,7 +964,8 @@ class SinSKITGModel(BaseModel):
         if "D" in self.model_names:
             self.optimizer_D.step(self._gscale, bump=False)
             lam = opt.lambda_G1_GAN
-            jobs.append((self.netD, [dict(in0=self.real_S, in1=self.fake_I, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
+            in0, in1 = self._d1_pair(self.real_S, self.fake_I)
+            jobs.append((self.netD, [dict(in0=in0, in1=in1, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
                                           param_grads=False, input_grad=(self._d_fake_I, self._have_dI),
                                           pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False))]))
             self._have_dI = True

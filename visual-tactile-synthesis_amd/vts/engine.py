@@ -1139,10 +1139,11 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
                 ops.conv4x4(Act(g), conv.weight, 16, cin * 16, cin, tgt, stride=st, pad=2, transposed=True, dmask=prev,
                             dmask_act=LRELU, bwd_sums=D.CONV_IDX[j - 1] in D.BN_IDX)
             g = tgt
-        elif want_input_grad:
-            c0 = a0.data.shape[1]
-            c1 = a1.data.shape[1]
-            tgt, acc_in = (torch.empty_like(a1.data), False) if into is None else into
+        elif want_input_grad:      # w.r.t. the second concat source, or the only one (D1 without the sketch: --use_cGAN False)
+            src = a1 if a1 is not None else a0
+            c0 = a0.data.shape[1] if a1 is not None else 0
+            c1 = src.data.shape[1]
+            tgt, acc_in = (torch.empty_like(src.data), False) if into is None else into
             ops.conv4x4(Act(g), conv.weight.view(-1)[c0 * 16:], 16, cin * 16, c1, tgt, stride=st, pad=2, transposed=True, accumulate=acc_in)
             return tgt
     return None
@@ -1342,11 +1343,12 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, st
             a0, a1 = p["_pyr"][s]
             if i in KO_LANES:   # timing experiment only (VTS_KO_LANES; results are wrong): what a lane costs on the step's critical path
                 p["preds"][s] = torch.zeros(1, 1, 1, 1, device=a0.data.device)
-                if p.get("input_grad") is not None and a1 is not None:
-                    p["_din"][s] = torch.zeros_like(a1.data)
+                if p.get("input_grad") is not None:
+                    p["_din"][s] = torch.zeros_like((a1 if a1 is not None else a0).data)
                 continue
             ig = p.get("input_grad")
-            into = (ig[0], ig[1]) if (ig is not None and s == 0 and a1 is not None and ig[0].shape == a1.data.shape and ig[0].is_contiguous()) else None
+            gsrc = a1 if a1 is not None else a0
+            into = (ig[0], ig[1]) if (ig is not None and s == 0 and ig[0].shape == gsrc.data.shape and ig[0].is_contiguous()) else None
             groups = p.get("groups")
             gstarts = [gr["n0"] for gr in groups] if groups else None
             stat_rec = p.setdefault("_stats", {}).setdefault(s, {}) if p.get("stat_only") else None
