@@ -319,7 +319,7 @@ static int conv4x4_impl(const vts_conv_desc* d, void* stream, const vts_norm_des
     int ck = 4;
     const int nchunks = (k.Cin + 3) / 4;
     static const int small_thr = vts_tune("VTS_SMALL_WGS", 300);   // < ~1.2 workgroups per CU: split (measured: 128 -> 300 = step 7.88 -> 7.51 ms)
-    static const int target_wgs = vts_tune("VTS_TARGET_WGS", 320);
+    static const int target_wgs = vts_tune("VTS_TARGET_WGS", 256);   // round 5 sweep on the step (same box, tools/ab_env.sh): 128 5.56, 192 - 256 5.51 - 5.53, 288 5.57, 320 (the round-2 value) 5.59, 512 5.59, 768 5.61 ms
     if (full_wgs < small_thr && (nr > 1 || nchunks >= 8)) {
       const int base = cdiv(GW, 32) * cdiv(GH, 4) * N * nr;
       int KS = target_wgs / base;
