@@ -297,23 +297,40 @@ def collective_ab(model, world, dev, barrier, steps=10):
         return float(t.item()) / steps * 1e3
 
     res = {"torch_all_reduce_ms_per_step": timed(), "direct_ms_per_step": None, "direct_checked": False, "chosen": "torch"}
+
+    def all_agree(flag):      # every rank takes the same branch below: a local failure must not leave the others inside a collective
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() == 1.0)
+
+    ok = True
     try:
-        n = 1000003
+        ddp.direct_comm()                                     # the library's communicator (its id travels over the default group)
+    except Exception as e:      # noqa: BLE001
+        ok = False
+        res["direct_error"] = repr(e)[:300]
+    if all_agree(ok):
+        n = 1000003                                           # not a multiple of any world size: exercises the tail all-reduce
         x = (torch.arange(n, device=dev, dtype=torch.float32) % 97.0) * float(dist.get_rank() + 1)
         ref = x.clone()
         dist.all_reduce(ref)
-        ddp.DIRECT = True
-        b = ddp.GradBucket(x)
-        b.start()
-        b.wait()
         torch.cuda.synchronize()
-        ok = torch.tensor([1.0 if torch.equal(x, ref) else 0.0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        res["direct_checked"] = bool(ok.item() == 1.0)
+        try:
+            ddp.DIRECT = True
+            b = ddp.GradBucket(x)
+            b.start()
+            b.wait()
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(x, ref))
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            res["direct_error"] = repr(e)[:300]
+        ddp.DIRECT = False
+        res["direct_checked"] = all_agree(ok)
         if res["direct_checked"]:
+            ddp.DIRECT = True
             res["direct_ms_per_step"] = timed()
-    except Exception as e:      # noqa: BLE001
-        res["direct_error"] = repr(e)[:300]
+            ddp.DIRECT = False
     use_direct = bool(res["direct_checked"] and res["direct_ms_per_step"] is not None and res["direct_ms_per_step"] < res["torch_all_reduce_ms_per_step"])
     flag = torch.tensor([1.0 if use_direct else 0.0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # one decision for all ranks
@@ -463,7 +480,7 @@ def main():
         model.optimize_parameters(epoch=1)
     barrier()
     ab = None
-    if world > 1 and os.environ.get("VTS_DDP_AB", "1") != "0" and "VTS_DDP_DIRECT" not in os.environ:
+    if ((world > 1 and os.environ.get("VTS_DDP_AB", "1") != "0") or (ddp.active() and os.environ.get("VTS_DDP_AB") == "force")) and "VTS_DDP_DIRECT" not in os.environ:
         ab = collective_ab(model, world, dev, barrier)      # torch.distributed all_reduce vs the library's reduce-scatter + all-gather
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step on the launch stream: spread, no sync
     t0 = time.perf_counter()

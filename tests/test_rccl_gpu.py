@@ -41,6 +41,16 @@ def test_rccl_debug_log_reports_the_rank_count():
     assert c["ms_per_step_per_rank"]["min"] == c["ms_per_step_per_rank"]["max"] > 0
 
 
+def test_bench_collective_ab_runs_on_the_one_rank_group():
+    """the warm-up A/B of bench.py (torch.distributed all_reduce vs the library's reduce-scatter + all-gather; automatic at world > 1) forced
+    on the one-rank group: the direct path is checked against all_reduce on a 1000003-element buffer, both are timed, one is chosen"""
+    out, err = _bench(["--size", "256", "--batch", "1", "--steps", "12"], {"VTS_DDP_FORCE": "1", "VTS_DDP_AB": "force", "MASTER_PORT": "29566"}, want_stderr=True)
+    ab = out["comm"]["collective_ab"]
+    assert ab is not None and ab["direct_checked"] is True and "direct_error" not in ab, (ab, err[-2000:])
+    assert ab["torch_all_reduce_ms_per_step"] > 0 and ab["direct_ms_per_step"] > 0 and ab["chosen"] in ("torch", "direct")
+    assert out["comm"]["collective"].startswith("reduce-scatter" if ab["chosen"] == "direct" else "torch.distributed")
+
+
 def test_direct_reduce_scatter_all_gather_collective_single_rank(tmp_path):
     """VTS_DDP_DIRECT=1: the buckets go through the library's own RCCL communicator (reduce-scatter + all-gather + tail all-reduce on a
     side stream, include/vts.h: vts_allreduce_flat_async / _wait) instead of torch.distributed's all_reduce -- one rank: the sum over
