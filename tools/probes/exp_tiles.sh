@@ -1,5 +1,8 @@
 cd $GRAFT_REPO_ROOT
-export VTS_LIB_PATH=$PWD/visual-tactile-synthesis_amd/libvts_hip_skew.so
-echo "== off"; python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
-for m in 1 2 3; do for d in 2 4; do echo "== m${m}d${d}"; VTS_SKEW=$m VTS_SKEW_DIV=$d python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"; done; done
-VTS_SKEW=2 VTS_SKEW_DIV=4 python -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py -x -q -m gpu 2>&1 | tail -2
+P=$PWD/visual-tactile-synthesis_amd
+echo "== run1 default"; VTS_LIB_PATH=$P/libvts_hip_run1.so python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
+echo "== run3 default"; VTS_LIB_PATH=$P/libvts_hip_run3.so python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
+echo "== run3 RUN=2"; VTS_TILE_RUN=2 VTS_LIB_PATH=$P/libvts_hip_run3.so python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
+echo "== run3 RUN=4"; VTS_TILE_RUN=4 VTS_LIB_PATH=$P/libvts_hip_run3.so python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
+echo "== run3 chunks<=10"; VTS_TILE_RUN_CHUNKS=10 VTS_LIB_PATH=$P/libvts_hip_run3.so python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
+echo "== run3 chunks<=10 wgs1024"; VTS_TILE_RUN_CHUNKS=10 VTS_TILE_RUN_WGS=1024 VTS_LIB_PATH=$P/libvts_hip_run3.so python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"

@@ -89,9 +89,9 @@ __device__ __forceinline__ float ld_buf(const rsrc_t& rs, unsigned voff) {
 // Measured per instance on the shapes of the step (tools/mb_conv_ab.py, profiles/r05b_conv_ab_launch_bounds.txt): 40 -> 10 transposed
 // 62.8 -> 57.2 us, its adjoint-of-down1 twin 39.5 -> 33.1; the small-tile members 1 - 4 % faster; but the forward-convolution instances with
 // >= 3 output-channel groups or 64-column tiles got SLOWER under the tighter budget (20 -> 80 at 256^2: 36.1 -> 46.2 us, 10 -> 40 at 512^2:
-// 52.3 -> 59.0, 10 -> 20: 35.2 -> 37.0) and keep the unconstrained allocation, as do the tile-run instances (their in-loop epilogue spills).
+// 52.3 -> 59.0, 10 -> 20: 35.2 -> 37.0) and keep the unconstrained allocation.
 constexpr int conv_min_waves(int mode, int s, int nr, int rw, int mt, bool run) {
-  if (run) return 1;
+  if (run) return rw * mt * ((mode == 1 && s == 2) ? 4 : 1) * nr * 4 <= 48 ? 3 : 2;   // (round 5: their epilogue's row arithmetic stays inside the tile loop -- opaque row origin --, 260 - 290 registers became 150 - 230)
   if (mode == 0 && (nr >= 3 || mt >= 4)) return 1;
   const int acc_regs = rw * mt * ((mode == 1 && s == 2) ? 4 : 1) * nr * 4;
   return acc_regs <= 64 ? 4 : (acc_regs <= 96 ? 3 : 2);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
   // range check cannot see row ends) falls back to per-dword stores on that lane.  16 channels x 64-byte runs per instruction.
   const int64_t oplane = (int64_t)p.OH * p.OW;
   const bool direct = !p.part && p.direct_epi;
-  auto epilogue_direct = [&](int tx0) {
+  auto epilogue_direct = [&](int tx0, int ty0e) {   // ty0e = ty0 (+ an opaque zero inside tile runs: keeps the row arithmetic inside the loop)
     const int onb = (int)((int64_t)p.Cout * oplane * 4);
     const rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + n * p.ons), 0, onb, 0x00020000);
     const rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dm ? p.dm + n * p.dmns : p.out), 0, p.dm ? (int)((int64_t)p.dmC * oplane * 4) : 0, 0x00020000);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int ph = 0; ph < P; ++ph) {
-              const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
+              const int gy = ty0e + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
               const int y = P == 4 ? gy * 2 + (ph >> 1) : gy, x = P == 4 ? gx * 2 + (ph & 1) : gx;
               const int nv = y < p.OH ? min(4, P == 4 ? (p.OW - x + 1) >> 1 : p.OW - x) : 0;   // valid elements of this lane's 4-vector
               const f32x4 a = acc[r][mt][ph][nr];
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
       for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const int gy = ty0 + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
+          const int gy = ty0e + wave * RW + r, gx = tx0 + mt * 16 + kq * 4;
           if (P == 1) {
             emit(co, gy, gx, bias, dsc, dsh, acc[r][mt][0][nr]);
           } else {
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
       if (VTS_ABL(p, 4)) {
         if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
       } else {
-        epilogue_direct(tile * TX);
+        epilogue_direct(tile * TX, ty0 + opaque_zero());
       }
     }
     __syncthreads();
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
   if (RUN) return;   // (the host launches RUN instances only with the direct epilogue)
   const int tx0 = tile_begin * TX;
   if (direct) {
-    if (!VTS_ABL(p, 4)) epilogue_direct(tx0);
+    if (!VTS_ABL(p, 4)) epilogue_direct(tx0, ty0);
     else if (acc[0][0][0][0][0] == 123.456f) p.out[0] = 1.f;
     stamp(7);
     return;
