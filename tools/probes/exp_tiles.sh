@@ -1,10 +1,5 @@
 cd $GRAFT_REPO_ROOT
 P=$PWD/visual-tactile-synthesis_amd
-export VTS_LIB_PATH=$P/libvts_hip_ck16.so
-echo "== off"; python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
-echo "== ck16>=64"; VTS_SPLIT_CK16=64 python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
-echo "== ck16>=128"; VTS_SPLIT_CK16=128 python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
-echo "== off again"; python tools/mb_conv_ab.py 2>/dev/null | grep -v "^#"
-export VTS_TUNING=1
-for v in 0 64 128; do echo -n "step ck16=$v: "; VTS_SPLIT_CK16=$v python bench.py --train_only --steps 150 --warmup 10 2>/dev/null | python -c "import json,sys; print(round(json.loads(sys.stdin.read())['ms_per_step'],3))"; done
-for v in 0 64 128; do echo -n "step ck16=$v: "; VTS_SPLIT_CK16=$v python bench.py --train_only --steps 150 --warmup 10 2>/dev/null | python -c "import json,sys; print(round(json.loads(sys.stdin.read())['ms_per_step'],3))"; done
+for L in libvts_hip_base.so libvts_hip.so libvts_hip_base.so; do echo "== $L"; VTS_LIB_PATH=$P/$L python tools/mb_px.py 2>/dev/null | grep " us"; done
+for i in 1 2; do for L in libvts_hip_base.so libvts_hip.so; do echo -n "step $L: "; VTS_LIB_PATH=$P/$L python bench.py --train_only --steps 200 --warmup 10 2>/dev/null | python -c "import json,sys; print(round(json.loads(sys.stdin.read())['ms_per_step'],3))"; done; done
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2

@@ -27,6 +27,15 @@
 
 namespace {
 
+// Register budget (round 5; second argument of __launch_bounds__ = minimum waves per SIMD): unconstrained, hipcc splits the allocation into
+// architectural + accumulation halves and these HBM-bound members ran 3 - 6 waves per SIMD (80 - 164 registers); they fit 5 - 6 waves (<= 96 /
+// <= 80) without a spill, and the extra waves hide the load latency: 9 -> 10 at 1024^2 66.4 -> 58.1 us, its input adjoint 90.6 -> 76.0,
+// D1 layer 0 (N = 8) 52.8 -> 48.9, its image gradient 56.7 -> 47.0, 16 -> 8 transposed 60.2 -> 55.1; sum over the thin-layer shapes of
+// tools/mb_px.py 958 -> 915 us (profiles/r05h_px_ab_launch_bounds.txt).  Six waves only where nothing spills (the convolution with <= 3
+// channel blocks); eight waves spilled and ran 2 - 10x slower.
+constexpr int px_min_waves(bool transposed, int nb) { return (!transposed && nb <= 3) ? 6 : 5; }
+
+
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr unsigned OOB_OFF = 0x40000000u;    // lane part of a byte offset outside the row (planes are < 2^30 bytes: checked by the host side)
 constexpr unsigned ROW_OOB = 0x7F000000u;    // uniform part of a row above / below the map: the sum stays beyond every plane without wrapping
@@ -140,7 +149,7 @@ __device__ __forceinline__ void px_merge_stats(const float* px_stat, const PxK& 
 }
 
 template <int NB, int T, int PP, int STATS>
-__global__ __launch_bounds__(256) void conv_px_s2_kernel(const PxK p) {
+__global__ __launch_bounds__(256, px_min_waves(false, NB)) void conv_px_s2_kernel(const PxK p) {
   constexpr int R = 2 * T + 2;   // input rows under T output rows
   constexpr int VL = PP ? 62 : 63, L0 = PP ? 1 : 0;
   extern __shared__ float wl[];  // [ci][blk][64]: A-operand images
@@ -408,7 +417,7 @@ __device__ __forceinline__ float tanh_fast(float x) {   // branch-free; absolute
 }
 
 template <int NB, int T, int PP, int STATS>
-__global__ __launch_bounds__(256) void convt_px_s2_kernel(const PxK p) {
+__global__ __launch_bounds__(256, px_min_waves(true, NB)) void convt_px_s2_kernel(const PxK p) {
   constexpr int ND = PP ? 3 : 2;
   constexpr int R = T + ND - 1;   // input rows under T low-resolution rows
   constexpr int VL = PP ? 62 : 63, L0 = PP ? 1 : 0;
