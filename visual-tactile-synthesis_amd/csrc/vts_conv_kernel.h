@@ -45,6 +45,9 @@ struct ConvK {
   // (S1, S2') pair per wave and tile in the layout of norm_bwd_partial_kernel: the stand-alone partial pass (a read of dy AND x)
   // and its launch disappear.
   float* bsum_part;
+  // round 5: reciprocals ceil(2^32 / d) of the divisors of the workgroup-id arithmetic (fast_div below): the five runtime integer
+  // divisions of the set-up were five v_rcp / v_readfirstlane / fix-up chains in front of the first load of every workgroup
+  unsigned rc_gxy, rc_gx, rc_N, rc_CG, rc_gridx;
 #ifdef VTS_PROFILING   // (make PROFILING=1: the production kernels carry none of this -- their bodies are 40 - 60 KB against a 64 KB instruction cache)
   int ablate;                  // env VTS_ABLATE: 1 skip global loads, 2 skip MFMA, 4 skip epilogue
   unsigned long long* trace;   // env VTS_CONV_TRACE: per workgroup 8 x 64-bit: hw id, then s_memrealtime (100 MHz) at the phase boundaries
@@ -95,6 +98,17 @@ constexpr int conv_min_waves(int mode, int s, int nr, int rw, int mt, bool run) 
   if (mode == 0 && (nr >= 3 || mt >= 4)) return 1;
   const int acc_regs = rw * mt * ((mode == 1 && s == 2) ? 4 : 1) * nr * 4;
   return acc_regs <= 64 ? 4 : (acc_regs <= 96 ? 3 : 2);
+}
+
+// floor(n / d) for 0 <= n < 2^31, d >= 1 from rc = ceil(2^32 / d) mod 2^32 (host: conv_recip): the product's high word is the quotient or
+// one above it (the excess term n * (rc * d - 2^32) / (d * 2^32) is below 1), one compare settles it.  d = 1 has rc = 0: the caller's
+// n itself.
+__host__ inline unsigned conv_recip(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ int fast_div(int n, int d, unsigned rc) {
+  if (rc == 0) return n;
+  int q = (int)__umulhi((unsigned)n, rc);
+  if (q * d > n) --q;
+  return q;
 }
 
 template <int MODE, int S, int NR, int RW, int MT, int CK, bool RUN, int STATS>
@@ -154,20 +168,21 @@ __global__ __launch_bounds__(256, conv_min_waves(MODE, S, NR, RW, MT, RUN)) void
     const int lin = bx + gx * (by + gy * bz);
     const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
     const int lin2 = xcd * q + min(xcd, r) + idx;
-    bz = lin2 / (gx * gy);
+    bz = fast_div(lin2, gx * gy, p.rc_gxy);
     const int rem = lin2 - bz * (gx * gy);
-    by = rem / gx;
+    by = fast_div(rem, gx, p.rc_gx);
     bx = rem - by * gx;
   }
-  const int n = bz % p.N;
-  const int cg = (bz / p.N) % p.CG, ks = bz / (p.N * p.CG);
+  const int bzn = fast_div(bz, p.N, p.rc_N), n = bz - bzn * p.N;
+  const int ks = fast_div(bzn, p.CG, p.rc_CG), cg = bzn - ks * p.CG;
   const int co0 = cg * NR * 16;
   // Tile run of this workgroup (round 2): thin layers have one or two input-channel chunks per tile, so a workgroup that owned a
   // single tile would load, multiply and store strictly one after the other (measured: the phases add up, co-resident workgroups
   // run in lock-step).  A run of tiles along x turns the chunk pipeline into a tile pipeline: the loads of the next tile are in
   // flight during the MFMA phase and the stores of the current one.
   // (RUN instances only; the others keep one tile per workgroup and the epilogue outside the chunk loop.)
-  const int tile_begin = RUN ? bx * p.tiles_x / (int)gridDim.x : bx, tile_end = RUN ? (bx + 1) * p.tiles_x / (int)gridDim.x : bx + 1;
+  const int tile_begin = RUN ? fast_div(bx * p.tiles_x, (int)gridDim.x, p.rc_gridx) : bx;
+  const int tile_end = RUN ? fast_div((bx + 1) * p.tiles_x, (int)gridDim.x, p.rc_gridx) : bx + 1;
   const int ty0 = by * TY;
   const int podd = p.pad & 1;
 
@@ -844,6 +859,8 @@ int launch(const ConvK& k0, int N, hipStream_t st, int CG = 1, int KS = 1) {
   }
   if (CK != 4) run = 1;
   dim3 grid(cdiv(tiles_x, run), tiles_y, N * CG * KS);
+  k.rc_gxy = conv_recip(grid.x * grid.y); k.rc_gx = k.rc_gridx = conv_recip(grid.x);
+  k.rc_N = conv_recip((unsigned)k.N); k.rc_CG = conv_recip((unsigned)k.CG);
   if (!(NR == 1 && RW == 1 && MT == 2) && (k.part || !k.direct_epi)) {
     vts_set_error("vts_conv4x4: this tile instance has no LDS epilogue (VTS_DIRECT_EPI=0 / output beyond 30-bit offsets)");
     return VTS_ERR_UNSUPPORTED;
