@@ -564,6 +564,14 @@ int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, con
 /* d g_raw = cat(d fake_I, d fake_T) * M * (1 - g_out^2)   (mask multiply + Tanh backward). */
 int vts_g_out_grad(const float* d_fake_I, const float* d_fake_T, const float* M, const float* g_out, int N, int H, int W,
                    float* d_raw, void* stream);
+/* ImagePool.query (reference util/image_pool.py:29-61; pix2pixHD's fake_pool, pix2pixHD_model.py:334, 582) on the device.  The host
+ * makes the reference's draws (Python's `random`) and hands over, per image n of the batch in order: ret_slot[n] = the pool slot whose
+ * CURRENT content is returned in place of image n (-1: image n itself) and put_slot[n] = the slot image n is stored into (-1: none).
+ * out[n] = ret_slot[n] < 0 ? images[n] : store[ret_slot[n]], then store[put_slot[n]] = images[n], for n = 0 .. N-1 IN ORDER (a later
+ * image of the batch may draw a slot an earlier one has just written); every thread walks the N images of its own elements, so the
+ * order holds without a barrier.  images, out [N, elems]; store [pool_size, elems]; ret_slot, put_slot: device int32 [N]. */
+int vts_pool_query(const float* images, float* store, const int* ret_slot, const int* put_slot, int N, int64_t elems, float* out,
+                   void* stream);
 /* y = x * M (M broadcast over channels). */
 int vts_mask_mul(const float* x, const float* M, int N, int C, int HW, float* y, void* stream);
 /* Sinusoidal positional grid, SPE(dim,0) (thirdparty/mmgeneration/positional_encoding.py:54-160): out [N,2*dim,H,W]. */

@@ -427,7 +427,7 @@ def golden_global(h=64, w=32, seed=404, ngf=8, n_down=3, n_blocks=3):
     print("wrote global_%dx%d.npz (%d entries)" % (h, w, len(out)))
 
 
-def golden_local(h=64, w=32, seed=707, ngf=4, n_down=2, n_blocks_global=2, n_blocks_local=2):
+def golden_local(h=64, w=32, seed=707, ngf=4, n_down=2, n_blocks_global=2, n_blocks_local=2, n_local=1):
     """pix2pixHD LocalEnhancer (define_G netG='local', BatchNorm, train mode): forward + gradients + BN buffers."""
     import copy
 
@@ -437,11 +437,12 @@ def golden_local(h=64, w=32, seed=707, ngf=4, n_down=2, n_blocks_global=2, n_blo
     from models import networks
 
     opt = copy.copy(_ref_opt("sinskitG", True, []))
-    opt.n_downsample_global, opt.n_blocks_global, opt.n_local_enhancers, opt.n_blocks_local = n_down, n_blocks_global, 1, n_blocks_local
-    out = {"h": h, "w": w, "seed": seed, "ngf": ngf, "n_down": n_down, "n_blocks_global": n_blocks_global, "n_blocks_local": n_blocks_local}
+    opt.n_downsample_global, opt.n_blocks_global, opt.n_local_enhancers, opt.n_blocks_local = n_down, n_blocks_global, n_local, n_blocks_local
+    out = {"h": h, "w": w, "seed": seed, "ngf": ngf, "n_down": n_down, "n_blocks_global": n_blocks_global, "n_blocks_local": n_blocks_local,
+           "n_local": n_local}
     G = networks.define_G(1, 5, ngf, "local", "batch", False, "xavier", 0.02, False, False, [], opt)
     ref = {k: tuple(v.shape) for k, v in G.state_dict().items()}
-    mine = nets.local_enhancer_param_shapes(1, 5, ngf, n_down, n_blocks_global, n_blocks_local)
+    mine = nets.local_enhancer_param_shapes(1, 5, ngf, n_down, n_blocks_global, n_blocks_local, n_local)
     assert ref == {k: tuple(v) for k, v in mine.items()}, sorted(set(ref) ^ set(mine))[:8]
     out["ref_keys"] = np.array(sorted(ref.keys()))
     G.load_state_dict(detrand.test_weights(mine, seed))
@@ -455,8 +456,9 @@ def golden_local(h=64, w=32, seed=707, ngf=4, n_down=2, n_blocks_global=2, n_blo
     for k, b in G.named_buffers():
         if b.dtype.is_floating_point:
             out["G_buf/" + k] = b.numpy()
-    np.savez_compressed(os.path.join(GOLD, "local_%dx%d.npz" % (h, w)), **out)
-    print("wrote local_%dx%d.npz (%d entries)" % (h, w, len(out)))
+    fname = ("local_%dx%d.npz" if n_local == 1 else "local%d_%%dx%%d.npz" % n_local) % (h, w)
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+    print("wrote %s (%d entries)" % (fname, len(out)))
 
 
 def p2p_batch(n, size, seed):
@@ -514,6 +516,126 @@ def golden_p2p_step(size=32, seed=505, n=4, steps=2, extra=(), fname="pix2pixHD_
     np.savez_compressed(os.path.join(GOLD, fname % size), **out)
     print("wrote " + fname % size + " (%d entries)" % len(out))
     print({k: float(v) for k, v in losses.items()})
+
+
+def golden_image_pool(seed=616, pool_size=3, n=4, batches=6):
+    """util/image_pool.py:ImagePool.query of the reference on `batches` batches of n constant images (image i of batch b is filled with
+    the id b * n + i): the ids it returns, under random.seed(seed)."""
+    import random
+
+    from oracle import ref_import
+
+    ref_import.load()
+    from util.image_pool import ImagePool
+    pool = ImagePool(pool_size)
+    random.seed(seed)
+    ids = []
+    for b in range(batches):
+        imgs = torch.stack([torch.full((2, 3, 5), float(b * n + i)) for i in range(n)])
+        out = pool.query(imgs)
+        assert all(float(o.min()) == float(o.max()) for o in out)
+        ids.append([int(o[0, 0, 0]) for o in out])
+    np.savez_compressed(os.path.join(GOLD, "image_pool.npz"), seed=seed, pool_size=pool_size, n=n, batches=batches, returned=np.array(ids))
+    print("wrote image_pool.npz", ids)
+
+
+def _p2p_model(extra, g_shapes, seed, n_layers=3, override=None):
+    """override: option attributes set after parsing (the reference's parser rejects --netG local / global -- `choices` lists neither,
+    options/base_options.py; 'global' arrives through set_defaults)"""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    import models
+    opt = _ref_opt("pix2pixHD", True, P2P_FLAGS + list(extra))
+    for k, v in (override or {}).items():
+        setattr(opt, k, v)
+    opt.checkpoints_dir, opt.name = "/tmp/vts_golden_ckpt", "p2p"
+    os.makedirs(os.path.join(opt.checkpoints_dir, opt.name), exist_ok=True)
+    model = models.create_model(opt)
+    model.setup(opt)
+    shD, shD2 = nets.d_if_param_shapes(4, 8, 2, n_layers), nets.d_if_param_shapes(3, 8, 2, n_layers)
+    for net, sh in ((model.netG, g_shapes), (model.netD, shD), (model.netD2, shD2)):
+        ref = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert ref == {k: tuple(v) for k, v in sh.items()}, (sorted(set(ref) ^ set(sh))[:6])
+    model.netG.load_state_dict(detrand.test_weights(g_shapes, seed))
+    model.netD.load_state_dict(detrand.test_weights(shD, seed + 1))
+    model.netD2.load_state_dict(detrand.test_weights(shD2, seed + 2))
+    model.train()
+    return model, opt
+
+
+def golden_p2p_pool_step(size=32, seed=535, n=4, steps=2, pool_size=3, rseed=548):
+    """Pix2PixHDModel.optimize_parameters x 2 with --pool_size 3 (fake_pool.query in backward_D, pix2pixHD_model.py:582, 626) under
+    random.seed(rseed): the first batch fills the pool and its fourth image draws (548: it swaps with slot 0), the second batch draws four
+    times (548: four swaps, the last with the slot the second image of the same batch has just written)."""
+    import random
+
+    from oracle import nets
+    extra = ["--pool_size", str(pool_size)]
+    shG = nets.resnet_param_shapes(1, 5, 8, 2, 3, norm="batch", down="stride", up="convT", conv_bias=True)
+    model, opt = _p2p_model(extra, shG, seed)
+    batch = p2p_batch(n, size, seed)
+    out = {"size": size, "seed": seed, "rseed": rseed, "n": n, "steps": steps, "pool_size": pool_size, "flags": np.array(P2P_FLAGS + extra)}
+    random.seed(rseed)
+    state = random.getstate()
+    plan = []
+    for it in range(steps):
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+        losses = model.get_current_losses()
+        out["s%d/loss_names" % it] = np.array(list(losses.keys()))
+        out["s%d/loss_values" % it] = np.array([float(v) for v in losses.values()], dtype=np.float64)
+        out["s%d/fake_I" % it] = model.fake_I.detach().numpy()
+        for kk, p in model.netD.named_parameters():
+            out["s%d/grad_D/%s" % (it, kk)] = p.grad.detach().numpy()
+    # the decisions the pool made (replayed from the same generator state: the step makes no other use of `random`)
+    random.setstate(state)
+    num = 0
+    for it in range(steps):
+        for i in range(n):
+            if num < pool_size:
+                plan.append((-1, num))
+                num += 1
+            elif random.uniform(0, 1) > 0.5:
+                k = random.randint(0, pool_size - 1)
+                plan.append((k, k))
+            else:
+                plan.append((-1, -1))
+    out["plan"] = np.array(plan).reshape(steps, n, 2)
+    np.savez_compressed(os.path.join(GOLD, "pix2pixHD_pool_step_%d.npz" % size), **out)
+    print("wrote pix2pixHD_pool_step_%d.npz" % size, out["plan"].tolist(), {k: float(v) for k, v in losses.items()})
+
+
+def golden_p2p_fix_global(size=32, seed=545, n=4):
+    """--netG local --niter_fix_global 1 (pix2pixHD_model.py:403-421, 942-949; train.py:209-211): one step with optimizer_G over the local
+    enhancer only, update_learning_rate + update_fixed_params as train.py calls them at the end of epoch 1, one more step."""
+    from oracle import nets
+    extra = ["--ngf", "4", "--n_downsample_global", "2", "--n_blocks_local", "2", "--niter_fix_global", "1"]
+    shG = nets.local_enhancer_param_shapes(1, 5, 4, 2, 2, 2)
+    model, opt = _p2p_model(extra, shG, seed, override={"netG": "local"})
+    batch = p2p_batch(n, size, seed)
+    keys = ["model.4.weight", "model.2.weight", "model1_1.4.weight", "model1_2.0.conv_block.1.weight", "model1_2.6.weight", "model1_2.6.bias"]
+    named = dict(model.netG.named_parameters())
+    assert all(k in named for k in keys), [k for k in keys if k not in named]
+    out = {"size": size, "seed": seed, "n": n, "flags": np.array(P2P_FLAGS + extra), "keys": np.array(keys), "lr": opt.lr,
+           "niter_decay": opt.niter_decay}
+    for k in keys:
+        out["init/" + k] = named[k].detach().numpy().copy()
+    for it in range(2):
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+        losses = model.get_current_losses()
+        out["s%d/loss_names" % it] = np.array(list(losses.keys()))
+        out["s%d/loss_values" % it] = np.array([float(v) for v in losses.values()], dtype=np.float64)
+        for k in keys:
+            out["s%d/param/%s" % (it, k)] = named[k].detach().numpy().copy()
+        if it == 0:
+            model.update_learning_rate()
+            model.update_fixed_params()
+            out["lr_after"] = float(model.optimizer_D.param_groups[0]["lr"])
+            out["lr_G_after"] = float(model.optimizer_G.param_groups[0]["lr"])
+    np.savez_compressed(os.path.join(GOLD, "pix2pixHD_fix_global_%d.npz" % size), **out)
+    print("wrote pix2pixHD_fix_global_%d.npz" % size, out["lr_after"], out["lr_G_after"], {k: float(v) for k, v in losses.items()})
 
 
 def golden_lpips_step(size=256, seed=212, nt=64):
@@ -1129,6 +1251,8 @@ if __name__ == "__main__":
         golden_global()
     if "local" in which:
         golden_local()
+    if "local2" in which:      # two local enhancers (--n_local_enhancers 2): three pyramid levels
+        golden_local(seed=717, n_local=2)
     if "p2p" in which:
         golden_p2p_step()
     if "metrics" in which:
@@ -1158,6 +1282,12 @@ if __name__ == "__main__":
     if "p2pvanilla" in which:
         # gan_mode 'vanilla' (the discriminators end in a Sigmoid and BCEWithLogits follows, networks.py:1659, 507-509) at PatchGAN depth 2
         golden_p2p_step(seed=525, steps=1, extra=("--gan_mode", "vanilla", "--n_layers_D", "2"), fname="pix2pixHD_vanilla_step_%d.npz", n_layers=2)
+    if "pool" in which:
+        golden_image_pool()
+    if "p2ppool" in which:
+        golden_p2p_pool_step()
+    if "p2pfix" in which:
+        golden_p2p_fix_global()
     if "diffaug" in which:
         golden_diffaug()
     if "variants" in which:

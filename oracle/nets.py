@@ -440,8 +440,10 @@ def resnet_forward(sd, x, n_blocks=9, n_down=2, norm="instance", down="blur", up
     return x
 
 
-def local_enhancer_forward(sd, x, n_down=3, n_blocks_global=9, n_blocks_local=3, norm="batch", training=True):
-    """pix2pixHD LocalEnhancer.forward, one local enhancer (models/networks.py:1897-1949)"""
+def local_enhancer_forward(sd, x, n_down=3, n_blocks_global=9, n_blocks_local=3, norm="batch", training=True, n_local=1):
+    """pix2pixHD LocalEnhancer.forward with n_local enhancers (models/networks.py:1897-1949): the global trunk on the input average-pooled
+    n_local times, then enhancer n = 1 .. n_local on the pyramid level n_local - n: model<n>_1 (7x7 conv, stride-2 3x3 conv) + the output
+    below, through model<n>_2 (blocks, ConvTranspose2d; the last one ends in the 7x7 conv + tanh)"""
     def c7(pre, i, t):
         return F.conv2d(F.pad(t, (3, 3, 3, 3), mode="reflect"), sd["%s.%d.weight" % (pre, i)], sd["%s.%d.bias" % (pre, i)])
 
@@ -458,9 +460,11 @@ def local_enhancer_forward(sd, x, n_down=3, n_blocks_global=9, n_blocks_local=3,
     def convT(pre, i, t):
         return F.conv_transpose2d(t, sd["%s.%d.weight" % (pre, i)], sd["%s.%d.bias" % (pre, i)], stride=2, padding=1, output_padding=1)
 
-    # global trunk on the average-pooled input (GlobalGenerator.model[:-3])
-    g = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
-    g = nr("model", 2, c7("model", 1, g))
+    pyramid = [x]
+    for _ in range(n_local):
+        pyramid.append(F.avg_pool2d(pyramid[-1], 3, stride=2, padding=1, count_include_pad=False))
+    # global trunk on the coarsest level (GlobalGenerator.model[:-3])
+    g = nr("model", 2, c7("model", 1, pyramid[-1]))
     i = 4
     for _ in range(n_down):
         g = nr("model", i + 1, F.conv2d(g, sd["model.%d.weight" % i], sd["model.%d.bias" % i], stride=2, padding=1))
@@ -471,18 +475,20 @@ def local_enhancer_forward(sd, x, n_down=3, n_blocks_global=9, n_blocks_local=3,
     for _ in range(n_down):
         g = nr("model", i + 1, convT("model", i, g))
         i += 3
-    # local branch
-    d = nr("model1_1", 2, c7("model1_1", 1, x))
-    d = nr("model1_1", 5, F.conv2d(d, sd["model1_1.4.weight"], sd["model1_1.4.bias"], stride=2, padding=1))
-    u = d + g
-    for j in range(n_blocks_local):
-        u = block("model1_2", j, u)
-    j = n_blocks_local
-    u = nr("model1_2", j + 1, convT("model1_2", j, u))
-    return torch.tanh(c7("model1_2", j + 4, u))
+    # local enhancers, coarse to fine
+    for n in range(1, n_local + 1):
+        m1, m2 = "model%d_1" % n, "model%d_2" % n
+        d = nr(m1, 2, c7(m1, 1, pyramid[n_local - n]))
+        d = nr(m1, 5, F.conv2d(d, sd[m1 + ".4.weight"], sd[m1 + ".4.bias"], stride=2, padding=1))
+        u = d + g
+        for j in range(n_blocks_local):
+            u = block(m2, j, u)
+        j = n_blocks_local
+        g = nr(m2, j + 1, convT(m2, j, u))
+    return torch.tanh(c7("model%d_2" % n_local, n_blocks_local + 4, g))
 
 
-def local_enhancer_param_shapes(input_nc=1, output_nc=5, ngf=32, n_down=3, n_blocks_global=9, n_blocks_local=3):
+def local_enhancer_param_shapes(input_nc=1, output_nc=5, ngf=32, n_down=3, n_blocks_global=9, n_blocks_local=3, n_local=1):
     """state_dict of LocalEnhancer (BatchNorm, every conv with bias)"""
     sh = {}
 
@@ -499,7 +505,7 @@ def local_enhancer_param_shapes(input_nc=1, output_nc=5, ngf=32, n_down=3, n_blo
             conv("%s.conv_block.%d" % (key, j), (c, c, 3, 3), c)
             bn("%s.conv_block.%d" % (key, j + 1), c)
 
-    c = 2 * ngf
+    c = ngf * 2 ** n_local
     conv("model.1", (c, input_nc, 7, 7), c); bn("model.2", c)
     i = 4
     for _ in range(n_down):
@@ -513,13 +519,17 @@ def local_enhancer_param_shapes(input_nc=1, output_nc=5, ngf=32, n_down=3, n_blo
         conv("model.%d" % i, (c, c // 2, 3, 3), c // 2); bn("model.%d" % (i + 1), c // 2)
         c //= 2
         i += 3
-    conv("model1_1.1", (ngf, input_nc, 7, 7), ngf); bn("model1_1.2", ngf)
-    conv("model1_1.4", (2 * ngf, ngf, 3, 3), 2 * ngf); bn("model1_1.5", 2 * ngf)
-    for j in range(n_blocks_local):
-        block("model1_2.%d" % j, 2 * ngf)
-    j = n_blocks_local
-    conv("model1_2.%d" % j, (2 * ngf, ngf, 3, 3), ngf); bn("model1_2.%d" % (j + 1), ngf)
-    conv("model1_2.%d" % (j + 4), (output_nc, ngf, 7, 7), output_nc)
+    for n in range(1, n_local + 1):
+        f = ngf * 2 ** (n_local - n)
+        m1, m2 = "model%d_1" % n, "model%d_2" % n
+        conv(m1 + ".1", (f, input_nc, 7, 7), f); bn(m1 + ".2", f)
+        conv(m1 + ".4", (2 * f, f, 3, 3), 2 * f); bn(m1 + ".5", 2 * f)
+        for j in range(n_blocks_local):
+            block("%s.%d" % (m2, j), 2 * f)
+        j = n_blocks_local
+        conv("%s.%d" % (m2, j), (2 * f, f, 3, 3), f); bn("%s.%d" % (m2, j + 1), f)
+        if n == n_local:
+            conv("%s.%d" % (m2, j + 4), (output_nc, f, 7, 7), output_nc)
     return sh
 
 

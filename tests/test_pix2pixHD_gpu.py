@@ -29,10 +29,14 @@ def p2p_batch(n, size, seed):
             "augmentation_params": {}}
 
 
-def make_model(extra=""):
+def make_model(extra="", override=None):
+    """override: option attributes set after parsing (the parser mirrors the reference's `choices`, which list neither 'global' nor 'local'
+    for --netG: 'global' arrives through set_defaults, 'local' only programmatically)"""
     from models import create_model
     from options.train_options import TrainOptions
     opt = TrainOptions(cmd_line=FLAGS + extra).parse()
+    for k, v in (override or {}).items():
+        setattr(opt, k, v)
     model = create_model(opt)
     model.setup(opt)
     model.parallelize()
@@ -248,3 +252,121 @@ def test_full_model_steps_at_2048x1024_graph_replay_equals_eager():
     for nm in ("G", "D", "D2"):
         assert rel(getattr(mg, "flat" + nm).flat, getattr(me, "flat" + nm).flat) < 1e-6, nm
     assert me.fake_I.shape == (1, 3, h, w) and torch.isfinite(me.fake_I).all() and float(me.fake_I.abs().max()) <= 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# round 5: the pix2pixHD options that used to refuse -- the history pool of fakes, --niter_fix_global, (n_local_enhancers > 1: test_resnet_gpu)
+
+def test_image_pool_on_the_device_returns_what_the_reference_returns(golden_dir):
+    """util/image_pool.py of the package (host decisions + vts_pool_query) against the ids the REFERENCE's ImagePool handed out for six
+    seeded batches (tests/golden/image_pool.npz); bit-exact data movement, including a slot written and drawn inside one batch"""
+    import random
+
+    from util.image_pool import ImagePool
+    g = np.load(os.path.join(golden_dir, "image_pool.npz"))
+    seed, size, n, batches = (int(g[k]) for k in ("seed", "pool_size", "n", "batches"))
+    dev = torch.device("cuda:0")
+    ramp = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5) * 1e-3
+    random.seed(seed)
+    pool = ImagePool(size)
+    for b in range(batches):
+        imgs = torch.stack([ramp + float(b * n + i) for i in range(n)]).to(dev)
+        out = pool.query(imgs).cpu()
+        want = torch.stack([ramp + float(v) for v in g["returned"][b]])
+        assert torch.equal(out, want), (b, out[:, 0, 0, 0], g["returned"][b])
+    assert ImagePool(0).query(imgs) is imgs
+
+
+def test_pool_step_matches_reference_golden(golden_dir):
+    """--pool_size 3 (fake_pool.query in backward_D): two steps of the reference under random.seed(548) -- the first batch fills the pool and
+    its last image is swapped for the first; the second batch (a captured graph here) is answered entirely from the history"""
+    import random
+    g = np.load(os.path.join(golden_dir, "pix2pixHD_pool_step_32.npz"))
+    size, seed, n, rseed = int(g["size"]), int(g["seed"]), int(g["n"]), int(g["rseed"])
+    model, opt = make_model(" --pool_size %d" % int(g["pool_size"]))
+    load_weights(model, seed)
+    batch = p2p_batch(n, size, seed)
+    random.seed(rseed)
+    for it in range(2):
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+        assert (model._graphs is not None) == (it == 1)
+        plan = model.fake_pool._slots.cpu().numpy().T
+        assert (plan == g["plan"][it]).all(), (it, plan, g["plan"][it])
+        losses = model.get_current_losses()
+        ref = dict(zip([str(k) for k in g["s%d/loss_names" % it]], g["s%d/loss_values" % it]))
+        tol = 1e-3 if it == 0 else 3e-3
+        for k, v in ref.items():
+            assert abs(losses[k] - v) <= tol * max(1.0, abs(v)), (it, k, losses[k], v)
+        assert rel(model.fake_I, torch.from_numpy(g["s%d/fake_I" % it])) < tol
+        for k, p in model.netD.named_parameters():
+            rg = torch.from_numpy(g["s%d/grad_D/%s" % (it, k)])
+            if k.endswith(".bias") and rg.norm() < 1e-4:
+                continue
+            assert rel(p.grad, rg) < (2e-3 if it == 0 else 6e-3), (it, k, rel(p.grad, rg))
+    # without the pool the second step's D_fake would be the plain one: the fixture's value must differ from it by more than the tolerance
+    model2, _ = make_model("")
+    load_weights(model2, seed)
+    for it in range(2):
+        model2.set_input(batch, phase="train")
+        model2.optimize_parameters(epoch=1)
+    assert abs(model2.get_current_losses()["l_D_fake"] - float(ref["l_D_fake"])) > 1e-2
+
+
+def test_pool_refuses_data_parallel_like_the_reference():
+    from models import create_model
+    from options.train_options import TrainOptions
+    opt = TrainOptions(cmd_line=FLAGS + " --pool_size 3").parse()
+    opt.gpu_ids = [0, 1]
+    with pytest.raises(NotImplementedError, match="Fake Pool"):
+        create_model(opt)
+
+
+def test_niter_fix_global_matches_reference_golden(golden_dir):
+    """--netG local --niter_fix_global 1: optimizer_G covers the local enhancer only (the global trunk must not move by one bit), then
+    update_learning_rate + update_fixed_params as train.py calls them -- a fresh Adam over all of netG at the initial rate -- and a second
+    step; parameter DELTAS against the reference's (tests/golden/pix2pixHD_fix_global_32.npz)"""
+    g = np.load(os.path.join(golden_dir, "pix2pixHD_fix_global_32.npz"))
+    size, seed, n = int(g["size"]), int(g["seed"]), int(g["n"])
+    model, opt = make_model(" --ngf 4 --n_downsample_global 2 --n_blocks_local 2 --niter_fix_global 1 --use_hip_graph False", {"netG": "local"})
+    sds = (detrand.test_weights(nets.local_enhancer_param_shapes(1, 5, 4, 2, 2, 2), seed),
+           detrand.test_weights(nets.d_if_param_shapes(4, 8, 2, 3), seed + 1), detrand.test_weights(nets.d_if_param_shapes(3, 8, 2, 3), seed + 2))
+    for net, sd in zip((model.netG, model.netD, model.netD2), sds):
+        net.load_state_dict(sd)
+    named = dict(model.netG.named_parameters())
+    keys = [str(k) for k in g["keys"]]
+    for k in keys:
+        assert torch.equal(named[k].cpu(), torch.from_numpy(g["init/" + k])), k
+    batch = p2p_batch(n, size, seed)
+    prev = {k: named[k].detach().cpu().clone() for k in keys}
+    ref_prev = {k: torch.from_numpy(g["init/" + k]) for k in keys}
+    for it in range(2):
+        model.set_input(batch, phase="train")
+        model.optimize_parameters(epoch=1)
+        losses = model.get_current_losses()
+        ref = dict(zip([str(k) for k in g["s%d/loss_names" % it]], g["s%d/loss_values" % it]))
+        for k, v in ref.items():
+            assert abs(losses[k] - v) <= 2e-3 * max(1.0, abs(v)), (it, k, losses[k], v)
+        for k in keys:
+            cur, ref_cur = named[k].detach().cpu(), torch.from_numpy(g["s%d/param/%s" % (it, k)])
+            if it == 0 and k.startswith("model."):
+                assert torch.equal(ref_cur, ref_prev[k]) and torch.equal(cur, prev[k]), k       # frozen: not one bit
+            else:
+                d, rd = cur - prev[k], ref_cur - ref_prev[k]
+                assert rd.abs().max() > 0.5 * float(g["lr"]), k
+                assert rel(d, rd) < 0.05, (it, k, rel(d, rd))
+            prev[k], ref_prev[k] = cur.clone(), ref_cur
+        if it == 0:
+            model.update_learning_rate()
+            model.update_fixed_params()
+            assert abs(model.optimizer_D.param_groups[0]["lr"] - float(g["lr_after"])) < 1e-12
+            assert abs(model.optimizer_D2.param_groups[0]["lr"] - float(g["lr_after"])) < 1e-12
+            assert abs(model.optimizer_G.param_groups[0]["lr"] - float(g["lr_G_after"])) < 1e-12
+            assert model.optimizer_G.span == (0, model.flatG.numel) and model.optimizer_G.step_count == 0
+
+
+def test_niter_fix_global_needs_the_local_generator():
+    from models import create_model
+    from options.train_options import TrainOptions
+    with pytest.raises(ValueError, match="empty parameter list"):        # the reference's Adam raises the same on netG 'global'
+        create_model(TrainOptions(cmd_line=FLAGS + " --niter_fix_global 1").parse())

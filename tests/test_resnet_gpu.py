@@ -563,16 +563,19 @@ def test_wgrad4x4_wide(shape, stride):
     assert torch.equal(dw, dw3)
 
 
-def test_local_enhancer_matches_reference_and_oracle(golden_dir):
-    """pix2pixHD LocalEnhancer (define_G netG='local'): forward vs the committed reference output, BN buffers, backward vs oracle"""
+@pytest.mark.parametrize("fixture", ["local_64x32.npz", "local2_64x32.npz"])
+def test_local_enhancer_matches_reference_and_oracle(golden_dir, fixture):
+    """pix2pixHD LocalEnhancer (define_G netG='local', --n_local_enhancers 1 and 2): forward vs the committed reference output, BN
+    buffers, backward vs oracle"""
     from models import networks
     from vts import engine
     from vts.optim import FlatParams
-    g = np.load(os.path.join(golden_dir, "local_64x32.npz"), allow_pickle=False)
+    g = np.load(os.path.join(golden_dir, fixture), allow_pickle=False)
     h, w, seed, ngf, nd, nbg, nbl = (int(g[k]) for k in ("h", "w", "seed", "ngf", "n_down", "n_blocks_global", "n_blocks_local"))
+    nl = int(g["n_local"]) if "n_local" in g.files else 1
     dev = _dev()
-    sd = detrand.test_weights(nets.local_enhancer_param_shapes(1, 5, ngf, nd, nbg, nbl), seed)
-    G = networks.LocalEnhancer(1, 5, ngf=ngf, n_downsample_global=nd, n_blocks_global=nbg, n_blocks_local=nbl).to(dev)
+    sd = detrand.test_weights(nets.local_enhancer_param_shapes(1, 5, ngf, nd, nbg, nbl, nl), seed)
+    G = networks.LocalEnhancer(1, 5, ngf=ngf, n_downsample_global=nd, n_blocks_global=nbg, n_local_enhancers=nl, n_blocks_local=nbl).to(dev)
     G.load_state_dict(sd)
     flat = FlatParams(G)
     G.train()
@@ -586,13 +589,13 @@ def test_local_enhancer_matches_reference_and_oracle(golden_dir):
     for k, v in sdo.items():
         if v.dtype.is_floating_point and "running" not in k:
             v.requires_grad_(True)
-    yo = nets.local_enhancer_forward(sdo, x, nd, nbg, nbl)
+    yo = nets.local_enhancer_forward(sdo, x, nd, nbg, nbl, n_local=nl)
     cot = detrand.uniform(tuple(yo.shape), seed, "g_cot")
     (yo * cot).sum().backward()
     flat.grad.zero_()
     engine.resnet_backward(G, ctx, (cot.to(dev) * (1.0 - y * y)).contiguous())
     named = dict(G.named_parameters())
-    last_bias = "model1_2.%d.bias" % (nbl + 4)
+    last_bias = "model%d_2.%d.bias" % (nl, nbl + 4)
     for k, v in sdo.items():
         if not (v.dtype.is_floating_point and v.requires_grad):
             continue

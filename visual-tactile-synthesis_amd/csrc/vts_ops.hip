@@ -433,6 +433,21 @@ __global__ __launch_bounds__(256) void mask_mul_kernel(const float* __restrict__
   y[((int64_t)n * C + c) * HW + i] = x[((int64_t)n * C + c) * HW + i] * M[n * HW + i];
 }
 
+// ImagePool.query (util/image_pool.py:29-61): one thread per element walks the batch in order -- "return the slot's current content, then
+// overwrite it" is sequential per slot, and a later image may draw the slot an earlier one has just filled
+__global__ __launch_bounds__(256) void pool_query_kernel(const float* __restrict__ images, float* __restrict__ store, const int* __restrict__ ret_slot,
+                                                         const int* __restrict__ put_slot, int N, int64_t elems, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= elems) return;
+  for (int n = 0; n < N; ++n) {
+    const float cur = images[(int64_t)n * elems + e];
+    const int r = ret_slot[n], w = put_slot[n];
+    const float ret = r >= 0 ? store[(int64_t)r * elems + e] : cur;
+    if (w >= 0) store[(int64_t)w * elems + e] = cur;
+    out[(int64_t)n * elems + e] = ret;
+  }
+}
+
 // 8-bit image data -> the float tensor the dataset's transform makes of it (torchvision ToTensor: v / 255 in fp32; Normalize(0.5, 0.5):
 // (t - 0.5) / 0.5), same operations in the same order and precision: bit-identical to the host tensor, a quarter of the PCIe bytes
 __global__ __launch_bounds__(256) void u8_expand_kernel(const uint8_t* __restrict__ src, int64_t n, int normalize, float* __restrict__ out) {
@@ -881,6 +896,16 @@ extern "C" int vts_diffaug_op(const float* x, int64_t x_ns, float* out, int64_t 
   hipLaunchKernelGGL(diffaug_op_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, x, x_ns, out, out_ns, C, H, W, op,
                      pf, pi0, pi1, noise, ws, M);
   VTS_CHECK_LAUNCH("vts_diffaug_op");
+  return VTS_OK;
+}
+
+extern "C" int vts_pool_query(const float* images, float* store, const int* ret_slot, const int* put_slot, int N, int64_t elems, float* out,
+                              void* stream) {
+  VTS_CHECK_ARG(images && store && ret_slot && put_slot && out && N >= 0 && elems >= 0, "vts_pool_query: bad args");
+  if (N == 0 || elems == 0) return VTS_OK;
+  hipLaunchKernelGGL(pool_query_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, store, ret_slot, put_slot,
+                     N, elems, out);
+  VTS_CHECK_LAUNCH("vts_pool_query");
   return VTS_OK;
 }
 

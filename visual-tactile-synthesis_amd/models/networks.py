@@ -288,19 +288,20 @@ class _SeqView:
 
 
 class LocalEnhancer(nn.Module):
-    """pix2pixHD LocalEnhancer with one local enhancer (reference: networks.py:1897-1949; `define_G(netG='local')`
-    :311-313): `model` = GlobalGenerator(ngf*2).model without its last three layers, applied to the average-pooled
-    input; `model1_1` = 7x7 conv + stride-2 3x3 conv on the full input; `model1_2` = ResnetBlocks, ConvTranspose2d,
-    7x7 conv, tanh on the sum."""
+    """pix2pixHD LocalEnhancer (reference: networks.py:1897-1949; `define_G(netG='local')` :311-313) with L = n_local_enhancers:
+    `model` = GlobalGenerator(ngf * 2^L).model without its last three layers, applied to the input average-pooled L times;
+    enhancer n = 1 .. L at pyramid level L - n with f = ngf * 2^(L - n) filters: `model<n>_1` = 7x7 conv + stride-2 3x3 conv on that
+    level, `model<n>_2` = ResnetBlocks + ConvTranspose2d on (its output + the output below); the last one ends in the 7x7 conv + tanh."""
     is_local_enhancer = True
 
     def __init__(self, input_nc, output_nc, ngf=32, n_downsample_global=3, n_blocks_global=9, n_local_enhancers=1, n_blocks_local=3,
                  norm="batch", opt=None):
         super().__init__()
-        if n_local_enhancers != 1:
-            raise NotImplementedError("LocalEnhancer: only n_local_enhancers=1 is built")
+        if n_local_enhancers < 1:
+            raise ValueError("LocalEnhancer: n_local_enhancers must be >= 1")
         self.norm = norm
-        ngf_g = ngf * 2
+        self.n_local_enhancers = L = n_local_enhancers
+        ngf_g = ngf * 2 ** L
         g = _SeqBuilder(norm)
         g.conv7(input_nc, ngf_g)
         for i in range(n_downsample_global):
@@ -310,16 +311,26 @@ class LocalEnhancer(nn.Module):
         for i in range(n_downsample_global):
             c = ngf_g * 2 ** (n_downsample_global - i)
             g.convT3(c, c // 2)
-        d = _SeqBuilder(norm)
-        d.conv7(input_nc, ngf)
-        d.conv3(ngf, ngf * 2, 2)
-        u = _SeqBuilder(norm)
-        for _ in range(n_blocks_local):
-            u.block(ngf * 2)
-        u.convT3(ngf * 2, ngf)
-        u.conv7(ngf, output_nc, final=True)
-        self.model, self.model1_1, self.model1_2 = _Holder(g.mods), _Holder(d.mods), _Holder(u.mods)
-        self.seq_global, self.seq_11, self.seq_12 = _SeqView(self.model, g.layout), _SeqView(self.model1_1, d.layout), _SeqView(self.model1_2, u.layout)
+        self.model = _Holder(g.mods)
+        self.seq_global = _SeqView(self.model, g.layout)
+        self.seq_down, self.seq_up = [], []          # [n - 1] -> the views of model<n>_1 / model<n>_2
+        for n in range(1, L + 1):
+            f = ngf * 2 ** (L - n)
+            d = _SeqBuilder(norm)
+            d.conv7(input_nc, f)
+            d.conv3(f, f * 2, 2)
+            u = _SeqBuilder(norm)
+            for _ in range(n_blocks_local):
+                u.block(f * 2)
+            u.convT3(f * 2, f)
+            if n == L:
+                u.conv7(f, output_nc, final=True)
+            hd, hu = _Holder(d.mods), _Holder(u.mods)
+            setattr(self, "model%d_1" % n, hd)
+            setattr(self, "model%d_2" % n, hu)
+            self.seq_down.append(_SeqView(hd, d.layout))
+            self.seq_up.append(_SeqView(hu, u.layout))
+        self.seq_11, self.seq_12 = self.seq_down[0], self.seq_up[0]
 
     def forward(self, x, style_code=None, verbose=False):
         out, _ = engine.resnet_forward(self, x, keep=False)

@@ -96,7 +96,8 @@ class Pix2PixHDModel(BaseModel):
         self.flatG = FlatParams(self.netG)
         # data parallel: the generator's gradient travels as up to 8 buckets cut at layer boundaries, each started as soon as the backward
         # has written it (_segments); VTS_G_BUCKETS=1: one bucket behind the whole backward; VTS_G_BUCKET_MIN_MB: smallest bucket worth a collective
-        self.flatG.chunk(int(os.environ.get("VTS_G_BUCKETS", "8")), min_floats=int(float(os.environ.get("VTS_G_BUCKET_MIN_MB", "16")) * (1 << 18)))
+        if not getattr(self.netG, "is_local_enhancer", False):     # (the local enhancer's backward is a tree, not a chain: one bucket)
+            self.flatG.chunk(int(os.environ.get("VTS_G_BUCKETS", "8")), min_floats=int(float(os.environ.get("VTS_G_BUCKET_MIN_MB", "16")) * (1 << 18)))
         if self.isTrain:
             self.netD = networks.define_D(opt.image_nc + opt.sketch_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm, num_D=opt.num_D_D1,
                                           gpu_ids=self.gpu_ids, opt=opt)
@@ -104,10 +105,16 @@ class Pix2PixHDModel(BaseModel):
                                            num_D=opt.num_D_D2, gpu_ids=self.gpu_ids, opt=opt)
             self.flatD, self.flatD2 = FlatParams(self.netD), FlatParams(self.netD2)
             betas = (opt.beta1, 0.999)
-            self.optimizer_G = FlatAdam(self.flatG, opt.lr, betas)
+            self.old_lr = opt.lr
+            self.optimizer_G = FlatAdam(self.flatG, opt.lr, betas, span=self._finetune_span(opt))
             self.optimizer_D = FlatAdam(self.flatD, opt.lr, betas)
             self.optimizer_D2 = FlatAdam(self.flatD2, opt.lr, betas)
             self.optimizers += [self.optimizer_G, self.optimizer_D, self.optimizer_D2]
+        if self.isTrain:
+            if opt.pool_size > 0 and len(self.gpu_ids) > 1:
+                raise NotImplementedError("Fake Pool Not Implemented for MultiGPU")      # (pix2pixHD_model.py:332-333)
+            from util.image_pool import ImagePool
+            self.fake_pool = ImagePool(opt.pool_size)
         self.netVGG = None
         if self.isTrain and not opt.no_vgg_loss:      # criterionVGG = VGGLoss(gpu_ids) (pix2pixHD_model.py; networks.py:2021-2067): frozen
             from . import perceptual
@@ -120,15 +127,59 @@ class Pix2PixHDModel(BaseModel):
         self._eager_steps_done = 0
         self.ddp = None
 
+    def _finetune_span(self, opt):
+        """--niter_fix_global > 0 (pix2pixHD_model.py:403-421): optimizer_G is built over the parameters whose name starts with
+        "model<n_local_enhancers>" only -- the last local enhancer, the tail of the flat buffer -- until update_fixed_params()."""
+        if opt.niter_fix_global <= 0:
+            return None
+        prefix = "model" + str(opt.n_local_enhancers)
+        lo, o, seen = None, 0, False
+        for k, p in self.netG.named_parameters():
+            hit = k.startswith(prefix)
+            if hit and lo is None:
+                lo = o
+            if seen and not hit:
+                raise RuntimeError("niter_fix_global: the finetuned parameters are not one contiguous range of the flat buffer")
+            seen = seen or hit
+            o += p.numel()
+        if lo is None:     # netG 'global' has no such layer: the reference's Adam raises on the empty list
+            raise ValueError("optimizer got an empty parameter list (--niter_fix_global needs --netG local)")
+        print("------------- Only training the local enhancer network (for %d epochs) ------------" % opt.niter_fix_global)
+        return (lo, o)
+
+    def update_fixed_params(self):
+        """pix2pixHD_model.py:942-949 (train.py:209-211 calls it at epoch niter_fix_global): a NEW Adam over all of netG -- fresh moments,
+        step 0, the initial rate until the next update_learning_rate"""
+        self.optimizer_G = FlatAdam(self.flatG, self.opt.lr, (self.opt.beta1, 0.999))
+        self.optimizers[0] = self.optimizer_G
+        self._drop_graphs()
+        if self.opt.verbose:
+            print("------------ Now also finetuning global generator -----------")
+
+    def update_learning_rate(self):
+        """pix2pixHD_model.py:951-962: every call lowers the rate of the three optimisers by opt.lr / niter_decay (the reference overrides
+        BaseModel's scheduler step with this, and has no floor)"""
+        lr = self.old_lr - self.opt.lr / self.opt.niter_decay
+        for o in (self.optimizer_D, self.optimizer_D2, self.optimizer_G):
+            for g in o.param_groups:
+                g["lr"] = lr
+        if self.opt.verbose:
+            print("update learning rate: %f -> %f" % (self.old_lr, lr))
+        self.old_lr = lr
+
     @staticmethod
     def _check_unbuilt(opt):
         bad = []
         if not opt.no_instance or opt.instance_feat or opt.label_feat or opt.label_nc != 0 or opt.load_features:
-            bad.append("instance / label feature inputs (netE) are not built")
+            # not reachable in the reference either: its forward() hands encode_input inst = image = feat = None (pix2pixHD_model.py:592-597),
+            # so --no_instance False dies on `inst_map.data` (:545-546), --instance_feat / --label_feat on netE.forward(None, ..) (:601-603)
+            # and --load_features on `feat_map.data` (:558-559); --label_nc > 0 one-hots the SKETCH values (:533-541)
+            bad.append("instance / label feature inputs (netE, label_nc > 0): the reference's forward() passes inst = image = feat = None "
+                       "(models/pix2pixHD_model.py:592-603), so these flags fail upstream as well and there is no behaviour to restate")
         if opt.netG not in ("global", "local"):
             bad.append("netG %s (built: global, local)" % opt.netG)
-        if opt.pool_size > 0 or opt.fp16 or opt.niter_fix_global > 0 or opt.T_resolution_multiplier != 1 or not opt.use_bg_mask:
-            bad.append("pool_size > 0 / fp16 / niter_fix_global / T_resolution_multiplier != 1 / use_bg_mask False")
+        if opt.fp16 or opt.T_resolution_multiplier != 1 or not opt.use_bg_mask:
+            bad.append("fp16 / T_resolution_multiplier != 1 / use_bg_mask False")
         if opt.isTrain and opt.no_gan_loss:
             bad.append("no_gan_loss")
         if bad:
@@ -196,7 +247,13 @@ class Pix2PixHDModel(BaseModel):
             return [dict(in0=self.real_S, in1=fake, real=False, coeff=1.0, slot=slot[s_fake], grad_coeff=0.5),
                     dict(in0=self.real_S, in1=real, real=True, coeff=1.0, slot=slot[s_real], grad_coeff=0.5, accumulate=True)]
 
-        engine.msd_multi([(self.netD, pair(self.fake_I, self.real_I, "D_fake", "D_real")),
+        jobs_D = pair(self.fake_I, self.real_I, "D_fake", "D_real")
+        if self.fake_pool.pool_size > 0:
+            # backward_D's fake pass of D sees fake_pool.query(cat(label, fake_I)) (pix2pixHD_model.py:582, 626): label and image pooled
+            # as parallel stores under one plan (drawn in optimize_parameters, outside the captured graphs)
+            jobs_D[0]["in0"] = self.fake_pool.apply("label", self.real_S)
+            jobs_D[0]["in1"] = self.fake_pool.apply("image", self.fake_I)
+        engine.msd_multi([(self.netD, jobs_D),
                           (self.netD2, pair(self.fake_T, self.real_T, "D2_fake", "D2_real"))], self.criterionGAN)
 
     def _seg_adam_d_g(self):
@@ -288,6 +345,12 @@ class Pix2PixHDModel(BaseModel):
 
     def optimize_parameters(self, epoch=0, timing=False):
         self._gscale = self.ddp.grad_scale if self.ddp is not None else 1.0
+        if self.fake_pool.pool_size > 0:
+            if self.ddp is not None:
+                from vts import ddp as _ddp
+                if _ddp.active():
+                    raise NotImplementedError("Fake Pool Not Implemented for MultiGPU")
+            self.fake_pool.next_batch(self.real_S.shape[0], self.device)
         for o in self.optimizers:
             o.sync_lr()
         use_graph = bool(getattr(self.opt, "use_hip_graph", False))

@@ -102,3 +102,6 @@ if __name__ == "__main__":
         print("End of epoch %d / %d \t Time Taken: %d sec" % (epoch, opt.n_epochs + opt.n_epochs_decay, time.time() - t_epoch))
         if opt.train_for_each_epoch:
             model.update_learning_rate()
+        # pix2pixHD: after niter_fix_global epochs on the local enhancer alone, train the whole generator (reference train.py:209-211)
+        if getattr(opt, "niter_fix_global", 0) != 0 and epoch == opt.niter_fix_global:
+            model.update_fixed_params()

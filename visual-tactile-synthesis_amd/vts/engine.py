@@ -681,20 +681,27 @@ def resnet_forward(G, x, keep=True, dropout_masks=None):
 
 
 def local_enhancer_forward(G, x, keep=True):
-    """pix2pixHD LocalEnhancer.forward with one local enhancer (networks.py:1933-1949): the global trunk on the
-    average-pooled input, the local downsampling branch on the full input, their sum through the local upsampling branch"""
+    """pix2pixHD LocalEnhancer.forward (networks.py:1933-1949): the global trunk on the input average-pooled L = n_local_enhancers times,
+    then enhancer n = 1 .. L: its downsampling branch on pyramid level L - n, plus the output below, through its upsampling branch"""
     x = _as_act(x)
-    xd = Act(ops.avgpool(x.data))
-    a, pa, steps_g = _seq_forward(G, G.seq_global, [xd], None, 0)
-    b, pb, steps_1 = _seq_forward(G, G.seq_11, [x], None, 0)
-    bm = ops.pad_affine(b, (0, 0, 0, 0), 0, act=pb)
-    s = ops.pad_affine(a, (0, 0, 0, 0), 0, act=pa, res=bm)
-    out, _, steps_2 = _seq_forward(G, G.seq_12, None, s, 0)
+    L = G.n_local_enhancers
+    pyr = [x]
+    for _ in range(L):
+        pyr.append(Act(ops.avgpool(pyr[-1].data)))
+    a, pa, steps_g = _seq_forward(G, G.seq_global, [pyr[-1]], None, 0)
+    levels = []
+    for n in range(1, L + 1):
+        b, pb, steps_1 = _seq_forward(G, G.seq_down[n - 1], [pyr[L - n]], None, 0)
+        bm = ops.pad_affine(b, (0, 0, 0, 0), 0, act=pb)
+        s = ops.pad_affine(a, (0, 0, 0, 0), 0, act=pa, res=bm)
+        out, pout, steps_2 = _seq_forward(G, G.seq_up[n - 1], None, s, 0)
+        levels.append((steps_1, steps_2, a, b))
+        a, pa = out, pout
     ctx = None
     if keep:
         ctx = ResnetCtx()
-        ctx.steps, ctx.g_out = (steps_g, steps_1, steps_2, a, b), out
-    return out, ctx
+        ctx.steps, ctx.g_out = (steps_g, levels), a
+    return a, ctx
 
 
 def _through_norm_relu(g_act, a, bn):
@@ -823,11 +830,14 @@ def resnet_backward(G, ctx, d_raw):
     Biases that feed a normalisation have identically zero gradient and are never written."""
     sq = SideQueue()     # weight / bias gradients: off the critical path of the backward-data chain
     if getattr(G, "is_local_enhancer", False):
-        steps_g, steps_1, steps_2, a, b = ctx.steps
-        bn_of = _bn_map(steps_g, steps_1, steps_2)
-        g_s = _seq_backward(steps_2, d_raw, sq, bn_of)         # gradient w.r.t. relu(norm(a)) + relu(norm(b))
-        _seq_backward(steps_g, _through_norm_relu(g_s, a, bn_of.get(id(a))), sq, bn_of)
-        _seq_backward(steps_1, _through_norm_relu(g_s, b, bn_of.get(id(b))), sq, bn_of)
+        steps_g, levels = ctx.steps
+        bn_of = _bn_map(steps_g, *[lv[0] for lv in levels], *[lv[1] for lv in levels])
+        g = d_raw
+        for steps_1, steps_2, a, b in reversed(levels):
+            g_s = _seq_backward(steps_2, g, sq, bn_of)         # gradient w.r.t. relu(norm(a)) + relu(norm(b))
+            _seq_backward(steps_1, _through_norm_relu(g_s, b, bn_of.get(id(b))), sq, bn_of)
+            g = _through_norm_relu(g_s, a, bn_of.get(id(a)))   # ... w.r.t. the raw output of the level below
+        _seq_backward(steps_g, g, sq, bn_of)
     else:
         _seq_backward(ctx.steps, d_raw, sq, _bn_map(ctx.steps))
     sq.join()

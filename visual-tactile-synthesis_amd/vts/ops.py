@@ -1218,6 +1218,17 @@ def input_images_u8(S, I, M, M_out, S_out, S_out2, I_out):
                                          L.stream()), "vts_input_images_u8")
 
 
+def pool_query(images, store, ret_slot, put_slot, out):
+    """ImagePool.query on the device (vts_pool_query): out[n] = store[ret_slot[n]] or images[n]; store[put_slot[n]] = images[n]; n in order"""
+    n = images.shape[0]
+    elems = images.numel() // max(n, 1)
+    assert images.is_contiguous() and store.is_contiguous() and out.is_contiguous() and store.numel() % max(elems, 1) == 0
+    assert ret_slot.dtype == torch.int32 and put_slot.dtype == torch.int32 and ret_slot.numel() == n and put_slot.numel() == n
+    L.check(L.load().vts_pool_query(images.data_ptr(), store.data_ptr(), ret_slot.data_ptr(), put_slot.data_ptr(), n, elems, out.data_ptr(),
+                                    L.stream()), "vts_pool_query")
+    return out
+
+
 def mask_mul(x, M, out=None):
     lib = L.load()
     n, c, h, w = x.shape

@@ -76,11 +76,15 @@ class FlatAdam(torch.optim.Optimizer):
     schedulers (networks.get_scheduler) can drive `param_groups[0]["lr"]`; the update itself
     is one vts_adam_flat_dev launch."""
 
-    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, step_dev=None):
+    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, step_dev=None, span=None):
         """step_dev: optional 1-element int32 device view that holds this optimiser's step counter (a model may keep the counters of
-        all its optimisers in one tensor and advance them with ONE launch per step: step(bump=False))"""
+        all its optimisers in one tensor and advance them with ONE launch per step: step(bump=False)).
+        span: (lo, hi) element range of the flat buffer this optimiser updates -- an optimiser built over a subset of the parameters
+        (pix2pixHD --niter_fix_global: only the last local enhancer, pix2pixHD_model.py:403-421); the rest is never touched."""
         super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps))
         self.flat = flat
+        self.span = (0, flat.numel) if span is None else (int(span[0]), int(span[1]))
+        assert 0 <= self.span[0] < self.span[1] <= flat.numel
         dev = flat.flat.device
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
@@ -107,8 +111,9 @@ class FlatAdam(torch.optim.Optimizer):
         if bump:
             self.step_dev.add_(1)
         g = self.param_groups[0]
-        ops.adam_flat_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.lr_dev, g["betas"][0], g["betas"][1], g["eps"],
-                          self.step_dev, grad_scale)
+        lo, hi = self.span
+        ops.adam_flat_dev(self.flat.flat[lo:hi], self.flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr_dev, g["betas"][0], g["betas"][1],
+                          g["eps"], self.step_dev, grad_scale)
 
     def load_named_state(self, module, m_by_name, v_by_name, step):
         """Load per-parameter Adam moments keyed by state_dict names (resume / parity tests)."""
