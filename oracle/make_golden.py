@@ -1094,6 +1094,58 @@ def golden_step_conditioning(size=256, seed=515, nt=64):
     print("wrote sinskitG_cond_step_%d.npz (%d entries)" % (size, len(out)))
 
 
+def golden_step_d3_warmup(size=256, seed=626, nt=64):
+    """One SinSKITGModel.optimize_parameters of the REFERENCE with its DEFAULT --use_vision_aided_loss True at epoch 1, i.e. before
+    --vision_aided_warmup_epoch (100): the model constructs vision_aided_loss.Discriminator (sinskitG_model.py:546-551; the package is
+    absent here, so a stand-in class whose forward RAISES is injected -- the fixture proves it is never called) and reports the three D3
+    entries as 0.0 (:1399-1402, 1721-1722).  Pinned: the order of the loss names and that the step is the flag-off step."""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    import vision_aided_loss
+
+    class _NeverCalled(torch.nn.Module):
+        def __init__(self, cv_type=None, loss_type=None, device=None, **kw):
+            super().__init__()
+            assert cv_type == "clip" and loss_type == "multilevel_sigmoid_s", (cv_type, loss_type)
+            self.cv_ensemble = torch.nn.Linear(1, 1)
+
+        def forward(self, *a, **k):
+            raise AssertionError("netD3 called before the warm-up epoch")
+
+    vision_aided_loss.Discriminator = _NeverCalled
+    from models.sinskitG_model import SinSKITGModel
+
+    flags = ["--lambda_G1_lpips", "0", "--lambda_G2_lpips", "0", "--lambda_G2_GAN_feat", "0", "--checkpoints_dir", "/tmp/vts_golden_ckpt",
+             "--name", "golden_d3"]
+    opt = _ref_opt("sinskitG", True, flags)
+    assert opt.use_vision_aided_loss is True and opt.vision_aided_warmup_epoch == 100
+    model = SinSKITGModel(opt)
+    model.setup(opt)
+    model.netG.load_state_dict(detrand.test_weights(nets.g_param_shapes(), seed))
+    model.netD.load_state_dict(detrand.test_weights(nets.d_param_shapes(4), seed + 1))
+    model.netD2.load_state_dict(detrand.test_weights(nets.d_param_shapes(7), seed + 2))
+    model.train()
+    batch = _synthetic_batch(size, nt, seed)
+    model.set_input(batch, phase="train")
+    k = int(nets.dilated_mask_positions(model.M).shape[0])
+    torch.manual_seed(seed)
+    aug = torch.stack([torch.rand(1, 1, 1, 1).flatten() for _ in range(4)])
+    random.seed(seed)
+    more = np.array(random.sample(range(k), opt.add_fake_T_sample_size), dtype=np.int64)[None]
+    torch.manual_seed(seed)
+    random.seed(seed)
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    out = {"size": size, "seed": seed, "nt": nt, "warmup_epoch": opt.vision_aided_warmup_epoch, "aug": aug.numpy(), "more_idx": more,
+           "loss_names": np.array(list(losses.keys())), "loss_values": np.array(list(losses.values()), dtype=np.float64),
+           "fake_I_probe": detrand.probe(model.fake_I, "fake_I"), "fake_T_probe": detrand.probe(model.fake_T, "fake_T")}
+    for kk, p in model.netG.named_parameters():
+        out["param_G/" + kk] = detrand.probe(p, kk)
+    np.savez_compressed(os.path.join(GOLD, "sinskitG_d3_warmup_step_%d.npz" % size), **out)
+    print("wrote sinskitG_d3_warmup_step_%d.npz" % size, {k: round(float(v), 5) for k, v in losses.items()})
+
+
 def variant_g_shapes(opt):
     from oracle import nets
     if opt.netG.startswith("resnet_"):
@@ -1282,6 +1334,8 @@ if __name__ == "__main__":
     if "p2pvanilla" in which:
         # gan_mode 'vanilla' (the discriminators end in a Sigmoid and BCEWithLogits follows, networks.py:1659, 507-509) at PatchGAN depth 2
         golden_p2p_step(seed=525, steps=1, extra=("--gan_mode", "vanilla", "--n_layers_D", "2"), fname="pix2pixHD_vanilla_step_%d.npz", n_layers=2)
+    if "d3warmup" in which:
+        golden_step_d3_warmup()
     if "pool" in which:
         golden_image_pool()
     if "p2ppool" in which:

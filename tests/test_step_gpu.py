@@ -939,3 +939,40 @@ def test_fresh_batch_staging_paths_agree_bit_for_bit(monkeypatch):
             assert torch.equal(results[0][0][n], r[0][n]), n
         assert results[0][1] == r[1]
         assert torch.equal(results[0][3], r[3])
+
+
+def test_default_vision_aided_flag_before_the_warmup_epoch_matches_reference(golden_dir):
+    """The reference's DEFAULT --use_vision_aided_loss True: before --vision_aided_warmup_epoch (100) its step never calls netD3 and logs the
+    three D3 entries as 0.0 (tests/golden/sinskitG_d3_warmup_step_256.npz: the reference run with a stand-in netD3 whose forward raises).
+    The HIP path accepts the flag, reports the same names in the same order and the same values, and raises once the epoch reaches the
+    warm-up epoch (CLIP + the package's head are not built)."""
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+
+    g = np.load(os.path.join(golden_dir, "sinskitG_d3_warmup_step_256.npz"))
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    opt = TrainOptions(cmd_line=FLAGS.replace("--use_vision_aided_loss False ", "") % (size, 1)).parse()
+    assert opt.use_vision_aided_loss is True and opt.vision_aided_warmup_epoch == int(g["warmup_epoch"])
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    model.train()
+    load_test_weights(model, seed)
+    batch = default_collate([make_sample(size, nt, nt, seed)])
+    model._draws = {"aug": torch.from_numpy(g["aug"]), "more_idx": torch.from_numpy(g["more_idx"])}
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    losses = model.get_current_losses()
+    assert list(losses.keys()) == [str(k) for k in g["loss_names"]]
+    for k, v in zip(losses.keys(), g["loss_values"]):
+        assert abs(losses[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses[k], v)
+    assert losses["l_G_D3"] == 0.0 and losses["l_D3_real_I"] == 0.0 and losses["l_D3_fake_I"] == 0.0
+    probe_close(model.fake_I.contiguous(), g["fake_I_probe"], "fake_I", 1e-3)
+    for k, p in model.netG.named_parameters():
+        if not null_grad_bias("G", k):
+            probe_close(p.data, g["param_G/" + k], k, 1e-3)
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=int(g["warmup_epoch"]) - 1)
+    with pytest.raises(NotImplementedError, match="vision_aided_warmup_epoch"):
+        model.optimize_parameters(epoch=int(g["warmup_epoch"]))

@@ -142,6 +142,8 @@ class SinSKITGModel(BaseModel):
         if getattr(opt, "train_for_each_epoch", False):
             if opt.lambda_G1_GAN > 0.0:
                 self.loss_names.extend(["G_GAN", "D_real_I", "D_fake_I", "D_I_grad_penalty"])
+                if getattr(opt, "use_vision_aided_loss", False):      # (sinskitG_model.py:434-435; 0.0 until the warm-up epoch, :1399-1402, 1721-1722)
+                    self.loss_names.extend(["G_D3", "D3_real_I", "D3_fake_I"])
             if opt.lambda_G1_L1 > 0.0:
                 self.loss_names.append("G_L1")
             if opt.lambda_G2_GAN > 0.0:
@@ -154,6 +156,7 @@ class SinSKITGModel(BaseModel):
                 self.loss_names.insert(self.loss_names.index("G_L1") + 1 if "G_L1" in self.loss_names else len(self.loss_names), "G_lpips")
             if opt.lambda_G2_lpips > 0.0:
                 self.loss_names.append("G2_lpips")
+        self.loss_G_D3 = self.loss_D3_real_I = self.loss_D3_fake_I = 0.0     # what the reference logs before the warm-up epoch
         # evaluation metrics (SIFID / LPIPS / PSNR / SSIM ...) are SURVEY.md §8(f) row 2: not built
         self.metric_names = []
 
@@ -251,13 +254,21 @@ class SinSKITGModel(BaseModel):
     def _check_unbuilt_terms(opt):
         if not opt.isTrain:
             return
-        bad = []
-        if opt.use_vision_aided_loss:
-            bad.append("CLIP vision-aided discriminator (--use_vision_aided_loss False)")
-        if bad:
+        # --use_vision_aided_loss (default True): the reference constructs vision_aided_loss.Discriminator(cv_type="clip",
+        # loss_type="multilevel_sigmoid_s") (sinskitG_model.py:546-551) but calls it only from epoch vision_aided_warmup_epoch (100) on
+        # (:1393, 1719); before that its three loss entries are the constant 0.0 and the step is exactly the step without the flag.  That
+        # part IS the HIP path's behaviour: the flag is accepted, the entries report 0.0, and optimize_parameters raises when the epoch
+        # reaches the warm-up epoch (_check_vision_aided) -- CLIP ViT-B/32 and the package's head exist neither offline nor in /root/reference.
+
+    def _check_vision_aided(self, epoch):
+        opt = self.opt
+        if getattr(opt, "use_vision_aided_loss", False) and opt.lambda_G1_GAN > 0.0 and epoch >= opt.vision_aided_warmup_epoch:
             raise NotImplementedError(
-                "third-party loss terms need pretrained weights that are not available offline and are not built: %s. "
-                "Disable them explicitly (SURVEY.md §7 'Third-party loss terms')." % "; ".join(bad))
+                "epoch %d >= --vision_aided_warmup_epoch %d: from here on the reference adds the CLIP vision-aided discriminator terms "
+                "(models/sinskitG_model.py:1393-1398, 1719-1720; third-party package vision_aided_loss + CLIP ViT-B/32 weights, neither "
+                "available offline).  They are not built on the HIP path: continue with --use_vision_aided_loss False (note that the "
+                "reference never hands netD3's head to an optimizer nor saves it, so the term is a frozen random projection of frozen "
+                "CLIP features)." % (epoch, opt.vision_aided_warmup_epoch))
 
     def _lpips_alex_net(self):
         """lpips.LPIPS(net="alex"), the reference's eval_LPIPS of the test phase (sinskitG_model.py:501)"""
@@ -1069,6 +1080,7 @@ class SinSKITGModel(BaseModel):
     def optimize_parameters(self, epoch=0, timing=False):
         if self.train_set is None:
             raise RuntimeError("optimize_parameters needs tactile patches in the batch (T_images)")
+        self._check_vision_aided(epoch)
         self._gscale = self.ddp.grad_scale if self.ddp is not None else 1.0
         for o in self.optimizers:
             o.sync_lr()
