@@ -46,12 +46,16 @@ def test_unbuilt_third_party_terms_raise():
     from options.train_options import TrainOptions
 
     opt = parse(TrainOptions, "--model sinskitG --gpu_ids 0 --checkpoints_dir /tmp/vts_opt")
-    with pytest.raises(NotImplementedError, match="CLIP vision-aided"):      # the reference's default flags: the CLIP discriminator is not built
-        SinSKITGModel._check_unbuilt_terms(opt)
+    # the reference's default flags: accepted at construction and before the warm-up epoch (upstream does not call the CLIP discriminator
+    # there either); the term itself is not built and raises from the warm-up epoch on
+    SinSKITGModel._check_unbuilt_terms(opt)
+    SinSKITGModel._check_unbuilt_terms(opt, opt.vision_aided_warmup_epoch - 1)
+    with pytest.raises(NotImplementedError, match="CLIP vision-aided"):
+        SinSKITGModel._check_unbuilt_terms(opt, opt.vision_aided_warmup_epoch)
     # LPIPS is built since round 3: the reference's default lambdas pass the check once the CLIP term is switched off
     opt = parse(TrainOptions, "--model sinskitG --gpu_ids 0 --checkpoints_dir /tmp/vts_opt --use_vision_aided_loss False")
     assert opt.lambda_G1_lpips == 1.0 and opt.lambda_G2_lpips == 10.0
-    SinSKITGModel._check_unbuilt_terms(opt)
+    SinSKITGModel._check_unbuilt_terms(opt, 10 ** 6)
 
 
 def test_synthetic_dataset_contract():

@@ -251,17 +251,15 @@ class SinSKITGModel(BaseModel):
         self.style_code = None
 
     @staticmethod
-    def _check_unbuilt_terms(opt):
-        if not opt.isTrain:
+    def _check_unbuilt_terms(opt, epoch=None):
+        """--use_vision_aided_loss (default True): the reference constructs vision_aided_loss.Discriminator(cv_type="clip",
+        loss_type="multilevel_sigmoid_s") (sinskitG_model.py:546-551) but calls it only from epoch vision_aided_warmup_epoch (100) on
+        (:1393, 1719); before that its three loss entries are the constant 0.0 and the step is exactly the step without the flag.  That
+        part IS the HIP path's behaviour: the flag is accepted at construction (epoch None), the entries report 0.0, and
+        optimize_parameters raises when the epoch reaches the warm-up epoch -- CLIP ViT-B/32 and the package's head exist neither offline
+        nor in /root/reference."""
+        if not opt.isTrain or epoch is None:
             return
-        # --use_vision_aided_loss (default True): the reference constructs vision_aided_loss.Discriminator(cv_type="clip",
-        # loss_type="multilevel_sigmoid_s") (sinskitG_model.py:546-551) but calls it only from epoch vision_aided_warmup_epoch (100) on
-        # (:1393, 1719); before that its three loss entries are the constant 0.0 and the step is exactly the step without the flag.  That
-        # part IS the HIP path's behaviour: the flag is accepted, the entries report 0.0, and optimize_parameters raises when the epoch
-        # reaches the warm-up epoch (_check_vision_aided) -- CLIP ViT-B/32 and the package's head exist neither offline nor in /root/reference.
-
-    def _check_vision_aided(self, epoch):
-        opt = self.opt
         if getattr(opt, "use_vision_aided_loss", False) and opt.lambda_G1_GAN > 0.0 and epoch >= opt.vision_aided_warmup_epoch:
             raise NotImplementedError(
                 "epoch %d >= --vision_aided_warmup_epoch %d: from here on the reference adds the CLIP vision-aided discriminator terms "
@@ -1080,7 +1078,7 @@ class SinSKITGModel(BaseModel):
     def optimize_parameters(self, epoch=0, timing=False):
         if self.train_set is None:
             raise RuntimeError("optimize_parameters needs tactile patches in the batch (T_images)")
-        self._check_vision_aided(epoch)
+        self._check_unbuilt_terms(self.opt, epoch)
         self._gscale = self.ddp.grad_scale if self.ddp is not None else 1.0
         for o in self.optimizers:
             o.sync_lr()
