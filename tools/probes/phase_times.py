@@ -30,7 +30,7 @@ def seg_fwd():
 
 
 def seg_d():
-    model._forward_and_stacks = lambda: None
+    model._forward_and_stacks = lambda *a, **k: None
     try:
         model._seg_d_updates()
     finally:
