@@ -275,6 +275,16 @@ def test_image_pool_on_the_device_returns_what_the_reference_returns(golden_dir)
         want = torch.stack([ramp + float(v) for v in g["returned"][b]])
         assert torch.equal(out, want), (b, out[:, 0, 0, 0], g["returned"][b])
     assert ImagePool(0).query(imgs) is imgs
+    # the host several batches AHEAD of the device (a training loop does not synchronise per step): the plans must not overtake each other
+    random.seed(seed)
+    pool = ImagePool(size)
+    batches_dev = [torch.stack([ramp + float(b * n + i) for i in range(n)]).to(dev) for b in range(batches)]
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(2e8))          # ~0.1 s of device time in front of all six queries
+    outs = [pool.query(x) for x in batches_dev]
+    for b, out in enumerate(outs):
+        want = torch.stack([ramp + float(v) for v in g["returned"][b]])
+        assert torch.equal(out.cpu(), want), ("run-ahead", b)
 
 
 def test_pool_step_matches_reference_golden(golden_dir):

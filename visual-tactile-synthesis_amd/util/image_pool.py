@@ -41,15 +41,25 @@ class ImagePool:
         return ret, put
 
     def next_batch(self, n, device):
-        """draw the plan of the next batch and put it where `apply` (possibly inside a captured graph) reads it"""
+        """draw the plan of the next batch and put it where `apply` (possibly inside a captured graph) reads it.  The upload is asynchronous
+        and the host may be several steps ahead of the device: the plan travels through a small ring of pinned buffers, each guarded by
+        the event of the copy that last read it."""
         if self.pool_size == 0:
             return
         ret, put = self.plan(n)
         if self._slots is None or self._slots.shape[1] != n:
             self._slots = torch.empty(2, n, dtype=torch.int32, device=device)
-            self._host = torch.empty(2, n, dtype=torch.int32).pin_memory()
-        self._host.copy_(torch.tensor([ret, put], dtype=torch.int32))
-        self._slots.copy_(self._host, non_blocking=True)
+            self._host = [torch.empty(2, n, dtype=torch.int32).pin_memory() for _ in range(4)]
+            self._sent = [None] * len(self._host)
+            self._turn = 0
+        k = self._turn
+        self._turn = (k + 1) % len(self._host)
+        if self._sent[k] is not None:
+            self._sent[k].synchronize()
+        self._host[k].copy_(torch.tensor([ret, put], dtype=torch.int32))
+        self._slots.copy_(self._host[k], non_blocking=True)
+        self._sent[k] = torch.cuda.Event()
+        self._sent[k].record()
 
     def apply(self, name, images, out=None):
         """out = what the discriminator sees in place of `images` under the current plan; the pool store `name` is updated"""
