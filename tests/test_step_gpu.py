@@ -415,6 +415,27 @@ def test_train_and_test_scripts_end_to_end(tmp_path):
     assert saved["fake_I"].shape == (1, 3, 256, 256) and saved["fake_gx"].shape == (1, 1, 256, 256)
 
 
+def test_train_script_runs_with_the_reference_default_loss_flags(tmp_path):
+    """train.py with NO loss flag touched -- the published command's defaults: both LPIPS terms on (stand-in VGG16 weights here) and
+    --use_vision_aided_loss True -- trains and logs the reference's loss names, the three D3 entries as 0 before the warm-up epoch; with
+    the warm-up epoch moved to 1 the run stops with the message that names the flag (the CLIP term is not built)."""
+    import subprocess
+    import sys
+
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visual-tactile-synthesis_amd")
+    common = [sys.executable, os.path.join(pkg, "train.py"), "--model", "sinskitG", "--gpu_ids", "0", "--dataset_mode", "synthetic", "--crop_size", "256",
+              "--checkpoints_dir", str(tmp_path), "--data_len", "2", "--n_epochs", "1", "--n_epochs_decay", "0", "--print_freq", "1",
+              "--save_latest_freq", "100", "--save_epoch_freq", "100", "--batch_size", "1"]
+    out = subprocess.run(common + ["--name", "dflt"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    log = open(os.path.join(str(tmp_path), "dflt", "loss_log.txt")).read()
+    for name in ("l_G_GAN", "l_G_D3", "l_D3_real_I", "l_D3_fake_I", "l_G_L1", "l_G_lpips", "l_G2_lpips"):
+        assert name in log, name
+    assert "l_G_D3: 0.000" in log and "nan" not in log.lower()
+    out = subprocess.run(common + ["--name", "warm", "--vision_aided_warmup_epoch", "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0 and "vision_aided_warmup_epoch" in out.stderr and "use_vision_aided_loss False" in out.stderr, out.stderr[-1500:]
+
+
 def test_skitG_trains_from_the_multi_material_dataset(tmp_path):
     """train.py --model skitG --dataset_mode skit: two seeded materials at the reference's relative place ./datasets/singleskit_<m>_padded_<size>_x1/
     (data/skit_dataset.py), each with a precomputed style code; batches alternate between the materials, checkpoints and the loss log appear"""
