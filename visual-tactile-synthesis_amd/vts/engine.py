@@ -1363,7 +1363,11 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, st
             gstarts = [gr["n0"] for gr in groups] if groups else None
             stat_rec = p.setdefault("_stats", {}).setdefault(s, {}) if p.get("stat_only") else None
             src = p.get("ext_from")
+            if KO_LANES and src is not None:
+                src.setdefault("_stats", {}).setdefault(s, {})
             ext = (src["_stats"][s], p.get("ext_after", 0)) if src is not None else None
+            if KO_LANES and src is not None and not ext[0]:      # (timing experiment: the early pass of this lane was knocked out too)
+                ext = None
             acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext)
             pred = acts[-1].data
             p["preds"][s] = pred

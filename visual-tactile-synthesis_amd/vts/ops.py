@@ -979,7 +979,8 @@ def norm_stats(x, mode, *, gamma=None, beta=None, running_mean=None, running_var
     if TIMER is not None:
         global DETAIL
         DETAIL = "%s N%d %dx%dx%d%s" % ("BN" if mode else "IN", n, c, h, w, " groups %s" % list(groups) if groups else "")
-    _run("norm_stats", 4.0 * n * c * h * w, 0.0, lib.vts_norm_stats, C.byref(d), ws.data_ptr(), L.stream())
+    # (label: the many-small-maps launches of the D2 patch stacks can be knocked out separately in timing experiments)
+    _run("norm_stats" if n < 128 else "norm_patch_stats", 4.0 * n * c * h * w, 0.0, lib.vts_norm_stats, C.byref(d), ws.data_ptr(), L.stream())
     return Act(x, st[0], st[1], st[2], st[3])
 
 
@@ -1010,7 +1011,7 @@ def norm_bwd(dy, act, mode, *, gamma=None, dgamma=None, dbeta=None, accumulate=F
         return dy
     ws = workspace(lib.vts_norm_ws_floats(n, c, h * w), dy.device)
     d.counters = L.ptr(counters(dy.device)) if n * c <= (1 << 16) else None
-    _run("norm_bwd", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
+    _run("norm_bwd" if n < 128 else "norm_patch_bwd", 4.0 * n * c * h * w * 3, 0.0, lib.vts_norm_bwd, C.byref(d), ws.data_ptr(), L.stream())
     return dy
 
 
