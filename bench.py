@@ -235,6 +235,22 @@ def kernel_roofline(model, batch_dict, detail_path=None):
     roof["step_t_roof_ms"] = step_t_roof * 1e3
     roof["launches_per_step_all"] = len(rec)
     roof["serialized_kernel_ms"] = total * 1e3
+    # The figures above describe the EAGER single-stream schedule (one launch after the other: clean per-launch times).  The step that
+    # `ms_per_step` times is the replayed LANE schedule: the discriminator scales, the D1 pass on the real images beside the generator
+    # forward and the weight gradients run on side streams, which un-batches some passes -- more launches of the same kernels.  Its
+    # launch list is taken from one more eager step with the lanes on (events on each launch's own stream: counts are exact, durations
+    # include the slow-down of kernels that overlap), its node count from the captured graphs themselves.
+    ops.TIMER = []
+    graph_flag, model.opt.use_hip_graph = model.opt.use_hip_graph, False
+    model.optimize_parameters(epoch=1)
+    torch.cuda.synchronize()
+    rec2, ops.TIMER = ops.TIMER, None
+    model.opt.use_hip_graph = graph_flag
+    fam2 = [(e0.elapsed_time(e1) * 1e-3) for label, _, _, e0, e1, _ in rec2 if "_kernel" in label and "_kernel+" not in label and fam_of(label) == fam]
+    roof["lane_schedule"] = {"launches_all": len(rec2), "launches_family": len(fam2), "family_ms_overlapped": round(sum(fam2) * 1e3, 3)}
+    nodes = getattr(model, "graph_nodes", None)
+    roof["launches_per_step_replayed"] = sum(k for _, k in nodes) if nodes else None          # kernel nodes of the captured step's graphs
+    roof["graph_nodes_per_step"] = sum(n for n, _ in nodes) if nodes else None                # ... all nodes (memset / memcpy / event nodes included)
     return roof
 
 

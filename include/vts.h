@@ -40,6 +40,10 @@ const char* vts_last_error(void);
 /* Kernel instance chosen by the last vts_conv4x4 / vts_wgrad4x4 call of this thread (profiling aid). */
 const char* vts_last_kernel(void);
 int vts_version(void);
+/* Number of nodes (and of kernel nodes among them) in the graph `stream` is capturing into, at this point of the capture; both 0
+ * when the stream is not capturing.  Measurement aid: the launch count of the REPLAYED step (bench.py `launches_per_step_replayed`),
+ * which differs from the eager single-stream schedule's.  No reference counterpart (the reference launches eagerly, train.py:39-66). */
+int vts_capture_node_count(void* stream, int* nodes, int* kernel_nodes);
 
 /* A (possibly channel-concatenated, lazily normalised) activation operand:
  *   value(n, c, y, x) = act( data[n*nstride + c*H*W + y*W + x] * scale[n*C + c] + shift[n*C + c] )

@@ -285,6 +285,9 @@ def test_image_pool_on_the_device_returns_what_the_reference_returns(golden_dir)
     for b, out in enumerate(outs):
         want = torch.stack([ramp + float(v) for v in g["returned"][b]])
         assert torch.equal(out.cpu(), want), ("run-ahead", b)
+    # a batch of another image shape cannot join a filled history (the reference's torch.cat would fail): loud, never zero-filled slots
+    with pytest.raises(ValueError, match="cannot change its image shape"):
+        pool.query(torch.zeros(n, 2, 3, 7, device=dev))
 
 
 def test_pool_step_matches_reference_golden(golden_dir):

@@ -321,6 +321,61 @@ def test_step_batch2_matches_oracle():
                 assert rel(b, sd[k]) < 1e-3, (nm, k)
 
 
+@pytest.mark.parametrize("name", ["G2_no_S", "G2_no_I"])
+def test_step_batch2_conditioning_ablations_match_oracle(name):
+    """The D2 conditioning ablations at batch 2 against the oracle.  The reference-golden test of these flags runs batch 1 (upstream
+    asserts it), where the batch stride of the full-resolution D2 stack never matters: with --use_cGAN_G2_S False the mask channel of
+    samples >= 1 was written into sample 0 (ops.g_post took the stride from the absent sketch slice) -- seen in the full-resolution
+    prediction map and in the BatchNorm running statistics that pass advances (sinskitG_model.py:1490-1501)."""
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+    from oracle.make_golden import COND_VARIANTS, cond_channels
+    import random
+
+    size, nt, seed, n = 256, 64, 91, 2
+    extra = COND_VARIANTS[name]
+    opt = TrainOptions(cmd_line=(FLAGS % (size, n)) + " " + " ".join(extra)).parse()
+    model = create_model(opt)
+    model.setup(opt)
+    model.parallelize()
+    model.train()
+    c1, c2 = cond_channels(extra)
+    sdG, sdD, sdD2 = (detrand.test_weights(nets.g_param_shapes(), seed), detrand.test_weights(nets.d_param_shapes(c1), seed + 1),
+                      detrand.test_weights(nets.d_param_shapes(c2), seed + 2))
+    for net, sd in zip((model.netG, model.netD, model.netD2), (sdG, sdD, sdD2)):
+        net.load_state_dict(sd)
+    batch = default_collate([make_sample(size, nt, nt, seed + i) for i in range(n)])
+    random.seed(6)
+    counts = [int(nets.dilated_mask_positions(batch["M"][i:i + 1].float()).shape[0]) for i in range(n)]
+    draws = {"aug": detrand.uniform((4, n), 4, "aug") * 0.5 + 0.5,
+             "more_idx": torch.tensor([random.sample(range(c), 32) for c in counts])}
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    oopt = step.hp()
+    for k, v in zip(extra[::2], extra[1::2]):
+        setattr(oopt, k.lstrip("-"), v == "True")
+    ref = step.train_step(sdG, sdD, sdD2, adam, batch, draws, opt=oopt)
+    model._draws = draws
+    model.set_input(batch, phase="train")
+    model.optimize_parameters(epoch=1)
+    assert model._full_stack.shape == (n, c2, size, size)
+    losses = model.get_current_losses()
+    for k, v in ref["losses"].items():
+        assert abs(losses["l_" + k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses["l_" + k], v)
+    assert rel(model.pred_fake_T_full, ref["pred_fake_T_full"]) < 1e-3
+    for nm, net, sd in (("D", model.netD, sdD), ("D2", model.netD2, sdD2)):
+        for k, p in net.named_parameters():
+            if null_grad_bias(nm, k):
+                continue
+            assert rel(p.grad, ref["grad_" + nm][k]) < GRAD_TOL, (nm, k)
+        for k, b in net.named_buffers():
+            if k.endswith("running_mean"):
+                scale = float(sd[k.replace("running_mean", "running_var")].max().sqrt())
+                assert (b.cpu() - sd[k]).abs().max().item() < 1e-3 * scale, (nm, k)
+            elif b.dtype.is_floating_point:
+                assert rel(b, sd[k]) < 1e-3, (nm, k)
+
+
 def test_inference_forward_matches_oracle_and_checkpoint_roundtrip(tmp_path):
     from data.synthetic_dataset import make_sample
     from models import create_model
@@ -434,6 +489,10 @@ def test_train_script_runs_with_the_reference_default_loss_flags(tmp_path):
     assert "l_G_D3: 0.000" in log and "nan" not in log.lower()
     out = subprocess.run(common + ["--name", "warm", "--vision_aided_warmup_epoch", "1"], capture_output=True, text=True, timeout=900)
     assert out.returncode != 0 and "vision_aided_warmup_epoch" in out.stderr and "use_vision_aided_loss False" in out.stderr, out.stderr[-1500:]
+    # the cutoff is announced at construction, and what was trained is on disk before the run stops
+    assert "WARNING: --use_vision_aided_loss True" in out.stdout and "STOPS" in out.stdout, out.stdout[-1500:]
+    for net in ("G", "D", "D2"):
+        assert os.path.exists(os.path.join(str(tmp_path), "warm", "latest_net_%s.pth" % net)), net
 
 
 def test_skitG_trains_from_the_multi_material_dataset(tmp_path):

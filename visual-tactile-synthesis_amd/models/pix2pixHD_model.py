@@ -328,13 +328,14 @@ class Pix2PixHDModel(BaseModel):
         pool = torch.cuda.graph_pool_handle()
         stream = torch.cuda.Stream()
         counts = [o.step_count for o in self.optimizers]
-        graphs = []
+        graphs, nodes = [], []
         ops.freeze_ws((id(self), "train"))
         try:
             for seg, _, _ in self._segments():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):   # RCCL's watchdog thread queries events meanwhile
                     seg()
+                    nodes.append(ops.capture_node_count())
                 graphs.append(g)
         except Exception:
             ops.release_ws((id(self), "train"))
@@ -342,6 +343,7 @@ class Pix2PixHDModel(BaseModel):
         for o, c in zip(self.optimizers, counts):
             o.step_count = c
         self._graphs = graphs
+        self.graph_nodes = nodes
 
     def optimize_parameters(self, epoch=0, timing=False):
         self._gscale = self.ddp.grad_scale if self.ddp is not None else 1.0

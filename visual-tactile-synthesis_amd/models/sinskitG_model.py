@@ -258,9 +258,18 @@ class SinSKITGModel(BaseModel):
         part IS the HIP path's behaviour: the flag is accepted at construction (epoch None), the entries report 0.0, and
         optimize_parameters raises when the epoch reaches the warm-up epoch -- CLIP ViT-B/32 and the package's head exist neither offline
         nor in /root/reference."""
-        if not opt.isTrain or epoch is None:
+        if not opt.isTrain:
             return
-        if getattr(opt, "use_vision_aided_loss", False) and opt.lambda_G1_GAN > 0.0 and epoch >= opt.vision_aided_warmup_epoch:
+        active = getattr(opt, "use_vision_aided_loss", False) and opt.lambda_G1_GAN > 0.0
+        if epoch is None:
+            last = getattr(opt, "n_epochs", 0) + getattr(opt, "n_epochs_decay", 0)
+            if active and last >= opt.vision_aided_warmup_epoch:
+                print("WARNING: --use_vision_aided_loss True with %d planned epochs: this build trains like the reference up to epoch %d and "
+                      "then STOPS (the CLIP vision-aided discriminator terms that start at --vision_aided_warmup_epoch %d are not built; "
+                      "the 'latest' checkpoint is written before the run stops).  Pass --use_vision_aided_loss False to train all epochs."
+                      % (last, opt.vision_aided_warmup_epoch - 1, opt.vision_aided_warmup_epoch), flush=True)
+            return
+        if active and epoch >= opt.vision_aided_warmup_epoch:
             raise NotImplementedError(
                 "epoch %d >= --vision_aided_warmup_epoch %d: from here on the reference adds the CLIP vision-aided discriminator terms "
                 "(models/sinskitG_model.py:1393-1398, 1719-1720; third-party package vision_aided_loss + CLIP ViT-B/32 weights, neither "
@@ -1057,13 +1066,14 @@ class SinSKITGModel(BaseModel):
         pool = torch.cuda.graph_pool_handle()
         stream = torch.cuda.Stream()
         counts = [o.step_count for o in self.optimizers]
-        graphs = []
+        graphs, nodes = [], []
         ops.freeze_ws((id(self), "train"))
         try:
             for seg, _, _ in self._segments():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):   # RCCL's watchdog thread queries events meanwhile
                     seg()
+                    nodes.append(ops.capture_node_count())      # (all nodes, kernel nodes) of this segment: the replayed launch count
                 graphs.append(g)
         except Exception:
             ops.release_ws((id(self), "train"))
@@ -1071,6 +1081,7 @@ class SinSKITGModel(BaseModel):
         for o, c in zip(self.optimizers, counts):
             o.step_count = c   # host mirrors moved during capture; the device counters did not
         self._graphs = graphs
+        self.graph_nodes = nodes
         # the tensors the captured step writes (visuals, predictions, patch stacks): a validation test() in between rebinds these
         # attributes to ITS outputs, so every replay re-attaches the training ones (get_current_visuals / compute_metrics('train_'))
         self._graph_attrs = {k: getattr(self, k) for k in self._STEP_OUTPUTS if hasattr(self, k)}
@@ -1078,7 +1089,17 @@ class SinSKITGModel(BaseModel):
     def optimize_parameters(self, epoch=0, timing=False):
         if self.train_set is None:
             raise RuntimeError("optimize_parameters needs tactile patches in the batch (T_images)")
-        self._check_unbuilt_terms(self.opt, epoch)
+        try:
+            self._check_unbuilt_terms(self.opt, epoch)
+        except NotImplementedError:
+            # the run ends here: keep what was trained since the last periodic checkpoint (--save_epoch_freq 50 by default)
+            if not getattr(self, "_saved_before_stop", False):
+                self._saved_before_stop = True
+                try:
+                    self.save_networks("latest")
+                except OSError as e:
+                    print("could not write the 'latest' checkpoint before stopping: %s" % e, flush=True)
+            raise
         self._gscale = self.ddp.grad_scale if self.ddp is not None else 1.0
         for o in self.optimizers:
             o.sync_lr()

@@ -66,7 +66,12 @@ class ImagePool:
         if self.pool_size == 0:
             return images
         st = self._stores.get(name)
-        if st is None or tuple(st.shape[1:]) != tuple(images.shape[1:]):
+        if st is not None and tuple(st.shape[1:]) != tuple(images.shape[1:]):
+            # the reference would fail here (torch.cat of history entries of another shape, util/image_pool.py:56); a silently re-created
+            # zero store would hand all-zero "history" images to the discriminator for every slot the plan already considers filled
+            raise ValueError("ImagePool: store '%s' holds images of shape %s, the batch has %s -- a history pool cannot change its image "
+                             "shape (create a new ImagePool)" % (name, tuple(st.shape[1:]), tuple(images.shape[1:])))
+        if st is None:
             st = self._stores[name] = torch.zeros((self.pool_size,) + tuple(images.shape[1:]), dtype=torch.float32, device=images.device)
         if out is None:
             out = torch.empty_like(images)

@@ -722,18 +722,18 @@ def _bn_map(*step_lists):
     return bn_of
 
 
-def _seq_backward(steps, g, sq, bn_of, lo=0, hi=None):
+def _seq_backward(steps, g, sq, bn_of, start=0, stop=None):
     """backward of one segment: g = gradient w.r.t. its output (the pre-tanh output for a final conv7, else w.r.t. the
     raw output of its last conv / the identity output of its last block).  Writes the parameters' .grad (overwrite;
     through the side queue sq) and returns the gradient w.r.t. the segment's input (None for a network input).
-    lo / hi: only steps[lo:hi] (the stages of resnet_backward_stage)."""
+    start / stop: only steps[start:stop] (the stages of resnet_backward_stage)."""
     dev = g.device
     through_norm_relu = _through_norm_relu
 
     def producer_bn(a):
         return bn_of.get(id(a))
 
-    for st in reversed(steps[lo:hi]):
+    for st in reversed(steps[start:stop]):
         kind = st[0]
         if kind == "conv7_out":
             _, conv, p, src_act, _, _ = st
@@ -748,7 +748,7 @@ def _seq_backward(steps, g, sq, bn_of, lo=0, hi=None):
             sq.run(lambda: ops.wgradk(g, p, conv.weight.grad, pad=0), g)  # network input: no gradient needed below
         elif kind == "conv3":
             _, conv, inp, inp_act, a, bn, stride, xp = st
-            hi = inp if isinstance(inp, Act) else Act(inp)
+            hi_act = inp if isinstance(inp, Act) else Act(inp)
             t = inp.data if isinstance(inp, Act) else inp
             din = torch.empty_like(t)
             if xp is not None:     # wide layer
@@ -760,19 +760,19 @@ def _seq_backward(steps, g, sq, bn_of, lo=0, hi=None):
                 else:
                     ops.tconv3x3s2_wide(ops.pad_affine(g, (0, 1, 0, 1), 0), ops.w3x3_pack(conv.weight, "conv_s2_adj"), None, din)
             elif stride == 1:
-                sq.run(lambda: ops.wgradk(g, hi, conv.weight.grad, pad=1, act_hi=inp_act), g)
+                sq.run(lambda: ops.wgradk(g, hi_act, conv.weight.grad, pad=1, act_hi=inp_act), g)
                 ops.convk_bwd_data(g, conv.weight, din, pad=1)
             else:
                 co, ci = conv.weight.shape[:2]
                 dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
-                sq.run(lambda: (ops.wgrad4x4(g, hi, dw4, stride=2, pad=1, act_hi=inp_act, defer=False), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
+                sq.run(lambda: (ops.wgrad4x4(g, hi_act, dw4, stride=2, pad=1, act_hi=inp_act, defer=False), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
                 w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
                 ops.conv4x4(g, w4, 16, ci * 16, ci, din, stride=2, pad=1, transposed=True)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din
         elif kind == "convT3":
             _, conv, inp, inp_act, a, bn, z = st
             ci, co = conv.weight.shape[:2]
-            lo = inp if isinstance(inp, Act) else Act(inp)
+            lo_act = inp if isinstance(inp, Act) else Act(inp)
             t = inp.data if isinstance(inp, Act) else inp
             din = torch.empty_like(t)
             if z is not None:      # wide layer
@@ -781,7 +781,7 @@ def _seq_backward(steps, g, sq, bn_of, lo=0, hi=None):
                 ops.conv3x3s2_wide(gp, ops.w3x3_pack(conv.weight, "convT_adj"), None, din)
             else:
                 dw4 = ops._w4_scratch(conv.weight.grad, 3, "grad")[0]
-                sq.run(lambda: (ops.wgrad4x4(lo, g, dw4, stride=2, pad=1, act_lo=inp_act, defer=False), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
+                sq.run(lambda: (ops.wgrad4x4(lo_act, g, dw4, stride=2, pad=1, act_lo=inp_act, defer=False), ops.tap_extract(dw4, 3, 0, 0, conv.weight.grad)), g)
                 w4 = ops.tap_embed(conv.weight, 3, 0, 0, ops._w4_scratch(conv.weight, 3, "fwd")[0])
                 ops.conv4x4(g, w4, co * 16, 16, ci, din, stride=2, pad=1)
             g = through_norm_relu(din, inp, producer_bn(inp)) if inp_act == RELU else din

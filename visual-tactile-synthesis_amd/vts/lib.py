@@ -101,7 +101,7 @@ _lib = None
 
 # every symbol include/vts.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
-    "vts_last_error", "vts_last_kernel", "vts_version", "vts_conv4x4", "vts_conv4x4_in", "vts_conv4x4_norm", "vts_conv4x4_norm_ws_floats", "vts_norm_stats_from_partials", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_wgrad_reduce_batch", "vts_channel_sum",
+    "vts_last_error", "vts_last_kernel", "vts_version", "vts_capture_node_count", "vts_conv4x4", "vts_conv4x4_in", "vts_conv4x4_norm", "vts_conv4x4_norm_ws_floats", "vts_norm_stats_from_partials", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_wgrad_reduce_batch", "vts_channel_sum",
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
     "vts_g_post", "vts_diffaug_bs_mask", "vts_diffaug_op", "vts_diffaug_op_ws_floats", "vts_g_out_grad", "vts_pool_query", "vts_mask_mul", "vts_input_images_u8", "vts_spe_grid", "vts_mask_candidates",

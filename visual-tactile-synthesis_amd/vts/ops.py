@@ -1048,6 +1048,13 @@ def loss_slots(n, device):
     return torch.zeros(n, dtype=torch.int64, device=device)
 
 
+def capture_node_count():
+    """(nodes, kernel nodes) of the graph the current stream is capturing into, (0, 0) outside a capture"""
+    n, k = C.c_int(0), C.c_int(0)
+    L.check(L.load().vts_capture_node_count(L.stream(), C.byref(n), C.byref(k)), "vts_capture_node_count")
+    return n.value, k.value
+
+
 def step_begin(slots, counters):
     """zero the loss slots and advance the optimisers' device step counters (one launch)"""
     BSUMS.clear()      # epilogue sums nobody consumed (a backward that raised) must not outlive their step
@@ -1099,10 +1106,17 @@ def g_post(g_out, M, scale_nz, rb=None, rs=None, fake_I=None, fake_T=None, fake_
     """stack_S / stack_M: 1-channel slices of the full-resolution D2 stack that also receive the sketch S and the mask"""
     lib = L.load()
     n, _, h, w = g_out.shape
+    # both slices belong to the same stack tensor: its batch stride comes from whichever is present (with --use_cGAN_G2_S False
+    # only the mask slice exists; taking the stride from stack_S alone wrote every sample's mask into sample 0)
+    present = [t for t in (stack_S, stack_M) if t is not None]
+    if len(present) == 2 and stack_S.stride(0) != stack_M.stride(0):
+        raise ValueError("g_post: stack_S and stack_M must be slices of one stack tensor (batch strides %d / %d)"
+                         % (stack_S.stride(0), stack_M.stride(0)))
+    stack_ns = present[0].stride(0) if present else 0
     L.check(lib.vts_g_post_stack(g_out.data_ptr(), M.data_ptr(), n, h, w, scale_nz, L.ptr(rb), L.ptr(rs), L.ptr(fake_I), L.ptr(fake_T),
                                  0 if fake_T is None else fake_T.stride(0), L.ptr(fake_N), L.ptr(aug_fake_I),
                                  0 if aug_fake_I is None else aug_fake_I.stride(0), L.ptr(S), L.ptr(stack_S), L.ptr(stack_M),
-                                 0 if stack_S is None else stack_S.stride(0), L.stream()), "vts_g_post")
+                                 stack_ns, L.stream()), "vts_g_post")
 
 
 def patch_jobs(jobs, size=32):
