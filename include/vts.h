@@ -681,7 +681,10 @@ int vts_unet_forward(const vts_unet_desc* d, float* ws, int64_t ws_floats, void*
  *   vts_comm_init             ncclCommInitRank on the CURRENT device; creates the side stream
  *   vts_allreduce_flat_async  in place, ordered behind everything enqueued on `producer_stream` so far
  *   vts_allreduce_flat_wait   `consumer_stream` waits for the last async call of this communicator
- *   vts_comm_destroy */
+ *   vts_comm_destroy
+ *   vts_allreduce_slice_plan  host arithmetic only: the slice [offset, offset + chunk) rank `rank` reduces and the remainder
+ *                             [tail_offset, tail_offset + tail) all ranks all-reduce; what vts_allreduce_flat_async itself uses */
+int vts_allreduce_slice_plan(int64_t n, int world, int rank, int64_t* offset, int64_t* chunk, int64_t* tail_offset, int64_t* tail);
 int vts_comm_unique_id(void* id128);
 int vts_comm_init(const void* id128, int rank, int world, void** comm);
 int vts_allreduce_flat_async(void* comm, float* buf, int64_t n, void* producer_stream);

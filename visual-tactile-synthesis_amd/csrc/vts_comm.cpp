@@ -117,6 +117,19 @@ extern "C" int vts_comm_init(const void* id128, int rank, int world, void** comm
   return VTS_OK;
 }
 
+// Which elements of an n-element bucket rank `rank` of `world` reduces: its slice [offset, offset + chunk) of the reduce-scatter and the
+// [tail_offset, tail_offset + tail) remainder every rank all-reduces.  Host arithmetic only (no GPU, no RCCL): vts_allreduce_flat_async
+// takes its offsets from here, and the CPU tests replay the same plan over gloo at world sizes the test box has no GPUs for.
+extern "C" int vts_allreduce_slice_plan(int64_t n, int world, int rank, int64_t* offset, int64_t* chunk, int64_t* tail_offset, int64_t* tail) {
+  VTS_CHECK_ARG(offset && chunk && tail_offset && tail, "vts_allreduce_slice_plan: null pointer");
+  VTS_CHECK_ARG(n >= 1 && world >= 1 && rank >= 0 && rank < world, "vts_allreduce_slice_plan: bad arguments (n %lld, rank %d of %d)", (long long)n, rank, world);
+  *chunk = n / world;
+  *offset = (int64_t)rank * *chunk;
+  *tail_offset = *chunk * world;
+  *tail = n - *tail_offset;
+  return VTS_OK;
+}
+
 // buf[0 .. n) <- sum over ranks, in place, on the communicator's side stream: the side stream first waits for everything enqueued on
 // `producer_stream` so far (the backward that filled the bucket).  Rank r reduces slice r of `chunk = n / world` elements
 // (ncclReduceScatter in place: recvbuff = sendbuff + r * chunk), all slices are gathered back (ncclAllGather in place); the
@@ -129,12 +142,13 @@ extern "C" int vts_allreduce_flat_async(void* comm, float* buf, int64_t n, void*
     vts_set_error("vts_allreduce_flat_async: stream ordering failed");
     return VTS_ERR_LAUNCH;
   }
-  const int64_t chunk = n / c->world, tail = n - chunk * c->world;
+  int64_t off = 0, chunk = 0, tail_off = 0, tail = 0;
+  if (vts_allreduce_slice_plan(n, c->world, c->rank, &off, &chunk, &tail_off, &tail) != VTS_OK) return VTS_ERR_ARG;
   if (chunk > 0) {
-    RCCL_CHECK(R->ReduceScatter(buf, buf + (int64_t)c->rank * chunk, (size_t)chunk, ncclFloat_, ncclSum_, c->comm, c->side), "ncclReduceScatter");
-    RCCL_CHECK(R->AllGather(buf + (int64_t)c->rank * chunk, buf, (size_t)chunk, ncclFloat_, c->comm, c->side), "ncclAllGather");
+    RCCL_CHECK(R->ReduceScatter(buf, buf + off, (size_t)chunk, ncclFloat_, ncclSum_, c->comm, c->side), "ncclReduceScatter");
+    RCCL_CHECK(R->AllGather(buf + off, buf, (size_t)chunk, ncclFloat_, c->comm, c->side), "ncclAllGather");
   }
-  if (tail > 0) RCCL_CHECK(R->AllReduce(buf + chunk * c->world, buf + chunk * c->world, (size_t)tail, ncclFloat_, ncclSum_, c->comm, c->side), "ncclAllReduce (tail)");
+  if (tail > 0) RCCL_CHECK(R->AllReduce(buf + tail_off, buf + tail_off, (size_t)tail, ncclFloat_, ncclSum_, c->comm, c->side), "ncclAllReduce (tail)");
   if (hipEventRecord(c->done, c->side) != hipSuccess) {
     vts_set_error("vts_allreduce_flat_async: event record failed");
     return VTS_ERR_LAUNCH;

@@ -82,6 +82,18 @@ def direct_comm():
     return _comm
 
 
+def slice_plan(n, world, rank):
+    """(offset, chunk, tail_offset, tail) of the direct collective for an n-element bucket: rank `rank` reduces [offset, offset + chunk),
+    everyone all-reduces the remainder [tail_offset, tail_offset + tail).  The C library's own arithmetic (vts_allreduce_slice_plan:
+    host only, no GPU), so that CPU tests can replay the plan over gloo at world sizes no test box has GPUs for."""
+    import ctypes as C
+
+    from . import lib as L
+    o, c, to, t = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    L.check(L.load().vts_allreduce_slice_plan(int(n), int(world), int(rank), C.byref(o), C.byref(c), C.byref(to), C.byref(t)), "vts_allreduce_slice_plan")
+    return o.value, c.value, to.value, t.value
+
+
 class GradBucket:
     """Asynchronous all-reduce of one flat gradient buffer."""
 

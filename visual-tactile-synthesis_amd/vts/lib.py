@@ -110,7 +110,7 @@ SYMBOLS = [
     "vts_mask_select", "vts_mask_sample_ranks", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
     "vts_maxpool2_relu_pad", "vts_maxpool3s2_relu_pad", "vts_s2d4_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
     "vts_patch_jobs", "vts_g_post_stack", "vts_step_begin", "vts_conv4x4_bsums", "vts_norm_bwd_from_partials",
-    "vts_u8_expand", "vts_unet_forward", "vts_unet_forward_ws_floats", "vts_comm_unique_id", "vts_comm_init", "vts_allreduce_flat_async", "vts_allreduce_flat_wait", "vts_comm_destroy",
+    "vts_u8_expand", "vts_unet_forward", "vts_unet_forward_ws_floats", "vts_allreduce_slice_plan", "vts_comm_unique_id", "vts_comm_init", "vts_allreduce_flat_async", "vts_allreduce_flat_wait", "vts_comm_destroy",
 ]
 
 
@@ -237,7 +237,7 @@ def load():
         "vts_zero_border": [vp, i64, i, i, i, vp],
         "vts_maxpool3s2_relu_pad": [vp, i, i, i, i, vp, vp],
         "vts_u8_expand": [vp, i64, i, vp, vp], "vts_unet_forward": [C.POINTER(UnetDesc), vp, i64, vp], "vts_comm_unique_id": [vp], "vts_comm_init": [vp, i, i, vp], "vts_allreduce_flat_async": [vp, vp, i64, vp],
-        "vts_allreduce_flat_wait": [vp, vp], "vts_comm_destroy": [vp],
+        "vts_allreduce_flat_wait": [vp, vp], "vts_comm_destroy": [vp], "vts_allreduce_slice_plan": [i64, i, i, vp, vp, vp, vp],
         "vts_s2d4_pad": [vp, i, i, i, i, i, i, i, vp, vp],
         "vts_maxpool2_relu_bwd": [vp, vp, i, i, i, vp, i, vp, i, vp],
         "vts_relu_mask_pad": [vp, vp, vp, i, i, i, i, vp, i, vp],
