@@ -1281,6 +1281,68 @@ def golden_step(size=256, seed=202, steps=2, nt=64):
     print({k: float(v) for k, v in losses.items()})
 
 
+FULL_GRAD_LAYERS = ("down4", "down5", "down6", "down7", "up7", "up6", "up5", "up4")
+
+
+def golden_step_full_grads(size=256, seed=202, nt=64):
+    """Step 0 of golden_step() once more, twice: the REFERENCE in its own fp32 and the same reference code in float64 (default dtype
+    float64, every network / input cast) -> tests/golden/sinskitG_step_grads_256.npz:
+      * g64/<key>: the float64 gradient (stored rounded to fp32) of every convolution weight of the generator (1.46 M values, of which
+        the inner layers down4 ... up4 -- `layers` -- hold 1.1 M): the HIP step is judged against these by TRUE relative L2
+        (tests/test_step_gpu.py);
+      * ref32_vs_64/<key>: relative L2 distance between the reference's fp32 gradient and its float64 gradient for EVERY generator
+        tensor -- how far the reference's own CPU path is from exact arithmetic (down0 ... down2: ~5e-3);
+      * g32_probe/<key>: the probes of the fp32 run (equal to sinskitG_step_256.npz: the two files belong to one run).
+    The generator's gradient does not depend on the DiffAugment draws (its loss is the D1 term on the un-augmented image plus the L1
+    terms, sinskitG_model.py:1671-1716), which is why the float64 run's different random stream does not matter here."""
+    from oracle import detrand, nets, ref_import
+
+    ref_import.load()
+    from models.sinskitG_model import SinSKITGModel
+
+    flags = ["--lambda_G1_lpips", "0", "--lambda_G2_lpips", "0", "--use_vision_aided_loss", "False",
+             "--lambda_G2_GAN_feat", "0", "--checkpoints_dir", "/tmp/vts_golden_ckpt", "--name", "golden"]
+
+    def run(dtype):
+        torch.set_default_dtype(dtype)
+        try:
+            opt = _ref_opt("sinskitG", True, flags)
+            model = SinSKITGModel(opt)
+            model.setup(opt)
+            cast = lambda sd: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}      # noqa: E731
+            model.netG.load_state_dict(cast(detrand.test_weights(nets.g_param_shapes(), seed)))
+            model.netD.load_state_dict(cast(detrand.test_weights(nets.d_param_shapes(4), seed + 1)))
+            model.netD2.load_state_dict(cast(detrand.test_weights(nets.d_param_shapes(7), seed + 2)))
+            for net in (model.netG, model.netD, model.netD2):
+                net.to(dtype)
+            model.train()
+            batch = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in _synthetic_batch(size, nt, seed).items()}
+            model.set_input(batch, phase="train")
+            torch.manual_seed(seed)
+            random.seed(seed)
+            model.optimize_parameters(epoch=1)
+            assert model.fake_I.dtype == dtype and next(model.netG.parameters()).grad.dtype == dtype
+            return ({k: p.grad.detach().clone() for k, p in model.netG.named_parameters()},
+                    {k: float(v) for k, v in model.get_current_losses().items()})
+        finally:
+            torch.set_default_dtype(torch.float32)
+
+    g32, l32 = run(torch.float32)
+    g64, l64 = run(torch.float64)
+    out = {"size": size, "seed": seed, "nt": nt, "layers": np.array(FULL_GRAD_LAYERS),
+           "loss_names": np.array(list(l32)), "loss32": np.array(list(l32.values())), "loss64": np.array([l64[k] for k in l32])}
+    for k in g32:
+        out["ref32_vs_64/" + k] = ((g32[k].double() - g64[k]).norm() / g64[k].norm().clamp_min(1e-300)).item()
+        out["g32_probe/" + k] = detrand.probe(g32[k], k)
+        if k.endswith("weight"):
+            out["g64/" + k] = g64[k].float().numpy()
+    np.savez_compressed(os.path.join(GOLD, "sinskitG_step_grads_%d.npz" % size), **out)
+    print("wrote sinskitG_step_grads_%d.npz" % size)
+    for k in g32:
+        if k.endswith("weight"):
+            print("  %-24s reference fp32 vs float64: %.3e" % (k, out["ref32_vs_64/" + k]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
@@ -1346,3 +1408,5 @@ if __name__ == "__main__":
         golden_diffaug()
     if "variants" in which:
         golden_step_variants()
+    if "fullgrads" in which:
+        golden_step_full_grads()

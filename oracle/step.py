@@ -46,17 +46,23 @@ def hp(**kw):
     return SimpleNamespace(**d)
 
 
+def _f(t):
+    """to the working precision: fp32 (the reference's), or float64 when a test evaluates the oracle under torch.set_default_dtype(float64)
+    to judge fp32 results (the HIP path's and this oracle's own) against exact arithmetic"""
+    return t.to(torch.get_default_dtype())
+
+
 def prepare_input(batch):
     """set_input: mask multiply, SPE, patch reshape."""
-    S = batch["S"].float()
-    M = batch["M"].float()
-    I = batch["I"].float()
+    S = _f(batch["S"])
+    M = _f(batch["M"])
+    I = _f(batch["I"])
     n, _, h, w = S.shape
     real_S = S * M
     real_I = I * M
-    S_pe = nets.spe_grid(n, h, w, 4)
-    T = torch.as_tensor(batch["T_images"]).float()
-    K = torch.as_tensor(batch["I_masks"]).float()
+    S_pe = _f(nets.spe_grid(n, h, w, 4))      # (evaluated in fp32 like the reference's buffer, then an INPUT at the working precision)
+    T = _f(torch.as_tensor(batch["T_images"]))
+    K = _f(torch.as_tensor(batch["I_masks"]))
     nt = T.shape[1]
     masks = K.reshape(-1, 1, 32, 32)
     real_T = T.reshape(-1, 2, 32, 32) * masks
@@ -163,7 +169,7 @@ def train_step(sdG, sdD, sdD2, adam, batch, draws, opt=None, style_code=None, re
         aug_real_I = nets.diffaug(inp.real_I, pol, draws["aug_policy"][0]) * inp.M
         aug_fake_I = nets.diffaug(fake_I, pol, draws["aug_policy"][1]) * inp.M
     elif opt.use_diffaug:
-        aug = draws["aug"].float()
+        aug = _f(draws["aug"])
         aug_real_I = nets.diffaug_bs(inp.real_I, aug[0], aug[1]) * inp.M
         aug_fake_I = nets.diffaug_bs(fake_I, aug[2], aug[3]) * inp.M
     else:

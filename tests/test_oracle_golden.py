@@ -380,6 +380,30 @@ def _variant_draws(g, name, opt, seed, vi, size):
     return draws
 
 
+def test_train_step_generator_gradients_against_the_reference_in_float64(golden_dir):
+    """tests/golden/sinskitG_step_grads_256.npz holds the gradient of every generator weight from the REFERENCE run in float64, and how far
+    the reference's own fp32 run is from it (`ref32_vs_64`: 5e-3 .. 6e-3 on down0 ... down2 -- PyTorch-CPU's fp32 weight gradient over
+    128^2 .. 32^2 pixel maps --, <= 2e-5 elsewhere).  The oracle (fp32, the same PyTorch-CPU arithmetic) must sit at the reference's
+    fp32 distance, not further: true relative L2 per tensor <= 3x the reference's own distance (floor 1e-4)."""
+    g = _load(golden_dir, "sinskitG_step_grads_256.npz")
+    s = _load(golden_dir, "sinskitG_step_256.npz")
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    assert (size, seed, nt) == (int(s["size"]), int(s["seed"]), int(s["nt"]))
+    for k in (f for f in g.files if f.startswith("g32_probe/")):          # the two fixtures describe the same fp32 run of the reference
+        np.testing.assert_allclose(g[k], s["s0/grad_G/" + k[len("g32_probe/"):]], rtol=1e-6, atol=1e-9)
+    sdG, sdD, sdD2 = (detrand.test_weights(nets.g_param_shapes(), seed), detrand.test_weights(nets.d_param_shapes(4), seed + 1),
+                      detrand.test_weights(nets.d_param_shapes(7), seed + 2))
+    adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    draws = {"aug": torch.from_numpy(s["s0/aug"]), "more_idx": torch.from_numpy(s["s0/more_idx"])}
+    out = step.train_step(sdG, sdD, sdD2, adam, _batch(size, nt, seed), draws)
+    keys = [f[len("g64/"):] for f in g.files if f.startswith("g64/")]
+    assert len(keys) == 20 and {str(l) for l in g["layers"]} <= {k.split(".")[0] for k in keys}
+    for k in keys:
+        ref64 = torch.from_numpy(g["g64/" + k]).double()
+        err = ((out["grad_G"][k].double() - ref64).norm() / ref64.norm()).item()
+        assert err <= max(1e-4, 3.0 * float(g["ref32_vs_64/" + k])), (k, err, float(g["ref32_vs_64/" + k]))
+
+
 def test_train_step_variants_match_reference(golden_dir):
     """PatchGAN depths 2 / 4 (n_layers_D, n_layers_D2), hinge, and the six-letter DiffAugment policy: one reference step each"""
     g = _load(golden_dir, "sinskitG_variants_step_256.npz")

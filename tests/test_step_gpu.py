@@ -20,7 +20,40 @@ pytestmark = pytest.mark.gpu
 # gradient comparisons against the oracle: every (relative L2 error, network, parameter) is recorded, the worst one is printed at the
 # end of the module (pytest -s) and the bound is ~2x the worst value observed on the MI355X (round 4: see the fixture below)
 GRAD_WORST = []
-GRAD_TOL = 2e-3       # observed worst on the MI355X (round 4): 1.27e-3 (G down5.model.1.weight against the reference's own fp32 CPU run)
+# north_star's 1e-3 on EVERY gradient tensor, by true relative L2.  Two judges: the oracle evaluated in FLOAT64 (oracle/step.py runs at
+# torch's default dtype) and the fp32 CPU oracle.  Almost every tensor is within 1e-4 of float64.  The exceptions are not rounding noise
+# but KINKS: a LeakyReLU / ReLU pre-activation within rounding distance of zero falls on different sides in fp32 and float64, which
+# changes one element of the gradient map by a factor of 5 (or switches it off) -- 2e-3 .. 1e-2 of the tensor's norm on the 34 x 34 .. 129 x 129
+# discriminator maps, carried down to every layer below (measured: tools/probes are not needed, `ref32 vs f64` in the report below shows
+# it for the CPU oracle alone: 5.2e-3 on D layer2.* at batch 2, 1e-3 .. 2.5e-3 on D2 layer2.* in the second step, 1.5e-3 on G up3).
+# The gradient is discontinuous there, so neither side is "the" answer: such a tensor must then agree within 1e-3 with the fp32 CPU
+# oracle, which took the same side as the device.  (Rounds 4 / 5 compared with the fp32 oracle only, at 2e-3, worst 1.27e-3.)
+GRAD_TOL = 1e-3
+
+
+def f64_state(sds, adam=None):
+    """deep copies of state dicts (and Adam states) in float64"""
+    out = [{k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()} for sd in sds]
+    if adam is None:
+        return out
+    a64 = {nm: {"step": st["step"], "m": {k: v.clone().double() for k, v in st["m"].items()}, "v": {k: v.clone().double() for k, v in st["v"].items()}}
+           for nm, st in adam.items()}
+    return out, a64
+
+
+def train_step_f64(sds64, adam64, batch, draws, **kw):
+    """oracle.step.train_step in float64 (the judge of both fp32 results)"""
+    torch.set_default_dtype(torch.float64)
+    try:
+        return step.train_step(sds64[0], sds64[1], sds64[2], adam64, batch, draws, **kw)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def check_grad(p_grad, ref32, ref64, nm, k):
+    e64, e32, e_cpu = rel(p_grad, ref64), rel(p_grad, ref32), rel(ref32, ref64)
+    GRAD_WORST.append((min(e64, e32), nm, k, e64, e32, e_cpu))
+    assert min(e64, e32) < GRAD_TOL, (nm, k, "HIP vs float64 %.3e" % e64, "HIP vs fp32 CPU %.3e" % e32, "fp32 CPU vs float64 %.3e" % e_cpu)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -28,7 +61,13 @@ def _report_worst_gradient():
     yield
     if GRAD_WORST:
         w = max(GRAD_WORST)
-        print("\n[%s] worst gradient rel-L2 vs the oracle over %d comparisons: %.3e (%s %s), bound %.1e" % (__name__, len(GRAD_WORST), w[0], w[1], w[2], GRAD_TOL))
+        smooth = [g for g in GRAD_WORST if g[5] < GRAD_TOL]            # tensors where fp32 CPU and float64 are on the same side of every kink
+        kinks = [g for g in GRAD_WORST if g[5] >= GRAD_TOL]
+        print("\n[%s] %d gradient tensors, bound %.1e.  Worst distance to the nearer judge: %.3e (%s %s).  Worst HIP vs float64 where the "
+              "fp32 CPU oracle agrees with float64: %.3e.  Tensors with a kink between fp32 and float64 (fp32 CPU vs float64 >= bound): %d, "
+              "there HIP vs fp32 CPU at most %.3e: %s"
+              % (__name__, len(GRAD_WORST), GRAD_TOL, w[0], w[1], w[2], max(g[3] for g in smooth) if smooth else 0.0, len(kinks),
+                 max(g[4] for g in kinks) if kinks else 0.0, [(g[1], g[2], "cpu32|f64 %.1e" % g[5]) for g in kinks]))
 
 from oracle import detrand, nets, step  # noqa: E402  (checker only)
 
@@ -118,6 +157,35 @@ def test_step_matches_reference_golden(golden_dir):
                     assert rel(b, refb) < tol, k
                 else:
                     assert int(b) == int(refb), k
+
+
+def test_generator_gradients_against_the_reference_in_float64(golden_dir):
+    """Every generator weight gradient of the reference step by TRUE relative L2 (not probes), against the reference run in FLOAT64
+    (tests/golden/sinskitG_step_grads_256.npz, oracle/make_golden.py:golden_step_full_grads).  Bound: north_star's 1e-3 on every tensor.
+    The fixture also records how far the reference's OWN fp32 CPU run is from its float64 run (`ref32_vs_64`): 5e-3 .. 6e-3 on
+    down0 ... down2 -- so a comparison against the fp32 reference cannot hold 1e-3 there whatever the device computes; the probes of
+    test_step_matches_reference_golden pass at 2e-3 only because a norm and one projection do not see most of that difference."""
+    from data.synthetic_dataset import make_sample
+
+    g = np.load(os.path.join(golden_dir, "sinskitG_step_grads_256.npz"))
+    s = np.load(os.path.join(golden_dir, "sinskitG_step_256.npz"))
+    size, seed, nt = int(g["size"]), int(g["seed"]), int(g["nt"])
+    model, opt = make_model(size, 1)
+    load_test_weights(model, seed)
+    model._draws = {"aug": torch.from_numpy(s["s0/aug"]), "more_idx": torch.from_numpy(s["s0/more_idx"])}
+    model.set_input(default_collate([make_sample(size, nt, nt, seed)]), phase="train")
+    model.optimize_parameters(epoch=1)
+    grads = dict(model.netG.named_parameters())
+    keys = [f[len("g64/"):] for f in g.files if f.startswith("g64/")]
+    assert len(keys) == 20
+    rows = []
+    for k in keys:
+        err = rel(grads[k].grad, torch.from_numpy(g["g64/" + k]))
+        rows.append((err, float(g["ref32_vs_64/" + k]), k))
+        assert err < 1e-3, (k, err)
+    worst = max(rows)
+    print("\n[generator gradients vs the float64 reference] worst %.3e (%s; the reference's own fp32 run: %.3e); tensors where the HIP step is "
+          "closer to float64 than the reference's fp32 run: %d of %d" % (worst[0], worst[2], worst[1], sum(e <= r for e, r, _ in rows), len(rows)))
 
 
 def test_step_conditioning_ablations_match_reference_golden(golden_dir):
@@ -266,7 +334,9 @@ def test_second_step_from_synced_state(golden_dir):
         net.load_state_dict({k: v.detach() for k, v in sd.items()})
         optim.load_named_state(net, adam[nm]["m"], adam[nm]["v"], adam[nm]["step"])
     d1 = {"aug": torch.from_numpy(g["s1/aug"]), "more_idx": torch.from_numpy(g["s1/more_idx"])}
+    sds64, adam64 = f64_state(sds, adam)                      # the same state, for the float64 evaluation of step 2
     ref = step.train_step(sds[0], sds[1], sds[2], adam, batch, d1)
+    ref64 = train_step_f64(sds64, adam64, batch, d1)
     model._draws = d1
     model.set_input(batch, phase="train")
     model.optimize_parameters(epoch=1)
@@ -278,8 +348,7 @@ def test_second_step_from_synced_state(golden_dir):
         for k, p in net.named_parameters():
             if null_grad_bias(nm, k):
                 continue
-            GRAD_WORST.append((rel(p.grad, ref["grad_" + nm][k]), nm, k))
-            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
+            check_grad(p.grad, ref["grad_" + nm][k], ref64["grad_" + nm][k], nm, k)
             assert rel(p.data, sd[k]) < 1e-3, (nm, k)
 
 
@@ -296,6 +365,8 @@ def test_step_batch2_matches_oracle():
     draws = {"aug": detrand.uniform((4, n), 3, "aug") * 0.5 + 0.5,
              "more_idx": torch.tensor([random.sample(range(c), 32) for c in counts])}
     adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    sds64 = f64_state((sdG, sdD, sdD2))
+    ref64 = train_step_f64(sds64, {k: step.new_adam_state() for k in ("G", "D", "D2")}, batch, draws)
     ref = step.train_step(sdG, sdD, sdD2, adam, batch, draws)
     model._draws = draws
     model.set_input(batch, phase="train")
@@ -308,8 +379,7 @@ def test_step_batch2_matches_oracle():
         for k, p in net.named_parameters():
             if null_grad_bias(nm, k):
                 continue
-            GRAD_WORST.append((rel(p.grad, ref["grad_" + nm][k]), nm, k))
-            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
+            check_grad(p.grad, ref["grad_" + nm][k], ref64["grad_" + nm][k], nm, k)
             # beta1 = 0: the first Adam update is ~lr*sign(g); elements whose gradient is rounding noise may
             # move by 2*lr either way, so post-step weights are compared at 3e-3 (the gradients above at 2e-3)
             assert rel(p.data, sd[k]) < 3e-3, (nm, k)
@@ -354,6 +424,7 @@ def test_step_batch2_conditioning_ablations_match_oracle(name):
     oopt = step.hp()
     for k, v in zip(extra[::2], extra[1::2]):
         setattr(oopt, k.lstrip("-"), v == "True")
+    ref64 = train_step_f64(f64_state((sdG, sdD, sdD2)), {k: step.new_adam_state() for k in ("G", "D", "D2")}, batch, draws, opt=oopt)
     ref = step.train_step(sdG, sdD, sdD2, adam, batch, draws, opt=oopt)
     model._draws = draws
     model.set_input(batch, phase="train")
@@ -367,7 +438,7 @@ def test_step_batch2_conditioning_ablations_match_oracle(name):
         for k, p in net.named_parameters():
             if null_grad_bias(nm, k):
                 continue
-            assert rel(p.grad, ref["grad_" + nm][k]) < GRAD_TOL, (nm, k)
+            check_grad(p.grad, ref["grad_" + nm][k], ref64["grad_" + nm][k], nm, k)
         for k, b in net.named_buffers():
             if k.endswith("running_mean"):
                 scale = float(sd[k.replace("running_mean", "running_var")].max().sqrt())
@@ -605,6 +676,7 @@ def test_step_on_a_singleskit_dataset_batch_matches_oracle(tmp_path):
     cnt = int(nets.dilated_mask_positions(batch["M"].float()).shape[0])
     draws = {"aug": detrand.uniform((4, 1), 5, "aug") * 0.5 + 0.5, "more_idx": torch.tensor([random.sample(range(cnt), 32)])}
     adam = {k: step.new_adam_state() for k in ("G", "D", "D2")}
+    ref64 = train_step_f64(f64_state(sds), {k: step.new_adam_state() for k in ("G", "D", "D2")}, batch, draws, opt=step.hp(batch_size_G2=nt))
     ref = step.train_step(sds[0], sds[1], sds[2], adam, batch, draws, opt=step.hp(batch_size_G2=nt))
     model._draws = draws
     model.set_input(batch, phase="train")
@@ -620,8 +692,7 @@ def test_step_on_a_singleskit_dataset_batch_matches_oracle(tmp_path):
         for k, gr in ref["grad_" + nm].items():
             if null_grad_bias(nm, k):
                 continue
-            GRAD_WORST.append((rel(named[k].grad, gr), nm, k))
-            assert GRAD_WORST[-1][0] < GRAD_TOL, GRAD_WORST[-1]
+            check_grad(named[k].grad, gr, ref64["grad_" + nm][k], nm, k)
 
 
 def test_eval_metrics_match_oracle():
