@@ -512,6 +512,51 @@ def test_hip_graph_replay_equals_eager():
     assert rel(graph.fake_I, eager.fake_I) < 1e-6
 
 
+def test_discriminator_chains_equal_the_joined_schedule_bit_for_bit(monkeypatch):
+    """engine.msd_chain (per-discriminator chains: update -> Adam -> its passes of the generator step, no join between D1 and D2; input
+    pyramids pooled inside the lanes) launches exactly the kernels of the joined schedule (msd_multi per stage, pyramids pooled up front)
+    on the same operands in the same per-tensor order: four steps -- eager, capture, two replays -- end in bit-identical weights, Adam
+    moments, BatchNorm buffers and logged losses."""
+    import random
+
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+    from vts import engine
+
+    size, n, seed = 256, 2, 58
+    batches = [default_collate([make_sample(size, 64, 64, seed + 10 * s + i) for i in range(n)]) for s in range(2)]
+    res = {}
+    for chains in (True, False):
+        monkeypatch.setattr(engine, "D_CHAINS", chains)
+        monkeypatch.setattr(engine, "LAZY_PYRAMID", chains)
+        opt = TrainOptions(cmd_line=(FLAGS % (size, n)) + " --use_hip_graph True").parse()
+        m = create_model(opt)
+        m.setup(opt)
+        m.parallelize()
+        m.train()
+        load_test_weights(m, seed)
+        random.seed(12)
+        torch.manual_seed(12)
+        for b in batches + batches:
+            m.set_input(b, phase="train")
+            m.optimize_parameters(epoch=1)
+        torch.cuda.synchronize()
+        assert m._graphs is not None
+        res[chains] = dict(flat={nm: getattr(m, "flat" + nm).flat.clone() for nm in ("G", "D", "D2")},
+                           m={nm: getattr(m, "optimizer_" + nm).m.clone() for nm in ("G", "D", "D2")},
+                           bufs={nm + "." + k: b.clone() for nm in ("D", "D2") for k, b in getattr(m, "net" + nm).named_buffers()},
+                           losses=m.get_current_losses(), nodes=sum(k for _, k in m.graph_nodes))
+    a, b = res[True], res[False]
+    for nm in ("G", "D", "D2"):
+        assert torch.equal(a["flat"][nm], b["flat"][nm]), nm
+        assert torch.equal(a["m"][nm], b["m"][nm]), nm
+    for k in a["bufs"]:
+        assert torch.equal(a["bufs"][k], b["bufs"][k]), k
+    assert a["losses"] == b["losses"]
+    assert a["nodes"] > 0 and b["nodes"] > 0
+
+
 def test_train_and_test_scripts_end_to_end(tmp_path):
     """The headless train.py / test.py entry points run against the synthetic dataset, write the
     reference checkpoint file set and loss log, and test.py reloads the generator."""

@@ -13,6 +13,9 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+from vts import engine as _engine  # noqa: E402
+
+_engine.D_CHAINS = False      # the phases below are those of the JOINED schedule (round 6's default chains the phases: no cut points between them)
 model, opt = bench.build_model(1024, batch, "skitG")
 opt.use_hip_graph = False
 data = bench.make_batch(1024, batch, 0, opt.style_code_dim)

@@ -34,6 +34,7 @@ from .base_model import BaseModel
 # 1 (default): on one GPU the generator's discriminator-free loss terms run as one more lane beside the discriminator updates; 0: serially
 # behind them (A/B timing; results are identical: the lanes only read the forward's outputs and add into their own fixed-point loss slots)
 G_PRE_LANE = tune.get("VTS_G_PRE_LANE", "1") != "0"
+D2_CHAIN = tune.get("VTS_D2_CHAIN", "lanes")      # "serial": the whole D2 chain as one lane (measurement: see _run_d_chains)
 D1_REAL_EARLY = tune.get("VTS_D1_REAL_EARLY", "1") != "0"     # D1's pass on the real images beside the generator forward (see _seg_d_updates)
 
 B = str2bool
@@ -242,6 +243,8 @@ class SinSKITGModel(BaseModel):
         self._bufs = {}         # persistent input buffers (stable addresses for captured HIP graphs)
         self._pins, self._pin_evt = {}, {}   # pinned staging buffers of pageable host inputs (see _load)
         self._graphs = None     # the captured segments of the step, or None
+        self._chained = False   # the chained single-segment schedule is in use (set by _segments)
+        self._d2_lane = None
         self._infer_graph, self._infer_eager_done = None, False   # captured inference forward (test())
         self._eager_steps_done = 0
         if tune.get("VTS_KO_LANES", None) and tune.get("VTS_KO_LANES_ACK", "") != "timing-only":
@@ -888,7 +891,13 @@ class SinSKITGModel(BaseModel):
                 self._seg_g_pre()
                 self._g_pre_done = True
         heavy = opt.lambda_G1_lpips > 0.0 or opt.lambda_G2_lpips > 0.0      # the perceptual terms: ~90 ms of VGG convolutions
-        engine.msd_multi(jobs, self.criterionGAN, extra=extra, extra_cost=90.0 if heavy else 0.1)
+        self._chains_done = False
+        if extra is not None and jobs and self._chained:
+            # single GPU: each discriminator's update, its Adam step and its passes of the generator step form ONE dependency chain
+            # (engine.msd_chain); the chains of D1 and D2 never wait for each other, and the generator's backward waits for D1's only
+            self._run_d_chains(jobs, extra)
+        else:
+            engine.msd_multi(jobs, self.criterionGAN, extra=extra, extra_cost=90.0 if heavy else 0.1)
         # (visuals: the maps as the discriminator returns them -- behind its Sigmoid where gan_mode 'vanilla' gives it one)
         if p_fake_I is not None:
             self.pred_fake_I = p_fake_I["preds"][-1][:n]
@@ -898,6 +907,74 @@ class SinSKITGModel(BaseModel):
             self.pred_fake_T_full = p_full["preds"][-1]
             if getattr(self.netD2, "use_sigmoid", False):
                 self.pred_fake_T_full = torch.sigmoid(self.pred_fake_T_full)
+
+    def _use_chains(self):
+        """single GPU, multiscale PatchGAN discriminators, no perceptual terms: the chained schedule (engine.msd_chain / fork_lane)"""
+        opt = self.opt
+        heavy = opt.lambda_G1_lpips > 0.0 or opt.lambda_G2_lpips > 0.0
+        nets = [getattr(self, "net" + n) for n in ("D", "D2") if n in self.model_names]
+        return bool(engine.D_CHAINS and G_PRE_LANE and not self._ddp_segments() and not heavy and nets
+                    and not any(getattr(net, "is_stylegan2_d", False) for net in nets)
+                    and isinstance(self.netG, networks.CustomUnetGenerator))
+
+    def _run_d_chains(self, jobs, g_pre):
+        """discriminator updates + Adam(D), Adam(D2) + the discriminator passes of the generator step (what _seg_g_main does after the
+        updates otherwise), one dependency chain per discriminator:
+          D1: its scales on the launch stream + one side stream, the generator's L1 terms beside them, Adam(D), its pass of the
+              generator step -- what the generator's backward waits for;
+          D2: its update as two lanes (scale 0 | scales 1, 2) beside the WHOLE D1 chain, joined when that chain is through; then
+              Adam(D2) and its forward of the generator step (a logged value: nothing of the step waits for it) as one lane that stays
+              open beside the generator's backward (joined in _seg_step_chained)."""
+        opt, ts, slot = self.opt, self.train_set, self._slot
+        chain_d1 = chain_d2 = None
+        for net, passes in jobs:
+            if net is self.netD:
+                def gstep_d1():
+                    lam = opt.lambda_G1_GAN
+                    in0, in1 = self._d1_pair(self.real_S, self.fake_I)
+                    g = [dict(in0=in0, in1=in1, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam, param_grads=False,
+                              input_grad=(self._d_fake_I, self._have_dI), pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False))]
+                    self._have_dI = True
+                    return g
+                chain_d1 = dict(D=net, index0=0, update=passes, mid=lambda: self.optimizer_D.step(self._gscale, bump=False), gstep=gstep_d1)
+            else:
+                # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
+                chain_d2 = dict(D=net, index0=3 if "D" in self.model_names else 0, update=passes,
+                                mid=lambda: self.optimizer_D2.step(self._gscale, bump=False),
+                                gstep=lambda: [dict(in0=self._fake_stack, real=True, coeff=opt.lambda_G2_GAN * ts["NT"], slot=slot["G2_GAN"])])
+        self._d2_lane = None
+        if chain_d2 is None or chain_d1 is None:
+            engine.msd_chain(chain_d1 or chain_d2, self.criterionGAN, side=g_pre)
+        elif D2_CHAIN == "serial":
+            # measured (round 6): the whole D2 chain as ONE lane is ~2.5 ms of dependent small launches and becomes the step's critical
+            # path (6.00 against 5.41 ms)
+            self._d2_lane = engine.fork_lane(lambda: engine.msd_chain(chain_d2, self.criterionGAN, serial=True))
+            engine.msd_chain(chain_d1, self.criterionGAN, side=g_pre)
+        else:
+            # D2's update: two lanes (scale 0 | scales 1, 2) beside the WHOLE D1 chain (update, Adam, generator-step pass); the launch
+            # stream joins them when D1's chain is through, runs Adam(D2), and D2's forward of the generator step goes on as one lane
+            # under the generator's backward
+            D2, upd = chain_d2["D"], chain_d2["update"]
+            engine._prepare_passes([(D2, upd)])
+
+            def d2_update(scales):
+                def run():
+                    with ops.deferred_wgrad():
+                        for sc in scales:
+                            engine._scale_lane(D2, sc, upd, self.criterionGAN, knocked_out=(chain_d2["index0"] + sc) in engine.KO_LANES)
+                        ops.wgrad_flush(ops.WS_LANE)
+                return run
+            spec = tune.get("VTS_D2_LANES", "")        # measurement: "0|1|2", "0,1,2", ... (default: scale 0 | the others)
+            groups = ([[int(t) for t in g.split(",")] for g in spec.split("|")] if spec else [[0], list(range(1, D2.num_D))])
+            lanes = [engine.fork_lane(d2_update(g)) for g in groups if g]
+            engine.msd_chain(chain_d1, self.criterionGAN, side=g_pre, serial=tune.get("VTS_D1_SERIAL", "0") == "1")
+            for h in reversed(lanes):
+                engine.join_lane(h)
+            engine._finish_passes([(D2, upd)])
+            chain_d2["mid"]()
+            tail = dict(chain_d2, update=[], mid=lambda: None)
+            self._d2_lane = engine.fork_lane(lambda: engine.msd_chain(tail, self.criterionGAN, serial=True))
+        self._chains_done = True
 
     def _d1_pyramid(self, rows, pool_fake):
         """input pyramid of D1 over the first `rows` samples of the pair buffers, or None (engine pools itself).  pool_fake: pool the
@@ -996,10 +1073,26 @@ class SinSKITGModel(BaseModel):
         self._g_backward(part)
 
     def _seg_g_update(self):
+        if getattr(self, "_chains_done", False):      # the discriminator chains already hold Adam(D / D2) and the generator step's D passes
+            self._chains_done = self._g_pre_done = False
+            self._g_backward("all")
+            return
         if not getattr(self, "_g_pre_done", False):
             self._seg_g_pre()
         self._g_pre_done = False
         self._seg_g_main()
+
+    def _seg_step_chained(self):
+        """the whole step as ONE segment (single GPU): the D2 chain opened in _run_d_chains stays open beside the generator's backward
+        and is joined in front of Adam(G)"""
+        self._d2_lane = None
+        try:
+            self._seg_d_updates()
+            self._seg_g_update()
+        finally:
+            engine.join_lane(self._d2_lane)
+            self._d2_lane = None
+        self._seg_adam_g()
 
     def _seg_g_enc(self):
         engine.unet_backward_encoder(self.netG, self._g_ctx, self._g_bwd_state)
@@ -1030,6 +1123,9 @@ class SinSKITGModel(BaseModel):
           G_dec (decoder gradients, complete halfway through the backward) under the encoder's backward (_seg_g_enc),
           G_enc is the exposed one (waited for right before Adam(G)).
         The reference has no counterpart (nn.DataParallel, base_model.py:104-108, reduces inside autograd)."""
+        self._chained = self._use_chains()
+        if self._chained:
+            return [(self._seg_step_chained, (), ())]
         if not self._ddp_segments():
             return [(self._seg_d_updates, (), ("D", "D2")), (self._seg_g_update, ("D", "D2"), ("G",)), (self._seg_adam_g, ("G",), ())]
         buckets = self.ddp.buckets

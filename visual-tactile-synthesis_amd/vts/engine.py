@@ -1016,6 +1016,46 @@ def _run_lanes(n_lanes, body):
 _LANE_BASE = 0
 
 
+def fork_lane(fn):
+    """fn() on a side stream forked from the current stream, with its own scratch lane; returns a handle for join_lane.  Until the
+    join, lane calls made on the launch stream (_run_lanes, msd_chain) take the side streams BEHIND this one -- the lane may stay open
+    across several of them (the D2 chain of the training step runs beside the D1 chain AND the generator's backward).  fn must not
+    fork lanes itself (no fork from a side stream: hipStreamEndCapture does not survive one).  Serial schedule: fn() runs inline."""
+    global _LANE_BASE
+    if not PARALLEL_SCALES:
+        fn()
+        return None
+    base = _LANE_BASE
+    main = torch.cuda.current_stream()
+    side = _SIDE_STREAMS.setdefault(torch.cuda.current_device(), [])
+    while len(side) < base + 1:
+        side.append(torch.cuda.Stream())
+    st = side[base]
+    st.wait_stream(main)
+    ws0, ops.WS_LANE = ops.WS_LANE, base + 1
+    _LANE_BASE = base + 1
+    try:
+        with torch.cuda.stream(st):
+            fn()
+    except BaseException:
+        _LANE_BASE = base
+        main.wait_stream(st)
+        raise
+    finally:
+        ops.WS_LANE = ws0
+    return (st, base)
+
+
+def join_lane(handle):
+    """the current stream waits for the lane fork_lane opened; its side stream is free for other lanes again"""
+    global _LANE_BASE
+    if handle is None:
+        return
+    st, base = handle
+    torch.cuda.current_stream().wait_stream(st)
+    _LANE_BASE = base
+
+
 def _pyramid(D, in0, in1):
     in0 = _as_act(in0)
     in1 = _as_act(in1) if in1 is not None else None
@@ -1317,19 +1357,122 @@ def _lane_cost(passes, s):
     """rough time of one discriminator scale over its passes, ms: a latency floor (its ~25 dependent launches) + a term per input pixel"""
     px = 0
     for p in passes:
-        a0 = p["_pyr"][s][0]
+        a0 = p["_pyr"][0][0]          # (level 0: asking a lazily pooled pyramid for level s here would pool on the caller's stream)
         t = a0.data if isinstance(a0, Act) else a0
-        px += t.shape[0] * t.shape[2] * t.shape[3]
+        h, w = t.shape[2], t.shape[3]
+        for _ in range(s):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        px += t.shape[0] * h * w
     return 0.35 + 1e-7 * px
+
+
+LAZY_PYRAMID = tune.get("VTS_LAZY_PYRAMID", "1") != "0"
+
+
+class _LanePyramid:
+    """Input pyramid whose level s is pooled INSIDE the lane that asks for it (s average pools from the full-resolution level, on that
+    lane's stream).  Pooling all levels up front (`_pyramid`) put 2 x (num_D - 1) launches on the serial stretch in front of every fork of
+    the lanes -- the D2 full-resolution stack and the patch stacks: 67 us per step with nothing beside them; here scale 2 repeats scale 1's
+    first pool on its own stream instead (same values bit for bit).  Serial schedule (PARALLEL_SCALES off): levels are shared."""
+
+    def __init__(self, in0, in1):
+        self.base = (_as_act(in0), _as_act(in1) if in1 is not None else None)
+        self.levels = {0: self.base}
+
+    def __getitem__(self, s):
+        if s in self.levels:
+            return self.levels[s]
+        cur = self.base
+        for t in range(1, s + 1):
+            if t in self.levels:
+                cur = self.levels[t]
+                continue
+            cur = (_pool_act(cur[0]), _pool_act(cur[1]))
+            if not PARALLEL_SCALES:
+                self.levels[t] = cur
+        return cur
+
+
+def _prepare_passes(jobs):
+    """per-pass bookkeeping of msd_multi / msd_chain: the input pyramid (the caller's, or pooled inside the lanes), result slots"""
+    for D, passes in jobs:
+        for p in passes:
+            if p.get("pyr"):
+                p["_pyr"] = p["pyr"]                                          # the caller's precomputed input pyramid
+            elif LAZY_PYRAMID:
+                p["_pyr"] = _LanePyramid(p["in0"], p.get("in1"))
+            else:
+                p["_pyr"] = _pyramid(D, p["in0"], p.get("in1"))
+            p["preds"] = [None] * D.num_D
+            p["_din"] = [None] * D.num_D
+
+
+def _finish_passes(jobs):
+    for D, passes in jobs:
+        for p in passes:
+            if p.get("input_grad") is not None:
+                _merge_input_grads(p["_din"], p["input_grad"])
+            p.pop("_pyr"), p.pop("_din")
+            if not p.get("keep_stats"):
+                p.pop("_stats", None)
+
+
+def _scale_lane(D, s, passes, criterion, knocked_out=False):
+    """the passes of ONE scale of one multiscale discriminator, in order (the body of a lane of msd_multi / msd_chain)"""
+    cache = {}      # packed weights of this scale: shared by its passes (they run in order in this lane)
+    for p in passes:
+        prep = p.get("prep")
+        if prep and s in prep:
+            prep[s]()       # per-scale preparation inside the lane (pooling of this scale's input level)
+        a0, a1 = p["_pyr"][s]
+        if knocked_out:   # timing experiment only (VTS_KO_LANES; results are wrong): what a lane costs on the step's critical path
+            p["preds"][s] = torch.zeros(1, 1, 1, 1, device=a0.data.device)
+            if p.get("input_grad") is not None:
+                p["_din"][s] = torch.zeros_like((a1 if a1 is not None else a0).data)
+            continue
+        ig = p.get("input_grad")
+        gsrc = a1 if a1 is not None else a0
+        into = (ig[0], ig[1]) if (ig is not None and s == 0 and ig[0].shape == gsrc.data.shape and ig[0].is_contiguous()) else None
+        groups = p.get("groups")
+        gstarts = [gr["n0"] for gr in groups] if groups else None
+        stat_rec = p.setdefault("_stats", {}).setdefault(s, {}) if p.get("stat_only") else None
+        src = p.get("ext_from")
+        if KO_LANES and src is not None:
+            src.setdefault("_stats", {}).setdefault(s, {})
+        ext = (src["_stats"][s], p.get("ext_after", 0)) if src is not None else None
+        if KO_LANES and src is not None and not ext[0]:      # (timing experiment: the early pass of this lane was knocked out too)
+            ext = None
+        acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext)
+        pred = acts[-1].data
+        p["preds"][s] = pred
+        if groups:
+            want = any(gr.get("grad_coeff") is not None for gr in groups)
+            g = torch.empty_like(pred) if want else None
+            for gr in groups:
+                gc = gr.get("grad_coeff")
+                if want and gc is None:
+                    g[gr["n0"]:gr["n1"]].zero_()
+                criterion.accumulate([pred[gr["n0"]:gr["n1"]]], gr["real"], gr["coeff"], gr["slot"], grad_coeff=gc,
+                                     want_grad=gc is not None, out_grads=[g[gr["n0"]:gr["n1"]]] if gc is not None else None,
+                                     pre_sigmoid=getattr(D, "use_sigmoid", False))
+            if want:
+                p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
+                                                   p.get("input_grad") is not None, cache, gstarts, into=into)
+            continue
+        if not p.get("loss", True):
+            continue
+        gc = p.get("grad_coeff")
+        g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None,
+                                 pre_sigmoid=getattr(D, "use_sigmoid", False))[0]
+        if gc is not None:
+            p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
+                                               p.get("input_grad") is not None, cache, into=into)
 
 
 def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, streams=None):
     lanes = []
+    _prepare_passes(jobs)
     for D, passes in jobs:
-        for p in passes:
-            p["_pyr"] = p.get("pyr") or _pyramid(D, p["in0"], p.get("in1"))   # `pyr`: the caller's precomputed input pyramid
-            p["preds"] = [None] * D.num_D
-            p["_din"] = [None] * D.num_D
         for s in range(D.num_D):
             lanes.append((D, s, passes))
     costs = [_lane_cost(passes, s) for _, s, passes in lanes]
@@ -1345,66 +1488,115 @@ def _msd_multi(jobs, criterion, extra=None, extra_cost=0.1, extra_main=False, st
         if D is None:
             passes()
             return
-        cache = {}      # packed weights of this scale: shared by its passes (they run in order in this lane)
-        for p in passes:
-            prep = p.get("prep")
-            if prep and s in prep:
-                prep[s]()       # per-scale preparation inside the lane (pooling of this scale's input level)
-            a0, a1 = p["_pyr"][s]
-            if i in KO_LANES:   # timing experiment only (VTS_KO_LANES; results are wrong): what a lane costs on the step's critical path
-                p["preds"][s] = torch.zeros(1, 1, 1, 1, device=a0.data.device)
-                if p.get("input_grad") is not None:
-                    p["_din"][s] = torch.zeros_like((a1 if a1 is not None else a0).data)
-                continue
-            ig = p.get("input_grad")
-            gsrc = a1 if a1 is not None else a0
-            into = (ig[0], ig[1]) if (ig is not None and s == 0 and ig[0].shape == gsrc.data.shape and ig[0].is_contiguous()) else None
-            groups = p.get("groups")
-            gstarts = [gr["n0"] for gr in groups] if groups else None
-            stat_rec = p.setdefault("_stats", {}).setdefault(s, {}) if p.get("stat_only") else None
-            src = p.get("ext_from")
-            if KO_LANES and src is not None:
-                src.setdefault("_stats", {}).setdefault(s, {})
-            ext = (src["_stats"][s], p.get("ext_after", 0)) if src is not None else None
-            if KO_LANES and src is not None and not ext[0]:      # (timing experiment: the early pass of this lane was knocked out too)
-                ext = None
-            acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext)
-            pred = acts[-1].data
-            p["preds"][s] = pred
-            if groups:
-                want = any(gr.get("grad_coeff") is not None for gr in groups)
-                g = torch.empty_like(pred) if want else None
-                for gr in groups:
-                    gc = gr.get("grad_coeff")
-                    if want and gc is None:
-                        g[gr["n0"]:gr["n1"]].zero_()
-                    criterion.accumulate([pred[gr["n0"]:gr["n1"]]], gr["real"], gr["coeff"], gr["slot"], grad_coeff=gc,
-                                         want_grad=gc is not None, out_grads=[g[gr["n0"]:gr["n1"]]] if gc is not None else None,
-                                         pre_sigmoid=getattr(D, "use_sigmoid", False))
-                if want:
-                    p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
-                                                       p.get("input_grad") is not None, cache, gstarts, into=into)
-                continue
-            if not p.get("loss", True):
-                continue
-            gc = p.get("grad_coeff")
-            g = criterion.accumulate([pred], p["real"], p["coeff"], p["slot"], grad_coeff=gc, want_grad=gc is not None,
-                                     pre_sigmoid=getattr(D, "use_sigmoid", False))[0]
-            if gc is not None:
-                p["_din"][s] = _msd_scale_backward(D, s, a0, a1, acts, g, p.get("param_grads", True), p.get("accumulate", False),
-                                                   p.get("input_grad") is not None, cache, into=into)
+        _scale_lane(D, s, passes, criterion, knocked_out=i in KO_LANES)
 
     nograd = all(not p.get("param_grads", True) for _, passes in jobs for p in passes)     # the generator step's passes
     groups = _lane_groups(costs, "VTS_LANE_GROUPS_G" if nograd else "VTS_LANE_GROUPS", streams)
     with ops.deferred_wgrad():    # one reduction launch for the weight-gradient partials of all lanes, after they have joined
         _run_lanes(len(groups), lambda gi: [lane(i) for i in groups[gi]])
-    for D, passes in jobs:
-        for p in passes:
-            if p.get("input_grad") is not None:
-                _merge_input_grads(p["_din"], p["input_grad"])
-            p.pop("_pyr"), p.pop("_din")
-            if not p.get("keep_stats"):
-                p.pop("_stats", None)
+    _finish_passes(jobs)
+
+
+D_CHAINS = tune.get("VTS_D_CHAINS", "1") != "0"
+
+
+def msd_chain(chain, criterion, side=None, side_cost=0.1, serial=False):
+    """One discriminator's part of a training step as ONE dependency chain:
+        update passes (its scales side by side)  ->  `mid` (its optimiser step)  ->  its passes of the generator step.
+    msd_multi joins the lanes of ALL discriminators between those stages (and the stages were separate graphs): the step waited for the
+    slowest lane of the update phase, ran the weight-gradient reductions and both Adam launches alone on the chip, and forked again --
+    although D1's optimiser step needs only D1's lanes, and the generator's backward only D1's chain (the D2 term of the generator is a
+    logged value).  The chain's scales share TWO streams: the launch stream (the chain's join points, `mid`, the merge of the input
+    gradients) and one side stream.
+    serial=True: everything on the current stream -- for a chain that the caller runs inside a lane of its own (fork_lane).
+    MEASURED (round 6): a chain led by a SIDE stream needs side <-> side waits (its own join in front of its optimiser step), and
+    hipStreamEndCapture crashes on those exactly as on a fork from a side stream: only the chain on the launch stream can have two streams.
+
+    chain: dict(D=, index0=<lane number of scale 0, for VTS_KO_LANES>, update=[passes], mid=callable, gstep=callable -> [passes])
+    (pass dictionaries as for msd_multi).  side: callable that runs as one more lane inside the chain's stream pair and is complete before
+    `mid` (the generator's L1 terms: the D1 pass of the generator step accumulates onto their gradient)."""
+    global _LANE_BASE
+    D = chain["D"]
+    _prepare_passes([(D, chain["update"])])
+
+    def stage_lanes(passes):
+        """[(cost, body)] per scale"""
+        return [(_lane_cost(passes, s), (lambda s=s: _scale_lane(D, s, passes, criterion, knocked_out=(chain.get("index0", 0) + s) in KO_LANES)))
+                for s in range(D.num_D)]
+
+    def split2(items):
+        """two bins, longest first, the heaviest item first on bin 0 (the launch stream)"""
+        order = sorted(range(len(items)), key=lambda i: -items[i][0])
+        bins, load = ([], []), [0.0, 0.0]
+        for i in order:
+            k = 0 if load[0] <= load[1] else 1
+            bins[k].append(items[i][1])
+            load[k] += items[i][0]
+        return bins
+
+    if serial or not PARALLEL_SCALES:
+        with ops.deferred_wgrad():
+            for _, body in stage_lanes(chain["update"]):
+                body()
+            if side is not None:
+                side()
+            ops.wgrad_flush(ops.WS_LANE)
+            _finish_passes([(D, chain["update"])])
+            chain["mid"]()
+            g = chain["gstep"]()
+            _prepare_passes([(D, g)])
+            for _, body in stage_lanes(g):
+                body()
+            _finish_passes([(D, g)])
+        return
+
+    base = _LANE_BASE
+    main = torch.cuda.current_stream()
+    side_streams = _SIDE_STREAMS.setdefault(torch.cuda.current_device(), [])
+    while len(side_streams) < base + 1:
+        side_streams.append(torch.cuda.Stream())
+    second = side_streams[base]
+    ws0 = ops.WS_LANE
+
+    def on_second(fn):
+        ops.WS_LANE = base + 1
+        try:
+            with torch.cuda.stream(second):
+                fn()
+        finally:
+            ops.WS_LANE = ws0
+
+    _LANE_BASE = base + 1
+    try:
+        with ops.deferred_wgrad():
+            second.wait_stream(main)
+            items = stage_lanes(chain["update"])
+            if side is not None:
+                items.append((float(side_cost), side))
+            b_main, b_second = split2(items)
+            on_second(lambda: ([b() for b in b_second], ops.wgrad_flush(base + 1)))
+            for b in b_main:
+                b()
+            ops.wgrad_flush(ws0)
+            main.wait_stream(second)                  # the chain's own join, its optimiser step
+            _finish_passes([(D, chain["update"])])
+            chain["mid"]()
+            g = chain["gstep"]()
+            _prepare_passes([(D, g)])
+            second.wait_stream(main)
+            b_main, b_second = split2(stage_lanes(g))
+            on_second(lambda: [b() for b in b_second])
+            for b in b_main:
+                b()
+            main.wait_stream(second)
+            _finish_passes([(D, g)])
+    except BaseException:
+        ops.WS_LANE = ws0
+        ops.wgrad_discard()
+        raise
+    finally:
+        _LANE_BASE = base
+        main.wait_stream(second)                # joined back in every case (a capture must not end with a dangling fork)
 
 
 # ======================================================================================================================

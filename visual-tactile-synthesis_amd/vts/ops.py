@@ -55,7 +55,7 @@ def _run(label, nbytes, flops, fn, *args):
     rc = fn(*args)
     e1.record()
     L.check(rc, label)
-    if label.startswith(("conv4x4", "wgrad4x4", "norm_", "conv3x3_wide", "wgrad3x3_wide")):
+    if label.startswith(("conv4x4", "wgrad4x4", "patch_conv4x4", "patch_wgrad4x4", "norm_", "conv3x3_wide", "wgrad3x3_wide")):
         label = L.load().vts_last_kernel().decode()   # the exact kernel instance, as rocprofv3 names it
     TIMER.append((label, nbytes, flops, e0, e1, DETAIL))
     DETAIL = None
@@ -187,6 +187,9 @@ def conv4x4(in0, w, ws_co, ws_ci, cout, out, *, in1=None, bias=None, stride=2, p
     nbytes = 4.0 * (d.N * cin * d.IH * d.IW + d.N * cout * d.OH * d.OW * (1 + (dmask is not None) + bool(accumulate))
                     + cout * cin * 16)
     label = "conv4x4<%s,s%d,nr%d>" % ("convT" if transposed else "conv", stride, (cout + 15) // 16)
+    if d.N >= 128 and max(d.IH, d.IW, d.OH, d.OW) <= 34:
+        label = "patch_" + label       # the D2 patch stacks (small-map kernels): their own label class for VTS_KNOCKOUT (round 5's
+        #                                knock-out of "conv_small,wgrad_small,conv_head_small" matched NO label and measured nothing)
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d %dx%dx%d -> %dx%dx%d p%d%s%s" % (d.N, cin, d.IH, d.IW, cout, d.OH, d.OW, pad, " dmask" if dmask is not None else "",
@@ -359,7 +362,8 @@ def wgrad4x4(lo0, hi0, dw, *, lo1=None, hi1=None, act_lo=0, act_hi=0, stride=2, 
     if TIMER is not None:
         global DETAIL
         DETAIL = "N%d lo %dx%dx%d hi %dx%dx%d p%d" % (d.N, cl, d.LH, d.LW, chn, d.HH, d.HW, pad)
-    _run("wgrad4x4<s%d>" % stride, nbytes, flops, lib.vts_wgrad4x4, C.byref(d), ws.data_ptr(), L.stream())
+    _run(("patch_wgrad4x4<s%d>" if (d.N >= 128 and max(d.HH, d.HW) <= 34) else "wgrad4x4<s%d>") % stride, nbytes, flops, lib.vts_wgrad4x4,
+         C.byref(d), ws.data_ptr(), L.stream())
     if defer:
         seg = (ws, int(n // nel))
         if prev is not None:
