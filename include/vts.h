@@ -568,6 +568,11 @@ int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H, int W, con
 /* d g_raw = cat(d fake_I, d fake_T) * M * (1 - g_out^2)   (mask multiply + Tanh backward). */
 int vts_g_out_grad(const float* d_fake_I, const float* d_fake_T, const float* M, const float* g_out, int N, int H, int W,
                    float* d_raw, void* stream);
+/* the same with the image gradient's next pyramid level d_fake_I_coarse [N, 3, ceil(H / 2), ceil(W / 2)] (or NULL): its adjoint of
+ * AvgPool2d(3, 2, padding 1, count_include_pad False) -- the pyramid of MultiscaleDiscriminator, models/networks.py:1682-1691 -- is added to
+ * d_fake_I on the fly, bit-identical to vts_avgpool3s2_bwd(accumulate) followed by vts_g_out_grad. */
+int vts_g_out_grad_pool(const float* d_fake_I, const float* d_fake_I_coarse, const float* d_fake_T, const float* M, const float* g_out,
+                        int N, int H, int W, float* d_raw, void* stream);
 /* ImagePool.query (reference util/image_pool.py:29-61; pix2pixHD's fake_pool, pix2pixHD_model.py:334, 582) on the device.  The host
  * makes the reference's draws (Python's `random`) and hands over, per image n of the batch in order: ret_slot[n] = the pool slot whose
  * CURRENT content is returned in place of image n (-1: image n itself) and put_slot[n] = the slot image n is stored into (-1: none).

@@ -714,6 +714,32 @@ def test_g_post_diffaug_outgrad_spe():
     assert rel(y, dI * M) < 1e-7
 
 
+@pytest.mark.parametrize("hw", [(64, 96), (65, 97), (33, 50)])
+def test_g_out_grad_with_the_pyramid_merge_equals_the_two_launch_form_bit_for_bit(hw):
+    """vts_g_out_grad_pool: the adjoint of the pyramid's average pool (AvgPool2d(3, 2, 1, count_include_pad=False)) of the coarse image
+    gradient added on the fly == vts_avgpool3s2_bwd(accumulate) + vts_g_out_grad, bitwise (even and odd map sizes: border windows hold
+    4 / 6 / 9 taps), and == the autograd adjoint of torch's pool"""
+    import torch.nn.functional as F
+    from vts import ops
+
+    dev = _dev()
+    N, (H, W) = 2, hw
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    dI, dT = detrand.uniform((N, 3, H, W), 25, "dI").to(dev), detrand.uniform((N, 2, H, W), 25, "dT").to(dev)
+    dc = detrand.uniform((N, 3, OH, OW), 25, "dIc").to(dev)
+    M = (detrand.uniform((N, 1, H, W), 25, "M") > 0).float().to(dev)
+    g = torch.tanh(detrand.uniform((N, 5, H, W), 25, "g")).to(dev)
+    fused = ops.g_out_grad(dI, dT, M, g, torch.empty(N, 5, H, W, device=dev), coarse=dc)
+    dI2 = dI.clone()
+    ops.avgpool_bwd(dc, dI2, accumulate=True)
+    two = ops.g_out_grad(dI2, dT, M, g, torch.empty(N, 5, H, W, device=dev))
+    assert torch.equal(fused, two)
+    x = torch.zeros(N, 3, H, W, requires_grad=True)
+    F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False).backward(dc.cpu())
+    want = torch.cat([dI.cpu() + x.grad, dT.cpu()], 1) * M.cpu() * (1 - g.cpu() * g.cpu())
+    assert rel(fused, want) < 1e-6
+
+
 def test_mask_candidates_and_select():
     import random
 

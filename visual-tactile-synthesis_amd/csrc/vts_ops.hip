@@ -78,12 +78,9 @@ __device__ __forceinline__ int pool_cnt(int o, int L) {  // valid taps of window
   return c;
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, int C, int H, int W, int OH, int OW,
-                                                          float* __restrict__ dx, int64_t dxns, int accumulate) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int c = blockIdx.z % C, n = blockIdx.z / C;
-  if (x >= W || y >= H) return;
-  const float* g = dy + ((int64_t)n * C + c) * OH * OW;
+// adjoint of AvgPool2d(3, 2, padding 1, count_include_pad False) at fine position (y, x): the sum over the windows that cover it.
+// One function for avgpool_bwd_kernel and g_out_grad_kernel's fused merge, so that both evaluate the same expression (bit-identical).
+__device__ __forceinline__ float avgpool_adjoint_at(const float* __restrict__ g, int y, int x, int H, int W, int OH, int OW) {
   // windows covering y: oy with |y - 2 oy| <= 1 (one for even y, two for odd y); a window has 3 taps per axis minus the ones outside
   // the map, so its weight is 1 / (cy * cx) with cy, cx in {1, 2, 3}
   const int oy_lo = y >> 1, oy_hi = min((y + 1) >> 1, OH - 1), ox_lo = x >> 1, ox_hi = min((x + 1) >> 1, OW - 1);
@@ -92,7 +89,15 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
   const float wx0 = rcnt(ox_lo, W), wx1 = ox_hi > ox_lo ? rcnt(ox_hi, W) : 0.f;
   const float* r0 = g + (int64_t)oy_lo * OW;
   const float* r1 = g + (int64_t)oy_hi * OW;
-  const float s = wy0 * (r0[ox_lo] * wx0 + r0[ox_hi] * wx1) + wy1 * (r1[ox_lo] * wx0 + r1[ox_hi] * wx1);
+  return wy0 * (r0[ox_lo] * wx0 + r0[ox_hi] * wx1) + wy1 * (r1[ox_lo] * wx0 + r1[ox_hi] * wx1);
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, int C, int H, int W, int OH, int OW,
+                                                          float* __restrict__ dx, int64_t dxns, int accumulate) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int c = blockIdx.z % C, n = blockIdx.z / C;
+  if (x >= W || y >= H) return;
+  const float s = avgpool_adjoint_at(dy + ((int64_t)n * C + c) * OH * OW, y, x, H, W, OH, OW);
   float* o = dx + n * dxns + ((int64_t)c * H + y) * W + x;
   *o = accumulate ? *o + s : s;
 }
@@ -408,19 +413,27 @@ __global__ __launch_bounds__(256) void diffaug_op_kernel(const float* __restrict
   }
 }
 
+// dIc (optional): the image gradient's NEXT pyramid level [N, 3, OH, OW] (the D1 pass of the generator step leaves one input gradient per
+// scale): its average-pool adjoint is added here, i.e. the last avgpool_bwd launch of the merge (50 MB read-modify-write of dI on the
+// serial stretch between the discriminator chain and the generator's backward) is this kernel's one more read of a 4x smaller tensor.
 __global__ __launch_bounds__(256) void g_out_grad_kernel(const float* __restrict__ dI, const float* __restrict__ dT,
                                                          const float* __restrict__ M, const float* __restrict__ g, int64_t HW,
-                                                         float* __restrict__ d) {
+                                                         float* __restrict__ d, const float* __restrict__ dIc, int H, int W, int OH, int OW) {
   const int n = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= HW) return;
   const float m = M[n * HW + i];
+  const int y = dIc ? (int)(i / W) : 0, x = dIc ? (int)(i - (int64_t)y * W) : 0;
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     const float o = g[(n * 5 + c) * HW + i];
     float up = 0.f;
-    if (c < 3) up = dI ? dI[(n * 3 + c) * HW + i] : 0.f;
-    else up = dT ? dT[(n * 2 + c - 3) * HW + i] : 0.f;
+    if (c < 3) {
+      up = dI ? dI[(n * 3 + c) * HW + i] : 0.f;
+      if (dIc) up = up + avgpool_adjoint_at(dIc + ((int64_t)n * 3 + c) * OH * OW, y, x, H, W, OH, OW);
+    } else {
+      up = dT ? dT[(n * 2 + c - 3) * HW + i] : 0.f;
+    }
     d[(n * 5 + c) * HW + i] = up * m * (1.f - o * o);
   }
 }
@@ -867,14 +880,20 @@ extern "C" int vts_diffaug_bs_mask(const float* x, const float* M, int N, int H,
   return VTS_OK;
 }
 
-extern "C" int vts_g_out_grad(const float* d_fake_I, const float* d_fake_T, const float* M, const float* g_out, int N, int H, int W,
-                              float* d_raw, void* stream) {
+extern "C" int vts_g_out_grad_pool(const float* d_fake_I, const float* d_fake_I_coarse, const float* d_fake_T, const float* M, const float* g_out,
+                                   int N, int H, int W, float* d_raw, void* stream) {
   VTS_CHECK_ARG(M && g_out && d_raw, "vts_g_out_grad: bad args");
+  VTS_CHECK_ARG(!d_fake_I_coarse || (d_fake_I && H >= 2 && W >= 2), "vts_g_out_grad_pool: a coarse gradient needs the fine one and a map of at least 2 x 2");
   const int64_t HW = (int64_t)H * W;
   hipLaunchKernelGGL(g_out_grad_kernel, dim3((unsigned)cdiv64(HW, 256), N), dim3(256), 0, (hipStream_t)stream, d_fake_I, d_fake_T, M,
-                     g_out, HW, d_raw);
+                     g_out, HW, d_raw, d_fake_I_coarse, H, W, (H + 1) / 2, (W + 1) / 2);
   VTS_CHECK_LAUNCH("vts_g_out_grad");
   return VTS_OK;
+}
+
+extern "C" int vts_g_out_grad(const float* d_fake_I, const float* d_fake_T, const float* M, const float* g_out, int N, int H, int W,
+                              float* d_raw, void* stream) {
+  return vts_g_out_grad_pool(d_fake_I, nullptr, d_fake_T, M, g_out, N, H, W, d_raw, stream);
 }
 
 extern "C" int vts_diffaug_op_ws_floats(int N) { return N * DIFFAUG_PARTS; }

@@ -34,6 +34,7 @@ from .base_model import BaseModel
 # 1 (default): on one GPU the generator's discriminator-free loss terms run as one more lane beside the discriminator updates; 0: serially
 # behind them (A/B timing; results are identical: the lanes only read the forward's outputs and add into their own fixed-point loss slots)
 G_PRE_LANE = tune.get("VTS_G_PRE_LANE", "1") != "0"
+FUSE_MERGE = tune.get("VTS_FUSE_MERGE", "1") != "0"       # last level of the D1 input-gradient pyramid merge inside g_out_grad
 D2_CHAIN = tune.get("VTS_D2_CHAIN", "lanes")      # "serial": the whole D2 chain as one lane (measurement: see _run_d_chains)
 D1_REAL_EARLY = tune.get("VTS_D1_REAL_EARLY", "1") != "0"     # D1's pass on the real images beside the generator forward (see _seg_d_updates)
 
@@ -669,6 +670,8 @@ class SinSKITGModel(BaseModel):
         if policy is not None:
             pass
         elif has_real and opt.use_diffaug and opt.diffaugment:
+            # (round 6, measured and dropped: the draws + this launch on the real image in a lane BESIDE the generator forward -- they need
+            #  nothing of the generator -- instead of on the serial stretch behind it: 5.31 vs 5.28 ms, the lane competes with D1's early pass)
             draws = self._draws["aug"].to(dev).float() if self._draws is not None else torch.rand(4, n, device=dev)
             self._aug = draws
             rb, rs = draws[2].contiguous(), draws[3].contiguous()
@@ -933,8 +936,10 @@ class SinSKITGModel(BaseModel):
                     lam = opt.lambda_G1_GAN
                     in0, in1 = self._d1_pair(self.real_S, self.fake_I)
                     g = [dict(in0=in0, in1=in1, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam, param_grads=False,
-                              input_grad=(self._d_fake_I, self._have_dI), pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False))]
+                              input_grad=(self._d_fake_I, self._have_dI), pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False),
+                              defer_merge=FUSE_MERGE)]      # the last pool^T of the pyramid merge rides in g_out_grad (_g_backward)
                     self._have_dI = True
+                    self._g_gan_pass = g[0]
                     return g
                 chain_d1 = dict(D=net, index0=0, update=passes, mid=lambda: self.optimizer_D.step(self._gscale, bump=False), gstep=gstep_d1)
             else:
@@ -1101,7 +1106,9 @@ class SinSKITGModel(BaseModel):
     def _g_backward(self, part="all"):
         n, _, h, w = self.real_S.shape
         d_raw = torch.empty(n, 5, h, w, device=self.device)
-        ops.g_out_grad(self._d_fake_I if self._have_dI else None, self._d_fake_T, self.M, self.g_out, d_raw)
+        gp, self._g_gan_pass = getattr(self, "_g_gan_pass", None), None
+        ops.g_out_grad(self._d_fake_I if self._have_dI else None, self._d_fake_T, self.M, self.g_out, d_raw,
+                       coarse=gp.get("coarse_grad") if gp is not None else None)
         if isinstance(self.netG, networks.ResnetGenerator):
             engine.resnet_backward(self.netG, self._g_ctx, d_raw)
         elif part == "decoder":

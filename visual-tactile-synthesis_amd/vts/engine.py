@@ -1199,11 +1199,16 @@ def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_inp
     return None
 
 
-def _merge_input_grads(din_scales, input_grad):
-    """d in1 = d0 + pool^T(d1 + pool^T(d2 ...)) into input_grad = (tensor, accumulate?)"""
+def _merge_input_grads(din_scales, input_grad, defer_last=False):
+    """d in1 = d0 + pool^T(d1 + pool^T(d2 ...)) into input_grad = (tensor, accumulate?).
+    defer_last (only where the full-resolution scale wrote into the caller's buffer): the last, full-resolution pool^T is left to the
+    caller -- returns d1 + pool^T(d2 ...), which ops.g_out_grad(coarse=...) adds on the fly."""
     dst, acc = input_grad
-    for s in range(len(din_scales) - 1, 0, -1):
+    last = 1 if (defer_last and len(din_scales) > 1 and din_scales[0] is dst and din_scales[1].is_contiguous()) else 0
+    for s in range(len(din_scales) - 1, last, -1):
         ops.avgpool_bwd(din_scales[s], din_scales[s - 1], accumulate=True)
+    if last:
+        return din_scales[1]
     if din_scales[0] is dst:      # the full-resolution scale already wrote / accumulated into the caller's buffer
         return
     if acc:
@@ -1411,7 +1416,7 @@ def _finish_passes(jobs):
     for D, passes in jobs:
         for p in passes:
             if p.get("input_grad") is not None:
-                _merge_input_grads(p["_din"], p["input_grad"])
+                p["coarse_grad"] = _merge_input_grads(p["_din"], p["input_grad"], defer_last=bool(p.get("defer_merge")))
             p.pop("_pyr"), p.pop("_din")
             if not p.get("keep_stats"):
                 p.pop("_stats", None)

@@ -104,7 +104,7 @@ SYMBOLS = [
     "vts_last_error", "vts_last_kernel", "vts_version", "vts_capture_node_count", "vts_conv4x4", "vts_conv4x4_in", "vts_conv4x4_norm", "vts_conv4x4_norm_ws_floats", "vts_norm_stats_from_partials", "vts_conv4x4_ws_floats", "vts_wgrad4x4_ws_floats", "vts_wgrad4x4", "vts_wgrad_reduce_batch", "vts_channel_sum",
     "vts_channel_sum_ws_floats", "vts_norm_ws_floats", "vts_norm_stats", "vts_norm_bwd", "vts_act_bwd",
     "vts_avgpool3s2", "vts_avgpool3s2_bwd", "vts_ganloss", "vts_l1", "vts_patch_gather", "vts_patch_scatter_bwd",
-    "vts_g_post", "vts_diffaug_bs_mask", "vts_diffaug_op", "vts_diffaug_op_ws_floats", "vts_g_out_grad", "vts_pool_query", "vts_mask_mul", "vts_input_images_u8", "vts_spe_grid", "vts_mask_candidates",
+    "vts_g_post", "vts_diffaug_bs_mask", "vts_diffaug_op", "vts_diffaug_op_ws_floats", "vts_g_out_grad", "vts_g_out_grad_pool", "vts_pool_query", "vts_mask_mul", "vts_input_images_u8", "vts_spe_grid", "vts_mask_candidates",
     "vts_pad_affine", "vts_pad_bwd", "vts_blur_down", "vts_blur_down_bwd", "vts_blur_up", "vts_blur_up_bwd", "vts_tap_embed", "vts_tap_extract", "vts_tap_embed_at", "vts_tap_extract_at", "vts_w3x3_pack", "vts_conv3x3_wide", "vts_w3x3_wino_floats", "vts_w3x3_wino_pack", "vts_conv3x3_wino_ok", "vts_conv3x3_wino", "vts_conv3x3_wide_relu_pad", "vts_conv3x3_wide_mask_pad", "vts_zero_border", "vts_conv3x3_wide_ws_floats", "vts_conv3x3s2_wide", "vts_tconv3x3s2_wide", "vts_wgrad3x3_wide", "vts_wgrad3x3_wide_ws_floats", "vts_upfirdn2d_out_size", "vts_upfirdn2d", "vts_upfirdn2d_bwd", "vts_bias_act", "vts_bias_act_bwd", "vts_modconv_demod", "vts_w4x4_pack", "vts_conv4x4_flat_ok", "vts_conv4x4_wide_ws_floats", "vts_conv4x4_wide", "vts_wgrad4x4_wide_ws_floats", "vts_wgrad4x4_wide",
     "vts_metric_ws_floats", "vts_minmax", "vts_metric_psnr", "vts_metric_tactile", "vts_metric_ssim", "vts_frechet_ws_floats", "vts_frechet_distance", "vts_sifid_input", "vts_modconv_weight", "vts_modconv_weight_bwd", "vts_adain", "vts_adain_bwd", "vts_resample_table",
     "vts_mask_select", "vts_mask_sample_ranks", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
@@ -180,7 +180,7 @@ def load():
         "vts_diffaug_bs_mask": [vp, vp, i, i, i, vp, vp, vp, vp],
         "vts_diffaug_op_ws_floats": [i],
         "vts_diffaug_op": [vp, i64, vp, i64, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp],
-        "vts_g_out_grad": [vp, vp, vp, vp, i, i, i, vp, vp],
+        "vts_g_out_grad": [vp, vp, vp, vp, i, i, i, vp, vp], "vts_g_out_grad_pool": [vp, vp, vp, vp, vp, i, i, i, vp, vp],
         "vts_mask_mul": [vp, vp, i, i, i, vp, vp],
         "vts_pool_query": [vp, vp, vp, vp, i, i64, vp, vp],
         "vts_spe_grid": [vp, i64, i, i, i, i, vp],

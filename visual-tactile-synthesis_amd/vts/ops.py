@@ -1209,11 +1209,15 @@ def diffaug_policy(x, policy, draws, M, out):
     return out
 
 
-def g_out_grad(d_fake_I, d_fake_T, M, g_out, d_raw):
+def g_out_grad(d_fake_I, d_fake_T, M, g_out, d_raw, coarse=None):
+    """coarse: the image gradient's next pyramid level [N, 3, ceil(H/2), ceil(W/2)], whose average-pool adjoint is added to d_fake_I on
+    the fly (the last avgpool_bwd of engine._merge_input_grads, fused)"""
     lib = L.load()
     n, _, h, w = g_out.shape
-    L.check(lib.vts_g_out_grad(L.ptr(d_fake_I), L.ptr(d_fake_T), M.data_ptr(), g_out.data_ptr(), n, h, w, d_raw.data_ptr(), L.stream()),
-            "vts_g_out_grad")
+    if coarse is not None:
+        assert d_fake_I is not None and coarse.is_contiguous() and tuple(coarse.shape) == (n, 3, (h + 1) // 2, (w + 1) // 2), coarse.shape
+    L.check(lib.vts_g_out_grad_pool(L.ptr(d_fake_I), L.ptr(coarse), L.ptr(d_fake_T), M.data_ptr(), g_out.data_ptr(), n, h, w, d_raw.data_ptr(),
+                                    L.stream()), "vts_g_out_grad")
     return d_raw
 
 
