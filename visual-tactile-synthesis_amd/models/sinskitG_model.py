@@ -865,7 +865,7 @@ class SinSKITGModel(BaseModel):
                 # (the sketch and mask channels of _full_stack were written by the forward's post-processing pass)
                 # batched: it runs first and only records its BatchNorm statistics; the patch pass splices its running-statistics
                 # update in after the fake patches, i.e. at the reference's position (sinskitG_model.py:1490-1501)
-                p_full = dict(in0=self._full_stack, loss=False, stat_only=batched)
+                p_full = dict(in0=self._full_stack, loss=False, stat_only=batched, pred_scales=(self.netD2.num_D - 1,))   # (only preds[-1] is shown)
                 passes.append(p_full)
             K = 0
             if opt.use_more_fakeT:

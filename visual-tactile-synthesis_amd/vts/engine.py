@@ -1099,7 +1099,7 @@ def _packed4(conv, mode, cache):
     return buf
 
 
-def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None, groups=None, stat_rec=None, ext=None):
+def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None, groups=None, stat_rec=None, ext=None, skip_head=False):
     """one PatchGAN of the pyramid: returns the list of layer outputs (Act), the last one is the prediction.
     groups: sample indices where the passes batched into this call start (BatchNorm statistics per pass: ops.norm_stats);
     stat_rec: dict filled with {bn layer: (mean, unbiased var)} of this call; ext: (such a dict, after) whose running-statistics
@@ -1110,6 +1110,8 @@ def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None, groups=None, stat
     cur0, cur1 = a0, a1
     h, w = cur0.data.shape[2], cur0.data.shape[3]
     for j, ci in enumerate(D.CONV_IDX):
+        if skip_head and j == len(D.CONV_IDX) - 1:
+            break      # a pass that only advances BatchNorm statistics at this scale: the prediction head has no normalisation behind it
         conv = getattr(layer, str(ci))
         st = D.STRIDE[ci]
         cout, cin = conv.weight.shape[0], conv.weight.shape[1]
@@ -1447,7 +1449,12 @@ def _scale_lane(D, s, passes, criterion, knocked_out=False):
         ext = (src["_stats"][s], p.get("ext_after", 0)) if src is not None else None
         if KO_LANES and src is not None and not ext[0]:      # (timing experiment: the early pass of this lane was knocked out too)
             ext = None
-        acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext)
+        # pred_scales: the scales whose prediction map the caller reads, for a pass without loss (the full-resolution D2 visualisation pass
+        # shows the coarsest scale only; at the other scales it exists for the BatchNorm running statistics: their head is not run)
+        skip_head = not p.get("loss", True) and p.get("pred_scales") is not None and s not in p["pred_scales"]
+        acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext, skip_head=skip_head)
+        if skip_head:
+            continue
         pred = acts[-1].data
         p["preds"][s] = pred
         if groups:
