@@ -971,10 +971,15 @@ class SinSKITGModel(BaseModel):
                 return run
             spec = tune.get("VTS_D2_LANES", "")        # measurement: "0|1|2", "0,1,2", ... (default: scale 0 | the others)
             groups = ([[int(t) for t in g.split(",")] for g in spec.split("|")] if spec else [[0], list(range(1, D2.num_D))])
-            lanes = [engine.fork_lane(d2_update(g)) for g in groups if g]
-            engine.msd_chain(chain_d1, self.criterionGAN, side=g_pre, serial=tune.get("VTS_D1_SERIAL", "0") == "1")
-            for h in reversed(lanes):
-                engine.join_lane(h)
+            lanes = []
+            try:
+                for g in groups:
+                    if g:
+                        lanes.append(engine.fork_lane(d2_update(g)))
+                engine.msd_chain(chain_d1, self.criterionGAN, side=g_pre, serial=tune.get("VTS_D1_SERIAL", "0") == "1")
+            finally:
+                for h in reversed(lanes):      # (also on an exception: an open lane would keep its side stream reserved for good)
+                    engine.join_lane(h)
             engine._finish_passes([(D2, upd)])
             chain_d2["mid"]()
             tail = dict(chain_d2, update=[], mid=lambda: None)
