@@ -678,6 +678,52 @@ typedef struct vts_unet_desc {
 int64_t vts_unet_forward_ws_floats(const vts_unet_desc* d);
 int vts_unet_forward(const vts_unet_desc* d, float* ws, int64_t ws_floats, void* stream);
 
+/* ---- network-level entries: the discriminators' forward (round 6; SURVEY.md 8(b): `vts_msd_fwd`; csrc/vts_msd.cpp) ---------------------
+ * vts_patchgan_forward = NLayerDiscriminator.forward (models/networks.py:1696-1750), vts_msd_forward = MultiscaleDiscriminator.forward
+ * (models/networks.py:1649-1691: num_D PatchGANs over an AvgPool2d(3, 2, 1, count_include_pad False) pyramid, full resolution first), in
+ * TRAINING mode -- BatchNorm2d normalises with the batch statistics and advances its running statistics (momentum, unbiased variance,
+ * num_batches_tracked += 1), as every discriminator call of a reference training step does (models/sinskitG_model.py:1361, 1374, 1490,
+ * 1567, 1584, 1781) -- forward only: nothing is kept for a backward.  Weights in the reference's state-dict layout
+ * (layer<k>.<i>.weight [Cout, Cin, 4, 4]).  Convolution j: Conv2d(4, stride[j], padding 2); LeakyReLU(0.2) in front of every convolution
+ * but the first; BatchNorm2d behind convolution j where gamma[j] / beta[j] are given (never the first or the last).
+ *   running_mean / running_var / num_batches_tracked [j]   NULL: this call does not advance the running statistics
+ *   stat_mean_out / stat_uvar_out [j]                      optional [cout[j]]: record the batch mean / unbiased variance (a pass whose
+ *                                                          running-statistics update is spliced into another launch: vts_norm_desc.ext_*)
+ *   run_head = 0                                           stop in front of the last convolution (a pass that exists for the statistics)
+ * No allocation, no host synchronisation (capturable); the workspace holds the raw layer outputs. */
+#define VTS_PATCHGAN_MAX_CONVS 8
+typedef struct vts_patchgan_desc {
+  vts_operand in0, in1; /* channel-concatenated input (in1.C = 0: one source), e.g. torch.cat((real_S, image), 1) */
+  int N, H, W;
+  int n_convs; /* n_layers + 2 */
+  int cout[VTS_PATCHGAN_MAX_CONVS];
+  int stride[VTS_PATCHGAN_MAX_CONVS];
+  const float* w[VTS_PATCHGAN_MAX_CONVS];
+  const float* b[VTS_PATCHGAN_MAX_CONVS];
+  const float* gamma[VTS_PATCHGAN_MAX_CONVS];
+  const float* beta[VTS_PATCHGAN_MAX_CONVS];
+  float* running_mean[VTS_PATCHGAN_MAX_CONVS];
+  float* running_var[VTS_PATCHGAN_MAX_CONVS];
+  int64_t* num_batches_tracked[VTS_PATCHGAN_MAX_CONVS];
+  float* stat_mean_out[VTS_PATCHGAN_MAX_CONVS];
+  float* stat_uvar_out[VTS_PATCHGAN_MAX_CONVS];
+  float eps, momentum; /* nn.BatchNorm2d defaults: 1e-5, 0.1 */
+  int run_head;
+  float* pred; /* [N, 1, h, w] of the last convolution (run_head) */
+} vts_patchgan_desc;
+int64_t vts_patchgan_forward_ws_floats(const vts_patchgan_desc* d);
+int vts_patchgan_forward(const vts_patchgan_desc* d, float* ws, int64_t ws_floats, void* stream);
+
+#define VTS_MSD_MAX_SCALES 4
+typedef struct vts_msd_desc {
+  int num_D;
+  /* scale[0] = the full-resolution PatchGAN (the reference's layer<num_D - 1>) and carries the input (in0, in1: plain tensors, N, H, W);
+   * the inputs / sizes of the other scales are filled in by the call (their pooled levels live in the workspace). */
+  vts_patchgan_desc scale[VTS_MSD_MAX_SCALES];
+} vts_msd_desc;
+int64_t vts_msd_forward_ws_floats(const vts_msd_desc* d);
+int vts_msd_forward(const vts_msd_desc* d, float* ws, int64_t ws_floats, void* stream);
+
 /* ---- optional collective of the data-parallel path (csrc/vts_comm.cpp; off by default, vts/ddp.py: VTS_DDP_DIRECT=1) ----------------
  * Sum-all-reduce of one flat fp32 gradient bucket as reduce-scatter + all-gather on the library's OWN RCCL communicator and side stream
  * (each rank reduces 1 / world of the bucket, all xGMI links carry a slice).  Replaces nn.DataParallel's gradient

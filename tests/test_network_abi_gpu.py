@@ -173,3 +173,170 @@ def test_a_cpp_host_runs_the_generator_without_python(tmp_path):
     assert "ms per image" in r.stdout
     y = torch.from_numpy(np.fromfile(fout, dtype="<f4").reshape(n, 5, size, size))
     assert torch.equal(y, y_py.cpu())
+
+
+# ---- vts_patchgan_forward / vts_msd_forward (round 6; SURVEY 8b's `vts_msd_fwd`): the discriminators' training-mode forward as one C call ----
+
+def _discriminator(input_nc, n_layers=3, seed=31):
+    from models import networks
+
+    D = networks.MultiscaleDiscriminator(input_nc, ndf=8, n_layers=n_layers, num_D=3).to("cuda:0")
+    sd = detrand.test_weights(nets.d_param_shapes(input_nc, n_layers=n_layers), seed)
+    D.load_state_dict(sd)
+    return D, sd
+
+
+def _buffers(D):
+    return {k: b.detach().clone() for k, b in D.named_buffers()}
+
+
+@pytest.mark.parametrize("shape,n_layers", [((2, 256, 256), 3), ((4, 130, 98), 3), ((96, 32, 32), 3), ((2, 128, 128), 2), ((3, 64, 64), 4)])
+def test_patchgan_c_forward_equals_the_python_schedule_bit_for_bit(shape, n_layers):
+    """every scale of the multiscale discriminator: prediction map, BatchNorm running statistics and num_batches_tracked after the call,
+    and the recorded batch statistics of a stat-only pass -- C entry against vts/engine.py:_msd_scale_forward (full-size maps: tiled
+    kernels with epilogue statistics; 32 x 32 patch stacks: small-map kernels; concat of two sources)"""
+    from vts import engine
+    from vts.ops import Act
+
+    n, h, w = shape
+    dev = torch.device("cuda:0")
+    x0 = detrand.uniform((n, 1, h, w), 41, "s").to(dev)
+    x1 = detrand.uniform((n, 3, h, w), 41, "i").to(dev)
+    for stat_only in (False, True):
+        res = {}
+        for which in ("py", "c"):
+            D, _ = _discriminator(4, n_layers)
+            pyr = engine._pyramid(D, x0, x1)
+            preds, recs = [], []
+            for s in range(D.num_D):
+                rec = {} if stat_only else None
+                if which == "py":
+                    acts = engine._msd_scale_forward(D, s, pyr[s][0], pyr[s][1], not stat_only, None, None, rec, None)
+                    preds.append(acts[-1].data)
+                else:
+                    preds.append(engine.patchgan_forward_c(D, s, pyr[s][0], pyr[s][1], not stat_only, rec))
+                recs.append(rec)
+            torch.cuda.synchronize()
+            res[which] = (preds, _buffers(D), recs)
+        # depth 4 has a 64 -> 128 layer: the Python schedule sends it to the GEMM-class kernel (engine._flat4), the C entry keeps the 4x4
+        # family -- the product does not take the C entry there (patchgan_c_ok); the entry itself is still correct to rounding
+        exact = all(engine.patchgan_c_ok(D, pyr[s][0].data.shape[2], pyr[s][0].data.shape[3]) for s in range(D.num_D))
+        assert exact == (n_layers <= 3)
+        same = torch.equal if exact else (lambda u, v: rel(u, v) < 2e-5)
+        for a, b in zip(res["py"][0], res["c"][0]):
+            assert a.shape == b.shape and same(a, b)
+        for k, v in res["py"][1].items():
+            assert same(v.float(), res["c"][1][k].float()), k
+        if stat_only:
+            for ra, rb in zip(res["py"][2], res["c"][2]):
+                assert sorted(ra) == sorted(rb) and len(ra) == n_layers
+                for ci in ra:
+                    assert same(ra[ci][0], rb[ci][0]) and same(ra[ci][1], rb[ci][1])
+            for k, v in res["c"][1].items():      # a stat-only pass leaves the running buffers alone
+                if k.endswith("num_batches_tracked"):
+                    assert int(v) == 0, k
+    # without the head: the statistics advance, no prediction map
+    D, _ = _discriminator(4, n_layers)
+    pyr = engine._pyramid(D, x0, x1)
+    assert engine.patchgan_forward_c(D, 0, pyr[0][0], pyr[0][1], True, None, run_head=False) is None
+    assert int(dict(D.named_buffers())["layer%d.3.num_batches_tracked" % (D.num_D - 1)]) == 1
+
+
+def test_msd_c_forward_matches_oracle_and_the_per_scale_entry():
+    """vts_msd_forward (all scales + the average-pool pyramid in one call) == the per-scale entry on the engine's pyramid, bit for bit, and
+    == the oracle's MultiscaleDiscriminator (pinned to the reference module: tests/golden/nets_256.npz) within the north_star tolerance,
+    predictions and BatchNorm buffers"""
+    import ctypes as C
+
+    from vts import engine
+    from vts import lib as L
+
+    dev = torch.device("cuda:0")
+    n, h, w = 2, 256, 256
+    x = detrand.uniform((n, 7, h, w), 43, "stack")
+    D, sd = _discriminator(7)
+    pyr = engine._pyramid(D, x.to(dev), None)
+    want = [engine.patchgan_forward_c(D, s, pyr[s][0], None) for s in range(D.num_D)]
+    bufs_scale = _buffers(D)
+    D2, _ = _discriminator(7)
+    d = L.MsdDesc()
+    d.num_D = D2.num_D
+    preds = []
+    xd = x.to(dev)
+    for s in range(D2.num_D):
+        sub, pred, _ = engine.patchgan_desc(D2, s, pyr[s][0], None)      # (shapes per scale; only scale 0's input is read by the call)
+        if s == 0:
+            sub.in0 = L.operand(xd)
+        d.scale[s] = sub
+        preds.append(pred)
+    lib = L.load()
+    need = int(lib.vts_msd_forward_ws_floats(C.byref(d)))
+    assert need > 0
+    ws = torch.empty(need, device=dev)
+    L.check(lib.vts_msd_forward(C.byref(d), ws.data_ptr(), ws.numel(), L.stream()), "vts_msd_forward")
+    torch.cuda.synchronize()
+    for a, b in zip(preds, want):
+        assert torch.equal(a, b)
+    for k, v in _buffers(D2).items():
+        assert torch.equal(v, bufs_scale[k]), k
+    # the oracle (CPU, pinned to the reference): training-mode forward, running statistics advanced once
+    ref = nets.msd_forward(sd, x, 3)
+    for s in range(3):
+        assert rel(preds[s], ref[s][-1]) < 1e-4, s
+    for k, v in _buffers(D2).items():
+        if v.dtype.is_floating_point:
+            assert rel(v, sd[k]) < 1e-4, k
+        else:
+            assert int(v) == int(sd[k]), k
+    # argument errors are reported, not crashed
+    assert lib.vts_patchgan_forward(None, None, 0, None) == -1 and b"null descriptor" in lib.vts_last_error()
+    bad = L.PatchganDesc()
+    assert lib.vts_patchgan_forward(C.byref(bad), ws.data_ptr(), ws.numel(), L.stream()) == -1
+    assert lib.vts_msd_forward(C.byref(d), ws.data_ptr(), 8, L.stream()) == -1 and b"workspace" in lib.vts_last_error()
+
+
+def test_forward_only_discriminator_passes_of_the_step_take_the_c_entry(monkeypatch):
+    """the product's forward-only passes (D2 visualisation pass, D2 term of the generator step) through vts_patchgan_forward give the
+    step of the Python schedule bit for bit: weights, BatchNorm buffers, logged losses, the visualised prediction map"""
+    from data.synthetic_dataset import make_sample
+    from models import create_model
+    from options.train_options import TrainOptions
+    from torch.utils.data import default_collate
+    from vts import engine
+
+    res = {}
+    calls = {"n": 0}
+    orig = engine.patchgan_forward_c
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    monkeypatch.setattr(engine, "patchgan_forward_c", counted)
+    for use_c in (True, False):
+        monkeypatch.setattr(engine, "MSD_C", use_c)
+        calls["n"] = 0
+        opt = TrainOptions(cmd_line=FLAGS % ("sinskitG", 256, 2)).parse()
+        m = create_model(opt)
+        m.setup(opt)
+        m.parallelize()
+        m.train()
+        for net, shapes, seed in ((m.netG, nets.g_param_shapes(), 61), (m.netD, nets.d_param_shapes(4), 62), (m.netD2, nets.d_param_shapes(7), 63)):
+            net.load_state_dict(detrand.test_weights(shapes, seed))
+        import random
+        random.seed(3)
+        torch.manual_seed(3)
+        batch = default_collate([make_sample(256, 64, 64, 70 + i) for i in range(2)])
+        for _ in range(2):
+            m.set_input(batch, phase="train")
+            m.optimize_parameters(epoch=1)
+        torch.cuda.synchronize()
+        assert (calls["n"] > 0) == use_c
+        res[use_c] = dict(flat={nm: getattr(m, "flat" + nm).flat.clone() for nm in ("G", "D", "D2")}, bufs=_buffers(m.netD2),
+                          losses=m.get_current_losses(), viz=m.pred_fake_T_full.clone())
+    a, b = res[True], res[False]
+    for nm in a["flat"]:
+        assert torch.equal(a["flat"][nm], b["flat"][nm]), nm
+    for k in a["bufs"]:
+        assert torch.equal(a["bufs"][k], b["bufs"][k]), k
+    assert a["losses"] == b["losses"] and torch.equal(a["viz"], b["viz"])

@@ -13,6 +13,7 @@ Reference graphs reproduced here:
   NLayerDiscriminator             /root/reference/models/networks.py:1696-1750
 (their backward is PyTorch autograd in the reference).
 """
+import ctypes as C
 import os
 from . import tune
 
@@ -1153,6 +1154,74 @@ def _msd_scale_forward(D, s, a0, a1, update_stats, cache=None, groups=None, stat
     return acts
 
 
+MSD_C = tune.get("VTS_MSD_C", "1") != "0"     # forward-only discriminator passes through the network-level C entry (0: the Python schedule)
+
+
+def patchgan_desc(D, s, a0, a1, update_stats=True, stat_rec=None, run_head=True, pred=None):
+    """vts_patchgan_desc of scale s of a multiscale discriminator (include/vts.h): weights from the module in the reference's state-dict
+    layout, BatchNorm running buffers when update_stats, `stat_rec` {conv index: (mean, uvar)} filled with recording buffers"""
+    layer = getattr(D, "layer%d" % (D.num_D - 1 - s))
+    d = L.PatchganDesc()
+    d.in0, d.in1 = ops._op(a0), ops._op(a1)
+    x = a0.data if isinstance(a0, Act) else a0
+    d.N, d.H, d.W = x.shape[0], x.shape[2], x.shape[3]
+    d.n_convs = len(D.CONV_IDX)
+    d.eps, d.momentum = 1e-5, 0.1
+    keep = []
+    for j, ci in enumerate(D.CONV_IDX):
+        conv = getattr(layer, str(ci))
+        d.cout[j], d.stride[j] = conv.weight.shape[0], D.STRIDE[ci]
+        d.w[j], d.b[j] = conv.weight.data_ptr(), L.ptr(conv.bias)
+        if ci in D.BN_IDX:
+            bn = getattr(layer, str(D.BN_IDX[ci]))
+            d.gamma[j], d.beta[j] = bn.weight.data_ptr(), bn.bias.data_ptr()
+            if update_stats:
+                d.running_mean[j], d.running_var[j] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                d.num_batches_tracked[j] = bn.num_batches_tracked.data_ptr()
+            if stat_rec is not None:
+                so = stat_rec[ci] = (torch.empty(conv.weight.shape[0], dtype=torch.float32, device=x.device),
+                                     torch.empty(conv.weight.shape[0], dtype=torch.float32, device=x.device))
+                d.stat_mean_out[j], d.stat_uvar_out[j] = so[0].data_ptr(), so[1].data_ptr()
+    d.run_head = int(bool(run_head))
+    if run_head:
+        h, w = d.H, d.W
+        for ci in D.CONV_IDX:
+            h, w = h // D.STRIDE[ci] + 1, w // D.STRIDE[ci] + 1
+        if pred is None:
+            pred = _empty(d.N, 1, h, w, x.device)
+        d.pred = pred.data_ptr()
+    return d, pred, keep
+
+
+def patchgan_c_ok(D, h, w):
+    """the C entry runs every layer on the 4x4 convolution family: not where the Python schedule sends a wide layer to the GEMM-class
+    kernels (_flat4: pix2pixHD's ndf = 64, depth >= 4 at ndf = 8), and PatchGAN depths within the descriptor; h, w: the input map"""
+    if not MSD_C or len(D.CONV_IDX) > L.PATCHGAN_MAX_CONVS:
+        return False
+    layer = getattr(D, "layer0")
+    for j, ci in enumerate(D.CONV_IDX):
+        conv = getattr(layer, str(ci))
+        st = D.STRIDE[ci]
+        oh, ow = h // st + 1, w // st + 1
+        if _flat4(conv, j, h, w, oh, ow, st) or conv.weight.shape[0] > 80:
+            return False
+        h, w = oh, ow
+    return True
+
+
+def patchgan_forward_c(D, s, a0, a1, update_stats=True, stat_rec=None, run_head=True):
+    """scale s of a multiscale discriminator, training-mode forward, nothing kept: ONE call of vts_patchgan_forward (the path of the
+    product's forward-only passes; bit-identical to _msd_scale_forward: tests/test_network_abi_gpu.py).  Returns the prediction map or None."""
+    d, pred, _ = patchgan_desc(D, s, a0, a1, update_stats, stat_rec, run_head)
+    lib = L.load()
+    need = int(lib.vts_patchgan_forward_ws_floats(C.byref(d)))
+    if need < 0:
+        raise RuntimeError("vts_patchgan_forward: %s" % lib.vts_last_error().decode())
+    ws = torch.empty(max(need, 1), dtype=torch.float32, device=pred.device if pred is not None else (a0.data if isinstance(a0, Act) else a0).device)
+    L.check(lib.vts_patchgan_forward(C.byref(d), ws.data_ptr(), ws.numel(), L.stream()), "vts_patchgan_forward")
+    return pred
+
+
 def _msd_scale_backward(D, s, a0, a1, acts, g, param_grads, accumulate, want_input_grad, cache=None, groups=None, into=None):
     """backward of one PatchGAN; returns the gradient w.r.t. the second concat source (or None).
     into = (tensor, accumulate?): write / add that gradient straight into the caller's buffer (the full-resolution scale: saves the
@@ -1455,10 +1524,17 @@ def _scale_lane(D, s, passes, criterion, knocked_out=False):
         # pred_scales: the scales whose prediction map the caller reads, for a pass without loss (the full-resolution D2 visualisation pass
         # shows the coarsest scale only; at the other scales it exists for the BatchNorm running statistics: their head is not run)
         skip_head = not p.get("loss", True) and p.get("pred_scales") is not None and s not in p["pred_scales"]
-        acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext, skip_head=skip_head)
+        forward_only = not groups and ext is None and (not p.get("loss", True) or p.get("grad_coeff") is None)
+        # (per-launch timing and label knock-outs need the single launches: they take the Python schedule)
+        if forward_only and ops.TIMER is None and not ops.KNOCKOUT and patchgan_c_ok(D, a0.data.shape[2], a0.data.shape[3]):
+            # nothing of this pass is needed again: the whole scale as ONE call of the network-level C entry (vts_patchgan_forward)
+            acts = None
+            pred = patchgan_forward_c(D, s, a0, a1, not p.get("stat_only", False), stat_rec, run_head=not skip_head)
+        else:
+            acts = _msd_scale_forward(D, s, a0, a1, not p.get("stat_only", False), cache, gstarts, stat_rec, ext, skip_head=skip_head)
+            pred = None if skip_head else acts[-1].data
         if skip_head:
             continue
-        pred = acts[-1].data
         p["preds"][s] = pred
         if groups:
             want = any(gr.get("grad_coeff") is not None for gr in groups)

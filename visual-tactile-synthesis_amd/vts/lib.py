@@ -82,6 +82,28 @@ class UnetDesc(C.Structure):
     ]
 
 
+PATCHGAN_MAX_CONVS, MSD_MAX_SCALES = 8, 4
+
+
+class PatchganDesc(C.Structure):
+    """vts_patchgan_desc (include/vts.h): one PatchGAN's training-mode forward as one C call"""
+    _fields_ = [
+        ("in0", Operand), ("in1", Operand), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("n_convs", C.c_int),
+        ("cout", C.c_int * PATCHGAN_MAX_CONVS), ("stride", C.c_int * PATCHGAN_MAX_CONVS),
+        ("w", C.c_void_p * PATCHGAN_MAX_CONVS), ("b", C.c_void_p * PATCHGAN_MAX_CONVS),
+        ("gamma", C.c_void_p * PATCHGAN_MAX_CONVS), ("beta", C.c_void_p * PATCHGAN_MAX_CONVS),
+        ("running_mean", C.c_void_p * PATCHGAN_MAX_CONVS), ("running_var", C.c_void_p * PATCHGAN_MAX_CONVS),
+        ("num_batches_tracked", C.c_void_p * PATCHGAN_MAX_CONVS),
+        ("stat_mean_out", C.c_void_p * PATCHGAN_MAX_CONVS), ("stat_uvar_out", C.c_void_p * PATCHGAN_MAX_CONVS),
+        ("eps", C.c_float), ("momentum", C.c_float), ("run_head", C.c_int), ("pred", C.c_void_p),
+    ]
+
+
+class MsdDesc(C.Structure):
+    """vts_msd_desc: the multiscale discriminator's training-mode forward as one C call"""
+    _fields_ = [("num_D", C.c_int), ("scale", PatchganDesc * MSD_MAX_SCALES)]
+
+
 class PatchJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_nstride", C.c_int64), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("img", C.c_void_p), ("offx", C.c_void_p), ("offy", C.c_void_p), ("P", C.c_int), ("dst", C.c_void_p),
@@ -110,7 +132,7 @@ SYMBOLS = [
     "vts_mask_select", "vts_mask_sample_ranks", "vts_adam_flat", "vts_adam_flat_dev", "vts_patchnce", "vts_l2norm_rows", "vts_patch_sample", "vts_linear_rows", "vts_copy_words",
     "vts_maxpool2_relu_pad", "vts_maxpool3s2_relu_pad", "vts_s2d4_pad", "vts_maxpool2_relu_bwd", "vts_relu_mask_pad", "vts_lpips_layer", "vts_l1_relu", "vts_lpips_input", "vts_lpips_input_bwd",
     "vts_patch_jobs", "vts_g_post_stack", "vts_step_begin", "vts_conv4x4_bsums", "vts_norm_bwd_from_partials",
-    "vts_u8_expand", "vts_unet_forward", "vts_unet_forward_ws_floats", "vts_allreduce_slice_plan", "vts_comm_unique_id", "vts_comm_init", "vts_allreduce_flat_async", "vts_allreduce_flat_wait", "vts_comm_destroy",
+    "vts_u8_expand", "vts_unet_forward", "vts_unet_forward_ws_floats", "vts_patchgan_forward", "vts_patchgan_forward_ws_floats", "vts_msd_forward", "vts_msd_forward_ws_floats", "vts_allreduce_slice_plan", "vts_comm_unique_id", "vts_comm_init", "vts_allreduce_flat_async", "vts_allreduce_flat_wait", "vts_comm_destroy",
 ]
 
 
@@ -148,6 +170,10 @@ def load():
     lib.vts_w3x3_wino_floats.argtypes = [C.c_int, C.c_int]
     lib.vts_w3x3_wino_floats.restype = C.c_int64
     lib.vts_unet_forward_ws_floats.restype = C.c_int64
+    lib.vts_patchgan_forward_ws_floats.argtypes = [C.POINTER(PatchganDesc)]
+    lib.vts_patchgan_forward_ws_floats.restype = C.c_int64
+    lib.vts_msd_forward_ws_floats.argtypes = [C.POINTER(MsdDesc)]
+    lib.vts_msd_forward_ws_floats.restype = C.c_int64
     lib.vts_conv4x4_norm_ws_floats.argtypes = [C.POINTER(ConvDesc)]
     lib.vts_conv4x4_norm_ws_floats.restype = C.c_int64
     lib.vts_norm_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -236,7 +262,7 @@ def load():
         "vts_conv3x3_wino": [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp],
         "vts_zero_border": [vp, i64, i, i, i, vp],
         "vts_maxpool3s2_relu_pad": [vp, i, i, i, i, vp, vp],
-        "vts_u8_expand": [vp, i64, i, vp, vp], "vts_unet_forward": [C.POINTER(UnetDesc), vp, i64, vp], "vts_comm_unique_id": [vp], "vts_comm_init": [vp, i, i, vp], "vts_allreduce_flat_async": [vp, vp, i64, vp],
+        "vts_u8_expand": [vp, i64, i, vp, vp], "vts_unet_forward": [C.POINTER(UnetDesc), vp, i64, vp], "vts_patchgan_forward": [C.POINTER(PatchganDesc), vp, i64, vp], "vts_msd_forward": [C.POINTER(MsdDesc), vp, i64, vp], "vts_comm_unique_id": [vp], "vts_comm_init": [vp, i, i, vp], "vts_allreduce_flat_async": [vp, vp, i64, vp],
         "vts_allreduce_flat_wait": [vp, vp], "vts_comm_destroy": [vp], "vts_allreduce_slice_plan": [i64, i, i, vp, vp, vp, vp],
         "vts_s2d4_pad": [vp, i, i, i, i, i, i, i, vp, vp],
         "vts_maxpool2_relu_bwd": [vp, vp, i, i, i, vp, i, vp, i, vp],
