@@ -145,6 +145,10 @@ def test_step_matches_reference_golden(golden_dir):
             for k, p in net.named_parameters():
                 if null_grad_bias(nm, k):
                     continue
+                # (gradient PROBES of the reference's fp32 run at 2e-3 (norm) / 8e-3 (projection): that run is itself 7e-4 / 5.2e-3 away from
+                #  its own float64 run on these probes for down0 ... down2 -- tests/golden/sinskitG_step_grads_256.npz, computed in
+                #  DESIGN.md section 8 item 8 -- so they cannot be tightened; the 1e-3 bound on every gradient TENSOR is held against the
+                #  float64 reference in test_generator_gradients_against_the_reference_in_float64 and against float64 oracles below)
                 probe_close(p.grad, g["%s/grad_%s/%s" % (tag, nm, k)], k, 2 * tol)
                 probe_close(p.data, g["%s/param_%s/%s" % (tag, nm, k)], k, tol)
             for k, b in net.named_buffers():
