@@ -1072,7 +1072,8 @@ class SinSKITGModel(BaseModel):
             in0, in1 = self._d1_pair(self.real_S, self.fake_I)
             jobs.append((self.netD, [dict(in0=in0, in1=in1, real=True, coeff=lam, slot=slot["G_GAN"], grad_coeff=lam,
                                           param_grads=False, input_grad=(self._d_fake_I, self._have_dI),
-                                          pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False))]))
+                                          pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False), defer_merge=FUSE_MERGE)]))
+            self._g_gan_pass = jobs[-1][1][0]      # (its last merge level rides in g_out_grad: _g_backward)
             self._have_dI = True
         if "D2" in self.model_names:
             self.optimizer_D2.step(self._gscale, bump=False)
