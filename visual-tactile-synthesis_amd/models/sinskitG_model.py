@@ -34,6 +34,7 @@ from .base_model import BaseModel
 # 1 (default): on one GPU the generator's discriminator-free loss terms run as one more lane beside the discriminator updates; 0: serially
 # behind them (A/B timing; results are identical: the lanes only read the forward's outputs and add into their own fixed-point loss slots)
 G_PRE_LANE = tune.get("VTS_G_PRE_LANE", "1") != "0"
+D2_TAIL_LANE = tune.get("VTS_D2_TAIL_LANE", "1") != "0"    # joined / data-parallel schedule: D2's generator-step forward as a lane under the backward
 FUSE_MERGE = tune.get("VTS_FUSE_MERGE", "1") != "0"       # last level of the D1 input-gradient pyramid merge inside g_out_grad
 D2_CHAIN = tune.get("VTS_D2_CHAIN", "lanes")      # "serial": the whole D2 chain as one lane (measurement: see _run_d_chains)
 D1_REAL_EARLY = tune.get("VTS_D1_REAL_EARLY", "1") != "0"     # D1's pass on the real images beside the generator forward (see _seg_d_updates)
@@ -1075,13 +1076,24 @@ class SinSKITGModel(BaseModel):
                                           pyr=self._d1_pyramid(self.real_S.shape[0], pool_fake=False), defer_merge=FUSE_MERGE)]))
             self._g_gan_pass = jobs[-1][1][0]      # (its last merge level rides in g_out_grad: _g_backward)
             self._have_dI = True
+        d2_lane = None
         if "D2" in self.model_names:
             self.optimizer_D2.step(self._gscale, bump=False)
             # G2 GAN term: fake_T_concat is detached in the reference (:1751) -> value only
-            jobs.append((self.netD2, [dict(in0=self._fake_stack, real=True, coeff=opt.lambda_G2_GAN * nt, slot=slot["G2_GAN"])]))
-        if jobs:
-            engine.msd_multi(jobs, self.criterionGAN)
-        self._g_backward(part)
+            g2 = dict(in0=self._fake_stack, real=True, coeff=opt.lambda_G2_GAN * nt, slot=slot["G2_GAN"])
+            if D2_TAIL_LANE and engine.PARALLEL_SCALES and not getattr(self.netD2, "is_stylegan2_d", False):
+                # a logged value that nothing of the step waits for: one lane that stays open under the generator's backward of this
+                # segment instead of three lanes in front of it (round 6; the chained single-GPU step does the same)
+                tail = dict(D=self.netD2, index0=3 if "D" in self.model_names else 0, update=[], mid=lambda: None, gstep=lambda: [g2])
+                d2_lane = engine.fork_lane(lambda: engine.msd_chain(tail, self.criterionGAN, serial=True))
+            else:
+                jobs.append((self.netD2, [g2]))
+        try:
+            if jobs:
+                engine.msd_multi(jobs, self.criterionGAN)
+            self._g_backward(part)
+        finally:
+            engine.join_lane(d2_lane)
 
     def _seg_g_update(self):
         if getattr(self, "_chains_done", False):      # the discriminator chains already hold Adam(D / D2) and the generator step's D passes
