@@ -827,7 +827,7 @@ class SinSKITGModel(BaseModel):
                                 stat_only=True, keep_stats=True)
             ops.step_begin(self._loss_buf, self._step_counters)      # (in front of the fork: the real pass adds into its loss slot)
             engine.msd_multi([(self.netD, [p_real_early])], self.criterionGAN, extra=lambda: self._forward_and_stacks(begin=False), extra_cost=1.0,
-                             extra_main=True, streams=3)
+                             extra_main=True, streams=int(tune.get("VTS_PHASE_A_STREAMS", "3")))
         else:
             self._forward_and_stacks()
         jobs = []
