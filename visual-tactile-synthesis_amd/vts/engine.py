@@ -421,7 +421,7 @@ def _unet_backward(G, ctx, d_raw, part="all", state=None):
             # (weight gradients inline.  Round 4 re-measured them on a queue of their own per lane -- four streams, both queues forked
             # from the launch stream in front of the lanes: + 0.22 ms on the step, as with one shared queue in round 3.  Round 6: the
             # lanes' SKIP-feature gradients -- first read when the encoder's backward reaches their level -- enqueued on the side queue
-            # behind the lanes instead of inside them: 5.31 - 5.34 against 5.25 - 5.28 ms, tools/probes/r06_defer_skip_ab.sh.  The backward
+            # behind the lanes instead of inside them: 5.31 - 5.34 against 5.25 - 5.28 ms (profiles/r06a_experiments.md section 2b).  The backward
             # is throughput-bound: work moved beside its chain slows the chain by as much.)
             for i in range(nls):
                 up_bwd(i, "up%d%s" % (i, "_T" if lane else ""), lane_dx[lane], lane_df[lane], inline, lane_mode=True)
