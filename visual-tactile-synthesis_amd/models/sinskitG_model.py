@@ -983,8 +983,11 @@ class SinSKITGModel(BaseModel):
                     engine.join_lane(h)
             engine._finish_passes([(D2, upd)])
             chain_d2["mid"]()
-            tail = dict(chain_d2, update=[], mid=lambda: None)
-            self._d2_lane = engine.fork_lane(lambda: engine.msd_chain(tail, self.criterionGAN, serial=True))
+            if tune.get("VTS_D2_TAIL", "lane") == "front":      # measurement: D2's generator-step forward as three lanes IN FRONT of the backward
+                engine.msd_multi([(D2, chain_d2["gstep"]())], self.criterionGAN)
+            else:
+                tail = dict(chain_d2, update=[], mid=lambda: None)
+                self._d2_lane = engine.fork_lane(lambda: engine.msd_chain(tail, self.criterionGAN, serial=True))
         self._chains_done = True
 
     def _d1_pyramid(self, rows, pool_fake):
