@@ -1,7 +1,7 @@
 # end-of-round measurement pass (run through gpurun): headline bench + per-shape table + rocprof kernel stats + PMC traffic / MFMA utilisation
 # + per-layer generator roofline table + secondary workloads.   bash tools/prof_round.sh [tag]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-T=${1:-r05}
+T=${1:-r06}
 WHAT=${2:-all}     # core: the headline step only (bench line, rocprof stats, PMC traffic / MFMA / SQ tables, per-layer table); all: + secondary workloads
 O=gpurun_out/prof_$T; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python bench.py --steps 10 --warmup 3 --train_only > $O/stats.log 2>&1
